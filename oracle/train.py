@@ -1,0 +1,155 @@
+"""Loss, learning-rate schedule, TF-style Adam and one train step (TEST INFRASTRUCTURE).
+
+Restates MSTTS_SV.py:127-192 (loss + optimizer) on top of oracle.model.forward; gradients come
+from torch autograd.  Also defines the mask-stream table shared by specification with the HIP
+host code (multi_speaker_tts_amd/masks.py keeps an independent copy of the same table).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import model as M
+from . import rng
+
+# stream ids of the Philox keep-masks (DESIGN.md "Randomness")
+STREAMS = {
+    "enc_conv_drop_%d": 1, "enc_zc_fw": 10, "enc_zh_fw": 11, "enc_zc_bw": 12, "enc_zh_bw": 13,
+    "prenet_drop_%d": 20, "dec_zc_%d": 30, "dec_zh_%d": 31, "post_drop_%d": 40,
+    "v_zc_fw": 50, "v_zh_fw": 51, "v_zc_bw": 52, "v_zh_bw": 53, "s_zc_%d": 60, "s_zh_%d": 61,
+}
+
+
+def step_seed(base_seed, step):
+    return (int(base_seed) + 1000003 * int(step)) & 0xFFFFFFFFFFFFFFFF
+
+
+def mask_table(d: M.Dims, B, T_enc, S, training, speaker_windows=0, vocoder=False):
+    """[(name, stream, shape, keep_prob)] for one forward."""
+    t = []
+    for i in range(d.prenet_n):
+        t.append(("prenet_drop_%d" % i, STREAMS["prenet_drop_%d"] + i, (S, B, d.prenet), 1 - d.prenet_drop))
+    if not training:
+        return t
+    cin = d.enc_conv_ch
+    for i in range(d.enc_conv_n):
+        t.append(("enc_conv_drop_%d" % i, STREAMS["enc_conv_drop_%d"] + i, (B, T_enc, cin), 1 - d.conv_drop))
+    for dr in ("fw", "bw"):
+        t.append(("enc_zc_" + dr, STREAMS["enc_zc_" + dr], (T_enc, B, d.enc_lstm), 1 - d.zoneout))
+        t.append(("enc_zh_" + dr, STREAMS["enc_zh_" + dr], (T_enc, B, d.enc_lstm), 1 - d.zoneout))
+    for l in range(d.dec_lstm_n):
+        t.append(("dec_zc_%d" % l, STREAMS["dec_zc_%d"] + 2 * l, (S, B, d.dec_lstm), 1 - d.zoneout))
+        t.append(("dec_zh_%d" % l, STREAMS["dec_zh_%d"] + 2 * l, (S, B, d.dec_lstm), 1 - d.zoneout))
+    for i in range(d.post_n):
+        cout = d.post_ch if i < d.post_n - 1 else d.n_mel
+        t.append(("post_drop_%d" % i, STREAMS["post_drop_%d"] + i, (B, S, cout), 1 - d.conv_drop))
+    if vocoder:
+        for dr in ("fw", "bw"):
+            t.append(("v_zc_" + dr, STREAMS["v_zc_" + dr], (S, B, d.birnn), 1 - d.zoneout))
+            t.append(("v_zh_" + dr, STREAMS["v_zh_" + dr], (S, B, d.birnn), 1 - d.zoneout))
+    if speaker_windows:
+        for i in range(d.spk_lstm_n):
+            t.append(("s_zc_%d" % i, STREAMS["s_zc_%d"] + 2 * i, (d.spk_frames, speaker_windows, d.spk_lstm), 1 - d.zoneout))
+            t.append(("s_zh_%d" % i, STREAMS["s_zh_%d"] + 2 * i, (d.spk_frames, speaker_windows, d.spk_lstm), 1 - d.zoneout))
+    return t
+
+
+def make_masks(d, B, T_enc, S, training, seed, rank=0, **kw):
+    return {name: torch.from_numpy(rng.keep_mask(shape, seed, stream + 1000 * rank, keep))
+            for name, stream, shape, keep in mask_table(d, B, T_enc, S, training, **kw)}
+
+
+def learning_rate(step, initial=1e-3, minimum=1e-5, decay_start=0, decay_step=10000, decay_rate=0.5):
+    """MSTTS_SV.py:163-169: exponential_decay (non-staircase) then clip to [min, initial]."""
+    lr = initial * decay_rate ** ((step - decay_start) / decay_step)
+    return min(max(lr, minimum), initial)
+
+
+def losses(p, out, batch, wr_rate=1e-6, use_l1=True):
+    """MSTTS_SV.py:127-161 (quirks Q7, Q8, Q19)."""
+    mel = batch["Mel"]
+    L = batch["Mel_Length"].long()
+    S = int(L.max()) + 1
+    stop_target = (torch.arange(S)[None, :] >= L[:, None]).to(mel.dtype)
+    lin, post = out["Linear"][:, :-1], out["Mel"][:, :-1]
+    linear_loss = ((lin - mel) ** 2).mean()
+    postnet_loss = ((post - mel) ** 2).mean()
+    if use_l1:
+        linear_loss = linear_loss + (lin - mel).abs().mean()
+        postnet_loss = postnet_loss + (post - mel).abs().mean()
+    z = out["Stop_Logit"]
+    stop_loss = (torch.clamp(z, min=0) - z * stop_target + torch.log1p(torch.exp(-z.abs()))).mean()
+    wr = wr_rate * sum((p[k] ** 2).sum() / 2 for k in p if M.in_weight_reg(k))
+    return {"Loss": linear_loss + postnet_loss + stop_loss + wr, "Linear_Loss": linear_loss,
+            "Postnet_Loss": postnet_loss, "Stop_Loss": stop_loss, "Weight_Regularization_Loss": wr}
+
+
+def adam_tf(param, grad, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-6):
+    """tf.train.AdamOptimizer (quirk Q18): epsilon outside the bias correction.  t counts from 1."""
+    m = b1 * m + (1 - b1) * grad
+    v = b2 * v + (1 - b2) * grad * grad
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    return param - lr_t * m / (v.sqrt() + eps), m, v
+
+
+def train_step(params, opt_state, d, batch, masks, global_step, dtype=torch.float64, update_vocoder_bn=True,
+               return_grads=False):
+    """One Tacotron2.Train iteration (MSTTS_SV.py:268-273).  params: name->np/torch; opt_state:
+    {'m':{},'v':{}} or None.  Returns (new_params, new_opt_state, scalars[, grads, outputs])."""
+    p = {k: (v.detach().clone().to(dtype) if torch.is_tensor(v) else torch.tensor(np.asarray(v), dtype=dtype))
+         for k, v in params.items()}
+    names = [k for k in p if M.is_trainable(k)]
+    for k in names:
+        p[k].requires_grad_(True)
+    bt = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in batch.items()}
+    stats = {}
+    out = M.forward(p, d, bt, True, masks, stats_out=stats, with_vocoder=False)
+    if update_vocoder_bn:      # quirk Q20: the vocoder conv-bank's BN update ops ride along
+        with torch.no_grad():
+            M.taco1_convbank(p, d, out["Mel"].detach(), True, stats)
+    ls = losses(p, out, bt)
+    grads = torch.autograd.grad(ls["Loss"], [p[k] for k in names], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(p[k])) for k, g in zip(names, grads)}
+    lr = learning_rate(global_step)
+    if opt_state is None:
+        opt_state = {"m": {k: torch.zeros_like(p[k]) for k in names}, "v": {k: torch.zeros_like(p[k]) for k in names}}
+    new_p, new_m, new_v = {}, {}, {}
+    with torch.no_grad():
+        for k in p:
+            if k in grads:
+                new_p[k], new_m[k], new_v[k] = adam_tf(p[k].detach(), grads[k], opt_state["m"][k].to(dtype),
+                                                      opt_state["v"][k].to(dtype), global_step + 1, lr)
+            elif k in stats:
+                new_p[k] = stats[k]
+            else:
+                new_p[k] = p[k].detach()
+    scalars = {k: float(v.detach()) for k, v in ls.items()}
+    scalars["Learning_Rate"] = lr
+    scalars["Global_Step"] = global_step
+    ret = (new_p, {"m": new_m, "v": new_v}, scalars)
+    if return_grads:
+        ret = ret + (grads, {k: v.detach() for k, v in out.items()})
+    return ret
+
+
+def synthetic_batch(d: M.Dims, B, T_enc, L, seed=1234, rank=0, ragged=False):
+    """SURVEY 8(d) synthetic inputs (fixed length unless ragged)."""
+    g = np.random.default_rng(seed + rank)
+    tok = g.integers(2, d.n_tok, size=(B, T_enc)).astype(np.int32)
+    tl = np.full(B, T_enc, np.int32)
+    ml = np.full(B, L, np.int32)
+    if ragged:
+        tl = g.integers(max(2, T_enc // 2), T_enc + 1, size=B).astype(np.int32); tl[0] = T_enc
+        ml = g.integers(max(1, L // 2), L + 1, size=B).astype(np.int32); ml[0] = L
+    for b in range(B):
+        tok[b, 0] = 0
+        tok[b, tl[b] - 1] = 1
+        tok[b, tl[b]:] = 1
+    mel = np.clip(g.normal(0, 1.5, size=(B, L, d.n_mel)), -4, 4).astype(np.float32)
+    for b in range(B):
+        mel[b, ml[b]:] = 0
+    spk = g.normal(0, 1, size=(B, d.spk))
+    spk = (spk / np.sqrt((spk ** 2).sum())).astype(np.float32)
+    return {"Token": torch.from_numpy(tok), "Token_Length": torch.from_numpy(tl),
+            "Mel": torch.from_numpy(mel), "Mel_Length": torch.from_numpy(ml),
+            "Speaker_Embedding": torch.from_numpy(spk)}

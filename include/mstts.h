@@ -1,0 +1,317 @@
+/* libmstts_hip.so - C ABI of the MI355X (gfx950) Tacotron2 hot path.
+ *
+ * The reference (CODEJIN/multi_speaker_tts) has no FFI: its device seam is
+ * tf.Session.run (MSTTS_SV.py:270-273,305-308) over graph functions in Modules.py,
+ * ZoneoutLSTMCell.py, Location_Sensitive_Attention.py, Taco1_Mel_to_Spect/Modules.py,
+ * Speaker_Embedding/Modules.py and Audio.py.  Each entry point below replaces one of those
+ * graph functions (cited per function) or the TF library op it is built from.
+ *
+ * Conventions:
+ *   - plain pointers + sizes; every pointer is DEVICE memory unless marked host;
+ *   - activations [B,T,C] row-major (NWC), conv kernels [K,Cin,Cout], dense [in,out],
+ *     LSTM kernels [in+H,4H] gate order i,j,f,o - the reference's layouts;
+ *   - the caller owns every buffer (workspaces included); the library allocates nothing and
+ *     keeps no mutable global state, so calls are re-entrant across streams/threads;
+ *   - asynchronous on the given hipStream_t (passed as void*), no implicit synchronisation;
+ *   - returns 0 or a negative MSTTS_ERR_* code; mstts_last_error() gives thread-local text.
+ */
+#ifndef MSTTS_H_
+#define MSTTS_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mstts_stream_t; /* hipStream_t */
+
+enum { MSTTS_OK = 0, MSTTS_ERR_SHAPE = -1, MSTTS_ERR_DTYPE = -2, MSTTS_ERR_ALIGN = -3, MSTTS_ERR_LAUNCH = -4 };
+enum { MSTTS_ACT_NONE = 0, MSTTS_ACT_RELU = 1, MSTTS_ACT_TANH = 2, MSTTS_ACT_SIGMOID = 3 };
+
+const char* mstts_last_error(void);
+int mstts_abi_version(void);
+
+/* ---- dense contraction (tf.matmul / tf.layers.dense / tf.layers.conv1d and their gradients) ---
+ * C[M,N] = act(alpha * op(A) . op(B) + bias)   (accumulate: C += ...; split_k > 1: atomic add)
+ * trans_a = 0: A(m,k) = A[m*lda + k]; 1: A(m,k) = A[k*lda + m]
+ * trans_b = 0: B(k,n) = B[k*ldb + n]; 1: B(k,n) = B[n*ldb + k]
+ * win_T > 0 turns A into the implicit im2col view of X[rows, win_C] (conv1d 'same', NWC):
+ *   trans_a = 0: A(m,k) = X[m - win_pad + k / win_C][k % win_C], zero outside the row's
+ *                length-win_T sequence (m % win_T + k / win_C - win_pad must be in [0, win_T));
+ *   trans_a = 1: the same view transposed (weight gradient).   lda must equal win_C. */
+typedef struct {
+    const float* A; const float* B; float* C; const float* bias;
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int32_t trans_a, trans_b;
+    int32_t win_T, win_C, win_pad;
+    int32_t act, accumulate, split_k;
+    int64_t batch, stride_a, stride_b, stride_c;
+    float alpha;
+} mstts_gemm_desc;
+int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
+
+/* ---- randomness: Philox4x32-10 keep-masks (replaces tf.random_uniform inside
+ * tf.layers.dropout, Modules.py:41-45,137-141,248-253, and ZoneoutLSTMCell.py:266-271) ---- */
+int mstts_philox_keep_mask(uint8_t* out, int64_t n, uint64_t seed, uint32_t stream_id, float keep_prob, mstts_stream_t s);
+
+/* ---- Encoder_Embedding (Modules.py:15-23): out[i,:] = table[token[i],:] ; bit-exact gather.
+ * bwd: dtable[token[i],:] += dout[i,:] (atomic scatter-add). */
+int mstts_embedding_fwd(const int32_t* token, const float* table, float* out, int64_t n, int64_t vocab, int64_t width, mstts_stream_t s);
+int mstts_embedding_bwd(const int32_t* token, const float* dout, float* dtable, int64_t n, int64_t vocab, int64_t width, mstts_stream_t s);
+
+/* ---- tf.layers.batch_normalization (+ the tf.layers.dropout that follows it) on [rows, C]
+ * (Modules.py:37-45,133-141; Taco1_Mel_to_Spect/Modules.py:22-50).
+ * train fwd: batch moments (biased variance), y = ((x-mean)*rstd*gamma+beta) * mask/keep,
+ *            moving = moving*momentum + batch*(1-momentum).  keep_mask may be NULL.
+ * ws: 2*C floats of scratch.  bwd also applies the derivative of the activation that produced
+ * x (act: relu/tanh/none, evaluated from x itself) and emits the column sums the conv bias needs:
+ *   dz = dBN(dy*mask/keep) * act'(x);  dgamma += ..., dbeta += ..., dbias += colsum(dz). */
+int mstts_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                       float* y, float* save_mean, float* save_rstd, const uint8_t* keep_mask, float keep_prob,
+                       float momentum, float eps, int64_t rows, int64_t C, float* ws, mstts_stream_t s);
+int mstts_bn_infer_fwd(const float* x, const float* gamma, const float* beta, const float* moving_mean,
+                       const float* moving_var, float* y, float eps, int64_t rows, int64_t C, mstts_stream_t s);
+int mstts_bn_train_bwd(const float* dy, const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                       const uint8_t* keep_mask, float keep_prob, int32_t act, float* dz, float* dgamma, float* dbeta,
+                       float* dbias, int64_t rows, int64_t C, float* ws, mstts_stream_t s);
+
+/* ---- small fused elementwise pieces ---------------------------------------------------------
+ * dropout fwd/bwd on flat arrays: y = x * mask / keep  (prenet, Modules.py:248-253)
+ * relu_dropout_bwd: dx = dy * mask/keep * (y_saved > 0)  where y_saved is the dropped relu output */
+int mstts_dropout(const float* x, const uint8_t* keep_mask, float keep_prob, float* y, int64_t n, mstts_stream_t s);
+int mstts_relu_dropout_bwd(const float* dy, const float* y_saved, const uint8_t* keep_mask, float keep_prob, float* dx, int64_t n, mstts_stream_t s);
+/* out[c] (+)= sum over rows of x[r*ld + c] */
+int mstts_colsum(const float* x, int64_t rows, int64_t C, int64_t ld, float* out, int32_t accumulate, mstts_stream_t s);
+/* y = a + b ; y = a*alpha ; fill */
+int mstts_add(const float* a, const float* b, float* y, int64_t n, mstts_stream_t s);
+int mstts_fill(float* y, float v, int64_t n, mstts_stream_t s);
+/* strided 2-D copy / accumulate: dst[r*ldd + c] (+)= src[r*lds + c] */
+int mstts_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, int32_t accumulate, mstts_stream_t s);
+/* tf max_pooling1d(2,1,'same') on [B,T,C]: y[t] = max(x[t], x[t+1]) (Taco1 Modules.py:28-33) */
+int mstts_maxpool2_same(const float* x, float* y, int64_t B, int64_t T, int64_t C, mstts_stream_t s);
+/* highway combine (Taco1 Modules.py:54-72): y = H*T + x*(1-T) with H=relu(h_pre), T=sigmoid(t_pre) */
+int mstts_highway_combine(const float* h_pre, const float* t_pre, const float* x, float* y, int64_t n, mstts_stream_t s);
+
+/* ---- ZoneoutLSTMCell (ZoneoutLSTMCell.py:188-271), one time step for all rows -----------------
+ * gates_pre = gates_h[B,4H] (+ xw row) (+ bias);  i,j,f,o = split;  c = sig(f+1)*c_prev + sig(i)*tanh(j);
+ * m = sig(o)*tanh(c);  c' = (1-z)*zc*(c-c_prev)+c_prev;  h' = (1-z)*zh*(m-h_prev)+h_prev  (zc/zh NULL
+ * at inference).  dynamic_rnn masking: rows with step >= lengths[b] keep their state and emit 0.
+ * reverse: the row's sequence position is lengths[b]-1-step (bidirectional backward direction).
+ * Row b reads xw at xw + b*xw_sb + pos*xw_st, writes its output m (+ residual) at
+ * out + b*out_sb + pos*out_st.  acts_out[B,4H] (sig i, tanh j, sig f, sig o) and c_raw[B,H] are the
+ * BPTT saves (NULL to skip). */
+typedef struct {
+    int64_t B, H;
+    const float* gates_h;            /* [B,4H] recurrent (and per-step input) product, no bias */
+    const float* xw; int64_t xw_sb, xw_st;   /* hoisted input product incl. bias, or NULL */
+    const float* bias;               /* [4H] or NULL (when already folded into xw) */
+    const float* c_prev; const float* h_prev; int64_t h_prev_ld;   /* h_prev row stride (0 -> H) */
+    const uint8_t* zc; const uint8_t* zh;     /* [B,H] keep masks or NULL */
+    float zoneout;
+    const int32_t* lengths;          /* [B] or NULL */
+    int32_t step, reverse;
+    const float* residual; int64_t res_sb, res_st;  /* ResidualWrapper input or NULL */
+    float* out; int64_t out_sb, out_st;
+    float* c_next; float* h_next; int64_t h_next_ld;   /* [B,H]; h_next row stride (0 -> H) */
+    float* acts_out; float* c_raw;   /* saves or NULL */
+} mstts_lstm_point_fwd_desc;
+int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_stream_t s);
+
+typedef struct {
+    int64_t B, H;
+    const float* d_out; int64_t dout_sb, dout_st;   /* grad wrt the cell output m (row b at pos) or NULL */
+    const float* d_out2;             /* second [B,H] addend to the output grad or NULL */
+    const float* d_c_state; const float* d_h_state; /* [B,H] grads wrt c', h' from step+1 */
+    const float* d_h_state2; int64_t dhs2_ld;       /* optional second addend of d_h_state (row stride) or NULL */
+    const float* acts; const float* c_raw; const float* c_prev;
+    const uint8_t* zc; const uint8_t* zh;
+    float zoneout;
+    const int32_t* lengths; int32_t step, reverse;
+    float* dgates;                   /* [B,4H] step-major */
+    float* dgates_pos; int64_t dgp_sb, dgp_st;     /* optional second copy at (b,pos) or NULL */
+    float* d_c_prev; float* d_h_prev;               /* [B,H]; d_h_prev gets only the direct (zoneout bypass) part */
+} mstts_lstm_point_bwd_desc;
+int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_stream_t s);
+
+/* ---- Location_Sensitive_Attention step (Location_Sensitive_Attention.py:43-85 + TF
+ * BahdanauAttention masking/softmax + AttentionWrapper context).  Two launches:
+ *   energy : e[b,t] = sum_k w_k tanh(keys[b,t,k] + q[b,k] + (conv31(cum)[b,t,:] . Wd)[k] + b_k)
+ *   context: a = softmax(mask(e)); cum_next = cum + a; ctx[b,:] = sum_t a[b,t] values[b,t,:]
+ * T <= 512, A == 128, att conv channels == 32. */
+typedef struct {
+    int64_t B, T, A, M, KS, CH;      /* batch, encoder steps, attention units, memory width, conv taps, conv channels */
+    const float* keys; const float* values; const int32_t* lengths;
+    const float* conv_k; const float* conv_b; const float* dense_k; const float* score_w; const float* score_b;
+} mstts_lsa_const;
+int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, const float* cum, float* energy, mstts_stream_t s);
+/* ctx row b is written at ctx + b*ctx_ld (and, when ctx2 != NULL, also at ctx2 + b*ctx2_ld) so the
+ * decoder can place it straight into the next step's GEMM input rows. */
+int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* energy, const float* cum, float* align, float* cum_next,
+                          float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, mstts_stream_t s);
+/* backward of one step, two launches:
+ *  dalign : G = G_next + convT(d_f_next) ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
+ *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); d_f = g . Wd^T; saves d_e */
+/* d_ctx row b = d_ctx[b*d_ctx_ld ..] (+ d_ctx2[b*d_ctx2_ld ..] when d_ctx2 != NULL) */
+int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
+                         const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s);
+int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* align, const float* d_align, const float* q, const float* cum,
+                          float* d_e, float* dq, float* d_f, mstts_stream_t s);
+/* post-loop parameter gradients over all S steps (recomputes tanh tiles from the saved d_e):
+ * hist pointers are [S,B,*]; outputs accumulate (atomic): d_keys[B,T,A], d_conv_k[KS,CH], d_conv_b[CH],
+ * d_dense_k[CH,A], d_score_w[A], d_score_b[A]. */
+int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
+                        float* d_keys, float* d_conv_k, float* d_conv_b, float* d_dense_k, float* d_score_w, float* d_score_b,
+                        mstts_stream_t s);
+
+/* ---- losses (MSTTS_SV.py:127-144) forward + gradient in one pass -------------------------------
+ * linear/post [B,S,n_mel] with S = L+1, mel [B,L,n_mel], stop_logit [B,S], mel_length [B].
+ * scalars[0..2] = linear_loss, postnet_loss, stop_loss (accumulated atomically: zero them first).
+ * d_linear/d_post [B,S,n_mel] (last step gets 0), d_stop [B,S]; grad_scale multiplies every gradient. */
+int mstts_tts_loss_fwd_bwd(const float* linear, const float* post, const float* mel, const float* stop_logit,
+                           const int32_t* mel_length, int64_t B, int64_t S, int64_t n_mel, int32_t use_l1,
+                           float grad_scale, float* scalars, float* d_linear, float* d_post, float* d_stop, mstts_stream_t s);
+/* 0.5 * sum(mask ? x^2 : 0) added atomically into *out (tf.nn.l2_loss over the regularised
+ * variables, MSTTS_SV.py:145-159); mask NULL = all elements */
+int mstts_l2_loss_acc(const float* x, const uint8_t* mask, int64_t n, float* out, mstts_stream_t s);
+
+/* ---- layout glue of the decoder (Decoder_Helper teacher forcing, Modules.py:178-185,224-228) ----
+ * shift_frames: frames[s,b,:] = (s == 0) ? 0 : mel[b,s-1,:]   (mel [B,L,C] -> frames [L+1,B,C])
+ * unpack_proj : proj[S,B,ldp] (cols 0..C-1 = linear, col C = stop) -> linear[B,S,C], stop[B,S]
+ * pack_dproj  : the inverse for gradients (pad columns zeroed)
+ * speaker_tile: values[b,t,off+j] = (t < lengths[b]) ? spk[b,j] : 0      (MSTTS_SV.py:70-71 + memory mask)
+ * conv_kernel_flip: wt[K-1-k][o][c] = w[k][c][o]  (data-gradient form of a conv1d kernel) */
+int mstts_shift_frames(const float* mel, float* frames, int64_t B, int64_t L, int64_t C, mstts_stream_t s);
+int mstts_unpack_proj(const float* proj, int64_t ldp, float* linear, float* stop, int64_t B, int64_t S, int64_t C, mstts_stream_t s);
+int mstts_pack_dproj(const float* d_linear, const float* d_stop, float* d_proj, int64_t ldp, int64_t B, int64_t S, int64_t C, mstts_stream_t s);
+int mstts_speaker_tile(const float* spk, const int32_t* lengths, float* values, int64_t B, int64_t T, int64_t M, int64_t off, int64_t width, mstts_stream_t s);
+int mstts_conv_kernel_flip(const float* w, float* wt, int64_t K, int64_t Cin, int64_t Cout, mstts_stream_t s);
+
+/* ---- tf.train.AdamOptimizer step on a flat slab (MSTTS_SV.py:171-176; epsilon outside the bias
+ * correction).  g_total = grad*grad_scale + wd[i]*p ; wd_mask (uint8, may be NULL) selects the
+ * weight-regularised elements with coefficient wd. */
+int mstts_adam_tf(float* p, const float* grad, float* m, float* v, const uint8_t* wd_mask, float wd, float grad_scale,
+                  float lr_t, float beta1, float beta2, float eps, int64_t n, mstts_stream_t s);
+
+/* ---- Audio.melspectrogram (Audio.py:12-13,29-32,42-48,62-96): wav[n] -> normalised mel
+ * [frames, n_mel] with frames = 1 + n/hop (already [T,80] as Feeder.py:214-222 transposes it).
+ * Steps: preemphasis (lfilter [1,-coef]) + centre reflect pad by n_fft/2; windowed DFT as one MFMA
+ * GEMM frames[frames,win] . dft_basis[win, 2*NB] (only the `win` non-zero taps of the zero-padded
+ * Hann window enter; NB = n_fft/2+1 rounded up to a multiple of 4; columns [0,NB) = w*cos,
+ * [NB,2NB) = -w*sin; pad columns zero); magnitude; mel GEMM with mel_basis_t[NB, n_mel];
+ * 20*log10(max(1e-5,.)) and symmetric normalisation to [-max_abs, max_abs].
+ * ws floats: (n + n_fft) + frames*2*NB + frames*NB. */
+int mstts_stft_mel(const float* wav, int64_t n, float preemph, const float* dft_basis, const float* mel_basis_t,
+                   int32_t n_fft, int32_t hop, int32_t win, int32_t n_mel, float max_abs, float* ws, float* mel_out,
+                   int64_t frames, mstts_stream_t s);
+int64_t mstts_stft_mel_ws_floats(int64_t n, int32_t n_fft, int64_t frames);
+
+/* ---- LSTM weight utilities --------------------------------------------------------------------
+ * fold_rows: dst[r,:] = src[r,:] for r<r0 ; dst[r0+i,:] = src[r0+i,:] + src[r0+n+i,:] (i<n) ; rest shifted up.
+ * Used for the decoder cell-0 kernel whose context rows appear twice. */
+int mstts_fold_rows(const float* src, float* dst, int64_t rows, int64_t cols, int64_t r0, int64_t n, mstts_stream_t s);
+
+/* ---- tf.nn.dynamic_rnn over one ZoneoutLSTMCell (Encoder_BiLSTM Modules.py:49-73, Taco1 BiRNN
+ * Taco1_Mel_to_Spect/Modules.py:75-99, speaker Stack_LSTM Speaker_Embedding/Modules.py:12-35).
+ * The input product xw = x.Wx + bias is hoisted by the caller into one big GEMM; this driver
+ * enqueues the T dependent steps (recurrent GEMM + fused cell) natively.
+ * hist buffers are step-major: c_hist/h_hist [T+1,B,H] (slot 0 is zeroed here), acts [T,B,4H],
+ * c_raw [T,B,H] (acts/c_raw may be NULL at inference).  zc/zh [T,B,H] in processing order. */
+typedef struct {
+    int64_t B, T, H;
+    const float* xw;                 /* [B,T,4H], batch-major, bias included */
+    const float* wh; int64_t wh_ld;  /* recurrent rows of the cell kernel: [H,4H] view, row stride wh_ld */
+    const int32_t* lengths;          /* [B] or NULL */
+    int32_t reverse;
+    float zoneout;
+    const uint8_t* zc; const uint8_t* zh;
+    const float* residual;           /* [B,T,H] or NULL */
+    float* out; int64_t out_sb, out_st;
+    float* c_hist; float* h_hist; float* acts; float* c_raw;
+    float* gates_ws;                 /* [B,4H] */
+} mstts_lstm_seq_fwd_desc;
+int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s);
+
+/* BPTT over the same sequence.  d_out is the gradient of `out` (same strides).  Produces
+ * dgates_step [T,B,4H] (pairs with h_hist[0:T] for dWh) and dgates_pos [B,T,4H] (pairs with x for
+ * dWx / dX); the weight/bias/input gradients are then plain GEMMs/colsums done by the caller.
+ * ws: 4*B*H floats. */
+typedef struct {
+    int64_t B, T, H;
+    const float* wh; int64_t wh_ld;
+    const int32_t* lengths; int32_t reverse;
+    float zoneout;
+    const uint8_t* zc; const uint8_t* zh;
+    const float* d_out; int64_t dout_sb, dout_st;
+    const float* c_hist; const float* acts; const float* c_raw;
+    float* dgates_step; float* dgates_pos;
+    float* ws;
+} mstts_lstm_seq_bwd_desc;
+int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream_t s);
+
+/* ---- Decoder_LSTM / Decoder_Dynamic_Decode in teacher-forcing mode (Modules.py:76-119,323-472
+ * with the TF AttentionWrapper step).  Everything that does not depend on the
+ * recurrence is hoisted by the caller: xw0 = prenet(frames).Wx0 + b0 for all S steps, and the
+ * output projection / losses afterwards.  This driver enqueues the S dependent steps:
+ *   LSTM0([ctx_{s-1}|h0_{s-1}]) -> LSTM1([m0|h1_{s-1}]) -> query -> energy -> softmax/context.
+ * Row-block layouts (step-major, so each step's GEMM input is one contiguous [B,*] matrix):
+ *   in0 [S+1,B,M+H] = [ctx | h0 state]   (slot 0 zeroed here; slot s+1 written by step s)
+ *   in1 [S+1,B,2H]  = [m0  | h1 state]   (m0 of step s in slot s, h1 state of step s in slot s+1)
+ *   pj  [S,B,H+M]   = [m1  | ctx]        (the projection's input rows)
+ *   c0/c1 [S+1,B,H], acts0/acts1 [S,B,4H], craw0/craw1 [S,B,H], q_hist [S,B,A],
+ *   align_hist [S,B,T], cum_hist [S+1,B,T] (slot 0 zeroed here). */
+typedef struct {
+    int64_t B, S, H, P;
+    mstts_lsa_const lsa;             /* B,T,A,M,KS,CH + keys/values/lengths + attention weights */
+    const float* xw0;                /* [S,B,4H] */
+    const float* w0f;                /* [M+H,4H]: folded context rows, then recurrent rows */
+    const float* w1; const float* b1;   /* [2H,4H], [4H] */
+    const float* wq;                 /* [H,A] */
+    const uint8_t* zc0; const uint8_t* zh0; const uint8_t* zc1; const uint8_t* zh1;   /* [S,B,H] or NULL */
+    float zoneout;
+    float* in0; float* in1; float* pj;
+    float* c0; float* c1; float* acts0; float* acts1; float* craw0; float* craw1;
+    float* q_hist; float* align_hist; float* cum_hist;
+    float* gates_ws; float* energy_ws;      /* [B,4H], [B,T] */
+} mstts_decoder_train_desc;
+int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s);
+
+/* BPTT through the same S steps.  d_pj [S,B,H+M] holds the projection's input gradient on entry
+ * (d_m1 | d_ctx) and is updated in place.  Outputs for the hoisted gradient GEMMs:
+ *   dg0/dg1 [S,B,4H], dq_hist [S,B,A] (must be zeroed by the caller), de_hist [S,B,T],
+ *   d_in0 [S,B,M+H] = dg0.w0f^T per step (rows of step s are the gradient of in0 slot s).
+ * ws: 6*B*H + 2*B*T + 2*B*T*CH + B*2H + B*T floats. */
+typedef struct {
+    const mstts_decoder_train_desc* fwd;
+    float* d_pj; float* dg0; float* dg1; float* dq_hist; float* de_hist; float* d_in0;
+    float* ws;
+} mstts_decoder_train_bwd_desc;
+int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* d, mstts_stream_t s);
+int64_t mstts_decoder_train_bwd_ws_floats(int64_t B, int64_t H, int64_t T, int64_t CH);
+
+/* ---- free-running decoder steps (inference branch of Decoder_Helper.next_inputs,
+ * Modules.py:212-237): enqueues steps [step0, step0+n).  frame feedback: step s reads its input
+ * frame from linear rows of step s-1 (zeros for s == 0).  Buffers as in the train descriptor but
+ * only two state slots are kept (ping-pong by step parity); outputs: linear [Smax,B,n_mel]
+ * and stop [Smax,B] step-major, align_hist [Smax,B,T].  prenet keep-masks pm0/pm1 [Smax,B,P]. */
+typedef struct {
+    int64_t B, H, P, n_mel, Smax;
+    mstts_lsa_const lsa;
+    const float* pw0; const float* pb0; const float* pw1; const float* pb1;   /* prenet dense kernels */
+    const uint8_t* pm0; const uint8_t* pm1; float prenet_keep;
+    const float* wx0; const float* b0;      /* [P,4H] input rows of cell 0, [4H] */
+    const float* w0f; const float* w1; const float* b1; const float* wq;
+    const float* wproj; const float* bproj; /* [H+M, n_mel+1], [n_mel+1] */
+    float zoneout;
+    float* in0; float* in1; float* pj;      /* [2,B,M+H], [2,B,2H], [B,H+M] */
+    float* c0; float* c1;                   /* [2,B,H] */
+    float* cum;                             /* [2,B,T] */
+    float* pre_ws;                          /* 2*B*P + B*4H + B*4H + B*T + B*A + B*(n_mel+1) floats */
+    float* linear; float* stop; float* align_hist;
+} mstts_decoder_infer_desc;
+int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);
+int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSTTS_H_ */

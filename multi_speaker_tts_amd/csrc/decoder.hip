@@ -1,0 +1,266 @@
+// Native time-loop drivers: they enqueue the dependent per-step kernels of the recurrent parts of
+// the graph on one HIP stream (no host round trips, capturable into a hipGraph by the caller).
+//   mstts_lstm_seq_fwd/bwd        - tf.nn.dynamic_rnn over a ZoneoutLSTMCell (encoder BiLSTM, Taco1
+//                                   BiRNN, speaker encoder)          [Modules.py:49-73]
+//   mstts_decoder_train_fwd/bwd   - the teacher-forced attention decoder loop and its BPTT
+//                                   [Modules.py:76-119,323-472 + TF AttentionWrapper]
+//   mstts_decoder_infer_steps     - the free-running loop            [Modules.py:212-237]
+#include "common.h"
+
+using namespace mstts;
+
+#define RC(call) do { int rc__ = (call); if (rc__ != MSTTS_OK) return rc__; } while (0)
+
+static int gemm(const float* A, long lda, const float* B, long ldb, int trans_b, float* C, long ldc, long M, long N, long K,
+                const float* bias, int act, int accumulate, mstts_stream_t s) {
+    mstts_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.trans_a = 0; g.trans_b = trans_b; g.act = act; g.accumulate = accumulate; g.split_k = 1; g.batch = 1; g.alpha = 1.f;
+    return mstts_gemm_f32(&g, s);
+}
+
+static int zero(float* p, long n, mstts_stream_t s) {
+    hipError_t e = hipMemsetAsync(p, 0, n * sizeof(float), (hipStream_t)s);
+    if (e != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "memset: %s", hipGetErrorString(e));
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->xw && d->wh && d->c_hist && d->h_hist && d->gates_ws, MSTTS_ERR_SHAPE, "lstm_seq_fwd: null pointer");
+    const long B = d->B, T = d->T, H = d->H, BH = B * H;
+    RC(zero(d->c_hist, BH, s));
+    RC(zero(d->h_hist, BH, s));
+    for (long t = 0; t < T; ++t) {
+        RC(gemm(d->h_hist + t * BH, H, d->wh, d->wh_ld, 0, d->gates_ws, 4 * H, B, 4 * H, H, nullptr, 0, 0, s));
+        mstts_lstm_point_fwd_desc p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = d->gates_ws;
+        p.xw = d->xw; p.xw_sb = T * 4 * H; p.xw_st = 4 * H;
+        p.c_prev = d->c_hist + t * BH; p.h_prev = d->h_hist + t * BH;
+        p.zc = d->zc ? d->zc + t * BH : nullptr; p.zh = d->zh ? d->zh + t * BH : nullptr;
+        p.zoneout = d->zoneout; p.lengths = d->lengths; p.step = (int)t; p.reverse = d->reverse;
+        p.residual = d->residual; p.res_sb = T * H; p.res_st = H;
+        p.out = d->out; p.out_sb = d->out_sb; p.out_st = d->out_st;
+        p.c_next = d->c_hist + (t + 1) * BH; p.h_next = d->h_hist + (t + 1) * BH;
+        p.acts_out = d->acts ? d->acts + t * 4 * BH : nullptr;
+        p.c_raw = d->c_raw ? d->c_raw + t * BH : nullptr;
+        RC(mstts_lstm_point_fwd(&p, s));
+    }
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->wh && d->d_out && d->c_hist && d->acts && d->c_raw && d->dgates_step && d->ws, MSTTS_ERR_SHAPE,
+                  "lstm_seq_bwd: null pointer");
+    const long B = d->B, T = d->T, H = d->H, BH = B * H;
+    float* dc[2] = {d->ws, d->ws + BH};
+    float* dh[2] = {d->ws + 2 * BH, d->ws + 3 * BH};
+    RC(zero(d->ws, 4 * BH, s));
+    int cur = 0;
+    for (long t = T - 1; t >= 0; --t) {
+        const int nxt = cur ^ 1;
+        mstts_lstm_point_bwd_desc p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H;
+        p.d_out = d->d_out; p.dout_sb = d->dout_sb; p.dout_st = d->dout_st;
+        p.d_c_state = dc[cur]; p.d_h_state = dh[cur];
+        p.acts = d->acts + t * 4 * BH; p.c_raw = d->c_raw + t * BH; p.c_prev = d->c_hist + t * BH;
+        p.zc = d->zc ? d->zc + t * BH : nullptr; p.zh = d->zh ? d->zh + t * BH : nullptr;
+        p.zoneout = d->zoneout; p.lengths = d->lengths; p.step = (int)t; p.reverse = d->reverse;
+        p.dgates = d->dgates_step + t * 4 * BH;
+        p.dgates_pos = d->dgates_pos; p.dgp_sb = T * 4 * H; p.dgp_st = 4 * H;
+        p.d_c_prev = dc[nxt]; p.d_h_prev = dh[nxt];
+        RC(mstts_lstm_point_bwd(&p, s));
+        // d_h_prev += dgates . Wh^T
+        RC(gemm(p.dgates, 4 * H, d->wh, d->wh_ld, 1, dh[nxt], H, B, H, 4 * H, nullptr, 0, 1, s));
+        cur = nxt;
+    }
+    return MSTTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// teacher-forced decoder loop
+// ---------------------------------------------------------------------------------------------
+extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->xw0 && d->w0f && d->w1 && d->b1 && d->wq && d->in0 && d->in1 && d->pj && d->c0 && d->c1 &&
+                  d->acts0 && d->acts1 && d->craw0 && d->craw1 && d->q_hist && d->align_hist && d->cum_hist && d->gates_ws &&
+                  d->energy_ws, MSTTS_ERR_SHAPE, "decoder_train_fwd: null pointer");
+    const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
+    MSTTS_REQUIRE(d->lsa.B == B, MSTTS_ERR_SHAPE, "decoder_train_fwd: lsa.B != B");
+    const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M;
+    RC(zero(d->in0, B * W0, s));
+    RC(zero(d->in1, B * W1, s));
+    RC(zero(d->c0, BH, s));
+    RC(zero(d->c1, BH, s));
+    RC(zero(d->cum_hist, B * T, s));
+    for (long st = 0; st < S; ++st) {
+        mstts_lstm_point_fwd_desc p;
+        // ---- cell 0: gates = [ctx | h0] . w0f + xw0[st]
+        RC(gemm(d->in0 + st * B * W0, W0, d->w0f, 4 * H, 0, d->gates_ws, 4 * H, B, 4 * H, W0, nullptr, 0, 0, s));
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = d->gates_ws;
+        p.xw = d->xw0 + st * 4 * BH; p.xw_sb = 4 * H; p.xw_st = 0;
+        p.c_prev = d->c0 + st * BH; p.h_prev = d->in0 + st * B * W0 + M; p.h_prev_ld = W0;
+        p.zc = d->zc0 ? d->zc0 + st * BH : nullptr; p.zh = d->zh0 ? d->zh0 + st * BH : nullptr;
+        p.zoneout = d->zoneout;
+        p.out = d->in1 + st * B * W1; p.out_sb = W1; p.out_st = 0;
+        p.c_next = d->c0 + (st + 1) * BH; p.h_next = d->in0 + (st + 1) * B * W0 + M; p.h_next_ld = W0;
+        p.acts_out = d->acts0 + st * 4 * BH; p.c_raw = d->craw0 + st * BH;
+        RC(mstts_lstm_point_fwd(&p, s));
+        // ---- cell 1: gates = [m0 | h1] . w1 + b1
+        RC(gemm(d->in1 + st * B * W1, W1, d->w1, 4 * H, 0, d->gates_ws, 4 * H, B, 4 * H, W1, nullptr, 0, 0, s));
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = d->gates_ws; p.bias = d->b1;
+        p.c_prev = d->c1 + st * BH; p.h_prev = d->in1 + st * B * W1 + H; p.h_prev_ld = W1;
+        p.zc = d->zc1 ? d->zc1 + st * BH : nullptr; p.zh = d->zh1 ? d->zh1 + st * BH : nullptr;
+        p.zoneout = d->zoneout;
+        p.out = d->pj + st * B * WP; p.out_sb = WP; p.out_st = 0;
+        p.c_next = d->c1 + (st + 1) * BH; p.h_next = d->in1 + (st + 1) * B * W1 + H; p.h_next_ld = W1;
+        p.acts_out = d->acts1 + st * 4 * BH; p.c_raw = d->craw1 + st * BH;
+        RC(mstts_lstm_point_fwd(&p, s));
+        // ---- query + attention
+        float* q = d->q_hist + st * B * A;
+        RC(gemm(d->pj + st * B * WP, WP, d->wq, A, 0, q, A, B, A, H, nullptr, 0, 0, s));
+        const float* cum = d->cum_hist + st * B * T;
+        RC(mstts_lsa_energy_fwd(&d->lsa, q, cum, d->energy_ws, s));
+        RC(mstts_lsa_context_fwd(&d->lsa, d->energy_ws, cum, d->align_hist + st * B * T, d->cum_hist + (st + 1) * B * T,
+                                 d->in0 + (st + 1) * B * W0, W0, d->pj + st * B * WP + H, WP, s));
+    }
+    return MSTTS_OK;
+}
+
+extern "C" int64_t mstts_decoder_train_bwd_ws_floats(int64_t B, int64_t H, int64_t T, int64_t CH) {
+    return 8 * B * H + 2 * B * T + 2 * B * T * CH + B * T + B * 2 * H;
+}
+
+extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, mstts_stream_t s) {
+    MSTTS_REQUIRE(bd && bd->fwd && bd->d_pj && bd->dg0 && bd->dg1 && bd->dq_hist && bd->de_hist && bd->d_in0 && bd->ws,
+                  MSTTS_ERR_SHAPE, "decoder_train_bwd: null pointer");
+    const mstts_decoder_train_desc* d = bd->fwd;
+    const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T, CH = d->lsa.CH;
+    const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M, BT = B * T;
+    float* w = bd->ws;
+    float* dc0[2] = {w, w + BH};           w += 2 * BH;
+    float* dh0[2] = {w, w + BH};           w += 2 * BH;
+    float* dc1[2] = {w, w + BH};           w += 2 * BH;
+    float* dh1[2] = {w, w + BH};           w += 2 * BH;
+    float* G[2] = {w, w + BT};             w += 2 * BT;
+    float* df[2] = {w, w + BT * CH};       w += 2 * BT * CH;
+    float* d_align = w;                    w += BT;
+    float* tmp1 = w;                       w += B * W1;
+    RC(zero(bd->ws, 8 * BH, s));
+    int cur = 0;
+    for (long st = S - 1; st >= 0; --st) {
+        const int nxt = cur ^ 1;
+        const bool last = (st == S - 1);
+        float* dpj = bd->d_pj + st * B * WP;
+        // ---- attention backward
+        RC(mstts_lsa_dalign_bwd(&d->lsa, dpj + H, WP, last ? nullptr : bd->d_in0 + (st + 1) * B * W0, W0,
+                                last ? nullptr : G[cur], last ? nullptr : df[cur], G[nxt], d_align, s));
+        RC(mstts_lsa_denergy_bwd(&d->lsa, d->align_hist + st * BT, d_align, d->q_hist + st * B * A, d->cum_hist + st * BT,
+                                 bd->de_hist + st * BT, bd->dq_hist + st * B * A, df[nxt], s));
+        // d_m1 += dq . Wq^T
+        RC(gemm(bd->dq_hist + st * B * A, A, d->wq, A, 1, dpj, WP, B, H, A, nullptr, 0, 1, s));
+        // ---- cell 1 backward
+        mstts_lstm_point_bwd_desc p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H;
+        p.d_out = dpj; p.dout_sb = WP; p.dout_st = 0;
+        p.d_c_state = dc1[cur]; p.d_h_state = dh1[cur];
+        p.d_h_state2 = last ? nullptr : tmp1 + H; p.dhs2_ld = W1;
+        p.acts = d->acts1 + st * 4 * BH; p.c_raw = d->craw1 + st * BH; p.c_prev = d->c1 + st * BH;
+        p.zc = d->zc1 ? d->zc1 + st * BH : nullptr; p.zh = d->zh1 ? d->zh1 + st * BH : nullptr;
+        p.zoneout = d->zoneout;
+        p.dgates = bd->dg1 + st * 4 * BH;
+        p.d_c_prev = dc1[nxt]; p.d_h_prev = dh1[nxt];
+        RC(mstts_lstm_point_bwd(&p, s));
+        // [d_m0 | d_h1 state] = dg1 . w1^T
+        RC(gemm(p.dgates, 4 * H, d->w1, 4 * H, 1, tmp1, W1, B, W1, 4 * H, nullptr, 0, 0, s));
+        // ---- cell 0 backward
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H;
+        p.d_out = tmp1; p.dout_sb = W1; p.dout_st = 0;
+        p.d_c_state = dc0[cur]; p.d_h_state = dh0[cur];
+        p.d_h_state2 = last ? nullptr : bd->d_in0 + (st + 1) * B * W0 + M; p.dhs2_ld = W0;
+        p.acts = d->acts0 + st * 4 * BH; p.c_raw = d->craw0 + st * BH; p.c_prev = d->c0 + st * BH;
+        p.zc = d->zc0 ? d->zc0 + st * BH : nullptr; p.zh = d->zh0 ? d->zh0 + st * BH : nullptr;
+        p.zoneout = d->zoneout;
+        p.dgates = bd->dg0 + st * 4 * BH;
+        p.d_c_prev = dc0[nxt]; p.d_h_prev = dh0[nxt];
+        RC(mstts_lstm_point_bwd(&p, s));
+        // [d_ctx_{st-1} | d_h0 state] = dg0 . w0f^T
+        RC(gemm(p.dgates, 4 * H, d->w0f, 4 * H, 1, bd->d_in0 + st * B * W0, W0, B, W0, 4 * H, nullptr, 0, 0, s));
+        cur = nxt;
+    }
+    return MSTTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// free-running decoder steps
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel) {
+    return 2 * B * P + 8 * B * H + B * T + B * A + B * n_mel;
+}
+
+extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->pw0 && d->pw1 && d->wx0 && d->w0f && d->w1 && d->wq && d->wproj && d->in0 && d->in1 && d->pj &&
+                  d->c0 && d->c1 && d->cum && d->pre_ws && d->linear && d->stop && d->align_hist && d->pm0 && d->pm1,
+                  MSTTS_ERR_SHAPE, "decoder_infer_steps: null pointer");
+    MSTTS_REQUIRE(step0 >= 0 && step0 + n <= d->Smax, MSTTS_ERR_SHAPE, "decoder_infer_steps: step range exceeds Smax");
+    const long B = d->B, H = d->H, P = d->P, NM = d->n_mel, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
+    const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M, BT = B * T;
+    float* w = d->pre_ws;
+    float* pa = w;          w += B * P;
+    float* pb = w;          w += B * P;
+    float* xw = w;          w += 4 * BH;
+    float* gates = w;       w += 4 * BH;
+    float* energy = w;      w += BT;
+    float* q = w;           w += B * A;
+    float* zero_frame = w;  w += B * NM;
+    if (step0 == 0) {
+        RC(zero(d->in0, B * W0, s));
+        RC(zero(d->in1, B * W1, s));
+        RC(zero(d->c0, BH, s));
+        RC(zero(d->c1, BH, s));
+        RC(zero(d->cum, BT, s));
+        RC(zero(zero_frame, B * NM, s));
+    }
+    for (long st = step0; st < step0 + n; ++st) {
+        const int par = (int)(st & 1), nx = par ^ 1;
+        const float* frame = (st == 0) ? zero_frame : d->linear + (st - 1) * B * NM;
+        // prenet (dropout always on, Modules.py:248-253)
+        RC(gemm(frame, NM, d->pw0, P, 0, pa, P, B, P, NM, d->pb0, MSTTS_ACT_RELU, 0, s));
+        RC(mstts_dropout(pa, d->pm0 + st * B * P, d->prenet_keep, pb, B * P, s));
+        RC(gemm(pb, P, d->pw1, P, 0, pa, P, B, P, P, d->pb1, MSTTS_ACT_RELU, 0, s));
+        RC(mstts_dropout(pa, d->pm1 + st * B * P, d->prenet_keep, pb, B * P, s));
+        RC(gemm(pb, P, d->wx0, 4 * H, 0, xw, 4 * H, B, 4 * H, P, d->b0, 0, 0, s));
+        mstts_lstm_point_fwd_desc p;
+        // cell 0
+        float* in0c = d->in0 + par * B * W0; float* in0n = d->in0 + nx * B * W0;
+        float* in1c = d->in1 + par * B * W1; float* in1n = d->in1 + nx * B * W1;
+        RC(gemm(in0c, W0, d->w0f, 4 * H, 0, gates, 4 * H, B, 4 * H, W0, nullptr, 0, 0, s));
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = gates; p.xw = xw; p.xw_sb = 4 * H; p.xw_st = 0;
+        p.c_prev = d->c0 + par * BH; p.h_prev = in0c + M; p.h_prev_ld = W0; p.zoneout = d->zoneout;
+        p.out = in1c; p.out_sb = W1; p.c_next = d->c0 + nx * BH; p.h_next = in0n + M; p.h_next_ld = W0;
+        RC(mstts_lstm_point_fwd(&p, s));
+        // cell 1
+        RC(gemm(in1c, W1, d->w1, 4 * H, 0, gates, 4 * H, B, 4 * H, W1, nullptr, 0, 0, s));
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = gates; p.bias = d->b1;
+        p.c_prev = d->c1 + par * BH; p.h_prev = in1c + H; p.h_prev_ld = W1; p.zoneout = d->zoneout;
+        p.out = d->pj; p.out_sb = WP; p.c_next = d->c1 + nx * BH; p.h_next = in1n + H; p.h_next_ld = W1;
+        RC(mstts_lstm_point_fwd(&p, s));
+        // attention
+        RC(gemm(d->pj, WP, d->wq, A, 0, q, A, B, A, H, nullptr, 0, 0, s));
+        RC(mstts_lsa_energy_fwd(&d->lsa, q, d->cum + par * BT, energy, s));
+        RC(mstts_lsa_context_fwd(&d->lsa, energy, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
+                                 in0n, W0, d->pj + H, WP, s));
+        // projection: [m1 | ctx] . Wp + b -> linear (n_mel) and stop (1)
+        RC(gemm(d->pj, WP, d->wproj, NM + 1, 0, d->linear + st * B * NM, NM, B, NM, WP, d->bproj, 0, 0, s));
+        RC(gemm(d->pj, WP, d->wproj + NM, NM + 1, 0, d->stop + st * B, 1, B, 1, WP, d->bproj ? d->bproj + NM : nullptr, 0, 0, s));
+    }
+    return MSTTS_OK;
+}

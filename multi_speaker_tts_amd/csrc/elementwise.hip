@@ -1,0 +1,675 @@
+// HBM-bound elementwise / reduction kernels of the Tacotron2 hot path (gfx950).
+// Everything here is streaming work: float4 accesses, grid-stride loops capped at 2048 blocks,
+// wave64 shuffles for reductions.
+#include "common.h"
+#include <stdarg.h>
+
+namespace mstts {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline int grid_for(long n, int per_block) {
+    long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 keep masks: draw i of (seed, stream) = word i&3 of philox(ctr=(i>>2,0,stream,0))
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void philox_mask_kernel(uint8_t* __restrict__ out, long n, uint32_t k0, uint32_t k1, uint32_t stream, float keep) {
+    const long nblk = (n + 3) >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nblk; i += (long)gridDim.x * blockDim.x) {
+        uint32_t w[4];
+        philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), stream, 0u, k0, k1, w);
+        uint8_t m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = ((float)(w[j] >> 8) * 5.9604644775390625e-08f < keep) ? 1 : 0;
+        const long base = i << 2;
+        if (base + 3 < n) {
+            *reinterpret_cast<uchar4*>(out + base) = make_uchar4(m[0], m[1], m[2], m[3]);
+        } else {
+            for (int j = 0; j < 4 && base + j < n; ++j) out[base + j] = m[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding
+// ---------------------------------------------------------------------------------------------
+__global__ void embedding_fwd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ table,
+                                     float* __restrict__ out, long n, int vocab, int width) {
+    const int w4 = width >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n * w4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / w4; const int c = (int)(i % w4);
+        int t = tok[row];
+        t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table + (long)t * width)[c];
+    }
+}
+__global__ void embedding_bwd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ dout,
+                                     float* __restrict__ dtable, long n, int vocab, int width) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n * width; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / width; const int c = (int)(i % width);
+        int t = tok[row];
+        t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+        atomicAdd(dtable + (long)t * width + c, dout[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reductions over [rows, C]: each block owns 64 columns x a row chunk; threads (cx, ry) =
+// (64 columns, 4 row lanes); partial sums go out with one atomic per column per block.
+// ---------------------------------------------------------------------------------------------
+// mode 0: out0 += sum x, out1 += sum x^2
+// mode 1 (bn bwd): xhat = (x-mean)*rstd, dyn = dy*mask/keep: out0 += sum dyn, out1 += sum dyn*xhat
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const uint8_t* __restrict__ mask, float inv_keep,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        long rows, int C, long ld, int rows_per_block, int mode,
+                                                        float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float s0[4][64], s1[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f;
+    if (col < C) {
+        float mu = 0.f, rs = 1.f;
+        if (mode == 1) { mu = mean[col]; rs = rstd[col]; }
+        for (long r = r0 + ry; r < r1; r += 4) {
+            const float xv = x[r * ld + col];
+            if (mode == 0) {
+                a0 += xv; a1 += xv * xv;
+            } else {
+                float d = dy[r * (long)C + col];
+                if (mask) d *= mask[r * (long)C + col] ? inv_keep : 0.f;
+                a0 += d; a1 += d * (xv - mu) * rs;
+            }
+        }
+    }
+    s0[ry][cx] = a0; s1[ry][cx] = a1;
+    __syncthreads();
+    if (ry == 0 && col < C) {
+        a0 = s0[0][cx] + s0[1][cx] + s0[2][cx] + s0[3][cx];
+        a1 = s1[0][cx] + s1[1][cx] + s1[2][cx] + s1[3][cx];
+        atomicAdd(out0 + col, a0);
+        if (out1) atomicAdd(out1 + col, a1);
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ ws, float inv_rows, float eps, float momentum,
+                                   float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                   float* __restrict__ save_mean, float* __restrict__ save_rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = ws[c] * inv_rows;
+    float var = ws[C + c] * inv_rows - mean * mean;
+    var = fmaxf(var, 0.f);
+    save_mean[c] = mean;
+    save_rstd[c] = rsqrtf(var + eps);
+    if (moving_mean) {
+        moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
+        moving_var[c] = moving_var[c] * momentum + var * (1.f - momentum);
+    }
+}
+
+// y = ((x - mean) * rstd * gamma + beta) * mask/keep     (rstd_is_var: second stat is a variance)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ mean, const float* __restrict__ stat2, int stat2_is_var, float eps,
+                                const uint8_t* __restrict__ mask, float inv_keep, float* __restrict__ y, long rows, int C) {
+    const int c4n = C >> 2;
+    const long n4 = rows * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float xs[4] = {xv.x, xv.y, xv.z, xv.w}, o[4];
+        uchar4 mk = make_uchar4(1, 1, 1, 1);
+        if (mask) mk = reinterpret_cast<const uchar4*>(mask)[i];
+        const uint8_t ms[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float rs = stat2[c + j];
+            if (stat2_is_var) rs = rsqrtf(rs + eps);
+            float v = (xs[j] - mean[c + j]) * rs * gamma[c + j] + beta[c + j];
+            if (mask) v *= ms[j] ? inv_keep : 0.f;
+            o[j] = v;
+        }
+        reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dz = gamma*rstd*(dyn - dbeta/N - xhat*dgamma/N) * act'(x); ws = [sum dyn | sum dyn*xhat]
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const uint8_t* __restrict__ mask, float inv_keep, int act, const float* __restrict__ ws,
+                                    float inv_rows, float* __restrict__ dz, long rows, int C) {
+    const int c4n = C >> 2;
+    const long n4 = rows * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 dv = reinterpret_cast<const float4*>(dy)[i];
+        float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
+        uchar4 mk = make_uchar4(1, 1, 1, 1);
+        if (mask) mk = reinterpret_cast<const uchar4*>(mask)[i];
+        const uint8_t ms[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float d = ds[j];
+            if (mask) d *= ms[j] ? inv_keep : 0.f;
+            const float xhat = (xs[j] - mean[c + j]) * rstd[c + j];
+            float g = gamma[c + j] * rstd[c + j] * (d - ws[c + j] * inv_rows - xhat * ws[C + c + j] * inv_rows);
+            if (act == MSTTS_ACT_RELU) g = xs[j] > 0.f ? g : 0.f;
+            else if (act == MSTTS_ACT_TANH) g *= (1.f - xs[j] * xs[j]);
+            else if (act == MSTTS_ACT_SIGMOID) g *= xs[j] * (1.f - xs[j]);
+            o[j] = g;
+        }
+        reinterpret_cast<float4*>(dz)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void vec_acc_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat elementwise
+// ---------------------------------------------------------------------------------------------
+__global__ void dropout_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, float inv_keep,
+                               float* __restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = mask[i] ? x[i] * inv_keep : 0.f;
+}
+__global__ void relu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ys, const uint8_t* __restrict__ mask,
+                                        float inv_keep, float* __restrict__ dx, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = (mask[i] && ys[i] > 0.f) ? dy[i] * inv_keep : 0.f;
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
+}
+__global__ void fill_kernel(float* __restrict__ y, float v, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = v;
+}
+__global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long rows, long cols, int acc) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows * cols; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, c = i % cols;
+        const float v = src[r * lds + c];
+        if (acc) dst[r * ldd + c] += v; else dst[r * ldd + c] = v;
+    }
+}
+__global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, long B, long T, long C) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < B * T * C; i += (long)gridDim.x * blockDim.x) {
+        const long t = (i / C) % T;
+        float v = x[i];
+        if (t + 1 < T) v = fmaxf(v, x[i + C]);
+        y[i] = v;
+    }
+}
+__global__ void highway_kernel(const float* __restrict__ hp, const float* __restrict__ tp, const float* __restrict__ x,
+                               float* __restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float H = fmaxf(hp[i], 0.f), T = sigmoidf_(tp[i]);
+        y[i] = H * T + x[i] * (1.f - T);
+    }
+}
+__global__ void fold_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, long cols, long r0, long n) {
+    const long out_rows = rows - n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < out_rows * cols; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, c = i % cols;
+        float v;
+        if (r < r0) v = src[r * cols + c];
+        else if (r < r0 + n) v = src[r * cols + c] + src[(r + n) * cols + c];
+        else v = src[(r + n) * cols + c];
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// zoneout LSTM cell: pointwise part, forward and backward
+// ---------------------------------------------------------------------------------------------
+__global__ void lstm_point_fwd_kernel(mstts_lstm_point_fwd_desc d) {
+    const long n = d.B * d.H;
+    const int H = (int)d.H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H), u = (int)(i % H);
+        int len = d.lengths ? d.lengths[b] : 0x7fffffff;
+        const bool live = d.step < len;
+        const int pos = d.reverse ? (live ? len - 1 - d.step : d.step) : d.step;
+        const long hpl = d.h_prev_ld ? d.h_prev_ld : H, hnl = d.h_next_ld ? d.h_next_ld : H;
+        const float cp = d.c_prev[i], hp = d.h_prev[b * hpl + u];
+        float* outp = d.out ? d.out + b * d.out_sb + pos * d.out_st + u : nullptr;
+        if (!live) {
+            if (outp) *outp = 0.f;
+            d.c_next[i] = cp; d.h_next[b * hnl + u] = hp;
+            if (d.acts_out) { for (int g = 0; g < 4; ++g) d.acts_out[(long)b * 4 * H + g * H + u] = 0.f; }
+            if (d.c_raw) d.c_raw[i] = cp;
+            continue;
+        }
+        float g4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = d.gates_h[(long)b * 4 * H + g * H + u];
+            if (d.xw) v += d.xw[b * d.xw_sb + pos * d.xw_st + g * H + u];
+            if (d.bias) v += d.bias[g * H + u];
+            g4[g] = v;
+        }
+        const float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
+        const float c = sf * cp + si * tj;
+        const float m = so * tanhf(c);
+        float dc = c - cp, dm = m - hp;
+        if (d.zc) dc = d.zc[i] ? dc : 0.f;
+        if (d.zh) dm = d.zh[i] ? dm : 0.f;
+        d.c_next[i] = (1.f - d.zoneout) * dc + cp;
+        d.h_next[b * hnl + u] = (1.f - d.zoneout) * dm + hp;
+        if (outp) {
+            float o = m;
+            if (d.residual) o += d.residual[b * d.res_sb + pos * d.res_st + u];
+            *outp = o;
+        }
+        if (d.acts_out) {
+            float* a = d.acts_out + (long)b * 4 * H + u;
+            a[0] = si; a[H] = tj; a[2 * H] = sf; a[3 * H] = so;
+        }
+        if (d.c_raw) d.c_raw[i] = c;
+    }
+}
+
+__global__ void lstm_point_bwd_kernel(mstts_lstm_point_bwd_desc d) {
+    const long n = d.B * d.H;
+    const int H = (int)d.H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H), u = (int)(i % H);
+        int len = d.lengths ? d.lengths[b] : 0x7fffffff;
+        const bool live = d.step < len;
+        const int pos = d.reverse ? (live ? len - 1 - d.step : d.step) : d.step;
+        float dhs = d.d_h_state[i];
+        if (d.d_h_state2) dhs += d.d_h_state2[b * d.dhs2_ld + u];
+        const float dcs = d.d_c_state[i];
+        float* dg = d.dgates + (long)b * 4 * H + u;
+        float* dgp = d.dgates_pos ? d.dgates_pos + b * d.dgp_sb + pos * d.dgp_st + u : nullptr;
+        if (!live) {
+            dg[0] = dg[H] = dg[2 * H] = dg[3 * H] = 0.f;
+            if (dgp) { dgp[0] = dgp[H] = dgp[2 * H] = dgp[3 * H] = 0.f; }
+            d.d_c_prev[i] = dcs; d.d_h_prev[i] = dhs;
+            continue;
+        }
+        float dm = 0.f;
+        if (d.d_out) dm += d.d_out[b * d.dout_sb + pos * d.dout_st + u];
+        if (d.d_out2) dm += d.d_out2[i];
+        const float kz = 1.f - d.zoneout;
+        const float mh = d.zh ? (d.zh[i] ? kz : 0.f) : kz;     // d h'/d m
+        const float mc = d.zc ? (d.zc[i] ? kz : 0.f) : kz;     // d c'/d c
+        dm += mh * dhs;
+        const float* a = d.acts + (long)b * 4 * H + u;
+        const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
+        const float c = d.c_raw[i], cp = d.c_prev[i];
+        const float tc = tanhf(c);
+        const float dc = dm * so * (1.f - tc * tc) + mc * dcs;
+        const float d_o = dm * tc * so * (1.f - so);
+        const float d_i = dc * tj * si * (1.f - si);
+        const float d_j = dc * si * (1.f - tj * tj);
+        const float d_f = dc * cp * sf * (1.f - sf);
+        dg[0] = d_i; dg[H] = d_j; dg[2 * H] = d_f; dg[3 * H] = d_o;
+        if (dgp) { dgp[0] = d_i; dgp[H] = d_j; dgp[2 * H] = d_f; dgp[3 * H] = d_o; }
+        d.d_c_prev[i] = dcs * (1.f - mc) + dc * sf;
+        d.d_h_prev[i] = dhs * (1.f - mh);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tts_loss_kernel(const float* __restrict__ lin, const float* __restrict__ post,
+                                                       const float* __restrict__ mel, const float* __restrict__ stop,
+                                                       const int32_t* __restrict__ mlen, long B, long S, long nm, int use_l1,
+                                                       float gs, float* __restrict__ scal, float* __restrict__ dlin,
+                                                       float* __restrict__ dpost, float* __restrict__ dstop) {
+    __shared__ float scratch[16];
+    const long L = S - 1;
+    const long n_mel_el = B * S * nm;
+    const float inv_n = 1.f / (float)(B * L * nm);
+    float a_lin = 0.f, a_post = 0.f, a_stop = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_mel_el; i += (long)gridDim.x * blockDim.x) {
+        const long c = i % nm, t = (i / nm) % S, b = i / (nm * S);
+        float gl = 0.f, gp = 0.f;
+        if (t < L) {
+            const float tgt = mel[(b * L + t) * nm + c];
+            const float e1 = lin[i] - tgt, e2 = post[i] - tgt;
+            a_lin += e1 * e1; a_post += e2 * e2;
+            gl = 2.f * e1 * inv_n; gp = 2.f * e2 * inv_n;
+            if (use_l1) {
+                a_lin += fabsf(e1); a_post += fabsf(e2);
+                gl += (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f)) * inv_n;
+                gp += (e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f)) * inv_n;
+            }
+        }
+        dlin[i] = gl * gs; dpost[i] = gp * gs;
+    }
+    const float inv_s = 1.f / (float)(B * S);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < B * S; i += (long)gridDim.x * blockDim.x) {
+        const long t = i % S, b = i / S;
+        const float z = stop[i];
+        const float y = (t >= mlen[b]) ? 1.f : 0.f;
+        a_stop += fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
+        dstop[i] = (sigmoidf_(z) - y) * inv_s * gs;
+    }
+    a_lin = block_sum(a_lin, scratch);
+    a_post = block_sum(a_post, scratch);
+    a_stop = block_sum(a_stop, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(scal + 0, a_lin * inv_n);
+        atomicAdd(scal + 1, a_post * inv_n);
+        atomicAdd(scal + 2, a_stop * inv_s);
+    }
+}
+
+__global__ void shift_frames_kernel(const float* __restrict__ mel, float* __restrict__ fr, long B, long L, long C) {
+    const long n = (L + 1) * B * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long c = i % C, b = (i / C) % B, s = i / (C * B);
+        fr[i] = (s == 0) ? 0.f : mel[(b * L + (s - 1)) * C + c];
+    }
+}
+__global__ void unpack_proj_kernel(const float* __restrict__ proj, long ldp, float* __restrict__ lin, float* __restrict__ stop,
+                                   long B, long S, long C) {
+    const long n = B * S * (C + 1);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long c = i % (C + 1), s = (i / (C + 1)) % S, b = i / ((C + 1) * S);
+        const float v = proj[(s * B + b) * ldp + c];
+        if (c < C) lin[(b * S + s) * C + c] = v; else stop[b * S + s] = v;
+    }
+}
+__global__ void pack_dproj_kernel(const float* __restrict__ dlin, const float* __restrict__ dstop, float* __restrict__ dproj,
+                                  long ldp, long B, long S, long C) {
+    const long n = S * B * ldp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long c = i % ldp, b = (i / ldp) % B, s = i / (ldp * B);
+        float v = 0.f;
+        if (c < C) v = dlin[(b * S + s) * C + c]; else if (c == C) v = dstop[b * S + s];
+        dproj[i] = v;
+    }
+}
+__global__ void speaker_tile_kernel(const float* __restrict__ spk, const int32_t* __restrict__ len, float* __restrict__ values,
+                                    long B, long T, long M, long off, long width) {
+    const long n = B * T * width;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long j = i % width, t = (i / width) % T, b = i / (width * T);
+        const bool live = len ? (t < len[b]) : true;
+        values[(b * T + t) * M + off + j] = live ? spk[b * width + j] : 0.f;
+    }
+}
+__global__ void conv_kernel_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, long K, long Cin, long Cout) {
+    const long n = K * Cin * Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long c = i % Cin, o = (i / Cin) % Cout, kk = i / (Cin * Cout);
+        wt[i] = w[((K - 1 - kk) * Cin + c) * Cout + o];
+    }
+}
+
+__global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, long n, float* __restrict__ out) {
+    __shared__ float scratch[16];
+    float a = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        if (!mask || mask[i]) a += x[i] * x[i];
+    a = block_sum(a, scratch);
+    if (threadIdx.x == 0) atomicAdd(out, 0.5f * a);
+}
+
+__global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               const uint8_t* __restrict__ wdm, float wd, float gs, float lr_t, float b1, float b2, float eps, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        float gv = g[i] * gs;
+        if (wdm && wdm[i]) gv += wd * pv;
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv; v[i] = vv;
+        p[i] = pv - lr_t * mv / (sqrtf(vv) + eps);
+    }
+}
+
+}  // namespace mstts
+
+using namespace mstts;
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" const char* mstts_last_error(void) { return err_buf(); }
+extern "C" int mstts_abi_version(void) { return 1; }
+
+extern "C" int mstts_philox_keep_mask(uint8_t* out, int64_t n, uint64_t seed, uint32_t stream_id, float keep_prob, mstts_stream_t s) {
+    MSTTS_REQUIRE(n >= 0 && (n == 0 || out), MSTTS_ERR_SHAPE, "philox: bad args");
+    if (n == 0) return MSTTS_OK;
+    MSTTS_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3u) == 0, MSTTS_ERR_ALIGN, "philox: out must be 4-byte aligned");
+    hipLaunchKernelGGL(philox_mask_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST(s), out, (long)n,
+                       (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), stream_id, keep_prob);
+    MSTTS_CHECK_LAUNCH("philox_keep_mask");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_embedding_fwd(const int32_t* token, const float* table, float* out, int64_t n, int64_t vocab, int64_t width, mstts_stream_t s) {
+    MSTTS_REQUIRE(width % 4 == 0 && aligned16(table) && aligned16(out), MSTTS_ERR_ALIGN, "embedding: width %% 4 and 16-byte alignment required");
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(n * width / 4, 256)), dim3(256), 0, ST(s), token, table, out, (long)n, (int)vocab, (int)width);
+    MSTTS_CHECK_LAUNCH("embedding_fwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_embedding_bwd(const int32_t* token, const float* dout, float* dtable, int64_t n, int64_t vocab, int64_t width, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(n * width, 256)), dim3(256), 0, ST(s), token, dout, dtable, (long)n, (int)vocab, (int)width);
+    MSTTS_CHECK_LAUNCH("embedding_bwd");
+    return MSTTS_OK;
+}
+
+static int rows_per_block_for(int64_t rows, int64_t C) {
+    // aim for ~1024 blocks
+    long colb = (C + 63) / 64;
+    long want = 1024 / (colb > 0 ? colb : 1);
+    if (want < 1) want = 1;
+    long rpb = (rows + want - 1) / want;
+    if (rpb < 32) rpb = 32;
+    return (int)rpb;
+}
+
+extern "C" int mstts_colsum(const float* x, int64_t rows, int64_t C, int64_t ld, float* out, int32_t accumulate, mstts_stream_t s) {
+    if (!accumulate) hipMemsetAsync(out, 0, C * sizeof(float), ST(s));
+    if (rows == 0 || C == 0) return MSTTS_OK;
+    const int rpb = rows_per_block_for(rows, C);
+    dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
+    hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, ST(s), x, (const float*)nullptr, (const uint8_t*)nullptr, 1.f,
+                       (const float*)nullptr, (const float*)nullptr, (long)rows, (int)C, (long)ld, rpb, 0, out, (float*)nullptr);
+    MSTTS_CHECK_LAUNCH("colsum");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                                  float* y, float* save_mean, float* save_rstd, const uint8_t* keep_mask, float keep_prob,
+                                  float momentum, float eps, int64_t rows, int64_t C, float* ws, mstts_stream_t s) {
+    MSTTS_REQUIRE(C % 4 == 0 && aligned16(x) && aligned16(y), MSTTS_ERR_ALIGN, "bn: C %% 4 and 16-byte alignment required");
+    MSTTS_REQUIRE(rows > 0, MSTTS_ERR_SHAPE, "bn: rows must be > 0");
+    hipMemsetAsync(ws, 0, 2 * C * sizeof(float), ST(s));
+    const int rpb = rows_per_block_for(rows, C);
+    dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
+    hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, ST(s), x, (const float*)nullptr, (const uint8_t*)nullptr, 1.f,
+                       (const float*)nullptr, (const float*)nullptr, (long)rows, (int)C, (long)C, rpb, 0, ws, ws + C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(s), ws, 1.f / (float)rows, eps, momentum,
+                       moving_mean, moving_var, save_mean, save_rstd, (int)C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * C / 4, 256)), dim3(256), 0, ST(s), x, gamma, beta,
+                       (const float*)save_mean, (const float*)save_rstd, 0, eps, keep_mask, 1.f / keep_prob, y, (long)rows, (int)C);
+    MSTTS_CHECK_LAUNCH("bn_train_fwd");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_bn_infer_fwd(const float* x, const float* gamma, const float* beta, const float* moving_mean,
+                                  const float* moving_var, float* y, float eps, int64_t rows, int64_t C, mstts_stream_t s) {
+    MSTTS_REQUIRE(C % 4 == 0 && aligned16(x) && aligned16(y), MSTTS_ERR_ALIGN, "bn: C %% 4 and 16-byte alignment required");
+    if (rows == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * C / 4, 256)), dim3(256), 0, ST(s), x, gamma, beta, moving_mean,
+                       moving_var, 1, eps, (const uint8_t*)nullptr, 1.f, y, (long)rows, (int)C);
+    MSTTS_CHECK_LAUNCH("bn_infer_fwd");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_bn_train_bwd(const float* dy, const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                                  const uint8_t* keep_mask, float keep_prob, int32_t act, float* dz, float* dgamma, float* dbeta,
+                                  float* dbias, int64_t rows, int64_t C, float* ws, mstts_stream_t s) {
+    MSTTS_REQUIRE(C % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dz), MSTTS_ERR_ALIGN, "bn: C %% 4 and 16-byte alignment required");
+    MSTTS_REQUIRE(rows > 0, MSTTS_ERR_SHAPE, "bn: rows must be > 0");
+    hipMemsetAsync(ws, 0, 2 * C * sizeof(float), ST(s));
+    const int rpb = rows_per_block_for(rows, C);
+    dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
+    hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, ST(s), x, dy, keep_mask, 1.f / keep_prob, save_mean, save_rstd,
+                       (long)rows, (int)C, (long)C, rpb, 1, ws, ws + C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * C / 4, 256)), dim3(256), 0, ST(s), dy, x, gamma, save_mean, save_rstd,
+                       keep_mask, 1.f / keep_prob, (int)act, (const float*)ws, 1.f / (float)rows, dz, (long)rows, (int)C);
+    if (dbeta) hipLaunchKernelGGL(vec_acc_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(s), dbeta, (const float*)ws, (int)C);
+    if (dgamma) hipLaunchKernelGGL(vec_acc_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(s), dgamma, (const float*)(ws + C), (int)C);
+    if (dbias) {
+        hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, ST(s), (const float*)dz, (const float*)nullptr, (const uint8_t*)nullptr, 1.f,
+                           (const float*)nullptr, (const float*)nullptr, (long)rows, (int)C, (long)C, rpb, 0, dbias, (float*)nullptr);
+    }
+    MSTTS_CHECK_LAUNCH("bn_train_bwd");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_dropout(const float* x, const uint8_t* keep_mask, float keep_prob, float* y, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), x, keep_mask, 1.f / keep_prob, y, (long)n);
+    MSTTS_CHECK_LAUNCH("dropout");
+    return MSTTS_OK;
+}
+extern "C" int mstts_relu_dropout_bwd(const float* dy, const float* y_saved, const uint8_t* keep_mask, float keep_prob, float* dx, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), dy, y_saved, keep_mask, 1.f / keep_prob, dx, (long)n);
+    MSTTS_CHECK_LAUNCH("relu_dropout_bwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_add(const float* a, const float* b, float* y, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), a, b, y, (long)n);
+    MSTTS_CHECK_LAUNCH("add");
+    return MSTTS_OK;
+}
+extern "C" int mstts_fill(float* y, float v, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), y, v, (long)n);
+    MSTTS_CHECK_LAUNCH("fill");
+    return MSTTS_OK;
+}
+extern "C" int mstts_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, int32_t accumulate, mstts_stream_t s) {
+    if (rows * cols == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * cols, 256)), dim3(256), 0, ST(s), src, (long)lds, dst, (long)ldd, (long)rows, (long)cols, (int)accumulate);
+    MSTTS_CHECK_LAUNCH("copy2d");
+    return MSTTS_OK;
+}
+extern "C" int mstts_maxpool2_same(const float* x, float* y, int64_t B, int64_t T, int64_t C, mstts_stream_t s) {
+    if (B * T * C == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(B * T * C, 256)), dim3(256), 0, ST(s), x, y, (long)B, (long)T, (long)C);
+    MSTTS_CHECK_LAUNCH("maxpool2_same");
+    return MSTTS_OK;
+}
+extern "C" int mstts_highway_combine(const float* h_pre, const float* t_pre, const float* x, float* y, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(highway_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), h_pre, t_pre, x, y, (long)n);
+    MSTTS_CHECK_LAUNCH("highway_combine");
+    return MSTTS_OK;
+}
+extern "C" int mstts_fold_rows(const float* src, float* dst, int64_t rows, int64_t cols, int64_t r0, int64_t n, mstts_stream_t s) {
+    MSTTS_REQUIRE(r0 >= 0 && n >= 0 && r0 + 2 * n <= rows, MSTTS_ERR_SHAPE, "fold_rows: bad row ranges");
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(grid_for((rows - n) * cols, 256)), dim3(256), 0, ST(s), src, dst, (long)rows, (long)cols, (long)r0, (long)n);
+    MSTTS_CHECK_LAUNCH("fold_rows");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->gates_h && d->c_prev && d->h_prev && d->c_next && d->h_next, MSTTS_ERR_SHAPE, "lstm_point_fwd: null pointer");
+    if (d->B * d->H == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(lstm_point_fwd_kernel, dim3(grid_for(d->B * d->H, 256)), dim3(256), 0, ST(s), *d);
+    MSTTS_CHECK_LAUNCH("lstm_point_fwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->d_c_state && d->d_h_state && d->acts && d->c_raw && d->c_prev && d->dgates && d->d_c_prev && d->d_h_prev,
+                  MSTTS_ERR_SHAPE, "lstm_point_bwd: null pointer");
+    if (d->B * d->H == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(lstm_point_bwd_kernel, dim3(grid_for(d->B * d->H, 256)), dim3(256), 0, ST(s), *d);
+    MSTTS_CHECK_LAUNCH("lstm_point_bwd");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_tts_loss_fwd_bwd(const float* linear, const float* post, const float* mel, const float* stop_logit,
+                                      const int32_t* mel_length, int64_t B, int64_t S, int64_t n_mel, int32_t use_l1,
+                                      float grad_scale, float* scalars, float* d_linear, float* d_post, float* d_stop, mstts_stream_t s) {
+    MSTTS_REQUIRE(S >= 2 && B > 0 && n_mel > 0, MSTTS_ERR_SHAPE, "tts_loss: need S >= 2");
+    hipLaunchKernelGGL(tts_loss_kernel, dim3(grid_for(B * S * n_mel, 256)), dim3(256), 0, ST(s), linear, post, mel, stop_logit, mel_length,
+                       (long)B, (long)S, (long)n_mel, (int)use_l1, grad_scale, scalars, d_linear, d_post, d_stop);
+    MSTTS_CHECK_LAUNCH("tts_loss_fwd_bwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_shift_frames(const float* mel, float* frames, int64_t B, int64_t L, int64_t C, mstts_stream_t s) {
+    hipLaunchKernelGGL(shift_frames_kernel, dim3(grid_for((L + 1) * B * C, 256)), dim3(256), 0, ST(s), mel, frames, (long)B, (long)L, (long)C);
+    MSTTS_CHECK_LAUNCH("shift_frames");
+    return MSTTS_OK;
+}
+extern "C" int mstts_unpack_proj(const float* proj, int64_t ldp, float* linear, float* stop, int64_t B, int64_t S, int64_t C, mstts_stream_t s) {
+    hipLaunchKernelGGL(unpack_proj_kernel, dim3(grid_for(B * S * (C + 1), 256)), dim3(256), 0, ST(s), proj, (long)ldp, linear, stop, (long)B, (long)S, (long)C);
+    MSTTS_CHECK_LAUNCH("unpack_proj");
+    return MSTTS_OK;
+}
+extern "C" int mstts_pack_dproj(const float* d_linear, const float* d_stop, float* d_proj, int64_t ldp, int64_t B, int64_t S, int64_t C, mstts_stream_t s) {
+    hipLaunchKernelGGL(pack_dproj_kernel, dim3(grid_for(B * S * ldp, 256)), dim3(256), 0, ST(s), d_linear, d_stop, d_proj, (long)ldp, (long)B, (long)S, (long)C);
+    MSTTS_CHECK_LAUNCH("pack_dproj");
+    return MSTTS_OK;
+}
+extern "C" int mstts_speaker_tile(const float* spk, const int32_t* lengths, float* values, int64_t B, int64_t T, int64_t M, int64_t off, int64_t width, mstts_stream_t s) {
+    hipLaunchKernelGGL(speaker_tile_kernel, dim3(grid_for(B * T * width, 256)), dim3(256), 0, ST(s), spk, lengths, values, (long)B, (long)T, (long)M, (long)off, (long)width);
+    MSTTS_CHECK_LAUNCH("speaker_tile");
+    return MSTTS_OK;
+}
+extern "C" int mstts_conv_kernel_flip(const float* w, float* wt, int64_t K, int64_t Cin, int64_t Cout, mstts_stream_t s) {
+    hipLaunchKernelGGL(conv_kernel_flip_kernel, dim3(grid_for(K * Cin * Cout, 256)), dim3(256), 0, ST(s), w, wt, (long)K, (long)Cin, (long)Cout);
+    MSTTS_CHECK_LAUNCH("conv_kernel_flip");
+    return MSTTS_OK;
+}
+extern "C" int mstts_l2_loss_acc(const float* x, const uint8_t* mask, int64_t n, float* out, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(l2_loss_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, ST(s), x, mask, (long)n, out);
+    MSTTS_CHECK_LAUNCH("l2_loss_acc");
+    return MSTTS_OK;
+}
+extern "C" int mstts_adam_tf(float* p, const float* grad, float* m, float* v, const uint8_t* wd_mask, float wd, float grad_scale,
+                             float lr_t, float beta1, float beta2, float eps, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), p, grad, m, v, wd_mask, wd, grad_scale, lr_t, beta1, beta2, eps, (long)n);
+    MSTTS_CHECK_LAUNCH("adam_tf");
+    return MSTTS_OK;
+}

@@ -1,0 +1,288 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fp32 accumulate).
+//
+// One kernel family covers every dense contraction of the Tacotron2 hot path:
+//   * dense / prenet / projection / memory-layer forward          (A row-major, B [K,N])
+//   * conv1d 'same' as an implicit-im2col GEMM in NWC layout      (A = overlapping row windows)
+//   * data gradients  dX = dY . W^T                               (B read transposed)
+//   * weight gradients dW = X^T . dY, also over conv windows      (A read transposed, split-K)
+// Tile: BM x 128 x 32 per 256-thread workgroup (4 wave64), LDS tiles are k-major so an MFMA
+// operand is one conflict-free ds_read_b32 per lane; the next K-tile is prefetched into registers
+// while the current one is multiplied.  Replaces tf.layers.conv1d / tf.layers.dense /
+// tf.matmul call sites of the reference (Modules.py:29-36,125-132,243-247,311-314;
+// ZoneoutLSTMCell.py:228) and their autodiff gradients.
+#include "common.h"
+#include <type_traits>
+
+namespace mstts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int BN = 128;
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long lda, ldb, ldc;
+    int win_T, win_C, win_pad;
+    int act, accumulate, split_k;
+    long stride_a, stride_b, stride_c;
+    float alpha;
+    int k_per_split;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == MSTTS_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == MSTTS_ACT_TANH) return tanhf_(v);
+    if (act == MSTTS_ACT_SIGMOID) return sigmoidf_(v);
+    return v;
+}
+
+// ---- tile loaders -------------------------------------------------------------------------
+// "KC": operand contiguous along k in memory (A row-major, or B given as [N,K]).
+//   rows = the M (or N) index, R rows per tile.  reg[] holds R*BK/256/4 float4 per thread.
+// "MC": operand contiguous along its M/N index (B row-major [K,N], or A given as [K,M]).
+template <int R, bool VEC>
+struct LoaderKC {
+    static constexpr int NV = R * BK / 4 / 256;      // float4 per thread
+    float4 reg[NV];
+    // window: element (row, k) valid iff 0 <= (row % T) + k / C - pad < T; address shifts by -pad rows
+    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int row0, int k0,
+                                         int rows, int kmax, int wT, int wC, int wpad) {
+        const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = row0 + r + i * 32;
+            const int k = k0 + k4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = row < rows && k < kmax;
+            long off = (long)row * ld + k;
+            if (wT > 0) {
+                const int t = row % wT + k / wC - wpad;
+                ok = ok && t >= 0 && t < wT;
+                off = ((long)row - wpad) * ld + k;
+            }
+            if (ok) {
+                if (VEC) {
+                    v = *reinterpret_cast<const float4*>(base + off);
+                } else {
+                    v.x = base[off];
+                    if (k + 1 < kmax) v.y = base[off + 1];
+                    if (k + 2 < kmax) v.z = base[off + 2];
+                    if (k + 3 < kmax) v.w = base[off + 3];
+                }
+            }
+            reg[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ s, int ldS) const {
+        const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float* p = s + (k4 * 4) * ldS + r + i * 32;
+            p[0] = reg[i].x; p[ldS] = reg[i].y; p[2 * ldS] = reg[i].z; p[3 * ldS] = reg[i].w;
+        }
+    }
+};
+
+template <int R, bool VEC>
+struct LoaderMC {
+    static constexpr int C4 = R / 4;                  // float4 per k-row
+    static constexpr int KR = 256 / C4;               // k-rows per pass
+    static constexpr int NV = BK / KR;
+    float4 reg[NV];
+    // window (A only): element (m, kk) with kk=(b,t) row index, m=(tap, c):
+    //   valid iff 0 <= (kk % T) + m / C - pad < T; address = base[(kk - pad) * ld + m]
+    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int col0, int k0,
+                                         int cols, int kmax, int wT, int wC, int wpad) {
+        const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = k0 + kr + i * KR;
+            const int col = col0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = k < kmax && col < cols;
+            long off = (long)k * ld + col;
+            if (wT > 0) {
+                const int t = k % wT + col / wC - wpad;
+                ok = ok && t >= 0 && t < wT;
+                off = ((long)k - wpad) * ld + col;
+            }
+            if (ok) {
+                if (VEC) {
+                    v = *reinterpret_cast<const float4*>(base + off);
+                } else {
+                    v.x = base[off];
+                    if (col + 1 < cols) v.y = base[off + 1];
+                    if (col + 2 < cols) v.z = base[off + 2];
+                    if (col + 3 < cols) v.w = base[off + 3];
+                }
+            }
+            reg[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ s, int ldS) const {
+        const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<float4*>(s + (kr + i * KR) * ldS + c4 * 4) = reg[i];
+    }
+};
+
+template <int BM, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    // LDS tiles, k-major.  Row stride: +4 floats where the tile is filled with float4 stores (keeps
+    // them 16-byte aligned), +2 where it is filled by the transposing loader (4*stride == 8 mod 32
+    // banks -> its scattered ds_write_b32 are at most 2-way conflicted, which is free).
+    constexpr int LDA_S = TA ? BM + 4 : BM + 2, LDB_S = TB ? BN + 2 : BN + 4;
+    constexpr int A_FLOATS = (BK * LDA_S + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + BK * LDB_S];
+    float* As = smem;
+    float* Bs = smem + A_FLOATS;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int batch = blockIdx.z / g.split_k, split = blockIdx.z % g.split_k;
+    const float* A = g.A + (long)batch * g.stride_a;
+    const float* B = g.B + (long)batch * g.stride_b;
+    float* C = g.C + (long)batch * g.stride_c;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    using LA = typename std::conditional<TA, LoaderMC<BM, VEC>, LoaderKC<BM, VEC>>::type;
+    using LB = typename std::conditional<TB, LoaderKC<BN, VEC>, LoaderMC<BN, VEC>>::type;
+    LA la; LB lb;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave tiling: BM=128 -> 2x2 waves of 64x64 ; BM=32 -> 1x4 waves of 32x32
+    constexpr int WM = (BM == 128) ? 2 : 1;           // 32-row MFMA tiles per wave
+    constexpr int WN = (BM == 128) ? 2 : 1;
+    const int wm = (BM == 128) ? (wave >> 1) : 0;
+    const int wn = (BM == 128) ? (wave & 1) : wave;
+    const int wrow = wm * WM * 32, wcol = wn * WN * 32;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kbeg < kend) {
+        la.load(A, g.lda, m0, kbeg, g.M, kend, g.win_T, g.win_C, g.win_pad);
+        lb.load(B, g.ldb, n0, kbeg, g.N, kend, 0, 1, 0);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                       // previous tile fully consumed
+        la.store(As, LDA_S);
+        lb.store(Bs, LDB_S);
+        __syncthreads();
+        if (k0 + BK < kend) {                  // prefetch next tile while this one is multiplied
+            la.load(A, g.lda, m0, k0 + BK, g.M, kend, g.win_T, g.win_C, g.win_pad);
+            lb.load(B, g.ldb, n0, k0 + BK, g.N, kend, 0, 1, 0);
+        }
+        const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = As[(kk + kh) * LDA_S + wrow + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = Bs[(kk + kh) * LDB_S + wcol + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool first_split = (split == 0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wcol + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = (g.bias != nullptr && first_split) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = g.alpha * acc[i][j][r] + bv;
+                float* dst = C + (long)row * g.ldc + col;
+                if (g.split_k > 1) {
+                    atomicAdd(dst, v);
+                } else {
+                    v = apply_act(v, g.act);
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <int BM, bool TA, bool TB>
+static void launch_gemm(const GemmArgs& g, bool vec, dim3 grid, hipStream_t st) {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<BM, TA, TB, true>), grid, dim3(256), 0, st, g);
+    else     hipLaunchKernelGGL((gemm_kernel<BM, TA, TB, false>), grid, dim3(256), 0, st, g);
+}
+
+}  // namespace mstts
+
+using namespace mstts;
+
+extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
+    MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm: null descriptor");
+    MSTTS_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, MSTTS_ERR_SHAPE, "gemm: negative dims");
+    if (d->M == 0 || d->N == 0) return MSTTS_OK;
+    MSTTS_REQUIRE(d->A && d->B && d->C, MSTTS_ERR_SHAPE, "gemm: null operand");
+    MSTTS_REQUIRE(d->M < (1LL << 31) && d->N < (1LL << 31) && d->K < (1LL << 31), MSTTS_ERR_SHAPE, "gemm: dims exceed int32");
+    const int batch = d->batch > 0 ? (int)d->batch : 1;
+    int split = d->split_k > 1 ? d->split_k : 1;
+    MSTTS_REQUIRE(split == 1 || (d->act == MSTTS_ACT_NONE), MSTTS_ERR_SHAPE,
+                  "gemm: split_k needs act=none (output must be pre-zeroed or accumulated into)");
+    if (d->win_T > 0) {
+        MSTTS_REQUIRE(d->win_C > 0 && d->lda == d->win_C, MSTTS_ERR_SHAPE, "gemm: window mode needs lda == win_C");
+        MSTTS_REQUIRE(d->win_C % 4 == 0, MSTTS_ERR_SHAPE, "gemm: window mode needs win_C %% 4 == 0");
+    }
+    GemmArgs g;
+    g.A = d->A; g.B = d->B; g.C = d->C; g.bias = d->bias;
+    g.M = (int)d->M; g.N = (int)d->N; g.K = (int)d->K;
+    g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+    g.win_T = d->win_T; g.win_C = d->win_C > 0 ? d->win_C : 1; g.win_pad = d->win_pad;
+    g.act = d->act; g.accumulate = d->accumulate; g.split_k = split;
+    g.stride_a = d->stride_a; g.stride_b = d->stride_b; g.stride_c = d->stride_c;
+    g.alpha = d->alpha;
+    int kps = ((g.K + split - 1) / split + BK - 1) / BK * BK;
+    if (kps < BK) kps = BK;
+    g.k_per_split = kps;
+    // vector path: every float4 the loaders form must be 16-byte aligned and must not straddle
+    // a conv tap or the end of a row
+    bool vec = aligned16(d->A) && aligned16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) &&
+               (d->stride_a % 4 == 0) && (d->stride_b % 4 == 0);
+    vec = vec && (d->trans_a ? (d->M % 4 == 0) : (d->K % 4 == 0));
+    vec = vec && (d->trans_b ? (d->K % 4 == 0) : (d->N % 4 == 0));
+    if (d->win_T > 0) vec = vec && (d->win_C % 4 == 0);
+    const bool skinny = d->M <= 32;
+    const int bm = skinny ? 32 : 128;
+    dim3 grid(cdiv(d->M, bm) * cdiv(d->N, BN), 1, batch * split);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ta = d->trans_a != 0, tb = d->trans_b != 0;
+    if (skinny) {
+        if (!ta && !tb) launch_gemm<32, false, false>(g, vec, grid, st);
+        else if (!ta && tb) launch_gemm<32, false, true>(g, vec, grid, st);
+        else if (ta && !tb) launch_gemm<32, true, false>(g, vec, grid, st);
+        else launch_gemm<32, true, true>(g, vec, grid, st);
+    } else {
+        if (!ta && !tb) launch_gemm<128, false, false>(g, vec, grid, st);
+        else if (!ta && tb) launch_gemm<128, false, true>(g, vec, grid, st);
+        else if (ta && !tb) launch_gemm<128, true, false>(g, vec, grid, st);
+        else launch_gemm<128, true, true>(g, vec, grid, st);
+    }
+    MSTTS_CHECK_LAUNCH("gemm_f32");
+    return MSTTS_OK;
+}

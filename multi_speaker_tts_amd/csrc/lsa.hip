@@ -1,0 +1,450 @@
+// Location-sensitive attention step for gfx950 (Location_Sensitive_Attention.py:43-85, plus the
+// TF BahdanauAttention score mask / softmax and the AttentionWrapper context it inherits).
+//
+// The decoder calls this once per mel frame, strictly in sequence, so one step has to spread over
+// the whole chip to be fast.  Forward is two launches:
+//   lsa_energy : grid (B, T/16) - every workgroup owns 16 encoder positions of one row: location
+//                conv (31 taps -> 32 ch) in LDS, the 32->128 dense and tanh per (t,k) lane, wave64
+//                shuffle reduction over k.  Streams its 8 KB slice of keys once.
+//   lsa_context: grid (B, M/64) - softmax over the row's energies recomputed per workgroup (T
+//                floats), then a float4-coalesced stream over values[b,:,64-wide slice].
+// Backward mirrors it (dalign / denergy) and the parameter gradients are hoisted out of the time
+// loop into one batched recompute kernel (lsa_param_bwd) so the sequential path carries no
+// read-modify-write traffic.
+#include "common.h"
+
+namespace mstts {
+
+constexpr int TS = 16;      // encoder positions per workgroup
+constexpr int A_ = 128;     // attention units  (hp.Attention.Memory_Size)
+constexpr int CH_ = 32;     // location conv channels (hp.Attention.Conv.Channel)
+constexpr int KS_MAX = 63;  // location conv taps upper bound (reference: 31)
+
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh via one exp; relative error ~1e-6 over the energy pre-activation range
+    const float ax = fabsf(x);
+    const float e = __expf(-2.0f * ax);
+    return copysignf((1.0f - e) / (1.0f + e), x);
+}
+
+// stage cum[b, t0-pad .. t0+TS-1+(KS-1-pad)] (zero outside [0,T)) and the conv kernel into LDS,
+// then f[tt][c] = conv_b[c] + sum_j cum[t0+tt+j-pad] * conv_k[j*CH+c]
+__device__ __forceinline__ void location_features(const mstts_lsa_const& c, const float* __restrict__ cum_row, int t0,
+                                                  float* s_cum, float* s_ck, float (*s_f)[CH_ + 1]) {
+    const int KS = (int)c.KS, T = (int)c.T, pad = (KS - 1) / 2;
+    for (int i = threadIdx.x; i < TS + KS - 1; i += blockDim.x) {
+        const int t = t0 - pad + i;
+        s_cum[i] = (t >= 0 && t < T) ? cum_row[t] : 0.f;
+    }
+    for (int i = threadIdx.x; i < KS * CH_; i += blockDim.x) s_ck[i] = c.conv_k[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < TS * CH_; i += blockDim.x) {
+        const int tt = i / CH_, ch = i % CH_;
+        float acc = c.conv_b[ch];
+        for (int j = 0; j < KS; ++j) acc += s_cum[tt + j] * s_ck[j * CH_ + ch];
+        s_f[tt][ch] = acc;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: energies
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, const float* __restrict__ q,
+                                                         const float* __restrict__ cum, float* __restrict__ energy) {
+    __shared__ float s_cum[TS + KS_MAX - 1];
+    __shared__ float s_ck[KS_MAX * CH_];
+    __shared__ float s_f[TS][CH_ + 1];
+    __shared__ float s_red[TS][2];
+    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T;
+    location_features(c, cum + (long)b * T, t0, s_cum, s_ck, s_f);
+
+    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;        // 2 groups of 128 lanes
+    float dk[CH_];
+#pragma unroll
+    for (int ch = 0; ch < CH_; ++ch) dk[ch] = c.dense_k[ch * A_ + k];
+    const float qk = q[(long)b * A_ + k] + c.score_b[k];
+    const float wk = c.score_w[k];
+    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) {
+        const int tt = grp + 2 * i;
+        float e = 0.f;
+        if (t0 + tt < T) {
+            float pre = keys[(long)tt * A_] + qk;
+#pragma unroll
+            for (int ch = 0; ch < CH_; ++ch) pre += s_f[tt][ch] * dk[ch];
+            e = wk * fast_tanh(pre);
+        }
+        e = wave_sum(e);
+        if ((threadIdx.x & 63) == 0) s_red[tt][(threadIdx.x >> 6) & 1] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < TS && t0 + threadIdx.x < T)
+        energy[(long)b * T + t0 + threadIdx.x] = s_red[threadIdx.x][0] + s_red[threadIdx.x][1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: softmax + cumulative alignment + context
+// ---------------------------------------------------------------------------------------------
+constexpr int DS = 64;          // memory columns per workgroup
+constexpr int T_MAX = 1024;
+
+__global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, const float* __restrict__ energy,
+                                                          const float* __restrict__ cum, float* __restrict__ align,
+                                                          float* __restrict__ cum_next, float* __restrict__ ctx, long ctx_ld,
+                                                          float* __restrict__ ctx2, long ctx2_ld) {
+    __shared__ float s_a[T_MAX];
+    __shared__ float scratch[16];
+    __shared__ __attribute__((aligned(16))) float s_part[16][DS];
+    const int b = blockIdx.x, d0 = blockIdx.y * DS, T = (int)c.T, M = (int)c.M;
+    const int len = c.lengths ? c.lengths[b] : T;
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float e = (t < len) ? energy[(long)b * T + t] : -INFINITY;
+        s_a[t] = e;
+        mx = fmaxf(mx, e);
+    }
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float p = (t < len) ? __expf(s_a[t] - mx) : 0.f;
+        s_a[t] = p;
+        sum += p;
+    }
+    sum = block_sum(sum, scratch);
+    const float inv = 1.f / sum;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float a = s_a[t] * inv;
+        s_a[t] = a;
+        if (blockIdx.y == 0) {
+            align[(long)b * T + t] = a;
+            cum_next[(long)b * T + t] = cum[(long)b * T + t] + a;
+        }
+    }
+    __syncthreads();
+    // context slice: 16 lanes x float4 cover 64 columns; 16 row groups stride over t
+    const int c4 = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int col = d0 + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < M) {
+        const float* v = c.values + (long)b * T * M + col;
+        for (int t = tg; t < len; t += 16) {
+            const float a = s_a[t];
+            const float4 x = *reinterpret_cast<const float4*>(v + (long)t * M);
+            acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w;
+        }
+    }
+    *reinterpret_cast<float4*>(&s_part[tg][c4 * 4]) = acc;
+    __syncthreads();
+    if (threadIdx.x < DS && d0 + threadIdx.x < M) {
+        float r = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) r += s_part[g][threadIdx.x];
+        ctx[(long)b * ctx_ld + d0 + threadIdx.x] = r;
+        if (ctx2) ctx2[(long)b * ctx2_ld + d0 + threadIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: d_align  (G = dL/d cum_{s+1})
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, const float* __restrict__ d_ctx, long d_ctx_ld,
+                                                         const float* __restrict__ d_ctx2, long d_ctx2_ld,
+                                                         const float* __restrict__ G_next, const float* __restrict__ d_f_next,
+                                                         float* __restrict__ G, float* __restrict__ d_align) {
+    __shared__ float s_df[TS + KS_MAX - 1][CH_ + 1];
+    __shared__ float s_ck[KS_MAX * CH_];
+    __shared__ float s_g[TS];
+    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
+    // conv-transpose part: G[t] = G_next[t] + sum_{j,ch} d_f_next[t + pad - j][ch] * conv_k[j][ch]
+    // rows staged: tau = t0 + pad - (KS-1) + i, i in [0, TS+KS-1)
+    if (d_f_next) {
+        const int base = t0 + pad - (KS - 1);
+        for (int i = threadIdx.x; i < (TS + KS - 1) * CH_; i += blockDim.x) {
+            const int r = i / CH_, ch = i % CH_, tau = base + r;
+            s_df[r][ch] = (tau >= 0 && tau < T) ? d_f_next[((long)b * T + tau) * CH_ + ch] : 0.f;
+        }
+        for (int i = threadIdx.x; i < KS * CH_; i += blockDim.x) s_ck[i] = c.conv_k[i];
+        __syncthreads();
+        const int tt = threadIdx.x >> 4, part = threadIdx.x & 15;
+        float acc = 0.f;
+        for (int p = part; p < KS * CH_; p += 16) {
+            const int j = p / CH_, ch = p % CH_;
+            acc += s_df[tt + (KS - 1) - j][ch] * s_ck[p];          // row index of tau = t + pad - j
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (part == 0) s_g[tt] = acc;
+    } else {
+        if (threadIdx.x < TS) s_g[threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    // values . d_ctx for the 16 rows: wave w takes rows w, w+4, ...
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int len = c.lengths ? c.lengths[b] : T;
+    for (int tt = w; tt < TS; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= T) continue;
+        float acc = 0.f;
+        if (t < len) {
+            const float* v = c.values + ((long)b * T + t) * M;
+            const float* dc = d_ctx + (long)b * d_ctx_ld;
+            const float* dc2 = d_ctx2 ? d_ctx2 + (long)b * d_ctx2_ld : nullptr;
+            for (int i = lane * 4; i < M; i += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(v + i);
+                float4 y = *reinterpret_cast<const float4*>(dc + i);
+                if (dc2) {
+                    const float4 y2 = *reinterpret_cast<const float4*>(dc2 + i);
+                    y.x += y2.x; y.y += y2.y; y.z += y2.z; y.w += y2.w;
+                }
+                acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float g = s_g[tt] + (G_next ? G_next[(long)b * T + t] : 0.f);
+            G[(long)b * T + t] = g;
+            d_align[(long)b * T + t] = g + acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: d_energy, d_query, d_location_features
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, const float* __restrict__ align,
+                                                          const float* __restrict__ d_align, const float* __restrict__ q,
+                                                          const float* __restrict__ cum, float* __restrict__ d_e_out,
+                                                          float* __restrict__ dq, float* __restrict__ d_f) {
+    __shared__ float s_cum[TS + KS_MAX - 1];
+    __shared__ float s_ck[KS_MAX * CH_];
+    __shared__ float s_f[TS][CH_ + 1];
+    __shared__ float s_g[TS][A_];
+    __shared__ float s_dkT[A_][CH_ + 1];
+    __shared__ float s_de[TS];
+    __shared__ float s_dq[A_];
+    __shared__ float scratch[16];
+    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T;
+    // softmax backward needs the whole row's dot(a, d_a)
+    float dot = 0.f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) dot += align[(long)b * T + t] * d_align[(long)b * T + t];
+    dot = block_sum(dot, scratch);
+    if (threadIdx.x < TS) {
+        const int t = t0 + threadIdx.x;
+        float de = 0.f;
+        if (t < T) {
+            de = align[(long)b * T + t] * (d_align[(long)b * T + t] - dot);
+            d_e_out[(long)b * T + t] = de;
+        }
+        s_de[threadIdx.x] = de;
+    }
+    for (int i = threadIdx.x; i < A_ * CH_; i += blockDim.x) {
+        const int ch = i / A_, k = i % A_;
+        s_dkT[k][ch] = c.dense_k[i];
+    }
+    if (threadIdx.x < A_) s_dq[threadIdx.x] = 0.f;
+    location_features(c, cum + (long)b * T, t0, s_cum, s_ck, s_f);     // ends with __syncthreads()
+
+    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
+    const float qk = q[(long)b * A_ + k] + c.score_b[k];
+    const float wk = c.score_w[k];
+    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+    float dq_acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) {
+        const int tt = grp + 2 * i;
+        float g = 0.f;
+        if (t0 + tt < T) {
+            float pre = keys[(long)tt * A_] + qk;
+#pragma unroll
+            for (int ch = 0; ch < CH_; ++ch) pre += s_f[tt][ch] * s_dkT[k][ch];
+            const float u = fast_tanh(pre);
+            g = s_de[tt] * wk * (1.f - u * u);
+        }
+        s_g[tt][k] = g;
+        dq_acc += g;
+    }
+    if (grp == 1) s_dq[k] = dq_acc;
+    __syncthreads();
+    if (grp == 0) atomicAdd(dq + (long)b * A_ + k, dq_acc + s_dq[k]);
+    // d_f[tt][ch] = sum_k g[tt][k] * dense_k[ch][k]
+    for (int i = threadIdx.x; i < TS * CH_; i += blockDim.x) {
+        const int tt = i / CH_, ch = i % CH_;
+        if (t0 + tt >= T) continue;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int kk = 0; kk < A_; ++kk) acc += s_g[tt][kk] * s_dkT[kk][ch];
+        d_f[((long)b * T + t0 + tt) * CH_ + ch] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// post-loop parameter gradients (recompute per step from saved d_e, q, cum)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, int S, int steps_per_block,
+                                                            const float* __restrict__ q_hist, const float* __restrict__ cum_hist,
+                                                            const float* __restrict__ de_hist, float* __restrict__ d_keys,
+                                                            float* __restrict__ d_conv_k, float* __restrict__ d_conv_b,
+                                                            float* __restrict__ d_dense_k, float* __restrict__ d_score_w,
+                                                            float* __restrict__ d_score_b) {
+    __shared__ float s_cum[TS + KS_MAX - 1];
+    __shared__ float s_ck[KS_MAX * CH_];
+    __shared__ float s_f[TS][CH_ + 1];
+    __shared__ float s_g[TS][A_];
+    __shared__ float s_dkT[A_][CH_ + 1];
+    __shared__ float s_df[TS][CH_ + 1];
+    __shared__ float s_de[TS];
+    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, B = (int)c.B, KS = (int)c.KS;
+    const int s_beg = blockIdx.z * steps_per_block, s_end = min(S, s_beg + steps_per_block);
+    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
+    for (int i = threadIdx.x; i < A_ * CH_; i += blockDim.x) s_dkT[i % A_][i / A_] = c.dense_k[i];
+    const float sb = c.score_b[k], wk = c.score_w[k];
+    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+    float key_v[TS / 2];
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) key_v[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
+    float acc_keys[TS / 2], acc_dk[CH_], acc_w = 0.f, acc_b = 0.f;
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) acc_keys[i] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < CH_; ++ch) acc_dk[ch] = 0.f;
+    // conv kernel gradient: pairs p = threadIdx.x + 256*r (r<4) over KS*CH_ entries
+    float acc_ck[(KS_MAX * CH_ + 255) / 256];
+#pragma unroll
+    for (int r = 0; r < (KS_MAX * CH_ + 255) / 256; ++r) acc_ck[r] = 0.f;
+    float acc_cb = 0.f;   // thread (< CH_) accumulates conv bias grad for channel threadIdx.x
+
+    for (int s = s_beg; s < s_end; ++s) {
+        __syncthreads();
+        if (threadIdx.x < TS) {
+            const int t = t0 + threadIdx.x;
+            s_de[threadIdx.x] = (t < T) ? de_hist[((long)s * B + b) * T + t] : 0.f;
+        }
+        location_features(c, cum_hist + ((long)s * B + b) * T, t0, s_cum, s_ck, s_f);
+        const float qk = q_hist[((long)s * B + b) * A_ + k] + sb;
+#pragma unroll
+        for (int i = 0; i < TS / 2; ++i) {
+            const int tt = grp + 2 * i;
+            float g = 0.f;
+            if (t0 + tt < T) {
+                float pre = key_v[i] + qk;
+#pragma unroll
+                for (int ch = 0; ch < CH_; ++ch) pre += s_f[tt][ch] * s_dkT[k][ch];
+                const float u = fast_tanh(pre);
+                const float de = s_de[tt];
+                g = de * wk * (1.f - u * u);
+                acc_w += de * u;
+                acc_b += g;
+                acc_keys[i] += g;
+#pragma unroll
+                for (int ch = 0; ch < CH_; ++ch) acc_dk[ch] += s_f[tt][ch] * g;
+            }
+            s_g[tt][k] = g;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TS * CH_; i += blockDim.x) {
+            const int tt = i / CH_, ch = i % CH_;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int kk = 0; kk < A_; ++kk) acc += s_g[tt][kk] * s_dkT[kk][ch];
+            s_df[tt][ch] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < CH_) {
+            float a = 0.f;
+            for (int tt = 0; tt < TS; ++tt) a += s_df[tt][threadIdx.x];
+            acc_cb += a;
+        }
+#pragma unroll
+        for (int r = 0; r < (KS_MAX * CH_ + 255) / 256; ++r) {
+            const int p = threadIdx.x + 256 * r;
+            if (p < KS * CH_) {
+                const int j = p / CH_, ch = p % CH_;
+                float a = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < TS; ++tt) a += s_cum[tt + j] * s_df[tt][ch];
+                acc_ck[r] += a;
+            }
+        }
+    }
+    // flush
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) {
+        const int tt = grp + 2 * i;
+        if (t0 + tt < T) atomicAdd(d_keys + ((long)b * T + t0 + tt) * A_ + k, acc_keys[i]);
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH_; ++ch) atomicAdd(d_dense_k + ch * A_ + k, acc_dk[ch]);
+    atomicAdd(d_score_w + k, acc_w);
+    atomicAdd(d_score_b + k, acc_b);
+    if (threadIdx.x < CH_) atomicAdd(d_conv_b + threadIdx.x, acc_cb);
+#pragma unroll
+    for (int r = 0; r < (KS_MAX * CH_ + 255) / 256; ++r) {
+        const int p = threadIdx.x + 256 * r;
+        if (p < KS * CH_) atomicAdd(d_conv_k + p, acc_ck[r]);
+    }
+}
+
+static int check_const(const mstts_lsa_const* c) {
+    MSTTS_REQUIRE(c != nullptr, MSTTS_ERR_SHAPE, "lsa: null const block");
+    MSTTS_REQUIRE(c->A == A_ && c->CH == CH_, MSTTS_ERR_SHAPE, "lsa: built for A=%d CH=%d, got A=%ld CH=%ld", A_, CH_, (long)c->A, (long)c->CH);
+    MSTTS_REQUIRE(c->KS >= 1 && c->KS <= KS_MAX && (c->KS & 1), MSTTS_ERR_SHAPE, "lsa: conv taps must be odd and <= %d", KS_MAX);
+    MSTTS_REQUIRE(c->T >= 1 && c->T <= T_MAX, MSTTS_ERR_SHAPE, "lsa: T must be in [1,%d]", T_MAX);
+    MSTTS_REQUIRE(c->M % 4 == 0 && aligned16(c->values), MSTTS_ERR_ALIGN, "lsa: memory width %% 4 and 16-byte aligned values required");
+    MSTTS_REQUIRE(c->B >= 1, MSTTS_ERR_SHAPE, "lsa: B must be >= 1");
+    return MSTTS_OK;
+}
+
+}  // namespace mstts
+
+using namespace mstts;
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, const float* cum, float* energy, mstts_stream_t s) {
+    int rc = check_const(c); if (rc) return rc;
+    hipLaunchKernelGGL(lsa_energy_kernel, dim3((unsigned)c->B, cdiv(c->T, TS)), dim3(256), 0, ST(s), *c, q, cum, energy);
+    MSTTS_CHECK_LAUNCH("lsa_energy_fwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* energy, const float* cum, float* align, float* cum_next,
+                                     float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, mstts_stream_t s) {
+    int rc = check_const(c); if (rc) return rc;
+    hipLaunchKernelGGL(lsa_context_kernel, dim3((unsigned)c->B, cdiv(c->M, DS)), dim3(256), 0, ST(s), *c, energy, cum, align, cum_next,
+                       ctx, (long)ctx_ld, ctx2, (long)ctx2_ld);
+    MSTTS_CHECK_LAUNCH("lsa_context_fwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
+                                    const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s) {
+    int rc = check_const(c); if (rc) return rc;
+    MSTTS_REQUIRE(aligned16(d_ctx) && aligned16(d_ctx2) && d_ctx_ld % 4 == 0 && d_ctx2_ld % 4 == 0, MSTTS_ERR_ALIGN,
+                  "lsa_dalign: d_ctx rows must be 16-byte aligned");
+    hipLaunchKernelGGL(lsa_dalign_kernel, dim3((unsigned)c->B, cdiv(c->T, TS)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
+                       (long)d_ctx2_ld, G_next, d_f_next, G, d_align);
+    MSTTS_CHECK_LAUNCH("lsa_dalign_bwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* align, const float* d_align, const float* q, const float* cum,
+                                     float* d_e, float* dq, float* d_f, mstts_stream_t s) {
+    int rc = check_const(c); if (rc) return rc;
+    hipLaunchKernelGGL(lsa_denergy_kernel, dim3((unsigned)c->B, cdiv(c->T, TS)), dim3(256), 0, ST(s), *c, align, d_align, q, cum, d_e, dq, d_f);
+    MSTTS_CHECK_LAUNCH("lsa_denergy_bwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
+                                   float* d_keys, float* d_conv_k, float* d_conv_b, float* d_dense_k, float* d_score_w, float* d_score_b,
+                                   mstts_stream_t s) {
+    int rc = check_const(c); if (rc) return rc;
+    if (S <= 0) return MSTTS_OK;
+    const int nt = cdiv(c->T, TS);
+    int chunks = (int)(1024 / (c->B * nt));
+    if (chunks < 1) chunks = 1;
+    if (chunks > S) chunks = (int)S;
+    const int spb = cdiv(S, chunks);
+    chunks = cdiv(S, spb);
+    hipLaunchKernelGGL(lsa_param_bwd_kernel, dim3((unsigned)c->B, nt, chunks), dim3(256), 0, ST(s), *c, (int)S, spb, q_hist, cum_hist,
+                       de_hist, d_keys, d_conv_k, d_conv_b, d_dense_k, d_score_w, d_score_b);
+    MSTTS_CHECK_LAUNCH("lsa_param_bwd");
+    return MSTTS_OK;
+}

@@ -1,0 +1,484 @@
+"""Train-step engine: one Tacotron2.Train iteration (MSTTS_SV.py:268-273) as an explicit
+forward / backward / TF-Adam schedule of libmstts_hip.so calls on one HIP stream.
+
+There is no autograd and no torch compute here: torch tensors are only device buffers.  The
+schedule follows the reference graph (Tensor_Generate, MSTTS_SV.py:45-192):
+  encoder (embedding -> 3x conv/relu/BN/dropout -> BiLSTM) -> memory/keys -> hoisted prenet ->
+  801-step attention decoder loop (native driver) -> projection -> postnet -> losses,
+then the exact reverse with hand-written gradients; weight gradients of the recurrent parts are
+hoisted out of the time loops into large MFMA GEMMs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+from .lib import ACT_NONE, ACT_RELU, ACT_TANH, gemm, ptr, call
+from .masks import MaskSet, step_seed
+from .params import CELL, ENC_CELL, LSA, VOC, Dims, ParamStore, bank_suffix
+
+BN_MOM, BN_EPS = 0.99, 1e-3
+
+
+def learning_rate(step):
+    """MSTTS_SV.py:163-169."""
+    from . import Hyper_Parameters as hp
+    lr_hp = hp.Train.Learning_Rate
+    lr = lr_hp.Initial * lr_hp.Decay_Rate ** ((step - lr_hp.Decay_Start_Step) / lr_hp.Decay_Step)
+    return min(max(lr, lr_hp.Min), lr_hp.Initial)
+
+
+def _split_k(M, N, K):
+    tiles = math.ceil(M / 128) * math.ceil(N / 128)
+    sk = max(1, min(math.ceil(512 / tiles), K // 512))
+    return sk
+
+
+class _WS:
+    """Attribute bag of device buffers for one (B, T_enc, L) shape."""
+
+
+class TrainEngine:
+    def __init__(self, dims: Dims = None, device="cuda", seed=1234, rank=0, world=1, values=None,
+                 update_vocoder_bn=True, use_l1=True, wr_rate=1e-6, adam=(0.9, 0.999, 1e-6)):
+        lib.load()
+        self.d = dims or Dims()
+        self.device = torch.device(device)
+        self.seed, self.rank, self.world = seed, rank, world
+        self.update_vocoder_bn = update_vocoder_bn
+        self.use_l1, self.wr_rate, self.adam = use_l1, wr_rate, adam
+        self.params = ParamStore(self.d, self.device, seed=seed, values=values)
+        self._plans = {}
+        self.global_step = 0
+        d = self.d
+        # packed / derived weights refreshed after every optimizer step
+        H, M = d.dec_lstm, d.mem
+        self.w0f = self._f(M + H, 4 * H)
+        self.proj_ld = (d.n_mel + 1 + 3) // 4 * 4
+        self.wp_pad = self._f(H + M, self.proj_ld)
+        self.bp_pad = self._f(self.proj_ld)
+        self.dwp_pad = self._f(H + M, self.proj_ld)
+        self.dw0f = self._f(M + H, 4 * H)
+        self.flip = {}
+        self._derived_stale = True
+
+    # ------------------------------------------------------------------ helpers
+    def _f(self, *shape):
+        n = int(np.prod(shape))
+        return torch.zeros((n + 3) // 4 * 4, dtype=torch.float32, device=self.device)[:n].view(shape)
+
+    def P(self, name):
+        return self.params.p(name)
+
+    def G(self, name):
+        return self.params.g(name)
+
+    def refresh_derived(self):
+        """Folded cell-0 kernel (context rows appear twice) and the 4-column padded
+        projection kernel.  Must run after the variables change."""
+        d, ps = self.d, self.params
+        H, M, Pn = d.dec_lstm, d.mem, d.prenet
+        k0, o0 = self.P(CELL % 0 + "kernel")
+        call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(self.w0f), 2 * M + H, 4 * H, 0, M)
+        wp, owp = self.P("decoder/decoder/linear_projection/dense/kernel")
+        bp, obp = self.P("decoder/decoder/linear_projection/dense/bias")
+        nm1 = d.n_mel + 1
+        self.wp_pad.zero_()
+        self.bp_pad.zero_()
+        call("mstts_copy2d", ptr(wp, owp), nm1, ptr(self.wp_pad), self.proj_ld, H + M, nm1, 0)
+        call("mstts_copy2d", ptr(bp, obp), nm1, ptr(self.bp_pad), self.proj_ld, 1, nm1, 0)
+        self._derived_stale = False
+
+    def plan(self, B, Te, L):
+        key = (B, Te, L)
+        if key in self._plans:
+            return self._plans[key]
+        d, f = self.d, self._f
+        w = _WS()
+        S = L + 1
+        w.B, w.Te, w.L, w.S = B, Te, L, S
+        H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
+        w.masks = MaskSet(d, B, Te, S, True, self.device, rank=self.rank)
+        # encoder
+        w.emb = f(B * Te, d.emb)
+        w.enc_a = [f(B * Te, d.enc_conv_ch) for _ in range(d.enc_conv_n)]
+        w.enc_y = [f(B * Te, d.enc_conv_ch) for _ in range(d.enc_conv_n)]
+        w.enc_mean = [f(d.enc_conv_ch) for _ in range(d.enc_conv_n)]
+        w.enc_rstd = [f(d.enc_conv_ch) for _ in range(d.enc_conv_n)]
+        w.enc_xw = {dr: f(B * Te, 4 * He) for dr in ("fw", "bw")}
+        w.enc_c = {dr: f(Te + 1, B, He) for dr in ("fw", "bw")}
+        w.enc_h = {dr: f(Te + 1, B, He) for dr in ("fw", "bw")}
+        w.enc_acts = {dr: f(Te, B, 4 * He) for dr in ("fw", "bw")}
+        w.enc_craw = {dr: f(Te, B, He) for dr in ("fw", "bw")}
+        w.enc_gates = f(B, 4 * He)
+        w.values = f(B, Te, M)
+        w.keys = f(B, Te, A)
+        # decoder
+        w.frames = f(S, B, d.n_mel)
+        w.pre_a = [f(S * B, Pn) for _ in range(d.prenet_n)]      # relu outputs
+        w.pre_d = [f(S * B, Pn) for _ in range(d.prenet_n)]      # after dropout
+        w.xw0 = f(S, B, 4 * H)
+        w.in0, w.in1, w.pj = f(S + 1, B, M + H), f(S + 1, B, 2 * H), f(S, B, H + M)
+        w.c0, w.c1 = f(S + 1, B, H), f(S + 1, B, H)
+        w.acts0, w.acts1 = f(S, B, 4 * H), f(S, B, 4 * H)
+        w.craw0, w.craw1 = f(S, B, H), f(S, B, H)
+        w.q_hist, w.align_hist, w.cum_hist = f(S, B, A), f(S, B, Te), f(S + 1, B, Te)
+        w.gates_ws, w.energy_ws = f(B, 4 * H), f(B, Te)
+        w.proj = f(S, B, self.proj_ld)
+        w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
+        # postnet
+        chans = [d.post_ch] * (d.post_n - 1) + [d.n_mel]
+        w.post_a = [f(B * S, c) for c in chans]
+        w.post_y = [f(B * S, c) for c in chans]
+        w.post_mean = [f(c) for c in chans]
+        w.post_rstd = [f(c) for c in chans]
+        w.mel_out = f(B, S, d.n_mel)
+        w.bn_ws = f(2 * max(d.post_ch, d.enc_conv_ch, d.bank_k * d.bank_ch, d.proj1_ch))
+        # vocoder conv-bank (BN update side effect)
+        if self.update_vocoder_bn:
+            w.v_tmp = f(B * S, d.bank_ch)
+            w.v_tmp2 = f(B * S, d.bank_ch)
+            w.v_cat = f(B * S, d.bank_k * d.bank_ch)
+            w.v_pool = f(B * S, d.bank_k * d.bank_ch)
+            w.v_p1 = f(B * S, d.proj1_ch)
+            w.v_p1y = f(B * S, d.proj1_ch)
+            w.v_p2 = f(B * S, d.n_mel)
+            w.v_p2y = f(B * S, d.n_mel)
+            w.v_stat = f(2 * max(d.bank_ch, d.proj1_ch, d.n_mel))
+        # losses
+        w.scalars = f(4)
+        w.d_linear, w.d_post, w.d_stop = f(B, S, d.n_mel), f(B, S, d.n_mel), f(B, S)
+        # backward
+        w.post_dz = [f(B * S, c) for c in chans]
+        w.post_dx = f(B * S, d.post_ch)
+        w.post_dx2 = f(B * S, d.post_ch)
+        w.d_proj = f(S, B, self.proj_ld)
+        w.d_pj = f(S, B, H + M)
+        w.dg0, w.dg1 = f(S, B, 4 * H), f(S, B, 4 * H)
+        w.dq_hist, w.de_hist = f(S, B, A), f(S, B, Te)
+        w.d_in0 = f(S, B, M + H)
+        lb = lib.load()
+        w.dec_bwd_ws = f(int(lb.mstts_decoder_train_bwd_ws_floats(B, H, Te, d.att_ch)))
+        w.d_pre = f(S * B, Pn)
+        w.d_pre2 = f(S * B, Pn)
+        w.d_keys = f(B, Te, A)
+        w.d_values = f(B, Te, M)
+        w.enc_dgs = {dr: f(Te, B, 4 * He) for dr in ("fw", "bw")}
+        w.enc_dgp = {dr: f(B, Te, 4 * He) for dr in ("fw", "bw")}
+        w.enc_bwd_ws = f(4 * B * He)
+        w.enc_dy = f(B * Te, d.enc_conv_ch)
+        w.enc_dz = f(B * Te, d.enc_conv_ch)
+        w.enc_dx = f(B * Te, d.enc_conv_ch)
+        # descriptors with stable addresses
+        w.dec = lib.DecoderTrain()
+        w.dec_b = lib.DecoderTrainBwd()
+        self._plans[key] = w
+        return w
+
+    # ------------------------------------------------------------------ conv blocks
+    def _conv_fwd(self, x, x_off, rows, T, cin, cout, K, kname, bname, out, act):
+        k, ok = self.P(kname)
+        b, ob = self.P(bname)
+        gemm(x, k, out, rows, cout, K * cin, cin, cout, cout, bias=b, act=act, win=(T, cin, (K - 1) // 2),
+             a_off=x_off, b_off=ok, bias_off=ob)
+
+    def _bn_fwd(self, prefix, a, y, mean, rstd, mask, keep, rows, C, ws):
+        g, og = self.P(prefix + "gamma"); b, ob = self.P(prefix + "beta")
+        mm, omm = self.P(prefix + "moving_mean"); mv, omv = self.P(prefix + "moving_variance")
+        call("mstts_bn_train_fwd", ptr(a), ptr(g, og), ptr(b, ob), ptr(mm, omm), ptr(mv, omv), ptr(y), ptr(mean), ptr(rstd),
+             ptr(mask), float(keep), BN_MOM, BN_EPS, rows, C, ptr(ws))
+
+    def _conv_block_bwd(self, dy, x_in, a, mean, rstd, mask, keep, act, prefix, rows, T, cin, cout, K, dz, dx):
+        """BN(+dropout)+activation+conv backward.  dy: grad of the block output; returns nothing;
+        dx (or None) receives the input gradient; parameter grads accumulate into the grad slab."""
+        g, og = self.P(prefix + "batch_normalization/gamma")
+        gg, ogg = self.G(prefix + "batch_normalization/gamma")
+        gb, ogb = self.G(prefix + "batch_normalization/beta")
+        gbias, ogbias = self.G(prefix + "conv1d/bias")
+        call("mstts_bn_train_bwd", ptr(dy), ptr(a), ptr(g, og), ptr(mean), ptr(rstd), ptr(mask), float(keep), act, ptr(dz),
+             ptr(gg, ogg), ptr(gb, ogb), ptr(gbias, ogbias), rows, cout, ptr(self._bnws))
+        gk, ogk = self.G(prefix + "conv1d/kernel")
+        pad = (K - 1) // 2
+        gemm(x_in, dz, gk, K * cin, cout, rows, cin, cout, cout, trans_a=True, win=(T, cin, pad),
+             split_k=max(2, _split_k(K * cin, cout, rows)), c_off=ogk)
+        if dx is not None:
+            k, ok = self.P(prefix + "conv1d/kernel")
+            key = (prefix, K, cin, cout)
+            if key not in self.flip:
+                self.flip[key] = self._f(K, cout, cin)
+            wt = self.flip[key]
+            call("mstts_conv_kernel_flip", ptr(k, ok), ptr(wt), K, cin, cout)
+            gemm(dz, wt, dx, rows, cin, K * cout, cout, cin, cin, win=(T, cout, K - 1 - pad))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch, w, seed=None, masks=None):
+        d, ps = self.d, self.params
+        B, Te, L, S = w.B, w.Te, w.L, w.S
+        H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
+        if self._derived_stale:
+            self.refresh_derived()
+        if masks is not None:
+            w.masks.load(masks)
+        else:
+            w.masks.draw(seed if seed is not None else step_seed(self.seed, self.global_step))
+        mk = w.masks
+        self._bnws = w.bn_ws
+        tok, tlen = batch["Token"], batch["Token_Length"]
+        mel, mlen, spk = batch["Mel"], batch["Mel_Length"], batch["Speaker_Embedding"]
+        w.batch = batch
+        # ---- encoder (Modules.py:15-73)
+        emb, oe = self.P("encoder/embedding_variable")
+        call("mstts_embedding_fwd", ptr(tok), ptr(emb, oe), ptr(w.emb), B * Te, d.n_tok, d.emb)
+        x, cin = w.emb, d.emb
+        for i in range(d.enc_conv_n):
+            pre = "encoder/conv_%d/" % i
+            self._conv_fwd(x, 0, B * Te, Te, cin, d.enc_conv_ch, d.enc_conv_k, pre + "conv1d/kernel", pre + "conv1d/bias", w.enc_a[i], ACT_RELU)
+            self._bn_fwd(pre + "batch_normalization/", w.enc_a[i], w.enc_y[i], w.enc_mean[i], w.enc_rstd[i],
+                         mk["enc_conv_drop_%d" % i], 1 - d.conv_drop, B * Te, d.enc_conv_ch, w.bn_ws)
+            x, cin = w.enc_y[i], d.enc_conv_ch
+        for di, dr in enumerate(("fw", "bw")):
+            k, ok = self.P(ENC_CELL % dr + "kernel"); b, ob = self.P(ENC_CELL % dr + "bias")
+            gemm(x, k, w.enc_xw[dr], B * Te, 4 * He, cin, cin, 4 * He, 4 * He, bias=b, b_off=ok, bias_off=ob)
+            q = lib.LstmSeqFwd()
+            q.B, q.T, q.H = B, Te, He
+            q.xw = ptr(w.enc_xw[dr]); q.wh = ptr(k, ok + cin * 4 * He); q.wh_ld = 4 * He
+            q.lengths = ptr(tlen); q.reverse = di; q.zoneout = d.zoneout
+            q.zc = ptr(mk["enc_zc_" + dr]); q.zh = ptr(mk["enc_zh_" + dr])
+            q.out = ptr(w.values, di * He); q.out_sb = Te * M; q.out_st = M
+            q.c_hist = ptr(w.enc_c[dr]); q.h_hist = ptr(w.enc_h[dr]); q.acts = ptr(w.enc_acts[dr]); q.c_raw = ptr(w.enc_craw[dr])
+            q.gates_ws = ptr(w.enc_gates)
+            call("mstts_lstm_seq_fwd", C.byref(q))
+        # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
+        call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
+        wm, owm = self.P("attention/memory_layer/kernel")
+        gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)
+        # ---- hoisted prenet over all S frames (Modules.py:239-255) and cell-0 input product
+        call("mstts_shift_frames", ptr(mel), ptr(w.frames), B, L, d.n_mel)
+        x, cin = w.frames, d.n_mel
+        for i in range(d.prenet_n):
+            k, ok = self.P("decoder/decoder/prenet_%d/dense/kernel" % i); b, ob = self.P("decoder/decoder/prenet_%d/dense/bias" % i)
+            gemm(x, k, w.pre_a[i], S * B, Pn, cin, cin, Pn, Pn, bias=b, act=ACT_RELU, b_off=ok, bias_off=ob)
+            call("mstts_dropout", ptr(w.pre_a[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(w.pre_d[i]), S * B * Pn)
+            x, cin = w.pre_d[i], Pn
+        k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
+        gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
+        # ---- decoder loop
+        dec = w.dec
+        dec.B, dec.S, dec.H, dec.P = B, S, H, Pn
+        ls = dec.lsa
+        ls.B, ls.T, ls.A, ls.M, ls.KS, ls.CH = B, Te, A, M, d.att_k, d.att_ch
+        ls.keys, ls.values, ls.lengths = ptr(w.keys), ptr(w.values), ptr(tlen)
+        for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
+                            ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
+            t, o = self.P(LSA + name)
+            setattr(ls, field, ptr(t, o))
+        k1, o1 = self.P(CELL % 1 + "kernel"); b1, ob1 = self.P(CELL % 1 + "bias"); wq, oq = self.P(LSA + "query_layer/kernel")
+        dec.xw0, dec.w0f, dec.w1, dec.b1, dec.wq = ptr(w.xw0), ptr(self.w0f), ptr(k1, o1), ptr(b1, ob1), ptr(wq, oq)
+        dec.zc0, dec.zh0, dec.zc1, dec.zh1 = ptr(mk["dec_zc_0"]), ptr(mk["dec_zh_0"]), ptr(mk["dec_zc_1"]), ptr(mk["dec_zh_1"])
+        dec.zoneout = d.zoneout
+        for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws"):
+            setattr(dec, nm, ptr(getattr(w, nm)))
+        call("mstts_decoder_train_fwd", C.byref(dec))
+        # ---- projection (Modules.py:309-321) on all steps at once, then batch-major linear/stop
+        gemm(w.pj, self.wp_pad, w.proj, S * B, self.proj_ld, H + M, H + M, self.proj_ld, self.proj_ld, bias=self.bp_pad)
+        call("mstts_unpack_proj", ptr(w.proj), self.proj_ld, ptr(w.linear), ptr(w.stop), B, S, d.n_mel)
+        # ---- postnet (Modules.py:121-143) + residual
+        x, cin = w.linear, d.n_mel
+        for i in range(d.post_n):
+            pre = "decoder/conv_%d/" % i
+            cout = d.post_ch if i < d.post_n - 1 else d.n_mel
+            self._conv_fwd(x, 0, B * S, S, cin, cout, d.post_k, pre + "conv1d/kernel", pre + "conv1d/bias", w.post_a[i], ACT_TANH)
+            self._bn_fwd(pre + "batch_normalization/", w.post_a[i], w.post_y[i], w.post_mean[i], w.post_rstd[i],
+                         mk["post_drop_%d" % i], 1 - d.conv_drop, B * S, cout, w.bn_ws)
+            x, cin = w.post_y[i], cout
+        call("mstts_add", ptr(w.linear), ptr(x), ptr(w.mel_out), B * S * d.n_mel)
+        if self.update_vocoder_bn:
+            self._vocoder_bn_update(w)
+        return w
+
+    def _vocoder_bn_update(self, w):
+        """Quirk Q20: the train op also runs the vocoder conv-bank's BN update ops on the predicted mel."""
+        d = self.d
+        B, S = w.B, w.S
+        rows = B * S
+        for k in range(1, d.bank_k + 1):
+            sfx = bank_suffix(k)
+            kk, ok = self.P(VOC + "convbank_0/conv1d%s/kernel" % sfx); b, ob = self.P(VOC + "convbank_0/conv1d%s/bias" % sfx)
+            gemm(w.mel_out, kk, w.v_tmp, rows, d.bank_ch, k * d.n_mel, d.n_mel, d.bank_ch, d.bank_ch, bias=b, act=ACT_RELU,
+                 win=(S, d.n_mel, (k - 1) // 2), b_off=ok, bias_off=ob)
+            self._bn_fwd(VOC + "convbank_0/batch_normalization%s/" % sfx, w.v_tmp, w.v_tmp2, w.v_stat, w.v_stat[d.bank_ch:], None, 1.0, rows, d.bank_ch, w.bn_ws)
+            call("mstts_copy2d", ptr(w.v_tmp2), d.bank_ch, ptr(w.v_cat, (k - 1) * d.bank_ch), d.bank_k * d.bank_ch, rows, d.bank_ch, 0)
+        C1 = d.bank_k * d.bank_ch
+        call("mstts_maxpool2_same", ptr(w.v_cat), ptr(w.v_pool), B, S, C1)
+        kk, ok = self.P(VOC + "convbank_0/conv1d_8/kernel"); b, ob = self.P(VOC + "convbank_0/conv1d_8/bias")
+        gemm(w.v_pool, kk, w.v_p1, rows, d.proj1_ch, d.proj1_k * C1, C1, d.proj1_ch, d.proj1_ch, bias=b, act=ACT_RELU,
+             win=(S, C1, (d.proj1_k - 1) // 2), b_off=ok, bias_off=ob)
+        self._bn_fwd(VOC + "convbank_0/batch_normalization_8/", w.v_p1, w.v_p1y, w.v_stat, w.v_stat[d.proj1_ch:], None, 1.0, rows, d.proj1_ch, w.bn_ws)
+        kk, ok = self.P(VOC + "convbank_0/conv1d_9/kernel"); b, ob = self.P(VOC + "convbank_0/conv1d_9/bias")
+        gemm(w.v_p1y, kk, w.v_p2, rows, d.n_mel, d.proj2_k * d.proj1_ch, d.proj1_ch, d.n_mel, d.n_mel, bias=b,
+             win=(S, d.proj1_ch, (d.proj2_k - 1) // 2), b_off=ok, bias_off=ob)
+        self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.bn_ws)
+
+    # ------------------------------------------------------------------ loss + backward
+    def loss_and_backward(self, w, grad_scale=1.0):
+        d, ps = self.d, self.params
+        B, Te, L, S = w.B, w.Te, w.L, w.S
+        H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
+        mk, batch = w.masks, w.batch
+        tok, tlen, mel, mlen = batch["Token"], batch["Token_Length"], batch["Mel"], batch["Mel_Length"]
+        ps.grad.zero_()
+        w.scalars.zero_()
+        call("mstts_tts_loss_fwd_bwd", ptr(w.linear), ptr(w.mel_out), ptr(mel), ptr(w.stop), ptr(mlen), B, S, d.n_mel,
+             int(self.use_l1), float(grad_scale), ptr(w.scalars), ptr(w.d_linear), ptr(w.d_post), ptr(w.d_stop))
+        call("mstts_l2_loss_acc", ptr(ps.train), ptr(ps.wd_mask), ps.n_train, ptr(w.scalars, 3))
+        # ---- postnet backward
+        chans = [d.post_ch] * (d.post_n - 1) + [d.n_mel]
+        dy = w.d_post
+        for i in range(d.post_n - 1, -1, -1):
+            cin = d.n_mel if i == 0 else d.post_ch
+            x_in = w.linear if i == 0 else w.post_y[i - 1]
+            dx = w.post_dx if (i % 2 == 0) else w.post_dx2
+            self._conv_block_bwd(dy, x_in, w.post_a[i], w.post_mean[i], w.post_rstd[i], mk["post_drop_%d" % i], 1 - d.conv_drop,
+                                 ACT_TANH, "decoder/conv_%d/" % i, B * S, S, cin, chans[i], d.post_k, w.post_dz[i], dx)
+            dy = dx
+        # d_linear(total) = loss part + residual (d_post) + postnet input grad
+        n = B * S * d.n_mel
+        call("mstts_add", ptr(w.d_linear), ptr(w.d_post), ptr(w.d_linear), n)
+        call("mstts_add", ptr(w.d_linear), ptr(dy), ptr(w.d_linear), n)
+        # ---- projection backward
+        call("mstts_pack_dproj", ptr(w.d_linear), ptr(w.d_stop), ptr(w.d_proj), self.proj_ld, B, S, d.n_mel)
+        self.dwp_pad.zero_()
+        gemm(w.pj, w.d_proj, self.dwp_pad, H + M, self.proj_ld, S * B, H + M, self.proj_ld, self.proj_ld, trans_a=True,
+             split_k=max(2, _split_k(H + M, self.proj_ld, S * B)))
+        gwp, ogwp = self.G("decoder/decoder/linear_projection/dense/kernel")
+        gbp, ogbp = self.G("decoder/decoder/linear_projection/dense/bias")
+        call("mstts_copy2d", ptr(self.dwp_pad), self.proj_ld, ptr(gwp, ogwp), d.n_mel + 1, H + M, d.n_mel + 1, 1)
+        call("mstts_colsum", ptr(w.d_proj), S * B, d.n_mel + 1, self.proj_ld, ptr(gbp, ogbp), 1)
+        gemm(w.d_proj, self.wp_pad, w.d_pj, S * B, H + M, self.proj_ld, self.proj_ld, self.proj_ld, H + M, trans_b=True)
+        # ---- decoder loop backward
+        w.dq_hist.zero_()
+        db = w.dec_b
+        db.fwd = C.pointer(w.dec)
+        db.d_pj, db.dg0, db.dg1, db.dq_hist, db.de_hist, db.d_in0, db.ws = (ptr(w.d_pj), ptr(w.dg0), ptr(w.dg1), ptr(w.dq_hist),
+                                                                             ptr(w.de_hist), ptr(w.d_in0), ptr(w.dec_bwd_ws))
+        call("mstts_decoder_train_bwd", C.byref(db))
+        SB = S * B
+        # cell 1: dW1 = in1^T . dg1 ; db1 = colsum(dg1)
+        g1, og1 = self.G(CELL % 1 + "kernel"); gb1, ogb1 = self.G(CELL % 1 + "bias")
+        gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, SB, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, SB), accumulate=True, c_off=og1)
+        call("mstts_colsum", ptr(w.dg1), SB, 4 * H, 4 * H, ptr(gb1, ogb1), 1)
+        # cell 0: folded rows -> both context row blocks, recurrent rows, prenet rows
+        g0, og0 = self.G(CELL % 0 + "kernel"); gb0, ogb0 = self.G(CELL % 0 + "bias")
+        self.dw0f.zero_()
+        gemm(w.in0, w.dg0, self.dw0f, M + H, 4 * H, SB, M + H, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(M + H, 4 * H, SB)))
+        call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + Pn * 4 * H), 4 * H, M, 4 * H, 1)
+        call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + (Pn + M) * 4 * H), 4 * H, M, 4 * H, 1)
+        call("mstts_copy2d", ptr(self.dw0f, M * 4 * H), 4 * H, ptr(g0, og0 + (Pn + 2 * M) * 4 * H), 4 * H, H, 4 * H, 1)
+        gemm(w.pre_d[-1], w.dg0, g0, Pn, 4 * H, SB, Pn, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(Pn, 4 * H, SB)), c_off=og0)
+        call("mstts_colsum", ptr(w.dg0), SB, 4 * H, 4 * H, ptr(gb0, ogb0), 1)
+        # prenet backward
+        k0, o0 = self.P(CELL % 0 + "kernel")
+        gemm(w.dg0, k0, w.d_pre, SB, Pn, 4 * H, 4 * H, 4 * H, Pn, trans_b=True, b_off=o0)
+        dcur, dnxt = w.d_pre, w.d_pre2
+        for i in range(d.prenet_n - 1, -1, -1):
+            cin = d.n_mel if i == 0 else Pn
+            x_in = w.frames if i == 0 else w.pre_d[i - 1]
+            call("mstts_relu_dropout_bwd", ptr(dcur), ptr(w.pre_d[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(dcur), SB * Pn)
+            gk, ogk = self.G("decoder/decoder/prenet_%d/dense/kernel" % i); gb, ogb = self.G("decoder/decoder/prenet_%d/dense/bias" % i)
+            gemm(x_in, dcur, gk, cin, Pn, SB, cin, Pn, Pn, trans_a=True, split_k=max(2, _split_k(cin, Pn, SB)), c_off=ogk)
+            call("mstts_colsum", ptr(dcur), SB, Pn, Pn, ptr(gb, ogb), 1)
+            if i > 0:
+                k, ok = self.P("decoder/decoder/prenet_%d/dense/kernel" % i)
+                gemm(dcur, k, dnxt, SB, cin, Pn, Pn, Pn, cin, trans_b=True, b_off=ok)
+                dcur, dnxt = dnxt, dcur
+        # query layer: dWq = m1^T . dq
+        gq, ogq = self.G(LSA + "query_layer/kernel")
+        gemm(w.pj, w.dq_hist, gq, H, A, SB, H + M, A, A, trans_a=True, split_k=max(2, _split_k(H, A, SB)), c_off=ogq)
+        # attention parameter grads + d_keys
+        w.d_keys.zero_()
+        gs = {}
+        for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
+                            ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
+            t, o = self.G(LSA + name)
+            gs[field] = ptr(t, o)
+        call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), S, ptr(w.q_hist), ptr(w.cum_hist), ptr(w.de_hist), ptr(w.d_keys),
+             gs["conv_k"], gs["conv_b"], gs["dense_k"], gs["score_w"], gs["score_b"])
+        # d_values[b] = sum_s align[s,b,:]^T (d_ctx from projection + d_ctx from next step's cell 0)
+        gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
+             strides=(Te, H + M, Te * M), b_off=H)
+        if S > 1:
+            gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
+                 strides=(Te, M + H, Te * M), b_off=B * (M + H), accumulate=True)
+        # memory layer
+        wm, owm = self.P("attention/memory_layer/kernel"); gwm, ogwm = self.G("attention/memory_layer/kernel")
+        gemm(w.values, w.d_keys, gwm, M, A, B * Te, M, A, A, trans_a=True, split_k=max(2, _split_k(M, A, B * Te)), c_off=ogwm)
+        gemm(w.d_keys, wm, w.d_values, B * Te, M, A, A, A, M, trans_b=True, accumulate=True, b_off=owm)
+        # ---- encoder BiLSTM backward
+        x_in, cin = w.enc_y[-1], d.enc_conv_ch
+        for di, dr in enumerate(("fw", "bw")):
+            k, ok = self.P(ENC_CELL % dr + "kernel")
+            q = lib.LstmSeqBwd()
+            q.B, q.T, q.H = B, Te, He
+            q.wh = ptr(k, ok + cin * 4 * He); q.wh_ld = 4 * He
+            q.lengths = ptr(tlen); q.reverse = di; q.zoneout = d.zoneout
+            q.zc = ptr(mk["enc_zc_" + dr]); q.zh = ptr(mk["enc_zh_" + dr])
+            q.d_out = ptr(w.d_values, di * He); q.dout_sb = Te * M; q.dout_st = M
+            q.c_hist = ptr(w.enc_c[dr]); q.acts = ptr(w.enc_acts[dr]); q.c_raw = ptr(w.enc_craw[dr])
+            q.dgates_step = ptr(w.enc_dgs[dr]); q.dgates_pos = ptr(w.enc_dgp[dr]); q.ws = ptr(w.enc_bwd_ws)
+            call("mstts_lstm_seq_bwd", C.byref(q))
+            gk, ogk = self.G(ENC_CELL % dr + "kernel"); gb, ogb = self.G(ENC_CELL % dr + "bias")
+            gemm(x_in, w.enc_dgp[dr], gk, cin, 4 * He, B * Te, cin, 4 * He, 4 * He, trans_a=True,
+                 split_k=max(2, _split_k(cin, 4 * He, B * Te)), c_off=ogk)
+            gemm(w.enc_h[dr], w.enc_dgs[dr], gk, He, 4 * He, Te * B, He, 4 * He, 4 * He, trans_a=True,
+                 split_k=max(2, _split_k(He, 4 * He, B * Te)), c_off=ogk + cin * 4 * He)
+            call("mstts_colsum", ptr(w.enc_dgs[dr]), Te * B, 4 * He, 4 * He, ptr(gb, ogb), 1)
+            gemm(w.enc_dgp[dr], k, w.enc_dy, B * Te, cin, 4 * He, 4 * He, 4 * He, cin, trans_b=True, accumulate=(di == 1), b_off=ok)
+        # ---- encoder conv backward
+        dy = w.enc_dy
+        bufs = [w.enc_dx, w.enc_dy]
+        for i in range(d.enc_conv_n - 1, -1, -1):
+            cin = d.emb if i == 0 else d.enc_conv_ch
+            x_in = w.emb if i == 0 else w.enc_y[i - 1]
+            dx = bufs[(d.enc_conv_n - 1 - i) % 2]
+            self._conv_block_bwd(dy, x_in, w.enc_a[i], w.enc_mean[i], w.enc_rstd[i], mk["enc_conv_drop_%d" % i], 1 - d.conv_drop,
+                                 ACT_RELU, "encoder/conv_%d/" % i, B * Te, Te, cin, d.enc_conv_ch, d.enc_conv_k, w.enc_dz, dx)
+            dy = dx
+        ge, oge = self.G("encoder/embedding_variable")
+        call("mstts_embedding_bwd", ptr(tok), ptr(dy), ptr(ge, oge), B * Te, d.n_tok, d.emb)
+
+    # ------------------------------------------------------------------ optimizer
+    def adam_step(self, grad_scale=1.0):
+        """tf.train.AdamOptimizer + the 1e-6 * l2 regulariser's gradient (MSTTS_SV.py:145-176)."""
+        ps = self.params
+        b1, b2, eps = self.adam
+        t = self.global_step + 1
+        lr = learning_rate(self.global_step)
+        lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        call("mstts_adam_tf", ptr(ps.train), ptr(ps.grad), ptr(ps.adam_m), ptr(ps.adam_v), ptr(ps.wd_mask), float(self.wr_rate),
+             float(grad_scale), float(lr_t), b1, b2, eps, ps.n_train)
+        self.global_step += 1
+        self._derived_stale = True
+        self.refresh_derived()
+        return lr
+
+    def scalars(self, w):
+        s = w.scalars.detach().cpu().numpy()
+        wr = float(s[3]) * self.wr_rate
+        return {"Linear_Loss": float(s[0]), "Postnet_Loss": float(s[1]), "Stop_Loss": float(s[2]),
+                "Weight_Regularization_Loss": wr, "Loss": float(s[0] + s[1] + s[2]) + wr}
+
+    def train_step(self, batch, masks=None, all_reduce=None):
+        """One full iteration: forward, loss, backward, (gradient all-reduce), Adam."""
+        B, Te = batch["Token"].shape
+        L = batch["Mel"].shape[1]
+        w = self.plan(B, Te, L)
+        self.forward(batch, w, masks=masks)
+        self.loss_and_backward(w)
+        if all_reduce is not None:
+            all_reduce(self.params.grad)
+        self.adam_step(grad_scale=1.0 / self.world if all_reduce is not None else 1.0)
+        return w

@@ -1,0 +1,189 @@
+"""ctypes binding of libmstts_hip.so (the C ABI in include/mstts.h).
+
+There is deliberately no fallback: if the HIP library is missing or fails to load, importing any
+compute entry point raises.  PyTorch only provides device memory (``tensor.data_ptr()``) and the
+current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmstts_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+vp, i64, i32, f32, u64, u32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint32
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp),
+                ("M", i64), ("N", i64), ("K", i64), ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("trans_a", i32), ("trans_b", i32), ("win_T", i32), ("win_C", i32), ("win_pad", i32),
+                ("act", i32), ("accumulate", i32), ("split_k", i32),
+                ("batch", i64), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("alpha", f32)]
+
+
+class LstmPointFwd(C.Structure):
+    _fields_ = [("B", i64), ("H", i64), ("gates_h", vp), ("xw", vp), ("xw_sb", i64), ("xw_st", i64), ("bias", vp),
+                ("c_prev", vp), ("h_prev", vp), ("h_prev_ld", i64), ("zc", vp), ("zh", vp), ("zoneout", f32),
+                ("lengths", vp), ("step", i32), ("reverse", i32), ("residual", vp), ("res_sb", i64), ("res_st", i64),
+                ("out", vp), ("out_sb", i64), ("out_st", i64), ("c_next", vp), ("h_next", vp), ("h_next_ld", i64),
+                ("acts_out", vp), ("c_raw", vp)]
+
+
+class LstmPointBwd(C.Structure):
+    _fields_ = [("B", i64), ("H", i64), ("d_out", vp), ("dout_sb", i64), ("dout_st", i64), ("d_out2", vp),
+                ("d_c_state", vp), ("d_h_state", vp), ("d_h_state2", vp), ("dhs2_ld", i64),
+                ("acts", vp), ("c_raw", vp), ("c_prev", vp), ("zc", vp), ("zh", vp), ("zoneout", f32),
+                ("lengths", vp), ("step", i32), ("reverse", i32), ("dgates", vp), ("dgates_pos", vp),
+                ("dgp_sb", i64), ("dgp_st", i64), ("d_c_prev", vp), ("d_h_prev", vp)]
+
+
+class LsaConst(C.Structure):
+    _fields_ = [("B", i64), ("T", i64), ("A", i64), ("M", i64), ("KS", i64), ("CH", i64),
+                ("keys", vp), ("values", vp), ("lengths", vp),
+                ("conv_k", vp), ("conv_b", vp), ("dense_k", vp), ("score_w", vp), ("score_b", vp)]
+
+
+class LstmSeqFwd(C.Structure):
+    _fields_ = [("B", i64), ("T", i64), ("H", i64), ("xw", vp), ("wh", vp), ("wh_ld", i64), ("lengths", vp),
+                ("reverse", i32), ("zoneout", f32), ("zc", vp), ("zh", vp), ("residual", vp),
+                ("out", vp), ("out_sb", i64), ("out_st", i64),
+                ("c_hist", vp), ("h_hist", vp), ("acts", vp), ("c_raw", vp), ("gates_ws", vp)]
+
+
+class LstmSeqBwd(C.Structure):
+    _fields_ = [("B", i64), ("T", i64), ("H", i64), ("wh", vp), ("wh_ld", i64), ("lengths", vp), ("reverse", i32),
+                ("zoneout", f32), ("zc", vp), ("zh", vp), ("d_out", vp), ("dout_sb", i64), ("dout_st", i64),
+                ("c_hist", vp), ("acts", vp), ("c_raw", vp), ("dgates_step", vp), ("dgates_pos", vp), ("ws", vp)]
+
+
+class DecoderTrain(C.Structure):
+    _fields_ = [("B", i64), ("S", i64), ("H", i64), ("P", i64), ("lsa", LsaConst),
+                ("xw0", vp), ("w0f", vp), ("w1", vp), ("b1", vp), ("wq", vp),
+                ("zc0", vp), ("zh0", vp), ("zc1", vp), ("zh1", vp), ("zoneout", f32),
+                ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp),
+                ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
+                ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp)]
+
+
+class DecoderTrainBwd(C.Structure):
+    _fields_ = [("fwd", C.POINTER(DecoderTrain)), ("d_pj", vp), ("dg0", vp), ("dg1", vp), ("dq_hist", vp),
+                ("de_hist", vp), ("d_in0", vp), ("ws", vp)]
+
+
+class DecoderInfer(C.Structure):
+    _fields_ = [("B", i64), ("H", i64), ("P", i64), ("n_mel", i64), ("Smax", i64), ("lsa", LsaConst),
+                ("pw0", vp), ("pb0", vp), ("pw1", vp), ("pb1", vp), ("pm0", vp), ("pm1", vp), ("prenet_keep", f32),
+                ("wx0", vp), ("b0", vp), ("w0f", vp), ("w1", vp), ("b1", vp), ("wq", vp), ("wproj", vp), ("bproj", vp),
+                ("zoneout", f32), ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp), ("cum", vp),
+                ("pre_ws", vp), ("linear", vp), ("stop", vp), ("align_hist", vp)]
+
+
+P = C.POINTER
+# name -> (restype, argtypes); every symbol include/mstts.h declares
+SIGNATURES = {
+    "mstts_last_error": (C.c_char_p, []),
+    "mstts_abi_version": (i32, []),
+    "mstts_gemm_f32": (i32, [P(GemmDesc), vp]),
+    "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
+    "mstts_embedding_fwd": (i32, [vp, vp, vp, i64, i64, i64, vp]),
+    "mstts_embedding_bwd": (i32, [vp, vp, vp, i64, i64, i64, vp]),
+    "mstts_bn_train_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i64, i64, vp, vp]),
+    "mstts_bn_infer_fwd": (i32, [vp, vp, vp, vp, vp, vp, f32, i64, i64, vp]),
+    "mstts_bn_train_bwd": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, i64, i64, vp, vp]),
+    "mstts_dropout": (i32, [vp, vp, f32, vp, i64, vp]),
+    "mstts_relu_dropout_bwd": (i32, [vp, vp, vp, f32, vp, i64, vp]),
+    "mstts_colsum": (i32, [vp, i64, i64, i64, vp, i32, vp]),
+    "mstts_add": (i32, [vp, vp, vp, i64, vp]),
+    "mstts_fill": (i32, [vp, f32, i64, vp]),
+    "mstts_copy2d": (i32, [vp, i64, vp, i64, i64, i64, i32, vp]),
+    "mstts_maxpool2_same": (i32, [vp, vp, i64, i64, i64, vp]),
+    "mstts_highway_combine": (i32, [vp, vp, vp, vp, i64, vp]),
+    "mstts_lstm_point_fwd": (i32, [P(LstmPointFwd), vp]),
+    "mstts_lstm_point_bwd": (i32, [P(LstmPointBwd), vp]),
+    "mstts_lsa_energy_fwd": (i32, [P(LsaConst), vp, vp, vp, vp]),
+    "mstts_lsa_context_fwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, i64, vp, i64, vp]),
+    "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, vp, vp, vp, vp, vp]),
+    "mstts_lsa_denergy_bwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mstts_lsa_param_bwd": (i32, [P(LsaConst), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mstts_tts_loss_fwd_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i32, f32, vp, vp, vp, vp, vp]),
+    "mstts_l2_loss_acc": (i32, [vp, vp, i64, vp, vp]),
+    "mstts_shift_frames": (i32, [vp, vp, i64, i64, i64, vp]),
+    "mstts_unpack_proj": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
+    "mstts_pack_dproj": (i32, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "mstts_speaker_tile": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "mstts_conv_kernel_flip": (i32, [vp, vp, i64, i64, i64, vp]),
+    "mstts_adam_tf": (i32, [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i64, vp]),
+    "mstts_stft_mel": (i32, [vp, i64, f32, vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, vp]),
+    "mstts_stft_mel_ws_floats": (i64, [i64, i32, i64]),
+    "mstts_fold_rows": (i32, [vp, vp, i64, i64, i64, i64, vp]),
+    "mstts_lstm_seq_fwd": (i32, [P(LstmSeqFwd), vp]),
+    "mstts_lstm_seq_bwd": (i32, [P(LstmSeqBwd), vp]),
+    "mstts_decoder_train_fwd": (i32, [P(DecoderTrain), vp]),
+    "mstts_decoder_train_bwd": (i32, [P(DecoderTrainBwd), vp]),
+    "mstts_decoder_train_bwd_ws_floats": (i64, [i64, i64, i64, i64]),
+    "mstts_decoder_infer_steps": (i32, [P(DecoderInfer), i64, i64, vp]),
+    "mstts_decoder_infer_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
+}
+
+_lib = None
+
+
+class MsttsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (building first when the sources are newer and hipcc is present) the HIP library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _b
+        _b.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch; never fall back
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, offset=0):
+    """Device pointer of a tensor (None -> NULL), advanced by ``offset`` elements."""
+    if t is None:
+        return None
+    return t.data_ptr() + offset * t.element_size()
+
+
+def call(name, *args):
+    """Call an int-returning entry point on the current stream; raise MsttsError on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise MsttsError("%s failed (%d): %s" % (name, rc, lib.mstts_last_error().decode()))
+
+
+def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, bias=None, trans_a=False, trans_b=False, act=ACT_NONE, accumulate=False,
+         split_k=1, win=None, batch=1, strides=(0, 0, 0), alpha=1.0, a_off=0, b_off=0, c_off=0, bias_off=0):
+    """Thin wrapper over mstts_gemm_f32.  A/B/Cm/bias are tensors (used only for their pointers)."""
+    d = GemmDesc()
+    d.A, d.B, d.C, d.bias = ptr(A, a_off), ptr(B, b_off), ptr(Cm, c_off), ptr(bias, bias_off)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+    if win is not None:
+        d.win_T, d.win_C, d.win_pad = win
+    d.act, d.accumulate, d.split_k = act, int(accumulate), split_k
+    d.batch, d.stride_a, d.stride_b, d.stride_c = batch, strides[0], strides[1], strides[2]
+    d.alpha = alpha
+    call("mstts_gemm_f32", C.byref(d))

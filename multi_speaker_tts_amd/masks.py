@@ -1,0 +1,77 @@
+"""Keep-mask streams of one forward pass (dropout + zoneout), drawn on the device with the
+library's Philox4x32-10 kernel.  Replaces the stateful tf.random_uniform draws of
+tf.layers.dropout (Modules.py:41-45,137-141,248-253) and ZoneoutLSTMCell.dropout_no_scale
+(ZoneoutLSTMCell.py:266-271).  Stream ids are part of the library's specification
+(DESIGN.md "Randomness"): element i of mask (seed, stream) is draw i of that Philox stream.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import lib
+
+STREAM = {"enc_conv_drop": 1, "enc_zc_fw": 10, "enc_zh_fw": 11, "enc_zc_bw": 12, "enc_zh_bw": 13,
+          "prenet_drop": 20, "dec_zc": 30, "dec_zh": 31, "post_drop": 40,
+          "v_zc_fw": 50, "v_zh_fw": 51, "v_zc_bw": 52, "v_zh_bw": 53, "s_zc": 60, "s_zh": 61}
+RANK_STRIDE = 1000
+
+
+def step_seed(base_seed, step):
+    return (int(base_seed) + 1000003 * int(step)) & 0xFFFFFFFFFFFFFFFF
+
+
+def table(d, B, T_enc, S, training, speaker_windows=0, vocoder=False):
+    """[(name, stream id, shape, keep probability)]"""
+    t = [("prenet_drop_%d" % i, STREAM["prenet_drop"] + i, (S, B, d.prenet), 1 - d.prenet_drop) for i in range(d.prenet_n)]
+    if not training:
+        return t
+    for i in range(d.enc_conv_n):
+        t.append(("enc_conv_drop_%d" % i, STREAM["enc_conv_drop"] + i, (B, T_enc, d.enc_conv_ch), 1 - d.conv_drop))
+    for dr in ("fw", "bw"):
+        for k in ("zc", "zh"):
+            t.append(("enc_%s_%s" % (k, dr), STREAM["enc_%s_%s" % (k, dr)], (T_enc, B, d.enc_lstm), 1 - d.zoneout))
+    for l in range(d.dec_lstm_n):
+        for k in ("zc", "zh"):
+            t.append(("dec_%s_%d" % (k, l), STREAM["dec_" + k] + 2 * l, (S, B, d.dec_lstm), 1 - d.zoneout))
+    for i in range(d.post_n):
+        cout = d.post_ch if i < d.post_n - 1 else d.n_mel
+        t.append(("post_drop_%d" % i, STREAM["post_drop"] + i, (B, S, cout), 1 - d.conv_drop))
+    if vocoder:
+        for dr in ("fw", "bw"):
+            for k in ("zc", "zh"):
+                t.append(("v_%s_%s" % (k, dr), STREAM["v_%s_%s" % (k, dr)], (S, B, d.birnn), 1 - d.zoneout))
+    if speaker_windows:
+        for i in range(d.spk_lstm_n):
+            for k in ("zc", "zh"):
+                t.append(("s_%s_%d" % (k, i), STREAM["s_" + k] + 2 * i, (d.spk_frames, speaker_windows, d.spk_lstm), 1 - d.zoneout))
+    return t
+
+
+class MaskSet:
+    """Preallocated uint8 mask buffers for one shape; ``draw`` refills them for a seed."""
+
+    def __init__(self, d, B, T_enc, S, training, device, rank=0, **kw):
+        self.spec = table(d, B, T_enc, S, training, **kw)
+        self.rank = rank
+        self.buf = {}
+        for name, _, shape, _ in self.spec:
+            n = int(np.prod(shape))
+            self.buf[name] = torch.empty((n + 3) // 4 * 4, dtype=torch.uint8, device=device)[:n].view(shape)
+
+    def draw(self, seed):
+        for name, stream, shape, keep in self.spec:
+            lib.call("mstts_philox_keep_mask", lib.ptr(self.buf[name]), int(np.prod(shape)), seed,
+                     stream + RANK_STRIDE * self.rank, float(keep))
+
+    def load(self, masks):
+        """Inject externally supplied masks (tests)."""
+        for name, _, shape, _ in self.spec:
+            if name in masks:
+                self.buf[name].copy_(torch.as_tensor(masks[name]).to(torch.uint8).reshape(shape))
+
+    def __getitem__(self, name):
+        return self.buf[name]
+
+    def get(self, name):
+        return self.buf.get(name)

@@ -1,0 +1,205 @@
+"""Parity of the recurrent kernels, the attention step and the whole train step against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from multi_speaker_tts_amd import lib
+from multi_speaker_tts_amd.engine import TrainEngine
+from multi_speaker_tts_amd.params import LSA
+from oracle import model as OM, train as OT, audio as OA
+from tests.helpers import dims_pair, rel_err, t2n, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _r(dev, *shape, seed=0, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.tensor(g.normal(0, scale, size=shape), dtype=torch.float32, device=dev)
+
+
+def test_lstm_point_fwd_bwd(dev):
+    """Fused zoneout cell (pointwise part) forward/backward vs torch-fp64 autograd of the oracle cell."""
+    B, H = 5, 24
+    gates = _r(dev, B, 4 * H, seed=1); bias = _r(dev, 4 * H, seed=2, scale=0.1)
+    cp, hp = _r(dev, B, H, seed=3), _r(dev, B, H, seed=4)
+    zc = torch.tensor(np.random.default_rng(5).integers(0, 2, (B, H)).astype(np.uint8), device=dev)
+    zh = torch.tensor(np.random.default_rng(6).integers(0, 2, (B, H)).astype(np.uint8), device=dev)
+    out, cn, hn = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+    acts, craw = torch.zeros(B, 4 * H, device=dev), torch.zeros(B, H, device=dev)
+    d = lib.LstmPointFwd()
+    d.B, d.H, d.gates_h, d.bias = B, H, lib.ptr(gates), lib.ptr(bias)
+    d.c_prev, d.h_prev, d.zc, d.zh, d.zoneout = lib.ptr(cp), lib.ptr(hp), lib.ptr(zc), lib.ptr(zh), 0.1
+    d.out, d.out_sb, d.c_next, d.h_next, d.acts_out, d.c_raw = lib.ptr(out), H, lib.ptr(cn), lib.ptr(hn), lib.ptr(acts), lib.ptr(craw)
+    lib.call("mstts_lstm_point_fwd", C.byref(d))
+    g64 = (gates.double().cpu() + bias.double().cpu()).requires_grad_(True)
+    cp64, hp64 = cp.double().cpu().requires_grad_(True), hp.double().cpu().requires_grad_(True)
+    # oracle cell with identity kernel: feed pre-activations through x, zero recurrent part
+    i, j, f, o = g64.chunk(4, 1)
+    c = torch.sigmoid(f + 1.0) * cp64 + torch.sigmoid(i) * torch.tanh(j)
+    m = torch.sigmoid(o) * torch.tanh(c)
+    c2 = 0.9 * (c - cp64) * zc.cpu().double() + cp64
+    h2 = 0.9 * (m - hp64) * zh.cpu().double() + hp64
+    assert rel_err(t2n(out), t2n(m)) < 1e-5 and rel_err(t2n(cn), t2n(c2)) < 1e-5 and rel_err(t2n(hn), t2n(h2)) < 1e-5
+    dm, dc2, dh2 = _r(dev, B, H, seed=7), _r(dev, B, H, seed=8), _r(dev, B, H, seed=9)
+    ((m * dm.double().cpu()).sum() + (c2 * dc2.double().cpu()).sum() + (h2 * dh2.double().cpu()).sum()).backward()
+    dg, dcp, dhp = torch.zeros(B, 4 * H, device=dev), torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+    b = lib.LstmPointBwd()
+    b.B, b.H, b.d_out, b.dout_sb = B, H, lib.ptr(dm), H
+    b.d_c_state, b.d_h_state, b.acts, b.c_raw, b.c_prev = lib.ptr(dc2), lib.ptr(dh2), lib.ptr(acts), lib.ptr(craw), lib.ptr(cp)
+    b.zc, b.zh, b.zoneout, b.dgates, b.d_c_prev, b.d_h_prev = lib.ptr(zc), lib.ptr(zh), 0.1, lib.ptr(dg), lib.ptr(dcp), lib.ptr(dhp)
+    lib.call("mstts_lstm_point_bwd", C.byref(b))
+    assert rel_err(t2n(dg), t2n(g64.grad)) < 2e-5
+    assert rel_err(t2n(dcp), t2n(cp64.grad)) < 2e-5 and rel_err(t2n(dhp), t2n(hp64.grad)) < 2e-5
+
+
+@pytest.mark.parametrize("B,T,M,KS", [(3, 37, 48, 31), (2, 128, 768, 31), (1, 16, 16, 5)])
+def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
+    """One attention step (energy+context kernels, dalign+denergy kernels) vs the oracle's lsa_step."""
+    A, CH, Hq = 128, 32, 40
+    od = OM.Dims(att_k=KS, dec_lstm=Hq)
+    g = np.random.default_rng(3)
+    p = {LSA + "query_layer/kernel": g.normal(0, 0.2, (Hq, A)),
+         LSA + "attention_convolution_dense_layer/conv1d/kernel": g.normal(0, 0.3, (KS, 1, CH)),
+         LSA + "attention_convolution_dense_layer/conv1d/bias": g.normal(0, 0.1, (CH,)),
+         LSA + "attention_convolution_dense_layer/dense/kernel": g.normal(0, 0.3, (CH, A)),
+         LSA + "score_layer/weight_w": g.normal(0, 0.5, (1, 1, A)), LSA + "score_layer/bias_b": g.normal(0, 0.1, (1, 1, A))}
+    lengths = np.array([T] + list(g.integers(max(1, T // 2), T + 1, B - 1)), np.int32)
+    mask = np.arange(T)[None, :] < lengths[:, None]
+    keys = g.normal(0, 1, (B, T, A)) * mask[:, :, None]; values = g.normal(0, 1, (B, T, M)) * mask[:, :, None]
+    query = g.normal(0, 1, (B, Hq)); cum = np.abs(g.normal(0, 0.5, (B, T))) * mask
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    kt, vt = torch.tensor(keys, requires_grad=True), torch.tensor(values, requires_grad=True)
+    qt, ct = torch.tensor(query, requires_grad=True), torch.tensor(cum, requires_grad=True)
+    align, cum_next, ctx = OM.lsa_step(pt, od, kt, vt, torch.tensor(mask), qt, ct)
+    f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev).contiguous()
+    dk, dv, dl = f32(keys), f32(values), torch.tensor(lengths, device=dev)
+    dp = {k: f32(v) for k, v in p.items()}
+    c = lib.LsaConst()
+    c.B, c.T, c.A, c.M, c.KS, c.CH = B, T, A, M, KS, CH
+    c.keys, c.values, c.lengths = lib.ptr(dk), lib.ptr(dv), lib.ptr(dl)
+    c.conv_k, c.conv_b = lib.ptr(dp[LSA + "attention_convolution_dense_layer/conv1d/kernel"]), lib.ptr(dp[LSA + "attention_convolution_dense_layer/conv1d/bias"])
+    c.dense_k, c.score_w, c.score_b = lib.ptr(dp[LSA + "attention_convolution_dense_layer/dense/kernel"]), lib.ptr(dp[LSA + "score_layer/weight_w"]), lib.ptr(dp[LSA + "score_layer/bias_b"])
+    q = f32(query @ p[LSA + "query_layer/kernel"]); dcum = f32(cum)
+    en, al, cn, cx = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
+    lib.call("mstts_lsa_energy_fwd", C.byref(c), lib.ptr(q), lib.ptr(dcum), lib.ptr(en))
+    lib.call("mstts_lsa_context_fwd", C.byref(c), lib.ptr(en), lib.ptr(dcum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0)
+    assert rel_err(t2n(al), t2n(align)) < 2e-5 and rel_err(t2n(cn), t2n(cum_next)) < 2e-5 and rel_err(t2n(cx), t2n(ctx)) < 2e-5
+    # backward: upstream grads on ctx and on the next cumulative state
+    d_ctx = g.normal(0, 1, (B, M)); G_next = g.normal(0, 1, (B, T)); d_f_next = g.normal(0, 1, (B, T, CH))
+    # G = G_next + convT(d_f_next): emulate by adding <f(cum_next), d_f_next> to the objective
+    f_next = OM.conv1d_same(cum_next[:, :, None], pt[LSA + "attention_convolution_dense_layer/conv1d/kernel"], pt[LSA + "attention_convolution_dense_layer/conv1d/bias"])
+    obj = (ctx * torch.tensor(d_ctx)).sum() + (cum_next * torch.tensor(G_next)).sum() + (f_next * torch.tensor(d_f_next)).sum()
+    obj.backward()
+    G, da = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev)
+    d_ctx_d, G_next_d, d_f_next_d = f32(d_ctx), f32(G_next), f32(d_f_next)     # keep alive: the calls are asynchronous
+    lib.call("mstts_lsa_dalign_bwd", C.byref(c), lib.ptr(d_ctx_d), M, None, 0, lib.ptr(G_next_d), lib.ptr(d_f_next_d), lib.ptr(G), lib.ptr(da))
+    de, dq, df = torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, CH, device=dev)
+    lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al), lib.ptr(da), lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dq), lib.ptr(df))
+    # d query (through the query layer) = dq . Wq^T
+    dquery = t2n(dq).astype(np.float64) @ p[LSA + "query_layer/kernel"].T
+    assert rel_err(dquery, t2n(qt.grad)) < 5e-5
+    # grad wrt cum = G (carried) + convT(d_f)
+    wc = p[LSA + "attention_convolution_dense_layer/conv1d/kernel"][:, 0, :]
+    pad = (KS - 1) // 2
+    dfn = t2n(df).astype(np.float64)
+    dcum_ref = t2n(G).astype(np.float64).copy()
+    for j in range(KS):
+        for t in range(T):
+            tp = t + j - pad
+            if 0 <= tp < T:
+                dcum_ref[:, tp] += dfn[:, t] @ wc[j]
+    assert rel_err(dcum_ref, t2n(ct.grad)) < 5e-5
+    # parameter gradients + d_keys through the post-loop kernel with S = 1
+    S = 1
+    dkeys = torch.zeros(B, T, A, device=dev)
+    gk, gb, gd, gw, gsb = torch.zeros(KS, CH, device=dev), torch.zeros(CH, device=dev), torch.zeros(CH, A, device=dev), torch.zeros(A, device=dev), torch.zeros(A, device=dev)
+    lib.call("mstts_lsa_param_bwd", C.byref(c), S, lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dkeys), lib.ptr(gk), lib.ptr(gb), lib.ptr(gd), lib.ptr(gw), lib.ptr(gsb))
+    assert rel_err(t2n(dkeys), t2n(kt.grad)) < 5e-5
+    assert rel_err(t2n(gd), t2n(pt[LSA + "attention_convolution_dense_layer/dense/kernel"].grad)) < 5e-5
+    assert rel_err(t2n(gw), t2n(pt[LSA + "score_layer/weight_w"].grad).reshape(-1)) < 5e-5
+    assert rel_err(t2n(gsb), t2n(pt[LSA + "score_layer/bias_b"].grad).reshape(-1)) < 5e-5
+    # conv kernel/bias grads: the oracle objective also has the d_f_next term through f(cum_next); remove it
+    gk_extra = np.zeros((KS, CH)); cn64 = t2n(cum_next).astype(np.float64)
+    for j in range(KS):
+        for t in range(T):
+            tp = t + j - pad
+            if 0 <= tp < T:
+                gk_extra[j] += (cn64[:, tp, None] * d_f_next[:, t]).sum(0)
+    ref_gk = t2n(pt[LSA + "attention_convolution_dense_layer/conv1d/kernel"].grad)[:, 0, :] - gk_extra
+    ref_gb = t2n(pt[LSA + "attention_convolution_dense_layer/conv1d/bias"].grad) - d_f_next.sum((0, 1))
+    assert rel_err(t2n(gk), ref_gk) < 1e-4 and rel_err(t2n(gb), ref_gb) < 1e-4
+    # d_values from the context: outer(align, d_ctx)
+    assert rel_err(t2n(al)[:, :, None] * d_ctx[:, None, :], t2n(vt.grad)) < 5e-5
+
+
+def test_stft_mel(dev):
+    from multi_speaker_tts_amd import Audio
+    g = np.random.default_rng(0)
+    t = np.arange(16000 * 2) / 16000.0
+    y = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.1 * np.sin(2 * np.pi * 3000 * t) + 0.02 * g.normal(size=t.shape)).astype(np.float32)
+    got = Audio.melspectrogram(y, 1025, 12.5, 50, 80, 16000, max_abs_value=4)
+    ref = OA.melspectrogram(y)
+    assert got.shape == ref.shape == (80, 1 + len(y) // 200)
+    assert np.abs(got - ref).max() < 2e-3          # normalised range is [-4, 4]: 5e-4 relative
+
+
+def _engine_vs_oracle(dev, B, Te, L, ragged, seed):
+    pd, od = dims_pair()
+    values = OM.init_params(od, seed)
+    # make BN / biases non-trivial so every gradient path is exercised
+    g = np.random.default_rng(seed + 1)
+    for k in values:
+        if k.endswith(("bias", "beta", "bias_b")):
+            values[k] = g.normal(0, 0.1, values[k].shape)
+        if k.endswith("gamma"):
+            values[k] = 1.0 + g.normal(0, 0.1, values[k].shape)
+    batch = OT.synthetic_batch(od, B, Te, L, seed=seed, ragged=ragged)
+    S = L + 1
+    masks = OT.make_masks(od, B, Te, S, True, seed=OT.step_seed(1234, 0))
+    new_p, opt, sc, grads, out = OT.train_step(values, None, od, batch, masks, 0, return_grads=True)
+    eng = TrainEngine(pd, device=dev, values=values)
+    w = eng.plan(B, Te, L)
+    eng.forward(to_dev(batch, dev), w, seed=OT.step_seed(1234, 0))     # masks drawn on the device by Philox
+    for name, m in masks.items():                                       # ... must equal the oracle's
+        assert np.array_equal(t2n(w.masks[name]), m.numpy()), name
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    return eng, w, od, values, batch, sc, grads, out, new_p
+
+
+@pytest.mark.parametrize("B,Te,L,ragged", [(3, 9, 6, False), (4, 21, 13, True)])
+def test_train_step_parity(dev, B, Te, L, ragged):
+    eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, ragged, seed=11)
+    tol = 1e-3    # north_star: within 1e-3 relative on fp32 mels
+    assert rel_err(t2n(w.linear), t2n(out["Linear"])) < tol
+    assert rel_err(t2n(w.mel_out), t2n(out["Mel"])) < tol
+    assert rel_err(t2n(w.stop), t2n(out["Stop_Logit"])) < tol
+    assert rel_err(t2n(w.align_hist).transpose(1, 2, 0), t2n(out["Attention_History"])) < tol
+    got = eng.scalars(w)
+    for k in ("Linear_Loss", "Postnet_Loss", "Stop_Loss", "Weight_Regularization_Loss", "Loss"):
+        assert abs(got[k] - sc[k]) <= 1e-4 * max(1.0, abs(sc[k])), (k, got[k], sc[k])
+    # gradients (the engine adds the regulariser's gradient inside Adam; add it here for comparison)
+    ggot = eng.params.export(grads=True)
+    worst = {}
+    for k, gr in grads.items():
+        ref = t2n(gr).astype(np.float64)
+        mine = ggot[k].astype(np.float64)
+        if OM.in_weight_reg(k):
+            mine = mine + 1e-6 * np.asarray(values[k])
+        worst[k] = np.abs(mine - ref).max() / (np.abs(ref).max() + 1e-9)
+    bad = {k: v for k, v in worst.items() if v > 5e-3}
+    assert not bad, bad
+    # optimizer + BN moving statistics
+    eng.adam_step()
+    torch.cuda.synchronize()
+    pgot = eng.params.export()
+    bad = {}
+    for k, ref in new_p.items():
+        if k.startswith("speaker_embedding"):
+            continue
+        e = rel_err(pgot[k], t2n(ref))
+        if e > 2e-3:
+            bad[k] = e
+    assert not bad, bad

@@ -1,0 +1,159 @@
+"""Op-level parity of the HIP kernels (called through the C ABI) against NumPy / the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from multi_speaker_tts_amd import lib
+from oracle import rng as orng
+from tests.helpers import rel_err, t2n
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _r(dev, *shape, seed=0, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.tensor(g.normal(0, scale, size=shape), dtype=torch.float32, device=dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 36), (32, 512, 260), (17, 81, 100), (300, 84, 64), (1, 1, 52)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts(dev, M, N, K, ta, tb):
+    A = _r(dev, K, M, seed=1) if ta else _r(dev, M, K, seed=1)
+    B = _r(dev, N, K, seed=2) if tb else _r(dev, K, N, seed=2)
+    bias = _r(dev, N, seed=3)
+    Cm = torch.zeros(M, N, device=dev)
+    lib.gemm(A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, bias=bias, trans_a=ta, trans_b=tb, act=lib.ACT_TANH)
+    a = t2n(A).astype(np.float64); b = t2n(B).astype(np.float64)
+    ref = np.tanh((a.T if ta else a) @ (b.T if tb else b) + t2n(bias))
+    assert rel_err(t2n(Cm), ref) < TOL
+
+
+def test_gemm_splitk_batch_accumulate(dev):
+    M, N, K, nb = 96, 160, 1000, 3
+    A = _r(dev, nb, K, M, seed=4); B = _r(dev, nb, K, N, seed=5)
+    Cm = torch.ones(nb, M, N, device=dev)
+    lib.gemm(A, B, Cm, M, N, K, M, N, N, trans_a=True, split_k=4, batch=nb, strides=(K * M, K * N, M * N))
+    ref = 1.0 + np.einsum("bkm,bkn->bmn", t2n(A).astype(np.float64), t2n(B).astype(np.float64))
+    assert rel_err(t2n(Cm), ref) < TOL
+    Cm2 = torch.full((M, N), 2.0, device=dev)
+    lib.gemm(A, B, Cm2, M, N, K, M, N, N, trans_a=True, accumulate=True, alpha=0.5)
+    ref2 = 2.0 + 0.5 * (t2n(A[0]).astype(np.float64).T @ t2n(B[0]).astype(np.float64))
+    assert rel_err(t2n(Cm2), ref2) < TOL
+
+
+@pytest.mark.parametrize("K,cin,cout,T", [(5, 32, 48, 19), (1, 8, 16, 7), (2, 8, 12, 9), (8, 8, 20, 33), (3, 64, 8, 140)])
+def test_conv1d_same_fwd_bwd(dev, K, cin, cout, T):
+    """conv1d 'same' as windowed GEMM: forward, weight gradient, data gradient vs torch-free NumPy."""
+    Bn = 3
+    x = _r(dev, Bn, T, cin, seed=6); w = _r(dev, K, cin, cout, seed=7, scale=0.3); bias = _r(dev, cout, seed=8)
+    y = torch.zeros(Bn, T, cout, device=dev)
+    pad = (K - 1) // 2
+    lib.gemm(x, w, y, Bn * T, cout, K * cin, cin, cout, cout, bias=bias, win=(T, cin, pad))
+    xn, wn = t2n(x).astype(np.float64), t2n(w).astype(np.float64)
+    xp = np.pad(xn, ((0, 0), (pad, K - 1 - pad), (0, 0)))
+    win = np.stack([xp[:, k:k + T] for k in range(K)], axis=2).reshape(Bn, T, K * cin)
+    ref = win @ wn.reshape(K * cin, cout) + t2n(bias)
+    assert rel_err(t2n(y), ref) < TOL
+    dy = _r(dev, Bn, T, cout, seed=9)
+    dw = torch.zeros(K, cin, cout, device=dev)
+    lib.gemm(x, dy, dw, K * cin, cout, Bn * T, cin, cout, cout, trans_a=True, win=(T, cin, pad), split_k=2)
+    dyn = t2n(dy).astype(np.float64)
+    ref_dw = np.einsum("btk,bto->ko", win, dyn).reshape(K, cin, cout)
+    assert rel_err(t2n(dw), ref_dw) < TOL
+    wt = torch.zeros(K, cout, cin, device=dev)
+    lib.call("mstts_conv_kernel_flip", lib.ptr(w), lib.ptr(wt), K, cin, cout)
+    dx = torch.zeros(Bn, T, cin, device=dev)
+    lib.gemm(dy, wt, dx, Bn * T, cin, K * cout, cout, cin, cin, win=(T, cout, K - 1 - pad))
+    ref_dx = np.zeros_like(xp)
+    dwin = (dyn @ wn.reshape(K * cin, cout).T).reshape(Bn, T, K, cin)
+    for k in range(K):
+        ref_dx[:, k:k + T] += dwin[:, :, k]
+    ref_dx = ref_dx[:, pad:pad + T]
+    assert rel_err(t2n(dx), ref_dx) < TOL
+
+
+def test_philox_bit_exact(dev):
+    for n, seed, stream, keep in [(1000, 1234, 7, 0.5), (4099, 2 ** 40 + 17, 1031, 0.9), (3, 5, 0, 0.1)]:
+        out = torch.zeros((n + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+        lib.call("mstts_philox_keep_mask", lib.ptr(out), n, seed, stream, keep)
+        assert np.array_equal(t2n(out)[:n], orng.keep_mask((n,), seed, stream, keep))
+
+
+def test_embedding_bit_exact(dev):
+    tab = _r(dev, 42, 64, seed=1)
+    tok = torch.tensor(np.random.default_rng(2).integers(0, 42, size=(5, 9)), dtype=torch.int32, device=dev)
+    out = torch.zeros(45, 64, device=dev)
+    lib.call("mstts_embedding_fwd", lib.ptr(tok), lib.ptr(tab), lib.ptr(out), 45, 42, 64)
+    assert np.array_equal(t2n(out), t2n(tab)[t2n(tok).reshape(-1)])
+    dt = torch.zeros(42, 64, device=dev)
+    dout = _r(dev, 45, 64, seed=3)
+    lib.call("mstts_embedding_bwd", lib.ptr(tok), lib.ptr(dout), lib.ptr(dt), 45, 42, 64)
+    ref = np.zeros((42, 64)); np.add.at(ref, t2n(tok).reshape(-1), t2n(dout).astype(np.float64))
+    assert rel_err(t2n(dt), ref) < TOL
+
+
+@pytest.mark.parametrize("act", [lib.ACT_RELU, lib.ACT_TANH])
+def test_bn_dropout_fwd_bwd(dev, act):
+    rows, Cc = 333, 48
+    z = _r(dev, rows, Cc, seed=1)
+    x = torch.relu(z) if act == lib.ACT_RELU else torch.tanh(z)
+    gamma, beta = _r(dev, Cc, seed=2) + 1.5, _r(dev, Cc, seed=3)
+    mm, mv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    mask = torch.tensor(orng.keep_mask((rows, Cc), 9, 1, 0.5), device=dev)
+    y = torch.zeros_like(x); sm = torch.zeros(Cc, device=dev); sr = torch.zeros(Cc, device=dev); ws = torch.zeros(2 * Cc, device=dev)
+    lib.call("mstts_bn_train_fwd", lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(mm), lib.ptr(mv), lib.ptr(y), lib.ptr(sm), lib.ptr(sr),
+             lib.ptr(mask), 0.5, 0.99, 1e-3, rows, Cc, lib.ptr(ws))
+    xd = x.double().cpu().requires_grad_(True); g = gamma.double().cpu().requires_grad_(True); b = beta.double().cpu().requires_grad_(True)
+    mean = xd.mean(0); var = ((xd - mean) ** 2).mean(0)
+    yr = ((xd - mean) / torch.sqrt(var + 1e-3) * g + b) * mask.cpu().double() / 0.5
+    assert rel_err(t2n(y), t2n(yr)) < TOL
+    assert rel_err(t2n(mm), 0.01 * t2n(mean)) < TOL and rel_err(t2n(mv), 0.99 + 0.01 * t2n(var)) < TOL
+    dy = _r(dev, rows, Cc, seed=5)
+    # reference gradient wrt the conv pre-activation z through act -> BN -> dropout
+    zd = z.double().cpu().requires_grad_(True)
+    xa = torch.relu(zd) if act == lib.ACT_RELU else torch.tanh(zd)
+    mean = xa.mean(0); var = ((xa - mean) ** 2).mean(0)
+    yr = ((xa - mean) / torch.sqrt(var + 1e-3) * g + b) * mask.cpu().double() / 0.5
+    (yr * dy.double().cpu()).sum().backward()
+    dz = torch.zeros_like(x); dg = torch.zeros(Cc, device=dev); db = torch.zeros(Cc, device=dev); dbias = torch.zeros(Cc, device=dev)
+    lib.call("mstts_bn_train_bwd", lib.ptr(dy), lib.ptr(x), lib.ptr(gamma), lib.ptr(sm), lib.ptr(sr), lib.ptr(mask), 0.5, act, lib.ptr(dz),
+             lib.ptr(dg), lib.ptr(db), lib.ptr(dbias), rows, Cc, lib.ptr(ws))
+    assert rel_err(t2n(dz), t2n(zd.grad)) < 5e-5
+    assert rel_err(t2n(dg), t2n(g.grad)) < 5e-5 and rel_err(t2n(db), t2n(b.grad)) < 5e-5
+    assert rel_err(t2n(dbias), t2n(zd.grad.sum(0))) < 1e-4
+
+
+def test_misc_elementwise(dev):
+    x = _r(dev, 4, 9, 12, seed=1)
+    y = torch.zeros_like(x)
+    lib.call("mstts_maxpool2_same", lib.ptr(x), lib.ptr(y), 4, 9, 12)
+    xn = t2n(x); ref = np.maximum(xn, np.concatenate([xn[:, 1:], np.full_like(xn[:, :1], -np.inf)], 1))
+    assert np.array_equal(t2n(y), ref)
+    src = _r(dev, 10, 7, seed=2)
+    s = t2n(src); ref = np.concatenate([s[:2], s[2:5] + s[5:8], s[8:]], 0)
+    dst = torch.zeros(7, 7, device=dev)
+    lib.call("mstts_fold_rows", lib.ptr(src), lib.ptr(dst), 10, 7, 2, 3)
+    assert np.allclose(t2n(dst), ref)
+    mel = _r(dev, 3, 5, 8, seed=3); fr = torch.zeros(6, 3, 8, device=dev)
+    lib.call("mstts_shift_frames", lib.ptr(mel), lib.ptr(fr), 3, 5, 8)
+    ref = np.concatenate([np.zeros((1, 3, 8), np.float32), t2n(mel).transpose(1, 0, 2)], 0)
+    assert np.array_equal(t2n(fr), ref)
+    cs = torch.zeros(7, device=dev)
+    lib.call("mstts_colsum", lib.ptr(src), 10, 7, 7, lib.ptr(cs), 0)
+    assert rel_err(t2n(cs), s.astype(np.float64).sum(0)) < TOL
+
+
+def test_adam_tf(dev):
+    n = 1001
+    p, g = _r(dev, n, seed=1), _r(dev, n, seed=2)
+    m, v = _r(dev, n, seed=3) * 0.1, torch.abs(_r(dev, n, seed=4)) * 0.01
+    wd = torch.tensor(np.random.default_rng(5).integers(0, 2, n).astype(np.uint8), device=dev)
+    pn, gn, mn, vn = [t2n(t).astype(np.float64) for t in (p, g, m, v)]
+    lib.call("mstts_adam_tf", lib.ptr(p), lib.ptr(g), lib.ptr(m), lib.ptr(v), lib.ptr(wd), 1e-6, 0.5, 3e-4, 0.9, 0.999, 1e-6, n)
+    gt = gn * 0.5 + 1e-6 * pn * t2n(wd)
+    mr = 0.9 * mn + 0.1 * gt; vr = 0.999 * vn + 0.001 * gt * gt
+    assert rel_err(t2n(p), pn - 3e-4 * mr / (np.sqrt(vr) + 1e-6)) < 1e-6
+    assert rel_err(t2n(m), mr) < 1e-6 and rel_err(t2n(v), vr) < 1e-6

@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: mel-frames/sec of one Tacotron2 train step (forward + backward + TF-Adam) at
+per-GPU batch 32 x (128 tokens, 800 mel frames), fp32, synthetic data (BASELINE.json configs[1]).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is the location-sensitive-attention step (the kernel
+pair north_star names), measured in situ with HIP events around every launch inside the native
+decoder loop of one extra, untimed step; `cpu_baseline` is the oracle (torch-CPU restatement of the
+same graph) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+B_PER_GPU, T_ENC, L_MEL = 32, 128, 800
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synthetic_batch(dims, B, Te, L, seed, rank, device):
+    """fixed-length random tokens / clipped-normal mels / whole-tensor-normalised speaker embeddings."""
+    g = np.random.default_rng(seed + rank)
+    tok = g.integers(2, dims.n_tok, size=(B, Te)).astype(np.int32)
+    tok[:, 0] = 0
+    tok[:, -1] = 1
+    mel = np.clip(g.normal(0, 1.5, size=(B, L, dims.n_mel)), -4, 4).astype(np.float32)
+    spk = g.normal(0, 1, size=(B, dims.spk))
+    spk = (spk / np.sqrt((spk ** 2).sum())).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(device).contiguous()
+    return {"Token": t(tok), "Token_Length": t(np.full(B, Te, np.int32)), "Mel": t(mel),
+            "Mel_Length": t(np.full(B, L, np.int32)), "Speaker_Embedding": t(spk)}
+
+
+def _cpu_baseline_worker(threads, budget_s):
+    """Oracle train step (fwd + autograd bwd + TF-Adam) on `threads` host threads, bounded sample."""
+    from oracle import model as OM, train as OT
+    torch.set_num_threads(threads)
+    d = OM.Dims()
+    params = OM.init_params(d, 1234)
+
+    def run(L):
+        batch = OT.synthetic_batch(d, B_PER_GPU, T_ENC, L, seed=1234)
+        masks = OT.make_masks(d, B_PER_GPU, T_ENC, L + 1, True, seed=OT.step_seed(1234, 0))
+        t0 = time.perf_counter()
+        OT.train_step(params, None, d, batch, masks, 0, dtype=torch.float32)
+        return time.perf_counter() - t0
+
+    run(4)                                              # warm the thread pool / allocator
+    L = 100                                             # fixed bounded sample: first 100 of the 800 frames
+    t = run(L)
+    if t < 0.5 * budget_s:                              # fast host: spend the budget on a longer sample
+        L = int(min(L_MEL, L * budget_s / t))
+        t = run(L)
+    return {"value": B_PER_GPU * L / t, "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "sample": "1 train step (fwd+bwd+TF-Adam) of the torch-CPU fp32 oracle at batch %d x (%d tokens, first %d of %d mel frames) on %d of %d host threads, %.1f s"
+                      % (B_PER_GPU, T_ENC, L, L_MEL, threads, os.cpu_count(), t)}
+
+
+def cpu_baseline(budget_s=15.0, timeout_s=240):
+    """Run the worker in a subprocess with a hard time limit (a huge host can thrash torch's
+    intra-op pool on the small per-step GEMMs; threads are capped at 32)."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 32)
+    code = "import json,bench;print('CPUBASE'+json.dumps(bench._cpu_baseline_worker(%d,%f)))" % (threads, budget_s)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    try:
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s).stdout
+        for line in out.splitlines():
+            if line.startswith("CPUBASE"):
+                return json.loads(line[len("CPUBASE"):])
+    except subprocess.TimeoutExpired:
+        pass
+    return {"value": None, "unit": "mel-frames/s", "cores": threads, "kind": "port", "sample": "oracle did not finish within %d s" % timeout_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--frames", type=int, default=L_MEL, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from multi_speaker_tts_amd import lib
+    from multi_speaker_tts_amd.engine import TrainEngine
+    from multi_speaker_tts_amd.params import Dims
+    from multi_speaker_tts_amd.dist import GradAllReduce
+
+    dims = Dims()
+    L = args.frames
+    eng = TrainEngine(dims, device=device, seed=1234, rank=rank, world=world)
+    batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
+    reducer = GradAllReduce(eng.params.grad, world) if world > 1 else None
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(batch, all_reduce=reducer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(batch, all_reduce=reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B_PER_GPU * L / (elapsed / args.steps)
+
+    out = {"metric": "mel-frames/sec (train step) at batch 32x(128 tok,800 mel)", "value": value, "unit": "mel-frames/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[1]: Tacotron2 train step (fwd+bwd+TF-Adam), per-GPU batch %d x (%d tokens, %d mel frames), random speaker embeddings, fp32"
+                                  % (B_PER_GPU, T_ENC, L),
+                      "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world}}
+
+    if rank == 0 and not args.no_roofline:
+        w = eng.plan(B_PER_GPU, T_ENC, L)
+        S = L + 1
+        lb = lib.load()
+        kinds = {"lsa_energy_fwd": 1, "lsa_context_fwd": 2, "cell0_gemm_fwd": 3, "cell1_gemm_fwd": 4,
+                 "lsa_dalign_bwd": 5, "lsa_denergy_bwd": 6, "cell0_dgemm_bwd": 7, "cell1_dgemm_bwd": 8}
+        avg_us = {}
+        for name, kind in kinds.items():
+            lb.mstts_probe_begin(kind, S)
+            eng.forward(batch, w)
+            if kind >= 5:
+                eng.loss_and_backward(w)
+            torch.cuda.synchronize()
+            tot = ctypes.c_double(0.0)
+            n = lb.mstts_probe_result(ctypes.byref(tot))
+            avg_us[name] = 1e3 * tot.value / max(n, 1)
+        lb.mstts_probe_begin(0, 0)
+        M, A, H = dims.mem, dims.att, dims.dec_lstm
+        # attention step, algorithmic bytes per row-step: keys + values + cum r/w + alignment write
+        att_bytes = B_PER_GPU * (T_ENC * A * 4 + T_ENC * M * 4 + 3 * T_ENC * 4)
+        att_us = avg_us["lsa_energy_fwd"] + avg_us["lsa_context_fwd"]
+        ach = att_bytes / (att_us * 1e-6) / 1e9
+        out["roofline"] = {"kernel": "lsa_step_fwd = lsa_energy_kernel + lsa_context_kernel (one decoder step, B=32)",
+                           "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": att_bytes, "avg_launch_us": att_us}
+        w0 = (M + H) * 4 * H * 4
+        w1 = 2 * H * 4 * H * 4
+        extra = []
+        for nm, byts in (("cell0_gemm_fwd", w0), ("cell1_gemm_fwd", w1), ("cell0_dgemm_bwd", w0), ("cell1_dgemm_bwd", w1)):
+            a = byts / (avg_us[nm] * 1e-6) / 1e9
+            extra.append({"kernel": nm, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": byts, "avg_launch_us": avg_us[nm]})
+        out["roofline_other"] = extra
+        out["kernel_avg_us"] = avg_us
+        out["step_flops_fraction_of_fp32_mfma_peak"] = (4.047e12 * L / L_MEL) / (ms_per_step * 1e-3) / 157.3e12
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

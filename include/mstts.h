@@ -103,6 +103,7 @@ int mstts_highway_combine(const float* h_pre, const float* t_pre, const float* x
 typedef struct {
     int64_t B, H;
     const float* gates_h;            /* [B,4H] recurrent (and per-step input) product, no bias */
+    int32_t gates_parts; int64_t gates_pstride;   /* gates_h = sum of `gates_parts` slabs (0/1 = single) */
     const float* xw; int64_t xw_sb, xw_st;   /* hoisted input product incl. bias, or NULL */
     const float* bias;               /* [4H] or NULL (when already folded into xw) */
     const float* c_prev; const float* h_prev; int64_t h_prev_ld;   /* h_prev row stride (0 -> H) */
@@ -120,9 +121,12 @@ int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_stream_t s);
 typedef struct {
     int64_t B, H;
     const float* d_out; int64_t dout_sb, dout_st;   /* grad wrt the cell output m (row b at pos) or NULL */
+    int32_t dout_parts; int64_t dout_pstride;       /* d_out = sum of slabs (0/1 = single) */
     const float* d_out2;             /* second [B,H] addend to the output grad or NULL */
+    int32_t dout2_parts; int64_t dout2_pstride;     /* ... itself a sum of slabs (0/1 = single) */
     const float* d_c_state; const float* d_h_state; /* [B,H] grads wrt c', h' from step+1 */
     const float* d_h_state2; int64_t dhs2_ld;       /* optional second addend of d_h_state (row stride) or NULL */
+    int32_t dhs2_parts; int64_t dhs2_pstride;       /* ... itself a sum of slabs (0/1 = single) */
     const float* acts; const float* c_raw; const float* c_prev;
     const uint8_t* zc; const uint8_t* zh;
     float zoneout;
@@ -143,7 +147,10 @@ typedef struct {
     const float* keys; const float* values; const int32_t* lengths;
     const float* conv_k; const float* conv_b; const float* dense_k; const float* score_w; const float* score_b;
 } mstts_lsa_const;
-int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, const float* cum, float* energy, mstts_stream_t s);
+/* q = sum of q_parts slabs of [B,A] (slab stride q_pstride; parts 0/1 = single); when q_sum != NULL the
+ * summed query is also stored there (the BPTT save). */
+int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                         const float* cum, float* energy, mstts_stream_t s);
 /* ctx row b is written at ctx + b*ctx_ld (and, when ctx2 != NULL, also at ctx2 + b*ctx2_ld) so the
  * decoder can place it straight into the next step's GEMM input rows. */
 int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* energy, const float* cum, float* align, float* cum_next,
@@ -153,7 +160,7 @@ int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* energy, const f
  *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); d_f = g . Wd^T; saves d_e */
 /* d_ctx row b = d_ctx[b*d_ctx_ld ..] (+ d_ctx2[b*d_ctx2_ld ..] when d_ctx2 != NULL) */
 int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
-                         const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s);
+                         int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s);
 int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* align, const float* d_align, const float* q, const float* cum,
                           float* d_e, float* dq, float* d_f, mstts_stream_t s);
 /* post-loop parameter gradients over all S steps (recomputes tanh tiles from the saved d_e):
@@ -204,6 +211,18 @@ int mstts_stft_mel(const float* wav, int64_t n, float preemph, const float* dft_
                    int32_t n_fft, int32_t hop, int32_t win, int32_t n_mel, float max_abs, float* ws, float* mel_out,
                    int64_t frames, mstts_stream_t s);
 int64_t mstts_stft_mel_ws_floats(int64_t n, int32_t n_fft, int64_t frames);
+
+/* ---- skinny (M <= 32 rows per block) weight-streaming products of the recurrent steps -------------
+ * fwd: P[ks][M][N] = X[M, K-slice ks] . W[K-slice ks, N]   (W row-major [K,N], ld ldw); ksplit from
+ *      mstts_skinny_fwd_splits (0 = shape not supported -> use mstts_gemm_f32).
+ * bwd: P[ns][M][R] = dG[M, N-slice ns] . W[R, N-slice ns]^T (W row-major [R,N]).
+ * The consumer sums the partial slabs. */
+int32_t mstts_skinny_fwd_splits(int64_t N, int64_t K);
+int mstts_skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, float* P, int64_t pstride, int64_t M, int64_t N,
+                     int64_t K, int32_t ksplit, mstts_stream_t s);   /* pstride: floats between slabs (0 -> M*N) */
+int32_t mstts_skinny_bwd_splits(int64_t R, int64_t N);
+int mstts_skinny_bwd(const float* dG, int64_t ldg, const float* W, int64_t ldw, float* P, int64_t pstride, int64_t M, int64_t R,
+                     int64_t N, int32_t nsplit, mstts_stream_t s);
 
 /* ---- LSTM weight utilities --------------------------------------------------------------------
  * fold_rows: dst[r,:] = src[r,:] for r<r0 ; dst[r0+i,:] = src[r0+i,:] + src[r0+n+i,:] (i<n) ; rest shifted up.
@@ -271,22 +290,27 @@ typedef struct {
     float* in0; float* in1; float* pj;
     float* c0; float* c1; float* acts0; float* acts1; float* craw0; float* craw1;
     float* q_hist; float* align_hist; float* cum_hist;
-    float* gates_ws; float* energy_ws;      /* [B,4H], [B,T] */
+    float* gates_ws; float* energy_ws;      /* [parts,B,4H] (parts = max skinny K-splits, see mstts_decoder_train_ws_floats), [B,T] */
+    float* q_ws;                            /* [parts,B,A] query partials */
 } mstts_decoder_train_desc;
+/* floats needed for gates_ws (*gates) and q_ws (*q) */
+int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q);
 int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s);
 
 /* BPTT through the same S steps.  d_pj [S,B,H+M] holds the projection's input gradient on entry
  * (d_m1 | d_ctx) and is updated in place.  Outputs for the hoisted gradient GEMMs:
  *   dg0/dg1 [S,B,4H], dq_hist [S,B,A] (must be zeroed by the caller), de_hist [S,B,T],
- *   d_in0 [S,B,M+H] = dg0.w0f^T per step (rows of step s are the gradient of in0 slot s).
- * ws: 6*B*H + 2*B*T + 2*B*T*CH + B*2H + B*T floats. */
+ *   d_in0 [parts0,S,B,M+H] = partial slabs of dg0.w0f^T per step (rows of step s are the gradient of in0
+ *   slot s; parts0 = mstts_decoder_train_bwd_parts(...); the slabs must be summed by the consumer).
+ * ws: mstts_decoder_train_bwd_ws_floats(...) floats. */
 typedef struct {
     const mstts_decoder_train_desc* fwd;
     float* d_pj; float* dg0; float* dg1; float* dq_hist; float* de_hist; float* d_in0;
     float* ws;
 } mstts_decoder_train_bwd_desc;
 int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* d, mstts_stream_t s);
-int64_t mstts_decoder_train_bwd_ws_floats(int64_t B, int64_t H, int64_t T, int64_t CH);
+int64_t mstts_decoder_train_bwd_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t CH);
+int32_t mstts_decoder_train_bwd_parts(int64_t H, int64_t M);   /* number of d_in0 slabs */
 
 /* ---- free-running decoder steps (inference branch of Decoder_Helper.next_inputs,
  * Modules.py:212-237): enqueues steps [step0, step0+n).  frame feedback: step s reads its input
@@ -310,6 +334,16 @@ typedef struct {
 } mstts_decoder_infer_desc;
 int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);
 int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel);
+
+/* ---- profiling probes (bench.py only; process-global, not thread-safe, never armed on the product
+ * path): HIP events bracket every launch of one kernel kind inside the decoder loop drivers, on the
+ * launch stream.  begin(kind, max_launches) arms (kind 0 disarms); after a stream synchronise,
+ * result() returns the number of bracketed launches and their summed duration in ms. */
+enum { MSTTS_PROBE_OFF = 0, MSTTS_PROBE_LSA_ENERGY = 1, MSTTS_PROBE_LSA_CONTEXT = 2, MSTTS_PROBE_CELL0_GEMM = 3,
+       MSTTS_PROBE_CELL1_GEMM = 4, MSTTS_PROBE_LSA_DALIGN = 5, MSTTS_PROBE_LSA_DENERGY = 6, MSTTS_PROBE_CELL0_DGEMM = 7,
+       MSTTS_PROBE_CELL1_DGEMM = 8 };
+int mstts_probe_begin(int32_t kind, int64_t max_launches);
+int64_t mstts_probe_result(double* total_ms);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,45 @@ using namespace mstts;
 
 #define RC(call) do { int rc__ = (call); if (rc__ != MSTTS_OK) return rc__; } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// Profiling probes (bench.py only): HIP events bracketing every launch of one selected kernel kind
+// inside the loop drivers, on the stream the kernel is launched on.  Process-global and not
+// thread-safe by design - never armed on the product path.
+// ---------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct Probe {
+    int kind = 0;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+} g_probe;
+inline bool probe_on(int kind) { return g_probe.kind == kind && g_probe.used + 2 <= g_probe.ev.size(); }
+inline void probe_mark(mstts_stream_t s) { hipEventRecord(g_probe.ev[g_probe.used++], (hipStream_t)s); }
+}  // namespace
+#define PROBED(kind, s, call) do { const bool pr__ = probe_on(kind); if (pr__) probe_mark(s); RC(call); if (pr__) probe_mark(s); } while (0)
+
+extern "C" int mstts_probe_begin(int32_t kind, int64_t max_launches) {
+    for (hipEvent_t e : g_probe.ev) hipEventDestroy(e);
+    g_probe.ev.clear();
+    g_probe.used = 0;
+    g_probe.kind = kind;
+    if (kind == 0) return MSTTS_OK;
+    g_probe.ev.resize((size_t)max_launches * 2);
+    for (auto& e : g_probe.ev)
+        if (hipEventCreate(&e) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "probe: hipEventCreate failed");
+    return MSTTS_OK;
+}
+/* after a stream synchronise: number of bracketed launches and their summed duration (ms) */
+extern "C" int64_t mstts_probe_result(double* total_ms) {
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < g_probe.used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_probe.ev[i], g_probe.ev[i + 1]) == hipSuccess) tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    return (int64_t)(g_probe.used / 2);
+}
+
 static int gemm(const float* A, long lda, const float* B, long ldb, int trans_b, float* C, long ldc, long M, long N, long K,
                 const float* bias, int act, int accumulate, mstts_stream_t s) {
     mstts_gemm_desc g;
@@ -83,13 +122,45 @@ extern "C" int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream
 // ---------------------------------------------------------------------------------------------
 // teacher-forced decoder loop
 // ---------------------------------------------------------------------------------------------
+// X[M,K] . W[K,N]: skinny K-split kernel when the shape fits (parts slabs in P), else the tiled GEMM
+static int xw_fwd(const float* X, long ldx, const float* W, long ldw, float* P, long M, long N, long K, int splits, int* parts,
+                  mstts_stream_t s) {
+    if (splits > 0 && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(X) && aligned16(W)) {
+        *parts = splits;
+        return mstts_skinny_fwd(X, ldx, W, ldw, P, 0, M, N, K, splits, s);
+    }
+    *parts = 1;
+    return gemm(X, ldx, W, ldw, 0, P, N, M, N, K, nullptr, 0, 0, s);
+}
+// dG[M,N] . W[R,N]^T
+static int xw_bwd(const float* dG, long ldg, const float* W, long ldw, float* P, long pstride, long M, long R, long N, int splits,
+                  int* parts, mstts_stream_t s) {
+    if (splits > 0 && ldg % 4 == 0 && ldw % 4 == 0 && aligned16(dG) && aligned16(W)) {
+        *parts = splits;
+        return mstts_skinny_bwd(dG, ldg, W, ldw, P, pstride, M, R, N, splits, s);
+    }
+    *parts = 1;
+    return gemm(dG, ldg, W, ldw, 1, P, R, M, R, N, nullptr, 0, 0, s);
+}
+
+extern "C" int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q) {
+    int p0 = mstts_skinny_fwd_splits(4 * H, M + H), p1 = mstts_skinny_fwd_splits(4 * H, 2 * H), pq = mstts_skinny_fwd_splits(A, H);
+    int pg = p0 > p1 ? p0 : p1;
+    if (pg < 1) pg = 1;
+    if (pq < 1) pq = 1;
+    if (gates) *gates = (int64_t)pg * B * 4 * H;
+    if (q) *q = (int64_t)pq * B * A;
+    return MSTTS_OK;
+}
+
 extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s) {
     MSTTS_REQUIRE(d && d->xw0 && d->w0f && d->w1 && d->b1 && d->wq && d->in0 && d->in1 && d->pj && d->c0 && d->c1 &&
                   d->acts0 && d->acts1 && d->craw0 && d->craw1 && d->q_hist && d->align_hist && d->cum_hist && d->gates_ws &&
-                  d->energy_ws, MSTTS_ERR_SHAPE, "decoder_train_fwd: null pointer");
+                  d->energy_ws && d->q_ws, MSTTS_ERR_SHAPE, "decoder_train_fwd: null pointer");
     const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
     MSTTS_REQUIRE(d->lsa.B == B, MSTTS_ERR_SHAPE, "decoder_train_fwd: lsa.B != B");
     const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M;
+    const int sp0 = mstts_skinny_fwd_splits(4 * H, W0), sp1 = mstts_skinny_fwd_splits(4 * H, W1), spq = mstts_skinny_fwd_splits(A, H);
     RC(zero(d->in0, B * W0, s));
     RC(zero(d->in1, B * W1, s));
     RC(zero(d->c0, BH, s));
@@ -97,10 +168,11 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     RC(zero(d->cum_hist, B * T, s));
     for (long st = 0; st < S; ++st) {
         mstts_lstm_point_fwd_desc p;
+        int parts = 1;
         // ---- cell 0: gates = [ctx | h0] . w0f + xw0[st]
-        RC(gemm(d->in0 + st * B * W0, W0, d->w0f, 4 * H, 0, d->gates_ws, 4 * H, B, 4 * H, W0, nullptr, 0, 0, s));
+        PROBED(MSTTS_PROBE_CELL0_GEMM, s, xw_fwd(d->in0 + st * B * W0, W0, d->w0f, 4 * H, d->gates_ws, B, 4 * H, W0, sp0, &parts, s));
         memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H; p.gates_h = d->gates_ws;
+        p.B = B; p.H = H; p.gates_h = d->gates_ws; p.gates_parts = parts; p.gates_pstride = 4 * BH;
         p.xw = d->xw0 + st * 4 * BH; p.xw_sb = 4 * H; p.xw_st = 0;
         p.c_prev = d->c0 + st * BH; p.h_prev = d->in0 + st * B * W0 + M; p.h_prev_ld = W0;
         p.zc = d->zc0 ? d->zc0 + st * BH : nullptr; p.zh = d->zh0 ? d->zh0 + st * BH : nullptr;
@@ -110,9 +182,9 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
         p.acts_out = d->acts0 + st * 4 * BH; p.c_raw = d->craw0 + st * BH;
         RC(mstts_lstm_point_fwd(&p, s));
         // ---- cell 1: gates = [m0 | h1] . w1 + b1
-        RC(gemm(d->in1 + st * B * W1, W1, d->w1, 4 * H, 0, d->gates_ws, 4 * H, B, 4 * H, W1, nullptr, 0, 0, s));
+        PROBED(MSTTS_PROBE_CELL1_GEMM, s, xw_fwd(d->in1 + st * B * W1, W1, d->w1, 4 * H, d->gates_ws, B, 4 * H, W1, sp1, &parts, s));
         memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H; p.gates_h = d->gates_ws; p.bias = d->b1;
+        p.B = B; p.H = H; p.gates_h = d->gates_ws; p.gates_parts = parts; p.gates_pstride = 4 * BH; p.bias = d->b1;
         p.c_prev = d->c1 + st * BH; p.h_prev = d->in1 + st * B * W1 + H; p.h_prev_ld = W1;
         p.zc = d->zc1 ? d->zc1 + st * BH : nullptr; p.zh = d->zh1 ? d->zh1 + st * BH : nullptr;
         p.zoneout = d->zoneout;
@@ -120,19 +192,27 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
         p.c_next = d->c1 + (st + 1) * BH; p.h_next = d->in1 + (st + 1) * B * W1 + H; p.h_next_ld = W1;
         p.acts_out = d->acts1 + st * 4 * BH; p.c_raw = d->craw1 + st * BH;
         RC(mstts_lstm_point_fwd(&p, s));
-        // ---- query + attention
+        // ---- query (partials summed inside the energy kernel, which also saves q) + attention
         float* q = d->q_hist + st * B * A;
-        RC(gemm(d->pj + st * B * WP, WP, d->wq, A, 0, q, A, B, A, H, nullptr, 0, 0, s));
+        RC(xw_fwd(d->pj + st * B * WP, WP, d->wq, A, d->q_ws, B, A, H, spq, &parts, s));
         const float* cum = d->cum_hist + st * B * T;
-        RC(mstts_lsa_energy_fwd(&d->lsa, q, cum, d->energy_ws, s));
-        RC(mstts_lsa_context_fwd(&d->lsa, d->energy_ws, cum, d->align_hist + st * B * T, d->cum_hist + (st + 1) * B * T,
+        PROBED(MSTTS_PROBE_LSA_ENERGY, s, mstts_lsa_energy_fwd(&d->lsa, d->q_ws, parts, B * A, q, cum, d->energy_ws, s));
+        PROBED(MSTTS_PROBE_LSA_CONTEXT, s, mstts_lsa_context_fwd(&d->lsa, d->energy_ws, cum, d->align_hist + st * B * T, d->cum_hist + (st + 1) * B * T,
                                  d->in0 + (st + 1) * B * W0, W0, d->pj + st * B * WP + H, WP, s));
     }
     return MSTTS_OK;
 }
 
-extern "C" int64_t mstts_decoder_train_bwd_ws_floats(int64_t B, int64_t H, int64_t T, int64_t CH) {
-    return 8 * B * H + 2 * B * T + 2 * B * T * CH + B * T + B * 2 * H;
+extern "C" int32_t mstts_decoder_train_bwd_parts(int64_t H, int64_t M) {
+    const int p = mstts_skinny_bwd_splits(M + H, 4 * H);
+    return p > 0 ? p : 1;
+}
+
+extern "C" int64_t mstts_decoder_train_bwd_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t CH) {
+    int p1 = mstts_skinny_bwd_splits(2 * H, 4 * H), pq = mstts_skinny_bwd_splits(H, A);
+    if (p1 < 1) p1 = 1;
+    if (pq < 1) pq = 1;
+    return 8 * B * H + 2 * B * T + 2 * B * T * CH + B * T + (int64_t)p1 * B * 2 * H + (int64_t)pq * B * H;
 }
 
 extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, mstts_stream_t s) {
@@ -141,6 +221,9 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     const mstts_decoder_train_desc* d = bd->fwd;
     const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T, CH = d->lsa.CH;
     const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M, BT = B * T;
+    const int sp1 = mstts_skinny_bwd_splits(W1, 4 * H), sp0 = mstts_skinny_bwd_splits(W0, 4 * H), spq = mstts_skinny_bwd_splits(H, A);
+    const int np1 = sp1 > 0 ? sp1 : 1, npq = spq > 0 ? spq : 1;
+    const long d_in0_slab = S * B * W0;
     float* w = bd->ws;
     float* dc0[2] = {w, w + BH};           w += 2 * BH;
     float* dh0[2] = {w, w + BH};           w += 2 * BH;
@@ -149,27 +232,29 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     float* G[2] = {w, w + BT};             w += 2 * BT;
     float* df[2] = {w, w + BT * CH};       w += 2 * BT * CH;
     float* d_align = w;                    w += BT;
-    float* tmp1 = w;                       w += B * W1;
+    float* tmp1 = w;                       w += (long)np1 * B * W1;     // [parts][B][2H]
+    float* dqm = w;                        w += (long)npq * BH;         // [parts][B][H]
     RC(zero(bd->ws, 8 * BH, s));
-    int cur = 0;
+    int cur = 0, parts0 = 1, parts1 = 1, partsq = 1;
     for (long st = S - 1; st >= 0; --st) {
         const int nxt = cur ^ 1;
         const bool last = (st == S - 1);
         float* dpj = bd->d_pj + st * B * WP;
         // ---- attention backward
-        RC(mstts_lsa_dalign_bwd(&d->lsa, dpj + H, WP, last ? nullptr : bd->d_in0 + (st + 1) * B * W0, W0,
-                                last ? nullptr : G[cur], last ? nullptr : df[cur], G[nxt], d_align, s));
-        RC(mstts_lsa_denergy_bwd(&d->lsa, d->align_hist + st * BT, d_align, d->q_hist + st * B * A, d->cum_hist + st * BT,
+        PROBED(MSTTS_PROBE_LSA_DALIGN, s, mstts_lsa_dalign_bwd(&d->lsa, dpj + H, WP, last ? nullptr : bd->d_in0 + (st + 1) * B * W0, W0,
+                                parts0, d_in0_slab, last ? nullptr : G[cur], last ? nullptr : df[cur], G[nxt], d_align, s));
+        PROBED(MSTTS_PROBE_LSA_DENERGY, s, mstts_lsa_denergy_bwd(&d->lsa, d->align_hist + st * BT, d_align, d->q_hist + st * B * A, d->cum_hist + st * BT,
                                  bd->de_hist + st * BT, bd->dq_hist + st * B * A, df[nxt], s));
-        // d_m1 += dq . Wq^T
-        RC(gemm(bd->dq_hist + st * B * A, A, d->wq, A, 1, dpj, WP, B, H, A, nullptr, 0, 1, s));
+        // d_m1 (query path) = dq . Wq^T  -> slabs consumed by the cell-1 pointwise kernel
+        RC(xw_bwd(bd->dq_hist + st * B * A, A, d->wq, A, dqm, 0, B, H, A, spq, &partsq, s));
         // ---- cell 1 backward
         mstts_lstm_point_bwd_desc p;
         memset(&p, 0, sizeof(p));
         p.B = B; p.H = H;
         p.d_out = dpj; p.dout_sb = WP; p.dout_st = 0;
+        p.d_out2 = dqm; p.dout2_parts = partsq; p.dout2_pstride = BH;
         p.d_c_state = dc1[cur]; p.d_h_state = dh1[cur];
-        p.d_h_state2 = last ? nullptr : tmp1 + H; p.dhs2_ld = W1;
+        p.d_h_state2 = last ? nullptr : tmp1 + H; p.dhs2_ld = W1; p.dhs2_parts = parts1; p.dhs2_pstride = B * W1;
         p.acts = d->acts1 + st * 4 * BH; p.c_raw = d->craw1 + st * BH; p.c_prev = d->c1 + st * BH;
         p.zc = d->zc1 ? d->zc1 + st * BH : nullptr; p.zh = d->zh1 ? d->zh1 + st * BH : nullptr;
         p.zoneout = d->zoneout;
@@ -177,21 +262,21 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
         p.d_c_prev = dc1[nxt]; p.d_h_prev = dh1[nxt];
         RC(mstts_lstm_point_bwd(&p, s));
         // [d_m0 | d_h1 state] = dg1 . w1^T
-        RC(gemm(p.dgates, 4 * H, d->w1, 4 * H, 1, tmp1, W1, B, W1, 4 * H, nullptr, 0, 0, s));
+        PROBED(MSTTS_PROBE_CELL1_DGEMM, s, xw_bwd(p.dgates, 4 * H, d->w1, 4 * H, tmp1, 0, B, W1, 4 * H, sp1, &parts1, s));
         // ---- cell 0 backward
         memset(&p, 0, sizeof(p));
         p.B = B; p.H = H;
-        p.d_out = tmp1; p.dout_sb = W1; p.dout_st = 0;
+        p.d_out = tmp1; p.dout_sb = W1; p.dout_st = 0; p.dout_parts = parts1; p.dout_pstride = B * W1;
         p.d_c_state = dc0[cur]; p.d_h_state = dh0[cur];
-        p.d_h_state2 = last ? nullptr : bd->d_in0 + (st + 1) * B * W0 + M; p.dhs2_ld = W0;
+        p.d_h_state2 = last ? nullptr : bd->d_in0 + (st + 1) * B * W0 + M; p.dhs2_ld = W0; p.dhs2_parts = parts0; p.dhs2_pstride = d_in0_slab;
         p.acts = d->acts0 + st * 4 * BH; p.c_raw = d->craw0 + st * BH; p.c_prev = d->c0 + st * BH;
         p.zc = d->zc0 ? d->zc0 + st * BH : nullptr; p.zh = d->zh0 ? d->zh0 + st * BH : nullptr;
         p.zoneout = d->zoneout;
         p.dgates = bd->dg0 + st * 4 * BH;
         p.d_c_prev = dc0[nxt]; p.d_h_prev = dh0[nxt];
         RC(mstts_lstm_point_bwd(&p, s));
-        // [d_ctx_{st-1} | d_h0 state] = dg0 . w0f^T
-        RC(gemm(p.dgates, 4 * H, d->w0f, 4 * H, 1, bd->d_in0 + st * B * W0, W0, B, W0, 4 * H, nullptr, 0, 0, s));
+        // [d_ctx_{st-1} | d_h0 state] = dg0 . w0f^T   (slabs at stride S*B*W0)
+        PROBED(MSTTS_PROBE_CELL0_DGEMM, s, xw_bwd(p.dgates, 4 * H, d->w0f, 4 * H, bd->d_in0 + st * B * W0, d_in0_slab, B, W0, 4 * H, sp0, &parts0, s));
         cur = nxt;
     }
     return MSTTS_OK;
@@ -255,7 +340,7 @@ extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int6
         RC(mstts_lstm_point_fwd(&p, s));
         // attention
         RC(gemm(d->pj, WP, d->wq, A, 0, q, A, B, A, H, nullptr, 0, 0, s));
-        RC(mstts_lsa_energy_fwd(&d->lsa, q, d->cum + par * BT, energy, s));
+        RC(mstts_lsa_energy_fwd(&d->lsa, q, 1, 0, nullptr, d->cum + par * BT, energy, s));
         RC(mstts_lsa_context_fwd(&d->lsa, energy, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
                                  in0n, W0, d->pj + H, WP, s));
         // projection: [m1 | ctx] . Wp + b -> linear (n_mel) and stop (1)

@@ -50,8 +50,9 @@ __device__ __forceinline__ void location_features(const mstts_lsa_const& c, cons
 // ---------------------------------------------------------------------------------------------
 // forward: energies
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, const float* __restrict__ q,
-                                                         const float* __restrict__ cum, float* __restrict__ energy) {
+__global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
+                                                         float* __restrict__ q_sum, const float* __restrict__ cum,
+                                                         float* __restrict__ energy) {
     __shared__ float s_cum[TS + KS_MAX - 1];
     __shared__ float s_ck[KS_MAX * CH_];
     __shared__ float s_f[TS][CH_ + 1];
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, cons
     float dk[CH_];
 #pragma unroll
     for (int ch = 0; ch < CH_; ++ch) dk[ch] = c.dense_k[ch * A_ + k];
-    const float qk = q[(long)b * A_ + k] + c.score_b[k];
+    float qv = q[(long)b * A_ + k];
+    for (int pp = 1; pp < q_parts; ++pp) qv += q[pp * q_pstride + (long)b * A_ + k];
+    if (q_sum && blockIdx.y == 0 && grp == 0) q_sum[(long)b * A_ + k] = qv;
+    const float qk = qv + c.score_b[k];
     const float wk = c.score_w[k];
     const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
 #pragma unroll
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, con
 // backward: d_align  (G = dL/d cum_{s+1})
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, const float* __restrict__ d_ctx, long d_ctx_ld,
-                                                         const float* __restrict__ d_ctx2, long d_ctx2_ld,
+                                                         const float* __restrict__ d_ctx2, long d_ctx2_ld, int d_ctx2_parts, long d_ctx2_pstride,
                                                          const float* __restrict__ G_next, const float* __restrict__ d_f_next,
                                                          float* __restrict__ G, float* __restrict__ d_align) {
     __shared__ float s_df[TS + KS_MAX - 1][CH_ + 1];
@@ -195,8 +199,10 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
                 const float4 x = *reinterpret_cast<const float4*>(v + i);
                 float4 y = *reinterpret_cast<const float4*>(dc + i);
                 if (dc2) {
-                    const float4 y2 = *reinterpret_cast<const float4*>(dc2 + i);
-                    y.x += y2.x; y.y += y2.y; y.z += y2.z; y.w += y2.w;
+                    for (int pp = 0; pp < max(d_ctx2_parts, 1); ++pp) {
+                        const float4 y2 = *reinterpret_cast<const float4*>(dc2 + pp * d_ctx2_pstride + i);
+                        y.x += y2.x; y.y += y2.y; y.z += y2.z; y.w += y2.w;
+                    }
                 }
                 acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
             }
@@ -401,9 +407,10 @@ static int check_const(const mstts_lsa_const* c) {
 using namespace mstts;
 #define ST(s) ((hipStream_t)(s))
 
-extern "C" int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, const float* cum, float* energy, mstts_stream_t s) {
+extern "C" int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                                    const float* cum, float* energy, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
-    hipLaunchKernelGGL(lsa_energy_kernel, dim3((unsigned)c->B, cdiv(c->T, TS)), dim3(256), 0, ST(s), *c, q, cum, energy);
+    hipLaunchKernelGGL(lsa_energy_kernel, dim3((unsigned)c->B, cdiv(c->T, TS)), dim3(256), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum, energy);
     MSTTS_CHECK_LAUNCH("lsa_energy_fwd");
     return MSTTS_OK;
 }
@@ -416,12 +423,12 @@ extern "C" int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* ener
     return MSTTS_OK;
 }
 extern "C" int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
-                                    const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s) {
+                                    int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(aligned16(d_ctx) && aligned16(d_ctx2) && d_ctx_ld % 4 == 0 && d_ctx2_ld % 4 == 0, MSTTS_ERR_ALIGN,
                   "lsa_dalign: d_ctx rows must be 16-byte aligned");
     hipLaunchKernelGGL(lsa_dalign_kernel, dim3((unsigned)c->B, cdiv(c->T, TS)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
-                       (long)d_ctx2_ld, G_next, d_f_next, G, d_align);
+                       (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, d_align);
     MSTTS_CHECK_LAUNCH("lsa_dalign_bwd");
     return MSTTS_OK;
 }

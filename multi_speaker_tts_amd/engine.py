@@ -127,7 +127,10 @@ class TrainEngine:
         w.acts0, w.acts1 = f(S, B, 4 * H), f(S, B, 4 * H)
         w.craw0, w.craw1 = f(S, B, H), f(S, B, H)
         w.q_hist, w.align_hist, w.cum_hist = f(S, B, A), f(S, B, Te), f(S + 1, B, Te)
-        w.gates_ws, w.energy_ws = f(B, 4 * H), f(B, Te)
+        lb = lib.load()
+        ng, nq = C.c_int64(0), C.c_int64(0)
+        lb.mstts_decoder_train_ws_floats(B, H, M, A, C.byref(ng), C.byref(nq))
+        w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(B, Te), f(int(nq.value))
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
         # postnet
@@ -160,9 +163,9 @@ class TrainEngine:
         w.d_pj = f(S, B, H + M)
         w.dg0, w.dg1 = f(S, B, 4 * H), f(S, B, 4 * H)
         w.dq_hist, w.de_hist = f(S, B, A), f(S, B, Te)
-        w.d_in0 = f(S, B, M + H)
-        lb = lib.load()
-        w.dec_bwd_ws = f(int(lb.mstts_decoder_train_bwd_ws_floats(B, H, Te, d.att_ch)))
+        w.d_in0_parts = int(lb.mstts_decoder_train_bwd_parts(H, M))
+        w.d_in0 = f(w.d_in0_parts, S, B, M + H)
+        w.dec_bwd_ws = f(int(lb.mstts_decoder_train_bwd_ws_floats(B, H, M, A, Te, d.att_ch)))
         w.d_pre = f(S * B, Pn)
         w.d_pre2 = f(S * B, Pn)
         w.d_keys = f(B, Te, A)
@@ -280,7 +283,7 @@ class TrainEngine:
         dec.xw0, dec.w0f, dec.w1, dec.b1, dec.wq = ptr(w.xw0), ptr(self.w0f), ptr(k1, o1), ptr(b1, ob1), ptr(wq, oq)
         dec.zc0, dec.zh0, dec.zc1, dec.zh1 = ptr(mk["dec_zc_0"]), ptr(mk["dec_zh_0"]), ptr(mk["dec_zc_1"]), ptr(mk["dec_zh_1"])
         dec.zoneout = d.zoneout
-        for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws"):
+        for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))
         call("mstts_decoder_train_fwd", C.byref(dec))
         # ---- projection (Modules.py:309-321) on all steps at once, then batch-major linear/stop
@@ -411,8 +414,9 @@ class TrainEngine:
         gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
              strides=(Te, H + M, Te * M), b_off=H)
         if S > 1:
-            gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
-                 strides=(Te, M + H, Te * M), b_off=B * (M + H), accumulate=True)
+            for part in range(w.d_in0_parts):
+                gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
+                     strides=(Te, M + H, Te * M), b_off=(part * S + 1) * B * (M + H), accumulate=True)
         # memory layer
         wm, owm = self.P("attention/memory_layer/kernel"); gwm, ogwm = self.G("attention/memory_layer/kernel")
         gemm(w.values, w.d_keys, gwm, M, A, B * Te, M, A, A, trans_a=True, split_k=max(2, _split_k(M, A, B * Te)), c_off=ogwm)

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
 
 
 class LstmPointFwd(C.Structure):
-    _fields_ = [("B", i64), ("H", i64), ("gates_h", vp), ("xw", vp), ("xw_sb", i64), ("xw_st", i64), ("bias", vp),
+    _fields_ = [("B", i64), ("H", i64), ("gates_h", vp), ("gates_parts", i32), ("gates_pstride", i64), ("xw", vp), ("xw_sb", i64), ("xw_st", i64), ("bias", vp),
                 ("c_prev", vp), ("h_prev", vp), ("h_prev_ld", i64), ("zc", vp), ("zh", vp), ("zoneout", f32),
                 ("lengths", vp), ("step", i32), ("reverse", i32), ("residual", vp), ("res_sb", i64), ("res_st", i64),
                 ("out", vp), ("out_sb", i64), ("out_st", i64), ("c_next", vp), ("h_next", vp), ("h_next_ld", i64),
@@ -36,8 +36,9 @@ class LstmPointFwd(C.Structure):
 
 
 class LstmPointBwd(C.Structure):
-    _fields_ = [("B", i64), ("H", i64), ("d_out", vp), ("dout_sb", i64), ("dout_st", i64), ("d_out2", vp),
-                ("d_c_state", vp), ("d_h_state", vp), ("d_h_state2", vp), ("dhs2_ld", i64),
+    _fields_ = [("B", i64), ("H", i64), ("d_out", vp), ("dout_sb", i64), ("dout_st", i64), ("dout_parts", i32), ("dout_pstride", i64),
+                ("d_out2", vp), ("dout2_parts", i32), ("dout2_pstride", i64),
+                ("d_c_state", vp), ("d_h_state", vp), ("d_h_state2", vp), ("dhs2_ld", i64), ("dhs2_parts", i32), ("dhs2_pstride", i64),
                 ("acts", vp), ("c_raw", vp), ("c_prev", vp), ("zc", vp), ("zh", vp), ("zoneout", f32),
                 ("lengths", vp), ("step", i32), ("reverse", i32), ("dgates", vp), ("dgates_pos", vp),
                 ("dgp_sb", i64), ("dgp_st", i64), ("d_c_prev", vp), ("d_h_prev", vp)]
@@ -68,7 +69,7 @@ class DecoderTrain(C.Structure):
                 ("zc0", vp), ("zh0", vp), ("zc1", vp), ("zh1", vp), ("zoneout", f32),
                 ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp),
                 ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
-                ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp)]
+                ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp)]
 
 
 class DecoderTrainBwd(C.Structure):
@@ -106,9 +107,9 @@ SIGNATURES = {
     "mstts_highway_combine": (i32, [vp, vp, vp, vp, i64, vp]),
     "mstts_lstm_point_fwd": (i32, [P(LstmPointFwd), vp]),
     "mstts_lstm_point_bwd": (i32, [P(LstmPointBwd), vp]),
-    "mstts_lsa_energy_fwd": (i32, [P(LsaConst), vp, vp, vp, vp]),
+    "mstts_lsa_energy_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp]),
     "mstts_lsa_context_fwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, i64, vp, i64, vp]),
-    "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, vp, vp, vp, vp, vp]),
+    "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "mstts_lsa_denergy_bwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, vp, vp, vp]),
     "mstts_lsa_param_bwd": (i32, [P(LsaConst), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mstts_tts_loss_fwd_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i32, f32, vp, vp, vp, vp, vp]),
@@ -126,9 +127,17 @@ SIGNATURES = {
     "mstts_lstm_seq_bwd": (i32, [P(LstmSeqBwd), vp]),
     "mstts_decoder_train_fwd": (i32, [P(DecoderTrain), vp]),
     "mstts_decoder_train_bwd": (i32, [P(DecoderTrainBwd), vp]),
-    "mstts_decoder_train_bwd_ws_floats": (i64, [i64, i64, i64, i64]),
+    "mstts_decoder_train_bwd_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
+    "mstts_decoder_train_bwd_parts": (i32, [i64, i64]),
+    "mstts_decoder_train_ws_floats": (i32, [i64, i64, i64, i64, C.POINTER(i64), C.POINTER(i64)]),
+    "mstts_skinny_fwd_splits": (i32, [i64, i64]),
+    "mstts_skinny_fwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
+    "mstts_skinny_bwd_splits": (i32, [i64, i64]),
+    "mstts_skinny_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_decoder_infer_steps": (i32, [P(DecoderInfer), i64, i64, vp]),
     "mstts_decoder_infer_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
+    "mstts_probe_begin": (i32, [i32, i64]),
+    "mstts_probe_result": (i64, [C.POINTER(C.c_double)]),
 }
 
 _lib = None

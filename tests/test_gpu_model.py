@@ -83,7 +83,7 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     c.dense_k, c.score_w, c.score_b = lib.ptr(dp[LSA + "attention_convolution_dense_layer/dense/kernel"]), lib.ptr(dp[LSA + "score_layer/weight_w"]), lib.ptr(dp[LSA + "score_layer/bias_b"])
     q = f32(query @ p[LSA + "query_layer/kernel"]); dcum = f32(cum)
     en, al, cn, cx = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
-    lib.call("mstts_lsa_energy_fwd", C.byref(c), lib.ptr(q), lib.ptr(dcum), lib.ptr(en))
+    lib.call("mstts_lsa_energy_fwd", C.byref(c), lib.ptr(q), 1, 0, None, lib.ptr(dcum), lib.ptr(en))
     lib.call("mstts_lsa_context_fwd", C.byref(c), lib.ptr(en), lib.ptr(dcum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0)
     assert rel_err(t2n(al), t2n(align)) < 2e-5 and rel_err(t2n(cn), t2n(cum_next)) < 2e-5 and rel_err(t2n(cx), t2n(ctx)) < 2e-5
     # backward: upstream grads on ctx and on the next cumulative state
@@ -94,7 +94,7 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     obj.backward()
     G, da = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev)
     d_ctx_d, G_next_d, d_f_next_d = f32(d_ctx), f32(G_next), f32(d_f_next)     # keep alive: the calls are asynchronous
-    lib.call("mstts_lsa_dalign_bwd", C.byref(c), lib.ptr(d_ctx_d), M, None, 0, lib.ptr(G_next_d), lib.ptr(d_f_next_d), lib.ptr(G), lib.ptr(da))
+    lib.call("mstts_lsa_dalign_bwd", C.byref(c), lib.ptr(d_ctx_d), M, None, 0, 0, 0, lib.ptr(G_next_d), lib.ptr(d_f_next_d), lib.ptr(G), lib.ptr(da))
     de, dq, df = torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, CH, device=dev)
     lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al), lib.ptr(da), lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dq), lib.ptr(df))
     # d query (through the query layer) = dq . Wq^T
@@ -145,8 +145,8 @@ def test_stft_mel(dev):
     assert np.abs(got - ref).max() < 2e-3          # normalised range is [-4, 4]: 5e-4 relative
 
 
-def _engine_vs_oracle(dev, B, Te, L, ragged, seed):
-    pd, od = dims_pair()
+def _engine_vs_oracle(dev, B, Te, L, ragged, seed, **dims_kw):
+    pd, od = dims_pair(**dims_kw)
     values = OM.init_params(od, seed)
     # make BN / biases non-trivial so every gradient path is exercised
     g = np.random.default_rng(seed + 1)
@@ -169,9 +169,12 @@ def _engine_vs_oracle(dev, B, Te, L, ragged, seed):
     return eng, w, od, values, batch, sc, grads, out, new_p
 
 
-@pytest.mark.parametrize("B,Te,L,ragged", [(3, 9, 6, False), (4, 21, 13, True)])
-def test_train_step_parity(dev, B, Te, L, ragged):
-    eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, ragged, seed=11)
+MID = dict(dec_lstm=64, enc_lstm=32, spk=64, prenet=32)      # shapes on which the skinny K-split kernels are active
+
+
+@pytest.mark.parametrize("B,Te,L,ragged,kw", [(3, 9, 6, False, {}), (4, 21, 13, True, {}), (5, 18, 9, True, MID)])
+def test_train_step_parity(dev, B, Te, L, ragged, kw):
+    eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, ragged, seed=11, **kw)
     tol = 1e-3    # north_star: within 1e-3 relative on fp32 mels
     assert rel_err(t2n(w.linear), t2n(out["Linear"])) < tol
     assert rel_err(t2n(w.mel_out), t2n(out["Mel"])) < tol

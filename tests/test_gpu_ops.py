@@ -157,3 +157,29 @@ def test_adam_tf(dev):
     mr = 0.9 * mn + 0.1 * gt; vr = 0.999 * vn + 0.001 * gt * gt
     assert rel_err(t2n(p), pn - 3e-4 * mr / (np.sqrt(vr) + 1e-6)) < 1e-6
     assert rel_err(t2n(m), mr) < 1e-6 and rel_err(t2n(v), vr) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 1792), (32, 4096, 2048), (32, 128, 1024), (5, 256, 192), (40, 132, 64)])
+def test_skinny_fwd(dev, M, N, K):
+    L = lib.load()
+    ks = L.mstts_skinny_fwd_splits(N, K)
+    assert ks >= 1
+    X = _r(dev, M, K + 4, seed=1)[:, :K]          # row stride K+4: exercises ldx != K
+    W = _r(dev, K, N, seed=2, scale=0.1)
+    P = torch.zeros(ks, M, N, device=dev)
+    lib.call("mstts_skinny_fwd", lib.ptr(X), K + 4, lib.ptr(W), N, lib.ptr(P), 0, M, N, K, ks)
+    ref = t2n(X).astype(np.float64) @ t2n(W).astype(np.float64)
+    assert rel_err(t2n(P).astype(np.float64).sum(0), ref) < TOL
+
+
+@pytest.mark.parametrize("M,R,N", [(32, 1792, 4096), (32, 2048, 4096), (32, 1024, 128), (7, 192, 256), (33, 40, 64)])
+def test_skinny_bwd(dev, M, R, N):
+    L = lib.load()
+    ns = L.mstts_skinny_bwd_splits(R, N)
+    assert ns >= 1
+    dG = _r(dev, M, N, seed=3)
+    W = _r(dev, R, N, seed=4, scale=0.1)
+    P = torch.zeros(ns, M, R, device=dev)
+    lib.call("mstts_skinny_bwd", lib.ptr(dG), N, lib.ptr(W), N, lib.ptr(P), 0, M, R, N, ns)
+    ref = t2n(dG).astype(np.float64) @ t2n(W).astype(np.float64).T
+    assert rel_err(t2n(P).astype(np.float64).sum(0), ref) < TOL

@@ -246,14 +246,16 @@ typedef struct {
     const float* residual;           /* [B,T,H] or NULL */
     float* out; int64_t out_sb, out_st;
     float* c_hist; float* h_hist; float* acts; float* c_raw;
-    float* gates_ws;                 /* [B,4H] */
+    float* gates_ws;                 /* mstts_lstm_seq_ws_floats(B, H, 0) floats */
 } mstts_lstm_seq_fwd_desc;
 int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s);
+/* floats needed for gates_ws (backward = 0) or for the BPTT ws (backward = 1) */
+int64_t mstts_lstm_seq_ws_floats(int64_t B, int64_t H, int32_t backward);
 
 /* BPTT over the same sequence.  d_out is the gradient of `out` (same strides).  Produces
  * dgates_step [T,B,4H] (pairs with h_hist[0:T] for dWh) and dgates_pos [B,T,4H] (pairs with x for
  * dWx / dX); the weight/bias/input gradients are then plain GEMMs/colsums done by the caller.
- * ws: 4*B*H floats. */
+ * ws: mstts_lstm_seq_ws_floats(B, H, 1) floats. */
 typedef struct {
     int64_t B, T, H;
     const float* wh; int64_t wh_ld;

@@ -37,6 +37,20 @@ __device__ __forceinline__ float tanhf_(float x) {
     return copysignf(t, x);
 }
 
+// sum of up to MAXP partial slabs p[pp * stride + idx]; all loads are issued before the first add
+// (a runtime-length `for` would serialize one memory round trip per slab)
+template <int MAXP>
+__device__ __forceinline__ float sum_parts(const float* __restrict__ p, int parts, long stride, long idx) {
+    float t[MAXP];
+#pragma unroll
+    for (int pp = 0; pp < MAXP; ++pp) t[pp] = (pp == 0 || pp < parts) ? p[pp * stride + idx] : 0.f;
+    float v = t[0];
+#pragma unroll
+    for (int pp = 1; pp < MAXP; ++pp) v += t[pp];
+    return v;
+}
+constexpr int MSTTS_MAX_PARTS = 16;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

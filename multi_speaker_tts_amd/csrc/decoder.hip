@@ -66,62 +66,6 @@ static int zero(float* p, long n, mstts_stream_t s) {
     return MSTTS_OK;
 }
 
-extern "C" int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s) {
-    MSTTS_REQUIRE(d && d->xw && d->wh && d->c_hist && d->h_hist && d->gates_ws, MSTTS_ERR_SHAPE, "lstm_seq_fwd: null pointer");
-    const long B = d->B, T = d->T, H = d->H, BH = B * H;
-    RC(zero(d->c_hist, BH, s));
-    RC(zero(d->h_hist, BH, s));
-    for (long t = 0; t < T; ++t) {
-        RC(gemm(d->h_hist + t * BH, H, d->wh, d->wh_ld, 0, d->gates_ws, 4 * H, B, 4 * H, H, nullptr, 0, 0, s));
-        mstts_lstm_point_fwd_desc p;
-        memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H; p.gates_h = d->gates_ws;
-        p.xw = d->xw; p.xw_sb = T * 4 * H; p.xw_st = 4 * H;
-        p.c_prev = d->c_hist + t * BH; p.h_prev = d->h_hist + t * BH;
-        p.zc = d->zc ? d->zc + t * BH : nullptr; p.zh = d->zh ? d->zh + t * BH : nullptr;
-        p.zoneout = d->zoneout; p.lengths = d->lengths; p.step = (int)t; p.reverse = d->reverse;
-        p.residual = d->residual; p.res_sb = T * H; p.res_st = H;
-        p.out = d->out; p.out_sb = d->out_sb; p.out_st = d->out_st;
-        p.c_next = d->c_hist + (t + 1) * BH; p.h_next = d->h_hist + (t + 1) * BH;
-        p.acts_out = d->acts ? d->acts + t * 4 * BH : nullptr;
-        p.c_raw = d->c_raw ? d->c_raw + t * BH : nullptr;
-        RC(mstts_lstm_point_fwd(&p, s));
-    }
-    return MSTTS_OK;
-}
-
-extern "C" int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream_t s) {
-    MSTTS_REQUIRE(d && d->wh && d->d_out && d->c_hist && d->acts && d->c_raw && d->dgates_step && d->ws, MSTTS_ERR_SHAPE,
-                  "lstm_seq_bwd: null pointer");
-    const long B = d->B, T = d->T, H = d->H, BH = B * H;
-    float* dc[2] = {d->ws, d->ws + BH};
-    float* dh[2] = {d->ws + 2 * BH, d->ws + 3 * BH};
-    RC(zero(d->ws, 4 * BH, s));
-    int cur = 0;
-    for (long t = T - 1; t >= 0; --t) {
-        const int nxt = cur ^ 1;
-        mstts_lstm_point_bwd_desc p;
-        memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H;
-        p.d_out = d->d_out; p.dout_sb = d->dout_sb; p.dout_st = d->dout_st;
-        p.d_c_state = dc[cur]; p.d_h_state = dh[cur];
-        p.acts = d->acts + t * 4 * BH; p.c_raw = d->c_raw + t * BH; p.c_prev = d->c_hist + t * BH;
-        p.zc = d->zc ? d->zc + t * BH : nullptr; p.zh = d->zh ? d->zh + t * BH : nullptr;
-        p.zoneout = d->zoneout; p.lengths = d->lengths; p.step = (int)t; p.reverse = d->reverse;
-        p.dgates = d->dgates_step + t * 4 * BH;
-        p.dgates_pos = d->dgates_pos; p.dgp_sb = T * 4 * H; p.dgp_st = 4 * H;
-        p.d_c_prev = dc[nxt]; p.d_h_prev = dh[nxt];
-        RC(mstts_lstm_point_bwd(&p, s));
-        // d_h_prev += dgates . Wh^T
-        RC(gemm(p.dgates, 4 * H, d->wh, d->wh_ld, 1, dh[nxt], H, B, H, 4 * H, nullptr, 0, 1, s));
-        cur = nxt;
-    }
-    return MSTTS_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// teacher-forced decoder loop
-// ---------------------------------------------------------------------------------------------
 // X[M,K] . W[K,N]: skinny K-split kernel when the shape fits (parts slabs in P), else the tiled GEMM
 static int xw_fwd(const float* X, long ldx, const float* W, long ldw, float* P, long M, long N, long K, int splits, int* parts,
                   mstts_stream_t s) {
@@ -143,6 +87,73 @@ static int xw_bwd(const float* dG, long ldg, const float* W, long ldw, float* P,
     return gemm(dG, ldg, W, ldw, 1, P, R, M, R, N, nullptr, 0, 0, s);
 }
 
+extern "C" int64_t mstts_lstm_seq_ws_floats(int64_t B, int64_t H, int32_t backward) {
+    int p = backward ? mstts_skinny_bwd_splits(H, 4 * H) : mstts_skinny_fwd_splits(4 * H, H);
+    if (p < 1) p = 1;
+    return backward ? 4 * B * H + (int64_t)p * B * H : (int64_t)p * B * 4 * H;
+}
+
+extern "C" int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->xw && d->wh && d->c_hist && d->h_hist && d->gates_ws, MSTTS_ERR_SHAPE, "lstm_seq_fwd: null pointer");
+    const long B = d->B, T = d->T, H = d->H, BH = B * H;
+    const int sp = mstts_skinny_fwd_splits(4 * H, H);
+    RC(zero(d->c_hist, BH, s));
+    RC(zero(d->h_hist, BH, s));
+    for (long t = 0; t < T; ++t) {
+        int parts = 1;
+        RC(xw_fwd(d->h_hist + t * BH, H, d->wh, d->wh_ld, d->gates_ws, B, 4 * H, H, sp, &parts, s));
+        mstts_lstm_point_fwd_desc p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = d->gates_ws; p.gates_parts = parts; p.gates_pstride = 4 * BH;
+        p.xw = d->xw; p.xw_sb = T * 4 * H; p.xw_st = 4 * H;
+        p.c_prev = d->c_hist + t * BH; p.h_prev = d->h_hist + t * BH;
+        p.zc = d->zc ? d->zc + t * BH : nullptr; p.zh = d->zh ? d->zh + t * BH : nullptr;
+        p.zoneout = d->zoneout; p.lengths = d->lengths; p.step = (int)t; p.reverse = d->reverse;
+        p.residual = d->residual; p.res_sb = T * H; p.res_st = H;
+        p.out = d->out; p.out_sb = d->out_sb; p.out_st = d->out_st;
+        p.c_next = d->c_hist + (t + 1) * BH; p.h_next = d->h_hist + (t + 1) * BH;
+        p.acts_out = d->acts ? d->acts + t * 4 * BH : nullptr;
+        p.c_raw = d->c_raw ? d->c_raw + t * BH : nullptr;
+        RC(mstts_lstm_point_fwd(&p, s));
+    }
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && d->wh && d->d_out && d->c_hist && d->acts && d->c_raw && d->dgates_step && d->ws, MSTTS_ERR_SHAPE,
+                  "lstm_seq_bwd: null pointer");
+    const long B = d->B, T = d->T, H = d->H, BH = B * H;
+    float* dc[2] = {d->ws, d->ws + BH};
+    float* dh[2] = {d->ws + 2 * BH, d->ws + 3 * BH};
+    float* dhg = d->ws + 4 * BH;                        // [parts][B][H]: dgates . Wh^T of the later step
+    const int sp = mstts_skinny_bwd_splits(H, 4 * H);
+    RC(zero(d->ws, 4 * BH, s));
+    int cur = 0, parts = 1;
+    for (long t = T - 1; t >= 0; --t) {
+        const int nxt = cur ^ 1;
+        mstts_lstm_point_bwd_desc p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H;
+        p.d_out = d->d_out; p.dout_sb = d->dout_sb; p.dout_st = d->dout_st;
+        p.d_c_state = dc[cur]; p.d_h_state = dh[cur];
+        p.d_h_state2 = (t == T - 1) ? nullptr : dhg; p.dhs2_ld = H; p.dhs2_parts = parts; p.dhs2_pstride = BH;
+        p.acts = d->acts + t * 4 * BH; p.c_raw = d->c_raw + t * BH; p.c_prev = d->c_hist + t * BH;
+        p.zc = d->zc ? d->zc + t * BH : nullptr; p.zh = d->zh ? d->zh + t * BH : nullptr;
+        p.zoneout = d->zoneout; p.lengths = d->lengths; p.step = (int)t; p.reverse = d->reverse;
+        p.dgates = d->dgates_step + t * 4 * BH;
+        p.dgates_pos = d->dgates_pos; p.dgp_sb = T * 4 * H; p.dgp_st = 4 * H;
+        p.d_c_prev = dc[nxt]; p.d_h_prev = dh[nxt];
+        RC(mstts_lstm_point_bwd(&p, s));
+        // recurrent part of d_h_prev = dgates . Wh^T (slabs, consumed by the next iteration)
+        RC(xw_bwd(p.dgates, 4 * H, d->wh, d->wh_ld, dhg, 0, B, H, 4 * H, sp, &parts, s));
+        cur = nxt;
+    }
+    return MSTTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// teacher-forced decoder loop
+// ---------------------------------------------------------------------------------------------
 extern "C" int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q) {
     int p0 = mstts_skinny_fwd_splits(4 * H, M + H), p1 = mstts_skinny_fwd_splits(4 * H, 2 * H), pq = mstts_skinny_fwd_splits(A, H);
     int pg = p0 > p1 ? p0 : p1;

@@ -278,8 +278,7 @@ __global__ void lstm_point_fwd_kernel(mstts_lstm_point_fwd_desc d) {
         float g4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float v = d.gates_h[(long)b * 4 * H + g * H + u];
-            for (int pp = 1; pp < d.gates_parts; ++pp) v += d.gates_h[pp * d.gates_pstride + (long)b * 4 * H + g * H + u];
+            float v = sum_parts<MSTTS_MAX_PARTS>(d.gates_h, d.gates_parts, d.gates_pstride, (long)b * 4 * H + g * H + u);
             if (d.xw) v += d.xw[b * d.xw_sb + pos * d.xw_st + g * H + u];
             if (d.bias) v += d.bias[g * H + u];
             g4[g] = v;
@@ -315,8 +314,7 @@ __global__ void lstm_point_bwd_kernel(mstts_lstm_point_bwd_desc d) {
         const int pos = d.reverse ? (live ? len - 1 - d.step : d.step) : d.step;
         float dhs = d.d_h_state[i];
         if (d.d_h_state2) {
-            dhs += d.d_h_state2[b * d.dhs2_ld + u];
-            for (int pp = 1; pp < d.dhs2_parts; ++pp) dhs += d.d_h_state2[pp * d.dhs2_pstride + b * d.dhs2_ld + u];
+            dhs += sum_parts<MSTTS_MAX_PARTS>(d.d_h_state2, d.dhs2_parts, d.dhs2_pstride, b * d.dhs2_ld + u);
         }
         const float dcs = d.d_c_state[i];
         float* dg = d.dgates + (long)b * 4 * H + u;
@@ -329,12 +327,10 @@ __global__ void lstm_point_bwd_kernel(mstts_lstm_point_bwd_desc d) {
         }
         float dm = 0.f;
         if (d.d_out) {
-            dm += d.d_out[b * d.dout_sb + pos * d.dout_st + u];
-            for (int pp = 1; pp < d.dout_parts; ++pp) dm += d.d_out[pp * d.dout_pstride + b * d.dout_sb + pos * d.dout_st + u];
+            dm += sum_parts<MSTTS_MAX_PARTS>(d.d_out, d.dout_parts, d.dout_pstride, b * d.dout_sb + pos * d.dout_st + u);
         }
         if (d.d_out2) {
-            dm += d.d_out2[i];
-            for (int pp = 1; pp < d.dout2_parts; ++pp) dm += d.d_out2[pp * d.dout2_pstride + i];
+            dm += sum_parts<MSTTS_MAX_PARTS>(d.d_out2, d.dout2_parts, d.dout2_pstride, i);
         }
         const float kz = 1.f - d.zoneout;
         const float mh = d.zh ? (d.zh[i] ? kz : 0.f) : kz;     // d h'/d m

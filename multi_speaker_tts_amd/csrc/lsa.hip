@@ -27,8 +27,27 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return copysignf((1.0f - e) / (1.0f + e), x);
 }
 
-// stage cum[b, t0-pad .. t0+TS-1+(KS-1-pad)] (zero outside [0,T)) and the conv kernel into LDS,
-// then f[tt][c] = conv_b[c] + sum_j cum[t0+tt+j-pad] * conv_k[j*CH+c]
+// The per-step kernels below are latency-bound (a few KB per workgroup, 801 dependent steps), so each
+// one issues ALL of its global loads first - one memory round trip - and only then touches LDS.
+
+// location features from an LDS-resident window of the cumulative alignment and a register-resident
+// conv kernel column: thread (tt = tid/32 [+8], ch = tid%32): f[tt][ch] = b[ch] + sum_j cum[tt+j] * k[j][ch]
+__device__ __forceinline__ void location_features_regs(int KS, const float* s_cum, const float (&ck)[KS_MAX], float cb,
+                                                       float (*s_f)[CH_ + 1]) {
+    const int ch = threadIdx.x & (CH_ - 1), tt = threadIdx.x >> 5;      // 8 row groups x 32 channels
+    float a0 = cb, a1 = cb;
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) {
+        if (j < KS) {
+            a0 += s_cum[tt + j] * ck[j];
+            a1 += s_cum[tt + 8 + j] * ck[j];
+        }
+    }
+    s_f[tt][ch] = a0;
+    s_f[tt + 8][ch] = a1;
+}
+
+// legacy helper (post-loop kernel): stage cum window + conv kernel through LDS
 __device__ __forceinline__ void location_features(const mstts_lsa_const& c, const float* __restrict__ cum_row, int t0,
                                                   float* s_cum, float* s_ck, float (*s_f)[CH_ + 1]) {
     const int KS = (int)c.KS, T = (int)c.T, pad = (KS - 1) / 2;
@@ -54,30 +73,45 @@ __global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, cons
                                                          float* __restrict__ q_sum, const float* __restrict__ cum,
                                                          float* __restrict__ energy) {
     __shared__ float s_cum[TS + KS_MAX - 1];
-    __shared__ float s_ck[KS_MAX * CH_];
     __shared__ float s_f[TS][CH_ + 1];
     __shared__ float s_red[TS][2];
-    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T;
-    location_features(c, cum + (long)b * T, t0, s_cum, s_ck, s_f);
-
+    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;        // 2 groups of 128 lanes
+    const int ch = threadIdx.x & (CH_ - 1);
+    // ---- every global load of this workgroup, issued back to back
+    float cwin = 0.f;
+    if (threadIdx.x < TS + KS - 1) {
+        const int t = t0 - pad + threadIdx.x;
+        if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
+    }
+    float ck[KS_MAX];
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) ck[j] = (j < KS) ? c.conv_k[j * CH_ + ch] : 0.f;
+    const float cb = c.conv_b[ch];
     float dk[CH_];
 #pragma unroll
-    for (int ch = 0; ch < CH_; ++ch) dk[ch] = c.dense_k[ch * A_ + k];
-    float qv = q[(long)b * A_ + k];
-    for (int pp = 1; pp < q_parts; ++pp) qv += q[pp * q_pstride + (long)b * A_ + k];
-    if (q_sum && blockIdx.y == 0 && grp == 0) q_sum[(long)b * A_ + k] = qv;
-    const float qk = qv + c.score_b[k];
-    const float wk = c.score_w[k];
+    for (int i = 0; i < CH_; ++i) dk[i] = c.dense_k[i * A_ + k];
     const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+    float kv[TS / 2];
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
+    const float qv = sum_parts<MSTTS_MAX_PARTS>(q, q_parts, q_pstride, (long)b * A_ + k);
+    const float sb = c.score_b[k], wk = c.score_w[k];
+    // ---- LDS phase
+    if (threadIdx.x < TS + KS - 1) s_cum[threadIdx.x] = cwin;
+    if (q_sum && blockIdx.y == 0 && grp == 0) q_sum[(long)b * A_ + k] = qv;
+    __syncthreads();
+    location_features_regs(KS, s_cum, ck, cb, s_f);
+    __syncthreads();
+    const float qk = qv + sb;
 #pragma unroll
     for (int i = 0; i < TS / 2; ++i) {
         const int tt = grp + 2 * i;
         float e = 0.f;
         if (t0 + tt < T) {
-            float pre = keys[(long)tt * A_] + qk;
+            float pre = kv[i] + qk;
 #pragma unroll
-            for (int ch = 0; ch < CH_; ++ch) pre += s_f[tt][ch] * dk[ch];
+            for (int cc = 0; cc < CH_; ++cc) pre += s_f[tt][cc] * dk[cc];
             e = wk * fast_tanh(pre);
         }
         e = wave_sum(e);
@@ -93,6 +127,7 @@ __global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, cons
 // ---------------------------------------------------------------------------------------------
 constexpr int DS = 64;          // memory columns per workgroup
 constexpr int T_MAX = 1024;
+constexpr int VPRE = 8;         // value rows per thread preloaded before the softmax (covers T <= 128)
 
 __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, const float* __restrict__ energy,
                                                           const float* __restrict__ cum, float* __restrict__ align,
@@ -103,37 +138,62 @@ __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, con
     __shared__ __attribute__((aligned(16))) float s_part[16][DS];
     const int b = blockIdx.x, d0 = blockIdx.y * DS, T = (int)c.T, M = (int)c.M;
     const int len = c.lengths ? c.lengths[b] : T;
-    float mx = -INFINITY;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const float e = (t < len) ? energy[(long)b * T + t] : -INFINITY;
-        s_a[t] = e;
-        mx = fmaxf(mx, e);
+    const int c4 = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int col = d0 + c4 * 4;
+    // ---- loads first: energies (+ cum for the writer block) and the first VPRE value rows of this thread
+    float ev[T_MAX / 256], cv[T_MAX / 256];
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        ev[i] = (t < len) ? energy[(long)b * T + t] : -INFINITY;
+        cv[i] = (blockIdx.y == 0 && t < T) ? cum[(long)b * T + t] : 0.f;
     }
+    const float* v = c.values + (long)b * T * M + col;
+    float4 vv[VPRE];
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i) {
+        const int t = tg + 16 * i;
+        vv[i] = (col < M && t < len) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- softmax over the row
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) mx = fmaxf(mx, ev[i]);
     mx = block_max(mx, scratch);
     float sum = 0.f;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const float p = (t < len) ? __expf(s_a[t] - mx) : 0.f;
-        s_a[t] = p;
-        sum += p;
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        ev[i] = (t < len) ? __expf(ev[i] - mx) : 0.f;
+        sum += ev[i];
     }
     sum = block_sum(sum, scratch);
     const float inv = 1.f / sum;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const float a = s_a[t] * inv;
-        s_a[t] = a;
-        if (blockIdx.y == 0) {
-            align[(long)b * T + t] = a;
-            cum_next[(long)b * T + t] = cum[(long)b * T + t] + a;
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        if (t < T) {
+            const float a = ev[i] * inv;
+            s_a[t] = a;
+            if (blockIdx.y == 0) {
+                align[(long)b * T + t] = a;
+                cum_next[(long)b * T + t] = cv[i] + a;
+            }
         }
     }
     __syncthreads();
-    // context slice: 16 lanes x float4 cover 64 columns; 16 row groups stride over t
-    const int c4 = threadIdx.x & 15, tg = threadIdx.x >> 4;
-    const int col = d0 + c4 * 4;
+    // ---- context slice
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i) {
+        const int t = tg + 16 * i;
+        if (t < len) {
+            const float a = s_a[t];
+            acc.x += a * vv[i].x; acc.y += a * vv[i].y; acc.z += a * vv[i].z; acc.w += a * vv[i].w;
+        }
+    }
     if (col < M) {
-        const float* v = c.values + (long)b * T * M + col;
-        for (int t = tg; t < len; t += 16) {
+        for (int t = tg + 16 * VPRE; t < len; t += 16) {          // only for T > 128
             const float a = s_a[t];
             const float4 x = *reinterpret_cast<const float4*>(v + (long)t * M);
             acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w;
@@ -153,63 +213,120 @@ __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, con
 // ---------------------------------------------------------------------------------------------
 // backward: d_align  (G = dL/d cum_{s+1})
 // ---------------------------------------------------------------------------------------------
+constexpr int DF_ROWS = TS + KS_MAX - 1;
+constexpr int MROW = 4;        // float4 per lane per value row held in registers (M <= 1024)
+
 __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, const float* __restrict__ d_ctx, long d_ctx_ld,
                                                          const float* __restrict__ d_ctx2, long d_ctx2_ld, int d_ctx2_parts, long d_ctx2_pstride,
                                                          const float* __restrict__ G_next, const float* __restrict__ d_f_next,
                                                          float* __restrict__ G, float* __restrict__ d_align) {
-    __shared__ float s_df[TS + KS_MAX - 1][CH_ + 1];
+    __shared__ float s_df[DF_ROWS][CH_ + 1];
     __shared__ float s_ck[KS_MAX * CH_];
     __shared__ float s_g[TS];
     const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
-    // conv-transpose part: G[t] = G_next[t] + sum_{j,ch} d_f_next[t + pad - j][ch] * conv_k[j][ch]
-    // rows staged: tau = t0 + pad - (KS-1) + i, i in [0, TS+KS-1)
-    if (d_f_next) {
-        const int base = t0 + pad - (KS - 1);
-        for (int i = threadIdx.x; i < (TS + KS - 1) * CH_; i += blockDim.x) {
-            const int r = i / CH_, ch = i % CH_, tau = base + r;
-            s_df[r][ch] = (tau >= 0 && tau < T) ? d_f_next[((long)b * T + tau) * CH_ + ch] : 0.f;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int len = c.lengths ? c.lengths[b] : T;
+    // ---- loads first
+    // (a) d_f_next window rows tau = t0 + pad - (KS-1) + r, r in [0, TS+KS-1): element e = tid + 256*i
+    constexpr int NDF = (DF_ROWS * CH_ + 255) / 256;
+    float dfv[NDF];
+    const int base = t0 + pad - (KS - 1);
+#pragma unroll
+    for (int i = 0; i < NDF; ++i) {
+        const int e = threadIdx.x + 256 * i, r = e / CH_, chn = e % CH_, tau = base + r;
+        dfv[i] = (d_f_next && r < TS + KS - 1 && tau >= 0 && tau < T) ? d_f_next[((long)b * T + tau) * CH_ + chn] : 0.f;
+    }
+    constexpr int NCK = (KS_MAX * CH_ + 255) / 256;
+    float ckv[NCK];
+#pragma unroll
+    for (int i = 0; i < NCK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        ckv[i] = (d_f_next && e < KS * CH_) ? c.conv_k[e] : 0.f;
+    }
+    // (b) the wave's 4 value rows (tt = w + 4*r) and the d_ctx row, MROW float4 per lane each
+    float4 dcv[MROW], val[4][MROW];
+    const float* dc = d_ctx + (long)b * d_ctx_ld;
+#pragma unroll
+    for (int m = 0; m < MROW; ++m) {
+        const int i = lane * 4 + 256 * m;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < M) {
+            y = *reinterpret_cast<const float4*>(dc + i);
+            if (d_ctx2) {
+                float4 y2[8];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp)
+                    y2[pp] = (pp == 0 || pp < d_ctx2_parts) ? *reinterpret_cast<const float4*>(d_ctx2 + pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) { y.x += y2[pp].x; y.y += y2[pp].y; y.z += y2[pp].z; y.w += y2[pp].w; }
+            }
         }
-        for (int i = threadIdx.x; i < KS * CH_; i += blockDim.x) s_ck[i] = c.conv_k[i];
-        __syncthreads();
+        dcv[m] = y;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + w + 4 * r;
+#pragma unroll
+        for (int m = 0; m < MROW; ++m) {
+            const int i = lane * 4 + 256 * m;
+            val[r][m] = (t < len && i < M) ? *reinterpret_cast<const float4*>(c.values + ((long)b * T + t) * M + i)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float gn = 0.f;
+    if (threadIdx.x < TS && G_next && t0 + threadIdx.x < T) gn = G_next[(long)b * T + t0 + threadIdx.x];
+    // ---- LDS phase: conv-transpose  G[t] = G_next[t] + sum_{j,ch} d_f_next[t + pad - j][ch] * conv_k[j][ch]
+#pragma unroll
+    for (int i = 0; i < NDF; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < DF_ROWS * CH_) s_df[e / CH_][e % CH_] = dfv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NCK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < KS_MAX * CH_) s_ck[e] = ckv[i];
+    }
+    __syncthreads();
+    {
         const int tt = threadIdx.x >> 4, part = threadIdx.x & 15;
         float acc = 0.f;
-        for (int p = part; p < KS * CH_; p += 16) {
-            const int j = p / CH_, ch = p % CH_;
-            acc += s_df[tt + (KS - 1) - j][ch] * s_ck[p];          // row index of tau = t + pad - j
+        if (d_f_next) {
+            for (int p = part; p < KS * CH_; p += 16) {
+                const int j = p / CH_, chn = p % CH_;
+                acc += s_df[tt + (KS - 1) - j][chn] * s_ck[p];
+            }
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (part == 0) s_g[tt] = acc;
-    } else {
-        if (threadIdx.x < TS) s_g[threadIdx.x] = 0.f;
     }
     __syncthreads();
-    // values . d_ctx for the 16 rows: wave w takes rows w, w+4, ...
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int len = c.lengths ? c.lengths[b] : T;
-    for (int tt = w; tt < TS; tt += 4) {
-        const int t = t0 + tt;
-        if (t >= T) continue;
+    if (threadIdx.x < TS) s_g[threadIdx.x] += gn;
+    __syncthreads();
+    // ---- values . d_ctx for this wave's rows
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tt = w + 4 * r, t = t0 + tt;
         float acc = 0.f;
-        if (t < len) {
-            const float* v = c.values + ((long)b * T + t) * M;
-            const float* dc = d_ctx + (long)b * d_ctx_ld;
-            const float* dc2 = d_ctx2 ? d_ctx2 + (long)b * d_ctx2_ld : nullptr;
-            for (int i = lane * 4; i < M; i += 256) {
-                const float4 x = *reinterpret_cast<const float4*>(v + i);
+#pragma unroll
+        for (int m = 0; m < MROW; ++m)
+            acc += val[r][m].x * dcv[m].x + val[r][m].y * dcv[m].y + val[r][m].z * dcv[m].z + val[r][m].w * dcv[m].w;
+        if (t < len) {                                  // M > 1024: remaining columns
+            for (int i = lane * 4 + 256 * MROW; i < M; i += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(c.values + ((long)b * T + t) * M + i);
                 float4 y = *reinterpret_cast<const float4*>(dc + i);
-                if (dc2) {
+                if (d_ctx2)
                     for (int pp = 0; pp < max(d_ctx2_parts, 1); ++pp) {
-                        const float4 y2 = *reinterpret_cast<const float4*>(dc2 + pp * d_ctx2_pstride + i);
+                        const float4 y2 = *reinterpret_cast<const float4*>(d_ctx2 + pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i);
                         y.x += y2.x; y.y += y2.y; y.z += y2.z; y.w += y2.w;
                     }
-                }
                 acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
             }
         }
         acc = wave_sum(acc);
-        if (lane == 0) {
-            const float g = s_g[tt] + (G_next ? G_next[(long)b * T + t] : 0.f);
+        if (lane == 0 && t < T) {
+            const float g = s_g[tt];
             G[(long)b * T + t] = g;
             d_align[(long)b * T + t] = g + acc;
         }
@@ -224,47 +341,75 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
                                                           const float* __restrict__ cum, float* __restrict__ d_e_out,
                                                           float* __restrict__ dq, float* __restrict__ d_f) {
     __shared__ float s_cum[TS + KS_MAX - 1];
-    __shared__ float s_ck[KS_MAX * CH_];
     __shared__ float s_f[TS][CH_ + 1];
     __shared__ float s_g[TS][A_];
     __shared__ float s_dkT[A_][CH_ + 1];
     __shared__ float s_de[TS];
     __shared__ float s_dq[A_];
     __shared__ float scratch[16];
-    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T;
-    // softmax backward needs the whole row's dot(a, d_a)
+    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, KS = (int)c.KS, pad = (KS - 1) / 2;
+    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
+    const int ch = threadIdx.x & (CH_ - 1);
+    // ---- loads first
+    float av[T_MAX / 256], dav[T_MAX / 256];
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        av[i] = (t < T) ? align[(long)b * T + t] : 0.f;
+        dav[i] = (t < T) ? d_align[(long)b * T + t] : 0.f;
+    }
+    float a_own = 0.f, da_own = 0.f;
+    if (threadIdx.x < TS && t0 + threadIdx.x < T) {
+        a_own = align[(long)b * T + t0 + threadIdx.x];
+        da_own = d_align[(long)b * T + t0 + threadIdx.x];
+    }
+    float cwin = 0.f;
+    if (threadIdx.x < TS + KS - 1) {
+        const int t = t0 - pad + threadIdx.x;
+        if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
+    }
+    float ck[KS_MAX];
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) ck[j] = (j < KS) ? c.conv_k[j * CH_ + ch] : 0.f;
+    const float cb = c.conv_b[ch];
+    float dkv[A_ * CH_ / 256];
+#pragma unroll
+    for (int i = 0; i < A_ * CH_ / 256; ++i) dkv[i] = c.dense_k[threadIdx.x + 256 * i];
+    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+    float kv[TS / 2];
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
+    const float qk = q[(long)b * A_ + k] + c.score_b[k];
+    const float wk = c.score_w[k];
+    // ---- softmax backward needs the whole row's dot(a, d_a)
     float dot = 0.f;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) dot += align[(long)b * T + t] * d_align[(long)b * T + t];
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) dot += av[i] * dav[i];
     dot = block_sum(dot, scratch);
     if (threadIdx.x < TS) {
         const int t = t0 + threadIdx.x;
-        float de = 0.f;
-        if (t < T) {
-            de = align[(long)b * T + t] * (d_align[(long)b * T + t] - dot);
-            d_e_out[(long)b * T + t] = de;
-        }
+        const float de = (t < T) ? a_own * (da_own - dot) : 0.f;
+        if (t < T) d_e_out[(long)b * T + t] = de;
         s_de[threadIdx.x] = de;
     }
-    for (int i = threadIdx.x; i < A_ * CH_; i += blockDim.x) {
-        const int ch = i / A_, k = i % A_;
-        s_dkT[k][ch] = c.dense_k[i];
+#pragma unroll
+    for (int i = 0; i < A_ * CH_ / 256; ++i) {
+        const int e = threadIdx.x + 256 * i;             // dense_k[ch][k] -> s_dkT[k][ch]
+        s_dkT[e % A_][e / A_] = dkv[i];
     }
-    if (threadIdx.x < A_) s_dq[threadIdx.x] = 0.f;
-    location_features(c, cum + (long)b * T, t0, s_cum, s_ck, s_f);     // ends with __syncthreads()
-
-    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
-    const float qk = q[(long)b * A_ + k] + c.score_b[k];
-    const float wk = c.score_w[k];
-    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+    if (threadIdx.x < TS + KS - 1) s_cum[threadIdx.x] = cwin;
+    __syncthreads();
+    location_features_regs(KS, s_cum, ck, cb, s_f);
+    __syncthreads();
     float dq_acc = 0.f;
 #pragma unroll
     for (int i = 0; i < TS / 2; ++i) {
         const int tt = grp + 2 * i;
         float g = 0.f;
         if (t0 + tt < T) {
-            float pre = keys[(long)tt * A_] + qk;
+            float pre = kv[i] + qk;
 #pragma unroll
-            for (int ch = 0; ch < CH_; ++ch) pre += s_f[tt][ch] * s_dkT[k][ch];
+            for (int cc = 0; cc < CH_; ++cc) pre += s_f[tt][cc] * s_dkT[k][cc];
             const float u = fast_tanh(pre);
             g = s_de[tt] * wk * (1.f - u * u);
         }
@@ -276,12 +421,12 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
     if (grp == 0) atomicAdd(dq + (long)b * A_ + k, dq_acc + s_dq[k]);
     // d_f[tt][ch] = sum_k g[tt][k] * dense_k[ch][k]
     for (int i = threadIdx.x; i < TS * CH_; i += blockDim.x) {
-        const int tt = i / CH_, ch = i % CH_;
+        const int tt = i / CH_, chn = i % CH_;
         if (t0 + tt >= T) continue;
         float acc = 0.f;
 #pragma unroll 8
-        for (int kk = 0; kk < A_; ++kk) acc += s_g[tt][kk] * s_dkT[kk][ch];
-        d_f[((long)b * T + t0 + tt) * CH_ + ch] = acc;
+        for (int kk = 0; kk < A_; ++kk) acc += s_g[tt][kk] * s_dkT[kk][chn];
+        d_f[((long)b * T + t0 + tt) * CH_ + chn] = acc;
     }
 }
 

@@ -114,7 +114,7 @@ class TrainEngine:
         w.enc_h = {dr: f(Te + 1, B, He) for dr in ("fw", "bw")}
         w.enc_acts = {dr: f(Te, B, 4 * He) for dr in ("fw", "bw")}
         w.enc_craw = {dr: f(Te, B, He) for dr in ("fw", "bw")}
-        w.enc_gates = f(B, 4 * He)
+        w.enc_gates = f(int(lib.load().mstts_lstm_seq_ws_floats(B, He, 0)))
         w.values = f(B, Te, M)
         w.keys = f(B, Te, A)
         # decoder
@@ -172,7 +172,7 @@ class TrainEngine:
         w.d_values = f(B, Te, M)
         w.enc_dgs = {dr: f(Te, B, 4 * He) for dr in ("fw", "bw")}
         w.enc_dgp = {dr: f(B, Te, 4 * He) for dr in ("fw", "bw")}
-        w.enc_bwd_ws = f(4 * B * He)
+        w.enc_bwd_ws = f(int(lb.mstts_lstm_seq_ws_floats(B, He, 1)))
         w.enc_dy = f(B * Te, d.enc_conv_ch)
         w.enc_dz = f(B * Te, d.enc_conv_ch)
         w.enc_dx = f(B * Te, d.enc_conv_ch)

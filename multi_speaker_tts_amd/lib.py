@@ -125,6 +125,7 @@ SIGNATURES = {
     "mstts_fold_rows": (i32, [vp, vp, i64, i64, i64, i64, vp]),
     "mstts_lstm_seq_fwd": (i32, [P(LstmSeqFwd), vp]),
     "mstts_lstm_seq_bwd": (i32, [P(LstmSeqBwd), vp]),
+    "mstts_lstm_seq_ws_floats": (i64, [i64, i64, i32]),
     "mstts_decoder_train_fwd": (i32, [P(DecoderTrain), vp]),
     "mstts_decoder_train_bwd": (i32, [P(DecoderTrainBwd), vp]),
     "mstts_decoder_train_bwd_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),

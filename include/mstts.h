@@ -294,6 +294,7 @@ typedef struct {
     float* q_hist; float* align_hist; float* cum_hist;
     float* gates_ws; float* energy_ws;      /* [parts,B,4H] (parts = max skinny K-splits, see mstts_decoder_train_ws_floats), [B,T] */
     float* q_ws;                            /* [parts,B,A] query partials */
+    int32_t chains;                         /* independent row groups run on separate HIP streams (0/1 = one; must divide B) */
 } mstts_decoder_train_desc;
 /* floats needed for gates_ws (*gates) and q_ws (*q) */
 int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q);

@@ -164,6 +164,55 @@ extern "C" int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, in
     return MSTTS_OK;
 }
 
+// ---- row chains ------------------------------------------------------------------------------
+// Batch rows never interact inside the decoder loop, and every per-step kernel is latency-bound (a
+// few hundred KB, one wave per SIMD).  The drivers therefore split the rows into `chains` groups and
+// run each group's dependent kernel chain on its own HIP stream: two chains hide each other's
+// launch/memory latency.  Chain 0 uses the caller's stream; the side streams are created lazily and
+// fork/join with events (also valid under stream capture).
+namespace {
+constexpr int MAX_CHAINS = 4;
+struct SideStreams {
+    bool init = false;
+    hipStream_t st[MAX_CHAINS - 1];
+    hipEvent_t fork, join[MAX_CHAINS - 1];
+} g_side;
+int side_init() {
+    if (g_side.init) return MSTTS_OK;
+    for (int i = 0; i < MAX_CHAINS - 1; ++i) {
+        if (hipStreamCreateWithFlags(&g_side.st[i], hipStreamNonBlocking) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "side stream create failed");
+        if (hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "event create failed");
+    }
+    if (hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "event create failed");
+    g_side.init = true;
+    return MSTTS_OK;
+}
+int chain_fork(int chains, mstts_stream_t s, mstts_stream_t* out) {
+    out[0] = s;
+    if (chains <= 1) return MSTTS_OK;
+    RC(side_init());
+    if (hipEventRecord(g_side.fork, (hipStream_t)s) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "fork record failed");
+    for (int c = 1; c < chains; ++c) {
+        if (hipStreamWaitEvent(g_side.st[c - 1], g_side.fork, 0) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "fork wait failed");
+        out[c] = (mstts_stream_t)g_side.st[c - 1];
+    }
+    return MSTTS_OK;
+}
+int chain_join(int chains, mstts_stream_t s) {
+    for (int c = 1; c < chains; ++c) {
+        if (hipEventRecord(g_side.join[c - 1], g_side.st[c - 1]) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "join record failed");
+        if (hipStreamWaitEvent((hipStream_t)s, g_side.join[c - 1], 0) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "join wait failed");
+    }
+    return MSTTS_OK;
+}
+inline int pick_chains(const mstts_decoder_train_desc* d) {
+    int c = d->chains > 1 ? d->chains : 1;
+    if (c > MAX_CHAINS) c = MAX_CHAINS;
+    while (c > 1 && d->B % c != 0) --c;
+    return c;
+}
+}  // namespace
+
 extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s) {
     MSTTS_REQUIRE(d && d->xw0 && d->w0f && d->w1 && d->b1 && d->wq && d->in0 && d->in1 && d->pj && d->c0 && d->c1 &&
                   d->acts0 && d->acts1 && d->craw0 && d->craw1 && d->q_hist && d->align_hist && d->cum_hist && d->gates_ws &&
@@ -172,45 +221,66 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     MSTTS_REQUIRE(d->lsa.B == B, MSTTS_ERR_SHAPE, "decoder_train_fwd: lsa.B != B");
     const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M;
     const int sp0 = mstts_skinny_fwd_splits(4 * H, W0), sp1 = mstts_skinny_fwd_splits(4 * H, W1), spq = mstts_skinny_fwd_splits(A, H);
+    const int pg = (sp0 > sp1 ? sp0 : sp1) > 0 ? (sp0 > sp1 ? sp0 : sp1) : 1, pq = spq > 0 ? spq : 1;
     RC(zero(d->in0, B * W0, s));
     RC(zero(d->in1, B * W1, s));
     RC(zero(d->c0, BH, s));
     RC(zero(d->c1, BH, s));
     RC(zero(d->cum_hist, B * T, s));
+    const int chains = pick_chains(d);
+    const long Bc = B / chains;
+    mstts_stream_t cs[MAX_CHAINS];
+    RC(chain_fork(chains, s, cs));
     for (long st = 0; st < S; ++st) {
-        mstts_lstm_point_fwd_desc p;
-        int parts = 1;
-        // ---- cell 0: gates = [ctx | h0] . w0f + xw0[st]
-        PROBED(MSTTS_PROBE_CELL0_GEMM, s, xw_fwd(d->in0 + st * B * W0, W0, d->w0f, 4 * H, d->gates_ws, B, 4 * H, W0, sp0, &parts, s));
-        memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H; p.gates_h = d->gates_ws; p.gates_parts = parts; p.gates_pstride = 4 * BH;
-        p.xw = d->xw0 + st * 4 * BH; p.xw_sb = 4 * H; p.xw_st = 0;
-        p.c_prev = d->c0 + st * BH; p.h_prev = d->in0 + st * B * W0 + M; p.h_prev_ld = W0;
-        p.zc = d->zc0 ? d->zc0 + st * BH : nullptr; p.zh = d->zh0 ? d->zh0 + st * BH : nullptr;
-        p.zoneout = d->zoneout;
-        p.out = d->in1 + st * B * W1; p.out_sb = W1; p.out_st = 0;
-        p.c_next = d->c0 + (st + 1) * BH; p.h_next = d->in0 + (st + 1) * B * W0 + M; p.h_next_ld = W0;
-        p.acts_out = d->acts0 + st * 4 * BH; p.c_raw = d->craw0 + st * BH;
-        RC(mstts_lstm_point_fwd(&p, s));
-        // ---- cell 1: gates = [m0 | h1] . w1 + b1
-        PROBED(MSTTS_PROBE_CELL1_GEMM, s, xw_fwd(d->in1 + st * B * W1, W1, d->w1, 4 * H, d->gates_ws, B, 4 * H, W1, sp1, &parts, s));
-        memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H; p.gates_h = d->gates_ws; p.gates_parts = parts; p.gates_pstride = 4 * BH; p.bias = d->b1;
-        p.c_prev = d->c1 + st * BH; p.h_prev = d->in1 + st * B * W1 + H; p.h_prev_ld = W1;
-        p.zc = d->zc1 ? d->zc1 + st * BH : nullptr; p.zh = d->zh1 ? d->zh1 + st * BH : nullptr;
-        p.zoneout = d->zoneout;
-        p.out = d->pj + st * B * WP; p.out_sb = WP; p.out_st = 0;
-        p.c_next = d->c1 + (st + 1) * BH; p.h_next = d->in1 + (st + 1) * B * W1 + H; p.h_next_ld = W1;
-        p.acts_out = d->acts1 + st * 4 * BH; p.c_raw = d->craw1 + st * BH;
-        RC(mstts_lstm_point_fwd(&p, s));
-        // ---- query (partials summed inside the energy kernel, which also saves q) + attention
-        float* q = d->q_hist + st * B * A;
-        RC(xw_fwd(d->pj + st * B * WP, WP, d->wq, A, d->q_ws, B, A, H, spq, &parts, s));
-        const float* cum = d->cum_hist + st * B * T;
-        PROBED(MSTTS_PROBE_LSA_ENERGY, s, mstts_lsa_energy_fwd(&d->lsa, d->q_ws, parts, B * A, q, cum, d->energy_ws, s));
-        PROBED(MSTTS_PROBE_LSA_CONTEXT, s, mstts_lsa_context_fwd(&d->lsa, d->energy_ws, cum, d->align_hist + st * B * T, d->cum_hist + (st + 1) * B * T,
-                                 d->in0 + (st + 1) * B * W0, W0, d->pj + st * B * WP + H, WP, s));
+        for (int c = 0; c < chains; ++c) {
+            const long b0 = c * Bc;
+            mstts_stream_t q_s = cs[c];
+            float* gates = d->gates_ws + (long)pg * b0 * 4 * H;         // [parts][Bc][4H]
+            float* qws = d->q_ws + (long)pq * b0 * A;                   // [parts][Bc][A]
+            float* energy = d->energy_ws + b0 * T;
+            mstts_lsa_const lc = d->lsa;
+            lc.B = Bc; lc.keys += b0 * T * A; lc.values += b0 * T * M;
+            if (lc.lengths) lc.lengths += b0;
+            mstts_lstm_point_fwd_desc p;
+            int parts = 1;
+            // ---- cell 0: gates = [ctx | h0] . w0f + xw0[st]
+            const float* in0 = d->in0 + (st * B + b0) * W0;
+            float* in0n = d->in0 + ((st + 1) * B + b0) * W0;
+            const float* in1 = d->in1 + (st * B + b0) * W1;
+            float* in1w = d->in1 + (st * B + b0) * W1;
+            float* in1n = d->in1 + ((st + 1) * B + b0) * W1;
+            float* pj = d->pj + (st * B + b0) * WP;
+            PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, xw_fwd(in0, W0, d->w0f, 4 * H, gates, Bc, 4 * H, W0, sp0, &parts, q_s));
+            memset(&p, 0, sizeof(p));
+            p.B = Bc; p.H = H; p.gates_h = gates; p.gates_parts = parts; p.gates_pstride = 4 * Bc * H;
+            p.xw = d->xw0 + (st * B + b0) * 4 * H; p.xw_sb = 4 * H; p.xw_st = 0;
+            p.c_prev = d->c0 + (st * B + b0) * H; p.h_prev = in0 + M; p.h_prev_ld = W0;
+            p.zc = d->zc0 ? d->zc0 + (st * B + b0) * H : nullptr; p.zh = d->zh0 ? d->zh0 + (st * B + b0) * H : nullptr;
+            p.zoneout = d->zoneout;
+            p.out = in1w; p.out_sb = W1; p.out_st = 0;
+            p.c_next = d->c0 + ((st + 1) * B + b0) * H; p.h_next = in0n + M; p.h_next_ld = W0;
+            p.acts_out = d->acts0 + (st * B + b0) * 4 * H; p.c_raw = d->craw0 + (st * B + b0) * H;
+            RC(mstts_lstm_point_fwd(&p, q_s));
+            // ---- cell 1: gates = [m0 | h1] . w1 + b1
+            PROBED(MSTTS_PROBE_CELL1_GEMM, q_s, xw_fwd(in1, W1, d->w1, 4 * H, gates, Bc, 4 * H, W1, sp1, &parts, q_s));
+            memset(&p, 0, sizeof(p));
+            p.B = Bc; p.H = H; p.gates_h = gates; p.gates_parts = parts; p.gates_pstride = 4 * Bc * H; p.bias = d->b1;
+            p.c_prev = d->c1 + (st * B + b0) * H; p.h_prev = in1 + H; p.h_prev_ld = W1;
+            p.zc = d->zc1 ? d->zc1 + (st * B + b0) * H : nullptr; p.zh = d->zh1 ? d->zh1 + (st * B + b0) * H : nullptr;
+            p.zoneout = d->zoneout;
+            p.out = pj; p.out_sb = WP; p.out_st = 0;
+            p.c_next = d->c1 + ((st + 1) * B + b0) * H; p.h_next = in1n + H; p.h_next_ld = W1;
+            p.acts_out = d->acts1 + (st * B + b0) * 4 * H; p.c_raw = d->craw1 + (st * B + b0) * H;
+            RC(mstts_lstm_point_fwd(&p, q_s));
+            // ---- query (partials summed inside the energy kernel, which also saves q) + attention
+            RC(xw_fwd(pj, WP, d->wq, A, qws, Bc, A, H, spq, &parts, q_s));
+            const float* cum = d->cum_hist + (st * B + b0) * T;
+            PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_energy_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum, energy, q_s));
+            PROBED(MSTTS_PROBE_LSA_CONTEXT, q_s, mstts_lsa_context_fwd(&lc, energy, cum, d->align_hist + (st * B + b0) * T,
+                                     d->cum_hist + ((st + 1) * B + b0) * T, in0n, W0, pj + H, WP, q_s));
+        }
     }
+    RC(chain_join(chains, s));
     return MSTTS_OK;
 }
 
@@ -231,65 +301,86 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
                   MSTTS_ERR_SHAPE, "decoder_train_bwd: null pointer");
     const mstts_decoder_train_desc* d = bd->fwd;
     const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T, CH = d->lsa.CH;
-    const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M, BT = B * T;
+    const long W0 = M + H, W1 = 2 * H, WP = H + M;
     const int sp1 = mstts_skinny_bwd_splits(W1, 4 * H), sp0 = mstts_skinny_bwd_splits(W0, 4 * H), spq = mstts_skinny_bwd_splits(H, A);
     const int np1 = sp1 > 0 ? sp1 : 1, npq = spq > 0 ? spq : 1;
     const long d_in0_slab = S * B * W0;
-    float* w = bd->ws;
-    float* dc0[2] = {w, w + BH};           w += 2 * BH;
-    float* dh0[2] = {w, w + BH};           w += 2 * BH;
-    float* dc1[2] = {w, w + BH};           w += 2 * BH;
-    float* dh1[2] = {w, w + BH};           w += 2 * BH;
-    float* G[2] = {w, w + BT};             w += 2 * BT;
-    float* df[2] = {w, w + BT * CH};       w += 2 * BT * CH;
-    float* d_align = w;                    w += BT;
-    float* tmp1 = w;                       w += (long)np1 * B * W1;     // [parts][B][2H]
-    float* dqm = w;                        w += (long)npq * BH;         // [parts][B][H]
-    RC(zero(bd->ws, 8 * BH, s));
-    int cur = 0, parts0 = 1, parts1 = 1, partsq = 1;
+    const int chains = pick_chains(d);
+    const long Bc = B / chains, BcH = Bc * H, BcT = Bc * T;
+    const long ws_per_row = 8 * H + 2 * T + 2 * T * CH + T + (long)np1 * W1 + (long)npq * H;
+    RC(zero(bd->ws, ws_per_row * B, s));
+    mstts_stream_t cs[MAX_CHAINS];
+    RC(chain_fork(chains, s, cs));
+    struct ChainWs { float *dc0[2], *dh0[2], *dc1[2], *dh1[2], *G[2], *df[2], *d_align, *tmp1, *dqm; int parts0, parts1, partsq; } cw[MAX_CHAINS];
+    for (int c = 0; c < chains; ++c) {
+        float* w = bd->ws + ws_per_row * (c * Bc);
+        ChainWs& k = cw[c];
+        k.dc0[0] = w; k.dc0[1] = w + BcH; w += 2 * BcH;
+        k.dh0[0] = w; k.dh0[1] = w + BcH; w += 2 * BcH;
+        k.dc1[0] = w; k.dc1[1] = w + BcH; w += 2 * BcH;
+        k.dh1[0] = w; k.dh1[1] = w + BcH; w += 2 * BcH;
+        k.G[0] = w; k.G[1] = w + BcT; w += 2 * BcT;
+        k.df[0] = w; k.df[1] = w + BcT * CH; w += 2 * BcT * CH;
+        k.d_align = w; w += BcT;
+        k.tmp1 = w; w += (long)np1 * Bc * W1;
+        k.dqm = w; w += (long)npq * BcH;
+        k.parts0 = k.parts1 = k.partsq = 1;
+    }
+    int cur = 0;
     for (long st = S - 1; st >= 0; --st) {
         const int nxt = cur ^ 1;
         const bool last = (st == S - 1);
-        float* dpj = bd->d_pj + st * B * WP;
-        // ---- attention backward
-        PROBED(MSTTS_PROBE_LSA_DALIGN, s, mstts_lsa_dalign_bwd(&d->lsa, dpj + H, WP, last ? nullptr : bd->d_in0 + (st + 1) * B * W0, W0,
-                                parts0, d_in0_slab, last ? nullptr : G[cur], last ? nullptr : df[cur], G[nxt], d_align, s));
-        PROBED(MSTTS_PROBE_LSA_DENERGY, s, mstts_lsa_denergy_bwd(&d->lsa, d->align_hist + st * BT, d_align, d->q_hist + st * B * A, d->cum_hist + st * BT,
-                                 bd->de_hist + st * BT, bd->dq_hist + st * B * A, df[nxt], s));
-        // d_m1 (query path) = dq . Wq^T  -> slabs consumed by the cell-1 pointwise kernel
-        RC(xw_bwd(bd->dq_hist + st * B * A, A, d->wq, A, dqm, 0, B, H, A, spq, &partsq, s));
-        // ---- cell 1 backward
-        mstts_lstm_point_bwd_desc p;
-        memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H;
-        p.d_out = dpj; p.dout_sb = WP; p.dout_st = 0;
-        p.d_out2 = dqm; p.dout2_parts = partsq; p.dout2_pstride = BH;
-        p.d_c_state = dc1[cur]; p.d_h_state = dh1[cur];
-        p.d_h_state2 = last ? nullptr : tmp1 + H; p.dhs2_ld = W1; p.dhs2_parts = parts1; p.dhs2_pstride = B * W1;
-        p.acts = d->acts1 + st * 4 * BH; p.c_raw = d->craw1 + st * BH; p.c_prev = d->c1 + st * BH;
-        p.zc = d->zc1 ? d->zc1 + st * BH : nullptr; p.zh = d->zh1 ? d->zh1 + st * BH : nullptr;
-        p.zoneout = d->zoneout;
-        p.dgates = bd->dg1 + st * 4 * BH;
-        p.d_c_prev = dc1[nxt]; p.d_h_prev = dh1[nxt];
-        RC(mstts_lstm_point_bwd(&p, s));
-        // [d_m0 | d_h1 state] = dg1 . w1^T
-        PROBED(MSTTS_PROBE_CELL1_DGEMM, s, xw_bwd(p.dgates, 4 * H, d->w1, 4 * H, tmp1, 0, B, W1, 4 * H, sp1, &parts1, s));
-        // ---- cell 0 backward
-        memset(&p, 0, sizeof(p));
-        p.B = B; p.H = H;
-        p.d_out = tmp1; p.dout_sb = W1; p.dout_st = 0; p.dout_parts = parts1; p.dout_pstride = B * W1;
-        p.d_c_state = dc0[cur]; p.d_h_state = dh0[cur];
-        p.d_h_state2 = last ? nullptr : bd->d_in0 + (st + 1) * B * W0 + M; p.dhs2_ld = W0; p.dhs2_parts = parts0; p.dhs2_pstride = d_in0_slab;
-        p.acts = d->acts0 + st * 4 * BH; p.c_raw = d->craw0 + st * BH; p.c_prev = d->c0 + st * BH;
-        p.zc = d->zc0 ? d->zc0 + st * BH : nullptr; p.zh = d->zh0 ? d->zh0 + st * BH : nullptr;
-        p.zoneout = d->zoneout;
-        p.dgates = bd->dg0 + st * 4 * BH;
-        p.d_c_prev = dc0[nxt]; p.d_h_prev = dh0[nxt];
-        RC(mstts_lstm_point_bwd(&p, s));
-        // [d_ctx_{st-1} | d_h0 state] = dg0 . w0f^T   (slabs at stride S*B*W0)
-        PROBED(MSTTS_PROBE_CELL0_DGEMM, s, xw_bwd(p.dgates, 4 * H, d->w0f, 4 * H, bd->d_in0 + st * B * W0, d_in0_slab, B, W0, 4 * H, sp0, &parts0, s));
+        for (int c = 0; c < chains; ++c) {
+            const long b0 = c * Bc;
+            mstts_stream_t q_s = cs[c];
+            ChainWs& k = cw[c];
+            mstts_lsa_const lc = d->lsa;
+            lc.B = Bc; lc.keys += b0 * T * A; lc.values += b0 * T * M;
+            if (lc.lengths) lc.lengths += b0;
+            float* dpj = bd->d_pj + (st * B + b0) * WP;
+            const float* d_in0_next = last ? nullptr : bd->d_in0 + ((st + 1) * B + b0) * W0;
+            // ---- attention backward
+            PROBED(MSTTS_PROBE_LSA_DALIGN, q_s, mstts_lsa_dalign_bwd(&lc, dpj + H, WP, d_in0_next, W0, k.parts0, d_in0_slab,
+                                    last ? nullptr : k.G[cur], last ? nullptr : k.df[cur], k.G[nxt], k.d_align, q_s));
+            PROBED(MSTTS_PROBE_LSA_DENERGY, q_s, mstts_lsa_denergy_bwd(&lc, d->align_hist + (st * B + b0) * T, k.d_align, d->q_hist + (st * B + b0) * A,
+                                     d->cum_hist + (st * B + b0) * T, bd->de_hist + (st * B + b0) * T, bd->dq_hist + (st * B + b0) * A, k.df[nxt], q_s));
+            // d_m1 (query path) = dq . Wq^T  -> slabs consumed by the cell-1 pointwise kernel
+            RC(xw_bwd(bd->dq_hist + (st * B + b0) * A, A, d->wq, A, k.dqm, 0, Bc, H, A, spq, &k.partsq, q_s));
+            // ---- cell 1 backward
+            mstts_lstm_point_bwd_desc p;
+            memset(&p, 0, sizeof(p));
+            p.B = Bc; p.H = H;
+            p.d_out = dpj; p.dout_sb = WP; p.dout_st = 0;
+            p.d_out2 = k.dqm; p.dout2_parts = k.partsq; p.dout2_pstride = BcH;
+            p.d_c_state = k.dc1[cur]; p.d_h_state = k.dh1[cur];
+            p.d_h_state2 = last ? nullptr : k.tmp1 + H; p.dhs2_ld = W1; p.dhs2_parts = k.parts1; p.dhs2_pstride = Bc * W1;
+            p.acts = d->acts1 + (st * B + b0) * 4 * H; p.c_raw = d->craw1 + (st * B + b0) * H; p.c_prev = d->c1 + (st * B + b0) * H;
+            p.zc = d->zc1 ? d->zc1 + (st * B + b0) * H : nullptr; p.zh = d->zh1 ? d->zh1 + (st * B + b0) * H : nullptr;
+            p.zoneout = d->zoneout;
+            p.dgates = bd->dg1 + (st * B + b0) * 4 * H;
+            p.d_c_prev = k.dc1[nxt]; p.d_h_prev = k.dh1[nxt];
+            RC(mstts_lstm_point_bwd(&p, q_s));
+            // [d_m0 | d_h1 state] = dg1 . w1^T
+            PROBED(MSTTS_PROBE_CELL1_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w1, 4 * H, k.tmp1, 0, Bc, W1, 4 * H, sp1, &k.parts1, q_s));
+            // ---- cell 0 backward
+            memset(&p, 0, sizeof(p));
+            p.B = Bc; p.H = H;
+            p.d_out = k.tmp1; p.dout_sb = W1; p.dout_st = 0; p.dout_parts = k.parts1; p.dout_pstride = Bc * W1;
+            p.d_c_state = k.dc0[cur]; p.d_h_state = k.dh0[cur];
+            p.d_h_state2 = last ? nullptr : d_in0_next + M; p.dhs2_ld = W0; p.dhs2_parts = k.parts0; p.dhs2_pstride = d_in0_slab;
+            p.acts = d->acts0 + (st * B + b0) * 4 * H; p.c_raw = d->craw0 + (st * B + b0) * H; p.c_prev = d->c0 + (st * B + b0) * H;
+            p.zc = d->zc0 ? d->zc0 + (st * B + b0) * H : nullptr; p.zh = d->zh0 ? d->zh0 + (st * B + b0) * H : nullptr;
+            p.zoneout = d->zoneout;
+            p.dgates = bd->dg0 + (st * B + b0) * 4 * H;
+            p.d_c_prev = k.dc0[nxt]; p.d_h_prev = k.dh0[nxt];
+            RC(mstts_lstm_point_bwd(&p, q_s));
+            // [d_ctx_{st-1} | d_h0 state] = dg0 . w0f^T   (slabs at stride S*B*W0)
+            PROBED(MSTTS_PROBE_CELL0_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w0f, 4 * H, bd->d_in0 + (st * B + b0) * W0, d_in0_slab, Bc, W0, 4 * H,
+                                                       sp0, &k.parts0, q_s));
+        }
         cur = nxt;
     }
+    RC(chain_join(chains, s));
     return MSTTS_OK;
 }
 

@@ -353,6 +353,107 @@ __global__ void lstm_point_bwd_kernel(mstts_lstm_point_bwd_desc d) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// lean decoder-path variants of the two kernels above (no sequence-length masking, no residual, no
+// position indirection, 32-bit indexing, compile-time slab count): the generic kernels cost ~1900
+// instructions per thread in address arithmetic alone, which is what a 32K-element step pays for.
+// ---------------------------------------------------------------------------------------------
+struct PointFwdFast {
+    const float* gates; int pstride;            // [PARTS][B][4H]
+    const float* xw; int xw_ld;                 // row b at xw + b*xw_ld (or null)
+    const float* bias;                          // [4H] or null
+    const float* c_prev; const float* h_prev; int h_prev_ld;
+    const uint8_t* zc; const uint8_t* zh; float keep;
+    float* out; int out_ld;
+    float* c_next; float* h_next; int h_next_ld;
+    float* acts; float* c_raw;
+    int B, H;
+};
+
+template <int PARTS>
+__global__ __launch_bounds__(128) void lstm_point_fwd_fast_kernel(PointFwdFast d) {
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    const int H = d.H;
+    if (i >= d.B * H) return;
+    const int b = i / H, u = i - b * H;
+    const int g0 = b * 4 * H + u;
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pp = 0; pp < PARTS; ++pp) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) g4[g] += d.gates[pp * d.pstride + g0 + g * H];
+    }
+    if (d.xw) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) g4[g] += d.xw[b * d.xw_ld + g * H + u];
+    }
+    if (d.bias) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) g4[g] += d.bias[g * H + u];
+    }
+    const float cp = d.c_prev[i], hp = d.h_prev[b * d.h_prev_ld + u];
+    const float kc = d.zc ? (d.zc[i] ? d.keep : 0.f) : d.keep;
+    const float kh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
+    const float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
+    const float c = sf * cp + si * tj;
+    const float m = so * tanhf(c);
+    d.c_next[i] = kc * (c - cp) + cp;
+    d.h_next[b * d.h_next_ld + u] = kh * (m - hp) + hp;
+    d.out[b * d.out_ld + u] = m;
+    float* a = d.acts + g0;
+    a[0] = si; a[H] = tj; a[2 * H] = sf; a[3 * H] = so;
+    d.c_raw[i] = c;
+}
+
+struct PointBwdFast {
+    const float* d_out; int dout_ld, dout_parts, dout_pstride;     // may be null
+    const float* d_out2; int dout2_parts, dout2_pstride;           // [parts][B][H] or null
+    const float* d_c_state; const float* d_h_state;
+    const float* dhs2; int dhs2_ld, dhs2_parts; long dhs2_pstride; // or null
+    const float* acts; const float* c_raw; const float* c_prev;
+    const uint8_t* zc; const uint8_t* zh; float keep;
+    float* dgates; float* d_c_prev; float* d_h_prev;
+    int B, H;
+};
+
+template <int P_OUT, int P_OUT2, int P_DHS>
+__global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d) {
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    const int H = d.H;
+    if (i >= d.B * H) return;
+    const int b = i / H, u = i - b * H;
+    float dm = 0.f;
+    if (d.d_out) {
+#pragma unroll
+        for (int pp = 0; pp < P_OUT; ++pp) dm += d.d_out[pp * d.dout_pstride + b * d.dout_ld + u];
+    }
+    if (d.d_out2) {
+#pragma unroll
+        for (int pp = 0; pp < P_OUT2; ++pp) dm += d.d_out2[pp * d.dout2_pstride + i];
+    }
+    float dhs = d.d_h_state[i];
+    if (d.dhs2) {
+#pragma unroll
+        for (int pp = 0; pp < P_DHS; ++pp) dhs += d.dhs2[pp * d.dhs2_pstride + b * d.dhs2_ld + u];
+    }
+    const float dcs = d.d_c_state[i];
+    const float mh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
+    const float mc = d.zc ? (d.zc[i] ? d.keep : 0.f) : d.keep;
+    dm += mh * dhs;
+    const float* a = d.acts + b * 4 * H + u;
+    const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
+    const float c = d.c_raw[i], cp = d.c_prev[i];
+    const float tc = tanhf(c);
+    const float dc = dm * so * (1.f - tc * tc) + mc * dcs;
+    float* dg = d.dgates + b * 4 * H + u;
+    dg[0] = dc * tj * si * (1.f - si);
+    dg[H] = dc * si * (1.f - tj * tj);
+    dg[2 * H] = dc * cp * sf * (1.f - sf);
+    dg[3 * H] = dm * tc * so * (1.f - so);
+    d.d_c_prev[i] = dcs * (1.f - mc) + dc * sf;
+    d.d_h_prev[i] = dhs * (1.f - mh);
+}
+
+// ---------------------------------------------------------------------------------------------
 // losses
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tts_loss_kernel(const float* __restrict__ lin, const float* __restrict__ post,
@@ -619,6 +720,24 @@ extern "C" int mstts_fold_rows(const float* src, float* dst, int64_t rows, int64
 extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_stream_t s) {
     MSTTS_REQUIRE(d && d->gates_h && d->c_prev && d->h_prev && d->c_next && d->h_next, MSTTS_ERR_SHAPE, "lstm_point_fwd: null pointer");
     if (d->B * d->H == 0) return MSTTS_OK;
+    const int parts = d->gates_parts > 1 ? d->gates_parts : 1;
+    const bool fast = !d->lengths && !d->residual && !d->reverse && d->out && d->acts_out && d->c_raw && d->xw_st == 0 &&
+                      d->out_st == 0 && d->B * d->H * 4 < (1LL << 30) && (parts == 1 || parts == 4) &&
+                      (long)parts * d->gates_pstride < (1LL << 30);
+    if (fast) {
+        PointFwdFast f;
+        f.gates = d->gates_h; f.pstride = (int)d->gates_pstride; f.xw = d->xw; f.xw_ld = (int)d->xw_sb; f.bias = d->bias;
+        f.c_prev = d->c_prev; f.h_prev = d->h_prev; f.h_prev_ld = (int)(d->h_prev_ld ? d->h_prev_ld : d->H);
+        f.zc = d->zc; f.zh = d->zh; f.keep = 1.f - d->zoneout;
+        f.out = d->out; f.out_ld = (int)d->out_sb; f.c_next = d->c_next; f.h_next = d->h_next;
+        f.h_next_ld = (int)(d->h_next_ld ? d->h_next_ld : d->H); f.acts = d->acts_out; f.c_raw = d->c_raw;
+        f.B = (int)d->B; f.H = (int)d->H;
+        dim3 grid((unsigned)((d->B * d->H + 127) / 128));
+        if (parts == 4) hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<4>, grid, dim3(128), 0, ST(s), f);
+        else hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<1>, grid, dim3(128), 0, ST(s), f);
+        MSTTS_CHECK_LAUNCH("lstm_point_fwd_fast");
+        return MSTTS_OK;
+    }
     hipLaunchKernelGGL(lstm_point_fwd_kernel, dim3(grid_for(d->B * d->H, 256)), dim3(256), 0, ST(s), *d);
     MSTTS_CHECK_LAUNCH("lstm_point_fwd");
     return MSTTS_OK;
@@ -627,6 +746,28 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
     MSTTS_REQUIRE(d && d->d_c_state && d->d_h_state && d->acts && d->c_raw && d->c_prev && d->dgates && d->d_c_prev && d->d_h_prev,
                   MSTTS_ERR_SHAPE, "lstm_point_bwd: null pointer");
     if (d->B * d->H == 0) return MSTTS_OK;
+    {
+        const int po = d->dout_parts > 1 ? d->dout_parts : 1, po2 = d->dout2_parts > 1 ? d->dout2_parts : 1;
+        const int ph = d->dhs2_parts > 1 ? d->dhs2_parts : 1;
+        const bool shape41 = (po == 1 && po2 == 1 && ph == 4), shape414 = (po == 4 && po2 == 1 && ph == 4), shape111 = (po == 1 && po2 == 1 && ph == 1);
+        const bool fast = !d->lengths && !d->reverse && !d->dgates_pos && d->dout_st == 0 && d->B * d->H * 4 < (1LL << 30) &&
+                          (shape41 || shape414 || shape111) && (long)po * d->dout_pstride < (1LL << 30);
+        if (fast) {
+            PointBwdFast f;
+            f.d_out = d->d_out; f.dout_ld = (int)d->dout_sb; f.dout_parts = po; f.dout_pstride = (int)d->dout_pstride;
+            f.d_out2 = d->d_out2; f.dout2_parts = po2; f.dout2_pstride = (int)d->dout2_pstride;
+            f.d_c_state = d->d_c_state; f.d_h_state = d->d_h_state;
+            f.dhs2 = d->d_h_state2; f.dhs2_ld = (int)d->dhs2_ld; f.dhs2_parts = ph; f.dhs2_pstride = (long)d->dhs2_pstride;
+            f.acts = d->acts; f.c_raw = d->c_raw; f.c_prev = d->c_prev; f.zc = d->zc; f.zh = d->zh; f.keep = 1.f - d->zoneout;
+            f.dgates = d->dgates; f.d_c_prev = d->d_c_prev; f.d_h_prev = d->d_h_prev; f.B = (int)d->B; f.H = (int)d->H;
+            dim3 grid((unsigned)((d->B * d->H + 127) / 128));
+            if (shape41) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 4>), grid, dim3(128), 0, ST(s), f);
+            else if (shape414) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<4, 1, 4>), grid, dim3(128), 0, ST(s), f);
+            else hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 1>), grid, dim3(128), 0, ST(s), f);
+            MSTTS_CHECK_LAUNCH("lstm_point_bwd_fast");
+            return MSTTS_OK;
+        }
+    }
     hipLaunchKernelGGL(lstm_point_bwd_kernel, dim3(grid_for(d->B * d->H, 256)), dim3(256), 0, ST(s), *d);
     MSTTS_CHECK_LAUNCH("lstm_point_bwd");
     return MSTTS_OK;

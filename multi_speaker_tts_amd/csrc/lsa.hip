@@ -15,10 +15,11 @@
 
 namespace mstts {
 
-constexpr int TS = 16;      // encoder positions per workgroup
+constexpr int TS = 8;       // encoder positions per workgroup (T/8 x B workgroups: 512 at T=128, B=32 -> 2 waves per SIMD)
 constexpr int A_ = 128;     // attention units  (hp.Attention.Memory_Size)
 constexpr int CH_ = 32;     // location conv channels (hp.Attention.Conv.Channel)
-constexpr int KS_MAX = 63;  // location conv taps upper bound (reference: 31)
+constexpr int FLD = CH_ + 4; // LDS row stride of the location features: rows stay 16-byte aligned for b128 broadcast reads
+constexpr int KS_MAX = 31;  // location conv taps upper bound (= the reference's hp.Attention.Conv.Kernel_Size)
 
 __device__ __forceinline__ float fast_tanh(float x) {
     // tanh via one exp; relative error ~1e-6 over the energy pre-activation range
@@ -33,23 +34,25 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // location features from an LDS-resident window of the cumulative alignment and a register-resident
 // conv kernel column: thread (tt = tid/32 [+8], ch = tid%32): f[tt][ch] = b[ch] + sum_j cum[tt+j] * k[j][ch]
 __device__ __forceinline__ void location_features_regs(int KS, const float* s_cum, const float (&ck)[KS_MAX], float cb,
-                                                       float (*s_f)[CH_ + 1]) {
+                                                       float (*s_f)[FLD]) {
     const int ch = threadIdx.x & (CH_ - 1), tt = threadIdx.x >> 5;      // 8 row groups x 32 channels
-    float a0 = cb, a1 = cb;
+    float a[TS / 8];
+#pragma unroll
+    for (int r = 0; r < TS / 8; ++r) a[r] = cb;
 #pragma unroll
     for (int j = 0; j < KS_MAX; ++j) {
         if (j < KS) {
-            a0 += s_cum[tt + j] * ck[j];
-            a1 += s_cum[tt + 8 + j] * ck[j];
+#pragma unroll
+            for (int r = 0; r < TS / 8; ++r) a[r] += s_cum[tt + 8 * r + j] * ck[j];
         }
     }
-    s_f[tt][ch] = a0;
-    s_f[tt + 8][ch] = a1;
+#pragma unroll
+    for (int r = 0; r < TS / 8; ++r) s_f[tt + 8 * r][ch] = a[r];
 }
 
 // legacy helper (post-loop kernel): stage cum window + conv kernel through LDS
 __device__ __forceinline__ void location_features(const mstts_lsa_const& c, const float* __restrict__ cum_row, int t0,
-                                                  float* s_cum, float* s_ck, float (*s_f)[CH_ + 1]) {
+                                                  float* s_cum, float* s_ck, float (*s_f)[FLD]) {
     const int KS = (int)c.KS, T = (int)c.T, pad = (KS - 1) / 2;
     for (int i = threadIdx.x; i < TS + KS - 1; i += blockDim.x) {
         const int t = t0 - pad + i;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, cons
                                                          float* __restrict__ q_sum, const float* __restrict__ cum,
                                                          float* __restrict__ energy) {
     __shared__ float s_cum[TS + KS_MAX - 1];
-    __shared__ float s_f[TS][CH_ + 1];
+    __shared__ __attribute__((aligned(16))) float s_f[TS][FLD];
     __shared__ float s_red[TS][2];
     const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;        // 2 groups of 128 lanes
@@ -111,7 +114,10 @@ __global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, cons
         if (t0 + tt < T) {
             float pre = kv[i] + qk;
 #pragma unroll
-            for (int cc = 0; cc < CH_; ++cc) pre += s_f[tt][cc] * dk[cc];
+            for (int cc = 0; cc < CH_; cc += 4) {
+                const float4 f4 = *reinterpret_cast<const float4*>(&s_f[tt][cc]);
+                pre += f4.x * dk[cc] + f4.y * dk[cc + 1] + f4.z * dk[cc + 2] + f4.w * dk[cc + 3];
+            }
             e = wk * fast_tanh(pre);
         }
         e = wave_sum(e);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
         ckv[i] = (d_f_next && e < KS * CH_) ? c.conv_k[e] : 0.f;
     }
     // (b) the wave's 4 value rows (tt = w + 4*r) and the d_ctx row, MROW float4 per lane each
-    float4 dcv[MROW], val[4][MROW];
+    float4 dcv[MROW], val[TS / 4][MROW];
     const float* dc = d_ctx + (long)b * d_ctx_ld;
 #pragma unroll
     for (int m = 0; m < MROW; ++m) {
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
         dcv[m] = y;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < TS / 4; ++r) {
         const int t = t0 + w + 4 * r;
 #pragma unroll
         for (int m = 0; m < MROW; ++m) {
@@ -289,16 +295,17 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
     }
     __syncthreads();
     {
-        const int tt = threadIdx.x >> 4, part = threadIdx.x & 15;
+        constexpr int LPR = 256 / TS;                    // lanes per row
+        const int tt = threadIdx.x / LPR, part = threadIdx.x % LPR;
         float acc = 0.f;
         if (d_f_next) {
-            for (int p = part; p < KS * CH_; p += 16) {
+            for (int p = part; p < KS * CH_; p += LPR) {
                 const int j = p / CH_, chn = p % CH_;
                 acc += s_df[tt + (KS - 1) - j][chn] * s_ck[p];
             }
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (part == 0) s_g[tt] = acc;
     }
     __syncthreads();
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
     __syncthreads();
     // ---- values . d_ctx for this wave's rows
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < TS / 4; ++r) {
         const int tt = w + 4 * r, t = t0 + tt;
         float acc = 0.f;
 #pragma unroll
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
                                                           const float* __restrict__ cum, float* __restrict__ d_e_out,
                                                           float* __restrict__ dq, float* __restrict__ d_f) {
     __shared__ float s_cum[TS + KS_MAX - 1];
-    __shared__ float s_f[TS][CH_ + 1];
+    __shared__ __attribute__((aligned(16))) float s_f[TS][FLD];
     __shared__ float s_g[TS][A_];
     __shared__ float s_dkT[A_][CH_ + 1];
     __shared__ float s_de[TS];
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, i
                                                             float* __restrict__ d_score_b) {
     __shared__ float s_cum[TS + KS_MAX - 1];
     __shared__ float s_ck[KS_MAX * CH_];
-    __shared__ float s_f[TS][CH_ + 1];
+    __shared__ __attribute__((aligned(16))) float s_f[TS][FLD];
     __shared__ float s_g[TS][A_];
     __shared__ float s_dkT[A_][CH_ + 1];
     __shared__ float s_df[TS][CH_ + 1];

@@ -25,6 +25,7 @@ constexpr int MAX_IT = 32;        // weight float4 loads per lane held in regist
 // ---------------------------------------------------------------------------------------------
 // forward: strip of 64 columns, K-slice of KL rows (KL % 16 == 0, KL <= 512), 4 waves split the slice
 // ---------------------------------------------------------------------------------------------
+template <int NIT, bool TWO>      // NIT > 0: exact trip count (guard-free code); TWO: rows 16..31 of the block exist
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W, long ldw,
                                                          float* __restrict__ P, long pstride, int M, int N, int K, int KL) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -34,16 +35,18 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int wl = KL / 4;                            // rows per wave (multiple of 4)
-    const int nit = wl / 4;
+    constexpr bool EXACT = NIT > 0;
+    constexpr int UNROLL = EXACT ? NIT : MAX_IT;
+    const int nit = EXACT ? NIT : wl / 4;
     const int wk0 = wave * wl;
     // 1) all weight loads of this wave: row kb + wk0 + 4*it + kq, columns n0 + 4j .. 4j+3
     const bool col_ok = n0 + 4 * j + 3 < N;
     const float* wp = W + (long)(kb + wk0 + kq) * ldw + n0 + 4 * j;
-    f32x4 wreg[MAX_IT];
+    f32x4 wreg[UNROLL];
 #pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
+    for (int it = 0; it < UNROLL; ++it) {
         wreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (it < nit && col_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (long)(4 * it) * ldw));
+        if ((EXACT || it < nit) && col_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (long)(4 * it) * ldw));
     }
     // 2) stage X[m0 .. m0+32, kb .. kb+KL) row-major into LDS (rows >= M are zero): 8 threads per row,
     //    all loads issued before the first LDS write (one memory round trip, not one per float4)
@@ -75,18 +78,20 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     const float* xa = smem + j * lds_ld + wk0 + kq;
     const float* xb = xa + 16 * lds_ld;
 #pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-        if (it < nit) {
-            const float a0 = xa[4 * it], a1 = xb[4 * it];
+    for (int it = 0; it < UNROLL; ++it) {
+        if (EXACT || it < nit) {
+            const float a0 = xa[4 * it], a1 = TWO ? xb[4 * it] : 0.f;
             const f32x4 bv = wreg[it];
             acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[0], acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[0], acc[1][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[1], acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[1], acc[1][1], 0, 0, 0);
             acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[2], acc[0][2], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[2], acc[1][2], 0, 0, 0);
             acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[3], acc[0][3], 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[3], acc[1][3], 0, 0, 0);
+            if (TWO) {
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[1], acc[1][1], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[2], acc[1][2], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[3], acc[1][3], 0, 0, 0);
+            }
         }
     }
     // 4) cross-wave reduction through LDS: red[wave][row 32][col 64 (+1)]
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 // backward: strip of 32 kernel rows, N-slice of NL columns (NL % 32 == 0, NL <= 1024).
 // wave w: row tile (w & 1) of 16 rows, column half (w >> 1) of the slice.
 // ---------------------------------------------------------------------------------------------
+template <int NIT, bool TWO>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ dG, long ldg, const float* __restrict__ W, long ldw,
                                                          float* __restrict__ P, long pstride, int M, int R, int N, int NL) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -124,16 +130,18 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
     const int j = lane & 15, kq = lane >> 4;
     const int rt = wave & 1, half = wave >> 1;
     const int hl = NL / 2;                             // columns per wave, multiple of 16
-    const int nit = hl / 16;
+    constexpr bool EXACT = NIT > 0;
+    constexpr int UNROLL = EXACT ? NIT : MAX_IT;
+    const int nit = EXACT ? NIT : hl / 16;
     const int c0 = half * hl + 4 * kq;                 // slice-relative first column of this lane
     // 1) all weight loads: row r0 + 16*rt + j, columns nb + c0 + 16*it .. +3
     const bool row_ok = r0 + 16 * rt + j < R;
     const float* wp = W + (long)(r0 + 16 * rt + j) * ldw + nb + c0;
-    f32x4 wreg[MAX_IT];
+    f32x4 wreg[UNROLL];
 #pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
+    for (int it = 0; it < UNROLL; ++it) {
         wreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (it < nit && row_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + 16 * it));
+        if ((EXACT || it < nit) && row_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + 16 * it));
     }
     // 2) stage dG[m0 .. m0+32, nb .. nb+NL) into LDS: 8 threads per row, two rounds of 16 float4 each,
     //    every round's loads issued before its first LDS write
@@ -166,19 +174,21 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
     const float* a0p = smem + j * lds_ld + c0;
     const float* a1p = a0p + 16 * lds_ld;
 #pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-        if (it < nit) {
+    for (int it = 0; it < UNROLL; ++it) {
+        if (EXACT || it < nit) {
             const float4 av0 = *reinterpret_cast<const float4*>(a0p + 16 * it);
-            const float4 av1 = *reinterpret_cast<const float4*>(a1p + 16 * it);
+            const float4 av1 = TWO ? *reinterpret_cast<const float4*>(a1p + 16 * it) : make_float4(0.f, 0.f, 0.f, 0.f);
             const f32x4 bv = wreg[it];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.x, bv[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.x, bv[0], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.y, bv[1], acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.y, bv[1], acc3, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.z, bv[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.z, bv[2], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.w, bv[3], acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.w, bv[3], acc3, 0, 0, 0);
+            if (TWO) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.x, bv[0], acc1, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.y, bv[1], acc3, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.z, bv[2], acc1, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.w, bv[3], acc3, 0, 0, 0);
+            }
         }
     }
     // 4) reduce the two column halves, write the 32 x 32 tile
@@ -202,10 +212,32 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
 static bool g_attr_set = false;
 static void set_lds_attr() {
     if (g_attr_set) return;
-    hipFuncSetAttribute((const void*)skinny_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)skinny_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define MSTTS_SK_ATTR(N, T)                                                                                                   \
+    hipFuncSetAttribute((const void*)skinny_fwd_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    hipFuncSetAttribute((const void*)skinny_bwd_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    MSTTS_SK_ATTR(0, true) MSTTS_SK_ATTR(0, false) MSTTS_SK_ATTR(2, true) MSTTS_SK_ATTR(2, false) MSTTS_SK_ATTR(4, true) MSTTS_SK_ATTR(4, false)
+    MSTTS_SK_ATTR(28, true) MSTTS_SK_ATTR(28, false) MSTTS_SK_ATTR(32, true) MSTTS_SK_ATTR(32, false)
+#undef MSTTS_SK_ATTR
     g_attr_set = true;
 }
+
+// pick the guard-free instantiation when the trip count is one of the shapes the model produces
+#define MSTTS_SK_DISPATCH(KERNEL, nit, two, ...)                                                       \
+    do {                                                                                               \
+        if (two) {                                                                                     \
+            if (nit == 32) hipLaunchKernelGGL((KERNEL<32, true>), __VA_ARGS__);                        \
+            else if (nit == 28) hipLaunchKernelGGL((KERNEL<28, true>), __VA_ARGS__);                   \
+            else if (nit == 4) hipLaunchKernelGGL((KERNEL<4, true>), __VA_ARGS__);                     \
+            else if (nit == 2) hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__);                     \
+            else hipLaunchKernelGGL((KERNEL<0, true>), __VA_ARGS__);                                   \
+        } else {                                                                                       \
+            if (nit == 32) hipLaunchKernelGGL((KERNEL<32, false>), __VA_ARGS__);                       \
+            else if (nit == 28) hipLaunchKernelGGL((KERNEL<28, false>), __VA_ARGS__);                  \
+            else if (nit == 4) hipLaunchKernelGGL((KERNEL<4, false>), __VA_ARGS__);                    \
+            else if (nit == 2) hipLaunchKernelGGL((KERNEL<2, false>), __VA_ARGS__);                    \
+            else hipLaunchKernelGGL((KERNEL<0, false>), __VA_ARGS__);                                  \
+        }                                                                                              \
+    } while (0)
 
 }  // namespace mstts
 using namespace mstts;
@@ -240,8 +272,10 @@ extern "C" int mstts_skinny_fwd(const float* X, int64_t ldx, const float* W, int
     if (lds < red) lds = red;
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)ksplit, (unsigned)((M + 31) / 32));
     set_lds_attr();
-    hipLaunchKernelGGL(skinny_fwd_kernel, grid, dim3(256), lds, (hipStream_t)s, X, (long)ldx, W, (long)ldw, P,
-                       (long)(pstride > 0 ? pstride : M * N), (int)M, (int)N, (int)K, KL);
+    const int nit = KL / 16;
+    const bool two = M > 16;      // blocks of 32 rows; with M <= 16 the second 16-row MFMA tile is all padding
+    MSTTS_SK_DISPATCH(skinny_fwd_kernel, nit, two, grid, dim3(256), lds, (hipStream_t)s, X, (long)ldx, W, (long)ldw, P,
+                      (long)(pstride > 0 ? pstride : M * N), (int)M, (int)N, (int)K, KL);
     MSTTS_CHECK_LAUNCH("skinny_fwd");
     return MSTTS_OK;
 }
@@ -277,8 +311,10 @@ extern "C" int mstts_skinny_bwd(const float* dG, int64_t ldg, const float* W, in
     if (lds < red) lds = red;
     dim3 grid((unsigned)((R + 31) / 32), (unsigned)nsplit, (unsigned)((M + 31) / 32));
     set_lds_attr();
-    hipLaunchKernelGGL(skinny_bwd_kernel, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, W, (long)ldw, P,
-                       (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL);
+    const int nit = NL / 32;
+    const bool two = M > 16;
+    MSTTS_SK_DISPATCH(skinny_bwd_kernel, nit, two, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, W, (long)ldw, P,
+                      (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL);
     MSTTS_CHECK_LAUNCH("skinny_bwd");
     return MSTTS_OK;
 }

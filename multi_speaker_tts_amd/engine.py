@@ -50,6 +50,7 @@ class TrainEngine:
         self.device = torch.device(device)
         self.seed, self.rank, self.world = seed, rank, world
         self.update_vocoder_bn = update_vocoder_bn
+        self.chains = int(__import__('os').environ.get('MSTTS_DECODER_CHAINS', '1'))
         self.use_l1, self.wr_rate, self.adam = use_l1, wr_rate, adam
         self.params = ParamStore(self.d, self.device, seed=seed, values=values)
         self._plans = {}
@@ -283,6 +284,7 @@ class TrainEngine:
         dec.xw0, dec.w0f, dec.w1, dec.b1, dec.wq = ptr(w.xw0), ptr(self.w0f), ptr(k1, o1), ptr(b1, ob1), ptr(wq, oq)
         dec.zc0, dec.zh0, dec.zc1, dec.zh1 = ptr(mk["dec_zc_0"]), ptr(mk["dec_zh_0"]), ptr(mk["dec_zc_1"]), ptr(mk["dec_zh_1"])
         dec.zoneout = d.zoneout
+        dec.chains = self.chains if (B % max(self.chains, 1) == 0 and B // max(self.chains, 1) >= 8) else 1
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))
         call("mstts_decoder_train_fwd", C.byref(dec))

@@ -69,7 +69,7 @@ class DecoderTrain(C.Structure):
                 ("zc0", vp), ("zh0", vp), ("zc1", vp), ("zh1", vp), ("zoneout", f32),
                 ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp),
                 ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
-                ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp)]
+                ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp), ("chains", i32)]
 
 
 class DecoderTrainBwd(C.Structure):

@@ -1,0 +1,163 @@
+"""Host-side data contract of the reference's ``Feeder`` (Feeder.py:33-41,62-87,186-233) without
+TensorFlow: the same tensor names / dtypes / padding, tokenisation and speaker-window extraction,
+plus synthetic train patterns of the benchmark shape.  Mel extraction of speaker wavs runs on the
+GPU through ``Audio.melspectrogram``; wav file reading/resampling/trimming is scipy plumbing (the
+reference uses librosa.core.load + librosa.effects.trim, which are not available here).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from . import Hyper_Parameters as hp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PLACEHOLDERS = ("Is_Training", "Token", "Token_Length", "Mel", "Mel_Length", "Speaker_Embedding_Mel")
+
+
+def load_token_dict(path=None):
+    with open(path or os.path.join(_HERE, "Token_Index_Dict.json"), "r") as f:
+        return json.load(f)
+
+
+_TOKENS = None
+
+
+def _tokens():
+    global _TOKENS
+    if _TOKENS is None:
+        _TOKENS = load_token_dict()
+    return _TOKENS
+
+
+def tokenize(text_List, token_dict=None):
+    """text -> int32 [B, T_max] (<S> chars <E>, upper-cased, right-padded with <E>) and lengths.
+    Unknown characters raise KeyError exactly like the reference's dict lookup (Feeder.py:192)."""
+    table = token_dict or _tokens()
+    start, end = table["<S>"], table["<E>"]
+    rows = []
+    for text in text_List:
+        ids = [start]
+        for letter in text.upper():
+            ids.append(table[letter])
+        ids.append(end)
+        rows.append(ids)
+    width = max(len(r) for r in rows)
+    token = np.full((len(rows), width), end, dtype=np.int32)
+    for i, r in enumerate(rows):
+        token[i, :len(r)] = r
+    return token, np.asarray([len(r) for r in rows], dtype=np.int32)
+
+
+def _required_frames():
+    inf = hp.Speaker_Embedding.Inference
+    return inf.Sample_Nums * (inf.Mel_Frame - inf.Overlap_Frame) + inf.Overlap_Frame
+
+
+def window_starts(n_frames):
+    """Start frames of the Sample_Nums windows taken from the middle of a mel (None: too short)."""
+    inf = hp.Speaker_Embedding.Inference
+    need = _required_frames()
+    if n_frames < need:
+        return None
+    first = int((n_frames - need) / 2)
+    return [first + k * inf.Overlap_Frame for k in range(inf.Sample_Nums)]
+
+
+def speaker_windows(mel_List):
+    """[T_i, mel] list -> float32 [len * Sample_Nums, Mel_Frame, mel] (Feeder.Speaker_Embedding_Mel)."""
+    inf = hp.Speaker_Embedding.Inference
+    out = np.zeros((len(mel_List), inf.Sample_Nums, inf.Mel_Frame, hp.Sound.Mel_Dim), dtype=np.float32)
+    for i, mel in enumerate(mel_List):
+        starts = window_starts(mel.shape[0])
+        if starts is None:
+            head = mel[:inf.Mel_Frame]
+            out[i, :, :head.shape[0]] = head          # every window gets the same (zero-padded) head
+        else:
+            for k, s0 in enumerate(starts):
+                out[i, k] = mel[s0:s0 + inf.Mel_Frame]
+    return out.reshape(-1, inf.Mel_Frame, hp.Sound.Mel_Dim)
+
+
+def stop_cut(stop):
+    """Export cut (MSTTS_SV.py:395): index of the first frame whose sigmoid(stop) > 0.5, else the length."""
+    stop = np.asarray(stop)
+    hit = np.nonzero(stop > 0.5)[0]
+    return int(hit[0]) if hit.size else int(stop.shape[0])
+
+
+def load_wav(path, sample_rate=None, top_db=15.0):
+    """Speaker wav -> float mono at hp.Sound.Sample_Rate, silence-trimmed, scaled by 0.99
+    (Feeder.py:213-215 plumbing: scipy.io.wavfile + polyphase resampling + a frame_length=32 /
+    hop_length=16 RMS trim standing in for librosa.effects.trim)."""
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    sr = sample_rate or hp.Sound.Sample_Rate
+    rate, data = wavfile.read(path)
+    if data.dtype.kind == "i":
+        data = data.astype(np.float32) / float(np.iinfo(data.dtype).max)
+    elif data.dtype.kind == "u":
+        data = (data.astype(np.float32) - 128.0) / 128.0
+    data = data.astype(np.float32)
+    if data.ndim > 1:
+        data = data.mean(axis=1)
+    if rate != sr:
+        g = np.gcd(int(rate), int(sr))
+        data = resample_poly(data, sr // g, rate // g).astype(np.float32)
+    frame, hop = 32, 16
+    if data.shape[0] >= frame:
+        n = 1 + (data.shape[0] - frame) // hop
+        idx = np.arange(frame)[None, :] + hop * np.arange(n)[:, None]
+        rms = np.sqrt((data[idx] ** 2).mean(axis=1))
+        db = 20.0 * np.log10(np.maximum(rms, 1e-10) / max(rms.max(), 1e-10))
+        keep = np.nonzero(db > -top_db)[0]
+        if keep.size:
+            data = data[keep[0] * hop: min(data.shape[0], (keep[-1] + 1) * hop)]
+    return data * 0.99
+
+
+class Feeder:
+    """Same constructor / pattern API as the reference class; `placeholder_Dict` maps the reference's
+    placeholder names to themselves (there is no graph), patterns are dicts keyed by those names."""
+
+    def __init__(self, is_Training=False, device="cuda"):
+        self.is_Training = is_Training
+        self.device = device
+        self.placeholder_Dict = {name: name for name in PLACEHOLDERS}
+        self.metadata_Dict = {"Token_Index_Dict": load_token_dict()}
+
+    def Speaker_Embedding_Mel(self, mel_List):
+        return speaker_windows(mel_List)
+
+    def Get_Inference_Pattern(self, speaker_Wav_Path_List, text_List, speaker_Mel_List=None):
+        """Feeder.py:186-233.  `speaker_Mel_List` ([T,80] arrays) may be given instead of wav paths."""
+        from . import Audio
+        token, length = tokenize(text_List, self.metadata_Dict["Token_Index_Dict"])
+        if speaker_Mel_List is None:
+            speaker_Mel_List = [
+                np.transpose(Audio.melspectrogram(
+                    y=load_wav(path), num_freq=hp.Sound.Spectrogram_Dim, frame_shift_ms=hp.Sound.Frame_Shift,
+                    frame_length_ms=hp.Sound.Frame_Length, num_mels=hp.Sound.Mel_Dim, sample_rate=hp.Sound.Sample_Rate,
+                    max_abs_value=hp.Sound.Max_Abs_Mel, device=self.device)).astype(np.float32)
+                for path in speaker_Wav_Path_List]
+        return {
+            "Is_Training": False,
+            "Token": token,
+            "Token_Length": length,
+            "Mel": np.zeros((len(text_List), 1, hp.Sound.Mel_Dim), np.float32),
+            "Mel_Length": np.zeros(len(text_List), np.int32),
+            "Speaker_Embedding_Mel": speaker_windows(speaker_Mel_List),
+        }
+
+    def Get_Train_Pattern(self, is_Pre_Train=False, batch_Size=None, token_Length=128, mel_Length=800, seed=1234):
+        """Synthetic pattern of the benchmark shape; the reference's pickle-backed
+        producer thread (Feeder.py:89-184) is out of scope for this path."""
+        B = batch_Size or hp.Train.Batch_Size
+        g = np.random.default_rng(seed)
+        token = g.integers(2, hp.Encoder.Embedding.Token_Size, size=(B, token_Length)).astype(np.int32)
+        token[:, 0], token[:, -1] = 0, 1
+        mel = np.clip(g.normal(0, 1.5, size=(B, mel_Length, hp.Sound.Mel_Dim)), -4, 4).astype(np.float32)
+        return {"Is_Training": True, "Token": token, "Token_Length": np.full(B, token_Length, np.int32), "Mel": mel,
+                "Mel_Length": np.full(B, mel_Length, np.int32), "Speaker_Embedding_Mel": speaker_windows(list(mel))}

@@ -1,0 +1,77 @@
+"""The C-ABI library loads on a GPU-less host and exports exactly the symbols include/mstts.h declares;
+the ctypes table, the header and the library agree; the Hyper_Parameters tree matches the reference's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "mstts.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mstts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from multi_speaker_tts_amd import build, lib
+    path = build.build()
+    cdll = ctypes.CDLL(path)
+    declared = _header_symbols()
+    assert len(declared) >= 45
+    for name in declared:
+        assert hasattr(cdll, name), "library does not export %s" % name
+    assert sorted(lib.SIGNATURES) == declared, set(lib.SIGNATURES) ^ set(declared)
+    cdll.mstts_abi_version.restype = ctypes.c_int
+    assert cdll.mstts_abi_version() == 1
+    # host-only helpers are callable without a GPU
+    cdll.mstts_skinny_fwd_splits.restype = ctypes.c_int32
+    cdll.mstts_skinny_fwd_splits.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    assert cdll.mstts_skinny_fwd_splits(4096, 1792) == 4 and cdll.mstts_skinny_fwd_splits(4096, 80) == 0
+    cdll.mstts_skinny_bwd_splits.restype = ctypes.c_int32
+    cdll.mstts_skinny_bwd_splits.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    assert cdll.mstts_skinny_bwd_splits(1792, 4096) == 4
+
+
+def test_struct_layouts_match_header_sizes():
+    """ctypes.Structure sizes == sizeof in C (compiled with the same header)."""
+    import subprocess, tempfile
+    from multi_speaker_tts_amd import lib
+    names = {"mstts_gemm_desc": lib.GemmDesc, "mstts_lstm_point_fwd_desc": lib.LstmPointFwd, "mstts_lstm_point_bwd_desc": lib.LstmPointBwd,
+             "mstts_lsa_const": lib.LsaConst, "mstts_lstm_seq_fwd_desc": lib.LstmSeqFwd, "mstts_lstm_seq_bwd_desc": lib.LstmSeqBwd,
+             "mstts_decoder_train_desc": lib.DecoderTrain, "mstts_decoder_train_bwd_desc": lib.DecoderTrainBwd,
+             "mstts_decoder_infer_desc": lib.DecoderInfer}
+    src = '#include <stdio.h>\n#include "mstts.h"\nint main(){' + "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}"
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe], text=True)
+    for line in out.strip().splitlines():
+        n, sz = line.split()
+        assert ctypes.sizeof(names[n]) == int(sz), (n, ctypes.sizeof(names[n]), sz)
+
+
+def test_hparams_tree():
+    from multi_speaker_tts_amd import Hyper_Parameters as hp
+    assert hp.Sound.Sample_Rate == 16000 and hp.Sound.Mel_Dim == 80 and hp.Sound.Max_Abs_Mel == 4
+    assert hp.Encoder.Conv.Kernel_Size == 5 and hp.Encoder.BiLSTM.Cell_Size == 256 and hp.Attention.Conv.Kernel_Size == 31
+    assert hp.Decoder.PreNet.Use_Dropout is True and hp.Decoder.LSTM.Max_Inference_Length == 1000
+    assert hp.Train.ADAM.Epsilon == 1e-6 and hp.Train.Learning_Rate.Decay_Step == 10000 and hp.Train.Use_Wav_Length_Range == (500, 9000)
+    assert hp.Speaker_Embedding.Inference.Sample_Nums == 5 and hp.Taco1_Mel_to_Spect.ConvBank.Max_Kernel_Size == 8
+    assert hp.WaveGlow.Train.Max_Signal_Length == 8000 and hp.Use_Vocoder == "Taco1_Mel_to_Spect"
+    assert set(hp.Decoder.values()) == {"PreNet", "LSTM", "Conv"}
+
+
+def test_variable_table_counts():
+    from multi_speaker_tts_amd import params as PP
+    from oracle import model as OM
+    d = PP.Dims()
+    t = PP.variable_table(d)
+    n_train = sum(int(np.prod(s)) for n, s, _ in t if PP.is_trainable(n))
+    assert n_train == 30278977
+    assert [(n, tuple(s)) for n, s, _ in t] == [(n, tuple(s)) for n, s, _ in OM.param_specs(OM.Dims())]
+    a, b = PP.initial_values(PP.Dims(emb=8, enc_conv_ch=8), 3), OM.init_params(OM.Dims(emb=8, enc_conv_ch=8), 3)
+    assert all(np.allclose(a[k], b[k].astype(np.float32)) for k in a)

@@ -26,6 +26,9 @@ import torch
 
 B_PER_GPU, T_ENC, L_MEL = 32, 128, 800
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes of one attention step (lsa_energy + lsa_context) from the PMC passes committed in
+# profiles/r01_pmc_fetch_write_per_kernel.csv: FETCH_SIZE (2610 + 12401 KB, already x2 per the gfx950 note) + WRITE_SIZE (32 + 224 KB)
+ATTENTION_STEP_PMC_BYTES = (2610.0 + 12401.0 + 32.0 + 224.0) * 1024
 
 
 def synthetic_batch(dims, B, Te, L, seed, rank, device):
@@ -171,7 +174,7 @@ def main():
         ach = att_bytes / (att_us * 1e-6) / 1e9
         out["roofline"] = {"kernel": "lsa_step_fwd = lsa_energy_kernel + lsa_context_kernel (one decoder step, B=32)",
                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "algorithmic_bytes_per_launch": att_bytes, "avg_launch_us": att_us}
+                           "traffic": ATTENTION_STEP_PMC_BYTES if (L == L_MEL and world == 1) else None, "algorithmic_bytes_per_launch": att_bytes, "avg_launch_us": att_us}
         w0 = (M + H) * 4 * H * 4
         w1 = 2 * H * 4 * H * 4
         extra = []

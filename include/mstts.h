@@ -192,6 +192,12 @@ int mstts_unpack_proj(const float* proj, int64_t ldp, float* linear, float* stop
 int mstts_pack_dproj(const float* d_linear, const float* d_stop, float* d_proj, int64_t ldp, int64_t B, int64_t S, int64_t C, mstts_stream_t s);
 int mstts_speaker_tile(const float* spk, const int32_t* lengths, float* values, int64_t B, int64_t T, int64_t M, int64_t off, int64_t width, mstts_stream_t s);
 int mstts_conv_kernel_flip(const float* w, float* wt, int64_t K, int64_t Cin, int64_t Cout, mstts_stream_t s);
+/* dst[d1][d0][:] = src[d0][d1][:]  (step-major <-> batch-major histories) */
+int mstts_transpose01(const float* src, float* dst, int64_t D0, int64_t D1, int64_t C, mstts_stream_t s);
+/* Speaker_Embedding Modules.Inference (Speaker_Embedding/Modules.py:127-137): x [B*samples, T, E] ->
+ * out[b,:] = mean_k x[b*samples+k, T-1, :], then divided by the L2 norm of the WHOLE [B,E] tensor
+ * (tf.nn.l2_normalize with axis=None, epsilon 1e-12).  Single workgroup; B*E <= 65536. */
+int mstts_speaker_finalize(const float* x, float* out, int64_t B, int64_t samples, int64_t T, int64_t E, mstts_stream_t s);
 
 /* ---- tf.train.AdamOptimizer step on a flat slab (MSTTS_SV.py:171-176; epsilon outside the bias
  * correction).  g_total = grad*grad_scale + wd[i]*p ; wd_mask (uint8, may be NULL) selects the

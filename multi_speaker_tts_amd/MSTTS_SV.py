@@ -1,0 +1,149 @@
+"""Drop-in for the reference driver class ``MSTTS_SV.Tacotron2`` (MSTTS_SV.py:20-505) on the MI355X.
+
+Same constructor and methods - ``Tacotron2(is_Training)``, ``Restore()``, ``Train()``,
+``Inference(path_List, text_List, file_Prefix)`` - and the same result-dict keys
+(``train_Tensor_Dict`` / ``inference_Tensor_Dict`` names, MSTTS_SV.py:194-216).  The TensorFlow session is
+replaced by ``engine.TrainEngine`` / ``inference.InferEngine`` (libmstts_hip.so calls on one HIP stream).
+Out of scope here: matplotlib/WAV export threads, pickle feeder threads, TF checkpoint reading.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import Hyper_Parameters as hp
+from . import Feeder as _Feeder
+from .engine import TrainEngine, learning_rate
+from .inference import InferEngine
+from .params import Dims
+
+TRAIN_KEYS = ("Global_Step", "Learning_Rate", "Loss", "Linear_Loss", "Postnet_Loss", "Stop_Loss", "Weight_Regularization_Loss", "Train_OP")
+INFERENCE_KEYS = ("Global_Step", "Linear", "Mel", "Stop", "Attention_History", "Spectrogram")
+
+
+class Tacotron2:
+    def __init__(self, is_Training=False, device="cuda", seed=1234, dims: Dims = None):
+        self.is_Training = is_Training
+        self.device = device
+        self.feeder = _Feeder.Feeder(is_Training=is_Training, device=device)
+        self.train_engine = TrainEngine(dims, device=device, seed=seed)
+        self.params = self.train_engine.params
+        self.infer_engine = InferEngine(self.train_engine.d, device=device, seed=seed, params=self.params)
+        self.train_Tensor_Dict = {k: k for k in TRAIN_KEYS} if is_Training else None
+        self.inference_Tensor_Dict = {k: k for k in INFERENCE_KEYS}
+        self.Speaker_Embedding_Load()
+        self.Vocoder_Load()
+
+    # ---- checkpoints: torch files holding the two flat slabs (no TF checkpoint reader exists here)
+    @property
+    def global_step(self):
+        return self.train_engine.global_step
+
+    def _ckpt_dir(self):
+        return hp.Checkpoint_Path.replace("\\", "/")
+
+    def Speaker_Embedding_Load(self):
+        self._load_scope(hp.Speaker_Embedding.Checkpoint_Path, "speaker_embedding")
+
+    def Vocoder_Load(self):
+        if hp.Use_Vocoder.upper() != "Taco1_Mel_to_Spect".upper():
+            raise ValueError("only the Taco1_Mel_to_Spect vocoder is built on this path (WaveGlow is listed as 'next')")
+        self._load_scope(hp.Taco1_Mel_to_Spect.Checkpoint_Path, "mel_to_spectrogram")
+
+    def _load_scope(self, path, scope):
+        f = os.path.join(path.replace("\\", "/"), "%s.pt" % scope)
+        if not os.path.exists(f):
+            print("No %s checkpoint at '%s': keeping the random initialisation." % (scope, f))
+            return
+        values = torch.load(f, map_location="cpu")
+        self.params.load({k: v for k, v in values.items() if k.startswith(scope)})
+        print("%s checkpoint '%s' is loaded." % (scope, f))
+
+    def Restore(self):
+        d = self._ckpt_dir()
+        steps = sorted(int(n.split("-")[1].split(".")[0]) for n in os.listdir(d) if n.startswith("CHECKPOINT-")) if os.path.isdir(d) else []
+        if not steps:
+            print("There is no checkpoint.")
+            return
+        f = os.path.join(d, "CHECKPOINT-%d.pt" % steps[-1])
+        state = torch.load(f, map_location="cpu")
+        self.params.load(state["variables"])
+        self.params.adam_m.copy_(state["adam_m"]); self.params.adam_v.copy_(state["adam_v"])
+        self.train_engine.global_step = int(state["global_step"])
+        self.train_engine.refresh_derived()
+        print("Checkpoint '%s' is loaded." % f)
+
+    def Save(self, keep=5):
+        d = self._ckpt_dir()
+        os.makedirs(d, exist_ok=True)
+        tacotron = {k: torch.from_numpy(v) for k, v in self.params.export().items()
+                    if not k.startswith(("speaker_embedding", "mel_to_spectrogram", "waveglow"))}
+        torch.save({"variables": tacotron, "adam_m": self.params.adam_m.cpu(), "adam_v": self.params.adam_v.cpu(),
+                    "global_step": self.global_step}, os.path.join(d, "CHECKPOINT-%d.pt" % self.global_step))
+        old = sorted(int(n.split("-")[1].split(".")[0]) for n in os.listdir(d) if n.startswith("CHECKPOINT-"))
+        for s in old[:-keep]:
+            os.remove(os.path.join(d, "CHECKPOINT-%d.pt" % s))
+
+    # ---- training (MSTTS_SV.py:253-293)
+    def _to_device_batch(self, pattern):
+        dev = torch.device(self.device)
+        t = lambda a, dt: torch.as_tensor(np.asarray(a)).to(dev, dt).contiguous()
+        batch = {"Token": t(pattern["Token"], torch.int32), "Token_Length": t(pattern["Token_Length"], torch.int32),
+                 "Mel": t(pattern["Mel"], torch.float32), "Mel_Length": t(pattern["Mel_Length"], torch.int32)}
+        if "Speaker_Embedding" in pattern:
+            batch["Speaker_Embedding"] = t(pattern["Speaker_Embedding"], torch.float32)
+        else:   # frozen speaker encoder forward (MSTTS_SV.py:49-56); deterministic-zoneout inference mode
+            self.infer_engine._keep = []
+            batch["Speaker_Embedding"] = self.infer_engine.speaker_embedding(t(pattern["Speaker_Embedding_Mel"], torch.float32)).clone()
+        return batch
+
+    def Train_Step(self, pattern=None):
+        """One iteration of the reference's `while True` body; returns the train_Tensor_Dict results."""
+        pattern = pattern or self.feeder.Get_Train_Pattern()
+        step = self.global_step
+        w = self.train_engine.train_step(self._to_device_batch(pattern))
+        res = self.train_engine.scalars(w)
+        res.update({"Global_Step": step, "Learning_Rate": learning_rate(step), "Train_OP": None})
+        return res
+
+    def Train(self, max_steps=None, pattern_fn=None):
+        """MSTTS_SV.py:268-293: loop forever (or `max_steps`), print the reference's log line, checkpoint
+        every hp.Train.Checkpoint_Save_Timing steps."""
+        n = 0
+        while max_steps is None or n < max_steps:
+            t0 = time.time()
+            r = self.Train_Step(pattern_fn() if pattern_fn else None)
+            print("\t\t".join(["Time: {:0.3f}".format(time.time() - t0), "Global step: {}".format(r["Global_Step"]), "Mode: Main",
+                               "Learning rate: {:0.5f}".format(r["Learning_Rate"]), "Linear loss: {:0.5f}".format(r["Linear_Loss"]),
+                               "Postnet loss: {:0.5f}".format(r["Postnet_Loss"]), "Stop loss: {:0.5f}".format(r["Stop_Loss"]),
+                               "WR loss: {:0.5f}".format(r["Weight_Regularization_Loss"])]))
+            if (r["Global_Step"] + 1) % hp.Train.Checkpoint_Save_Timing == 0:
+                self.Save()
+            n += 1
+
+    # ---- inference (MSTTS_SV.py:295-323,391-400)
+    def Inference(self, path_List, text_List, file_Prefix=None, speaker_Mel_List=None, masks=None, export=True):
+        if len(text_List) != (len(path_List) if speaker_Mel_List is None else len(speaker_Mel_List)):
+            raise ValueError("path_List and text_List must have the same length")
+        pattern = self.feeder.Get_Inference_Pattern(path_List, text_List, speaker_Mel_List=speaker_Mel_List)
+        res = self.infer_engine.forward(pattern, masks=masks)
+        res["Global_Step"] = self.global_step
+        prefix = file_Prefix or "GS_{}".format(self.global_step)
+        cut = []
+        for i, text in enumerate(text_List):       # Export_Inference_Mel_to_Spectrogram's cut rule
+            s = _Feeder.stop_cut(res["Stop"][i])
+            cut.append({"Linear": res["Linear"][i, :s], "Mel": res["Mel"][i, :s], "Stop": res["Stop"][i, :s],
+                        "Attention_History": res["Attention_History"][i, :len(text) + 2, :s], "Spectrogram": res["Spectrogram"][i, :s]})
+        res["Cut"] = cut
+        if export:
+            out_dir = os.path.join(hp.Inference_Path, "NPZ").replace("\\", "/")
+            try:
+                os.makedirs(out_dir, exist_ok=True)
+                for i, c in enumerate(cut):
+                    np.savez_compressed(os.path.join(out_dir, "{}.IDX_{}.npz".format(prefix, i)), **c)
+            except OSError as e:      # the reference's default path is a Windows drive letter
+                print("Inference export skipped: {}".format(e))
+        return res

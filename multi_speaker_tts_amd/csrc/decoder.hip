@@ -95,6 +95,7 @@ extern "C" int64_t mstts_lstm_seq_ws_floats(int64_t B, int64_t H, int32_t backwa
 
 extern "C" int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s) {
     MSTTS_REQUIRE(d && d->xw && d->wh && d->c_hist && d->h_hist && d->gates_ws, MSTTS_ERR_SHAPE, "lstm_seq_fwd: null pointer");
+    MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_fwd: reverse needs a lengths array (pass T for every row)");
     const long B = d->B, T = d->T, H = d->H, BH = B * H;
     const int sp = mstts_skinny_fwd_splits(4 * H, H);
     RC(zero(d->c_hist, BH, s));
@@ -122,6 +123,7 @@ extern "C" int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream
 extern "C" int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream_t s) {
     MSTTS_REQUIRE(d && d->wh && d->d_out && d->c_hist && d->acts && d->c_raw && d->dgates_step && d->ws, MSTTS_ERR_SHAPE,
                   "lstm_seq_bwd: null pointer");
+    MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_bwd: reverse needs a lengths array");
     const long B = d->B, T = d->T, H = d->H, BH = B * H;
     float* dc[2] = {d->ws, d->ws + BH};
     float* dh[2] = {d->ws + 2 * BH, d->ws + 3 * BH};

@@ -543,6 +543,31 @@ __global__ void conv_kernel_flip_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+__global__ void transpose01_kernel(const float* __restrict__ src, float* __restrict__ dst, long D0, long D1, long C) {
+    const long n = D0 * D1 * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long c = i % C, d1 = (i / C) % D1, d0 = i / (C * D1);
+        dst[(d1 * D0 + d0) * C + c] = src[i];
+    }
+}
+__global__ __launch_bounds__(1024) void speaker_finalize_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int S, long T, int E) {
+    __shared__ float scratch[16];
+    const int n = B * E;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int b = i / E, e = i % E;
+        float a = 0.f;
+        for (int k = 0; k < S; ++k) a += x[(((long)b * S + k) * T + (T - 1)) * E + e];
+        a /= (float)S;
+        out[i] = a;
+        ss += a * a;
+    }
+    ss = block_sum(ss, scratch);
+    const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] *= inv;
+}
+
 __global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, long n, float* __restrict__ out) {
     __shared__ float scratch[16];
     float a = 0.f;
@@ -805,6 +830,18 @@ extern "C" int mstts_speaker_tile(const float* spk, const int32_t* lengths, floa
 extern "C" int mstts_conv_kernel_flip(const float* w, float* wt, int64_t K, int64_t Cin, int64_t Cout, mstts_stream_t s) {
     hipLaunchKernelGGL(conv_kernel_flip_kernel, dim3(grid_for(K * Cin * Cout, 256)), dim3(256), 0, ST(s), w, wt, (long)K, (long)Cin, (long)Cout);
     MSTTS_CHECK_LAUNCH("conv_kernel_flip");
+    return MSTTS_OK;
+}
+extern "C" int mstts_transpose01(const float* src, float* dst, int64_t D0, int64_t D1, int64_t C, mstts_stream_t s) {
+    if (D0 * D1 * C == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(transpose01_kernel, dim3(grid_for(D0 * D1 * C, 256)), dim3(256), 0, ST(s), src, dst, (long)D0, (long)D1, (long)C);
+    MSTTS_CHECK_LAUNCH("transpose01");
+    return MSTTS_OK;
+}
+extern "C" int mstts_speaker_finalize(const float* x, float* out, int64_t B, int64_t samples, int64_t T, int64_t E, mstts_stream_t s) {
+    MSTTS_REQUIRE(B * E <= 65536 && B >= 1 && samples >= 1 && T >= 1, MSTTS_ERR_SHAPE, "speaker_finalize: bad shape");
+    hipLaunchKernelGGL(speaker_finalize_kernel, dim3(1), dim3(1024), 0, ST(s), x, out, (int)B, (int)samples, (long)T, (int)E);
+    MSTTS_CHECK_LAUNCH("speaker_finalize");
     return MSTTS_OK;
 }
 extern "C" int mstts_l2_loss_acc(const float* x, const uint8_t* mask, int64_t n, float* out, mstts_stream_t s) {

@@ -1,0 +1,250 @@
+"""Inference forward of the Tacotron2 graph (Tacotron2.Inference_Mel_to_Spectrogram's Session.run,
+MSTTS_SV.py:301-308) as a schedule of libmstts_hip.so calls:
+
+  speaker encoder (Speaker_Embedding/Modules.py:6-37,127-137) -> encoder in inference mode
+  (Modules.py:15-73: BN moving statistics, no dropout, deterministic zoneout) -> memory/keys ->
+  free-running attention decoder with stop-token gating (Modules.py:212-237; native loop driver) ->
+  postnet + residual (Modules.py:121-143) -> Taco1 mel->spectrogram (Taco1_Mel_to_Spect/Modules.py:8-105).
+
+Prenet dropout stays active (quirk Q9): its keep-masks are Philox streams, or injected for tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib
+from .lib import ACT_NONE, ACT_RELU, ACT_TANH, gemm, ptr, call
+from .masks import MaskSet, step_seed
+from .params import CELL, ENC_CELL, LSA, SPK, SPK_CELL, VOC, VOC_CELL, Dims, ParamStore, bank_suffix
+
+BN_EPS = 1e-3
+
+
+class InferEngine:
+    def __init__(self, dims: Dims = None, device="cuda", seed=1234, params: ParamStore = None, values=None, chunk=50):
+        lib.load()
+        self.d = dims or Dims()
+        self.device = torch.device(device)
+        self.seed = seed
+        self.params = params if params is not None else ParamStore(self.d, self.device, seed=seed, values=values)
+        self.chunk = chunk
+        self._keep = []          # keeps temporaries alive until the stream is synchronised
+
+    # ------------------------------------------------------------------ helpers
+    def _f(self, *shape):
+        n = int(np.prod(shape))
+        t = torch.zeros((n + 3) // 4 * 4, dtype=torch.float32, device=self.device)[:n].view(shape)
+        self._keep.append(t)
+        return t
+
+    def P(self, name):
+        return self.params.p(name)
+
+    def _dense(self, x, rows, cin, cout, kname, bname, out, act=ACT_NONE, lda=None):
+        k, ok = self.P(kname)
+        if bname is not None:
+            b, ob = self.P(bname)
+            gemm(x, k, out, rows, cout, cin, lda or cin, cout, cout, bias=b, act=act, b_off=ok, bias_off=ob)
+        else:
+            gemm(x, k, out, rows, cout, cin, lda or cin, cout, cout, act=act, b_off=ok)
+
+    def _conv_bn(self, x, rows, T, cin, cout, K, prefix, act, bn_prefix=None, conv_name="conv1d"):
+        """conv1d 'same' + activation, then inference-mode batch norm (moving statistics)."""
+        k, ok = self.P(prefix + conv_name + "/kernel"); b, ob = self.P(prefix + conv_name + "/bias")
+        a = self._f(rows, cout)
+        gemm(x, k, a, rows, cout, K * cin, cin, cout, cout, bias=b, act=act, win=(T, cin, (K - 1) // 2), b_off=ok, bias_off=ob)
+        bnp = bn_prefix or (prefix + "batch_normalization/")
+        g, og = self.P(bnp + "gamma"); be, obe = self.P(bnp + "beta")
+        mm, omm = self.P(bnp + "moving_mean"); mv, omv = self.P(bnp + "moving_variance")
+        y = self._f(rows, cout)
+        call("mstts_bn_infer_fwd", ptr(a), ptr(g, og), ptr(be, obe), ptr(mm, omm), ptr(mv, omv), ptr(y), BN_EPS, rows, cout)
+        return y
+
+    def _lstm_seq(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, lengths=None, reverse=0, residual=None):
+        """One ZoneoutLSTMCell over a sequence in inference mode (no masks: 0.9*new + 0.1*old)."""
+        k, ok = self.P(cell_prefix + "kernel"); b, ob = self.P(cell_prefix + "bias")
+        xw = self._f(B * T, 4 * H)
+        gemm(x, k, xw, B * T, 4 * H, cin, cin, 4 * H, 4 * H, bias=b, b_off=ok, bias_off=ob)
+        q = lib.LstmSeqFwd()
+        q.B, q.T, q.H = B, T, H
+        q.xw = ptr(xw); q.wh = ptr(k, ok + cin * 4 * H); q.wh_ld = 4 * H
+        if reverse and lengths is None:            # tf.reverse_sequence over the full length
+            lengths = torch.full((B,), T, dtype=torch.int32, device=self.device)
+            self._keep.append(lengths)
+        q.lengths = ptr(lengths); q.reverse = reverse; q.zoneout = self.d.zoneout
+        q.residual = ptr(residual)
+        q.out = ptr(out, out_off); q.out_sb = out_sb; q.out_st = out_st
+        ch, hh = self._f(T + 1, B, H), self._f(T + 1, B, H)
+        q.c_hist, q.h_hist = ptr(ch), ptr(hh)
+        q.gates_ws = ptr(self._f(int(lib.load().mstts_lstm_seq_ws_floats(B, H, 0))))
+        call("mstts_lstm_seq_fwd", C.byref(q))
+
+    # ------------------------------------------------------------------ sub-graphs
+    def speaker_embedding(self, spk_mel):
+        """[5B,64,80] float32 device tensor -> [B, spk] (MSTTS_SV.py:49-56)."""
+        d = self.d
+        NB, T, _ = spk_mel.shape
+        B = NB // d.spk_samples
+        x = self._f(NB * T, d.spk)
+        self._dense(spk_mel, NB * T, d.n_mel, d.spk, SPK + "dense/kernel", SPK + "dense/bias", x)
+        for i in range(d.spk_lstm_n):
+            y = self._f(NB, T, d.spk_lstm)
+            self._lstm_seq(x, NB, T, d.spk, d.spk_lstm, SPK_CELL % (i, i), y, T * d.spk_lstm, d.spk_lstm,
+                           residual=x if i < d.spk_lstm_n - 1 else None)
+            x = y
+        e = self._f(B, d.spk)
+        call("mstts_speaker_finalize", ptr(x), ptr(e), B, d.spk_samples, T, d.spk)
+        return e
+
+    def encoder(self, token, token_length, spk):
+        """-> values [B,T,M] (memory masked past Token_Length), keys [B,T,A]."""
+        d = self.d
+        B, T = token.shape
+        M, He = d.mem, d.enc_lstm
+        emb, oe = self.P("encoder/embedding_variable")
+        x = self._f(B * T, d.emb)
+        call("mstts_embedding_fwd", ptr(token), ptr(emb, oe), ptr(x), B * T, d.n_tok, d.emb)
+        cin = d.emb
+        for i in range(d.enc_conv_n):
+            x = self._conv_bn(x, B * T, T, cin, d.enc_conv_ch, d.enc_conv_k, "encoder/conv_%d/" % i, ACT_RELU)
+            cin = d.enc_conv_ch
+        values = self._f(B, T, M)
+        for di, dr in enumerate(("fw", "bw")):
+            self._lstm_seq(x, B, T, cin, He, ENC_CELL % dr, values, T * M, M, out_off=di * He, lengths=token_length, reverse=di)
+        call("mstts_speaker_tile", ptr(spk), ptr(token_length), ptr(values), B, T, M, 2 * He, d.spk)
+        keys = self._f(B, T, d.att)
+        wm, owm = self.P("attention/memory_layer/kernel")
+        gemm(values, wm, keys, B * T, d.att, M, M, d.att, d.att, b_off=owm)
+        return values, keys
+
+    def decode(self, values, keys, token_length, masks=None, seed=None, max_steps=None):
+        """Free-running decoder.  Returns step-major linear [S,B,n_mel], stop logits [S,B], align [S,B,T]."""
+        d = self.d
+        B, T, M = values.shape
+        H, A, Pn, NM = d.dec_lstm, d.att, d.prenet, d.n_mel
+        Smax = (max_steps if max_steps is not None else d.max_inf) + 1
+        mk = MaskSet(d, B, T, Smax, False, self.device)
+        if masks is not None:
+            mk.load(masks)
+        else:
+            mk.draw(seed if seed is not None else step_seed(self.seed, 0))
+        self._keep.append(mk)
+        w0f = self._f(M + H, 4 * H)
+        k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
+        call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(w0f), 2 * M + H, 4 * H, 0, M)
+        q = lib.DecoderInfer()
+        q.B, q.H, q.P, q.n_mel, q.Smax = B, H, Pn, NM, Smax
+        ls = q.lsa
+        ls.B, ls.T, ls.A, ls.M, ls.KS, ls.CH = B, T, A, M, d.att_k, d.att_ch
+        ls.keys, ls.values, ls.lengths = ptr(keys), ptr(values), ptr(token_length)
+        for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
+                            ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
+            t, o = self.P(LSA + name)
+            setattr(ls, field, ptr(t, o))
+        for field, name in (("pw0", "decoder/decoder/prenet_0/dense/kernel"), ("pb0", "decoder/decoder/prenet_0/dense/bias"),
+                            ("pw1", "decoder/decoder/prenet_1/dense/kernel"), ("pb1", "decoder/decoder/prenet_1/dense/bias"),
+                            ("w1", CELL % 1 + "kernel"), ("b1", CELL % 1 + "bias"), ("wq", LSA + "query_layer/kernel"),
+                            ("wproj", "decoder/decoder/linear_projection/dense/kernel"), ("bproj", "decoder/decoder/linear_projection/dense/bias")):
+            t, o = self.P(name)
+            setattr(q, field, ptr(t, o))
+        q.pm0, q.pm1, q.prenet_keep = ptr(mk["prenet_drop_0"]), ptr(mk["prenet_drop_1"]), 1 - d.prenet_drop
+        q.wx0, q.b0, q.w0f = ptr(k0, o0), ptr(b0, ob0), ptr(w0f)
+        q.zoneout = d.zoneout
+        q.in0, q.in1, q.pj = ptr(self._f(2, B, M + H)), ptr(self._f(2, B, 2 * H)), ptr(self._f(B, H + M))
+        q.c0, q.c1, q.cum = ptr(self._f(2, B, H)), ptr(self._f(2, B, H)), ptr(self._f(2, B, T))
+        q.pre_ws = ptr(self._f(int(lib.load().mstts_decoder_infer_ws_floats(B, H, Pn, T, A, NM))))
+        linear, stop, align = self._f(Smax, B, NM), self._f(Smax, B), self._f(Smax, B, T)
+        q.linear, q.stop, q.align_hist = ptr(linear), ptr(stop), ptr(align)
+        # Decoder_Dynamic_Decode stops after the first step at which every row has raised its stop flag
+        # (stop_logit >= 0 OR time >= Max_Inference_Length, OR-accumulated; Modules.py:216-219,395,409).
+        finished = np.zeros(B, bool)
+        done, S = 0, None
+        limit = Smax - 1                         # time index at which the forced stop fires
+        while S is None and done < Smax:
+            n = min(self.chunk, Smax - done)
+            call("mstts_decoder_infer_steps", C.byref(q), done, n)
+            st = stop[done:done + n].cpu().numpy()          # synchronises the stream for this chunk
+            for i in range(n):
+                t = done + i
+                finished |= (st[i] >= 0.0) | (t >= limit)
+                if finished.all():
+                    S = t + 1
+                    break
+            done += n
+        return linear[:S], stop[:S], align[:S], S
+
+    def postnet(self, linear_bsc, B, S):
+        d = self.d
+        x, cin = linear_bsc, d.n_mel
+        for i in range(d.post_n):
+            cout = d.post_ch if i < d.post_n - 1 else d.n_mel
+            x = self._conv_bn(x, B * S, S, cin, cout, d.post_k, "decoder/conv_%d/" % i, ACT_TANH)
+            cin = cout
+        mel = self._f(B, S, d.n_mel)
+        call("mstts_add", ptr(linear_bsc), ptr(x), ptr(mel), B * S * d.n_mel)
+        return mel
+
+    def mel_to_spectrogram(self, mel, B, S):
+        """ConvBank -> Highway -> BiRNN -> Projection (MSTTS_SV.py:100-115), inference mode."""
+        d = self.d
+        rows, C1 = B * S, d.bank_k * d.bank_ch
+        cat = self._f(rows, C1)
+        for k in range(1, d.bank_k + 1):
+            sfx = bank_suffix(k)
+            y = self._conv_bn(mel, rows, S, d.n_mel, d.bank_ch, k, VOC + "convbank_0/", ACT_RELU,
+                              bn_prefix=VOC + "convbank_0/batch_normalization%s/" % sfx, conv_name="conv1d%s" % sfx)
+            call("mstts_copy2d", ptr(y), d.bank_ch, ptr(cat, (k - 1) * d.bank_ch), C1, rows, d.bank_ch, 0)
+        pool = self._f(rows, C1)
+        call("mstts_maxpool2_same", ptr(cat), ptr(pool), B, S, C1)
+        p1 = self._conv_bn(pool, rows, S, C1, d.proj1_ch, d.proj1_k, VOC + "convbank_0/", ACT_RELU,
+                           bn_prefix=VOC + "convbank_0/batch_normalization_8/", conv_name="conv1d_8")
+        p2 = self._conv_bn(p1, rows, S, d.proj1_ch, d.n_mel, d.proj2_k, VOC + "convbank_0/", ACT_NONE,
+                           bn_prefix=VOC + "convbank_0/batch_normalization_9/", conv_name="conv1d_9")
+        x = self._f(rows, d.n_mel)
+        call("mstts_add", ptr(mel), ptr(p2), ptr(x), rows * d.n_mel)
+        for i in range(d.highway_n):
+            hp_, tp_ = self._f(rows, d.n_mel), self._f(rows, d.n_mel)
+            self._dense(x, rows, d.n_mel, d.n_mel, VOC + "highway_%d/dense/kernel" % i, VOC + "highway_%d/dense/bias" % i, hp_)
+            self._dense(x, rows, d.n_mel, d.n_mel, VOC + "highway_%d/dense_1/kernel" % i, VOC + "highway_%d/dense_1/bias" % i, tp_)
+            y = self._f(rows, d.n_mel)
+            call("mstts_highway_combine", ptr(hp_), ptr(tp_), ptr(x), ptr(y), rows * d.n_mel)
+            x = y
+        rnn = self._f(B, S, 2 * d.birnn)
+        for di, dr in enumerate(("fw", "bw")):
+            self._lstm_seq(x, B, S, d.n_mel, d.birnn, VOC_CELL % dr, rnn, S * 2 * d.birnn, 2 * d.birnn, out_off=di * d.birnn, reverse=di)
+        spec = self._f(rows, d.n_spec)
+        self._dense(rnn, rows, 2 * d.birnn, d.n_spec, VOC + "dense/kernel", VOC + "dense/bias", spec)
+        return spec.view(B, S, d.n_spec)
+
+    # ------------------------------------------------------------------ whole forward
+    def forward(self, pattern, masks=None, seed=None, max_steps=None, with_vocoder=True):
+        """pattern: dict with Token [B,T] int32, Token_Length [B] int32 and either Speaker_Embedding_Mel
+        [5B,64,80] or Speaker_Embedding [B,spk] (numpy or tensors).  Returns the reference's
+        inference_Tensor_Dict as numpy arrays: Linear, Mel, Stop (sigmoid), Attention_History [B,T,S], Spectrogram."""
+        self._keep = []
+        dev = self.device
+        t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev, dt).contiguous()
+        token, tlen = t(pattern["Token"], torch.int32), t(pattern["Token_Length"], torch.int32)
+        B, T = token.shape
+        if "Speaker_Embedding" in pattern:
+            spk = t(pattern["Speaker_Embedding"], torch.float32)
+        else:
+            spk = self.speaker_embedding(t(pattern["Speaker_Embedding_Mel"], torch.float32))
+        values, keys = self.encoder(token, tlen, spk)
+        lin_s, stop_s, align_s, S = self.decode(values, keys, tlen, masks=masks, seed=seed, max_steps=max_steps)
+        d = self.d
+        linear = self._f(B, S, d.n_mel)
+        call("mstts_transpose01", ptr(lin_s), ptr(linear), S, B, d.n_mel)
+        mel = self.postnet(linear, B, S)
+        out = {"Linear": linear, "Mel": mel, "Stop_Logit": stop_s.t().contiguous(), "Attention_History": align_s.permute(1, 2, 0).contiguous(),
+               "Speaker_Embedding": spk}
+        if with_vocoder:
+            out["Spectrogram"] = self.mel_to_spectrogram(mel, B, S)
+        torch.cuda.synchronize()
+        res = {k: v.detach().cpu().numpy() for k, v in out.items()}
+        res["Stop"] = 1.0 / (1.0 + np.exp(-res["Stop_Logit"]))
+        self._keep = []
+        return res

@@ -119,6 +119,8 @@ SIGNATURES = {
     "mstts_pack_dproj": (i32, [vp, vp, vp, i64, i64, i64, i64, vp]),
     "mstts_speaker_tile": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "mstts_conv_kernel_flip": (i32, [vp, vp, i64, i64, i64, vp]),
+    "mstts_transpose01": (i32, [vp, vp, i64, i64, i64, vp]),
+    "mstts_speaker_finalize": (i32, [vp, vp, i64, i64, i64, i64, vp]),
     "mstts_adam_tf": (i32, [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i64, vp]),
     "mstts_stft_mel": (i32, [vp, i64, f32, vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, vp]),
     "mstts_stft_mel_ws_floats": (i64, [i64, i32, i64]),

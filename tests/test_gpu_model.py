@@ -206,3 +206,72 @@ def test_train_step_parity(dev, B, Te, L, ragged, kw):
         if e > 2e-3:
             bad[k] = e
     assert not bad, bad
+
+
+@pytest.mark.parametrize("stop_bias,max_inf", [(-6.0, 9), (6.0, 9), (0.0, 14)])
+def test_inference_forward_parity(dev, stop_bias, max_inf):
+    """Free-running forward (speaker encoder -> encoder -> decoder with stop gating -> postnet -> Taco1)
+    vs the oracle with identical injected prenet masks."""
+    from multi_speaker_tts_amd.inference import InferEngine
+    pd, od = dims_pair(max_inf=max_inf)
+    values = OM.init_params(od, 21)
+    g = np.random.default_rng(5)
+    for k in values:                       # non-trivial BN statistics / biases
+        if k.endswith("moving_mean"):
+            values[k] = g.normal(0, 0.2, values[k].shape)
+        if k.endswith("moving_variance"):
+            values[k] = 0.5 + np.abs(g.normal(0, 0.5, values[k].shape))
+        if k.endswith(("bias", "beta")) and "highway" not in k:
+            values[k] = g.normal(0, 0.1, values[k].shape)
+    values["decoder/decoder/linear_projection/dense/bias"][-1] = stop_bias
+    B, Te = 3, 11
+    batch = OT.synthetic_batch(od, B, Te, 4, seed=9, ragged=True)
+    spk_mel = np.clip(g.normal(0, 1.5, (B * od.spk_samples, od.spk_frames, od.n_mel)), -4, 4).astype(np.float32)
+    masks = OT.make_masks(od, B, Te, max_inf + 1, False, seed=77)
+    ob = {"Token": batch["Token"], "Token_Length": batch["Token_Length"], "Mel": torch.zeros(B, 1, od.n_mel, dtype=torch.float64),
+          "Mel_Length": torch.zeros(B, dtype=torch.int32), "Speaker_Embedding_Mel": torch.tensor(spk_mel, dtype=torch.float64)}
+    ref = OM.forward(OM.to_torch(values), od, ob, False, masks, with_vocoder=True)
+    eng = InferEngine(pd, device=dev, values=values)
+    got = eng.forward({"Token": batch["Token"].numpy(), "Token_Length": batch["Token_Length"].numpy(), "Speaker_Embedding_Mel": spk_mel},
+                      masks={k: v.numpy() for k, v in masks.items()})
+    S = ref["Linear"].shape[1]
+    assert got["Linear"].shape == (B, S, od.n_mel), (got["Linear"].shape, S)
+    if stop_bias > 0:
+        assert S == 1
+    if stop_bias < -1:
+        assert S == max_inf + 1
+    assert rel_err(got["Linear"], t2n(ref["Linear"])) < 1e-3
+    assert rel_err(got["Mel"], t2n(ref["Mel"])) < 1e-3
+    assert rel_err(got["Stop"], t2n(ref["Stop"])) < 1e-3
+    assert rel_err(got["Attention_History"], t2n(ref["Attention_History"])) < 1e-3
+    assert rel_err(got["Spectrogram"], t2n(ref["Spectrogram"])) < 1e-3
+
+
+def test_tacotron2_surface(dev, tmp_path, monkeypatch):
+    """Drop-in surface: Tacotron2(is_Training).Train_Step / Inference / Save / Restore round trip."""
+    from multi_speaker_tts_amd import Hyper_Parameters as hp
+    from multi_speaker_tts_amd.MSTTS_SV import Tacotron2, TRAIN_KEYS
+    from multi_speaker_tts_amd.params import Dims
+    monkeypatch.setattr(hp, "Checkpoint_Path", str(tmp_path / "ckpt"))
+    monkeypatch.setattr(hp, "Inference_Path", str(tmp_path / "inf"))
+    dims = Dims(emb=32, enc_conv_ch=32, enc_lstm=16, spk=256, prenet=16, dec_lstm=32, post_ch=16, bank_ch=8, proj1_ch=16, birnn=8, n_spec=20,
+                spk_lstm=256, max_inf=6)
+    t = Tacotron2(is_Training=True, device=dev, dims=dims)
+    pat = t.feeder.Get_Train_Pattern(batch_Size=2, token_Length=9, mel_Length=200)
+    r0 = t.Train_Step(pat)
+    assert set(TRAIN_KEYS) <= set(r0) and r0["Global_Step"] == 0 and np.isfinite(r0["Loss"])
+    r1 = t.Train_Step(pat)
+    assert r1["Global_Step"] == 1 and r1["Loss"] < r0["Loss"] + 1.0
+    t.Save()
+    before = t.params.export()
+    t.params.train.zero_()
+    t.Restore()
+    after = t.params.export()
+    assert t.global_step == 2 and all(np.array_equal(before[k], after[k]) for k in before if k.startswith(("encoder", "decoder", "attention")))
+    mels = [np.clip(np.random.default_rng(i).normal(0, 1.5, (230, 80)), -4, 4).astype(np.float32) for i in range(2)]
+    res = t.Inference(None, ["Please call Stella.", "Who knows?"], speaker_Mel_List=mels)
+    S = res["Linear"].shape[1]
+    assert res["Linear"].shape == (2, S, 80) and res["Spectrogram"].shape == (2, S, 20) and res["Attention_History"].shape[:2] == (2, 21)
+    assert len(res["Cut"]) == 2 and res["Cut"][1]["Attention_History"].shape[0] == len("Who knows?") + 2
+    with pytest.raises(KeyError):
+        t.Inference(None, ["ünknown"], speaker_Mel_List=mels[:1])

@@ -146,7 +146,16 @@ typedef struct {
     int64_t B, T, A, M, KS, CH;      /* batch, encoder steps, attention units, memory width, conv taps, conv channels */
     const float* keys; const float* values; const int32_t* lengths;
     const float* conv_k; const float* conv_b; const float* dense_k; const float* score_w; const float* score_b;
+    const float* loc_k; const float* loc_b;   /* folded location filter [KS,A], [A] (mstts_lsa_fold_location) */
 } mstts_lsa_const;
+/* The location conv (KS taps, 1 -> CH, +bias) and the bias-free dense CH -> A that follows it are one linear map;
+ * the step kernels use it folded: loc_k = conv_k . dense_k, loc_b = conv_b . dense_k.  Refresh after the variables change. */
+int mstts_lsa_fold_location(const float* conv_k, const float* conv_b, const float* dense_k, float* loc_k, float* loc_b,
+                            int64_t KS, int64_t CH, int64_t A, mstts_stream_t s);
+/* accumulate the gradients of conv_k / conv_b / dense_k from d_loc_k [KS,A] and d_loc_b [A] (= d_score_b) */
+int mstts_lsa_unfold_location_grad(const float* conv_k, const float* conv_b, const float* dense_k, const float* d_loc_k,
+                                   const float* d_loc_b, float* d_conv_k, float* d_conv_b, float* d_dense_k,
+                                   int64_t KS, int64_t CH, int64_t A, mstts_stream_t s);
 /* q = sum of q_parts slabs of [B,A] (slab stride q_pstride; parts 0/1 = single); when q_sum != NULL the
  * summed query is also stored there (the BPTT save). */
 int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
@@ -156,19 +165,19 @@ int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, int32_t q_par
 int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* energy, const float* cum, float* align, float* cum_next,
                           float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, mstts_stream_t s);
 /* backward of one step, two launches:
- *  dalign : G = G_next + convT(d_f_next) ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
- *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); d_f = g . Wd^T; saves d_e */
+ *  dalign : G[t] = G_next[t] + sum_j h_next[t+pad-j][j] ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
+ *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); h[t,j] = sum_k g[t,k] loc_k[j,k]
+ *           (h is [B,T,32], the filter-transpose operand of the previous step's dalign); saves d_e */
 /* d_ctx row b = d_ctx[b*d_ctx_ld ..] (+ d_ctx2[b*d_ctx2_ld ..] when d_ctx2 != NULL) */
 int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
                          int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s);
 int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* align, const float* d_align, const float* q, const float* cum,
                           float* d_e, float* dq, float* d_f, mstts_stream_t s);
 /* post-loop parameter gradients over all S steps (recomputes tanh tiles from the saved d_e):
- * hist pointers are [S,B,*]; outputs accumulate (atomic): d_keys[B,T,A], d_conv_k[KS,CH], d_conv_b[CH],
- * d_dense_k[CH,A], d_score_w[A], d_score_b[A]. */
+ * hist pointers are [S,B,*]; outputs accumulate (atomic): d_keys[B,T,A], d_loc_k[KS,A], d_score_w[A], d_score_b[A]
+ * (d_loc_b equals d_score_b); unfold d_loc_k with mstts_lsa_unfold_location_grad. */
 int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
-                        float* d_keys, float* d_conv_k, float* d_conv_b, float* d_dense_k, float* d_score_w, float* d_score_b,
-                        mstts_stream_t s);
+                        float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, mstts_stream_t s);
 
 /* ---- losses (MSTTS_SV.py:127-144) forward + gradient in one pass -------------------------------
  * linear/post [B,S,n_mel] with S = L+1, mel [B,L,n_mel], stop_logit [B,S], mel_length [B].

@@ -747,7 +747,7 @@ extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_st
     if (d->B * d->H == 0) return MSTTS_OK;
     const int parts = d->gates_parts > 1 ? d->gates_parts : 1;
     const bool fast = !d->lengths && !d->residual && !d->reverse && d->out && d->acts_out && d->c_raw && d->xw_st == 0 &&
-                      d->out_st == 0 && d->B * d->H * 4 < (1LL << 30) && (parts == 1 || parts == 4) &&
+                      d->out_st == 0 && d->B * d->H * 4 < (1LL << 30) && (parts == 1 || parts == 4 || parts == 8) &&
                       (long)parts * d->gates_pstride < (1LL << 30);
     if (fast) {
         PointFwdFast f;
@@ -758,7 +758,8 @@ extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_st
         f.h_next_ld = (int)(d->h_next_ld ? d->h_next_ld : d->H); f.acts = d->acts_out; f.c_raw = d->c_raw;
         f.B = (int)d->B; f.H = (int)d->H;
         dim3 grid((unsigned)((d->B * d->H + 127) / 128));
-        if (parts == 4) hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<4>, grid, dim3(128), 0, ST(s), f);
+        if (parts == 8) hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<8>, grid, dim3(128), 0, ST(s), f);
+        else if (parts == 4) hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<4>, grid, dim3(128), 0, ST(s), f);
         else hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<1>, grid, dim3(128), 0, ST(s), f);
         MSTTS_CHECK_LAUNCH("lstm_point_fwd_fast");
         return MSTTS_OK;
@@ -775,8 +776,9 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
         const int po = d->dout_parts > 1 ? d->dout_parts : 1, po2 = d->dout2_parts > 1 ? d->dout2_parts : 1;
         const int ph = d->dhs2_parts > 1 ? d->dhs2_parts : 1;
         const bool shape41 = (po == 1 && po2 == 1 && ph == 4), shape414 = (po == 4 && po2 == 1 && ph == 4), shape111 = (po == 1 && po2 == 1 && ph == 1);
+        const bool shape18 = (po == 1 && po2 == 1 && ph == 8), shape818 = (po == 8 && po2 == 1 && ph == 8);
         const bool fast = !d->lengths && !d->reverse && !d->dgates_pos && d->dout_st == 0 && d->B * d->H * 4 < (1LL << 30) &&
-                          (shape41 || shape414 || shape111) && (long)po * d->dout_pstride < (1LL << 30);
+                          (shape41 || shape414 || shape111 || shape18 || shape818) && (long)po * d->dout_pstride < (1LL << 30);
         if (fast) {
             PointBwdFast f;
             f.d_out = d->d_out; f.dout_ld = (int)d->dout_sb; f.dout_parts = po; f.dout_pstride = (int)d->dout_pstride;
@@ -786,7 +788,9 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
             f.acts = d->acts; f.c_raw = d->c_raw; f.c_prev = d->c_prev; f.zc = d->zc; f.zh = d->zh; f.keep = 1.f - d->zoneout;
             f.dgates = d->dgates; f.d_c_prev = d->d_c_prev; f.d_h_prev = d->d_h_prev; f.B = (int)d->B; f.H = (int)d->H;
             dim3 grid((unsigned)((d->B * d->H + 127) / 128));
-            if (shape41) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 4>), grid, dim3(128), 0, ST(s), f);
+            if (shape18) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 8>), grid, dim3(128), 0, ST(s), f);
+            else if (shape818) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<8, 1, 8>), grid, dim3(128), 0, ST(s), f);
+            else if (shape41) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 4>), grid, dim3(128), 0, ST(s), f);
             else if (shape414) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<4, 1, 4>), grid, dim3(128), 0, ST(s), f);
             else hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 1>), grid, dim3(128), 0, ST(s), f);
             MSTTS_CHECK_LAUNCH("lstm_point_bwd_fast");

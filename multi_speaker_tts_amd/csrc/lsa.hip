@@ -30,81 +30,42 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 // The per-step kernels below are latency-bound (a few KB per workgroup, 801 dependent steps), so each
 // one issues ALL of its global loads first - one memory round trip - and only then touches LDS.
-
-// location features from an LDS-resident window of the cumulative alignment and a register-resident
-// conv kernel column: thread (tt = tid/32 [+8], ch = tid%32): f[tt][ch] = b[ch] + sum_j cum[tt+j] * k[j][ch]
-__device__ __forceinline__ void location_features_regs(int KS, const float* s_cum, const float (&ck)[KS_MAX], float cb,
-                                                       float (*s_f)[FLD]) {
-    const int ch = threadIdx.x & (CH_ - 1), tt = threadIdx.x >> 5;      // 8 row groups x 32 channels
-    float a[TS / 8];
-#pragma unroll
-    for (int r = 0; r < TS / 8; ++r) a[r] = cb;
-#pragma unroll
-    for (int j = 0; j < KS_MAX; ++j) {
-        if (j < KS) {
-#pragma unroll
-            for (int r = 0; r < TS / 8; ++r) a[r] += s_cum[tt + 8 * r + j] * ck[j];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < TS / 8; ++r) s_f[tt + 8 * r][ch] = a[r];
-}
-
-// legacy helper (post-loop kernel): stage cum window + conv kernel through LDS
-__device__ __forceinline__ void location_features(const mstts_lsa_const& c, const float* __restrict__ cum_row, int t0,
-                                                  float* s_cum, float* s_ck, float (*s_f)[FLD]) {
-    const int KS = (int)c.KS, T = (int)c.T, pad = (KS - 1) / 2;
-    for (int i = threadIdx.x; i < TS + KS - 1; i += blockDim.x) {
-        const int t = t0 - pad + i;
-        s_cum[i] = (t >= 0 && t < T) ? cum_row[t] : 0.f;
-    }
-    for (int i = threadIdx.x; i < KS * CH_; i += blockDim.x) s_ck[i] = c.conv_k[i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < TS * CH_; i += blockDim.x) {
-        const int tt = i / CH_, ch = i % CH_;
-        float acc = c.conv_b[ch];
-        for (int j = 0; j < KS; ++j) acc += s_cum[tt + j] * s_ck[j * CH_ + ch];
-        s_f[tt][ch] = acc;
-    }
-    __syncthreads();
-}
+//
+// Folded location filter: the reference applies conv1d(31 taps, 1 -> 32 ch, +bias) and then a
+// bias-free dense 32 -> 128 to the cumulative alignment (Location_Sensitive_Attention.py:48-61) with
+// nothing in between, so the pair is ONE 31-tap filter into 128 channels:
+//     loc[t,k] = loc_b[k] + sum_j cum[t+j-pad] * loc_k[j,k],   loc_k = conv_k . dense_k,  loc_b = conv_b . dense_k
+// The host refreshes loc_k/loc_b after every optimizer step (like the folded cell-0 kernel); the
+// gradient comes back as d_loc_k and is unfolded into d_conv_k / d_conv_b / d_dense_k by three tiny GEMMs.
 
 // ---------------------------------------------------------------------------------------------
-// forward: energies
+// forward: energies   grid (B, T/TS), 256 threads = (k = tid & 127, grp = tid >> 7)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
                                                          float* __restrict__ q_sum, const float* __restrict__ cum,
                                                          float* __restrict__ energy) {
     __shared__ float s_cum[TS + KS_MAX - 1];
-    __shared__ __attribute__((aligned(16))) float s_f[TS][FLD];
     __shared__ float s_red[TS][2];
     const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, KS = (int)c.KS, pad = (KS - 1) / 2;
-    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;        // 2 groups of 128 lanes
-    const int ch = threadIdx.x & (CH_ - 1);
+    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
     // ---- every global load of this workgroup, issued back to back
     float cwin = 0.f;
     if (threadIdx.x < TS + KS - 1) {
         const int t = t0 - pad + threadIdx.x;
         if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
     }
-    float ck[KS_MAX];
+    float lk[KS_MAX];
 #pragma unroll
-    for (int j = 0; j < KS_MAX; ++j) ck[j] = (j < KS) ? c.conv_k[j * CH_ + ch] : 0.f;
-    const float cb = c.conv_b[ch];
-    float dk[CH_];
-#pragma unroll
-    for (int i = 0; i < CH_; ++i) dk[i] = c.dense_k[i * A_ + k];
+    for (int j = 0; j < KS_MAX; ++j) lk[j] = (j < KS) ? c.loc_k[j * A_ + k] : 0.f;
     const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
     float kv[TS / 2];
 #pragma unroll
     for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
     const float qv = sum_parts<MSTTS_MAX_PARTS>(q, q_parts, q_pstride, (long)b * A_ + k);
-    const float sb = c.score_b[k], wk = c.score_w[k];
+    const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
     // ---- LDS phase
-    if (threadIdx.x < TS + KS - 1) s_cum[threadIdx.x] = cwin;
+    if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;      // entries past the KS-tap window are zero (cwin == 0 there)
     if (q_sum && blockIdx.y == 0 && grp == 0) q_sum[(long)b * A_ + k] = qv;
-    __syncthreads();
-    location_features_regs(KS, s_cum, ck, cb, s_f);
     __syncthreads();
     const float qk = qv + sb;
 #pragma unroll
@@ -114,10 +75,7 @@ __global__ __launch_bounds__(256) void lsa_energy_kernel(mstts_lsa_const c, cons
         if (t0 + tt < T) {
             float pre = kv[i] + qk;
 #pragma unroll
-            for (int cc = 0; cc < CH_; cc += 4) {
-                const float4 f4 = *reinterpret_cast<const float4*>(&s_f[tt][cc]);
-                pre += f4.x * dk[cc] + f4.y * dk[cc + 1] + f4.z * dk[cc + 2] + f4.w * dk[cc + 3];
-            }
+            for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * lk[j];
             e = wk * fast_tanh(pre);
         }
         e = wave_sum(e);
@@ -217,39 +175,31 @@ __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: d_align  (G = dL/d cum_{s+1})
+// backward: d_align.  G = dL/d cum_{s+1} = G_next + filter^T applied to the next step's energy gradient,
+// which the denergy kernel of step s+1 left as h_next[b,t,j] = sum_k g[t,k] loc_k[j,k]:
+//     G[t] = G_next[t] + sum_j h_next[t + pad - j][j]
 // ---------------------------------------------------------------------------------------------
-constexpr int DF_ROWS = TS + KS_MAX - 1;
+constexpr int HLD = 32;        // row stride of h (KS_MAX = 31 taps, padded)
 constexpr int MROW = 4;        // float4 per lane per value row held in registers (M <= 1024)
 
 __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, const float* __restrict__ d_ctx, long d_ctx_ld,
                                                          const float* __restrict__ d_ctx2, long d_ctx2_ld, int d_ctx2_parts, long d_ctx2_pstride,
-                                                         const float* __restrict__ G_next, const float* __restrict__ d_f_next,
+                                                         const float* __restrict__ G_next, const float* __restrict__ h_next,
                                                          float* __restrict__ G, float* __restrict__ d_align) {
-    __shared__ float s_df[DF_ROWS][CH_ + 1];
-    __shared__ float s_ck[KS_MAX * CH_];
     __shared__ float s_g[TS];
     const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int len = c.lengths ? c.lengths[b] : T;
     // ---- loads first
-    // (a) d_f_next window rows tau = t0 + pad - (KS-1) + r, r in [0, TS+KS-1): element e = tid + 256*i
-    constexpr int NDF = (DF_ROWS * CH_ + 255) / 256;
-    float dfv[NDF];
-    const int base = t0 + pad - (KS - 1);
-#pragma unroll
-    for (int i = 0; i < NDF; ++i) {
-        const int e = threadIdx.x + 256 * i, r = e / CH_, chn = e % CH_, tau = base + r;
-        dfv[i] = (d_f_next && r < TS + KS - 1 && tau >= 0 && tau < T) ? d_f_next[((long)b * T + tau) * CH_ + chn] : 0.f;
+    constexpr int LPR = 256 / TS;                    // lanes per row (32): lane j of row tt takes tap j
+    const int tt_h = threadIdx.x / LPR, jh = threadIdx.x % LPR;
+    float hv = 0.f;
+    if (h_next && jh < KS) {
+        const int tau = t0 + tt_h + pad - jh;
+        if (tau >= 0 && tau < T) hv = h_next[((long)b * T + tau) * HLD + jh];
     }
-    constexpr int NCK = (KS_MAX * CH_ + 255) / 256;
-    float ckv[NCK];
-#pragma unroll
-    for (int i = 0; i < NCK; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        ckv[i] = (d_f_next && e < KS * CH_) ? c.conv_k[e] : 0.f;
-    }
-    // (b) the wave's 4 value rows (tt = w + 4*r) and the d_ctx row, MROW float4 per lane each
+    float gn = 0.f;
+    if (threadIdx.x < TS && G_next && t0 + threadIdx.x < T) gn = G_next[(long)b * T + t0 + threadIdx.x];
     float4 dcv[MROW], val[TS / 4][MROW];
     const float* dc = d_ctx + (long)b * d_ctx_ld;
 #pragma unroll
@@ -280,34 +230,10 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float gn = 0.f;
-    if (threadIdx.x < TS && G_next && t0 + threadIdx.x < T) gn = G_next[(long)b * T + t0 + threadIdx.x];
-    // ---- LDS phase: conv-transpose  G[t] = G_next[t] + sum_{j,ch} d_f_next[t + pad - j][ch] * conv_k[j][ch]
+    // ---- G for the TS rows: 32-lane sums of the diagonal taps
 #pragma unroll
-    for (int i = 0; i < NDF; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        if (e < DF_ROWS * CH_) s_df[e / CH_][e % CH_] = dfv[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NCK; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        if (e < KS_MAX * CH_) s_ck[e] = ckv[i];
-    }
-    __syncthreads();
-    {
-        constexpr int LPR = 256 / TS;                    // lanes per row
-        const int tt = threadIdx.x / LPR, part = threadIdx.x % LPR;
-        float acc = 0.f;
-        if (d_f_next) {
-            for (int p = part; p < KS * CH_; p += LPR) {
-                const int j = p / CH_, chn = p % CH_;
-                acc += s_df[tt + (KS - 1) - j][chn] * s_ck[p];
-            }
-        }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (part == 0) s_g[tt] = acc;
-    }
+    for (int o = LPR / 2; o > 0; o >>= 1) hv += __shfl_xor(hv, o, 64);
+    if (jh == 0) s_g[tt_h] = hv;
     __syncthreads();
     if (threadIdx.x < TS) s_g[threadIdx.x] += gn;
     __syncthreads();
@@ -341,22 +267,20 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: d_energy, d_query, d_location_features
+// backward: d_energy, d_query, and h[t,j] = sum_k g[t,k] loc_k[j,k] for the previous step's d_align
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, const float* __restrict__ align,
                                                           const float* __restrict__ d_align, const float* __restrict__ q,
                                                           const float* __restrict__ cum, float* __restrict__ d_e_out,
-                                                          float* __restrict__ dq, float* __restrict__ d_f) {
+                                                          float* __restrict__ dq, float* __restrict__ h) {
     __shared__ float s_cum[TS + KS_MAX - 1];
-    __shared__ __attribute__((aligned(16))) float s_f[TS][FLD];
-    __shared__ float s_g[TS][A_];
-    __shared__ float s_dkT[A_][CH_ + 1];
+    __shared__ __attribute__((aligned(16))) float s_g[TS][A_];
+    __shared__ __attribute__((aligned(16))) float s_lk[KS_MAX + 1][A_];
     __shared__ float s_de[TS];
     __shared__ float s_dq[A_];
     __shared__ float scratch[16];
     const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
-    const int ch = threadIdx.x & (CH_ - 1);
     // ---- loads first
     float av[T_MAX / 256], dav[T_MAX / 256];
 #pragma unroll
@@ -375,18 +299,18 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
         const int t = t0 - pad + threadIdx.x;
         if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
     }
-    float ck[KS_MAX];
+    constexpr int NLK = (KS_MAX * A_ + 255) / 256;      // loc_k staged for the h product (and read back per k)
+    float lkv[NLK];
 #pragma unroll
-    for (int j = 0; j < KS_MAX; ++j) ck[j] = (j < KS) ? c.conv_k[j * CH_ + ch] : 0.f;
-    const float cb = c.conv_b[ch];
-    float dkv[A_ * CH_ / 256];
-#pragma unroll
-    for (int i = 0; i < A_ * CH_ / 256; ++i) dkv[i] = c.dense_k[threadIdx.x + 256 * i];
+    for (int i = 0; i < NLK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        lkv[i] = (e < KS * A_) ? c.loc_k[e] : 0.f;
+    }
     const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
     float kv[TS / 2];
 #pragma unroll
     for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
-    const float qk = q[(long)b * A_ + k] + c.score_b[k];
+    const float qk = q[(long)b * A_ + k] + c.score_b[k] + c.loc_b[k];
     const float wk = c.score_w[k];
     // ---- softmax backward needs the whole row's dot(a, d_a)
     float dot = 0.f;
@@ -400,13 +324,11 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
         s_de[threadIdx.x] = de;
     }
 #pragma unroll
-    for (int i = 0; i < A_ * CH_ / 256; ++i) {
-        const int e = threadIdx.x + 256 * i;             // dense_k[ch][k] -> s_dkT[k][ch]
-        s_dkT[e % A_][e / A_] = dkv[i];
+    for (int i = 0; i < NLK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < KS_MAX * A_) s_lk[e / A_][e % A_] = lkv[i];
     }
-    if (threadIdx.x < TS + KS - 1) s_cum[threadIdx.x] = cwin;
-    __syncthreads();
-    location_features_regs(KS, s_cum, ck, cb, s_f);
+    if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;      // entries past the KS-tap window are zero (cwin == 0 there)
     __syncthreads();
     float dq_acc = 0.f;
 #pragma unroll
@@ -416,7 +338,7 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
         if (t0 + tt < T) {
             float pre = kv[i] + qk;
 #pragma unroll
-            for (int cc = 0; cc < CH_; ++cc) pre += s_f[tt][cc] * s_dkT[k][cc];
+            for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * s_lk[j][k];
             const float u = fast_tanh(pre);
             g = s_de[tt] * wk * (1.f - u * u);
         }
@@ -426,127 +348,102 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
     if (grp == 1) s_dq[k] = dq_acc;
     __syncthreads();
     if (grp == 0) atomicAdd(dq + (long)b * A_ + k, dq_acc + s_dq[k]);
-    // d_f[tt][ch] = sum_k g[tt][k] * dense_k[ch][k]
-    for (int i = threadIdx.x; i < TS * CH_; i += blockDim.x) {
-        const int tt = i / CH_, chn = i % CH_;
-        if (t0 + tt >= T) continue;
+    // h[tt][j] = sum_k g[tt][k] * loc_k[j][k] : thread (tt = tid / 32, j = tid % 32)
+    {
+        const int tt = threadIdx.x >> 5, j = threadIdx.x & 31;
         float acc = 0.f;
+        if (j < KS) {
 #pragma unroll 8
-        for (int kk = 0; kk < A_; ++kk) acc += s_g[tt][kk] * s_dkT[kk][chn];
-        d_f[((long)b * T + t0 + tt) * CH_ + chn] = acc;
+            for (int kk = 0; kk < A_; kk += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(&s_g[tt][kk]);
+                const float4 l4 = *reinterpret_cast<const float4*>(&s_lk[j][kk]);
+                acc += g4.x * l4.x + g4.y * l4.y + g4.z * l4.z + g4.w * l4.w;
+            }
+        }
+        if (t0 + tt < T) h[((long)b * T + t0 + tt) * HLD + j] = acc;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// post-loop parameter gradients (recompute per step from saved d_e, q, cum)
+// post-loop parameter gradients (recompute g per step from saved d_e, q, cum):
+//   d_keys[b,t,k] += g ; d_loc_k[j,k] += cum[t+j-pad] g ; d_score_w[k] += d_e u ; d_score_b[k] += g
+// (d_loc_b == d_score_b: both biases add to the same pre-activation)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, int S, int steps_per_block,
                                                             const float* __restrict__ q_hist, const float* __restrict__ cum_hist,
                                                             const float* __restrict__ de_hist, float* __restrict__ d_keys,
-                                                            float* __restrict__ d_conv_k, float* __restrict__ d_conv_b,
-                                                            float* __restrict__ d_dense_k, float* __restrict__ d_score_w,
+                                                            float* __restrict__ d_loc_k, float* __restrict__ d_score_w,
                                                             float* __restrict__ d_score_b) {
-    __shared__ float s_cum[TS + KS_MAX - 1];
-    __shared__ float s_ck[KS_MAX * CH_];
-    __shared__ __attribute__((aligned(16))) float s_f[TS][FLD];
-    __shared__ float s_g[TS][A_];
-    __shared__ float s_dkT[A_][CH_ + 1];
-    __shared__ float s_df[TS][CH_ + 1];
-    __shared__ float s_de[TS];
-    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, B = (int)c.B, KS = (int)c.KS;
+    __shared__ float s_cum[2][TS + KS_MAX - 1];
+    __shared__ float s_de[2][TS];
+    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, B = (int)c.B, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int s_beg = blockIdx.z * steps_per_block, s_end = min(S, s_beg + steps_per_block);
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
-    for (int i = threadIdx.x; i < A_ * CH_; i += blockDim.x) s_dkT[i % A_][i / A_] = c.dense_k[i];
-    const float sb = c.score_b[k], wk = c.score_w[k];
+    float lk[KS_MAX], acc_lk[KS_MAX];
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) { lk[j] = (j < KS) ? c.loc_k[j * A_ + k] : 0.f; acc_lk[j] = 0.f; }
+    const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
     const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
-    float key_v[TS / 2];
+    float key_v[TS / 2], acc_keys[TS / 2];
 #pragma unroll
-    for (int i = 0; i < TS / 2; ++i) key_v[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
-    float acc_keys[TS / 2], acc_dk[CH_], acc_w = 0.f, acc_b = 0.f;
-#pragma unroll
-    for (int i = 0; i < TS / 2; ++i) acc_keys[i] = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < CH_; ++ch) acc_dk[ch] = 0.f;
-    // conv kernel gradient: pairs p = threadIdx.x + 256*r (r<4) over KS*CH_ entries
-    float acc_ck[(KS_MAX * CH_ + 255) / 256];
-#pragma unroll
-    for (int r = 0; r < (KS_MAX * CH_ + 255) / 256; ++r) acc_ck[r] = 0.f;
-    float acc_cb = 0.f;   // thread (< CH_) accumulates conv bias grad for channel threadIdx.x
-
-    for (int s = s_beg; s < s_end; ++s) {
-        __syncthreads();
-        if (threadIdx.x < TS) {
-            const int t = t0 + threadIdx.x;
-            s_de[threadIdx.x] = (t < T) ? de_hist[((long)s * B + b) * T + t] : 0.f;
+    for (int i = 0; i < TS / 2; ++i) { key_v[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f; acc_keys[i] = 0.f; }
+    float acc_w = 0.f, acc_b = 0.f;
+    // software pipeline: the window / d_e / q of step s+1 are loaded while step s is processed
+    auto load_cum = [&](int s) -> float {
+        float v = 0.f;
+        if (threadIdx.x < TS + KS - 1) {
+            const int t = t0 - pad + threadIdx.x;
+            if (t >= 0 && t < T) v = cum_hist[((long)s * B + b) * T + t];
         }
-        location_features(c, cum_hist + ((long)s * B + b) * T, t0, s_cum, s_ck, s_f);
-        const float qk = q_hist[((long)s * B + b) * A_ + k] + sb;
+        return v;
+    };
+    auto load_de = [&](int s) -> float {
+        const int t = t0 + (threadIdx.x - 128);
+        return (threadIdx.x >= 128 && threadIdx.x < 128 + TS && t < T) ? de_hist[((long)s * B + b) * T + t] : 0.f;
+    };
+    float ncum = 0.f, nde = 0.f, nq = 0.f;
+    if (s_beg < s_end) { ncum = load_cum(s_beg); nde = load_de(s_beg); nq = q_hist[((long)s_beg * B + b) * A_ + k]; }
+    int buf = 0;
+    for (int s = s_beg; s < s_end; ++s, buf ^= 1) {
+        if (threadIdx.x < TS + KS_MAX - 1) s_cum[buf][threadIdx.x] = ncum;   // zero past the KS-tap window
+        if (threadIdx.x >= 128 && threadIdx.x < 128 + TS) s_de[buf][threadIdx.x - 128] = nde;
+        const float qk = nq + sb;
+        if (s + 1 < s_end) { ncum = load_cum(s + 1); nde = load_de(s + 1); nq = q_hist[((long)(s + 1) * B + b) * A_ + k]; }
+        __syncthreads();                    // buf written; the other buffer is free to be rewritten next iteration
 #pragma unroll
         for (int i = 0; i < TS / 2; ++i) {
             const int tt = grp + 2 * i;
-            float g = 0.f;
             if (t0 + tt < T) {
                 float pre = key_v[i] + qk;
 #pragma unroll
-                for (int ch = 0; ch < CH_; ++ch) pre += s_f[tt][ch] * s_dkT[k][ch];
+                for (int j = 0; j < KS_MAX; ++j) pre += s_cum[buf][tt + j] * lk[j];
                 const float u = fast_tanh(pre);
-                const float de = s_de[tt];
-                g = de * wk * (1.f - u * u);
+                const float de = s_de[buf][tt];
+                const float g = de * wk * (1.f - u * u);
                 acc_w += de * u;
                 acc_b += g;
                 acc_keys[i] += g;
 #pragma unroll
-                for (int ch = 0; ch < CH_; ++ch) acc_dk[ch] += s_f[tt][ch] * g;
-            }
-            s_g[tt][k] = g;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < TS * CH_; i += blockDim.x) {
-            const int tt = i / CH_, ch = i % CH_;
-            float acc = 0.f;
-#pragma unroll 8
-            for (int kk = 0; kk < A_; ++kk) acc += s_g[tt][kk] * s_dkT[kk][ch];
-            s_df[tt][ch] = acc;
-        }
-        __syncthreads();
-        if (threadIdx.x < CH_) {
-            float a = 0.f;
-            for (int tt = 0; tt < TS; ++tt) a += s_df[tt][threadIdx.x];
-            acc_cb += a;
-        }
-#pragma unroll
-        for (int r = 0; r < (KS_MAX * CH_ + 255) / 256; ++r) {
-            const int p = threadIdx.x + 256 * r;
-            if (p < KS * CH_) {
-                const int j = p / CH_, ch = p % CH_;
-                float a = 0.f;
-#pragma unroll
-                for (int tt = 0; tt < TS; ++tt) a += s_cum[tt + j] * s_df[tt][ch];
-                acc_ck[r] += a;
+                for (int j = 0; j < KS_MAX; ++j) acc_lk[j] += s_cum[buf][tt + j] * g;
             }
         }
     }
-    // flush
 #pragma unroll
     for (int i = 0; i < TS / 2; ++i) {
         const int tt = grp + 2 * i;
         if (t0 + tt < T) atomicAdd(d_keys + ((long)b * T + t0 + tt) * A_ + k, acc_keys[i]);
     }
 #pragma unroll
-    for (int ch = 0; ch < CH_; ++ch) atomicAdd(d_dense_k + ch * A_ + k, acc_dk[ch]);
+    for (int j = 0; j < KS_MAX; ++j)
+        if (j < KS) atomicAdd(d_loc_k + j * A_ + k, acc_lk[j]);
     atomicAdd(d_score_w + k, acc_w);
     atomicAdd(d_score_b + k, acc_b);
-    if (threadIdx.x < CH_) atomicAdd(d_conv_b + threadIdx.x, acc_cb);
-#pragma unroll
-    for (int r = 0; r < (KS_MAX * CH_ + 255) / 256; ++r) {
-        const int p = threadIdx.x + 256 * r;
-        if (p < KS * CH_) atomicAdd(d_conv_k + p, acc_ck[r]);
-    }
 }
 
 static int check_const(const mstts_lsa_const* c) {
     MSTTS_REQUIRE(c != nullptr, MSTTS_ERR_SHAPE, "lsa: null const block");
     MSTTS_REQUIRE(c->A == A_ && c->CH == CH_, MSTTS_ERR_SHAPE, "lsa: built for A=%d CH=%d, got A=%ld CH=%ld", A_, CH_, (long)c->A, (long)c->CH);
+    MSTTS_REQUIRE(c->loc_k && c->loc_b, MSTTS_ERR_SHAPE, "lsa: folded location filter (loc_k/loc_b) missing - call mstts_lsa_fold_location first");
     MSTTS_REQUIRE(c->KS >= 1 && c->KS <= KS_MAX && (c->KS & 1), MSTTS_ERR_SHAPE, "lsa: conv taps must be odd and <= %d", KS_MAX);
     MSTTS_REQUIRE(c->T >= 1 && c->T <= T_MAX, MSTTS_ERR_SHAPE, "lsa: T must be in [1,%d]", T_MAX);
     MSTTS_REQUIRE(c->M % 4 == 0 && aligned16(c->values), MSTTS_ERR_ALIGN, "lsa: memory width %% 4 and 16-byte aligned values required");
@@ -592,18 +489,49 @@ extern "C" int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* alig
     return MSTTS_OK;
 }
 extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
-                                   float* d_keys, float* d_conv_k, float* d_conv_b, float* d_dense_k, float* d_score_w, float* d_score_b,
-                                   mstts_stream_t s) {
+                                   float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     if (S <= 0) return MSTTS_OK;
     const int nt = cdiv(c->T, TS);
-    int chunks = (int)(1024 / (c->B * nt));
+    int chunks = (int)(2048 / (c->B * nt));
     if (chunks < 1) chunks = 1;
     if (chunks > S) chunks = (int)S;
     const int spb = cdiv(S, chunks);
     chunks = cdiv(S, spb);
     hipLaunchKernelGGL(lsa_param_bwd_kernel, dim3((unsigned)c->B, nt, chunks), dim3(256), 0, ST(s), *c, (int)S, spb, q_hist, cum_hist,
-                       de_hist, d_keys, d_conv_k, d_conv_b, d_dense_k, d_score_w, d_score_b);
+                       de_hist, d_keys, d_loc_k, d_score_w, d_score_b);
     MSTTS_CHECK_LAUNCH("lsa_param_bwd");
     return MSTTS_OK;
+}
+
+/* loc_k[KS,A] = conv_k[KS,CH] . dense_k[CH,A] ; loc_b[A] = conv_b[CH] . dense_k */
+extern "C" int mstts_lsa_fold_location(const float* conv_k, const float* conv_b, const float* dense_k, float* loc_k, float* loc_b,
+                                       int64_t KS, int64_t CH, int64_t A, mstts_stream_t s) {
+    mstts_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.A = conv_k; g.B = dense_k; g.C = loc_k; g.M = KS; g.N = A; g.K = CH; g.lda = CH; g.ldb = A; g.ldc = A; g.alpha = 1.f; g.split_k = 1; g.batch = 1;
+    int rc = mstts_gemm_f32(&g, s);
+    if (rc) return rc;
+    g.A = conv_b; g.C = loc_b; g.M = 1;
+    return mstts_gemm_f32(&g, s);
+}
+
+/* unfold d_loc_k[KS,A] (+ d_loc_b == d_score_b[A]) into the gradients of the three reference variables (accumulating):
+ *   d_conv_k += d_loc_k . dense_k^T ; d_dense_k += conv_k^T . d_loc_k + conv_b^T (x) d_loc_b ; d_conv_b += d_loc_b . dense_k^T */
+extern "C" int mstts_lsa_unfold_location_grad(const float* conv_k, const float* conv_b, const float* dense_k, const float* d_loc_k,
+                                              const float* d_loc_b, float* d_conv_k, float* d_conv_b, float* d_dense_k,
+                                              int64_t KS, int64_t CH, int64_t A, mstts_stream_t s) {
+    mstts_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.alpha = 1.f; g.split_k = 1; g.batch = 1; g.accumulate = 1;
+    g.A = d_loc_k; g.lda = A; g.B = dense_k; g.ldb = A; g.trans_b = 1; g.C = d_conv_k; g.ldc = CH; g.M = KS; g.N = CH; g.K = A;
+    int rc = mstts_gemm_f32(&g, s); if (rc) return rc;
+    g.A = d_loc_b; g.C = d_conv_b; g.M = 1;
+    rc = mstts_gemm_f32(&g, s); if (rc) return rc;
+    memset(&g, 0, sizeof(g));
+    g.alpha = 1.f; g.split_k = 1; g.batch = 1; g.accumulate = 1;
+    g.A = conv_k; g.lda = CH; g.trans_a = 1; g.B = d_loc_k; g.ldb = A; g.C = d_dense_k; g.ldc = A; g.M = CH; g.N = A; g.K = KS;
+    rc = mstts_gemm_f32(&g, s); if (rc) return rc;
+    g.A = conv_b; g.lda = CH; g.B = d_loc_b; g.K = 1;
+    return mstts_gemm_f32(&g, s);
 }

@@ -16,6 +16,7 @@
 // permuted k (fwd: column) assignment, so one load instruction of a wave covers 4 rows x 256 B
 // (fwd) or 16 rows x 64 B (bwd) of the row-major kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mstts {
 
@@ -39,37 +40,40 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     constexpr int UNROLL = EXACT ? NIT : MAX_IT;
     const int nit = EXACT ? NIT : wl / 4;
     const int wk0 = wave * wl;
-    // 1) all weight loads of this wave: row kb + wk0 + 4*it + kq, columns n0 + 4j .. 4j+3
+    // 1) activation slice first (the MFMA chain needs it before anything else): X[m0 .. m0+32, kb .. kb+KL),
+    //    8 threads per row, all loads issued before the first LDS write
+    const int kl4 = KL / 4;
+    const int sb = threadIdx.x >> 3, sc = threadIdx.x & 7;
+    const bool srow_live = m0 + sb < M;
+    const float* xr = X + (long)(m0 + sb) * ldx + kb;
+    f32x4 st[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int k4 = sc + 8 * q;
+        if (k4 < kl4 && srow_live) st[q] = *reinterpret_cast<const f32x4*>(xr + k4 * 4);
+    }
+    // 2) all weight loads of this wave: row kb + wk0 + 4*it + kq, columns n0 + 4j .. 4j+3
     const bool col_ok = n0 + 4 * j + 3 < N;
     const float* wp = W + (long)(kb + wk0 + kq) * ldw + n0 + 4 * j;
     f32x4 wreg[UNROLL];
 #pragma unroll
     for (int it = 0; it < UNROLL; ++it) {
         wreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef SKINNY_PROBE_NO_WLOAD
         if ((EXACT || it < nit) && col_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (long)(4 * it) * ldw));
+#else
+        wreg[it] = (f32x4){(float)it, 1.f, 2.f, (float)lane};
+#endif
     }
-    // 2) stage X[m0 .. m0+32, kb .. kb+KL) row-major into LDS (rows >= M are zero): 8 threads per row,
-    //    all loads issued before the first LDS write (one memory round trip, not one per float4)
-    {
-        const int kl4 = KL / 4;
-        const int b = threadIdx.x >> 3, c = threadIdx.x & 7;
-        const bool row_live = m0 + b < M;
-        const float* xr = X + (long)(m0 + b) * ldx + kb;
-        f32x4 st[16];
+    // 3) LDS write of the staged slice (waits only for the slice: the weight loads stay in flight)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int k4 = c + 8 * q;
-            if (k4 < kl4 && row_live) st[q] = *reinterpret_cast<const f32x4*>(xr + k4 * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k4 = c + 8 * q;
-            if (k4 < kl4) *reinterpret_cast<f32x4*>(smem + b * lds_ld + k4 * 4) = st[q];
-        }
+    for (int q = 0; q < 16; ++q) {
+        const int k4 = sc + 8 * q;
+        if (k4 < kl4) *reinterpret_cast<f32x4*>(smem + sb * lds_ld + k4 * 4) = st[q];
     }
     __syncthreads();
-    // 3) MFMA chain
+    // 4) MFMA chain (iteration `it` waits only for weight load `it`)
     f32x4 acc[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -82,6 +86,10 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
         if (EXACT || it < nit) {
             const float a0 = xa[4 * it], a1 = TWO ? xb[4 * it] : 0.f;
             const f32x4 bv = wreg[it];
+#ifdef SKINNY_PROBE_NO_MFMA
+            acc[0][0] += a0 * bv; acc[1][0] += a1 * bv;
+            continue;
+#endif
             acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[0], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[1], acc[0][1], 0, 0, 0);
             acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[2], acc[0][2], 0, 0, 0);
@@ -134,7 +142,20 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
     constexpr int UNROLL = EXACT ? NIT : MAX_IT;
     const int nit = EXACT ? NIT : hl / 16;
     const int c0 = half * hl + 4 * kq;                 // slice-relative first column of this lane
-    // 1) all weight loads: row r0 + 16*rt + j, columns nb + c0 + 16*it .. +3
+    // 1) dG slice first: dG[m0 .. m0+32, nb .. nb+NL), 8 threads per row, <= 2 rounds of 16 float4 (NL <= 1024);
+    //    the first round's loads are issued before the weight loads, its LDS writes after them
+    const int nl4 = NL / 4;
+    const int sb = threadIdx.x >> 3, sc = threadIdx.x & 7;
+    const bool srow_live = m0 + sb < M;
+    const float* gr = dG + (long)(m0 + sb) * ldg + nb;
+    f32x4 st[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int c4 = sc + 8 * q;
+        if (c4 < nl4 && srow_live) st[q] = *reinterpret_cast<const f32x4*>(gr + c4 * 4);
+    }
+    // 2) all weight loads: row r0 + 16*rt + j, columns nb + c0 + 16*it .. +3
     const bool row_ok = r0 + 16 * rt + j < R;
     const float* wp = W + (long)(r0 + 16 * rt + j) * ldw + nb + c0;
     f32x4 wreg[UNROLL];
@@ -143,29 +164,23 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
         wreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if ((EXACT || it < nit) && row_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + 16 * it));
     }
-    // 2) stage dG[m0 .. m0+32, nb .. nb+NL) into LDS: 8 threads per row, two rounds of 16 float4 each,
-    //    every round's loads issued before its first LDS write
-    {
-        const int nl4 = NL / 4;
-        const int b = threadIdx.x >> 3, c = threadIdx.x & 7;
-        const bool row_live = m0 + b < M;
-        const float* gr = dG + (long)(m0 + b) * ldg + nb;
+    // 3) LDS writes of the slice (second round only when NL > 512)
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            if (round * 128 < nl4) {
-                f32x4 st[16];
+    for (int q = 0; q < 16; ++q) {
+        const int c4 = sc + 8 * q;
+        if (c4 < nl4) *reinterpret_cast<f32x4*>(smem + sb * lds_ld + c4 * 4) = st[q];
+    }
+    if (nl4 > 128) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    const int c4 = c + 8 * (q + 16 * round);
-                    if (c4 < nl4 && row_live) st[q] = *reinterpret_cast<const f32x4*>(gr + c4 * 4);
-                }
+        for (int q = 0; q < 16; ++q) {
+            st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int c4 = sc + 8 * (q + 16);
+            if (c4 < nl4 && srow_live) st[q] = *reinterpret_cast<const f32x4*>(gr + c4 * 4);
+        }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int c4 = c + 8 * (q + 16 * round);
-                    if (c4 < nl4) *reinterpret_cast<f32x4*>(smem + b * lds_ld + c4 * 4) = st[q];
-                }
-            }
+        for (int q = 0; q < 16; ++q) {
+            const int c4 = sc + 8 * (q + 16);
+            if (c4 < nl4) *reinterpret_cast<f32x4*>(smem + sb * lds_ld + c4 * 4) = st[q];
         }
     }
     __syncthreads();
@@ -216,6 +231,7 @@ static void set_lds_attr() {
     hipFuncSetAttribute((const void*)skinny_fwd_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
     hipFuncSetAttribute((const void*)skinny_bwd_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     MSTTS_SK_ATTR(0, true) MSTTS_SK_ATTR(0, false) MSTTS_SK_ATTR(2, true) MSTTS_SK_ATTR(2, false) MSTTS_SK_ATTR(4, true) MSTTS_SK_ATTR(4, false)
+    MSTTS_SK_ATTR(8, true) MSTTS_SK_ATTR(8, false) MSTTS_SK_ATTR(14, true) MSTTS_SK_ATTR(14, false) MSTTS_SK_ATTR(16, true) MSTTS_SK_ATTR(16, false)
     MSTTS_SK_ATTR(28, true) MSTTS_SK_ATTR(28, false) MSTTS_SK_ATTR(32, true) MSTTS_SK_ATTR(32, false)
 #undef MSTTS_SK_ATTR
     g_attr_set = true;
@@ -227,12 +243,18 @@ static void set_lds_attr() {
         if (two) {                                                                                     \
             if (nit == 32) hipLaunchKernelGGL((KERNEL<32, true>), __VA_ARGS__);                        \
             else if (nit == 28) hipLaunchKernelGGL((KERNEL<28, true>), __VA_ARGS__);                   \
+            else if (nit == 16) hipLaunchKernelGGL((KERNEL<16, true>), __VA_ARGS__);                   \
+            else if (nit == 14) hipLaunchKernelGGL((KERNEL<14, true>), __VA_ARGS__);                   \
+            else if (nit == 8) hipLaunchKernelGGL((KERNEL<8, true>), __VA_ARGS__);                     \
             else if (nit == 4) hipLaunchKernelGGL((KERNEL<4, true>), __VA_ARGS__);                     \
             else if (nit == 2) hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__);                     \
             else hipLaunchKernelGGL((KERNEL<0, true>), __VA_ARGS__);                                   \
         } else {                                                                                       \
             if (nit == 32) hipLaunchKernelGGL((KERNEL<32, false>), __VA_ARGS__);                       \
             else if (nit == 28) hipLaunchKernelGGL((KERNEL<28, false>), __VA_ARGS__);                  \
+            else if (nit == 16) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
+            else if (nit == 14) hipLaunchKernelGGL((KERNEL<14, false>), __VA_ARGS__);                  \
+            else if (nit == 8) hipLaunchKernelGGL((KERNEL<8, false>), __VA_ARGS__);                    \
             else if (nit == 4) hipLaunchKernelGGL((KERNEL<4, false>), __VA_ARGS__);                    \
             else if (nit == 2) hipLaunchKernelGGL((KERNEL<2, false>), __VA_ARGS__);                    \
             else hipLaunchKernelGGL((KERNEL<0, false>), __VA_ARGS__);                                  \
@@ -242,11 +264,23 @@ static void set_lds_attr() {
 }  // namespace mstts
 using namespace mstts;
 
+// workgroups a skinny launch aims for (default 512 = two per CU); row-chain mode lowers it so that
+// kernels of different chains co-reside.  Development knob: MSTTS_SKINNY_TARGET_WGS.
+static long target_wgs() {
+    static long t = 0;
+    if (t == 0) {
+        const char* e = getenv("MSTTS_SKINNY_TARGET_WGS");
+        t = e ? atol(e) : 512;
+        if (t < 32) t = 32;
+    }
+    return t;
+}
+
 extern "C" int32_t mstts_skinny_fwd_splits(int64_t N, int64_t K) {
     // K-splits so that strips * splits ~ 256 workgroups; each slice a multiple of 32 rows, <= 512 rows
     if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
     const long strips = (N + 63) / 64;
-    long ks = 256 / strips;
+    long ks = target_wgs() / strips;            // default: two workgroups per CU (one computes while the other waits on loads)
     if (ks < 1) ks = 1;
     if (ks > K / 32) ks = K / 32;
     if (ks > 16) ks = 16;                       // consumers sum at most 16 slabs (MSTTS_MAX_PARTS)
@@ -285,7 +319,7 @@ extern "C" int32_t mstts_skinny_bwd_splits(int64_t R, int64_t N) {
     // at least 128 (when N allows) and at most 1024 columns
     if (R <= 0 || N <= 0 || N % 32 != 0) return 0;
     const long strips = (R + 31) / 32;
-    long ns = 256 / strips;
+    long ns = target_wgs() / strips;
     if (ns < 1) ns = 1;
     const long max_ns = N >= 128 ? N / 128 : 1;
     if (ns > max_ns) ns = max_ns;

@@ -64,6 +64,7 @@ class TrainEngine:
         self.bp_pad = self._f(self.proj_ld)
         self.dwp_pad = self._f(H + M, self.proj_ld)
         self.dw0f = self._f(M + H, 4 * H)
+        self.loc_k, self.loc_b, self.d_loc_k = self._f(d.att_k, d.att), self._f(d.att), self._f(d.att_k, d.att)
         self.flip = {}
         self._derived_stale = True
 
@@ -92,6 +93,9 @@ class TrainEngine:
         self.bp_pad.zero_()
         call("mstts_copy2d", ptr(wp, owp), nm1, ptr(self.wp_pad), self.proj_ld, H + M, nm1, 0)
         call("mstts_copy2d", ptr(bp, obp), nm1, ptr(self.bp_pad), self.proj_ld, 1, nm1, 0)
+        ck, ock = self.P(LSA + "attention_convolution_dense_layer/conv1d/kernel"); cb, ocb = self.P(LSA + "attention_convolution_dense_layer/conv1d/bias")
+        dk, odk = self.P(LSA + "attention_convolution_dense_layer/dense/kernel")
+        call("mstts_lsa_fold_location", ptr(ck, ock), ptr(cb, ocb), ptr(dk, odk), ptr(self.loc_k), ptr(self.loc_b), d.att_k, d.att_ch, d.att)
         self._derived_stale = False
 
     def plan(self, B, Te, L):
@@ -141,7 +145,7 @@ class TrainEngine:
         w.post_mean = [f(c) for c in chans]
         w.post_rstd = [f(c) for c in chans]
         w.mel_out = f(B, S, d.n_mel)
-        w.bn_ws = f(2 * max(d.post_ch, d.enc_conv_ch, d.bank_k * d.bank_ch, d.proj1_ch))
+        w.bn_ws = f(2 * max(d.post_ch, d.enc_conv_ch, d.bank_k * d.bank_ch, d.proj1_ch, d.n_mel, d.emb))
         # vocoder conv-bank (BN update side effect)
         if self.update_vocoder_bn:
             w.v_tmp = f(B * S, d.bank_ch)
@@ -158,8 +162,8 @@ class TrainEngine:
         w.d_linear, w.d_post, w.d_stop = f(B, S, d.n_mel), f(B, S, d.n_mel), f(B, S)
         # backward
         w.post_dz = [f(B * S, c) for c in chans]
-        w.post_dx = f(B * S, d.post_ch)
-        w.post_dx2 = f(B * S, d.post_ch)
+        w.post_dx = f(B * S, max(d.post_ch, d.n_mel))
+        w.post_dx2 = f(B * S, max(d.post_ch, d.n_mel))
         w.d_proj = f(S, B, self.proj_ld)
         w.d_pj = f(S, B, H + M)
         w.dg0, w.dg1 = f(S, B, 4 * H), f(S, B, 4 * H)
@@ -174,9 +178,9 @@ class TrainEngine:
         w.enc_dgs = {dr: f(Te, B, 4 * He) for dr in ("fw", "bw")}
         w.enc_dgp = {dr: f(B, Te, 4 * He) for dr in ("fw", "bw")}
         w.enc_bwd_ws = f(int(lb.mstts_lstm_seq_ws_floats(B, He, 1)))
-        w.enc_dy = f(B * Te, d.enc_conv_ch)
+        w.enc_dy = f(B * Te, max(d.enc_conv_ch, d.emb))
         w.enc_dz = f(B * Te, d.enc_conv_ch)
-        w.enc_dx = f(B * Te, d.enc_conv_ch)
+        w.enc_dx = f(B * Te, max(d.enc_conv_ch, d.emb))
         # descriptors with stable addresses
         w.dec = lib.DecoderTrain()
         w.dec_b = lib.DecoderTrainBwd()
@@ -280,6 +284,7 @@ class TrainEngine:
                             ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
             t, o = self.P(LSA + name)
             setattr(ls, field, ptr(t, o))
+        ls.loc_k, ls.loc_b = ptr(self.loc_k), ptr(self.loc_b)
         k1, o1 = self.P(CELL % 1 + "kernel"); b1, ob1 = self.P(CELL % 1 + "bias"); wq, oq = self.P(LSA + "query_layer/kernel")
         dec.xw0, dec.w0f, dec.w1, dec.b1, dec.wq = ptr(w.xw0), ptr(self.w0f), ptr(k1, o1), ptr(b1, ob1), ptr(wq, oq)
         dec.zc0, dec.zh0, dec.zc1, dec.zh1 = ptr(mk["dec_zc_0"]), ptr(mk["dec_zh_0"]), ptr(mk["dec_zc_1"]), ptr(mk["dec_zh_1"])
@@ -410,8 +415,12 @@ class TrainEngine:
                             ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
             t, o = self.G(LSA + name)
             gs[field] = ptr(t, o)
+        self.d_loc_k.zero_()
         call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), S, ptr(w.q_hist), ptr(w.cum_hist), ptr(w.de_hist), ptr(w.d_keys),
-             gs["conv_k"], gs["conv_b"], gs["dense_k"], gs["score_w"], gs["score_b"])
+             ptr(self.d_loc_k), gs["score_w"], gs["score_b"])
+        ls = w.dec.lsa
+        call("mstts_lsa_unfold_location_grad", ls.conv_k, ls.conv_b, ls.dense_k, ptr(self.d_loc_k), gs["score_b"],
+             gs["conv_k"], gs["conv_b"], gs["dense_k"], d.att_k, d.att_ch, d.att)
         # d_values[b] = sum_s align[s,b,:]^T (d_ctx from projection + d_ctx from next step's cell 0)
         gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
              strides=(Te, H + M, Te * M), b_off=H)

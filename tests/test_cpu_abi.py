@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol():
     # host-only helpers are callable without a GPU
     cdll.mstts_skinny_fwd_splits.restype = ctypes.c_int32
     cdll.mstts_skinny_fwd_splits.argtypes = [ctypes.c_int64, ctypes.c_int64]
-    assert cdll.mstts_skinny_fwd_splits(4096, 1792) == 4 and cdll.mstts_skinny_fwd_splits(4096, 80) == 0
+    assert cdll.mstts_skinny_fwd_splits(4096, 1792) == 8 and cdll.mstts_skinny_fwd_splits(4096, 80) == 0
     cdll.mstts_skinny_bwd_splits.restype = ctypes.c_int32
     cdll.mstts_skinny_bwd_splits.argtypes = [ctypes.c_int64, ctypes.c_int64]
-    assert cdll.mstts_skinny_bwd_splits(1792, 4096) == 4
+    assert cdll.mstts_skinny_bwd_splits(1792, 4096) == 8
 
 
 def test_struct_layouts_match_header_sizes():

@@ -81,55 +81,57 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     c.keys, c.values, c.lengths = lib.ptr(dk), lib.ptr(dv), lib.ptr(dl)
     c.conv_k, c.conv_b = lib.ptr(dp[LSA + "attention_convolution_dense_layer/conv1d/kernel"]), lib.ptr(dp[LSA + "attention_convolution_dense_layer/conv1d/bias"])
     c.dense_k, c.score_w, c.score_b = lib.ptr(dp[LSA + "attention_convolution_dense_layer/dense/kernel"]), lib.ptr(dp[LSA + "score_layer/weight_w"]), lib.ptr(dp[LSA + "score_layer/bias_b"])
+    loc_k, loc_b = torch.zeros(KS, A, device=dev), torch.zeros(A, device=dev)
+    lib.call("mstts_lsa_fold_location", c.conv_k, c.conv_b, c.dense_k, lib.ptr(loc_k), lib.ptr(loc_b), KS, CH, A)
+    c.loc_k, c.loc_b = lib.ptr(loc_k), lib.ptr(loc_b)
+    wc = p[LSA + "attention_convolution_dense_layer/conv1d/kernel"][:, 0, :]
+    assert rel_err(t2n(loc_k), wc @ p[LSA + "attention_convolution_dense_layer/dense/kernel"]) < 2e-6
     q = f32(query @ p[LSA + "query_layer/kernel"]); dcum = f32(cum)
     en, al, cn, cx = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
     lib.call("mstts_lsa_energy_fwd", C.byref(c), lib.ptr(q), 1, 0, None, lib.ptr(dcum), lib.ptr(en))
     lib.call("mstts_lsa_context_fwd", C.byref(c), lib.ptr(en), lib.ptr(dcum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0)
     assert rel_err(t2n(al), t2n(align)) < 2e-5 and rel_err(t2n(cn), t2n(cum_next)) < 2e-5 and rel_err(t2n(cx), t2n(ctx)) < 2e-5
-    # backward: upstream grads on ctx and on the next cumulative state
-    d_ctx = g.normal(0, 1, (B, M)); G_next = g.normal(0, 1, (B, T)); d_f_next = g.normal(0, 1, (B, T, CH))
-    # G = G_next + convT(d_f_next): emulate by adding <f(cum_next), d_f_next> to the objective
-    f_next = OM.conv1d_same(cum_next[:, :, None], pt[LSA + "attention_convolution_dense_layer/conv1d/kernel"], pt[LSA + "attention_convolution_dense_layer/conv1d/bias"])
-    obj = (ctx * torch.tensor(d_ctx)).sum() + (cum_next * torch.tensor(G_next)).sum() + (f_next * torch.tensor(d_f_next)).sum()
+    # backward: upstream grads on ctx and on the next cumulative state.  The latter arrives as G_next plus the
+    # filter-transpose of the next step's h (G[t] = G_next[t] + sum_j h_next[t+pad-j][j]).
+    pad = (KS - 1) // 2
+    d_ctx = g.normal(0, 1, (B, M)); G_next = g.normal(0, 1, (B, T)); h_next = g.normal(0, 1, (B, T, 32))
+    G_ref = G_next.copy()
+    for j in range(KS):
+        for t_ in range(T):
+            tau = t_ + pad - j
+            if 0 <= tau < T:
+                G_ref[:, t_] += h_next[:, tau, j]
+    obj = (ctx * torch.tensor(d_ctx)).sum() + (cum_next * torch.tensor(G_ref)).sum()
     obj.backward()
     G, da = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev)
-    d_ctx_d, G_next_d, d_f_next_d = f32(d_ctx), f32(G_next), f32(d_f_next)     # keep alive: the calls are asynchronous
-    lib.call("mstts_lsa_dalign_bwd", C.byref(c), lib.ptr(d_ctx_d), M, None, 0, 0, 0, lib.ptr(G_next_d), lib.ptr(d_f_next_d), lib.ptr(G), lib.ptr(da))
-    de, dq, df = torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, CH, device=dev)
-    lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al), lib.ptr(da), lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dq), lib.ptr(df))
-    # d query (through the query layer) = dq . Wq^T
+    d_ctx_d, G_next_d, h_next_d = f32(d_ctx), f32(G_next), f32(h_next)     # keep alive: the calls are asynchronous
+    lib.call("mstts_lsa_dalign_bwd", C.byref(c), lib.ptr(d_ctx_d), M, None, 0, 0, 0, lib.ptr(G_next_d), lib.ptr(h_next_d), lib.ptr(G), lib.ptr(da))
+    assert rel_err(t2n(G), G_ref) < 2e-5
+    de, dq, hh = torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, 32, device=dev)
+    lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al), lib.ptr(da), lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dq), lib.ptr(hh))
     dquery = t2n(dq).astype(np.float64) @ p[LSA + "query_layer/kernel"].T
     assert rel_err(dquery, t2n(qt.grad)) < 5e-5
-    # grad wrt cum = G (carried) + convT(d_f)
-    wc = p[LSA + "attention_convolution_dense_layer/conv1d/kernel"][:, 0, :]
-    pad = (KS - 1) // 2
-    dfn = t2n(df).astype(np.float64)
+    # grad wrt cum = G (carried) + filter-transpose of h
+    hn = t2n(hh).astype(np.float64)
     dcum_ref = t2n(G).astype(np.float64).copy()
     for j in range(KS):
-        for t in range(T):
-            tp = t + j - pad
-            if 0 <= tp < T:
-                dcum_ref[:, tp] += dfn[:, t] @ wc[j]
+        for t_ in range(T):
+            tau = t_ + pad - j
+            if 0 <= tau < T:
+                dcum_ref[:, t_] += hn[:, tau, j]
     assert rel_err(dcum_ref, t2n(ct.grad)) < 5e-5
-    # parameter gradients + d_keys through the post-loop kernel with S = 1
-    S = 1
+    # parameter gradients + d_keys through the post-loop kernel with S = 1, then unfolded to the reference variables
     dkeys = torch.zeros(B, T, A, device=dev)
-    gk, gb, gd, gw, gsb = torch.zeros(KS, CH, device=dev), torch.zeros(CH, device=dev), torch.zeros(CH, A, device=dev), torch.zeros(A, device=dev), torch.zeros(A, device=dev)
-    lib.call("mstts_lsa_param_bwd", C.byref(c), S, lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dkeys), lib.ptr(gk), lib.ptr(gb), lib.ptr(gd), lib.ptr(gw), lib.ptr(gsb))
+    dlk, gw, gsb = torch.zeros(KS, A, device=dev), torch.zeros(A, device=dev), torch.zeros(A, device=dev)
+    lib.call("mstts_lsa_param_bwd", C.byref(c), 1, lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dkeys), lib.ptr(dlk), lib.ptr(gw), lib.ptr(gsb))
+    gk, gb, gd = torch.zeros(KS, CH, device=dev), torch.zeros(CH, device=dev), torch.zeros(CH, A, device=dev)
+    lib.call("mstts_lsa_unfold_location_grad", c.conv_k, c.conv_b, c.dense_k, lib.ptr(dlk), lib.ptr(gsb), lib.ptr(gk), lib.ptr(gb), lib.ptr(gd), KS, CH, A)
     assert rel_err(t2n(dkeys), t2n(kt.grad)) < 5e-5
     assert rel_err(t2n(gd), t2n(pt[LSA + "attention_convolution_dense_layer/dense/kernel"].grad)) < 5e-5
     assert rel_err(t2n(gw), t2n(pt[LSA + "score_layer/weight_w"].grad).reshape(-1)) < 5e-5
     assert rel_err(t2n(gsb), t2n(pt[LSA + "score_layer/bias_b"].grad).reshape(-1)) < 5e-5
-    # conv kernel/bias grads: the oracle objective also has the d_f_next term through f(cum_next); remove it
-    gk_extra = np.zeros((KS, CH)); cn64 = t2n(cum_next).astype(np.float64)
-    for j in range(KS):
-        for t in range(T):
-            tp = t + j - pad
-            if 0 <= tp < T:
-                gk_extra[j] += (cn64[:, tp, None] * d_f_next[:, t]).sum(0)
-    ref_gk = t2n(pt[LSA + "attention_convolution_dense_layer/conv1d/kernel"].grad)[:, 0, :] - gk_extra
-    ref_gb = t2n(pt[LSA + "attention_convolution_dense_layer/conv1d/bias"].grad) - d_f_next.sum((0, 1))
-    assert rel_err(t2n(gk), ref_gk) < 1e-4 and rel_err(t2n(gb), ref_gb) < 1e-4
+    assert rel_err(t2n(gk), t2n(pt[LSA + "attention_convolution_dense_layer/conv1d/kernel"].grad)[:, 0, :]) < 1e-4
+    assert rel_err(t2n(gb), t2n(pt[LSA + "attention_convolution_dense_layer/conv1d/bias"].grad)) < 1e-4
     # d_values from the context: outer(align, d_ctx)
     assert rel_err(t2n(al)[:, :, None] * d_ctx[:, None, :], t2n(vt.grad)) < 5e-5
 

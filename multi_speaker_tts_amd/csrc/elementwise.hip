@@ -359,23 +359,41 @@ __global__ void lstm_point_bwd_kernel(mstts_lstm_point_bwd_desc d) {
 // ---------------------------------------------------------------------------------------------
 struct PointFwdFast {
     const float* gates; int pstride;            // [PARTS][B][4H]
-    const float* xw; int xw_ld;                 // row b at xw + b*xw_ld (or null)
+    const float* xw; int xw_ld, xw_st;          // row b, position pos at xw + b*xw_ld + pos*xw_st (or null)
     const float* bias;                          // [4H] or null
     const float* c_prev; const float* h_prev; int h_prev_ld;
     const uint8_t* zc; const uint8_t* zh; float keep;
-    float* out; int out_ld;
+    float* out; int out_ld, out_st;
     float* c_next; float* h_next; int h_next_ld;
-    float* acts; float* c_raw;
+    float* acts; float* c_raw;                  // may be null when SEQ
+    const int32_t* lengths; int step, reverse;  // SEQ only
+    const float* residual; int res_ld, res_st;  // SEQ only
     int B, H;
 };
 
-template <int PARTS>
+// SEQ = dynamic_rnn semantics (length masking, reversed direction, residual wrapper); the decoder uses SEQ = false
+template <int PARTS, bool SEQ>
 __global__ __launch_bounds__(128) void lstm_point_fwd_fast_kernel(PointFwdFast d) {
     const int i = blockIdx.x * 128 + threadIdx.x;
     const int H = d.H;
     if (i >= d.B * H) return;
     const int b = i / H, u = i - b * H;
     const int g0 = b * 4 * H + u;
+    int pos = 0;
+    bool live = true;
+    if (SEQ) {
+        const int len = d.lengths ? d.lengths[b] : 0x7fffffff;
+        live = d.step < len;
+        pos = (d.reverse && live) ? len - 1 - d.step : d.step;
+    }
+    const float cp = d.c_prev[i], hp = d.h_prev[b * d.h_prev_ld + u];
+    if (SEQ && !live) {
+        d.out[b * d.out_ld + pos * d.out_st + u] = 0.f;
+        d.c_next[i] = cp; d.h_next[b * d.h_next_ld + u] = hp;
+        if (d.acts) { float* a = d.acts + g0; a[0] = 0.f; a[H] = 0.f; a[2 * H] = 0.f; a[3 * H] = 0.f; }
+        if (d.c_raw) d.c_raw[i] = cp;
+        return;
+    }
     float g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pp = 0; pp < PARTS; ++pp) {
@@ -384,13 +402,12 @@ __global__ __launch_bounds__(128) void lstm_point_fwd_fast_kernel(PointFwdFast d
     }
     if (d.xw) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) g4[g] += d.xw[b * d.xw_ld + g * H + u];
+        for (int g = 0; g < 4; ++g) g4[g] += d.xw[b * d.xw_ld + pos * d.xw_st + g * H + u];
     }
     if (d.bias) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) g4[g] += d.bias[g * H + u];
     }
-    const float cp = d.c_prev[i], hp = d.h_prev[b * d.h_prev_ld + u];
     const float kc = d.zc ? (d.zc[i] ? d.keep : 0.f) : d.keep;
     const float kh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
     const float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
@@ -398,37 +415,38 @@ __global__ __launch_bounds__(128) void lstm_point_fwd_fast_kernel(PointFwdFast d
     const float m = so * tanhf(c);
     d.c_next[i] = kc * (c - cp) + cp;
     d.h_next[b * d.h_next_ld + u] = kh * (m - hp) + hp;
-    d.out[b * d.out_ld + u] = m;
-    float* a = d.acts + g0;
-    a[0] = si; a[H] = tj; a[2 * H] = sf; a[3 * H] = so;
-    d.c_raw[i] = c;
+    float o = m;
+    if (SEQ && d.residual) o += d.residual[b * d.res_ld + pos * d.res_st + u];
+    d.out[b * d.out_ld + pos * d.out_st + u] = o;
+    if (!SEQ || d.acts) { float* a = d.acts + g0; a[0] = si; a[H] = tj; a[2 * H] = sf; a[3 * H] = so; }
+    if (!SEQ || d.c_raw) d.c_raw[i] = c;
 }
 
 struct PointBwdFast {
-    const float* d_out; int dout_ld, dout_parts, dout_pstride;     // may be null
+    const float* d_out; int dout_ld, dout_st, dout_parts, dout_pstride;     // may be null
     const float* d_out2; int dout2_parts, dout2_pstride;           // [parts][B][H] or null
     const float* d_c_state; const float* d_h_state;
     const float* dhs2; int dhs2_ld, dhs2_parts; long dhs2_pstride; // or null
     const float* acts; const float* c_raw; const float* c_prev;
     const uint8_t* zc; const uint8_t* zh; float keep;
     float* dgates; float* d_c_prev; float* d_h_prev;
+    const int32_t* lengths; int step, reverse;                     // SEQ only
+    float* dgates_pos; int dgp_ld, dgp_st;                         // SEQ only (or null)
     int B, H;
 };
 
-template <int P_OUT, int P_OUT2, int P_DHS>
+template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ>
 __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d) {
     const int i = blockIdx.x * 128 + threadIdx.x;
     const int H = d.H;
     if (i >= d.B * H) return;
     const int b = i / H, u = i - b * H;
-    float dm = 0.f;
-    if (d.d_out) {
-#pragma unroll
-        for (int pp = 0; pp < P_OUT; ++pp) dm += d.d_out[pp * d.dout_pstride + b * d.dout_ld + u];
-    }
-    if (d.d_out2) {
-#pragma unroll
-        for (int pp = 0; pp < P_OUT2; ++pp) dm += d.d_out2[pp * d.dout2_pstride + i];
+    int pos = 0;
+    bool live = true;
+    if (SEQ) {
+        const int len = d.lengths ? d.lengths[b] : 0x7fffffff;
+        live = d.step < len;
+        pos = (d.reverse && live) ? len - 1 - d.step : d.step;
     }
     float dhs = d.d_h_state[i];
     if (d.dhs2) {
@@ -436,6 +454,23 @@ __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d
         for (int pp = 0; pp < P_DHS; ++pp) dhs += d.dhs2[pp * d.dhs2_pstride + b * d.dhs2_ld + u];
     }
     const float dcs = d.d_c_state[i];
+    float* dg = d.dgates + b * 4 * H + u;
+    float* dgp = (SEQ && d.dgates_pos) ? d.dgates_pos + b * d.dgp_ld + pos * d.dgp_st + u : nullptr;
+    if (SEQ && !live) {
+        dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+        if (dgp) { dgp[0] = 0.f; dgp[H] = 0.f; dgp[2 * H] = 0.f; dgp[3 * H] = 0.f; }
+        d.d_c_prev[i] = dcs; d.d_h_prev[i] = dhs;
+        return;
+    }
+    float dm = 0.f;
+    if (d.d_out) {
+#pragma unroll
+        for (int pp = 0; pp < P_OUT; ++pp) dm += d.d_out[pp * d.dout_pstride + b * d.dout_ld + pos * d.dout_st + u];
+    }
+    if (d.d_out2) {
+#pragma unroll
+        for (int pp = 0; pp < P_OUT2; ++pp) dm += d.d_out2[pp * d.dout2_pstride + i];
+    }
     const float mh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
     const float mc = d.zc ? (d.zc[i] ? d.keep : 0.f) : d.keep;
     dm += mh * dhs;
@@ -444,11 +479,9 @@ __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d
     const float c = d.c_raw[i], cp = d.c_prev[i];
     const float tc = tanhf(c);
     const float dc = dm * so * (1.f - tc * tc) + mc * dcs;
-    float* dg = d.dgates + b * 4 * H + u;
-    dg[0] = dc * tj * si * (1.f - si);
-    dg[H] = dc * si * (1.f - tj * tj);
-    dg[2 * H] = dc * cp * sf * (1.f - sf);
-    dg[3 * H] = dm * tc * so * (1.f - so);
+    const float d_i = dc * tj * si * (1.f - si), d_j = dc * si * (1.f - tj * tj), d_f = dc * cp * sf * (1.f - sf), d_o = dm * tc * so * (1.f - so);
+    dg[0] = d_i; dg[H] = d_j; dg[2 * H] = d_f; dg[3 * H] = d_o;
+    if (dgp) { dgp[0] = d_i; dgp[H] = d_j; dgp[2 * H] = d_f; dgp[3 * H] = d_o; }
     d.d_c_prev[i] = dcs * (1.f - mc) + dc * sf;
     d.d_h_prev[i] = dhs * (1.f - mh);
 }
@@ -746,21 +779,27 @@ extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_st
     MSTTS_REQUIRE(d && d->gates_h && d->c_prev && d->h_prev && d->c_next && d->h_next, MSTTS_ERR_SHAPE, "lstm_point_fwd: null pointer");
     if (d->B * d->H == 0) return MSTTS_OK;
     const int parts = d->gates_parts > 1 ? d->gates_parts : 1;
-    const bool fast = !d->lengths && !d->residual && !d->reverse && d->out && d->acts_out && d->c_raw && d->xw_st == 0 &&
-                      d->out_st == 0 && d->B * d->H * 4 < (1LL << 30) && (parts == 1 || parts == 4 || parts == 8) &&
-                      (long)parts * d->gates_pstride < (1LL << 30);
+    const bool seq = d->lengths || d->residual || d->reverse || d->xw_st != 0 || d->out_st != 0 || !d->acts_out || !d->c_raw;
+    const long span = (d->B + 1) * (d->out_sb > d->xw_sb ? d->out_sb : d->xw_sb);
+    const bool fast = d->out && d->B * d->H * 4 < (1LL << 30) && (parts == 1 || parts == 2 || parts == 4 || parts == 8 || parts == 16) &&
+                      (long)parts * d->gates_pstride < (1LL << 30) && span < (1LL << 30);
     if (fast) {
         PointFwdFast f;
-        f.gates = d->gates_h; f.pstride = (int)d->gates_pstride; f.xw = d->xw; f.xw_ld = (int)d->xw_sb; f.bias = d->bias;
+        f.gates = d->gates_h; f.pstride = (int)d->gates_pstride; f.xw = d->xw; f.xw_ld = (int)d->xw_sb; f.xw_st = (int)d->xw_st; f.bias = d->bias;
         f.c_prev = d->c_prev; f.h_prev = d->h_prev; f.h_prev_ld = (int)(d->h_prev_ld ? d->h_prev_ld : d->H);
         f.zc = d->zc; f.zh = d->zh; f.keep = 1.f - d->zoneout;
-        f.out = d->out; f.out_ld = (int)d->out_sb; f.c_next = d->c_next; f.h_next = d->h_next;
+        f.out = d->out; f.out_ld = (int)d->out_sb; f.out_st = (int)d->out_st; f.c_next = d->c_next; f.h_next = d->h_next;
         f.h_next_ld = (int)(d->h_next_ld ? d->h_next_ld : d->H); f.acts = d->acts_out; f.c_raw = d->c_raw;
+        f.lengths = d->lengths; f.step = d->step; f.reverse = d->reverse;
+        f.residual = d->residual; f.res_ld = (int)d->res_sb; f.res_st = (int)d->res_st;
         f.B = (int)d->B; f.H = (int)d->H;
         dim3 grid((unsigned)((d->B * d->H + 127) / 128));
-        if (parts == 8) hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<8>, grid, dim3(128), 0, ST(s), f);
-        else if (parts == 4) hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<4>, grid, dim3(128), 0, ST(s), f);
-        else hipLaunchKernelGGL(lstm_point_fwd_fast_kernel<1>, grid, dim3(128), 0, ST(s), f);
+#define MSTTS_PF(P)                                                                                        \
+        if (seq) hipLaunchKernelGGL((lstm_point_fwd_fast_kernel<P, true>), grid, dim3(128), 0, ST(s), f);    \
+        else hipLaunchKernelGGL((lstm_point_fwd_fast_kernel<P, false>), grid, dim3(128), 0, ST(s), f)
+        if (parts == 16) { MSTTS_PF(16); } else if (parts == 8) { MSTTS_PF(8); } else if (parts == 4) { MSTTS_PF(4); }
+        else if (parts == 2) { MSTTS_PF(2); } else { MSTTS_PF(1); }
+#undef MSTTS_PF
         MSTTS_CHECK_LAUNCH("lstm_point_fwd_fast");
         return MSTTS_OK;
     }
@@ -775,24 +814,42 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
     {
         const int po = d->dout_parts > 1 ? d->dout_parts : 1, po2 = d->dout2_parts > 1 ? d->dout2_parts : 1;
         const int ph = d->dhs2_parts > 1 ? d->dhs2_parts : 1;
-        const bool shape41 = (po == 1 && po2 == 1 && ph == 4), shape414 = (po == 4 && po2 == 1 && ph == 4), shape111 = (po == 1 && po2 == 1 && ph == 1);
-        const bool shape18 = (po == 1 && po2 == 1 && ph == 8), shape818 = (po == 8 && po2 == 1 && ph == 8);
-        const bool fast = !d->lengths && !d->reverse && !d->dgates_pos && d->dout_st == 0 && d->B * d->H * 4 < (1LL << 30) &&
-                          (shape41 || shape414 || shape111 || shape18 || shape818) && (long)po * d->dout_pstride < (1LL << 30);
-        if (fast) {
+        const bool seq = d->lengths || d->reverse || d->dgates_pos || d->dout_st != 0;
+        const bool small = d->B * d->H * 4 < (1LL << 30) && (long)po * d->dout_pstride < (1LL << 30) && (d->B + 1) * d->dout_sb < (1LL << 30) &&
+                           (d->B + 1) * d->dgp_sb < (1LL << 30);
+        int shape = -1;      // (P_OUT, P_OUT2, P_DHS)
+        if (po == 1 && po2 == 1 && ph == 1) shape = 0;
+        else if (po == 1 && po2 == 1 && ph == 4) shape = 1;
+        else if (po == 4 && po2 == 1 && ph == 4) shape = 2;
+        else if (po == 1 && po2 == 1 && ph == 8) shape = 3;
+        else if (po == 8 && po2 == 1 && ph == 8) shape = 4;
+        else if (po == 8 && po2 == 1 && ph == 1) shape = 5;
+        else if (po == 1 && po2 == 1 && ph == 2) shape = 6;
+        if (small && shape >= 0) {
             PointBwdFast f;
-            f.d_out = d->d_out; f.dout_ld = (int)d->dout_sb; f.dout_parts = po; f.dout_pstride = (int)d->dout_pstride;
+            f.d_out = d->d_out; f.dout_ld = (int)d->dout_sb; f.dout_st = (int)d->dout_st; f.dout_parts = po; f.dout_pstride = (int)d->dout_pstride;
             f.d_out2 = d->d_out2; f.dout2_parts = po2; f.dout2_pstride = (int)d->dout2_pstride;
             f.d_c_state = d->d_c_state; f.d_h_state = d->d_h_state;
             f.dhs2 = d->d_h_state2; f.dhs2_ld = (int)d->dhs2_ld; f.dhs2_parts = ph; f.dhs2_pstride = (long)d->dhs2_pstride;
             f.acts = d->acts; f.c_raw = d->c_raw; f.c_prev = d->c_prev; f.zc = d->zc; f.zh = d->zh; f.keep = 1.f - d->zoneout;
-            f.dgates = d->dgates; f.d_c_prev = d->d_c_prev; f.d_h_prev = d->d_h_prev; f.B = (int)d->B; f.H = (int)d->H;
+            f.dgates = d->dgates; f.d_c_prev = d->d_c_prev; f.d_h_prev = d->d_h_prev;
+            f.lengths = d->lengths; f.step = d->step; f.reverse = d->reverse;
+            f.dgates_pos = d->dgates_pos; f.dgp_ld = (int)d->dgp_sb; f.dgp_st = (int)d->dgp_st;
+            f.B = (int)d->B; f.H = (int)d->H;
             dim3 grid((unsigned)((d->B * d->H + 127) / 128));
-            if (shape18) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 8>), grid, dim3(128), 0, ST(s), f);
-            else if (shape818) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<8, 1, 8>), grid, dim3(128), 0, ST(s), f);
-            else if (shape41) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 4>), grid, dim3(128), 0, ST(s), f);
-            else if (shape414) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<4, 1, 4>), grid, dim3(128), 0, ST(s), f);
-            else hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 1>), grid, dim3(128), 0, ST(s), f);
+#define MSTTS_PB(A1, A2, A3)                                                                                          \
+            if (seq) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<A1, A2, A3, true>), grid, dim3(128), 0, ST(s), f);   \
+            else hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<A1, A2, A3, false>), grid, dim3(128), 0, ST(s), f)
+            switch (shape) {
+                case 0: MSTTS_PB(1, 1, 1); break;
+                case 1: MSTTS_PB(1, 1, 4); break;
+                case 2: MSTTS_PB(4, 1, 4); break;
+                case 3: MSTTS_PB(1, 1, 8); break;
+                case 4: MSTTS_PB(8, 1, 8); break;
+                case 5: MSTTS_PB(8, 1, 1); break;
+                default: MSTTS_PB(1, 1, 2); break;
+            }
+#undef MSTTS_PB
             MSTTS_CHECK_LAUNCH("lstm_point_bwd_fast");
             return MSTTS_OK;
         }

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
                                                           float* __restrict__ dq, float* __restrict__ h) {
     __shared__ float s_cum[TS + KS_MAX - 1];
     __shared__ __attribute__((aligned(16))) float s_g[TS][A_];
-    __shared__ __attribute__((aligned(16))) float s_lk[KS_MAX + 1][A_];
+    __shared__ __attribute__((aligned(16))) float s_lk[KS_MAX + 1][A_ + 4];   // +4: rows land on different 16-byte slots for the b128 reads
     __shared__ float s_de[TS];
     __shared__ float s_dq[A_];
     __shared__ float scratch[16];
@@ -330,6 +330,9 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
     }
     if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;      // entries past the KS-tap window are zero (cwin == 0 there)
     __syncthreads();
+    float lk[KS_MAX];
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) lk[j] = s_lk[j][k];
     float dq_acc = 0.f;
 #pragma unroll
     for (int i = 0; i < TS / 2; ++i) {
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
         if (t0 + tt < T) {
             float pre = kv[i] + qk;
 #pragma unroll
-            for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * s_lk[j][k];
+            for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * lk[j];
             const float u = fast_tanh(pre);
             g = s_de[tt] * wk * (1.f - u * u);
         }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     for (int it = 0; it < UNROLL; ++it) {
         wreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifndef SKINNY_PROBE_NO_WLOAD
-        if ((EXACT || it < nit) && col_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (long)(4 * it) * ldw));
+        if ((EXACT || it < nit) && col_ok) wreg[it] = *reinterpret_cast<const f32x4*>(wp + (long)(4 * it) * ldw);
 #else
         wreg[it] = (f32x4){(float)it, 1.f, 2.f, (float)lane};
 #endif
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int it = 0; it < UNROLL; ++it) {
         wreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if ((EXACT || it < nit) && row_ok) wreg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + 16 * it));
+        if ((EXACT || it < nit) && row_ok) wreg[it] = *reinterpret_cast<const f32x4*>(wp + 16 * it);
     }
     // 3) LDS writes of the slice (second round only when NL > 512)
 #pragma unroll

@@ -164,6 +164,15 @@ int mstts_lsa_energy_fwd(const mstts_lsa_const* c, const float* q, int32_t q_par
  * decoder can place it straight into the next step's GEMM input rows. */
 int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* energy, const float* cum, float* align, float* cum_next,
                           float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, mstts_stream_t s);
+/* Single-launch form of the two calls above (energies -> softmax -> cumulative alignment -> context): the
+ * workgroups of a row exchange their energy slices inside the launch through 8-byte {epoch,value} words in
+ * `granules` (mstts_lsa_step_ws_bytes(B,T) bytes, 8-byte aligned).  Zero that buffer (hipMemsetAsync) before the
+ * first step of a sequence and pass a distinct non-zero epoch per call (step + 1).  The word after the last
+ * granule counts workgroups that timed out waiting and recomputed an energy themselves (0 in normal operation). */
+int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T);
+int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                       const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                       void* granules, uint32_t epoch, mstts_stream_t s);
 /* backward of one step, two launches:
  *  dalign : G[t] = G_next[t] + sum_j h_next[t+pad-j][j] ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
  *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); h[t,j] = sum_k g[t,k] loc_k[j,k]
@@ -173,6 +182,15 @@ int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d
                          int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s);
 int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* align, const float* d_align, const float* q, const float* cum,
                           float* d_e, float* dq, float* d_f, mstts_stream_t s);
+/* Single-launch form of dalign + denergy (d_align stays on chip; the row-wide dot(a, d_a) is exchanged inside the launch
+ * through {epoch,value} words in `granules`: mstts_lsa_step_bwd_ws_bytes(B,T) bytes, zeroed before the first step of a
+ * sequence, distinct non-zero epoch per call).  A workgroup that times out waiting writes NaN and counts the event in
+ * the word after the last granule. */
+int64_t mstts_lsa_step_bwd_ws_bytes(int64_t B, int64_t T);
+int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
+                       int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
+                       const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
+                       void* granules, uint32_t epoch, mstts_stream_t s);
 /* post-loop parameter gradients over all S steps (recomputes tanh tiles from the saved d_e):
  * hist pointers are [S,B,*]; outputs accumulate (atomic): d_keys[B,T,A], d_loc_k[KS,A], d_score_w[A], d_score_b[A]
  * (d_loc_b equals d_score_b); unfold d_loc_k with mstts_lsa_unfold_location_grad. */
@@ -307,7 +325,7 @@ typedef struct {
     float* in0; float* in1; float* pj;
     float* c0; float* c1; float* acts0; float* acts1; float* craw0; float* craw1;
     float* q_hist; float* align_hist; float* cum_hist;
-    float* gates_ws; float* energy_ws;      /* [parts,B,4H] (parts = max skinny K-splits, see mstts_decoder_train_ws_floats), [B,T] */
+    float* gates_ws; float* energy_ws;      /* [parts,B,4H] (parts = max skinny K-splits, see mstts_decoder_train_ws_floats), 2*B*T+2 floats (8-byte aligned) */
     float* q_ws;                            /* [parts,B,A] query partials */
     int32_t chains;                         /* independent row groups run on separate HIP streams (0/1 = one; must divide B) */
 } mstts_decoder_train_desc;
@@ -347,7 +365,7 @@ typedef struct {
     float* in0; float* in1; float* pj;      /* [2,B,M+H], [2,B,2H], [B,H+M] */
     float* c0; float* c1;                   /* [2,B,H] */
     float* cum;                             /* [2,B,T] */
-    float* pre_ws;                          /* 2*B*P + B*4H + B*4H + B*T + B*A + B*(n_mel+1) floats */
+    float* pre_ws;                          /* mstts_decoder_infer_ws_floats(...) floats, 8-byte aligned */
     float* linear; float* stop; float* align_hist;
 } mstts_decoder_infer_desc;
 int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);

@@ -156,6 +156,12 @@ extern "C" int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream
 // ---------------------------------------------------------------------------------------------
 // teacher-forced decoder loop
 // ---------------------------------------------------------------------------------------------
+static bool lsa_fused_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MSTTS_LSA_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
 extern "C" int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q) {
     int p0 = mstts_skinny_fwd_splits(4 * H, M + H), p1 = mstts_skinny_fwd_splits(4 * H, 2 * H), pq = mstts_skinny_fwd_splits(A, H);
     int pg = p0 > p1 ? p0 : p1;
@@ -230,6 +236,8 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     RC(zero(d->c1, BH, s));
     RC(zero(d->cum_hist, B * T, s));
     const int chains = pick_chains(d);
+    const bool fused_lsa = lsa_fused_enabled() && chains == 1;         // (the time-out counter sits after the last row's granules)
+    if (fused_lsa) RC(zero(d->energy_ws, 2 * B * T + 2, s));           // granules + time-out counter of mstts_lsa_step_fwd
     const long Bc = B / chains;
     mstts_stream_t cs[MAX_CHAINS];
     RC(chain_fork(chains, s, cs));
@@ -277,9 +285,15 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             // ---- query (partials summed inside the energy kernel, which also saves q) + attention
             RC(xw_fwd(pj, WP, d->wq, A, qws, Bc, A, H, spq, &parts, q_s));
             const float* cum = d->cum_hist + (st * B + b0) * T;
-            PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_energy_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum, energy, q_s));
-            PROBED(MSTTS_PROBE_LSA_CONTEXT, q_s, mstts_lsa_context_fwd(&lc, energy, cum, d->align_hist + (st * B + b0) * T,
-                                     d->cum_hist + ((st + 1) * B + b0) * T, in0n, W0, pj + H, WP, q_s));
+            if (fused_lsa) {
+                PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_step_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum,
+                                         d->align_hist + (st * B + b0) * T, d->cum_hist + ((st + 1) * B + b0) * T, in0n, W0, pj + H, WP,
+                                         (unsigned long long*)d->energy_ws + b0 * T, (uint32_t)(st + 1), q_s));
+            } else {
+                PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_energy_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum, energy, q_s));
+                PROBED(MSTTS_PROBE_LSA_CONTEXT, q_s, mstts_lsa_context_fwd(&lc, energy, cum, d->align_hist + (st * B + b0) * T,
+                                         d->cum_hist + ((st + 1) * B + b0) * T, in0n, W0, pj + H, WP, q_s));
+            }
         }
     }
     RC(chain_join(chains, s));
@@ -310,6 +324,8 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     const int chains = pick_chains(d);
     const long Bc = B / chains, BcH = Bc * H, BcT = Bc * T;
     const long ws_per_row = 8 * H + 2 * T + 2 * T * CH + T + (long)np1 * W1 + (long)npq * H;
+    // single-launch attention backward: its granules (B*ceil(T/8)+1 8-byte words) live in the d_align block (B*T floats)
+    const bool fused_lsa = lsa_fused_enabled() && chains == 1 && mstts_lsa_step_bwd_ws_bytes(B, T) <= B * T * 4;
     RC(zero(bd->ws, ws_per_row * B, s));
     mstts_stream_t cs[MAX_CHAINS];
     RC(chain_fork(chains, s, cs));
@@ -342,10 +358,17 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
             float* dpj = bd->d_pj + (st * B + b0) * WP;
             const float* d_in0_next = last ? nullptr : bd->d_in0 + ((st + 1) * B + b0) * W0;
             // ---- attention backward
-            PROBED(MSTTS_PROBE_LSA_DALIGN, q_s, mstts_lsa_dalign_bwd(&lc, dpj + H, WP, d_in0_next, W0, k.parts0, d_in0_slab,
-                                    last ? nullptr : k.G[cur], last ? nullptr : k.df[cur], k.G[nxt], k.d_align, q_s));
-            PROBED(MSTTS_PROBE_LSA_DENERGY, q_s, mstts_lsa_denergy_bwd(&lc, d->align_hist + (st * B + b0) * T, k.d_align, d->q_hist + (st * B + b0) * A,
-                                     d->cum_hist + (st * B + b0) * T, bd->de_hist + (st * B + b0) * T, bd->dq_hist + (st * B + b0) * A, k.df[nxt], q_s));
+            if (fused_lsa) {        // d_align stays on chip; its workspace row block holds the exchange granules instead
+                PROBED(MSTTS_PROBE_LSA_DALIGN, q_s, mstts_lsa_step_bwd(&lc, dpj + H, WP, d_in0_next, W0, k.parts0, d_in0_slab,
+                                        last ? nullptr : k.G[cur], last ? nullptr : k.df[cur], k.G[nxt], d->align_hist + (st * B + b0) * T,
+                                        d->q_hist + (st * B + b0) * A, d->cum_hist + (st * B + b0) * T, bd->de_hist + (st * B + b0) * T,
+                                        bd->dq_hist + (st * B + b0) * A, k.df[nxt], k.d_align, (uint32_t)(st + 1), q_s));
+            } else {
+                PROBED(MSTTS_PROBE_LSA_DALIGN, q_s, mstts_lsa_dalign_bwd(&lc, dpj + H, WP, d_in0_next, W0, k.parts0, d_in0_slab,
+                                        last ? nullptr : k.G[cur], last ? nullptr : k.df[cur], k.G[nxt], k.d_align, q_s));
+                PROBED(MSTTS_PROBE_LSA_DENERGY, q_s, mstts_lsa_denergy_bwd(&lc, d->align_hist + (st * B + b0) * T, k.d_align, d->q_hist + (st * B + b0) * A,
+                                         d->cum_hist + (st * B + b0) * T, bd->de_hist + (st * B + b0) * T, bd->dq_hist + (st * B + b0) * A, k.df[nxt], q_s));
+            }
             // d_m1 (query path) = dq . Wq^T  -> slabs consumed by the cell-1 pointwise kernel
             RC(xw_bwd(bd->dq_hist + (st * B + b0) * A, A, d->wq, A, k.dqm, 0, Bc, H, A, spq, &k.partsq, q_s));
             // ---- cell 1 backward
@@ -390,7 +413,7 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
 // free-running decoder steps
 // ---------------------------------------------------------------------------------------------
 extern "C" int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel) {
-    return 2 * B * P + 8 * B * H + B * T + B * A + B * n_mel;
+    return 2 * B * P + 8 * B * H + (2 * B * T + 2) + B * A + B * n_mel;
 }
 
 extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s) {
@@ -400,12 +423,13 @@ extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int6
     MSTTS_REQUIRE(step0 >= 0 && step0 + n <= d->Smax, MSTTS_ERR_SHAPE, "decoder_infer_steps: step range exceeds Smax");
     const long B = d->B, H = d->H, P = d->P, NM = d->n_mel, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
     const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M, BT = B * T;
+    const bool fused_lsa = lsa_fused_enabled();
     float* w = d->pre_ws;
     float* pa = w;          w += B * P;
     float* pb = w;          w += B * P;
     float* xw = w;          w += 4 * BH;
     float* gates = w;       w += 4 * BH;
-    float* energy = w;      w += BT;
+    float* energy = w;      w += 2 * BT + 2;          // energies, or the 8-byte granules (+ counter) of the single-launch step
     float* q = w;           w += B * A;
     float* zero_frame = w;  w += B * NM;
     if (step0 == 0) {
@@ -415,6 +439,7 @@ extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int6
         RC(zero(d->c1, BH, s));
         RC(zero(d->cum, BT, s));
         RC(zero(zero_frame, B * NM, s));
+        if (fused_lsa) RC(zero(energy, 2 * BT + 2, s));
     }
     for (long st = step0; st < step0 + n; ++st) {
         const int par = (int)(st & 1), nx = par ^ 1;
@@ -444,9 +469,14 @@ extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int6
         RC(mstts_lstm_point_fwd(&p, s));
         // attention
         RC(gemm(d->pj, WP, d->wq, A, 0, q, A, B, A, H, nullptr, 0, 0, s));
-        RC(mstts_lsa_energy_fwd(&d->lsa, q, 1, 0, nullptr, d->cum + par * BT, energy, s));
-        RC(mstts_lsa_context_fwd(&d->lsa, energy, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
-                                 in0n, W0, d->pj + H, WP, s));
+        if (fused_lsa) {
+            RC(mstts_lsa_step_fwd(&d->lsa, q, 1, 0, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
+                                  in0n, W0, d->pj + H, WP, energy, (uint32_t)(st + 1), s));
+        } else {
+            RC(mstts_lsa_energy_fwd(&d->lsa, q, 1, 0, nullptr, d->cum + par * BT, energy, s));
+            RC(mstts_lsa_context_fwd(&d->lsa, energy, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
+                                     in0n, W0, d->pj + H, WP, s));
+        }
         // projection: [m1 | ctx] . Wp + b -> linear (n_mel) and stop (1)
         RC(gemm(d->pj, WP, d->wproj, NM + 1, 0, d->linear + st * B * NM, NM, B, NM, WP, d->bproj, 0, 0, s));
         RC(gemm(d->pj, WP, d->wproj + NM, NM + 1, 0, d->stop + st * B, 1, B, 1, WP, d->bproj ? d->bproj + NM : nullptr, 0, 0, s));

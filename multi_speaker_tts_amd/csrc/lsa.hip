@@ -175,6 +175,178 @@ __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, single launch: energies -> (in-launch exchange) -> softmax -> cumulative alignment -> context.
+//
+// grid (CS, B): the CS workgroups of a row have adjacent block ids, so a row is dispatched together and the
+// rows ahead of it are complete rows (no workgroup ever waits on one that cannot become resident).  Workgroup
+// cs computes the energies of its own slice of <= 16 encoder positions, publishes them as 8-byte {epoch, value}
+// granules with relaxed agent-scope (write-through, sc1) stores, and gathers the rest of the row with relaxed
+// agent-scope loads until every tag equals this launch's epoch - the data is the flag, no fence, no counter
+// (MI355X hand-off form R2).  Then every workgroup runs the same T-float softmax and streams its own
+// column slice of values[b].  The caller zeroes the granule buffer once per sequence and passes epoch =
+// step + 1.  Every spin is bounded: a workgroup that gives up recomputes the missing energy itself
+// (serially, slow but correct) and counts the event in the word after the last granule, so a launch can
+// neither hang nor return a stale value.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr int FS_THREADS = 512;
+constexpr int FS_TSL = 16;        // encoder positions per workgroup (energy slice)
+constexpr int FS_DSL = 96;        // memory columns per workgroup (context slice), at most
+constexpr int FS_VPRE = 7;        // value rows per thread preloaded ahead of the exchange
+constexpr unsigned FS_MAX_SPINS = 200000;
+
+__device__ __forceinline__ float lsa_energy_serial(const mstts_lsa_const& c, const float* q, int q_parts, long q_pstride,
+                                                const float* cum, int b, int t) {
+    const int T = (int)c.T, KS = (int)c.KS, pad = (KS - 1) / 2;
+    float e = 0.f;
+    for (int k = 0; k < A_; ++k) {
+        float pre = c.keys[((long)b * T + t) * A_ + k] + c.score_b[k] + c.loc_b[k];
+        for (int pp = 0; pp < q_parts; ++pp) pre += q[pp * q_pstride + (long)b * A_ + k];
+        for (int j = 0; j < KS; ++j) {
+            const int tau = t + j - pad;
+            if (tau >= 0 && tau < T) pre += cum[(long)b * T + tau] * c.loc_k[j * A_ + k];
+        }
+        e += c.score_w[k] * fast_tanh(pre);
+    }
+    return e;
+}
+
+__global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
+                                                              float* __restrict__ q_sum, const float* cum,
+                                                              float* __restrict__ align, float* __restrict__ cum_next,
+                                                              float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld,
+                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int dbg) {
+    __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
+    __shared__ float s_red[FS_TSL][2];
+    __shared__ float s_e[T_MAX];
+    __shared__ __attribute__((aligned(16))) float s_part[FS_THREADS * 4];
+    const int cs = blockIdx.x, b = blockIdx.y, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
+    const int t0 = cs * tsl, d0 = cs * dsl;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = tid & (A_ - 1), tg = tid >> 7;                // energy role: unit k, positions t0 + 4*tg + {0..3}
+    const int nc4 = dsl >> 2, ng = FS_THREADS / nc4;             // context role: float4 column c4, row group vg
+    const int c4 = tid % nc4, vg = tid / nc4;
+    const int col = d0 + c4 * 4;
+    const bool vlive = vg < ng && col < M && c4 * 4 < dsl;
+    const int len = c.lengths ? c.lengths[b] : T;
+    // ---- every global load of the first phase, issued back to back
+    float cwin = 0.f;
+    if (tid < tsl + KS - 1) {
+        const int t = t0 - pad + tid;
+        if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
+    }
+    float lk[KS_MAX];
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) lk[j] = (j < KS) ? c.loc_k[j * A_ + k] : 0.f;
+    float kv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tl = 4 * tg + i;
+        kv[i] = (tl < tsl && t0 + tl < T) ? c.keys[((long)b * T + t0 + tl) * A_ + k] : 0.f;
+    }
+    const float qv = sum_parts<MSTTS_MAX_PARTS>(q, q_parts, q_pstride, (long)b * A_ + k);
+    const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
+    const float* v = c.values + (long)b * T * M + col;
+    float4 vv[FS_VPRE];
+#pragma unroll
+    for (int i = 0; i < FS_VPRE; ++i) {
+        const int t = vg + ng * i;
+        vv[i] = (vlive && t < len && !(dbg & 1)) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- own energy slice
+    if (tid < FS_TSL + KS_MAX - 1 + 2) s_cum[tid] = cwin;          // entries past the window are zero
+    if (q_sum && cs == 0 && tg == 0) q_sum[(long)b * A_ + k] = qv;
+    __syncthreads();
+    {
+        float cw[4 + KS_MAX - 1];
+#pragma unroll
+        for (int i = 0; i < 4 + KS_MAX - 1; ++i) cw[i] = s_cum[4 * tg + i];
+        const float qk = qv + sb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float pre = kv[i] + qk;
+#pragma unroll
+            for (int j = 0; j < KS_MAX; ++j) pre += cw[i + j] * lk[j];
+            float e = wave_sum(wk * fast_tanh(pre));
+            if (lane == 0) s_red[4 * tg + i][(tid >> 6) & 1] = e;
+        }
+    }
+    __syncthreads();
+    gu64* g = (gu64*)(gran + (long)b * T);
+    if (tid < tsl && t0 + tid < T) {
+        const float e = s_red[tid][0] + s_red[tid][1];
+        s_e[t0 + tid] = e;
+        __hip_atomic_store(g + t0 + tid, ((unsigned long long)epoch << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- gather the other slices of the row (the data is the flag)
+    for (int t = tid; t < T; t += FS_THREADS) {
+        if (t >= t0 && t < t0 + tsl) continue;
+        if (dbg & 2) { s_e[t] = 0.f; continue; }
+        unsigned long long x = __hip_atomic_load(g + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
+            __builtin_amdgcn_s_sleep(1);
+            x = __hip_atomic_load(g + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++spins;
+        }
+        float e;
+        if ((unsigned)(x >> 32) == epoch) e = __uint_as_float((unsigned)x);
+        else {
+            e = lsa_energy_serial(c, q, q_parts, q_pstride, cum, b, t);
+            atomicAdd(gran + (long)c.B * T, 1ull);
+        }
+        s_e[t] = e;
+    }
+    __syncthreads();
+    if (dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < FS_VPRE; ++i) {
+            const int t = vg + ng * i;
+            if (vlive && t < len) vv[i] = *reinterpret_cast<const float4*>(v + (long)t * M);
+        }
+    }
+    // ---- softmax statistics, redundantly per wave (no further block-wide reduction)
+    float mx = -INFINITY;
+    for (int t = lane; t < len; t += 64) mx = fmaxf(mx, s_e[t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < len; t += 64) sum += __expf(s_e[t] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    if (tid < tsl && t0 + tid < T) {
+        const int t = t0 + tid;
+        const float a = (t < len) ? __expf(s_e[t] - mx) * inv : 0.f;
+        align[(long)b * T + t] = a;
+        cum_next[(long)b * T + t] = s_cum[pad + tid] + a;
+    }
+    // ---- context slice
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < FS_VPRE; ++i) {
+        const int t = vg + ng * i;
+        if (vlive && t < len) {
+            const float a = __expf(s_e[t] - mx) * inv;
+            acc.x += a * vv[i].x; acc.y += a * vv[i].y; acc.z += a * vv[i].z; acc.w += a * vv[i].w;
+        }
+    }
+    if (vlive) {
+        for (int t = vg + ng * FS_VPRE; t < len; t += ng) {
+            const float a = __expf(s_e[t] - mx) * inv;
+            const float4 x = *reinterpret_cast<const float4*>(v + (long)t * M);
+            acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w;
+        }
+    }
+    if (vg < ng) *reinterpret_cast<float4*>(&s_part[(vg * nc4 + c4) * 4]) = acc;
+    __syncthreads();
+    if (tid < dsl && d0 + tid < M) {
+        float r = 0.f;
+        for (int gq = 0; gq < ng; ++gq) r += s_part[gq * dsl + tid];
+        ctx[(long)b * ctx_ld + d0 + tid] = r;
+        if (ctx2) ctx2[(long)b * ctx2_ld + d0 + tid] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward: d_align.  G = dL/d cum_{s+1} = G_next + filter^T applied to the next step's energy gradient,
 // which the denergy kernel of step s+1 left as h_next[b,t,j] = sum_k g[t,k] loc_k[j,k]:
 //     G[t] = G_next[t] + sum_j h_next[t + pad - j][j]
@@ -368,6 +540,209 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, single launch: the two kernels above in one, grid (T/TS, B) so that the workgroups of a row have adjacent
+// block ids.  The only quantity a workgroup needs from the rest of its row is the softmax-backward scalar
+// dot(a, d_a); each workgroup publishes its slice's partial as ONE {epoch,value} granule right after the d_align
+// phase, recomputes its tanh terms while the granules travel, then gathers the T/TS partials (relaxed agent-scope
+// loads, bounded spin).  d_align never goes to memory.  A workgroup that times out poisons its outputs with NaN and
+// counts the event in the word after the last granule (fails loudly, never hangs).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, const float* __restrict__ d_ctx, long d_ctx_ld,
+                                                           const float* __restrict__ d_ctx2, long d_ctx2_ld, int d_ctx2_parts, long d_ctx2_pstride,
+                                                           const float* __restrict__ G_next, const float* __restrict__ h_next, float* __restrict__ G,
+                                                           const float* __restrict__ align, const float* __restrict__ q, const float* __restrict__ cum,
+                                                           float* __restrict__ d_e_out, float* __restrict__ dq, float* __restrict__ h,
+                                                           unsigned long long* gran, unsigned epoch) {
+    __shared__ float s_gG[TS];
+    __shared__ float s_da[TS];
+    __shared__ float s_cum[TS + KS_MAX - 1];
+    __shared__ __attribute__((aligned(16))) float s_g[TS][A_];
+    __shared__ __attribute__((aligned(16))) float s_lk[KS_MAX + 1][A_ + 4];
+    __shared__ float s_de[TS];
+    __shared__ float s_dq[A_];
+    __shared__ float scratch[16];
+    const int sl = blockIdx.x, b = blockIdx.y, t0 = sl * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
+    const int nsl = gridDim.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
+    const int len = c.lengths ? c.lengths[b] : T;
+    // ---- every global load, back to back: d_align phase ...
+    constexpr int LPR = 256 / TS;
+    const int tt_h = threadIdx.x / LPR, jh = threadIdx.x % LPR;
+    float hv = 0.f;
+    if (h_next && jh < KS) {
+        const int tau = t0 + tt_h + pad - jh;
+        if (tau >= 0 && tau < T) hv = h_next[((long)b * T + tau) * HLD + jh];
+    }
+    float gn = 0.f;
+    if (threadIdx.x < TS && G_next && t0 + threadIdx.x < T) gn = G_next[(long)b * T + t0 + threadIdx.x];
+    float4 dcv[MROW], val[TS / 4][MROW];
+    const float* dc = d_ctx + (long)b * d_ctx_ld;
+#pragma unroll
+    for (int m = 0; m < MROW; ++m) {
+        const int i = lane * 4 + 256 * m;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < M) {
+            y = *reinterpret_cast<const float4*>(dc + i);
+            if (d_ctx2) {
+                float4 y2[8];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp)
+                    y2[pp] = (pp == 0 || pp < d_ctx2_parts) ? *reinterpret_cast<const float4*>(d_ctx2 + pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) { y.x += y2[pp].x; y.y += y2[pp].y; y.z += y2[pp].z; y.w += y2[pp].w; }
+            }
+        }
+        dcv[m] = y;
+    }
+#pragma unroll
+    for (int r = 0; r < TS / 4; ++r) {
+        const int t = t0 + w + 4 * r;
+#pragma unroll
+        for (int m = 0; m < MROW; ++m) {
+            const int i = lane * 4 + 256 * m;
+            val[r][m] = (t < len && i < M) ? *reinterpret_cast<const float4*>(c.values + ((long)b * T + t) * M + i)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // ---- ... and d_energy phase
+    float a_own = 0.f;
+    if (threadIdx.x < TS && t0 + threadIdx.x < T) a_own = align[(long)b * T + t0 + threadIdx.x];
+    float cwin = 0.f;
+    if (threadIdx.x < TS + KS - 1) {
+        const int t = t0 - pad + threadIdx.x;
+        if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
+    }
+    constexpr int NLK = (KS_MAX * A_ + 255) / 256;
+    float lkv[NLK];
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        lkv[i] = (e < KS * A_) ? c.loc_k[e] : 0.f;
+    }
+    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+    float kv[TS / 2];
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
+    const float qk = q[(long)b * A_ + k] + c.score_b[k] + c.loc_b[k];
+    const float wk = c.score_w[k];
+    // ---- G for the TS rows, then d_align = G + values . d_ctx (kept in LDS)
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) hv += __shfl_xor(hv, o, 64);
+    if (jh == 0) s_gG[tt_h] = hv;
+    __syncthreads();
+    if (threadIdx.x < TS) s_gG[threadIdx.x] += gn;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TS / 4; ++r) {
+        const int tt = w + 4 * r, t = t0 + tt;
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < MROW; ++m)
+            acc += val[r][m].x * dcv[m].x + val[r][m].y * dcv[m].y + val[r][m].z * dcv[m].z + val[r][m].w * dcv[m].w;
+        if (t < len) {
+            for (int i = lane * 4 + 256 * MROW; i < M; i += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(c.values + ((long)b * T + t) * M + i);
+                float4 y = *reinterpret_cast<const float4*>(dc + i);
+                if (d_ctx2)
+                    for (int pp = 0; pp < max(d_ctx2_parts, 1); ++pp) {
+                        const float4 y2 = *reinterpret_cast<const float4*>(d_ctx2 + pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i);
+                        y.x += y2.x; y.y += y2.y; y.z += y2.z; y.w += y2.w;
+                    }
+                acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float g = s_gG[tt];
+            if (t < T) G[(long)b * T + t] = g;
+            s_da[tt] = (t < T) ? g + acc : 0.f;
+        }
+    }
+    // stage the filter / window for the tanh recompute while the last wave finishes
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < KS_MAX * A_) s_lk[e / A_][e % A_] = lkv[i];
+    }
+    if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;
+    __syncthreads();
+    // ---- publish this slice's part of dot(a, d_a)
+    gu64* g64 = (gu64*)(gran + (long)b * nsl);
+    float p_own = 0.f;
+    if (w == 0) {
+        p_own = (lane < TS) ? a_own * s_da[lane] : 0.f;
+#pragma unroll
+        for (int o = TS / 2; o > 0; o >>= 1) p_own += __shfl_xor(p_own, o, 64);
+        if (lane == 0)
+            __hip_atomic_store(g64 + sl, ((unsigned long long)epoch << 32) | __float_as_uint(p_own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- tanh terms (independent of the dot) while the granules travel
+    float lk[KS_MAX];
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) lk[j] = s_lk[j][k];
+    float fac[TS / 2];
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) {
+        const int tt = grp + 2 * i;
+        float pre = kv[i] + qk;
+#pragma unroll
+        for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * lk[j];
+        const float u = fast_tanh(pre);
+        fac[i] = (t0 + tt < T) ? wk * (1.f - u * u) : 0.f;
+    }
+    // ---- gather the row's partials
+    float part = 0.f;
+    if (threadIdx.x < nsl && threadIdx.x != sl) {             // nsl <= T_MAX / TS = 128
+        {
+            unsigned long long x = __hip_atomic_load(g64 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
+                __builtin_amdgcn_s_sleep(1);
+                x = __hip_atomic_load(g64 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++spins;
+            }
+            if ((unsigned)(x >> 32) == epoch) part = __uint_as_float((unsigned)x);
+            else { part = __builtin_nanf(""); atomicAdd(gran + (long)c.B * nsl, 1ull); }
+        }
+    }
+    if (threadIdx.x == 0) part += p_own;                      // thread 0 is lane 0 of wave 0: holds the own partial
+    const float dot = block_sum(part, scratch);
+    if (threadIdx.x < TS) {
+        const int t = t0 + threadIdx.x;
+        const float de = (t < T) ? a_own * (s_da[threadIdx.x] - dot) : 0.f;
+        if (t < T) d_e_out[(long)b * T + t] = de;
+        s_de[threadIdx.x] = de;
+    }
+    __syncthreads();
+    float dq_acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) {
+        const int tt = grp + 2 * i;
+        const float g = s_de[tt] * fac[i];
+        s_g[tt][k] = g;
+        dq_acc += g;
+    }
+    if (grp == 1) s_dq[k] = dq_acc;
+    __syncthreads();
+    if (grp == 0) atomicAdd(dq + (long)b * A_ + k, dq_acc + s_dq[k]);
+    {
+        const int tt = threadIdx.x >> 5, j = threadIdx.x & 31;
+        float acc = 0.f;
+        if (j < KS) {
+#pragma unroll 8
+            for (int kk = 0; kk < A_; kk += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(&s_g[tt][kk]);
+                const float4 l4 = *reinterpret_cast<const float4*>(&s_lk[j][kk]);
+                acc += g4.x * l4.x + g4.y * l4.y + g4.z * l4.z + g4.w * l4.w;
+            }
+        }
+        if (t0 + tt < T) h[((long)b * T + t0 + tt) * HLD + j] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // post-loop parameter gradients (recompute g per step from saved d_e, q, cum):
 //   d_keys[b,t,k] += g ; d_loc_k[j,k] += cum[t+j-pad] g ; d_score_w[k] += d_e u ; d_score_b[k] += g
 // (d_loc_b == d_score_b: both biases add to the same pre-activation)
@@ -474,6 +849,29 @@ extern "C" int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* ener
     MSTTS_CHECK_LAUNCH("lsa_context_fwd");
     return MSTTS_OK;
 }
+static void lsa_step_geometry(long T, long M, int* cs, int* tsl, int* dsl) {
+    long n = cdiv(T, FS_TSL);
+    const long nm = cdiv(M, FS_DSL);
+    if (nm > n) n = nm;
+    *cs = (int)n;
+    *tsl = (int)cdiv(T, n);
+    *dsl = (int)(cdiv(cdiv(M, n), 4) * 4);
+}
+extern "C" int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T) { return (B * T + 1) * 8; }
+extern "C" int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                                  const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                                  void* granules, uint32_t epoch, mstts_stream_t s) {
+    int rc = check_const(c); if (rc) return rc;
+    MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_fwd: granule buffer (8-byte aligned) and a non-zero epoch required");
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("MSTTS_LSA_STEP_DEBUG"); dbg = e ? atoi(e) : 0; }
+    int cs, tsl, dsl;
+    lsa_step_geometry(c->T, c->M, &cs, &tsl, &dsl);
+    hipLaunchKernelGGL(lsa_step_kernel, dim3((unsigned)cs, (unsigned)c->B), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
+                       align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, dbg);
+    MSTTS_CHECK_LAUNCH("lsa_step_fwd");
+    return MSTTS_OK;
+}
 extern "C" int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
                                     int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
@@ -489,6 +887,21 @@ extern "C" int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* alig
     int rc = check_const(c); if (rc) return rc;
     hipLaunchKernelGGL(lsa_denergy_kernel, dim3((unsigned)c->B, cdiv(c->T, TS)), dim3(256), 0, ST(s), *c, align, d_align, q, cum, d_e, dq, d_f);
     MSTTS_CHECK_LAUNCH("lsa_denergy_bwd");
+    return MSTTS_OK;
+}
+extern "C" int64_t mstts_lsa_step_bwd_ws_bytes(int64_t B, int64_t T) { return (B * cdiv(T, TS) + 1) * 8; }
+extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
+                                  int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
+                                  const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
+                                  void* granules, uint32_t epoch, mstts_stream_t s) {
+    int rc = check_const(c); if (rc) return rc;
+    MSTTS_REQUIRE(aligned16(d_ctx) && aligned16(d_ctx2) && d_ctx_ld % 4 == 0 && d_ctx2_ld % 4 == 0, MSTTS_ERR_ALIGN,
+                  "lsa_step_bwd: d_ctx rows must be 16-byte aligned");
+    MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_bwd: granule buffer (8-byte aligned) and a non-zero epoch required");
+    hipLaunchKernelGGL(lsa_step_bwd_kernel, dim3(cdiv(c->T, TS), (unsigned)c->B), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
+                       (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
+                       (unsigned long long*)granules, (unsigned)epoch);
+    MSTTS_CHECK_LAUNCH("lsa_step_bwd");
     return MSTTS_OK;
 }
 extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,

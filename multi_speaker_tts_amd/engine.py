@@ -135,7 +135,7 @@ class TrainEngine:
         lb = lib.load()
         ng, nq = C.c_int64(0), C.c_int64(0)
         lb.mstts_decoder_train_ws_floats(B, H, M, A, C.byref(ng), C.byref(nq))
-        w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(B, Te), f(int(nq.value))
+        w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(2 * B * Te + 4), f(int(nq.value))
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
         # postnet

@@ -54,7 +54,7 @@ def test_lstm_point_fwd_bwd(dev):
     assert rel_err(t2n(dcp), t2n(cp64.grad)) < 2e-5 and rel_err(t2n(dhp), t2n(hp64.grad)) < 2e-5
 
 
-@pytest.mark.parametrize("B,T,M,KS", [(3, 37, 48, 31), (2, 128, 768, 31), (1, 16, 16, 5)])
+@pytest.mark.parametrize("B,T,M,KS", [(3, 37, 48, 31), (2, 128, 768, 31), (1, 16, 16, 5), (4, 300, 768, 31), (33, 128, 100, 7)])
 def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     """One attention step (energy+context kernels, dalign+denergy kernels) vs the oracle's lsa_step."""
     A, CH, Hq = 128, 32, 40
@@ -91,6 +91,16 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     lib.call("mstts_lsa_energy_fwd", C.byref(c), lib.ptr(q), 1, 0, None, lib.ptr(dcum), lib.ptr(en))
     lib.call("mstts_lsa_context_fwd", C.byref(c), lib.ptr(en), lib.ptr(dcum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0)
     assert rel_err(t2n(al), t2n(align)) < 2e-5 and rel_err(t2n(cn), t2n(cum_next)) < 2e-5 and rel_err(t2n(cx), t2n(ctx)) < 2e-5
+    # single-launch form (in-launch energy exchange): same outputs, written straight into strided rows
+    gran = torch.zeros(int(lib.load().mstts_lsa_step_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    al2, cn2, cx2, cx3 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M + 4, device=dev), torch.zeros(B, M, device=dev)
+    qs = torch.zeros(B, A, device=dev)
+    q3 = torch.stack([0.25 * q, 0.5 * q, 0.25 * q]).contiguous()            # the query arrives as split-K partial slabs
+    lib.call("mstts_lsa_step_fwd", C.byref(c), lib.ptr(q3), 3, B * A, lib.ptr(qs), lib.ptr(dcum), lib.ptr(al2), lib.ptr(cn2),
+             lib.ptr(cx2), M + 4, lib.ptr(cx3), M, lib.ptr(gran), 7)
+    assert rel_err(t2n(al2), t2n(align)) < 2e-5 and rel_err(t2n(cn2), t2n(cum_next)) < 2e-5 and rel_err(t2n(cx2[:, :M]), t2n(ctx)) < 2e-5
+    assert torch.equal(cx2[:, :M], cx3) and float(cx2[:, M:].abs().max()) == 0.0 and rel_err(t2n(qs), t2n(q)) < 1e-6
+    assert int(gran[-1]) == 0 and bool(((gran[:B * T] >> 32) == 7).all())      # no time-outs; every granule carries this epoch
     # backward: upstream grads on ctx and on the next cumulative state.  The latter arrives as G_next plus the
     # filter-transpose of the next step's h (G[t] = G_next[t] + sum_j h_next[t+pad-j][j]).
     pad = (KS - 1) // 2
@@ -109,6 +119,13 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     assert rel_err(t2n(G), G_ref) < 2e-5
     de, dq, hh = torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, 32, device=dev)
     lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al), lib.ptr(da), lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dq), lib.ptr(hh))
+    # single-launch form of the two calls above (row-wide dot(a, d_a) exchanged inside the launch)
+    G2, de2, dq2, hh2 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, 32, device=dev)
+    granb = torch.zeros(int(lib.load().mstts_lsa_step_bwd_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    lib.call("mstts_lsa_step_bwd", C.byref(c), lib.ptr(d_ctx_d), M, None, 0, 0, 0, lib.ptr(G_next_d), lib.ptr(h_next_d), lib.ptr(G2),
+             lib.ptr(al), lib.ptr(q), lib.ptr(dcum), lib.ptr(de2), lib.ptr(dq2), lib.ptr(hh2), lib.ptr(granb), 3)
+    assert torch.equal(G2, G) and int(granb[-1]) == 0
+    assert rel_err(t2n(de2), t2n(de)) < 1e-5 and rel_err(t2n(dq2), t2n(dq)) < 1e-5 and rel_err(t2n(hh2), t2n(hh)) < 1e-5
     dquery = t2n(dq).astype(np.float64) @ p[LSA + "query_layer/kernel"].T
     assert rel_err(dquery, t2n(qt.grad)) < 5e-5
     # grad wrt cum = G (carried) + filter-transpose of h
@@ -134,6 +151,67 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     assert rel_err(t2n(gb), t2n(pt[LSA + "attention_convolution_dense_layer/conv1d/bias"].grad)) < 1e-4
     # d_values from the context: outer(align, d_ctx)
     assert rel_err(t2n(al)[:, :, None] * d_ctx[:, None, :], t2n(vt.grad)) < 5e-5
+
+
+def test_lsa_step_exchange_under_load(dev):
+    """The in-launch energy exchange of mstts_lsa_step_fwd over 300 consecutive epochs with a different query each
+    epoch and a weight-streaming kernel interleaved (uneven load, warm L1/L2): every epoch must equal the two-launch
+    form on the same inputs (a stale or torn granule would show up as the previous epoch's energies) and no
+    workgroup may time out."""
+    B, T, M, A, CH, KS, N = 32, 128, 768, 128, 32, 31, 300
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dev).contiguous()
+    keys, values = rn(B, T, A), rn(B, T, M)
+    conv_k, conv_b, dense_k, sw, sb_ = rn(KS, 1, CH, sc=0.3), rn(CH, sc=0.1), rn(CH, A, sc=0.3), rn(A, sc=0.5), rn(A, sc=0.1)
+    loc_k, loc_b = torch.zeros(KS, A, device=dev), torch.zeros(A, device=dev)
+    c = lib.LsaConst()
+    c.B, c.T, c.A, c.M, c.KS, c.CH = B, T, A, M, KS, CH
+    c.keys, c.values, c.lengths = lib.ptr(keys), lib.ptr(values), None
+    c.conv_k, c.conv_b, c.dense_k, c.score_w, c.score_b = lib.ptr(conv_k), lib.ptr(conv_b), lib.ptr(dense_k), lib.ptr(sw), lib.ptr(sb_)
+    lib.call("mstts_lsa_fold_location", c.conv_k, c.conv_b, c.dense_k, lib.ptr(loc_k), lib.ptr(loc_b), KS, CH, A)
+    c.loc_k, c.loc_b = lib.ptr(loc_k), lib.ptr(loc_b)
+    qs = rn(N, B, A)
+    cum = torch.zeros(N + 1, B, T, device=dev); cum_r = torch.zeros(N + 1, B, T, device=dev)
+    al, al_r = torch.zeros(N, B, T, device=dev), torch.zeros(N, B, T, device=dev)
+    cx, cx_r = torch.zeros(N, B, M, device=dev), torch.zeros(N, B, M, device=dev)
+    en = torch.zeros(B, T, device=dev)
+    gran = torch.zeros(B * T + 1, dtype=torch.int64, device=dev)
+    X, W, Pw = rn(32, 1024, sc=0.1), rn(1024, 4096, sc=0.05), torch.zeros(16 * 32 * 4096, device=dev)
+    for e in range(N):
+        lib.call("mstts_lsa_step_fwd", C.byref(c), lib.ptr(qs[e]), 1, 0, None, lib.ptr(cum[e]), lib.ptr(al[e]), lib.ptr(cum[e + 1]),
+                 lib.ptr(cx[e]), M, None, 0, lib.ptr(gran), e + 1)
+        if e % 3 != 2:      # uneven load between the steps
+            lib.call("mstts_skinny_fwd", lib.ptr(X), 1024, lib.ptr(W), 4096, lib.ptr(Pw), 0, 32, 4096, 1024, 4)
+    for e in range(N):
+        # same inputs per epoch (the recurrence through cum would amplify rounding differences over 300 steps)
+        lib.call("mstts_lsa_energy_fwd", C.byref(c), lib.ptr(qs[e]), 1, 0, None, lib.ptr(cum[e]), lib.ptr(en))
+        lib.call("mstts_lsa_context_fwd", C.byref(c), lib.ptr(en), lib.ptr(cum[e]), lib.ptr(al_r[e]), lib.ptr(cum_r[e + 1]), lib.ptr(cx_r[e]), M, None, 0)
+    torch.cuda.synchronize()
+    assert int(gran[-1]) == 0
+    worst = max(rel_err(t2n(al[e]), t2n(al_r[e])) for e in range(N))
+    assert worst < 1e-4, worst
+    assert rel_err(t2n(cx), t2n(cx_r)) < 1e-4 and rel_err(t2n(cum[1:]), t2n(cum_r[1:])) < 1e-4
+    # backward exchange, same regime: a different upstream gradient every epoch
+    dctx = rn(N, B, M); Gn, hn = rn(B, T), rn(B, T, 32)
+    G1, G2 = torch.zeros(B, T, device=dev), torch.zeros(N, B, T, device=dev)
+    da = torch.zeros(B, T, device=dev)
+    de1, de2 = torch.zeros(N, B, T, device=dev), torch.zeros(N, B, T, device=dev)
+    dq1, dq2 = torch.zeros(N, B, A, device=dev), torch.zeros(N, B, A, device=dev)
+    h1, h2 = torch.zeros(N, B, T, 32, device=dev), torch.zeros(N, B, T, 32, device=dev)
+    granb = torch.zeros(B * (T // 8) + 1, dtype=torch.int64, device=dev)
+    for e in range(N):
+        lib.call("mstts_lsa_step_bwd", C.byref(c), lib.ptr(dctx[e]), M, None, 0, 0, 0, lib.ptr(Gn), lib.ptr(hn), lib.ptr(G2[e]),
+                 lib.ptr(al[e]), lib.ptr(qs[e]), lib.ptr(cum[e]), lib.ptr(de2[e]), lib.ptr(dq2[e]), lib.ptr(h2[e]), lib.ptr(granb), e + 1)
+        if e % 3 != 2:
+            lib.call("mstts_skinny_fwd", lib.ptr(X), 1024, lib.ptr(W), 4096, lib.ptr(Pw), 0, 32, 4096, 1024, 4)
+    for e in range(N):
+        lib.call("mstts_lsa_dalign_bwd", C.byref(c), lib.ptr(dctx[e]), M, None, 0, 0, 0, lib.ptr(Gn), lib.ptr(hn), lib.ptr(G1), lib.ptr(da))
+        lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al[e]), lib.ptr(da), lib.ptr(qs[e]), lib.ptr(cum[e]), lib.ptr(de1[e]), lib.ptr(dq1[e]), lib.ptr(h1[e]))
+    torch.cuda.synchronize()
+    assert int(granb[-1]) == 0 and bool(torch.isfinite(de2).all())
+    worst = max(rel_err(t2n(de2[e]), t2n(de1[e])) for e in range(N))
+    assert worst < 1e-4, worst
+    assert rel_err(t2n(dq2), t2n(dq1)) < 1e-4 and rel_err(t2n(h2), t2n(h1)) < 1e-4
 
 
 def test_stft_mel(dev):

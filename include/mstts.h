@@ -362,12 +362,16 @@ typedef struct {
     const float* w0f; const float* w1; const float* b1; const float* wq;
     const float* wproj; const float* bproj; /* [H+M, n_mel+1], [n_mel+1] */
     float zoneout;
-    float* in0; float* in1; float* pj;      /* [2,B,M+H], [2,B,2H], [B,H+M] */
+    float* in0; float* in1; float* pj;      /* [2,B,P+M+H] (the generic path uses [2,B,M+H] of it), [2,B,2H], [B,H+M] */
     float* c0; float* c1;                   /* [2,B,H] */
     float* cum;                             /* [2,B,T] */
     float* pre_ws;                          /* mstts_decoder_infer_ws_floats(...) floats, 8-byte aligned */
     float* linear; float* stop; float* align_hist;
+    /* optional, enable the weight-streaming path when mstts_decoder_infer_fast(...) == 1:
+     * w0s = [wx0 ; w0f] stacked [P+M+H, 4H]; wp_pad = wproj zero-padded to [H+M, 4*ceil((n_mel+1)/4)] columns */
+    const float* w0s; const float* wp_pad;
 } mstts_decoder_infer_desc;
+int32_t mstts_decoder_infer_fast(int64_t B, int64_t H, int64_t P, int64_t M, int64_t A, int64_t n_mel);
 int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);
 int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel);
 
@@ -379,7 +383,9 @@ enum { MSTTS_PROBE_OFF = 0, MSTTS_PROBE_LSA_ENERGY = 1, MSTTS_PROBE_LSA_CONTEXT 
        MSTTS_PROBE_CELL1_GEMM = 4, MSTTS_PROBE_LSA_DALIGN = 5, MSTTS_PROBE_LSA_DENERGY = 6, MSTTS_PROBE_CELL0_DGEMM = 7,
        MSTTS_PROBE_CELL1_DGEMM = 8 };
 int mstts_probe_begin(int32_t kind, int64_t max_launches);
-int64_t mstts_probe_result(double* total_ms);
+/* after a stream synchronise: launches bracketed, their summed event-to-event time (ms) and the summed time of an empty
+ * event bracket recorded right behind each one (what the event pair itself costs on that stream) */
+int64_t mstts_probe_result(double* total_ms, double* empty_total_ms);
 
 #ifdef __cplusplus
 }

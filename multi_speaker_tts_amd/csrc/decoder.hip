@@ -23,10 +23,12 @@ struct Probe {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
 } g_probe;
-inline bool probe_on(int kind) { return g_probe.kind == kind && g_probe.used + 2 <= g_probe.ev.size(); }
+inline bool probe_on(int kind) { return g_probe.kind == kind && g_probe.used + 3 <= g_probe.ev.size(); }
 inline void probe_mark(mstts_stream_t s) { hipEventRecord(g_probe.ev[g_probe.used++], (hipStream_t)s); }
 }  // namespace
-#define PROBED(kind, s, call) do { const bool pr__ = probe_on(kind); if (pr__) probe_mark(s); RC(call); if (pr__) probe_mark(s); } while (0)
+// three events per launch: e0 | launch | e1 | e2 - (e1 - e0) is the bracketed launch, (e2 - e1) an empty bracket on the same stream
+// in the same place, i.e. what the event pair itself costs
+#define PROBED(kind, s, call) do { const bool pr__ = probe_on(kind); if (pr__) probe_mark(s); RC(call); if (pr__) { probe_mark(s); probe_mark(s); } } while (0)
 
 extern "C" int mstts_probe_begin(int32_t kind, int64_t max_launches) {
     for (hipEvent_t e : g_probe.ev) hipEventDestroy(e);
@@ -34,20 +36,22 @@ extern "C" int mstts_probe_begin(int32_t kind, int64_t max_launches) {
     g_probe.used = 0;
     g_probe.kind = kind;
     if (kind == 0) return MSTTS_OK;
-    g_probe.ev.resize((size_t)max_launches * 2);
+    g_probe.ev.resize((size_t)max_launches * 3);
     for (auto& e : g_probe.ev)
         if (hipEventCreate(&e) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "probe: hipEventCreate failed");
     return MSTTS_OK;
 }
 /* after a stream synchronise: number of bracketed launches and their summed duration (ms) */
-extern "C" int64_t mstts_probe_result(double* total_ms) {
-    double tot = 0.0;
-    for (size_t i = 0; i + 1 < g_probe.used; i += 2) {
+extern "C" int64_t mstts_probe_result(double* total_ms, double* empty_total_ms) {
+    double tot = 0.0, emp = 0.0;
+    for (size_t i = 0; i + 2 < g_probe.used; i += 3) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_probe.ev[i], g_probe.ev[i + 1]) == hipSuccess) tot += ms;
+        if (hipEventElapsedTime(&ms, g_probe.ev[i + 1], g_probe.ev[i + 2]) == hipSuccess) emp += ms;
     }
     if (total_ms) *total_ms = tot;
-    return (int64_t)(g_probe.used / 2);
+    if (empty_total_ms) *empty_total_ms = emp;
+    return (int64_t)(g_probe.used / 3);
 }
 
 static int gemm(const float* A, long lda, const float* B, long ldb, int trans_b, float* C, long ldc, long M, long N, long K,
@@ -412,8 +416,185 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
 // ---------------------------------------------------------------------------------------------
 // free-running decoder steps
 // ---------------------------------------------------------------------------------------------
+namespace mstts {
+// Two-layer prenet of one decoder step for B <= 32 rows in ONE launch (Modules.py:239-255; dropout always on):
+//   h1 = drop0(relu(frame . W0 + b0)),  out[:, c0:c0+16] = drop1(relu(h1 . W1[:, c0:c0+16] + b1)).
+// grid = P/16 workgroups of 4 waves; every workgroup recomputes the small first layer (wave w owns column tiles w, w+4, ..)
+// and owns one 16-column tile of the second (its reduction split over the 4 waves).  fp32 MFMA 16x16x4, the kernel
+// operands go global -> registers in one round trip issued before anything else.
+constexpr int PN_MAXB = 32, PN_COLS = 16, PN_MAXNM4 = 20, PN_MAXTPW = 4, PN_MAXK1 = 16;
+typedef float pn_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restrict__ frame, int NM, const float* __restrict__ w0,
+                                                          const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, float inv_keep,
+                                                          int B, int P, float* __restrict__ out, long out_ld) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ldx = NM + 1, ldh = P + 1;
+    float* s_x = sm;                               // [32][NM + 1]
+    float* s_h = s_x + PN_MAXB * ldx;              // [32][P + 1]
+    float* s_r = s_h + PN_MAXB * ldh;              // [4][32][17]
+    const int c0 = blockIdx.x * PN_COLS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nit0 = NM / 4, tpw = P / 64, nit1 = P / 16;          // k-steps of layer 0; column tiles per wave; k-steps per wave of layer 1
+    const bool two = B > 16;
+    // ---- loads first
+    float xr[(PN_MAXB * 4 * PN_MAXNM4 + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (PN_MAXB * 4 * PN_MAXNM4 + 255) / 256; ++i) {
+        const int e = tid + 256 * i;
+        xr[i] = (e < B * NM) ? frame[e] : 0.f;
+    }
+    float w0r[PN_MAXTPW][PN_MAXNM4];
+#pragma unroll
+    for (int t = 0; t < PN_MAXTPW; ++t)
+#pragma unroll
+        for (int it = 0; it < PN_MAXNM4; ++it)
+            w0r[t][it] = (t < tpw && it < nit0) ? w0[(long)(4 * it + kq) * P + (wave + 4 * t) * 16 + j] : 0.f;
+    float w1r[PN_MAXK1];
+#pragma unroll
+    for (int it = 0; it < PN_MAXK1; ++it)
+        w1r[it] = (it < nit1 && c0 + j < P) ? w1[(long)(wave * (P / 4) + 4 * it + kq) * P + c0 + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < (PN_MAXB * 4 * PN_MAXNM4 + 255) / 256; ++i) {
+        const int e = tid + 256 * i;
+        if (e < PN_MAXB * NM) s_x[(e / NM) * ldx + e % NM] = xr[i];          // rows >= B are zero
+    }
+    __syncthreads();
+    // ---- layer 0
+    float a0[PN_MAXNM4], a1[PN_MAXNM4];
+#pragma unroll
+    for (int it = 0; it < PN_MAXNM4; ++it) {
+        a0[it] = (it < nit0) ? s_x[j * ldx + 4 * it + kq] : 0.f;
+        a1[it] = (it < nit0) ? s_x[(16 + j) * ldx + 4 * it + kq] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < PN_MAXTPW; ++t) {
+        if (t < tpw) {
+            pn_f32x4 acc0 = (pn_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int it = 0; it < PN_MAXNM4; ++it) {
+                if (it < nit0) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[it], w0r[t][it], acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[it], w0r[t][it], acc1, 0, 0, 0);
+                }
+            }
+            const int col = (wave + 4 * t) * 16 + j;
+            const float bj = b0[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kq * 4 + r;
+                s_h[row * ldh + col] = (row < B && m0[(long)row * P + col]) ? fmaxf(acc0[r] + bj, 0.f) * inv_keep : 0.f;
+                s_h[(16 + row) * ldh + col] = (16 + row < B && m0[(long)(16 + row) * P + col]) ? fmaxf(acc1[r] + bj, 0.f) * inv_keep : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 1: this wave's quarter of the reduction
+    {
+        pn_f32x4 acc0 = (pn_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        const float* ha = s_h + j * ldh + wave * (P / 4) + kq;
+#pragma unroll
+        for (int it = 0; it < PN_MAXK1; ++it) {
+            if (it < nit1) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[4 * it], w1r[it], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[16 * ldh + 4 * it], w1r[it], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s_r[(wave * 32 + kq * 4 + r) * 17 + j] = acc0[r];
+            s_r[(wave * 32 + 16 + kq * 4 + r) * 17 + j] = acc1[r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < B * PN_COLS; e += 256) {
+        const int b = e / PN_COLS, cc = e % PN_COLS;
+        if (c0 + cc >= P) continue;
+        const float v = s_r[b * 17 + cc] + s_r[(32 + b) * 17 + cc] + s_r[(64 + b) * 17 + cc] + s_r[(96 + b) * 17 + cc] + b1[c0 + cc];
+        out[(long)b * out_ld + c0 + cc] = m1[(long)b * P + c0 + cc] ? fmaxf(v, 0.f) * inv_keep : 0.f;
+    }
+}
+// [parts][B][NP] projection partial slabs + bias -> linear[B][NM], stop[B] (column NM)
+__global__ void proj_finish_kernel(const float* __restrict__ P_, int parts, long pstride, const float* __restrict__ bias, int B, int NP, int NM,
+                                   float* __restrict__ linear, float* __restrict__ stop) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (NM + 1)) return;
+    const int b = i / (NM + 1), c = i % (NM + 1);
+    float v = bias ? bias[c] : 0.f;
+    for (int pp = 0; pp < parts; ++pp) v += P_[pp * pstride + (long)b * NP + c];
+    if (c < NM) linear[(long)b * NM + c] = v; else stop[b] = v;
+}
+}  // namespace mstts
+
+/* 1 when mstts_decoder_infer_steps can take its weight-streaming path (stacked cell-0 kernel w0s = [wx0 ; w0f] and the padded
+ * projection kernel wp_pad must then be supplied in the descriptor). */
+extern "C" int32_t mstts_decoder_infer_fast(int64_t B, int64_t H, int64_t P, int64_t M, int64_t A, int64_t n_mel) {
+    const long NP = (n_mel + 1 + 3) / 4 * 4;
+    if (B < 1 || B > PN_MAXB || M % 4 != 0) return 0;
+    if (P % 64 != 0 || P / 64 > PN_MAXTPW || P / 16 > PN_MAXK1 || n_mel % 4 != 0 || n_mel / 4 > PN_MAXNM4) return 0;     // prenet_step_kernel tiles
+    return mstts_skinny_fwd_splits(4 * H, P + M + H) > 0 && mstts_skinny_fwd_splits(4 * H, 2 * H) > 0 &&
+           mstts_skinny_fwd_splits(A, H) > 0 && mstts_skinny_fwd_splits(NP, H + M) > 0;
+}
+
+static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s) {
+    const long B = d->B, H = d->H, P = d->P, NM = d->n_mel, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
+    const long BH = B * H, W0 = P + M + H, W1 = 2 * H, WP = H + M, BT = B * T, NP = (NM + 1 + 3) / 4 * 4;
+    const int sp0 = mstts_skinny_fwd_splits(4 * H, W0), sp1 = mstts_skinny_fwd_splits(4 * H, W1), spq = mstts_skinny_fwd_splits(A, H),
+              spp = mstts_skinny_fwd_splits(NP, WP);
+    float* w = d->pre_ws;
+    float* gates = w;       w += (long)MSTTS_MAX_PARTS * 4 * BH;
+    float* gran = w;        w += 2 * BT + 2;
+    float* q = w;           w += (long)MSTTS_MAX_PARTS * B * A;
+    float* pp = w;          w += (long)MSTTS_MAX_PARTS * B * NP;
+    float* zero_frame = w;  w += B * NM;
+    if (step0 == 0) {
+        RC(zero(d->in0, 2 * B * W0, s));
+        RC(zero(d->in1, 2 * B * W1, s));
+        RC(zero(d->c0, 2 * BH, s));
+        RC(zero(d->c1, 2 * BH, s));
+        RC(zero(d->cum, 2 * BT, s));
+        RC(zero(zero_frame, B * NM, s));
+        RC(zero(gran, 2 * BT + 2, s));
+    }
+    const size_t pn_lds = sizeof(float) * (size_t)(PN_MAXB * (NM + 1) + PN_MAXB * (P + 1) + 4 * 32 * 17);
+    for (long st = step0; st < step0 + n; ++st) {
+        const int par = (int)(st & 1), nx = par ^ 1;
+        const float* frame = (st == 0) ? zero_frame : d->linear + (st - 1) * B * NM;
+        float* in0c = d->in0 + par * B * W0; float* in0n = d->in0 + nx * B * W0;      // rows [prenet P | ctx M | h0 H]
+        float* in1c = d->in1 + par * B * W1; float* in1n = d->in1 + nx * B * W1;      // rows [m0 H | h1 H]
+        hipLaunchKernelGGL(prenet_step_kernel, dim3((unsigned)((P + PN_COLS - 1) / PN_COLS)), dim3(256), pn_lds, (hipStream_t)s, frame, (int)NM,
+                           d->pw0, d->pb0, d->pw1, d->pb1, d->pm0 + st * B * P, d->pm1 + st * B * P, 1.f / d->prenet_keep, (int)B, (int)P, in0c, W0);
+        MSTTS_CHECK_LAUNCH("prenet_step");
+        mstts_lstm_point_fwd_desc p;
+        int parts = 1;
+        RC(xw_fwd(in0c, W0, d->w0s, 4 * H, gates, B, 4 * H, W0, sp0, &parts, s));
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = gates; p.gates_parts = parts; p.gates_pstride = 4 * BH; p.bias = d->b0;
+        p.c_prev = d->c0 + par * BH; p.h_prev = in0c + P + M; p.h_prev_ld = W0; p.zoneout = d->zoneout;
+        p.out = in1c; p.out_sb = W1; p.c_next = d->c0 + nx * BH; p.h_next = in0n + P + M; p.h_next_ld = W0;
+        RC(mstts_lstm_point_fwd(&p, s));
+        RC(xw_fwd(in1c, W1, d->w1, 4 * H, gates, B, 4 * H, W1, sp1, &parts, s));
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.gates_h = gates; p.gates_parts = parts; p.gates_pstride = 4 * BH; p.bias = d->b1;
+        p.c_prev = d->c1 + par * BH; p.h_prev = in1c + H; p.h_prev_ld = W1; p.zoneout = d->zoneout;
+        p.out = d->pj; p.out_sb = WP; p.c_next = d->c1 + nx * BH; p.h_next = in1n + H; p.h_next_ld = W1;
+        RC(mstts_lstm_point_fwd(&p, s));
+        RC(xw_fwd(d->pj, WP, d->wq, A, q, B, A, H, spq, &parts, s));
+        RC(mstts_lsa_step_fwd(&d->lsa, q, parts, B * A, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
+                              in0n + P, W0, d->pj + H, WP, gran, (uint32_t)(st + 1), s));
+        RC(xw_fwd(d->pj, WP, d->wp_pad, NP, pp, B, NP, WP, spp, &parts, s));
+        hipLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)((B * (NM + 1) + 255) / 256)), dim3(256), 0, (hipStream_t)s, pp, parts, B * NP, d->bproj,
+                           (int)B, (int)NP, (int)NM, d->linear + st * B * NM, d->stop + st * B);
+        MSTTS_CHECK_LAUNCH("proj_finish");
+    }
+    return MSTTS_OK;
+}
+
 extern "C" int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel) {
-    return 2 * B * P + 8 * B * H + (2 * B * T + 2) + B * A + B * n_mel;
+    const long np = (n_mel + 1 + 3) / 4 * 4;
+    const long slow = 2 * B * P + 8 * B * H + (2 * B * T + 2) + B * A + B * n_mel;
+    const long fast = (long)MSTTS_MAX_PARTS * (4 * B * H + B * A + B * np) + (2 * B * T + 2) + B * n_mel;
+    return slow > fast ? slow : fast;
 }
 
 extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s) {
@@ -421,6 +602,7 @@ extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int6
                   d->c0 && d->c1 && d->cum && d->pre_ws && d->linear && d->stop && d->align_hist && d->pm0 && d->pm1,
                   MSTTS_ERR_SHAPE, "decoder_infer_steps: null pointer");
     MSTTS_REQUIRE(step0 >= 0 && step0 + n <= d->Smax, MSTTS_ERR_SHAPE, "decoder_infer_steps: step range exceeds Smax");
+    if (d->w0s && d->wp_pad && mstts_decoder_infer_fast(d->B, d->H, d->P, d->lsa.M, d->lsa.A, d->n_mel)) return infer_steps_fast(d, step0, n, s);
     const long B = d->B, H = d->H, P = d->P, NM = d->n_mel, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
     const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M, BT = B * T;
     const bool fused_lsa = lsa_fused_enabled();

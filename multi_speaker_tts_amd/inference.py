@@ -156,7 +156,17 @@ class InferEngine:
         q.pm0, q.pm1, q.prenet_keep = ptr(mk["prenet_drop_0"]), ptr(mk["prenet_drop_1"]), 1 - d.prenet_drop
         q.wx0, q.b0, q.w0f = ptr(k0, o0), ptr(b0, ob0), ptr(w0f)
         q.zoneout = d.zoneout
-        q.in0, q.in1, q.pj = ptr(self._f(2, B, M + H)), ptr(self._f(2, B, 2 * H)), ptr(self._f(B, H + M))
+        q.in0, q.in1, q.pj = ptr(self._f(2, B, Pn + M + H)), ptr(self._f(2, B, 2 * H)), ptr(self._f(B, H + M))
+        if lib.load().mstts_decoder_infer_fast(B, H, Pn, M, A, NM):
+            # weight-streaming path: cell-0 kernel with the prenet rows stacked on the folded [ctx ; h] rows, padded projection
+            w0s = self._f(Pn + M + H, 4 * H)
+            call("mstts_copy2d", ptr(k0, o0), 4 * H, ptr(w0s), 4 * H, Pn, 4 * H, 0)
+            call("mstts_copy2d", ptr(w0f), 4 * H, ptr(w0s, Pn * 4 * H), 4 * H, M + H, 4 * H, 0)
+            npad = (NM + 1 + 3) // 4 * 4
+            wp_pad = self._f(H + M, npad)
+            wpj, owpj = self.P("decoder/decoder/linear_projection/dense/kernel")
+            call("mstts_copy2d", ptr(wpj, owpj), NM + 1, ptr(wp_pad), npad, H + M, NM + 1, 0)
+            q.w0s, q.wp_pad = ptr(w0s), ptr(wp_pad)
         q.c0, q.c1, q.cum = ptr(self._f(2, B, H)), ptr(self._f(2, B, H)), ptr(self._f(2, B, T))
         q.pre_ws = ptr(self._f(int(lib.load().mstts_decoder_infer_ws_floats(B, H, Pn, T, A, NM))))
         linear, stop, align = self._f(Smax, B, NM), self._f(Smax, B), self._f(Smax, B, T)

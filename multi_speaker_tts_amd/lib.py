@@ -82,7 +82,7 @@ class DecoderInfer(C.Structure):
                 ("pw0", vp), ("pb0", vp), ("pw1", vp), ("pb1", vp), ("pm0", vp), ("pm1", vp), ("prenet_keep", f32),
                 ("wx0", vp), ("b0", vp), ("w0f", vp), ("w1", vp), ("b1", vp), ("wq", vp), ("wproj", vp), ("bproj", vp),
                 ("zoneout", f32), ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp), ("cum", vp),
-                ("pre_ws", vp), ("linear", vp), ("stop", vp), ("align_hist", vp)]
+                ("pre_ws", vp), ("linear", vp), ("stop", vp), ("align_hist", vp), ("w0s", vp), ("wp_pad", vp)]
 
 
 P = C.POINTER
@@ -143,10 +143,11 @@ SIGNATURES = {
     "mstts_skinny_fwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_skinny_bwd_splits": (i32, [i64, i64]),
     "mstts_skinny_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
+    "mstts_decoder_infer_fast": (i32, [i64, i64, i64, i64, i64, i64]),
     "mstts_decoder_infer_steps": (i32, [P(DecoderInfer), i64, i64, vp]),
     "mstts_decoder_infer_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
     "mstts_probe_begin": (i32, [i32, i64]),
-    "mstts_probe_result": (i64, [C.POINTER(C.c_double)]),
+    "mstts_probe_result": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

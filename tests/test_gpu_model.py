@@ -327,6 +327,37 @@ def test_inference_forward_parity(dev, stop_bias, max_inf):
     assert rel_err(got["Spectrogram"], t2n(ref["Spectrogram"])) < 1e-3
 
 
+def test_inference_decode_full_width(dev):
+    """Free-running decoder at the reference's layer widths (weight-streaming path: fused prenet, stacked cell-0 kernel,
+    single-launch attention, padded projection) vs the oracle, ragged token lengths, injected prenet masks."""
+    from multi_speaker_tts_amd.inference import InferEngine
+    pd, od = dims_pair(dec_lstm=1024, prenet=256, enc_lstm=256, spk=256, n_mel=80, max_inf=7)
+    assert od.mem == 768 and od.att == 128
+    B, Te = 5, 23
+    assert lib.load().mstts_decoder_infer_fast(B, pd.dec_lstm, pd.prenet, pd.mem, pd.att, pd.n_mel) == 1
+    values = OM.init_params(od, 33)
+    g = np.random.default_rng(6)
+    for k in values:
+        if k.endswith(("bias", "beta")) and "highway" not in k:
+            values[k] = g.normal(0, 0.1, values[k].shape)
+    values["decoder/decoder/linear_projection/dense/bias"][-1] = -8.0
+    batch = OT.synthetic_batch(od, B, Te, 4, seed=10, ragged=True)
+    spk = g.normal(0, 1, (B, od.spk)); spk = spk / np.sqrt((spk ** 2).sum())
+    masks = OT.make_masks(od, B, Te, od.max_inf + 1, False, seed=78)
+    ob = {"Token": batch["Token"], "Token_Length": batch["Token_Length"], "Mel": torch.zeros(B, 1, od.n_mel, dtype=torch.float64),
+          "Mel_Length": torch.zeros(B, dtype=torch.int32), "Speaker_Embedding": torch.tensor(spk, dtype=torch.float64)}
+    ref = OM.forward(OM.to_torch(values), od, ob, False, masks, with_vocoder=False)
+    eng = InferEngine(pd, device=dev, values=values)
+    got = eng.forward({"Token": batch["Token"].numpy(), "Token_Length": batch["Token_Length"].numpy(), "Speaker_Embedding": spk.astype(np.float32)},
+                      masks={k: v.numpy() for k, v in masks.items()}, with_vocoder=False)
+    S = ref["Linear"].shape[1]
+    assert S == od.max_inf + 1 and got["Linear"].shape == (B, S, od.n_mel)
+    assert rel_err(got["Linear"], t2n(ref["Linear"])) < 1e-3
+    assert rel_err(got["Mel"], t2n(ref["Mel"])) < 1e-3
+    assert rel_err(got["Stop"], t2n(ref["Stop"])) < 1e-3
+    assert rel_err(got["Attention_History"], t2n(ref["Attention_History"])) < 1e-3
+
+
 def test_tacotron2_surface(dev, tmp_path, monkeypatch):
     """Drop-in surface: Tacotron2(is_Training).Train_Step / Inference / Save / Restore round trip."""
     from multi_speaker_tts_amd import Hyper_Parameters as hp

@@ -6,7 +6,7 @@ per-GPU batch 32 x (128 tokens, 800 mel frames), fp32, synthetic data (BASELINE.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  `roofline` is the location-sensitive-attention step (the kernel
-pair north_star names), measured in situ with HIP events around every launch inside the native
+north_star names), measured in situ with HIP events around every launch inside the native
 decoder loop of one extra, untimed step; `cpu_baseline` is the oracle (torch-CPU restatement of the
 same graph) timed on this host on a bounded sample of the same workload.
 """
@@ -26,9 +26,9 @@ import torch
 
 B_PER_GPU, T_ENC, L_MEL = 32, 128, 800
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes of one attention step (lsa_energy + lsa_context) from the PMC passes committed in
-# profiles/r01_pmc_fetch_write_per_kernel.csv: FETCH_SIZE (2610 + 12401 KB, already x2 per the gfx950 note) + WRITE_SIZE (32 + 224 KB)
-ATTENTION_STEP_PMC_BYTES = (2610.0 + 12401.0 + 32.0 + 224.0) * 1024
+# HBM-side bytes of one attention step (lsa_step_kernel) from the PMC passes committed in
+# profiles/r01c_pmc_fetch_write_per_kernel.csv: FETCH_SIZE 8520.82 KB x 2 (gfx950 correction) + WRITE_SIZE 272 KB
+ATTENTION_STEP_PMC_BYTES = (17041.65 + 272.0) * 1024
 
 
 def synthetic_batch(dims, B, Te, L, seed, rank, device):
@@ -167,10 +167,12 @@ def main():
             n = lb.mstts_probe_result(ctypes.byref(tot), ctypes.byref(emp))
             if n == 0:                      # kernel kind not launched (the attention step is a single launch by default)
                 continue
-            # HIP events bracketing every launch in the live decoder loop; the empty bracket recorded right behind each
-            # launch measures what the event pair itself costs there and is subtracted
+            # HIP events bracketing every launch in the live decoder loop.  An event-to-event interval contains the
+            # event packets' own processing; the empty bracket recorded right behind each launch pays that twice
+            # (measured: bracket - empty/2 reproduces the rocprofv3 kernel-trace average of the same kernel to within
+            # 3 % on all six loop kernels, DESIGN.md "Measurement"), so half of it is subtracted.
             raw_us[name], empty_us[name] = 1e3 * tot.value / n, 1e3 * emp.value / n
-            avg_us[name] = raw_us[name] - empty_us[name]
+            avg_us[name] = raw_us[name] - 0.5 * empty_us[name]
         lb.mstts_probe_begin(0, 0)
         M, A, H = dims.mem, dims.att, dims.dec_lstm
         # attention step, algorithmic bytes per row-step: keys + values + cum r/w + alignment write

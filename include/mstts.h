@@ -37,7 +37,8 @@ int mstts_abi_version(void);
  * win_T > 0 turns A into the implicit im2col view of X[rows, win_C] (conv1d 'same', NWC):
  *   trans_a = 0: A(m,k) = X[m - win_pad + k / win_C][k % win_C], zero outside the row's
  *                length-win_T sequence (m % win_T + k / win_C - win_pad must be in [0, win_T));
- *   trans_a = 1: the same view transposed (weight gradient).   lda must equal win_C. */
+ *   trans_a = 1: the same view transposed (weight gradient).   lda must equal win_C.
+ *   win_dil > 1 dilates the taps (tap j reads row m + (j - win_pad) * win_dil; WaveGlow/Modules.py:267-275); 0 means 1. */
 typedef struct {
     const float* A; const float* B; float* C; const float* bias;
     int64_t M, N, K;
@@ -47,6 +48,7 @@ typedef struct {
     int32_t act, accumulate, split_k;
     int64_t batch, stride_a, stride_b, stride_c;
     float alpha;
+    int32_t win_dil;
 } mstts_gemm_desc;
 int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
 
@@ -256,6 +258,21 @@ int mstts_skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, f
 int32_t mstts_skinny_bwd_splits(int64_t R, int64_t N);
 int mstts_skinny_bwd(const float* dG, int64_t ldg, const float* W, int64_t ldw, float* P, int64_t pstride, int64_t M, int64_t R,
                      int64_t N, int32_t nsplit, mstts_stream_t s);
+
+/* ---- WaveGlow vocoder, inference direction (WaveGlow/Modules.py:177-208,210-327,354-371; Inv1x1.py:9-41).  The contractions run
+ * on mstts_gemm_f32 (win_dil for the dilated K=3 convs); these are the remaining pieces, all [rows, channels] row-major.
+ *  overlap_add : Y[N,T,K,C] tap products of conv2d_transpose((1,K), stride (1,S), VALID) -> out[N,(T-1)*S+K,C] + bias
+ *  gate        : z[rows,C] = tanh(a[:, :C]) * sigmoid(a[:, C:2C]),  a rows are lda floats apart
+ *  res_skip    : !last: x = z + rs[:, :C], skip = rs[:, C:] (rs [rows,2C]); last: skip = rs [rows,C]; out = first ? skip : out + skip
+ *  coupling_inv: a1 = (audio[:, c/2:] - b) * exp(-log_s) with log_s_b = [log_s | b] [rows,c]; out[:, c_early:] = [a0 | a1] . w_inv[c,c];
+ *                out[:, :c_early] = early * sigma (the re-injected latent, Glow_Inference :362-369); out is [rows, c + c_early]
+ *  philox_normal: out[i] ~ N(0, sigma^2), Box-Muller over Philox4x32-10 stream (seed, stream_id) (tf.random.normal stand-in) */
+int mstts_wg_overlap_add(const float* Y, const float* bias, float* out, int64_t N, int64_t T, int64_t K, int64_t S, int64_t C, mstts_stream_t s);
+int mstts_wg_gate(const float* a, int64_t lda, float* z, int64_t rows, int64_t C, mstts_stream_t s);
+int mstts_wg_res_skip(const float* z, const float* rs, float* x, float* out, int64_t rows, int64_t C, int32_t last, int32_t first, mstts_stream_t s);
+int mstts_wg_coupling_inv(const float* audio, const float* log_s_b, const float* w_inv, const float* early, float sigma, float* out,
+                          int64_t rows, int64_t c, int64_t c_early, mstts_stream_t s);
+int mstts_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t stream_id, float sigma, mstts_stream_t s);
 
 /* ---- LSTM weight utilities --------------------------------------------------------------------
  * fold_rows: dst[r,:] = src[r,:] for r<r0 ; dst[r0+i,:] = src[r0+i,:] + src[r0+n+i,:] (i<n) ; rest shifted up.

@@ -4,7 +4,7 @@ Same constructor and methods - ``Tacotron2(is_Training)``, ``Restore()``, ``Trai
 ``Inference(path_List, text_List, file_Prefix)`` - and the same result-dict keys
 (``train_Tensor_Dict`` / ``inference_Tensor_Dict`` names, MSTTS_SV.py:194-216).  The TensorFlow session is
 replaced by ``engine.TrainEngine`` / ``inference.InferEngine`` (libmstts_hip.so calls on one HIP stream).
-Out of scope here: matplotlib/WAV export threads, pickle feeder threads, TF checkpoint reading.
+Out of scope here: matplotlib export threads, pickle feeder threads, TF checkpoint reading.
 """
 from __future__ import annotations
 
@@ -49,9 +49,22 @@ class Tacotron2:
         self._load_scope(hp.Speaker_Embedding.Checkpoint_Path, "speaker_embedding")
 
     def Vocoder_Load(self):
-        if hp.Use_Vocoder.upper() != "Taco1_Mel_to_Spect".upper():
-            raise ValueError("only the Taco1_Mel_to_Spect vocoder is built on this path (WaveGlow is listed as 'next')")
-        self._load_scope(hp.Taco1_Mel_to_Spect.Checkpoint_Path, "mel_to_spectrogram")
+        """MSTTS_SV.py:229-242: the vocoder named by hp.Use_Vocoder is restored from its own checkpoint directory."""
+        self.waveglow = None
+        if hp.Use_Vocoder.upper() == "Taco1_Mel_to_Spect".upper():
+            self._load_scope(hp.Taco1_Mel_to_Spect.Checkpoint_Path, "mel_to_spectrogram")
+        elif hp.Use_Vocoder.upper() == "WaveGlow".upper():
+            from .waveglow import WaveGlowEngine, WGDims
+            f = os.path.join(hp.WaveGlow.Checkpoint_Path.replace("\\", "/"), "waveglow.pt")
+            values = None
+            if os.path.exists(f):
+                values = {k: np.asarray(v) for k, v in torch.load(f, map_location="cpu").items()}
+                print("waveglow checkpoint '%s' is loaded." % f)
+            else:
+                print("No waveglow checkpoint at '%s': keeping the random initialisation." % f)
+            self.waveglow = WaveGlowEngine(WGDims.from_hp(hp), device=self.device, values=values)
+        else:
+            raise ValueError("hp.Use_Vocoder must be 'Taco1_Mel_to_Spect' or 'WaveGlow'")
 
     def _load_scope(self, path, scope):
         f = os.path.join(path.replace("\\", "/"), "%s.pt" % scope)
@@ -109,6 +122,36 @@ class Tacotron2:
         res.update({"Global_Step": step, "Learning_Rate": learning_rate(step), "Train_OP": None})
         return res
 
+    def Inference_WaveGlow(self, path_List, text_List, file_Prefix=None, speaker_Mel_List=None, masks=None, export=True, noise_seed=None):
+        """MSTTS_SV.py:325-389 + Export_Inference_WaveGlow :449-466: Tacotron2 forward, the mels cut into
+        hp.WaveGlow.Inference.Mel_Split_Length-frame chunks, vocoded hp.WaveGlow.Inference.Batch_Size chunks at a time,
+        stitched per utterance, cut at the stop token (in samples of Export_Sample_Rate)."""
+        from . import waveglow as WG
+        pattern = self.feeder.Get_Inference_Pattern(path_List, text_List, speaker_Mel_List=speaker_Mel_List)
+        res = self.infer_engine.forward(pattern, masks=masks, with_vocoder=False)
+        res["Global_Step"] = self.global_step
+        prefix = file_Prefix or "GS_{}".format(self.global_step)
+        wavs = WG.vocode(self.waveglow, list(res["Mel"]), hp.WaveGlow.Inference.Mel_Split_Length, hp.WaveGlow.Inference.Batch_Size,
+                         noise_seed=noise_seed)
+        res["Wav"] = wavs
+        cut = []
+        for i, text in enumerate(text_List):
+            s = _Feeder.stop_cut(res["Stop"][i])
+            n = WG.export_length(res["Stop"][i], hp.Sound.Frame_Shift, hp.WaveGlow.Export_Sample_Rate)
+            cut.append({"Linear": res["Linear"][i, :s], "Mel": res["Mel"][i, :s], "Stop": res["Stop"][i, :s],
+                        "Attention_History": res["Attention_History"][i, :len(text) + 2, :s], "Wav": wavs[i][:n]})
+        res["Cut"] = cut
+        if export:
+            out_dir = os.path.join(hp.Inference_Path, "WAV").replace("\\", "/")
+            try:
+                from scipy.io import wavfile
+                os.makedirs(out_dir, exist_ok=True)
+                for i, c in enumerate(cut):
+                    wavfile.write(os.path.join(out_dir, "{}.IDX_{}.WAV".format(prefix, i)), hp.WaveGlow.Export_Sample_Rate, c["Wav"].astype(np.float32))
+            except OSError as e:
+                print("Inference export skipped: {}".format(e))
+        return res
+
     def Train(self, max_steps=None, pattern_fn=None):
         """MSTTS_SV.py:268-293: loop forever (or `max_steps`), print the reference's log line, checkpoint
         every hp.Train.Checkpoint_Save_Timing steps."""
@@ -128,6 +171,8 @@ class Tacotron2:
     def Inference(self, path_List, text_List, file_Prefix=None, speaker_Mel_List=None, masks=None, export=True):
         if len(text_List) != (len(path_List) if speaker_Mel_List is None else len(speaker_Mel_List)):
             raise ValueError("path_List and text_List must have the same length")
+        if hp.Use_Vocoder.upper() == "WaveGlow".upper():          # MSTTS_SV.py:295-299
+            return self.Inference_WaveGlow(path_List, text_List, file_Prefix, speaker_Mel_List=speaker_Mel_List, masks=masks, export=export)
         pattern = self.feeder.Get_Inference_Pattern(path_List, text_List, speaker_Mel_List=speaker_Mel_List)
         res = self.infer_engine.forward(pattern, masks=masks)
         res["Global_Step"] = self.global_step

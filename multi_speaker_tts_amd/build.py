@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmstts_hip.so")
-SOURCES = ["gemm.hip", "skinny.hip", "elementwise.hip", "lsa.hip", "decoder.hip", "audio.hip"]
+SOURCES = ["gemm.hip", "skinny.hip", "elementwise.hip", "lsa.hip", "decoder.hip", "audio.hip", "waveglow.hip"]
 
 
 def _hipcc():

@@ -24,7 +24,7 @@ struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K;
     long lda, ldb, ldc;
-    int win_T, win_C, win_pad;
+    int win_T, win_C, win_pad, win_dil;
     int act, accumulate, split_k;
     long stride_a, stride_b, stride_c;
     float alpha;
@@ -46,9 +46,10 @@ template <int R, bool VEC>
 struct LoaderKC {
     static constexpr int NV = R * BK / 4 / 256;      // float4 per thread
     float4 reg[NV];
-    // window: element (row, k) valid iff 0 <= (row % T) + k / C - pad < T; address shifts by -pad rows
+    // window: element (row, k) is tap j = k / C of a dilated 'same' conv: source row = row + (j - pad) * dil, valid iff it
+    // stays inside the row's length-T sequence (dil == 1: the taps of a row are contiguous, address = (row - pad) * ld + k)
     __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int row0, int k0,
-                                         int rows, int kmax, int wT, int wC, int wpad) {
+                                         int rows, int kmax, int wT, int wC, int wpad, int wdil) {
         const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -58,9 +59,10 @@ struct LoaderKC {
             bool ok = row < rows && k < kmax;
             long off = (long)row * ld + k;
             if (wT > 0) {
-                const int t = row % wT + k / wC - wpad;
+                const int sh = (k / wC - wpad) * wdil;
+                const int t = row % wT + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)row - wpad) * ld + k;
+                off = ((long)row + sh) * ld + k % wC;
             }
             if (ok) {
                 if (VEC) {
@@ -94,7 +96,7 @@ struct LoaderMC {
     // window (A only): element (m, kk) with kk=(b,t) row index, m=(tap, c):
     //   valid iff 0 <= (kk % T) + m / C - pad < T; address = base[(kk - pad) * ld + m]
     __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int col0, int k0,
-                                         int cols, int kmax, int wT, int wC, int wpad) {
+                                         int cols, int kmax, int wT, int wC, int wpad, int wdil) {
         const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -104,9 +106,10 @@ struct LoaderMC {
             bool ok = k < kmax && col < cols;
             long off = (long)k * ld + col;
             if (wT > 0) {
-                const int t = k % wT + col / wC - wpad;
+                const int sh = (col / wC - wpad) * wdil;
+                const int t = k % wT + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)k - wpad) * ld + col;
+                off = ((long)k + sh) * ld + col % wC;
             }
             if (ok) {
                 if (VEC) {
@@ -171,8 +174,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kbeg < kend) {
-        la.load(A, g.lda, m0, kbeg, g.M, kend, g.win_T, g.win_C, g.win_pad);
-        lb.load(B, g.ldb, n0, kbeg, g.N, kend, 0, 1, 0);
+        la.load(A, g.lda, m0, kbeg, g.M, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
+        lb.load(B, g.ldb, n0, kbeg, g.N, kend, 0, 1, 0, 1);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                       // previous tile fully consumed
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         lb.store(Bs, LDB_S);
         __syncthreads();
         if (k0 + BK < kend) {                  // prefetch next tile while this one is multiplied
-            la.load(A, g.lda, m0, k0 + BK, g.M, kend, g.win_T, g.win_C, g.win_pad);
-            lb.load(B, g.ldb, n0, k0 + BK, g.N, kend, 0, 1, 0);
+            la.load(A, g.lda, m0, k0 + BK, g.M, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
+            lb.load(B, g.ldb, n0, k0 + BK, g.N, kend, 0, 1, 0, 1);
         }
         const int kh = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -253,7 +256,7 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     g.A = d->A; g.B = d->B; g.C = d->C; g.bias = d->bias;
     g.M = (int)d->M; g.N = (int)d->N; g.K = (int)d->K;
     g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
-    g.win_T = d->win_T; g.win_C = d->win_C > 0 ? d->win_C : 1; g.win_pad = d->win_pad;
+    g.win_T = d->win_T; g.win_C = d->win_C > 0 ? d->win_C : 1; g.win_pad = d->win_pad; g.win_dil = d->win_dil > 0 ? d->win_dil : 1;
     g.act = d->act; g.accumulate = d->accumulate; g.split_k = split;
     g.stride_a = d->stride_a; g.stride_b = d->stride_b; g.stride_c = d->stride_c;
     g.alpha = d->alpha;

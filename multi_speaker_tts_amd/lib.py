@@ -24,7 +24,7 @@ class GemmDesc(C.Structure):
                 ("M", i64), ("N", i64), ("K", i64), ("lda", i64), ("ldb", i64), ("ldc", i64),
                 ("trans_a", i32), ("trans_b", i32), ("win_T", i32), ("win_C", i32), ("win_pad", i32),
                 ("act", i32), ("accumulate", i32), ("split_k", i32),
-                ("batch", i64), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("alpha", f32)]
+                ("batch", i64), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("alpha", f32), ("win_dil", i32)]
 
 
 class LstmPointFwd(C.Structure):
@@ -131,6 +131,11 @@ SIGNATURES = {
     "mstts_stft_mel": (i32, [vp, i64, f32, vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, vp]),
     "mstts_stft_mel_ws_floats": (i64, [i64, i32, i64]),
     "mstts_fold_rows": (i32, [vp, vp, i64, i64, i64, i64, vp]),
+    "mstts_wg_overlap_add": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "mstts_wg_gate": (i32, [vp, i64, vp, i64, i64, vp]),
+    "mstts_wg_res_skip": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, vp]),
+    "mstts_wg_coupling_inv": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, vp]),
+    "mstts_philox_normal": (i32, [vp, i64, u64, u32, f32, vp]),
     "mstts_lstm_seq_fwd": (i32, [P(LstmSeqFwd), vp]),
     "mstts_lstm_seq_bwd": (i32, [P(LstmSeqBwd), vp]),
     "mstts_lstm_seq_ws_floats": (i64, [i64, i64, i32]),
@@ -201,7 +206,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, bias=None, trans_a=False, trans_b=Fal
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
     d.trans_a, d.trans_b = int(trans_a), int(trans_b)
     if win is not None:
-        d.win_T, d.win_C, d.win_pad = win
+        d.win_T, d.win_C, d.win_pad = win[:3]
+        d.win_dil = win[3] if len(win) > 3 else 1
     d.act, d.accumulate, d.split_k = act, int(accumulate), split_k
     d.batch, d.stride_a, d.stride_b, d.stride_c = batch, strides[0], strides[1], strides[2]
     d.alpha = alpha

@@ -134,3 +134,41 @@ def test_speaker_encoder_whole_tensor_norm():
     x = torch.randn(3 * d.spk_samples, d.spk_frames, d.n_mel, dtype=torch.float64)
     e = OM.speaker_encoder(p, d, x)
     assert e.shape == (3, d.spk) and abs(float((e ** 2).sum()) - 1.0) < 1e-9        # Q14: whole-tensor l2 norm
+
+
+def test_waveglow_flow_is_invertible():
+    """Pins oracle/waveglow.py against itself: Glow_Train direction followed by Glow_Inference on the emitted latents
+    returns the audio (WaveGlow/Modules.py:329-371), for a configuration with two early outputs."""
+    from oracle import waveglow as OW
+    d = OW.WGDims(n_mel=8, flows=6, groups=8, early_every=2, early_size=2, up_k=16, up_stride=4, layers=3, ch=16, k=3)
+    p = OW.to_torch(OW.init_params(d, seed=1))
+    g = np.random.default_rng(2)
+    N, T = 2, 5
+    mel = torch.tensor(g.normal(0, 1, (N, T, d.n_mel)))
+    L = (T - 1) * d.up_stride + d.up_k
+    audio = torch.tensor(g.normal(0, 0.3, (N, L // d.groups, d.groups)))
+    melg = OW.restructure_inference_mel(p, d, mel)
+    assert melg.shape == (N, L // d.groups, d.groups * d.n_mel)
+    noise = OW.glow_forward(p, d, audio, melg)
+    assert noise["z"].shape[-1] == d.z_channels == 4 and set(noise) == {"z", "early_2", "early_4"}
+    back = OW.glow_inference(p, d, mel, noise, sigma=1.0)
+    assert float((back - audio.reshape(N, -1)).abs().max()) < 1e-9
+    # weight norm: unit-norm direction per output channel scaled by g (WaveGlow/Modules.py:32-34)
+    w = OW.weight_norm(torch.tensor([2.0, 3.0]), torch.tensor(g.normal(0, 1, (1, 3, 4, 2))))
+    assert np.allclose(np.sqrt((w ** 2).sum(dim=(0, 1, 2)).numpy()), [2.0, 3.0])
+    # upsampler length and channel bookkeeping of the reference hyper-parameters
+    full = OW.WGDims()
+    assert full.z_channels == 4 and [full.channels(f) for f in (0, 3, 4, 7, 8, 11)] == [8, 8, 6, 6, 4, 4]
+    assert (40 - 1) * full.up_stride + full.up_k == 11008 and 11008 % full.groups == 0
+
+
+def test_waveglow_chunking_kats():
+    """MSTTS_SV.Inference_WaveGlow host arithmetic (MSTTS_SV.py:335-347,452-458) - product and oracle agree with hand values."""
+    from oracle import waveglow as OW
+    from multi_speaker_tts_amd import waveglow as WG
+    mels = [np.zeros((95, 80)), np.zeros((40, 80)), np.zeros((3, 80))]
+    for mod in (OW, WG):
+        chunks, index = mod.split_mels(mels, 40)
+        assert [c.shape[0] for c in chunks] == [40, 40, 15, 40, 3] and index == [(0, 3), (3, 4), (4, 5)]
+        assert mod.export_length([.1, .2, .6, .9], 12.5, 22050) == int(2 * 12.5 / 1000 * 22050) == 551
+        assert mod.export_length([.1, .2, .3], 12.5, 22050) == int(3 * 12.5 / 1000 * 22050)

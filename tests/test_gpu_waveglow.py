@@ -1,0 +1,138 @@
+"""WaveGlow vocoder (inference direction) through the C ABI vs the oracle restatement (oracle/waveglow.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from multi_speaker_tts_amd import lib
+from multi_speaker_tts_amd import waveglow as WG
+from oracle import waveglow as OW
+from tests.helpers import rel_err, t2n
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _rn(dev, *shape, seed=0, scale=1.0):
+    return torch.tensor(np.random.default_rng(seed).normal(0, scale, shape), dtype=torch.float32, device=dev)
+
+
+@pytest.mark.parametrize("N,T,K,S,Cc", [(2, 5, 16, 4, 8), (3, 7, 12, 5, 6), (1, 1, 8, 8, 4)])
+def test_upsample_overlap_add(dev, N, T, K, S, Cc):
+    """conv2d_transpose((1,K), stride (1,S), VALID) as GEMM + overlap-add vs torch conv_transpose1d in fp64 (Upsample_Mel)."""
+    mel, w, b = _rn(dev, N, T, Cc, seed=1), _rn(dev, K, Cc, Cc, seed=2, scale=0.3), _rn(dev, Cc, seed=3)       # w: [K, Cout, Cin]
+    wt = w.permute(2, 0, 1).reshape(Cc, K * Cc).contiguous()
+    Y = torch.zeros(N * T, K * Cc, device=dev)
+    lib.gemm(mel, wt, Y, N * T, K * Cc, Cc, Cc, K * Cc, K * Cc)
+    L = (T - 1) * S + K
+    out = torch.zeros(N, L, Cc, device=dev)
+    lib.call("mstts_wg_overlap_add", lib.ptr(Y), lib.ptr(b), lib.ptr(out), N, T, K, S, Cc)
+    ref = F.conv_transpose1d(mel.double().cpu().transpose(1, 2), w.double().cpu().permute(2, 1, 0), stride=S).transpose(1, 2) + b.double().cpu()
+    assert rel_err(t2n(out), t2n(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("N,Lg,Cin,Cout,K,dil", [(2, 37, 32, 64, 3, 1), (3, 50, 32, 48, 3, 4), (1, 20, 64, 32, 3, 16), (2, 64, 32, 32, 5, 2)])
+def test_dilated_conv_gemm(dev, N, Lg, Cin, Cout, K, dil):
+    """Dilated 'same' conv1d as implicit-im2col GEMM (win_dil), accumulated onto a wider buffer, vs F.conv1d."""
+    x, w, b = _rn(dev, N, Lg, Cin, seed=4), _rn(dev, K, Cin, Cout, seed=5, scale=0.2), _rn(dev, Cout, seed=6)
+    ldc = Cout + 16
+    base = _rn(dev, N * Lg, ldc, seed=7)
+    y = base.clone()
+    lib.gemm(x, w.reshape(K * Cin, Cout).contiguous(), y, N * Lg, Cout, K * Cin, Cin, Cout, ldc, bias=b, accumulate=True,
+             win=(Lg, Cin, (K - 1) // 2, dil), c_off=8)
+    pad = (K - 1) * dil // 2
+    ref = F.conv1d(F.pad(x.double().cpu().transpose(1, 2), (pad, (K - 1) * dil - pad)), w.double().cpu().permute(2, 1, 0), dilation=dil).transpose(1, 2) + b.double().cpu()
+    exp = base.double().cpu().clone()
+    exp[:, 8:8 + Cout] += ref.reshape(N * Lg, Cout)
+    assert rel_err(t2n(y), t2n(exp)) < 1e-5
+
+
+def test_philox_normal(dev):
+    n = 1 << 20
+    a, b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lib.call("mstts_philox_normal", lib.ptr(a), n, 1234, 70, 1.0)
+    lib.call("mstts_philox_normal", lib.ptr(b), n, 1234, 70, 1.0)
+    assert torch.equal(a, b)                                   # counter-based: reproducible
+    lib.call("mstts_philox_normal", lib.ptr(b), n, 1234, 71, 2.0)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3 and abs(float(b.std()) - 2.0) < 1e-2
+    assert abs(float((a * b).mean())) < 1e-2 and bool(torch.isfinite(a).all())
+    k4 = float(((a - a.mean()) ** 4).mean() / a.var() ** 2)    # kurtosis of a normal = 3
+    assert abs(k4 - 3.0) < 0.05
+
+
+CFGS = [dict(n_mel=8, flows=4, groups=8, early_every=2, early_size=2, up_k=16, up_stride=4, layers=3, ch=32, k=3),
+        dict(n_mel=16, flows=12, groups=8, early_every=4, early_size=2, up_k=32, up_stride=8, layers=4, ch=64, k=3),
+        dict(n_mel=8, flows=6, groups=4, early_every=3, early_size=2, up_k=8, up_stride=4, layers=8, ch=32, k=3)]
+
+
+@pytest.mark.parametrize("cfg,N,T", [(CFGS[0], 2, 5), (CFGS[1], 3, 6), (CFGS[2], 1, 9)])
+def test_glow_inference_parity(dev, cfg, N, T):
+    """Glow_Inference (upsample -> 12 reverse couplings with WaveNet + inverse 1x1 + early-latent re-injection) vs the
+    oracle on identical injected latents."""
+    od, pd = OW.WGDims(**cfg), WG.WGDims(**cfg)
+    values = OW.init_params(od, seed=3)
+    g = np.random.default_rng(8)
+    mel = np.clip(g.normal(0, 1.5, (N, T, od.n_mel)), -4, 4)
+    L = (T - 1) * od.up_stride + od.up_k
+    noise = OW.make_noise(od, N, L // od.groups, seed=9)
+    ref = OW.glow_inference(OW.to_torch(values), od, torch.tensor(mel), {k: torch.tensor(v) for k, v in noise.items()}, sigma=0.8)
+    eng = WG.WaveGlowEngine(pd, device=dev, values=values)
+    got = eng.infer(mel.astype(np.float32), noise=noise, sigma=0.8)
+    assert got.shape == (N, L)
+    assert rel_err(t2n(got), t2n(ref)) < 1e-3, rel_err(t2n(got), t2n(ref))
+    # own latents: deterministic per seed, finite
+    w1, w2 = eng.infer(mel.astype(np.float32), seed=5), eng.infer(mel.astype(np.float32), seed=5)
+    assert torch.equal(w1, w2) and bool(torch.isfinite(w1).all())
+
+
+def test_vocode_chunking(dev):
+    """Inference_WaveGlow host logic: 40-frame chunks, zero padding, batches, stitching incl. the untrimmed tail."""
+    cfg = CFGS[0]
+    pd = WG.WGDims(**cfg)
+    eng = WG.WaveGlowEngine(pd, device=dev, values=OW.init_params(OW.WGDims(**cfg), seed=4))
+    g = np.random.default_rng(1)
+    mels = [g.normal(0, 1, (t, pd.n_mel)).astype(np.float32) for t in (7, 3, 10)]
+    wavs = WG.vocode(eng, mels, split=3, batch=2, noise_seed=11)
+    per_chunk = (3 - 1) * pd.up_stride + pd.up_k
+    assert [w.shape[0] for w in wavs] == [3 * per_chunk, 1 * per_chunk, 4 * per_chunk]
+    assert all(np.isfinite(w).all() for w in wavs)
+
+
+def test_tacotron2_inference_waveglow_surface(dev, tmp_path, monkeypatch):
+    """hp.Use_Vocoder = 'WaveGlow': Tacotron2.Inference dispatches to Inference_WaveGlow (MSTTS_SV.py:295-299,325-389):
+    chunked vocoding, per-utterance stitching, stop-token cut in samples, WAV export."""
+    from multi_speaker_tts_amd import Hyper_Parameters as hp
+    from multi_speaker_tts_amd.MSTTS_SV import Tacotron2
+    from multi_speaker_tts_amd.params import Dims
+    monkeypatch.setattr(hp, "Checkpoint_Path", str(tmp_path / "ckpt"))
+    monkeypatch.setattr(hp, "Inference_Path", str(tmp_path / "inf"))
+    monkeypatch.setattr(hp, "Use_Vocoder", "WaveGlow")
+    for k, v in dict(Flows=4, Early_Every=2).items():
+        monkeypatch.setattr(hp.WaveGlow, k, v)
+    monkeypatch.setattr(hp.WaveGlow.WaveNet, "Channels", 32)
+    monkeypatch.setattr(hp.WaveGlow.WaveNet, "Layers", 2)
+    monkeypatch.setattr(hp.WaveGlow.Upsample, "Kernel_Size", 32)
+    monkeypatch.setattr(hp.WaveGlow.Upsample, "Strides", 8)
+    monkeypatch.setattr(hp.WaveGlow.Inference, "Mel_Split_Length", 3)
+    monkeypatch.setattr(hp.WaveGlow, "Checkpoint_Path", str(tmp_path / "wg"))
+    dims = Dims(emb=32, enc_conv_ch=32, enc_lstm=16, spk=256, prenet=16, dec_lstm=32, post_ch=16, bank_ch=8, proj1_ch=16, birnn=8, n_spec=20,
+                spk_lstm=256, max_inf=6)
+    t = Tacotron2(is_Training=False, device=dev, dims=dims)
+    assert t.waveglow is not None
+    mels = [np.clip(np.random.default_rng(i).normal(0, 1.5, (230, 80)), -4, 4).astype(np.float32) for i in range(2)]
+    res = t.Inference(None, ["Please call Stella.", "Who knows?"], speaker_Mel_List=mels, file_Prefix="wg")
+    S = res["Mel"].shape[1]
+    per_chunk = (3 - 1) * 8 + 32
+    n_chunks = -(-S // 3)
+    last = S - 3 * (n_chunks - 1)
+    assert len(res["Wav"]) == 2 and res["Wav"][0].shape[0] == n_chunks * per_chunk          # chunks are padded to the longest (3 frames)
+    assert "Spectrogram" not in res and np.isfinite(res["Wav"][0]).all()
+    for i in range(2):
+        assert res["Cut"][i]["Wav"].shape[0] == min(res["Wav"][i].shape[0], int(res["Cut"][i]["Mel"].shape[0] * 12.5 / 1000 * 22050))
+    assert (tmp_path / "inf" / "WAV" / "wg.IDX_1.WAV").exists() and last >= 1

@@ -88,7 +88,7 @@ def test_glow_inference_parity(dev, cfg, N, T):
     assert rel_err(t2n(got), t2n(ref)) < 1e-3, rel_err(t2n(got), t2n(ref))
     # own latents: deterministic per seed, finite
     w1, w2 = eng.infer(mel.astype(np.float32), seed=5), eng.infer(mel.astype(np.float32), seed=5)
-    assert torch.equal(w1, w2) and bool(torch.isfinite(w1).all())
+    assert rel_err(t2n(w1), t2n(w2)) < 1e-5 and bool(torch.isfinite(w1).all())      # same latents (split-K atomics: not bitwise)
 
 
 def test_vocode_chunking(dev):

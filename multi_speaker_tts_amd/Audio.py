@@ -83,3 +83,86 @@ def melspectrogram(y, num_freq, frame_shift_ms, frame_length_ms, num_mels, sampl
              float(max_abs_value), lib.ptr(ws), lib.ptr(out), frames)
     out = out.t()
     return out if return_tensor else out.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Spectrogram -> waveform (Griffin-Lim), the export leg of Tacotron2.Inference with the Taco1 vocoder
+# (Audio.py:15-27,50-60,84-99; Taco1_Mel_to_Spect/Modules.py:110-119; MSTTS_SV.py:403-412).  Host plumbing like in
+# the reference (it runs in the export thread there; BASELINE config 1 calls it "plumbing, no GPU"): NumPy rFFTs.
+# ---------------------------------------------------------------------------------------------------------------------
+def _padded_window(n_fft, win_length):
+    """librosa.util.pad_center(scipy.signal.get_window('hann', win_length, fftbins=True), n_fft)."""
+    w = np.zeros(n_fft)
+    lpad = (n_fft - win_length) // 2
+    w[lpad:lpad + win_length] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win_length) / win_length)
+    return w
+
+
+def _stft(y, num_freq, frame_shift_ms, frame_length_ms, sample_rate):
+    """librosa.stft(y, n_fft, hop_length, win_length): center=True, reflect padding -> [num_freq, 1 + len(y) // hop]."""
+    n_fft, hop, win = _stft_parameters(num_freq, frame_shift_ms, frame_length_ms, sample_rate)
+    w = _padded_window(n_fft, win)
+    yp = np.pad(np.asarray(y, np.float64), n_fft // 2, mode="reflect")
+    n_frames = 1 + (len(yp) - n_fft) // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    return np.fft.rfft(yp[idx] * w[None, :], axis=1).T
+
+
+def _istft(D, num_freq, frame_shift_ms, frame_length_ms, sample_rate):
+    """librosa.istft(D, hop_length, win_length): windowed overlap-add of the inverse rFFTs, divided by the summed squared
+    window where that is non-negligible, centre padding (n_fft // 2 each side) removed."""
+    n_fft, hop, win = _stft_parameters(num_freq, frame_shift_ms, frame_length_ms, sample_rate)
+    w = _padded_window(n_fft, win)
+    n_frames = D.shape[1]
+    frames = np.fft.irfft(D.T, n=n_fft, axis=1) * w[None, :]
+    n = n_fft + hop * (n_frames - 1)
+    y, wss = np.zeros(n), np.zeros(n)
+    for i in range(n_frames):
+        y[i * hop:i * hop + n_fft] += frames[i]
+        wss[i * hop:i * hop + n_fft] += w * w
+    nz = wss > np.finfo(np.float32).tiny
+    y[nz] /= wss[nz]
+    return y[n_fft // 2:n - n_fft // 2]
+
+
+def inv_preemphasis(x, preemphasis=0.97):
+    """scipy.signal.lfilter([1], [1, -preemphasis], x) (Audio.py:15-16)."""
+    from scipy import signal
+    return signal.lfilter([1], [1, -preemphasis], x)
+
+
+def _denormalize(S, min_level_db=-100):
+    return (np.clip(S, 0, 1) * -min_level_db) + min_level_db
+
+
+def _db_to_amp(x):
+    return np.power(10.0, x * 0.05)
+
+
+def _griffin_lim(S, num_freq, frame_shift_ms, frame_length_ms, sample_rate, griffin_lim_iters=60, rng=None):
+    """Audio.py:50-60: random initial phase, then `iters` rounds of istft -> stft -> keep the phase."""
+    rng = rng if rng is not None else np.random
+    angles = np.exp(2j * np.pi * rng.rand(*S.shape))
+    S_complex = np.abs(S).astype(np.complex128)
+    args = (num_freq, frame_shift_ms, frame_length_ms, sample_rate)
+    y = _istft(S_complex * angles, *args)
+    for _ in range(griffin_lim_iters):
+        angles = np.exp(1j * np.angle(_stft(y, *args)))
+        y = _istft(S_complex * angles, *args)
+    return y
+
+
+def inv_spectrogram(spectrogram, num_freq, frame_shift_ms, frame_length_ms, sample_rate, ref_level_db=20, power=1.5,
+                    griffin_lim_iters=60, rng=None):
+    """Same signature as the reference (Audio.py:24-27); spectrogram is [num_freq, frames], normalised to [0, 1]."""
+    S = _db_to_amp(_denormalize(np.asarray(spectrogram, np.float64)) + ref_level_db)
+    return inv_preemphasis(_griffin_lim(S ** power, num_freq, frame_shift_ms, frame_length_ms, sample_rate,
+                                        griffin_lim_iters=griffin_lim_iters, rng=rng))
+
+
+def Griffin_Lim(spectrogram, rng=None):
+    """Taco1_Mel_to_Spect/Modules.py:110-119: spectrogram [Time, Dim] -> waveform at hp.Sound.Sample_Rate."""
+    from . import Hyper_Parameters as hp
+    return inv_spectrogram(np.asarray(spectrogram).transpose(), num_freq=hp.Sound.Spectrogram_Dim, frame_shift_ms=hp.Sound.Frame_Shift,
+                           frame_length_ms=hp.Sound.Frame_Length, sample_rate=hp.Sound.Sample_Rate,
+                           griffin_lim_iters=hp.Taco1_Mel_to_Spect.Griffin_Lim_Iteration, rng=rng)

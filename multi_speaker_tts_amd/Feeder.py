@@ -88,7 +88,7 @@ def stop_cut(stop):
     return int(hit[0]) if hit.size else int(stop.shape[0])
 
 
-def load_wav(path, sample_rate=None, top_db=15.0):
+def load_wav(path, sample_rate=None, top_db=15.0, frame=32, hop=16):
     """Speaker wav -> float mono at hp.Sound.Sample_Rate, silence-trimmed, scaled by 0.99
     (Feeder.py:213-215 plumbing: scipy.io.wavfile + polyphase resampling + a frame_length=32 /
     hop_length=16 RMS trim standing in for librosa.effects.trim)."""
@@ -106,7 +106,6 @@ def load_wav(path, sample_rate=None, top_db=15.0):
     if rate != sr:
         g = np.gcd(int(rate), int(sr))
         data = resample_poly(data, sr // g, rate // g).astype(np.float32)
-    frame, hop = 32, 16
     if data.shape[0] >= frame:
         n = 1 + (data.shape[0] - frame) // hop
         idx = np.arange(frame)[None, :] + hop * np.arange(n)[:, None]
@@ -118,15 +117,111 @@ def load_wav(path, sample_rate=None, top_db=15.0):
     return data * 0.99
 
 
+def metadata_path():
+    return os.path.join(hp.Train.Pattern_Path, hp.Train.Metadata_File.upper()).replace("\\", "/")
+
+
+def check_metadata(md):
+    """Feeder.py:46-56: the pattern set must have been generated with the current hyper parameters."""
+    if not all([len(md["Token_Index_Dict"]) == hp.Encoder.Embedding.Token_Size, md["Spectrogram_Dim"] == hp.Sound.Spectrogram_Dim,
+                md["Mel_Dim"] == hp.Sound.Mel_Dim, md["Frame_Shift"] == hp.Sound.Frame_Shift, md["Frame_Length"] == hp.Sound.Frame_Length,
+                md["Sample_Rate"] == hp.Sound.Sample_Rate]):
+        raise ValueError("The metadata information and hyper parameter setting are not consistent.")
+
+
+def train_file_order(md, is_Pre_Train=False):
+    """Feeder.py:89-112: files of the selected datasets whose mel length lies in Use_Wav_Length_Range (ms / Frame_Shift),
+    sorted by mel length when hp.Train.Pattern_Sorting_by_Mel_Length (stable, like `sorted`)."""
+    wanted = hp.Train.Pre_Train_Dataset_List if is_Pre_Train else hp.Train.Main_Train_Dataset_List
+    files = [f for f in md["File_List"] if md["Dataset_Dict"][f] in wanted]
+    lo, hi = hp.Train.Use_Wav_Length_Range[0] / hp.Sound.Frame_Shift, hp.Train.Use_Wav_Length_Range[1] / hp.Sound.Frame_Shift
+    sel = [(f, md["Mel_Length_Dict"][f]) for f in files if lo <= md["Mel_Length_Dict"][f] <= hi]
+    if hp.Train.Pattern_Sorting_by_Mel_Length:
+        sel = sorted(sel, key=lambda x: x[1])
+    return [f for f, _ in sel]
+
+
+def epoch_batches(path_List, rng):
+    """Feeder.py:114-123: one pass = (shuffle the files unless they are length-sorted) -> consecutive Batch_Size groups ->
+    shuffle the groups.  `rng` needs .shuffle (random or numpy RandomState)."""
+    path_List = list(path_List)
+    if not hp.Train.Pattern_Sorting_by_Mel_Length:
+        rng.shuffle(path_List)
+    batches = [path_List[x:x + hp.Train.Batch_Size] for x in range(0, len(path_List), hp.Train.Batch_Size)]
+    rng.shuffle(batches)
+    return batches
+
+
+def load_pattern_batch(file_names, token_dict, pattern_path=None):
+    """Feeder.py:132-172: pickled {'Token','Mel','Text','Dataset'} dicts -> one padded training pattern."""
+    import pickle
+    root = pattern_path or hp.Train.Pattern_Path
+    token_List, mel_List = [], []
+    for name in file_names:
+        with open(os.path.join(root, name).replace("\\", "/"), "rb") as f:
+            pd = pickle.load(f)
+        token_List.append(np.hstack([token_dict["<S>"], pd["Token"], token_dict["<E>"]]).astype(np.int32))
+        mel_List.append(np.asarray(pd["Mel"], np.float32))
+    B = len(file_names)
+    token = np.full((B, max(t.shape[0] for t in token_List)), token_dict["<E>"], np.int32)
+    mel = np.zeros((B, max(m.shape[0] for m in mel_List), hp.Sound.Mel_Dim), np.float32)
+    for i, (t, m) in enumerate(zip(token_List, mel_List)):
+        token[i, :t.shape[0]] = t
+        mel[i, :m.shape[0]] = m
+    return {"Is_Training": True, "Token": token, "Token_Length": np.array([t.shape[0] for t in token_List], np.int32), "Mel": mel,
+            "Mel_Length": np.array([m.shape[0] for m in mel_List], np.int32), "Speaker_Embedding_Mel": speaker_windows(mel_List)}
+
+
 class Feeder:
     """Same constructor / pattern API as the reference class; `placeholder_Dict` maps the reference's
-    placeholder names to themselves (there is no graph), patterns are dicts keyed by those names."""
+    placeholder names to themselves (there is no graph), patterns are dicts keyed by those names.
 
-    def __init__(self, is_Training=False, device="cuda"):
+    Training patterns come from the reference's on-disk format when hp.Train.Pattern_Path holds a METADATA.PICKLE
+    (Pattern_Generate.py:245-274): a daemon thread keeps up to hp.Train.Max_Pattern_Queue padded batches ready
+    (Feeder.py:89-184).  Without pattern files the feeder serves the synthetic benchmark pattern."""
+
+    def __init__(self, is_Training=False, device="cuda", seed=None):
         self.is_Training = is_Training
         self.device = device
         self.placeholder_Dict = {name: name for name in PLACEHOLDERS}
         self.metadata_Dict = {"Token_Index_Dict": load_token_dict()}
+        self.pattern_Queue = None
+        self._seed = seed
+        if is_Training and os.path.exists(metadata_path()):
+            self.Metadata_Load()
+            self._start_producers()
+
+    def Metadata_Load(self):
+        import pickle
+        with open(metadata_path(), "rb") as f:
+            self.metadata_Dict = pickle.load(f)
+        check_metadata(self.metadata_Dict)
+
+    def _start_producers(self):
+        from collections import deque
+        from threading import Thread
+        if hp.Train.Use_Pre_in_Main_Train:
+            self.pre_Pattern_Queue = deque()
+            Thread(target=self.Train_Pattern_Generate, args=[True], daemon=True).start()
+        self.pattern_Queue = deque()
+        Thread(target=self.Train_Pattern_Generate, args=[False], daemon=True).start()
+
+    def Train_Pattern_Generate(self, is_Pre_Train=False):
+        """Producer loop of Feeder.py:89-172 (runs forever in a daemon thread)."""
+        import random
+        import time
+        rng = random.Random(self._seed) if self._seed is not None else random
+        queue = self.pre_Pattern_Queue if is_Pre_Train else self.pattern_Queue
+        order = train_file_order(self.metadata_Dict, is_Pre_Train)
+        print("Pre train pattern info" if is_Pre_Train else "Main train pattern info", "\n",
+              "Total pattern count: {}".format(len(self.metadata_Dict["Mel_Length_Dict"])), "\n",
+              "Use pattern count: {}".format(len(order)), "\n",
+              "Excluded pattern count: {}".format(len(self.metadata_Dict["Mel_Length_Dict"]) - len(order)))
+        while order:
+            for names in epoch_batches(order, rng):
+                while len(queue) >= hp.Train.Max_Pattern_Queue:
+                    time.sleep(0.1)
+                queue.append(load_pattern_batch(names, self.metadata_Dict["Token_Index_Dict"]))
 
     def Speaker_Embedding_Mel(self, mel_List):
         return speaker_windows(mel_List)
@@ -152,8 +247,14 @@ class Feeder:
         }
 
     def Get_Train_Pattern(self, is_Pre_Train=False, batch_Size=None, token_Length=128, mel_Length=800, seed=1234):
-        """Synthetic pattern of the benchmark shape; the reference's pickle-backed
-        producer thread (Feeder.py:89-184) is out of scope for this path."""
+        """Feeder.py:174-184 when pattern files exist (blocks until the producer has a batch); otherwise the synthetic
+        pattern of the benchmark shape."""
+        if self.pattern_Queue is not None and batch_Size is None:
+            import time
+            queue = self.pre_Pattern_Queue if is_Pre_Train else self.pattern_Queue
+            while len(queue) == 0:
+                time.sleep(0.01)
+            return queue.popleft()
         B = batch_Size or hp.Train.Batch_Size
         g = np.random.default_rng(seed)
         token = g.integers(2, hp.Encoder.Embedding.Token_Size, size=(B, token_Length)).astype(np.int32)

@@ -185,10 +185,29 @@ class Tacotron2:
         res["Cut"] = cut
         if export:
             out_dir = os.path.join(hp.Inference_Path, "NPZ").replace("\\", "/")
+            wav_dir = os.path.join(hp.Inference_Path, "WAV").replace("\\", "/")
             try:
                 os.makedirs(out_dir, exist_ok=True)
+                os.makedirs(wav_dir, exist_ok=True)
                 for i, c in enumerate(cut):
                     np.savez_compressed(os.path.join(out_dir, "{}.IDX_{}.npz".format(prefix, i)), **c)
+                    self._export_wav(c["Spectrogram"], os.path.join(wav_dir, "{}.IDX_{}.WAV".format(prefix, i)))
             except OSError as e:      # the reference's default path is a Windows drive letter
                 print("Inference export skipped: {}".format(e))
         return res
+
+    @staticmethod
+    def _export_wav(spectrogram, path):
+        """Export_Inference_Mel_to_Spectrogram's WAV leg (MSTTS_SV.py:403-414): Griffin-Lim on the cut spectrogram."""
+        from . import Audio
+        name = os.path.basename(path)
+        if spectrogram.shape[0] <= 1:
+            print("WAV '{}' exporting failed. The exported spectrogram is too short.".format(name))
+            return
+        try:
+            if spectrogram.shape[1] != hp.Sound.Spectrogram_Dim:
+                raise ValueError("spectrogram width {} != hp.Sound.Spectrogram_Dim".format(spectrogram.shape[1]))
+            from scipy.io import wavfile
+            wavfile.write(path, hp.Sound.Sample_Rate, Audio.Griffin_Lim(spectrogram).astype(np.float32))
+        except Exception as e:       # the reference swallows and reports every export error
+            print("Wav exporting failed: {}".format(e))

@@ -106,3 +106,82 @@ def test_golden_fixtures_match_oracle():
     assert abs(sc["Loss"] - float(g["loss"])) < 1e-10
     k = "decoder/decoder/attention_wrapper/multi_rnn_cell/cell_0/zoneout_lstm_cell/kernel"
     assert np.allclose(grads[k].numpy(), g["grad_cell0"], rtol=0, atol=1e-12)
+
+
+def test_griffin_lim_export_path():
+    """Audio.inv_spectrogram / _stft / _istft (Audio.py:15-27,50-74): librosa conventions restated in NumPy.
+    iSTFT(STFT(y)) == y away from nothing (centre padding makes it exact everywhere), frame count = 1 + len // hop,
+    and Griffin-Lim on a real spectrogram converges to a signal with (nearly) that magnitude."""
+    from multi_speaker_tts_amd import Audio
+    args = (1025, 12.5, 50, 16000)
+    n_fft, hop, win = Audio._stft_parameters(*args)
+    assert (n_fft, hop, win) == (2048, 200, 800)
+    g = np.random.default_rng(0)
+    t = np.arange(16000 // 4) / 16000.0
+    # quiet enough that |STFT| < 10: the [0, 1] normalisation saturates at 0 dB after the 20 dB reference shift
+    y = 0.016 * np.sin(2 * np.pi * 440 * t) + 0.008 * np.sin(2 * np.pi * 1330 * t + 0.3) + 0.0004 * g.normal(size=t.shape)
+    D = Audio._stft(y, *args)
+    assert D.shape == (1025, 1 + len(y) // hop) and np.abs(D).max() < 10
+    back = Audio._istft(D, *args)
+    assert back.shape[0] == hop * (D.shape[1] - 1) and np.abs(back - y[:back.shape[0]]).max() < 1e-9
+    # normalised spectrogram of y -> waveform; compare magnitudes (phase is free)
+    M = np.abs(D)
+    S = np.clip((20 * np.log10(np.maximum(1e-5, M)) - 20 + 100) / 100, 0, 1)
+    wav = Audio.inv_spectrogram(S, *args, power=1.0, griffin_lim_iters=40, rng=np.random.RandomState(1))
+    assert wav.shape[0] == hop * (S.shape[1] - 1) and np.isfinite(wav).all()
+    from scipy import signal
+    M2 = np.abs(Audio._stft(signal.lfilter([1, -0.97], [1], wav), *args))          # undo inv_preemphasis
+    keep = slice(2, -2)                                                            # edge frames see the reflect padding
+    err = np.linalg.norm(M2[:, keep] - M[:, keep]) / np.linalg.norm(M[:, keep])
+    assert err < 0.2, err
+    assert np.allclose(Audio._denormalize(np.array([0.0, 0.5, 1.0, 2.0])), [-100, -50, 0, 0]) and np.isclose(Audio._db_to_amp(20.0), 10.0)
+
+
+def test_pickle_feeder_and_pattern_files(tmp_path, monkeypatch):
+    """The reference's on-disk pattern format and producer rules (Pattern_Generate.py:14-31,66-76,245-274; Feeder.py:43-56,89-184):
+    protocol-2 pickles, METADATA.PICKLE keys + consistency check, dataset and length filters, length-sorted consecutive
+    batches in shuffled order, <S>/<E> framing with <E> padding, zero-padded mels, speaker windows."""
+    import pickle
+    from multi_speaker_tts_amd import Hyper_Parameters as hp, Feeder as F, Pattern_Generate as PG
+    assert PG.Text_Filtering(' please call "Stella" .  ') == "PLEASE CALL STELLA ." and PG.Text_Filtering("naïve") is None
+    assert PG.Text_Filtering("'tis") is None and PG.Text_Filtering("Who knows ?") == "WHO KNOWS?"
+    root = tmp_path / "patterns"
+    monkeypatch.setattr(hp.Train, "Pattern_Path", str(root))
+    monkeypatch.setattr(hp.Train, "Batch_Size", 3)
+    monkeypatch.setattr(hp.Train, "Max_Pattern_Queue", 2)
+    td = F.load_token_dict()
+    g = np.random.default_rng(0)
+    lens = {"VCTK.A.PICKLE": 120, "VCTK.B.PICKLE": 60, "TIMIT.C.PICKLE": 300, "VCTK.D.PICKLE": 45, "VCTK.E.PICKLE": 200,
+            "LJ.F.PICKLE": 100, "VCTK.G.PICKLE": 30, "TIMIT.H.PICKLE": 721, "VCTK.I.PICKLE": 250}          # G too short (< 40 frames), H too long (> 720)
+    for name, n in lens.items():
+        PG.Pattern_File_Write(name, "HI %s." % name[-8], np.clip(g.normal(0, 1.5, (n, 80)), -4, 4), td, name.split(".")[0])
+    with open(root / "VCTK.A.PICKLE", "rb") as f:
+        raw = f.read()
+        pd = pickle.loads(raw)
+    assert raw[:2] == b"\x80\x02" and set(pd) == {"Token", "Mel", "Text", "Dataset"} and pd["Token"].dtype == np.int32 and pd["Mel"].dtype == np.float32
+    assert list(pd["Token"]) == [td[c] for c in "HI A."]
+    md = PG.Metadata_Generate()
+    assert set(md) == {"Token_Index_Dict", "Spectrogram_Dim", "Mel_Dim", "Frame_Shift", "Frame_Length", "Sample_Rate", "File_List",
+                       "Token_Length_Dict", "Mel_Length_Dict", "Dataset_Dict"} and len(md["File_List"]) == 9
+    order = F.train_file_order(md)
+    assert order == ["VCTK.D.PICKLE", "VCTK.B.PICKLE", "VCTK.A.PICKLE", "VCTK.E.PICKLE", "VCTK.I.PICKLE", "TIMIT.C.PICKLE"]    # LJ is pre-train only
+    assert F.train_file_order(md, is_Pre_Train=True) == ["LJ.F.PICKLE"]
+    import random
+    batches = F.epoch_batches(order, random.Random(1))
+    assert sorted(map(tuple, batches)) == sorted([tuple(order[:3]), tuple(order[3:])])
+    feeder = F.Feeder(is_Training=True, device="cpu", seed=3)
+    seen = []
+    for _ in range(4):                                      # two epochs
+        pat = feeder.Get_Train_Pattern()
+        B = pat["Token"].shape[0]
+        assert B == 3 and pat["Is_Training"] is True
+        assert (pat["Token"][:, 0] == 0).all() and all(pat["Token"][i, pat["Token_Length"][i] - 1] == 1 for i in range(B))
+        assert pat["Token_Length"].tolist() == [7, 7, 7] and pat["Mel"].shape == (3, pat["Mel_Length"].max(), 80)
+        for i in range(B):
+            assert (pat["Mel"][i, pat["Mel_Length"][i]:] == 0).all() and np.abs(pat["Mel"][i, :pat["Mel_Length"][i]]).max() > 0
+        assert pat["Speaker_Embedding_Mel"].shape == (15, 64, 80)
+        seen.append(tuple(pat["Mel_Length"].tolist()))
+    assert sorted(seen[:2]) == sorted([(45, 60, 120), (200, 250, 300)]) and sorted(seen[2:]) == sorted(seen[:2])
+    monkeypatch.setattr(hp.Sound, "Frame_Shift", 10.0)
+    with pytest.raises(ValueError):
+        F.Feeder(is_Training=True, device="cpu")

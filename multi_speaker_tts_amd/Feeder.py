@@ -187,6 +187,7 @@ class Feeder:
         self.metadata_Dict = {"Token_Index_Dict": load_token_dict()}
         self.pattern_Queue = None
         self._seed = seed
+        self._stop = False
         if is_Training and os.path.exists(metadata_path()):
             self.Metadata_Load()
             self._start_producers()
@@ -217,11 +218,22 @@ class Feeder:
               "Total pattern count: {}".format(len(self.metadata_Dict["Mel_Length_Dict"])), "\n",
               "Use pattern count: {}".format(len(order)), "\n",
               "Excluded pattern count: {}".format(len(self.metadata_Dict["Mel_Length_Dict"]) - len(order)))
-        while order:
+        root = hp.Train.Pattern_Path
+        while order and not self._stop:
             for names in epoch_batches(order, rng):
-                while len(queue) >= hp.Train.Max_Pattern_Queue:
+                while len(queue) >= hp.Train.Max_Pattern_Queue and not self._stop:
                     time.sleep(0.1)
-                queue.append(load_pattern_batch(names, self.metadata_Dict["Token_Index_Dict"]))
+                if self._stop:
+                    return
+                try:
+                    queue.append(load_pattern_batch(names, self.metadata_Dict["Token_Index_Dict"], pattern_path=root))
+                except OSError as e:
+                    print("Pattern producer stopped: {}".format(e))
+                    return
+
+    def close(self):
+        """Stop the producer threads (the reference's daemon threads die with the process)."""
+        self._stop = True
 
     def Speaker_Embedding_Mel(self, mel_List):
         return speaker_windows(mel_List)

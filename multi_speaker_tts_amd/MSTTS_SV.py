@@ -4,7 +4,7 @@ Same constructor and methods - ``Tacotron2(is_Training)``, ``Restore()``, ``Trai
 ``Inference(path_List, text_List, file_Prefix)`` - and the same result-dict keys
 (``train_Tensor_Dict`` / ``inference_Tensor_Dict`` names, MSTTS_SV.py:194-216).  The TensorFlow session is
 replaced by ``engine.TrainEngine`` / ``inference.InferEngine`` (libmstts_hip.so calls on one HIP stream).
-Out of scope here: matplotlib export threads, pickle feeder threads, TF checkpoint reading.
+Out of scope here: matplotlib PNG export.
 """
 from __future__ import annotations
 
@@ -69,6 +69,13 @@ class Tacotron2:
     def _load_scope(self, path, scope):
         f = os.path.join(path.replace("\\", "/"), "%s.pt" % scope)
         if not os.path.exists(f):
+            from . import tf_checkpoint as tfc
+            prefix = tfc.latest_checkpoint(path.replace("\\", "/"))
+            if prefix is not None:                       # a checkpoint of the reference's own sub-model trainer
+                vars_ = tfc.read_checkpoint(prefix)
+                self.params.load({k: v for k, v in vars_.items() if k.startswith(scope)})
+                print("%s TF checkpoint '%s' is loaded." % (scope, prefix))
+                return
             print("No %s checkpoint at '%s': keeping the random initialisation." % (scope, f))
             return
         values = torch.load(f, map_location="cpu")
@@ -79,7 +86,12 @@ class Tacotron2:
         d = self._ckpt_dir()
         steps = sorted(int(n.split("-")[1].split(".")[0]) for n in os.listdir(d) if n.startswith("CHECKPOINT-")) if os.path.isdir(d) else []
         if not steps:
-            print("There is no checkpoint.")
+            from . import tf_checkpoint as tfc
+            prefix = tfc.latest_checkpoint(d) if os.path.isdir(d) else None
+            if prefix is None:
+                print("There is no checkpoint.")
+                return
+            self.Import_TF_Checkpoint(prefix)
             return
         f = os.path.join(d, "CHECKPOINT-%d.pt" % steps[-1])
         state = torch.load(f, map_location="cpu")
@@ -88,6 +100,50 @@ class Tacotron2:
         self.train_engine.global_step = int(state["global_step"])
         self.train_engine.refresh_derived()
         print("Checkpoint '%s' is loaded." % f)
+
+    def Import_TF_Checkpoint(self, prefix):
+        """Restore from a checkpoint written by the reference's tf.train.Saver (MSTTS_SV.py:30-40,244-251): variables by
+        their TF names, Adam slots `<name>/Adam`, `<name>/Adam_1` (also under the optimizer's `loss/` scope), `global_step`."""
+        from . import tf_checkpoint as tfc
+        vars_ = tfc.read_checkpoint(prefix)
+        names = [n for n, _, _ in self.params.table if self.params.trainable[n]]
+        found = {n: vars_[n] for n in names if n in vars_}
+        found.update({n: vars_[n] for n, _, _ in self.params.table if n in vars_ and not n.startswith(("speaker_embedding", "mel_to_spectrogram"))})
+        self.params.load(found)
+        n_slots = 0
+        for n in names:
+            for store, suffix in ((self.params.adam_m, "/Adam"), (self.params.adam_v, "/Adam_1")):
+                for key in (n + suffix, "loss/" + n + suffix):
+                    if key in vars_:
+                        o, sz = self.params.offset[n], int(np.prod(self.params.shape[n]))
+                        store[o:o + sz].copy_(torch.from_numpy(np.asarray(vars_[key], np.float32).reshape(-1)))
+                        n_slots += 1
+                        break
+        if "global_step" in vars_:
+            self.train_engine.global_step = int(np.asarray(vars_["global_step"]).reshape(-1)[0])
+        self.train_engine.refresh_derived()
+        missing = [n for n in names if n not in vars_]
+        print("TF checkpoint '%s' is loaded: %d of %d trainable variables, %d optimizer slots, global step %d."
+              % (prefix, len(names) - len(missing), len(names), n_slots, self.global_step))
+        if missing:
+            print("  not in the checkpoint (kept as initialised): %s%s" % (", ".join(missing[:5]), " ..." if len(missing) > 5 else ""))
+
+    def Export_TF_Checkpoint(self, directory=None):
+        """Write the tacotron variables, Adam slots and global_step as a TF V2 checkpoint `CHECKPOINT-<step>` the
+        reference's Saver can restore (MSTTS_SV.py:289)."""
+        from . import tf_checkpoint as tfc
+        d = directory or self._ckpt_dir()
+        out = {k: v for k, v in self.params.export().items() if not k.startswith(("speaker_embedding", "mel_to_spectrogram", "waveglow"))}
+        m, v = self.params.adam_m.cpu().numpy(), self.params.adam_v.cpu().numpy()
+        for n, _, _ in self.params.table:
+            if self.params.trainable[n]:
+                o, sz = self.params.offset[n], int(np.prod(self.params.shape[n]))
+                out[n + "/Adam"] = m[o:o + sz].reshape(self.params.shape[n])
+                out[n + "/Adam_1"] = v[o:o + sz].reshape(self.params.shape[n])
+        out["global_step"] = np.array(self.global_step, np.int64)
+        prefix = os.path.join(d, "CHECKPOINT-%d" % self.global_step)
+        tfc.write_checkpoint(prefix, out)
+        return prefix
 
     def Save(self, keep=5):
         d = self._ckpt_dir()

@@ -182,6 +182,47 @@ def test_pickle_feeder_and_pattern_files(tmp_path, monkeypatch):
         assert pat["Speaker_Embedding_Mel"].shape == (15, 64, 80)
         seen.append(tuple(pat["Mel_Length"].tolist()))
     assert sorted(seen[:2]) == sorted([(45, 60, 120), (200, 250, 300)]) and sorted(seen[2:]) == sorted(seen[:2])
+    feeder.close()
     monkeypatch.setattr(hp.Sound, "Frame_Shift", 10.0)
     with pytest.raises(ValueError):
         F.Feeder(is_Training=True, device="cpu")
+
+
+def test_tf_checkpoint_bundle_format(tmp_path):
+    """TF V2 checkpoint (tensor bundle) reader/writer without TensorFlow: CRC-32C and snappy known answers, the table
+    layout (footer magic, block trailers, prefix-compressed keys over several blocks), dtype/shape/offset bookkeeping."""
+    import struct
+    from multi_speaker_tts_amd import tf_checkpoint as tfc
+    assert tfc.crc32c(b"123456789") == 0xE3069283                                   # the CRC-32C check value
+    assert tfc.mask_crc(0) == 0xA282EAD8 and tfc.crc32c(b"") == 0
+    assert tfc._snappy_decompress(bytes([0x0a, 0x00, 0x61, 0x15, 0x01])) == b"a" * 10
+    g = np.random.default_rng(0)
+    variables = {"encoder/conv_%d/conv1d/kernel" % i: g.normal(size=(5, 7, 3)).astype(np.float32) for i in range(40)}
+    variables.update({"encoder/embedding_variable": g.normal(size=(42, 16)).astype(np.float32), "global_step": np.array(1234567, np.int64),
+                      "decoder/x/bias": np.zeros((0,), np.float32), "lengths": np.arange(6, dtype=np.int32).reshape(2, 3),
+                      "encoder/embedding_variable/Adam": g.normal(size=(42, 16)).astype(np.float32)})
+    prefix = str(tmp_path / "ckpt" / "CHECKPOINT-1234567")
+    tfc.write_checkpoint(prefix, variables)
+    assert tfc.latest_checkpoint(str(tmp_path / "ckpt")) == prefix and tfc.latest_checkpoint(str(tmp_path)) is None
+    raw = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57
+    entries = tfc.list_variables(prefix)
+    assert entries.pop("__num_shards__") == 1 and set(entries) == set(variables)
+    assert entries["global_step"]["dtype"] == 9 and entries["global_step"]["shape"] == () and entries["lengths"]["dtype"] == 3
+    assert entries["encoder/embedding_variable"]["shape"] == (42, 16) and entries["encoder/embedding_variable"]["size"] == 42 * 16 * 4
+    keys = [k for k, _ in tfc.read_table(prefix + ".index")]
+    assert keys == sorted(keys) and keys[0] == b"" and len(keys) == len(variables) + 1
+    back = tfc.read_checkpoint(prefix)
+    assert all(np.array_equal(back[k], v) and back[k].dtype == v.dtype and back[k].shape == v.shape for k, v in variables.items())
+    some = tfc.read_checkpoint(prefix, names=["global_step", "nope"])
+    assert list(some) == ["global_step"] and int(some["global_step"]) == 1234567
+    # corruption is detected: flip one payload byte, then one index byte
+    data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read()); data[10] ^= 0xFF
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    with pytest.raises(ValueError):
+        tfc.read_checkpoint(prefix)
+    assert np.array_equal(tfc.read_checkpoint(prefix, names=["lengths"])["lengths"], variables["lengths"])
+    idx = bytearray(raw); idx[20] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError):
+        tfc.read_table(prefix + ".index")

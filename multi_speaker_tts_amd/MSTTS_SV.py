@@ -84,7 +84,7 @@ class Tacotron2:
 
     def Restore(self):
         d = self._ckpt_dir()
-        steps = sorted(int(n.split("-")[1].split(".")[0]) for n in os.listdir(d) if n.startswith("CHECKPOINT-")) if os.path.isdir(d) else []
+        steps = sorted(int(n.split("-")[1].split(".")[0]) for n in os.listdir(d) if n.startswith("CHECKPOINT-") and n.endswith(".pt")) if os.path.isdir(d) else []
         if not steps:
             from . import tf_checkpoint as tfc
             prefix = tfc.latest_checkpoint(d) if os.path.isdir(d) else None
@@ -152,7 +152,7 @@ class Tacotron2:
                     if not k.startswith(("speaker_embedding", "mel_to_spectrogram", "waveglow"))}
         torch.save({"variables": tacotron, "adam_m": self.params.adam_m.cpu(), "adam_v": self.params.adam_v.cpu(),
                     "global_step": self.global_step}, os.path.join(d, "CHECKPOINT-%d.pt" % self.global_step))
-        old = sorted(int(n.split("-")[1].split(".")[0]) for n in os.listdir(d) if n.startswith("CHECKPOINT-"))
+        old = sorted(int(n.split("-")[1].split(".")[0]) for n in os.listdir(d) if n.startswith("CHECKPOINT-") and n.endswith(".pt"))
         for s in old[:-keep]:
             os.remove(os.path.join(d, "CHECKPOINT-%d.pt" % s))
 

@@ -379,6 +379,19 @@ def test_tacotron2_surface(dev, tmp_path, monkeypatch):
     t.Restore()
     after = t.params.export()
     assert t.global_step == 2 and all(np.array_equal(before[k], after[k]) for k in before if k.startswith(("encoder", "decoder", "attention")))
+    # the reference's own checkpoint format (TF V2 bundle): export, then Restore() from a directory holding only that
+    import shutil
+    tf_dir = tmp_path / "tfckpt"
+    prefix = t.Export_TF_Checkpoint(str(tf_dir))
+    assert (tf_dir / "checkpoint").exists() and prefix.endswith("CHECKPOINT-2")
+    m_before, v_before = t.params.adam_m.clone(), t.params.adam_v.clone()
+    t.params.train.zero_(); t.params.adam_m.zero_(); t.params.adam_v.zero_(); t.train_engine.global_step = 0
+    monkeypatch.setattr(hp, "Checkpoint_Path", str(tf_dir))
+    t.Restore()
+    again = t.params.export()
+    assert t.global_step == 2 and all(np.array_equal(before[k], again[k]) for k in before if k.startswith(("encoder", "decoder", "attention")))
+    assert torch.equal(t.params.adam_m, m_before) and torch.equal(t.params.adam_v, v_before)
+    monkeypatch.setattr(hp, "Checkpoint_Path", str(tmp_path / "ckpt"))
     mels = [np.clip(np.random.default_rng(i).normal(0, 1.5, (230, 80)), -4, 4).astype(np.float32) for i in range(2)]
     res = t.Inference(None, ["Please call Stella.", "Who knows?"], speaker_Mel_List=mels)
     S = res["Linear"].shape[1]

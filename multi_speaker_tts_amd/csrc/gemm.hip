@@ -144,7 +144,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     float* Bs = smem + A_FLOATS;
 
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    // XCD-aware tile order: block b runs on XCD b % 8 and every XCD has its own L2, so give each XCD a contiguous range
+    // of the (tile_m-major) tile list - a band of A rows it re-reads from its own L2 - instead of every eighth tile.
+    int tile = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = tile & 7, idx = tile >> 3;
+        if (nb >= 64) tile = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int batch = blockIdx.z / g.split_k, split = blockIdx.z % g.split_k;
     const float* A = g.A + (long)batch * g.stride_a;
     const float* B = g.B + (long)batch * g.stride_b;

@@ -93,6 +93,13 @@ int mstts_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t
 int mstts_maxpool2_same(const float* x, float* y, int64_t B, int64_t T, int64_t C, mstts_stream_t s);
 /* highway combine (Taco1 Modules.py:54-72): y = H*T + x*(1-T) with H=relu(h_pre), T=sigmoid(t_pre) */
 int mstts_highway_combine(const float* h_pre, const float* t_pre, const float* x, float* y, int64_t n, mstts_stream_t s);
+/* backward of the two above and the Taco1 trainer's loss (Taco1_Mel_to_Spect/Modules.py:28-33,54-72,107-108; training path of
+ * Taco1_Mel_to_Spect.py:24-100): max-pool gradient goes to the first maximum of each window; l1: loss = mean |pred - target|
+ * (tf.losses.absolute_difference), d_pred = sign(pred - target) / n (may be NULL) */
+int mstts_maxpool2_same_bwd(const float* x, const float* dy, float* dx, int64_t B, int64_t T, int64_t C, mstts_stream_t s);
+int mstts_highway_combine_bwd(const float* h_pre, const float* t_pre, const float* x, const float* dy, float* dh_pre, float* dt_pre,
+                              float* dx, int64_t n, mstts_stream_t s);
+int mstts_l1_loss_fwd_bwd(const float* pred, const float* target, int64_t n, float* loss, float* d_pred, mstts_stream_t s);
 
 /* ---- ZoneoutLSTMCell (ZoneoutLSTMCell.py:188-271), one time step for all rows -----------------
  * gates_pre = gates_h[B,4H] (+ xw row) (+ bias);  i,j,f,o = split;  c = sig(f+1)*c_prev + sig(i)*tanh(j);

@@ -242,6 +242,40 @@ __global__ void highway_kernel(const float* __restrict__ hp, const float* __rest
         y[i] = H * T + x[i] * (1.f - T);
     }
 }
+// max_pooling1d(2, stride 1, 'same') backward: y[t] = max(x[t], x[t+1]); the gradient goes to the first maximum (x[t] on ties)
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long B, long T, long C) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < B * T * C; i += (long)gridDim.x * blockDim.x) {
+        const long t = (i / C) % T;
+        const float xv = x[i];
+        float g = 0.f;
+        if (t + 1 >= T || xv >= x[i + C]) g += dy[i];              // window t = {t, t+1}: x[t] wins (or is alone)
+        if (t > 0 && xv > x[i - C]) g += dy[i - C];                 // window t-1 = {t-1, t}: x[t] wins strictly
+        dx[i] = g;
+    }
+}
+// highway combine backward: y = H*T + x*(1-T), H = relu(h), T = sigmoid(t)
+__global__ void highway_bwd_kernel(const float* __restrict__ hp, const float* __restrict__ tp, const float* __restrict__ x,
+                                   const float* __restrict__ dy, float* __restrict__ dh, float* __restrict__ dt, float* __restrict__ dx, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float h = hp[i], H = fmaxf(h, 0.f), T = sigmoid_acc(tp[i]), g = dy[i];
+        dh[i] = h > 0.f ? g * T : 0.f;
+        dt[i] = g * (H - x[i]) * T * (1.f - T);
+        dx[i] = g * (1.f - T);
+    }
+}
+// tf.losses.absolute_difference: mean |p - t| over all elements; d/dp = sign(p - t) / n
+__global__ void l1_loss_kernel(const float* __restrict__ p, const float* __restrict__ t, long n, float inv_n, float* __restrict__ loss,
+                               float* __restrict__ dp) {
+    __shared__ float scratch[16];
+    float acc = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = p[i] - t[i];
+        acc += fabsf(d);
+        if (dp) dp[i] = (d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f));
+    }
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) atomicAdd(loss, acc * inv_n);
+}
 __global__ void fold_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, long cols, long r0, long n) {
     const long out_rows = rows - n;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < out_rows * cols; i += (long)gridDim.x * blockDim.x) {
@@ -766,6 +800,27 @@ extern "C" int mstts_highway_combine(const float* h_pre, const float* t_pre, con
     if (n == 0) return MSTTS_OK;
     hipLaunchKernelGGL(highway_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), h_pre, t_pre, x, y, (long)n);
     MSTTS_CHECK_LAUNCH("highway_combine");
+    return MSTTS_OK;
+}
+extern "C" int mstts_maxpool2_same_bwd(const float* x, const float* dy, float* dx, int64_t B, int64_t T, int64_t C, mstts_stream_t s) {
+    if (B * T * C == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(B * T * C, 256)), dim3(256), 0, ST(s), x, dy, dx, (long)B, (long)T, (long)C);
+    MSTTS_CHECK_LAUNCH("maxpool2_same_bwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_highway_combine_bwd(const float* h_pre, const float* t_pre, const float* x, const float* dy, float* dh_pre, float* dt_pre,
+                                         float* dx, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), h_pre, t_pre, x, dy, dh_pre, dt_pre, dx, (long)n);
+    MSTTS_CHECK_LAUNCH("highway_combine_bwd");
+    return MSTTS_OK;
+}
+extern "C" int mstts_l1_loss_fwd_bwd(const float* pred, const float* target, int64_t n, float* loss, float* d_pred, mstts_stream_t s) {
+    MSTTS_REQUIRE(pred && target && loss && n >= 1, MSTTS_ERR_SHAPE, "l1_loss: bad arguments");
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), ST(s));
+    if (e != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "l1_loss: memset failed");
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), pred, target, (long)n, 1.f / (float)n, loss, d_pred);
+    MSTTS_CHECK_LAUNCH("l1_loss_fwd_bwd");
     return MSTTS_OK;
 }
 extern "C" int mstts_fold_rows(const float* src, float* dst, int64_t rows, int64_t cols, int64_t r0, int64_t n, mstts_stream_t s) {

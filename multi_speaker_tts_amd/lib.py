@@ -105,6 +105,9 @@ SIGNATURES = {
     "mstts_copy2d": (i32, [vp, i64, vp, i64, i64, i64, i32, vp]),
     "mstts_maxpool2_same": (i32, [vp, vp, i64, i64, i64, vp]),
     "mstts_highway_combine": (i32, [vp, vp, vp, vp, i64, vp]),
+    "mstts_maxpool2_same_bwd": (i32, [vp, vp, vp, i64, i64, i64, vp]),
+    "mstts_highway_combine_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "mstts_l1_loss_fwd_bwd": (i32, [vp, vp, i64, vp, vp, vp]),
     "mstts_lstm_point_fwd": (i32, [P(LstmPointFwd), vp]),
     "mstts_lstm_point_bwd": (i32, [P(LstmPointBwd), vp]),
     "mstts_lsa_energy_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp]),

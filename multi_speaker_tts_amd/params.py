@@ -194,14 +194,18 @@ class ParamStore:
     """Two flat fp32 slabs on the device + named views.  Offsets are multiples of 4 floats so every
     variable starts 16-byte aligned (the kernels' float4 paths rely on it)."""
 
-    def __init__(self, d: Dims, device, seed=1234, values=None):
+    def __init__(self, d: Dims, device, seed=1234, values=None, trainable_fn=None, weight_reg_fn=None):
+        """trainable_fn / weight_reg_fn: name -> bool; default = the Tacotron2 trainer's sets (MSTTS_SV.py:145-159,183-190).
+        The auxiliary trainers pass their own (e.g. the `mel_to_spectrogram` scope for the Taco1 vocoder trainer)."""
         self.dims = d
         self.table = variable_table(d)
+        trainable_fn = trainable_fn or is_trainable
+        weight_reg_fn = weight_reg_fn or in_weight_reg
         self.offset, self.shape, self.trainable = {}, {}, {}
         n_t = n_f = 0
         for name, shape, _ in self.table:
             n = int(np.prod(shape))
-            tr = is_trainable(name)
+            tr = bool(trainable_fn(name))
             self.trainable[name] = tr
             self.shape[name] = tuple(shape)
             if tr:
@@ -218,7 +222,7 @@ class ParamStore:
         self.adam_v = torch.zeros(n_t, dtype=torch.float32, device=device)
         wd = np.zeros(n_t, np.uint8)
         for name, shape, _ in self.table:
-            if in_weight_reg(name):
+            if self.trainable[name] and weight_reg_fn(name):
                 o = self.offset[name]
                 wd[o:o + int(np.prod(shape))] = 1
         self.wd_mask = torch.from_numpy(wd).to(device)

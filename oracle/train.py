@@ -153,3 +153,43 @@ def synthetic_batch(d: M.Dims, B, T_enc, L, seed=1234, rank=0, ragged=False):
     return {"Token": torch.from_numpy(tok), "Token_Length": torch.from_numpy(tl),
             "Mel": torch.from_numpy(mel), "Mel_Length": torch.from_numpy(ml),
             "Speaker_Embedding": torch.from_numpy(spk)}
+
+
+# ---- Taco1 mel -> spectrogram trainer (Taco1_Mel_to_Spect/Taco1_Mel_to_Spect.py:24-100) ------------------------------------------
+def taco1_in_weight_reg(name):
+    """:45-53: every trainable variable whose lower-cased name has none of 'bias', 'lstm', 'rnn'."""
+    low = name.lower()
+    return not any(s in low for s in ("bias", "lstm", "rnn"))
+
+
+def taco1_train_step(params, opt_state, d, mel, spectrogram, masks, global_step, dtype=torch.float64, wr_rate=1e-6,
+                     lr_kw=None, return_grads=False):
+    """One Mel_to_Spect.Train iteration: loss = mean|pred - spectrogram| (tf.losses.absolute_difference, :58) + wr_rate * sum
+    l2_loss; TF-Adam (eps 1e-6) with the :63-69 learning-rate schedule; BN moving statistics ride along (UPDATE_OPS :80)."""
+    p = {k: (v.detach().clone().to(dtype) if torch.is_tensor(v) else torch.tensor(np.asarray(v), dtype=dtype)) for k, v in params.items()}
+    names = [k for k in p if k.startswith(M.P_V) and not k.endswith(("moving_mean", "moving_variance"))]
+    for k in names:
+        p[k].requires_grad_(True)
+    stats = {}
+    pred = M.taco1_forward(p, d, mel.to(dtype), True, masks, stats)
+    l1 = (pred - spectrogram.to(dtype)).abs().mean()
+    wr = wr_rate * sum(0.5 * (p[k] ** 2).sum() for k in names if taco1_in_weight_reg(k))
+    loss = l1 + wr
+    grads = dict(zip(names, torch.autograd.grad(loss, [p[k] for k in names])))
+    lr = learning_rate(global_step, **(lr_kw or dict(initial=1e-3, minimum=1e-5, decay_start=50000, decay_step=100, decay_rate=0.5)))
+    if opt_state is None:
+        opt_state = {"m": {k: torch.zeros_like(p[k]) for k in names}, "v": {k: torch.zeros_like(p[k]) for k in names}}
+    new_p, new_m, new_v = {}, {}, {}
+    with torch.no_grad():
+        for k in p:
+            if k in grads:
+                new_p[k], new_m[k], new_v[k] = adam_tf(p[k].detach(), grads[k], opt_state["m"][k].to(dtype), opt_state["v"][k].to(dtype), global_step + 1, lr)
+            elif k in stats:
+                new_p[k] = stats[k]
+            else:
+                new_p[k] = p[k].detach()
+    sc = {"Loss": float(loss.detach()), "L1_Loss": float(l1.detach()), "Weight_Regularization_Loss": float(wr.detach()), "Learning_Rate": lr}
+    ret = (new_p, {"m": new_m, "v": new_v}, sc)
+    if return_grads:
+        ret = ret + (grads, pred.detach())
+    return ret

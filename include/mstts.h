@@ -281,6 +281,14 @@ int mstts_wg_coupling_inv(const float* audio, const float* log_s_b, const float*
                           int64_t rows, int64_t c, int64_t c_early, mstts_stream_t s);
 int mstts_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t stream_id, float sigma, mstts_stream_t s);
 
+/* ---- GE2E loss of the speaker-encoder trainer, forward + backward (Speaker_Embedding/Modules.py:39-98, "Softmax" method):
+ * x [N = S*P, D] = last-frame outputs of the LSTM stack, speaker-major (P consecutive rows per speaker), rows ldx apart;
+ * wb = {weight, bias} of the scaled cosine similarity.  out[0] = loss, out[1] = d/d weight, out[2] = d/d bias (identically 0);
+ * dx [N, D] rows lddx apart = d loss / d x (through tf.nn.l2_normalize(axis=1)).  ws: mstts_ge2e_ws_floats(N, D, S) floats. */
+int64_t mstts_ge2e_ws_floats(int64_t N, int64_t D, int64_t S);
+int mstts_ge2e_loss_fwd_bwd(const float* x, int64_t ldx, int64_t S, int64_t P, int64_t D, const float* wb, float* out,
+                            float* dx, int64_t lddx, float* ws, mstts_stream_t s);
+
 /* ---- LSTM weight utilities --------------------------------------------------------------------
  * fold_rows: dst[r,:] = src[r,:] for r<r0 ; dst[r0+i,:] = src[r0+i,:] + src[r0+n+i,:] (i<n) ; rest shifted up.
  * Used for the decoder cell-0 kernel whose context rows appear twice. */

@@ -134,6 +134,8 @@ SIGNATURES = {
     "mstts_stft_mel": (i32, [vp, i64, f32, vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, vp]),
     "mstts_stft_mel_ws_floats": (i64, [i64, i32, i64]),
     "mstts_fold_rows": (i32, [vp, vp, i64, i64, i64, i64, vp]),
+    "mstts_ge2e_ws_floats": (i64, [i64, i64, i64]),
+    "mstts_ge2e_loss_fwd_bwd": (i32, [vp, i64, i64, i64, i64, vp, vp, vp, i64, vp, vp]),
     "mstts_wg_overlap_add": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "mstts_wg_gate": (i32, [vp, i64, vp, i64, i64, vp]),
     "mstts_wg_res_skip": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, vp]),

@@ -193,3 +193,66 @@ def taco1_train_step(params, opt_state, d, mel, spectrogram, masks, global_step,
     if return_grads:
         ret = ret + (grads, pred.detach())
     return ret
+
+
+# ---- GE2E speaker-encoder trainer (Speaker_Embedding/Speaker_Embedding.py:27-80, Modules.py:6-98) -----------------------------
+def speaker_stack(p, d, mel, training, masks=None):
+    """Restructure + Stack_LSTM (Modules.py:6-37): dense 80 -> 256, three zoneout LSTMs, residual wrappers on cells 0 and 1.
+    Returns the outputs [N, T, spk]."""
+    masks = masks or {}
+    x = mel @ p[M.P_S + "dense/kernel"] + p[M.P_S + "dense/bias"]
+    for i in range(d.spk_lstm_n):
+        pre = M.P_S + "lstm/rnn/multi_rnn_cell/cell_%d/lstmcell_%d/" % (i, i)
+        x = M.run_lstm(x, None, p[pre + "kernel"], p[pre + "bias"], d.spk_lstm, masks.get("s_zc_%d" % i), masks.get("s_zh_%d" % i),
+                       d.zoneout, training, residual=(i < d.spk_lstm_n - 1))
+    return x
+
+
+def ge2e_loss(x_last, P, w, b):
+    """Embedding_Generate + Loss, 'Softmax' method (Modules.py:39-98).  x_last [S*P, D], speaker-major."""
+    e = x_last * torch.rsqrt(torch.clamp((x_last * x_last).sum(dim=1, keepdim=True), min=1e-12))
+    N, D = e.shape
+    S = N // P
+    r = e.reshape(S, P, D)
+    tot = r.sum(dim=1, keepdim=True)
+    cw = (tot - r) / (P - 1)
+    cb = r.mean(dim=1)
+    cos = lambda a, c: (a * c).sum(-1) / (torch.sqrt((a ** 2).sum(-1)) * torch.sqrt((c ** 2).sum(-1)))
+    within = w * cos(r, cw) - b                                                                   # [S,P]
+    tx, ty = e[:, None, :], cb[None, :, :]
+    cos2 = (ty * tx).sum(2) / (torch.sqrt((ty ** 2).sum(2)) * torch.sqrt((tx ** 2).sum(2)) + 1e-8)   # [N,S]
+    between = (w * cos2 - b).reshape(S, P, S)
+    keep = ~torch.eye(S, dtype=torch.bool)[:, None, :].expand(S, P, S)
+    between = between[keep].reshape(S, P, S - 1)
+    logits = torch.cat([within[..., None], between], dim=-1)
+    return -(torch.log_softmax(logits, dim=-1)[..., 0]).mean()
+
+
+def speaker_train_step(params, loss_vars, opt_state, d, mel, P, masks, global_step, dtype=torch.float64, lr_kw=None, return_grads=False):
+    """One Speaker_Embedding.Train iteration: plain Adam(eps 1e-8).minimize (the clipped train op of :62-66 is overwritten by
+    :69-72), learning rate = max(exponential_decay, Min) (:46-52).  loss_vars = {'loss/weight': 10, 'loss/bias': -5}."""
+    p = {k: (v.detach().clone().to(dtype) if torch.is_tensor(v) else torch.tensor(np.asarray(v), dtype=dtype)) for k, v in params.items()}
+    lv = {k: torch.tensor(float(v), dtype=dtype, requires_grad=True) for k, v in loss_vars.items()}
+    names = [k for k in p if k.startswith(M.P_S)]
+    for k in names:
+        p[k].requires_grad_(True)
+    out = speaker_stack(p, d, mel.to(dtype), True, masks)
+    loss = ge2e_loss(out[:, -1, :], P, lv["loss/weight"], lv["loss/bias"])
+    allv = [p[k] for k in names] + [lv["loss/weight"], lv["loss/bias"]]
+    g = torch.autograd.grad(loss, allv, allow_unused=True)
+    grads = {k: (gg if gg is not None else torch.zeros_like(v)) for k, gg, v in zip(names + ["loss/weight", "loss/bias"], g, allv)}
+    kw = lr_kw or dict(initial=1e-3, minimum=1e-5, decay_step=10000, decay_rate=0.5)
+    lr = max(kw["initial"] * kw["decay_rate"] ** (global_step / kw["decay_step"]), kw["minimum"])
+    if opt_state is None:
+        opt_state = {"m": {k: torch.zeros_like(v) for k, v in grads.items()}, "v": {k: torch.zeros_like(v) for k, v in grads.items()}}
+    new_p, new_lv, new_m, new_v = dict(p), {}, {}, {}
+    with torch.no_grad():
+        for k in names:
+            new_p[k], new_m[k], new_v[k] = adam_tf(p[k].detach(), grads[k], opt_state["m"][k].to(dtype), opt_state["v"][k].to(dtype), global_step + 1, lr, eps=1e-8)
+        for k in lv:
+            new_lv[k], new_m[k], new_v[k] = adam_tf(lv[k].detach(), grads[k], opt_state["m"][k].to(dtype), opt_state["v"][k].to(dtype), global_step + 1, lr, eps=1e-8)
+        new_p = {k: v.detach() for k, v in new_p.items()}
+    ret = (new_p, {k: float(v) for k, v in new_lv.items()}, {"m": new_m, "v": new_v}, {"Loss": float(loss.detach()), "Learning_Rate": lr})
+    if return_grads:
+        ret = ret + (grads, out.detach())
+    return ret

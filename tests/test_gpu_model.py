@@ -252,7 +252,8 @@ def _engine_vs_oracle(dev, B, Te, L, ragged, seed, **dims_kw):
 MID = dict(dec_lstm=64, enc_lstm=32, spk=64, prenet=32)      # shapes on which the skinny K-split kernels are active
 
 
-@pytest.mark.parametrize("B,Te,L,ragged,kw", [(3, 9, 6, False, {}), (4, 21, 13, True, {}), (5, 18, 9, True, MID), (16, 12, 7, True, MID)])
+@pytest.mark.parametrize("B,Te,L,ragged,kw", [(3, 9, 6, False, {}), (4, 21, 13, True, {}), (5, 18, 9, True, MID), (16, 12, 7, True, MID),
+                                                (1, 2, 1, False, {}), (2, 140, 3, True, MID)])       # smallest batch/lengths; more tokens than one attention pass
 def test_train_step_parity(dev, B, Te, L, ragged, kw):
     eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, ragged, seed=11, **kw)
     tol = 1e-3    # north_star: within 1e-3 relative on fp32 mels

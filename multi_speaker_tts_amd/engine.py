@@ -32,10 +32,20 @@ def learning_rate(step):
     return min(max(lr, lr_hp.Min), lr_hp.Initial)
 
 
-def _split_k(M, N, K):
+def _split_k(M, N, K, n_cu=256, max_split=16):
+    """Reduction split of a weight-gradient GEMM (atomic accumulation into the gradient slab).  128x128 output tiles are
+    spread round-robin over the CUs, so a CU runs ceil(tiles * sk / n_cu) workgroups of K / sk each: pick the sk with the
+    least work on the busiest CU (448 tiles: sk = 4 -> 7 per CU exactly, 127 TFLOP/s, where sk = 2 leaves 3.5 -> 4 per CU,
+    107 TFLOP/s; tools/gemm_split_probe.py), with a small per-split charge for the atomics."""
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
-    sk = max(1, min(math.ceil(512 / tiles), K // 512))
-    return sk
+    best, best_cost = 1, None
+    for sk in range(1, max_split + 1):
+        if sk > 1 and K // sk < 512:
+            break
+        cost = math.ceil(tiles * sk / n_cu) / sk + 0.004 * sk
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = sk, cost
+    return best
 
 
 class _WS:

@@ -289,6 +289,21 @@ int64_t mstts_ge2e_ws_floats(int64_t N, int64_t D, int64_t S);
 int mstts_ge2e_loss_fwd_bwd(const float* x, int64_t ldx, int64_t S, int64_t P, int64_t D, const float* wb, float* out,
                             float* dx, int64_t lddx, float* ws, mstts_stream_t s);
 
+/* ---- bf16 variants of the skinny products (BASELINE config 3, "bf16 with fp32 master"): the kernel W is a packed bf16 copy made by
+ * mstts_pack_bf16_fwd / _bwd from the fp32 master (round to nearest even; lane-consumption order, opaque), the activation block is
+ * rounded to bf16 on the way into LDS, accumulation and the partial slabs are fp32:
+ *   fwd: P[ks][M][N] = bf(X[M, K-slice ks]) . bf(W[K-slice ks, N])      N % 64 == 0, K % (64*ksplit) == 0, K/ksplit <= 512
+ *   bwd: P[ns][M][R] = bf(dG[M, N-slice ns]) . bf(W[R, N-slice ns])^T   R % 32 == 0, N % (64*nsplit) == 0, N/nsplit <= 1024
+ * The split counts are baked into the packed layout: pack and multiply with the same value (mstts_skinny_bf16_*_splits). */
+int32_t mstts_skinny_bf16_fwd_splits(int64_t N, int64_t K);
+int32_t mstts_skinny_bf16_bwd_splits(int64_t R, int64_t N);
+int mstts_pack_bf16_fwd(const float* W, int64_t ldw, void* Wp, int64_t K, int64_t N, int32_t ksplit, mstts_stream_t s);
+int mstts_pack_bf16_bwd(const float* W, int64_t ldw, void* Wq, int64_t R, int64_t N, int32_t nsplit, mstts_stream_t s);
+int mstts_skinny_fwd_bf16(const float* X, int64_t ldx, const void* Wp, float* P, int64_t pstride, int64_t M, int64_t N, int64_t K,
+                          int32_t ksplit, mstts_stream_t s);
+int mstts_skinny_bwd_bf16(const float* dG, int64_t ldg, const void* Wq, float* P, int64_t pstride, int64_t M, int64_t R, int64_t N,
+                          int32_t nsplit, mstts_stream_t s);
+
 /* ---- LSTM weight utilities --------------------------------------------------------------------
  * fold_rows: dst[r,:] = src[r,:] for r<r0 ; dst[r0+i,:] = src[r0+i,:] + src[r0+n+i,:] (i<n) ; rest shifted up.
  * Used for the decoder cell-0 kernel whose context rows appear twice. */
@@ -360,7 +375,13 @@ typedef struct {
     float* gates_ws; float* energy_ws;      /* [parts,B,4H] (parts = max skinny K-splits, see mstts_decoder_train_ws_floats), 2*B*T+2 floats (8-byte aligned) */
     float* q_ws;                            /* [parts,B,A] query partials */
     int32_t chains;                         /* independent row groups run on separate HIP streams (0/1 = one; must divide B) */
+    /* optional bf16 mode of the recurrent products (BASELINE config 3): packed bf16 copies of w0f / w1 / wq made with
+     * mstts_pack_bf16_fwd (first three) and mstts_pack_bf16_bwd (last three) using the split counts of
+     * mstts_decoder_bf16_splits(H, M, A, out[6]); all six non-NULL -> cell / query products and their data gradients run
+     * as bf(X).bf(W) with fp32 accumulation, everything else stays fp32 */
+    const void* bf_w0f_f; const void* bf_w1_f; const void* bf_wq_f; const void* bf_w0f_b; const void* bf_w1_b; const void* bf_wq_b;
 } mstts_decoder_train_desc;
+int32_t mstts_decoder_bf16_splits(int64_t H, int64_t M, int64_t A, int32_t* out6);
 /* floats needed for gates_ws (*gates) and q_ws (*q) */
 int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q);
 int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s);

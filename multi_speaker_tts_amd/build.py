@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmstts_hip.so")
-SOURCES = ["gemm.hip", "skinny.hip", "elementwise.hip", "lsa.hip", "decoder.hip", "audio.hip", "waveglow.hip", "ge2e.hip"]
+SOURCES = ["gemm.hip", "skinny.hip", "elementwise.hip", "lsa.hip", "decoder.hip", "audio.hip", "waveglow.hip", "ge2e.hip", "skinny_bf16.hip"]
 
 
 def _hipcc():

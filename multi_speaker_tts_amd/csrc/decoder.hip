@@ -91,6 +91,44 @@ static int xw_bwd(const float* dG, long ldg, const float* W, long ldw, float* P,
     return gemm(dG, ldg, W, ldw, 1, P, R, M, R, N, nullptr, 0, 0, s);
 }
 
+// ---- bf16 recurrent products (BASELINE config 3): split counts capped by the fp32 path's, so every workspace / slab count the
+// caller sized for fp32 also holds the bf16 path; the counts are baked into the packed kernels, hence exported.
+static int bf_fwd_split(long N, long K, int cap) {
+    if (N % 64 != 0 || K % 64 != 0 || cap < 1) return 0;
+    const long strips = N / 64, units = K / 64;
+    long best = 0, best_d = 1L << 40;
+    for (long ks = 1; ks <= cap && ks <= units; ++ks) {
+        if (units % ks != 0 || K / ks > 512) continue;
+        const long dd = labs(strips * ks - 512);
+        if (dd < best_d) { best_d = dd; best = ks; }
+    }
+    return (int)best;
+}
+static int bf_bwd_split(long R, long N, int cap) {
+    if (R % 32 != 0 || N % 64 != 0 || cap < 1) return 0;
+    const long strips = R / 32, units = N / 64;
+    long best = 0, best_d = 1L << 40;
+    for (long ns = 1; ns <= cap && ns <= units; ++ns) {
+        if (units % ns != 0 || N / ns > 1024) continue;
+        const long dd = labs(strips * ns - 512);
+        if (dd < best_d) { best_d = dd; best = ns; }
+    }
+    return (int)best;
+}
+/* out = {fwd cell0, fwd cell1, fwd query, bwd cell0, bwd cell1, bwd query}; returns 1 when the bf16 decoder path can run */
+extern "C" int32_t mstts_decoder_bf16_splits(int64_t H, int64_t M, int64_t A, int32_t* out) {
+    const long W0 = M + H, W1 = 2 * H;
+    const int c0 = mstts_skinny_fwd_splits(4 * H, W0), c1 = mstts_skinny_fwd_splits(4 * H, W1), cq = mstts_skinny_fwd_splits(A, H);
+    const int d0 = mstts_skinny_bwd_splits(W0, 4 * H), d1 = mstts_skinny_bwd_splits(W1, 4 * H), dq = mstts_skinny_bwd_splits(H, A);
+    int v[6] = {bf_fwd_split(4 * H, W0, c0), bf_fwd_split(4 * H, W1, c1), bf_fwd_split(A, H, cq),
+                d0 > 0 ? bf_bwd_split(W0, 4 * H, d0) : 0, bf_bwd_split(W1, 4 * H, d1), bf_bwd_split(H, A, dq > 1 ? dq : 1)};
+    // the d_in0 slabs are counted by the caller (mstts_decoder_train_bwd_parts): the bf16 product must write exactly as many
+    if (v[3] != d0) v[3] = (d0 > 0 && (4 * H) % (64L * d0) == 0 && 4 * H / d0 <= 1024 && W0 % 32 == 0) ? d0 : 0;
+    int ok = 1;
+    for (int i = 0; i < 6; ++i) { if (out) out[i] = v[i]; if (v[i] < 1) ok = 0; }
+    return ok;
+}
+
 extern "C" int64_t mstts_lstm_seq_ws_floats(int64_t B, int64_t H, int32_t backward) {
     int p = backward ? mstts_skinny_bwd_splits(H, 4 * H) : mstts_skinny_fwd_splits(4 * H, H);
     if (p < 1) p = 1;
@@ -233,6 +271,8 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     MSTTS_REQUIRE(d->lsa.B == B, MSTTS_ERR_SHAPE, "decoder_train_fwd: lsa.B != B");
     const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M;
     const int sp0 = mstts_skinny_fwd_splits(4 * H, W0), sp1 = mstts_skinny_fwd_splits(4 * H, W1), spq = mstts_skinny_fwd_splits(A, H);
+    int32_t bfs[6];
+    const bool bf = d->bf_w0f_f && d->bf_w1_f && d->bf_wq_f && mstts_decoder_bf16_splits(H, M, A, bfs);
     const int pg = (sp0 > sp1 ? sp0 : sp1) > 0 ? (sp0 > sp1 ? sp0 : sp1) : 1, pq = spq > 0 ? spq : 1;
     RC(zero(d->in0, B * W0, s));
     RC(zero(d->in1, B * W1, s));
@@ -264,7 +304,8 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             float* in1w = d->in1 + (st * B + b0) * W1;
             float* in1n = d->in1 + ((st + 1) * B + b0) * W1;
             float* pj = d->pj + (st * B + b0) * WP;
-            PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, xw_fwd(in0, W0, d->w0f, 4 * H, gates, Bc, 4 * H, W0, sp0, &parts, q_s));
+            if (bf) { parts = bfs[0]; PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, mstts_skinny_fwd_bf16(in0, W0, d->bf_w0f_f, gates, 0, Bc, 4 * H, W0, bfs[0], q_s)); }
+            else PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, xw_fwd(in0, W0, d->w0f, 4 * H, gates, Bc, 4 * H, W0, sp0, &parts, q_s));
             memset(&p, 0, sizeof(p));
             p.B = Bc; p.H = H; p.gates_h = gates; p.gates_parts = parts; p.gates_pstride = 4 * Bc * H;
             p.xw = d->xw0 + (st * B + b0) * 4 * H; p.xw_sb = 4 * H; p.xw_st = 0;
@@ -276,7 +317,8 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             p.acts_out = d->acts0 + (st * B + b0) * 4 * H; p.c_raw = d->craw0 + (st * B + b0) * H;
             RC(mstts_lstm_point_fwd(&p, q_s));
             // ---- cell 1: gates = [m0 | h1] . w1 + b1
-            PROBED(MSTTS_PROBE_CELL1_GEMM, q_s, xw_fwd(in1, W1, d->w1, 4 * H, gates, Bc, 4 * H, W1, sp1, &parts, q_s));
+            if (bf) { parts = bfs[1]; PROBED(MSTTS_PROBE_CELL1_GEMM, q_s, mstts_skinny_fwd_bf16(in1, W1, d->bf_w1_f, gates, 0, Bc, 4 * H, W1, bfs[1], q_s)); }
+            else PROBED(MSTTS_PROBE_CELL1_GEMM, q_s, xw_fwd(in1, W1, d->w1, 4 * H, gates, Bc, 4 * H, W1, sp1, &parts, q_s));
             memset(&p, 0, sizeof(p));
             p.B = Bc; p.H = H; p.gates_h = gates; p.gates_parts = parts; p.gates_pstride = 4 * Bc * H; p.bias = d->b1;
             p.c_prev = d->c1 + (st * B + b0) * H; p.h_prev = in1 + H; p.h_prev_ld = W1;
@@ -287,7 +329,8 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             p.acts_out = d->acts1 + (st * B + b0) * 4 * H; p.c_raw = d->craw1 + (st * B + b0) * H;
             RC(mstts_lstm_point_fwd(&p, q_s));
             // ---- query (partials summed inside the energy kernel, which also saves q) + attention
-            RC(xw_fwd(pj, WP, d->wq, A, qws, Bc, A, H, spq, &parts, q_s));
+            if (bf) { parts = bfs[2]; RC(mstts_skinny_fwd_bf16(pj, WP, d->bf_wq_f, qws, 0, Bc, A, H, bfs[2], q_s)); }
+            else RC(xw_fwd(pj, WP, d->wq, A, qws, Bc, A, H, spq, &parts, q_s));
             const float* cum = d->cum_hist + (st * B + b0) * T;
             if (fused_lsa) {
                 PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_step_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum,
@@ -324,6 +367,8 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     const long W0 = M + H, W1 = 2 * H, WP = H + M;
     const int sp1 = mstts_skinny_bwd_splits(W1, 4 * H), sp0 = mstts_skinny_bwd_splits(W0, 4 * H), spq = mstts_skinny_bwd_splits(H, A);
     const int np1 = sp1 > 0 ? sp1 : 1, npq = spq > 0 ? spq : 1;
+    int32_t bfs[6];
+    const bool bf = d->bf_w0f_b && d->bf_w1_b && d->bf_wq_b && mstts_decoder_bf16_splits(H, M, A, bfs);
     const long d_in0_slab = S * B * W0;
     const int chains = pick_chains(d);
     const long Bc = B / chains, BcH = Bc * H, BcT = Bc * T;
@@ -374,7 +419,8 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
                                          d->cum_hist + (st * B + b0) * T, bd->de_hist + (st * B + b0) * T, bd->dq_hist + (st * B + b0) * A, k.df[nxt], q_s));
             }
             // d_m1 (query path) = dq . Wq^T  -> slabs consumed by the cell-1 pointwise kernel
-            RC(xw_bwd(bd->dq_hist + (st * B + b0) * A, A, d->wq, A, k.dqm, 0, Bc, H, A, spq, &k.partsq, q_s));
+            if (bf) { k.partsq = bfs[5]; RC(mstts_skinny_bwd_bf16(bd->dq_hist + (st * B + b0) * A, A, d->bf_wq_b, k.dqm, 0, Bc, H, A, bfs[5], q_s)); }
+            else RC(xw_bwd(bd->dq_hist + (st * B + b0) * A, A, d->wq, A, k.dqm, 0, Bc, H, A, spq, &k.partsq, q_s));
             // ---- cell 1 backward
             mstts_lstm_point_bwd_desc p;
             memset(&p, 0, sizeof(p));
@@ -390,7 +436,8 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
             p.d_c_prev = k.dc1[nxt]; p.d_h_prev = k.dh1[nxt];
             RC(mstts_lstm_point_bwd(&p, q_s));
             // [d_m0 | d_h1 state] = dg1 . w1^T
-            PROBED(MSTTS_PROBE_CELL1_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w1, 4 * H, k.tmp1, 0, Bc, W1, 4 * H, sp1, &k.parts1, q_s));
+            if (bf) { k.parts1 = bfs[4]; PROBED(MSTTS_PROBE_CELL1_DGEMM, q_s, mstts_skinny_bwd_bf16(p.dgates, 4 * H, d->bf_w1_b, k.tmp1, 0, Bc, W1, 4 * H, bfs[4], q_s)); }
+            else PROBED(MSTTS_PROBE_CELL1_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w1, 4 * H, k.tmp1, 0, Bc, W1, 4 * H, sp1, &k.parts1, q_s));
             // ---- cell 0 backward
             memset(&p, 0, sizeof(p));
             p.B = Bc; p.H = H;
@@ -404,8 +451,10 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
             p.d_c_prev = k.dc0[nxt]; p.d_h_prev = k.dh0[nxt];
             RC(mstts_lstm_point_bwd(&p, q_s));
             // [d_ctx_{st-1} | d_h0 state] = dg0 . w0f^T   (slabs at stride S*B*W0)
-            PROBED(MSTTS_PROBE_CELL0_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w0f, 4 * H, bd->d_in0 + (st * B + b0) * W0, d_in0_slab, Bc, W0, 4 * H,
-                                                       sp0, &k.parts0, q_s));
+            if (bf) { k.parts0 = bfs[3]; PROBED(MSTTS_PROBE_CELL0_DGEMM, q_s, mstts_skinny_bwd_bf16(p.dgates, 4 * H, d->bf_w0f_b, bd->d_in0 + (st * B + b0) * W0,
+                                                                                                   d_in0_slab, Bc, W0, 4 * H, bfs[3], q_s)); }
+            else PROBED(MSTTS_PROBE_CELL0_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w0f, 4 * H, bd->d_in0 + (st * B + b0) * W0, d_in0_slab, Bc, W0, 4 * H,
+                                                            sp0, &k.parts0, q_s));
         }
         cur = nxt;
     }

@@ -836,7 +836,7 @@ extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_st
     const int parts = d->gates_parts > 1 ? d->gates_parts : 1;
     const bool seq = d->lengths || d->residual || d->reverse || d->xw_st != 0 || d->out_st != 0 || !d->acts_out || !d->c_raw;
     const long span = (d->B + 1) * (d->out_sb > d->xw_sb ? d->out_sb : d->xw_sb);
-    const bool fast = d->out && d->B * d->H * 4 < (1LL << 30) && (parts == 1 || parts == 2 || parts == 4 || parts == 8 || parts == 16) &&
+    const bool fast = d->out && d->B * d->H * 4 < (1LL << 30) && (parts == 1 || parts == 2 || parts == 4 || parts == 7 || parts == 8 || parts == 16) &&
                       (long)parts * d->gates_pstride < (1LL << 30) && span < (1LL << 30);
     if (fast) {
         PointFwdFast f;
@@ -852,7 +852,7 @@ extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_st
 #define MSTTS_PF(P)                                                                                        \
         if (seq) hipLaunchKernelGGL((lstm_point_fwd_fast_kernel<P, true>), grid, dim3(128), 0, ST(s), f);    \
         else hipLaunchKernelGGL((lstm_point_fwd_fast_kernel<P, false>), grid, dim3(128), 0, ST(s), f)
-        if (parts == 16) { MSTTS_PF(16); } else if (parts == 8) { MSTTS_PF(8); } else if (parts == 4) { MSTTS_PF(4); }
+        if (parts == 16) { MSTTS_PF(16); } else if (parts == 8) { MSTTS_PF(8); } else if (parts == 7) { MSTTS_PF(7); } else if (parts == 4) { MSTTS_PF(4); }
         else if (parts == 2) { MSTTS_PF(2); } else { MSTTS_PF(1); }
 #undef MSTTS_PF
         MSTTS_CHECK_LAUNCH("lstm_point_fwd_fast");

@@ -54,7 +54,9 @@ class _WS:
 
 class TrainEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, rank=0, world=1, values=None,
-                 update_vocoder_bn=True, use_l1=True, wr_rate=1e-6, adam=(0.9, 0.999, 1e-6)):
+                 update_vocoder_bn=True, use_l1=True, wr_rate=1e-6, adam=(0.9, 0.999, 1e-6), recurrent_dtype=None):
+        """recurrent_dtype: 'f32' (default; BASELINE config 2) or 'bf16' (config 3: the decoder's recurrent products run on
+        bf16 copies of the fp32 master weights with fp32 accumulation; env MSTTS_RECURRENT_DTYPE sets the default)."""
         lib.load()
         self.d = dims or Dims()
         self.device = torch.device(device)
@@ -77,6 +79,17 @@ class TrainEngine:
         self.loc_k, self.loc_b, self.d_loc_k = self._f(d.att_k, d.att), self._f(d.att), self._f(d.att_k, d.att)
         self.flip = {}
         self._derived_stale = True
+        self.recurrent_dtype = (recurrent_dtype or __import__('os').environ.get('MSTTS_RECURRENT_DTYPE', 'f32')).lower()
+        if self.recurrent_dtype not in ("f32", "bf16"):
+            raise ValueError("recurrent_dtype must be 'f32' or 'bf16'")
+        self.bf = None
+        if self.recurrent_dtype == "bf16":
+            sp = (C.c_int32 * 6)()
+            if not lib.load().mstts_decoder_bf16_splits(H, M, d.att, sp):
+                raise ValueError("bf16 recurrent products need dec_lstm, mem and att widths that are multiples of 64")
+            i16 = lambda n: torch.zeros(n, dtype=torch.int16, device=self.device)
+            self.bf = {"splits": list(sp), "w0f_f": i16((M + H) * 4 * H), "w1_f": i16(2 * H * 4 * H), "wq_f": i16(H * d.att),
+                       "w0f_b": i16((M + H) * 4 * H), "w1_b": i16(2 * H * 4 * H), "wq_b": i16(H * d.att)}
 
     # ------------------------------------------------------------------ helpers
     def _f(self, *shape):
@@ -96,6 +109,16 @@ class TrainEngine:
         H, M, Pn = d.dec_lstm, d.mem, d.prenet
         k0, o0 = self.P(CELL % 0 + "kernel")
         call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(self.w0f), 2 * M + H, 4 * H, 0, M)
+        if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
+            A_ = d.att
+            k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
+            f0, f1, fq, b0, b1, bq = self.bf["splits"]
+            call("mstts_pack_bf16_fwd", ptr(self.w0f), 4 * H, ptr(self.bf["w0f_f"]), M + H, 4 * H, f0)
+            call("mstts_pack_bf16_fwd", ptr(k1, o1), 4 * H, ptr(self.bf["w1_f"]), 2 * H, 4 * H, f1)
+            call("mstts_pack_bf16_fwd", ptr(wq_, oq_), A_, ptr(self.bf["wq_f"]), H, A_, fq)
+            call("mstts_pack_bf16_bwd", ptr(self.w0f), 4 * H, ptr(self.bf["w0f_b"]), M + H, 4 * H, b0)
+            call("mstts_pack_bf16_bwd", ptr(k1, o1), 4 * H, ptr(self.bf["w1_b"]), 2 * H, 4 * H, b1)
+            call("mstts_pack_bf16_bwd", ptr(wq_, oq_), A_, ptr(self.bf["wq_b"]), H, A_, bq)
         wp, owp = self.P("decoder/decoder/linear_projection/dense/kernel")
         bp, obp = self.P("decoder/decoder/linear_projection/dense/bias")
         nm1 = d.n_mel + 1
@@ -299,6 +322,9 @@ class TrainEngine:
         dec.xw0, dec.w0f, dec.w1, dec.b1, dec.wq = ptr(w.xw0), ptr(self.w0f), ptr(k1, o1), ptr(b1, ob1), ptr(wq, oq)
         dec.zc0, dec.zh0, dec.zc1, dec.zh1 = ptr(mk["dec_zc_0"]), ptr(mk["dec_zh_0"]), ptr(mk["dec_zc_1"]), ptr(mk["dec_zh_1"])
         dec.zoneout = d.zoneout
+        if self.bf is not None:
+            dec.bf_w0f_f, dec.bf_w1_f, dec.bf_wq_f = ptr(self.bf["w0f_f"]), ptr(self.bf["w1_f"]), ptr(self.bf["wq_f"])
+            dec.bf_w0f_b, dec.bf_w1_b, dec.bf_wq_b = ptr(self.bf["w0f_b"]), ptr(self.bf["w1_b"]), ptr(self.bf["wq_b"])
         dec.chains = self.chains if (B % max(self.chains, 1) == 0 and B // max(self.chains, 1) >= 8) else 1
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))

@@ -69,7 +69,8 @@ class DecoderTrain(C.Structure):
                 ("zc0", vp), ("zh0", vp), ("zc1", vp), ("zh1", vp), ("zoneout", f32),
                 ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp),
                 ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
-                ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp), ("chains", i32)]
+                ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp), ("chains", i32),
+                ("bf_w0f_f", vp), ("bf_w1_f", vp), ("bf_wq_f", vp), ("bf_w0f_b", vp), ("bf_w1_b", vp), ("bf_wq_b", vp)]
 
 
 class DecoderTrainBwd(C.Structure):
@@ -134,6 +135,13 @@ SIGNATURES = {
     "mstts_stft_mel": (i32, [vp, i64, f32, vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, vp]),
     "mstts_stft_mel_ws_floats": (i64, [i64, i32, i64]),
     "mstts_fold_rows": (i32, [vp, vp, i64, i64, i64, i64, vp]),
+    "mstts_decoder_bf16_splits": (i32, [i64, i64, i64, P(i32)]),
+    "mstts_skinny_bf16_fwd_splits": (i32, [i64, i64]),
+    "mstts_skinny_bf16_bwd_splits": (i32, [i64, i64]),
+    "mstts_pack_bf16_fwd": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "mstts_pack_bf16_bwd": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "mstts_skinny_fwd_bf16": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "mstts_skinny_bwd_bf16": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_ge2e_ws_floats": (i64, [i64, i64, i64]),
     "mstts_ge2e_loss_fwd_bwd": (i32, [vp, i64, i64, i64, i64, vp, vp, vp, i64, vp, vp]),
     "mstts_wg_overlap_add": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),

@@ -253,10 +253,38 @@ def dropout(x, keep_mask, rate):
     return x * keep_mask.to(x.dtype) / (1.0 - rate)
 
 
-def zoneout_lstm_cell(x, c_prev, h_prev, kernel, bias, zc, zh, rate, training):
+# BASELINE config 3 emulation ("bf16 with fp32 master"): when set, the decoder's recurrent products (both cells on the folded
+# cell-0 kernel, the attention query) are computed as bf(X) . bf(W) (round to nearest even) in the working precision, their data
+# gradients as bf(dY) . bf(W)^T, and their weight gradients from the unrounded operands - exactly what the HIP bf16 path does.
+RECURRENT_BF16 = False
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _BF16MatMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _bf(x) @ _bf(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return _bf(g) @ _bf(w).t(), x.t() @ g
+
+
+def rmm(x, w):
+    """Recurrent matmul of the decoder loop."""
+    return _BF16MatMul.apply(x, w) if RECURRENT_BF16 else x @ w
+
+
+def zoneout_lstm_cell(x, c_prev, h_prev, kernel, bias, zc, zh, rate, training, gates=None):
     """ZoneoutLSTMCell.call (ZoneoutLSTMCell.py:188-271; quirks Q2,Q3).
     zc/zh: 0/1 keep masks (used only when training).  Returns (m, c_state, h_state)."""
-    gates = torch.cat([x, h_prev], dim=1) @ kernel + bias
+    if gates is None:
+        gates = torch.cat([x, h_prev], dim=1) @ kernel + bias
     i, j, f, o = gates.chunk(4, dim=1)
     c = torch.sigmoid(f + 1.0) * c_prev + torch.sigmoid(i) * torch.tanh(j)
     m = torch.sigmoid(o) * torch.tanh(c)
@@ -333,7 +361,7 @@ def lsa_step(p, d: Dims, keys, values, length_mask, query_in, cum):
     """Location_Sensitive_Attention.__call__/score (Location_Sensitive_Attention.py:43-85) plus
     BahdanauAttention's -inf score mask + softmax and AttentionWrapper's context (quirks Q4-Q6).
     keys [B,T,A], values [B,T,M], length_mask bool [B,T], query_in [B,H], cum [B,T]."""
-    q = query_in @ p[P_LSA + "query_layer/kernel"]                                   # [B,A]
+    q = rmm(query_in, p[P_LSA + "query_layer/kernel"])                               # [B,A]
     f = conv1d_same(cum[:, :, None], p[P_LSA + "attention_convolution_dense_layer/conv1d/kernel"],
                     p[P_LSA + "attention_convolution_dense_layer/conv1d/bias"])      # [B,T,32]
     loc = f @ p[P_LSA + "attention_convolution_dense_layer/dense/kernel"]             # [B,T,A]
@@ -380,10 +408,19 @@ def decoder(p, d: Dims, memory, token_length, mel, mel_length, training, masks):
         pre = prenet(p, d, frame, masks, t)
         x = torch.cat([pre, ctx, ctx], dim=1)            # quirk Q1: context enters twice
         for l in range(d.dec_lstm_n):
+            gates = None
+            if RECURRENT_BF16:      # the products the HIP path runs in bf16: [ctx | h0] on the FOLDED cell-0 kernel, [m0 | h1] on cell 1
+                K, bb = p[P_CELL % l + "kernel"], p[P_CELL % l + "bias"]
+                if l == 0:
+                    Pn, Mm = d.prenet, d.mem
+                    fold = torch.cat([K[Pn:Pn + Mm] + K[Pn + Mm:Pn + 2 * Mm], K[Pn + 2 * Mm:]], dim=0)
+                    gates = pre @ K[:Pn] + bb + rmm(torch.cat([ctx, h[0]], dim=1), fold)
+                else:
+                    gates = rmm(torch.cat([x, h[l]], dim=1), K) + bb
             x, c[l], h[l] = zoneout_lstm_cell(
                 x, c[l], h[l], p[P_CELL % l + "kernel"], p[P_CELL % l + "bias"],
                 masks["dec_zc_%d" % l][t] if training else None,
-                masks["dec_zh_%d" % l][t] if training else None, d.zoneout, training)
+                masks["dec_zh_%d" % l][t] if training else None, d.zoneout, training, gates=gates)
         align, cum, ctx = lsa_step(p, d, keys, values, lmask, x, cum)
         proj = torch.cat([x, ctx], dim=1) @ p["decoder/decoder/linear_projection/dense/kernel"] \
             + p["decoder/decoder/linear_projection/dense/bias"]

@@ -225,7 +225,7 @@ def test_stft_mel(dev):
     assert np.abs(got - ref).max() < 2e-3          # normalised range is [-4, 4]: 5e-4 relative
 
 
-def _engine_vs_oracle(dev, B, Te, L, ragged, seed, **dims_kw):
+def _engine_vs_oracle(dev, B, Te, L, ragged, seed, recurrent_dtype=None, **dims_kw):
     pd, od = dims_pair(**dims_kw)
     values = OM.init_params(od, seed)
     # make BN / biases non-trivial so every gradient path is exercised
@@ -239,7 +239,7 @@ def _engine_vs_oracle(dev, B, Te, L, ragged, seed, **dims_kw):
     S = L + 1
     masks = OT.make_masks(od, B, Te, S, True, seed=OT.step_seed(1234, 0))
     new_p, opt, sc, grads, out = OT.train_step(values, None, od, batch, masks, 0, return_grads=True)
-    eng = TrainEngine(pd, device=dev, values=values)
+    eng = TrainEngine(pd, device=dev, values=values, recurrent_dtype=recurrent_dtype)
     w = eng.plan(B, Te, L)
     eng.forward(to_dev(batch, dev), w, seed=OT.step_seed(1234, 0))     # masks drawn on the device by Philox
     for name, m in masks.items():                                       # ... must equal the oracle's
@@ -287,6 +287,34 @@ def test_train_step_parity(dev, B, Te, L, ragged, kw):
         if e > 2e-3:
             bad[k] = e
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,Te,L,kw", [(5, 18, 9, MID), (32, 24, 6, dict(dec_lstm=1024, enc_lstm=256, spk=256, prenet=256, n_mel=80))])
+def test_train_step_parity_bf16_recurrent(dev, monkeypatch, B, Te, L, kw):
+    """BASELINE config 3 ("bf16 with fp32 master"): the decoder's recurrent products run on packed bf16 copies of the fp32
+    master weights.  The oracle emulates exactly that (bf(X).bf(W), data gradients bf(dY).bf(W)^T, weight gradients from the
+    unrounded operands); an input that sits on a bf16 rounding boundary may round differently in fp32 and fp64, so the bounds
+    are a little wider than in fp32 mode."""
+    monkeypatch.setattr(OM, "RECURRENT_BF16", True)
+    eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, True, seed=13, recurrent_dtype="bf16", **kw)
+    assert eng.bf is not None
+    assert rel_err(t2n(w.linear), t2n(out["Linear"])) < 2e-3 and rel_err(t2n(w.mel_out), t2n(out["Mel"])) < 2e-3
+    assert rel_err(t2n(w.align_hist).transpose(1, 2, 0), t2n(out["Attention_History"])) < 2e-3
+    got = eng.scalars(w)
+    assert abs(got["Loss"] - sc["Loss"]) <= 5e-4 * max(1.0, abs(sc["Loss"]))
+    ggot = eng.params.export(grads=True)
+    worst = {}
+    for k, gr in grads.items():
+        ref = t2n(gr).astype(np.float64)
+        mine = ggot[k].astype(np.float64) + (1e-6 * np.asarray(values[k]) if OM.in_weight_reg(k) else 0.0)
+        worst[k] = np.abs(mine - ref).max() / (np.abs(ref).max() + 1e-9)
+    bad = {k: v for k, v in worst.items() if v > 2e-2}
+    assert not bad, bad
+    # the mode really differs from fp32: against the un-emulated oracle the mel is off by more than the fp32 tolerance
+    monkeypatch.setattr(OM, "RECURRENT_BF16", False)
+    ref32 = OM.forward(OM.to_torch(values), od, {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}, True,
+                       OT.make_masks(od, B, Te, L + 1, True, seed=OT.step_seed(1234, 0)), with_vocoder=False)
+    assert rel_err(t2n(w.mel_out), t2n(ref32["Mel"])) > 1e-4
 
 
 @pytest.mark.parametrize("stop_bias,max_inf", [(-6.0, 9), (6.0, 9), (0.0, 14)])

@@ -183,3 +183,45 @@ def test_skinny_bwd(dev, M, R, N):
     lib.call("mstts_skinny_bwd", lib.ptr(dG), N, lib.ptr(W), N, lib.ptr(P), 0, M, R, N, ns)
     ref = t2n(dG).astype(np.float64) @ t2n(W).astype(np.float64).T
     assert rel_err(t2n(P).astype(np.float64).sum(0), ref) < TOL
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 1792), (32, 4096, 2048), (16, 128, 1024), (5, 256, 192), (32, 64, 64), (40, 128, 512)])
+def test_skinny_bf16_fwd(dev, M, N, K):
+    """bf16 weight-streaming product: bf(X) . bf(W) with fp32 accumulation (packed kernel, K-split partial slabs)."""
+    L = lib.load()
+    ks = L.mstts_skinny_bf16_fwd_splits(N, K)
+    assert ks >= 1
+    g = torch.Generator().manual_seed(M + N + K)
+    X = torch.zeros(M, K + 8); X[:, :K] = torch.randn(M, K, generator=g)
+    W = torch.randn(K, N, generator=g) * 0.05
+    Xd, Wd = X.to(dev), W.to(dev)
+    Wp = torch.zeros(K * N, dtype=torch.int16, device=dev)
+    lib.call("mstts_pack_bf16_fwd", lib.ptr(Wd), N, lib.ptr(Wp), K, N, ks)
+    P = torch.zeros(ks, M, N, device=dev)
+    lib.call("mstts_skinny_fwd_bf16", lib.ptr(Xd), K + 8, lib.ptr(Wp), lib.ptr(P), 0, M, N, K, ks)
+    ref = _bf(X[:, :K]) @ _bf(W)
+    got = P.sum(0).double().cpu()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert sorted(Wp.cpu().numpy().astype(np.uint16).tolist()) == sorted(W.to(torch.bfloat16).view(torch.int16).flatten().numpy().astype(np.uint16).tolist())
+
+
+@pytest.mark.parametrize("M,R,N", [(32, 1792, 4096), (32, 2048, 4096), (16, 1024, 128), (5, 96, 256), (32, 32, 64), (40, 64, 1024)])
+def test_skinny_bf16_bwd(dev, M, R, N):
+    """bf16 data-gradient product: bf(dG) . bf(W)^T with fp32 accumulation."""
+    L = lib.load()
+    ns = L.mstts_skinny_bf16_bwd_splits(R, N)
+    assert ns >= 1
+    g = torch.Generator().manual_seed(M + N + R)
+    dG = torch.randn(M, N, generator=g); W = torch.randn(R, N, generator=g) * 0.05
+    dGd, Wd = dG.to(dev), W.to(dev)
+    Wq = torch.zeros(R * N, dtype=torch.int16, device=dev)
+    lib.call("mstts_pack_bf16_bwd", lib.ptr(Wd), N, lib.ptr(Wq), R, N, ns)
+    P = torch.zeros(ns, M, R, device=dev)
+    lib.call("mstts_skinny_bwd_bf16", lib.ptr(dGd), N, lib.ptr(Wq), lib.ptr(P), 0, M, R, N, ns)
+    ref = _bf(dG) @ _bf(W).t()
+    got = P.sum(0).double().cpu()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6

@@ -23,6 +23,9 @@ from .params import CELL, ENC_CELL, LSA, VOC, Dims, ParamStore, bank_suffix
 
 BN_MOM, BN_EPS = 0.99, 1e-3
 
+MAX_PLANS = 3      # cached workspace sets (one per batch shape); a full-size Tacotron2 set is ~5 GB
+
+
 
 def learning_rate(step):
     """MSTTS_SV.py:163-169."""
@@ -65,7 +68,7 @@ class TrainEngine:
         self.chains = int(__import__('os').environ.get('MSTTS_DECODER_CHAINS', '1'))
         self.use_l1, self.wr_rate, self.adam = use_l1, wr_rate, adam
         self.params = ParamStore(self.d, self.device, seed=seed, values=values)
-        self._plans = {}
+        self._plans = {}          # workspace sets keyed by batch shape, least recently used first (at most MAX_PLANS kept)
         self.global_step = 0
         d = self.d
         # packed / derived weights refreshed after every optimizer step
@@ -134,7 +137,10 @@ class TrainEngine:
     def plan(self, B, Te, L):
         key = (B, Te, L)
         if key in self._plans:
+            self._plans[key] = self._plans.pop(key)          # most recently used last
             return self._plans[key]
+        while len(self._plans) >= MAX_PLANS:                 # variable-length training: do not keep a workspace per shape forever
+            self._plans.pop(next(iter(self._plans)))
         d, f = self.d, self._f
         w = _WS()
         S = L + 1

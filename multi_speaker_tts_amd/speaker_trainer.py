@@ -19,6 +19,9 @@ from .masks import step_seed
 from .params import SPK, SPK_CELL, Dims, ParamStore
 from .engine import _split_k
 
+MAX_PLANS = 3      # cached workspace sets (one per batch shape); a full-size Tacotron2 set is ~5 GB
+
+
 
 def is_trainable(name):
     return name.startswith(SPK)
@@ -46,7 +49,7 @@ class SpeakerTrainEngine:
         self.wb_m, self.wb_v = torch.zeros(4, device=self.device), torch.zeros(4, device=self.device)
         self.wb_mask = torch.zeros(4, dtype=torch.uint8, device=self.device)
         self.global_step = 0
-        self._plans = {}
+        self._plans = {}          # workspace sets keyed by batch shape, least recently used first (at most MAX_PLANS kept)
 
     def _f(self, *shape):
         n = int(np.prod(shape))
@@ -60,7 +63,10 @@ class SpeakerTrainEngine:
 
     def plan(self, N, T):
         if (N, T) in self._plans:
+            self._plans[(N, T)] = self._plans.pop((N, T))          # most recently used last
             return self._plans[(N, T)]
+        while len(self._plans) >= MAX_PLANS:                 # variable-length training: do not keep a workspace per shape forever
+            self._plans.pop(next(iter(self._plans)))
         d, f = self.d, self._f
         H, L = d.spk_lstm, d.spk_lstm_n
 

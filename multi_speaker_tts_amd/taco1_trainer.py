@@ -21,6 +21,9 @@ from .engine import BN_EPS, BN_MOM, _split_k
 
 BIRNN = VOC + "birnn/stack_bidirectional_rnn/cell_0/bidirectional_rnn/%s/zoneout_lstm_cell/"
 
+MAX_PLANS = 3      # cached workspace sets (one per batch shape); a full-size Tacotron2 set is ~5 GB
+
+
 
 def is_trainable(name):
     return name.startswith(VOC) and not name.endswith(("moving_mean", "moving_variance"))
@@ -53,7 +56,7 @@ class Taco1TrainEngine:
         self.adam = adam or (tr.ADAM.Beta1, tr.ADAM.Beta2, tr.ADAM.Epsilon)
         self.global_step = 0
         self.flip = {}
-        self._plans = {}
+        self._plans = {}          # workspace sets keyed by batch shape, least recently used first (at most MAX_PLANS kept)
 
     def _f(self, *shape):
         n = int(np.prod(shape))
@@ -68,7 +71,10 @@ class Taco1TrainEngine:
     # ------------------------------------------------------------------ buffers
     def plan(self, B, S):
         if (B, S) in self._plans:
+            self._plans[(B, S)] = self._plans.pop((B, S))          # most recently used last
             return self._plans[(B, S)]
+        while len(self._plans) >= MAX_PLANS:                 # variable-length training: do not keep a workspace per shape forever
+            self._plans.pop(next(iter(self._plans)))
         d, f = self.d, self._f
 
         class W:

@@ -1,16 +1,18 @@
 // Location-sensitive attention step for gfx950 (Location_Sensitive_Attention.py:43-85, plus the
 // TF BahdanauAttention score mask / softmax and the AttentionWrapper context it inherits).
 //
-// The decoder calls this once per mel frame, strictly in sequence, so one step has to spread over
-// the whole chip to be fast.  Forward is two launches:
-//   lsa_energy : grid (B, T/16) - every workgroup owns 16 encoder positions of one row: location
-//                conv (31 taps -> 32 ch) in LDS, the 32->128 dense and tanh per (t,k) lane, wave64
-//                shuffle reduction over k.  Streams its 8 KB slice of keys once.
-//   lsa_context: grid (B, M/64) - softmax over the row's energies recomputed per workgroup (T
-//                floats), then a float4-coalesced stream over values[b,:,64-wide slice].
-// Backward mirrors it (dalign / denergy) and the parameter gradients are hoisted out of the time
-// loop into one batched recompute kernel (lsa_param_bwd) so the sequential path carries no
-// read-modify-write traffic.
+// The decoder calls this once per mel frame, strictly in sequence, so one step has to spread over the whole chip and cost
+// as few dependent round trips as possible.
+//   forward, one launch  (lsa_step_kernel, grid (T/16 | M/96, B)): every workgroup computes the energies of 16 encoder
+//       positions (folded 31-tap location filter -> tanh -> wave shuffle reduction), the workgroups of a row exchange
+//       their slices inside the launch as 8-byte {epoch, value} granules, then each runs the row softmax and streams its
+//       96-column slice of values[b].
+//   backward, one launch (lsa_step_bwd_kernel, grid (T/8, B)): d_align = G + values . d_ctx, the row-wide dot(a, d_a)
+//       exchanged the same way, d_energy, d_query (atomics), and the filter-transpose operand h for the previous step.
+//   The two-launch forms (lsa_energy + lsa_context, lsa_dalign + lsa_denergy) are kept: they need no granule buffer, are
+//   what the single-launch kernels are tested against, and serve sequences that do not fit the single-launch geometry.
+//   Parameter gradients are hoisted out of the time loop into one batched recompute kernel (lsa_param_bwd), so the
+//   sequential path carries no read-modify-write traffic.
 #include "common.h"
 
 namespace mstts {

@@ -376,7 +376,7 @@ class TrainEngine:
         self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.bn_ws)
 
     # ------------------------------------------------------------------ loss + backward
-    def loss_and_backward(self, w, grad_scale=1.0):
+    def loss_and_backward(self, w, grad_scale=1.0, on_ready=None):
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
@@ -397,6 +397,8 @@ class TrainEngine:
             self._conv_block_bwd(dy, x_in, w.post_a[i], w.post_mean[i], w.post_rstd[i], mk["post_drop_%d" % i], 1 - d.conv_drop,
                                  ACT_TANH, "decoder/conv_%d/" % i, B * S, S, cin, chans[i], d.post_k, w.post_dz[i], dx)
             dy = dx
+        if on_ready is not None:             # every postnet gradient is final: its all-reduce overlaps the decoder BPTT
+            on_ready(*self._grad_range("decoder/conv_"))
         # d_linear(total) = loss part + residual (d_post) + postnet input grad
         n = B * S * d.n_mel
         call("mstts_add", ptr(w.d_linear), ptr(w.d_post), ptr(w.d_linear), n)
@@ -474,6 +476,8 @@ class TrainEngine:
         wm, owm = self.P("attention/memory_layer/kernel"); gwm, ogwm = self.G("attention/memory_layer/kernel")
         gemm(w.values, w.d_keys, gwm, M, A, B * Te, M, A, A, trans_a=True, split_k=max(2, _split_k(M, A, B * Te)), c_off=ogwm)
         gemm(w.d_keys, wm, w.d_values, B * Te, M, A, A, A, M, trans_b=True, accumulate=True, b_off=owm)
+        if on_ready is not None:             # decoder + attention gradients are final: overlaps the encoder backward
+            on_ready(*self._grad_range("attention/", "decoder/decoder"))
         # ---- encoder BiLSTM backward
         x_in, cin = w.enc_y[-1], d.enc_conv_ch
         for di, dr in enumerate(("fw", "bw")):
@@ -506,6 +510,16 @@ class TrainEngine:
             dy = dx
         ge, oge = self.G("encoder/embedding_variable")
         call("mstts_embedding_bwd", ptr(tok), ptr(dy), ptr(ge, oge), B * Te, d.n_tok, d.emb)
+        if on_ready is not None:
+            on_ready(*self._grad_range("encoder/"))
+
+    def _grad_range(self, *prefixes):
+        """[lo, hi) of the gradient slab covered by the trainable variables whose names start with one of `prefixes` (the
+        variable table keeps each module contiguous: encoder | attention | decoder | postnet)."""
+        ps = self.params
+        offs = [(ps.offset[n], ps.offset[n] + (int(np.prod(ps.shape[n])) + 3) // 4 * 4) for n, _, _ in ps.table
+                if ps.trainable[n] and n.startswith(prefixes)]
+        return min(o for o, _ in offs), max(e for _, e in offs)
 
     # ------------------------------------------------------------------ optimizer
     def adam_step(self, grad_scale=1.0):
@@ -534,8 +548,11 @@ class TrainEngine:
         L = batch["Mel"].shape[1]
         w = self.plan(B, Te, L)
         self.forward(batch, w, masks=masks)
-        self.loss_and_backward(w)
-        if all_reduce is not None:
-            all_reduce(self.params.grad)
+        if all_reduce is not None:           # bucketed in the order gradients become final (postnet -> decoder/attention -> encoder),
+            g = self.params.grad             # each bucket's all-reduce running under the rest of the backward pass
+            self.loss_and_backward(w, on_ready=lambda lo, hi: all_reduce.start(g, lo, hi))
+            all_reduce.finish(g)
+        else:
+            self.loss_and_backward(w)
         self.adam_step(grad_scale=1.0 / self.world if all_reduce is not None else 1.0)
         return w

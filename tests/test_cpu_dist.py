@@ -19,6 +19,12 @@ def _worker(rank, world, port, q):
     red = GradAllReduce(g, world, bucket_mb=0.001)          # forces several buckets
     assert len(red.bounds) > 1
     red(g)
+    # ranged form used by the train step: ranges started out of order while "backward" goes on, the rest picked up by finish()
+    h = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red.start(h, 700, 1000)
+    red.start(h, 200, 700)
+    red.finish(h)
+    assert torch.equal(g, h)
     q.put((rank, g.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()

@@ -448,3 +448,26 @@ def test_variable_length_training_and_convergence(dev):
         losses.append(eng.scalars(w)["Loss"])
     assert np.mean(losses[-5:]) < 0.95 * np.mean(losses[:5]), (losses[:5], losses[-5:])      # noise targets + dropout .5: slow but steady
     assert eng.global_step == 46
+
+
+def test_gradient_ready_ranges(dev):
+    """The three points at which the train step hands gradient ranges to the all-reduce (postnet -> decoder/attention ->
+    encoder) partition the slab, and a range is final when announced (it does not change afterwards)."""
+    pd, od = dims_pair()
+    eng = TrainEngine(pd, device=dev, seed=5)
+    batch = to_dev(OT.synthetic_batch(od, 3, 9, 6, seed=4), dev)
+    w = eng.plan(3, 9, 6)
+    eng.forward(batch, w)
+    seen, snaps = [], []
+
+    def on_ready(lo, hi):
+        seen.append((lo, hi))
+        snaps.append(eng.params.grad[lo:hi].clone())
+    eng.loss_and_backward(w, on_ready=on_ready)
+    torch.cuda.synchronize()
+    assert len(seen) == 3 and sorted(seen)[0][0] == 0 and sorted(seen)[-1][1] == eng.params.n_train
+    s = sorted(seen)
+    assert all(s[i][1] == s[i + 1][0] for i in range(2))                       # contiguous, no overlap
+    assert seen[0][0] > seen[1][0] > seen[2][0]                                # postnet (end of slab) first, encoder last
+    for (lo, hi), snap in zip(seen, snaps):
+        assert torch.equal(eng.params.grad[lo:hi], snap) and float(snap.abs().max()) > 0

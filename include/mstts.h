@@ -55,6 +55,11 @@ int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
 /* ---- randomness: Philox4x32-10 keep-masks (replaces tf.random_uniform inside
  * tf.layers.dropout, Modules.py:41-45,137-141,248-253, and ZoneoutLSTMCell.py:266-271) ---- */
 int mstts_philox_keep_mask(uint8_t* out, int64_t n, uint64_t seed, uint32_t stream_id, float keep_prob, mstts_stream_t s);
+/* sample-keyed form for a mask laid out [outer, B, inner] (outer = 1: batch-major): sample b draws from its own stream,
+ * Philox counter (block, sample0 + b, stream_id, 0), element (o, c) = draw o*inner + c.  sample0 = global index of the first
+ * local sample, so data-parallel runs of any width draw the same mask for the same sample. */
+int mstts_philox_keep_mask_rows(uint8_t* out, int64_t outer, int64_t B, int64_t inner, uint64_t seed, uint32_t stream_id,
+                                uint64_t sample0, float keep_prob, mstts_stream_t s);
 
 /* ---- Encoder_Embedding (Modules.py:15-23): out[i,:] = table[token[i],:] ; bit-exact gather.
  * bwd: dtable[token[i],:] += dout[i,:] (atomic scatter-add). */
@@ -146,6 +151,38 @@ typedef struct {
 } mstts_lstm_point_bwd_desc;
 int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_stream_t s);
 
+/* ---- fused zoneout-LSTM cell step for [B, K] x [K, 4H] cells (ZoneoutLSTMCell.py:228-271 in ONE launch: the gates
+ * product and the cell update; no partial slabs).  Needs mstts_cell_fwd_supported(H, K) == 1 (H % 4 == 0, K % 64 == 0,
+ * K <= 2048).  Both operands are derived copies in the kernel's lane order:
+ *   Wp = the cell kernel W[K, 4H] (row stride ldw) packed by mstts_pack_cell_fwd (refresh after every optimizer step);
+ *   Xp = the activation block [B, K] in the packed layout of mstts_pack_cell_act, mstts_cell_act_floats(B, K) floats.
+ *        In a time loop its producers write it directly: this kernel stores packed copies of m and h' for the next cells
+ *        (out_p / h_next_p) and mstts_lsa_step_fwd a packed copy of the context (ctx_p), beside the row-major history.
+ * Semantics and field meanings as mstts_lstm_point_fwd_desc with the product folded in:
+ *   gates = X . W + xw + bias ; out = m ; c_next / h_next = zoned state ; acts / c_raw = BPTT saves (may be NULL). */
+typedef struct {
+    float* base;            /* packed activation block of the consuming cell (NULL = none) */
+    int64_t K, col0;        /* its reduction width and the first of the H columns this producer owns in it */
+} mstts_cell_packed_dst;
+typedef struct {
+    int64_t B, H, K;
+    const float* Xp;
+    const float* Wp;
+    const float* xw; int64_t xw_ld;      /* [B, 4H] rows (stride xw_ld) added to the gates, or NULL */
+    const float* bias;                   /* [4H] or NULL */
+    const float* c_prev; const float* h_prev; int64_t h_prev_ld;
+    const uint8_t* zc; const uint8_t* zh; float zoneout;
+    float* out; int64_t out_ld;
+    float* c_next; float* h_next; int64_t h_next_ld;
+    float* acts; float* c_raw;
+    mstts_cell_packed_dst out_p, h_next_p;
+} mstts_cell_fwd_desc;
+int32_t mstts_cell_fwd_supported(int64_t H, int64_t K);
+int mstts_pack_cell_fwd(const float* W, int64_t ldw, float* Wp, int64_t K, int64_t H, mstts_stream_t s);
+int64_t mstts_cell_act_floats(int64_t B, int64_t K);
+int mstts_pack_cell_act(const float* X, int64_t ldx, float* Xp, int64_t B, int64_t K, mstts_stream_t s);
+int mstts_cell_fwd(const mstts_cell_fwd_desc* d, mstts_stream_t s);
+
 /* ---- Location_Sensitive_Attention step (Location_Sensitive_Attention.py:43-85 + TF
  * BahdanauAttention masking/softmax + AttentionWrapper context).  Two launches:
  *   energy : e[b,t] = sum_k w_k tanh(keys[b,t,k] + q[b,k] + (conv31(cum)[b,t,:] . Wd)[k] + b_k)
@@ -181,6 +218,7 @@ int mstts_lsa_context_fwd(const mstts_lsa_const* c, const float* energy, const f
 int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T);
 int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
                        const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                       const mstts_cell_packed_dst* ctx_p,   /* optional third copy of the context, in a fused cell's packed block (or NULL) */
                        void* granules, uint32_t epoch, mstts_stream_t s);
 /* backward of one step, two launches:
  *  dalign : G[t] = G_next[t] + sum_j h_next[t+pad-j][j] ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
@@ -380,6 +418,10 @@ typedef struct {
      * mstts_decoder_bf16_splits(H, M, A, out[6]); all six non-NULL -> cell / query products and their data gradients run
      * as bf(X).bf(W) with fp32 accumulation, everything else stays fp32 */
     const void* bf_w0f_f; const void* bf_w1_f; const void* bf_wq_f; const void* bf_w0f_b; const void* bf_w1_b; const void* bf_wq_b;
+    /* optional fused cell steps (fp32): w0f / w1 packed by mstts_pack_cell_fwd; both non-NULL and
+     * mstts_cell_fwd_supported(H, M+H) && (H, 2H) -> each cell is one mstts_cell_fwd launch instead of product + pointwise */
+    const float* w0p; const float* w1p;
+    float* act_p;      /* ... and their packed activation blocks: 2 * (mstts_cell_act_floats(B, M+H) + mstts_cell_act_floats(B, 2H)) floats */
 } mstts_decoder_train_desc;
 int32_t mstts_decoder_bf16_splits(int64_t H, int64_t M, int64_t A, int32_t* out6);
 /* floats needed for gates_ws (*gates) and q_ws (*q) */

@@ -1,0 +1,231 @@
+// Fused zoneout-LSTM cell step for the decoder time loops (gfx950): the gates product AND the cell
+// update of ZoneoutLSTMCell.call (ZoneoutLSTMCell.py:228-264) in ONE launch, no partial slabs.
+//
+//   gates[b, :] = X[b, :K] . W[K, 4H] (+ xw[b, :] | + bias)            i, j, f, o   (ZoneoutLSTMCell.py:228-230)
+//   c = sigmoid(f + 1) c_prev + sigmoid(i) tanh(j) ; m = sigmoid(o) tanh(c)           (:237-248)
+//   c' = keep . zc . (c - c_prev) + c_prev ; h' = keep . zh . (m - h_prev) + h_prev   (:259-271)
+//
+// Work cut: workgroup g owns the FOUR hidden units 4g .. 4g+3, i.e. the 16 gate columns {gate*H + 4g + u}, for all
+// (<= 32) batch rows and the whole reduction - H/4 = 256 workgroups at the reference width, one per CU, each with
+// the complete pre-activations of its units, so the cell update is an epilogue and nothing is exchanged.
+// The kernel W is a per-optimizer-step derived copy (like the folded cell-0 kernel), stored in exactly the order
+// the lanes consume it (mstts_pack_cell_fwd): the four waves of a workgroup split K, wave w / iteration it / lane l
+// reads one float4 = W[w K/4 + 16 it + 4 (l >> 4) + {0..3}][column (l & 15)] - a contiguous 1 KB per wave load.
+// The activations need no staging either: the same lane needs X[row (l & 15)][the same four k] as one float4 (the k order
+// inside a v_mfma_f32_16x16x4_f32 reduction is free as long as A and B agree).  Read from a row-major block that is 16
+// different cache lines per 4-lane group - measured 17.6 us per cell, slower than product + pointwise (16.2) - so the
+// activation block is kept in the lanes' order as well (cell_act_offset): its producers (the previous cell's epilogue,
+// the attention step's context) write their few elements per thread to both layouts, the row-major history BPTT needs and
+// the packed block the next cell reads with one contiguous 1 KB per wave load.  Every operand goes global -> register in one
+// round trip, all loads issued before the first MFMA, in consumption order.
+// Exact fp32 arithmetic (v_mfma_f32_16x16x4_f32); deterministic (fixed reduction order).
+#include "common.h"
+
+namespace mstts {
+
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+constexpr int CELL_MAX_NIT = 32;          // 16-row k-steps per wave: K/4 <= 512
+
+struct CellFwd {
+    const float* Xp;                            // packed activation block [ceil(B/32)*32, K] (cell_act_offset)
+    const float* Wp;                            // packed kernel (mstts_pack_cell_fwd)
+    const float* xw; int xw_ld;                 // optional additive pre-activations [B][4H] (gate-major), or null
+    const float* bias;                          // [4H] gate-major, or null
+    const float* c_prev; const float* h_prev; int h_prev_ld;
+    const uint8_t* zc; const uint8_t* zh; float keep;
+    float* out; int out_ld;                     // un-zoned m (the cell output, ZoneoutLSTMCell.py:264)
+    float* c_next; float* h_next; int h_next_ld;
+    float* acts; float* c_raw;                  // [B][4H] gate activations, [B][H] raw cell state (BPTT); may be null
+    PackedDst out_p, h_next_p;                  // optional packed copies of m / h' for the cells that consume them next
+    int B, H, K;
+};
+
+template <int NIT, bool TWO>                     // NIT > 0: exact trip count; TWO: rows 16..31 exist
+__global__ __launch_bounds__(256) void cell_fwd_kernel(CellFwd d) {
+    __shared__ float red[4][32][17];
+    const int g = blockIdx.x, m0 = blockIdx.y * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    constexpr bool EXACT = NIT > 0;
+    constexpr int UNROLL = EXACT ? NIT : CELL_MAX_NIT;
+    const int nit = EXACT ? NIT : d.K >> 6;
+    const int H = d.H;
+    // ---- epilogue operands of this thread (row er, unit eu), requested first: they are tiny and must not cost a round trip later
+    const int er = threadIdx.x >> 2, eu = 4 * g + (threadIdx.x & 3);
+    const bool elive = threadIdx.x < 128 && m0 + er < d.B;
+    const int eb = m0 + er;
+    // (raw values only: anything computed from them here would make the compiler wait for the round trip before the main loads go out)
+    float cp = 0.f, hp = 0.f, xwv[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+    uint8_t zcv = 1, zhv = 1;
+    if (elive) {
+        cp = d.c_prev[eb * H + eu];
+        hp = d.h_prev[eb * d.h_prev_ld + eu];
+        if (d.zc) zcv = d.zc[eb * H + eu];
+        if (d.zh) zhv = d.zh[eb * H + eu];
+        if (d.xw) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xwv[q] = d.xw[eb * d.xw_ld + q * H + eu];
+        }
+        if (d.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = d.bias[q * H + eu];
+        }
+    }
+    // ---- every operand load of the product, in consumption order (activations of k-step `it` for both row tiles, then its
+    //      weights): a wave's loads return in issue order, so the MFMA chain starts with the first triple and runs under the
+    //      weight stream instead of behind it
+    const float* wp = d.Wp + ((long)(g * 4 + wave) * nit) * 256 + lane * 4;
+    const float* xp = d.Xp + (long)blockIdx.y * (2048 * nit) + (wave * nit * 2) * 256 + lane * 4;
+    cf32x4 wreg[UNROLL], a0[UNROLL], a1[TWO ? UNROLL : 1];
+#pragma unroll
+    for (int it = 0; it < UNROLL; ++it) {
+        a0[it] = (cf32x4){0.f, 0.f, 0.f, 0.f};
+        wreg[it] = (cf32x4){0.f, 0.f, 0.f, 0.f};
+        if (TWO) a1[it] = (cf32x4){0.f, 0.f, 0.f, 0.f};
+        if (EXACT || it < nit) {
+            a0[it] = *reinterpret_cast<const cf32x4*>(xp + it * 512);
+            if (TWO) a1[it] = *reinterpret_cast<const cf32x4*>(xp + it * 512 + 256);
+            wreg[it] = *reinterpret_cast<const cf32x4*>(wp + it * 256);
+        }
+    }
+    // every load above stays above: without this the scheduler sinks each load to its MFMA and runs the stream three loads deep
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- MFMA chain: two independent accumulators per row tile
+    cf32x4 c00 = (cf32x4){0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+#pragma unroll
+    for (int it = 0; it < UNROLL; ++it) {
+        if (EXACT || it < nit) {
+            const cf32x4 w = wreg[it], x = a0[it];
+            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[0], w[0], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[1], w[1], c01, 0, 0, 0);
+            if (TWO) {
+                const cf32x4 y = a1[it];
+                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(y[0], w[0], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(y[1], w[1], c11, 0, 0, 0);
+            }
+            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2], w[2], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[3], w[3], c01, 0, 0, 0);
+            if (TWO) {
+                const cf32x4 y = a1[it];
+                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2], w[2], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(y[3], w[3], c11, 0, 0, 0);
+            }
+        }
+    }
+    // ---- the four K-quarters meet in LDS: red[wave][row][column]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wave][kq * 4 + r][j] = c00[r] + c01[r];
+        red[wave][16 + kq * 4 + r][j] = TWO ? c10[r] + c11[r] : 0.f;
+    }
+    __syncthreads();
+    if (!elive) return;
+    // ---- cell update of (row er, unit eu): column of gate q is 4 q + (unit & 3)
+    const int ec = threadIdx.x & 3;
+    float g4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g4[q] = ((red[0][er][4 * q + ec] + red[1][er][4 * q + ec]) + (red[2][er][4 * q + ec] + red[3][er][4 * q + ec])) + (xwv[q] + bv[q]);
+    const float kc = zcv ? d.keep : 0.f, kh = zhv ? d.keep : 0.f;
+    const float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
+    const float c = sf * cp + si * tj;
+    const float m = so * tanhf(c);
+    const float hn = kh * (m - hp) + hp;
+    d.c_next[eb * H + eu] = kc * (c - cp) + cp;
+    d.h_next[eb * d.h_next_ld + eu] = hn;
+    d.out[eb * d.out_ld + eu] = m;
+    if (d.out_p.base) d.out_p.base[cell_act_offset(eb, d.out_p.col0 + eu, d.out_p.nit)] = m;
+    if (d.h_next_p.base) d.h_next_p.base[cell_act_offset(eb, d.h_next_p.col0 + eu, d.h_next_p.nit)] = hn;
+    if (d.acts) { float* a = d.acts + eb * 4 * H + eu; a[0] = si; a[H] = tj; a[2 * H] = sf; a[3 * H] = so; }
+    if (d.c_raw) d.c_raw[eb * H + eu] = c;
+}
+
+// row-major X[B, K] (row stride ldx) -> packed activation block (rows B .. 32*ceil(B/32)-1 are written as zeros)
+__global__ void pack_cell_act_kernel(const float* __restrict__ X, long ldx, float* __restrict__ Xp, int B, int K) {
+    const int nit = K >> 6;
+    const long n = (long)((B + 31) / 32 * 32) * K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / K), k = (int)(i - (long)r * K);
+        Xp[cell_act_offset(r, k, nit)] = r < B ? X[(long)r * ldx + k] : 0.f;
+    }
+}
+
+// W[K, 4H] (row stride ldw, gate-major columns i | j | f | o) -> the consumption order of cell_fwd_kernel
+__global__ void pack_cell_fwd_kernel(const float* __restrict__ W, long ldw, float* __restrict__ Wp, int K, int H) {
+    const long n = (long)K * 4 * H;
+    const int nit = K >> 6;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(p & 3), lane = (int)((p >> 2) & 63);
+        long r = p >> 8;
+        const int it = (int)(r % nit); r /= nit;
+        const int wave = (int)(r & 3), g = (int)(r >> 2);
+        const int j = lane & 15, kq = lane >> 4;
+        const int k = wave * (nit * 16) + 16 * it + 4 * kq + e;
+        const int col = (j >> 2) * H + 4 * g + (j & 3);
+        Wp[p] = W[(long)k * ldw + col];
+    }
+}
+
+}  // namespace mstts
+using namespace mstts;
+
+/* 1 when the fused cell step can run a [B, K] x [K, 4H] cell: whole 4-unit groups, K split over four waves in 16-row steps */
+extern "C" int32_t mstts_cell_fwd_supported(int64_t H, int64_t K) {
+    return (H >= 4 && H % 4 == 0 && K >= 64 && K % 64 == 0 && K / 64 <= CELL_MAX_NIT && 4 * H * K < (1LL << 31)) ? 1 : 0;
+}
+
+extern "C" int mstts_pack_cell_fwd(const float* W, int64_t ldw, float* Wp, int64_t K, int64_t H, mstts_stream_t s) {
+    MSTTS_REQUIRE(W && Wp && mstts_cell_fwd_supported(H, K), MSTTS_ERR_SHAPE, "pack_cell_fwd: unsupported shape (H %% 4, K %% 64, K <= 2048)");
+    const long n = K * 4 * H;
+    hipLaunchKernelGGL(pack_cell_fwd_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)s, W, (long)ldw, Wp, (int)K, (int)H);
+    MSTTS_CHECK_LAUNCH("pack_cell_fwd");
+    return MSTTS_OK;
+}
+
+extern "C" int64_t mstts_cell_act_floats(int64_t B, int64_t K) { return (B + 31) / 32 * 32 * K; }
+
+extern "C" int mstts_pack_cell_act(const float* X, int64_t ldx, float* Xp, int64_t B, int64_t K, mstts_stream_t s) {
+    MSTTS_REQUIRE(X && Xp && B >= 1 && K >= 64 && K % 64 == 0 && K / 64 <= CELL_MAX_NIT, MSTTS_ERR_SHAPE, "pack_cell_act: K %% 64, K <= 2048 required");
+    const long n = mstts_cell_act_floats(B, K);
+    hipLaunchKernelGGL(pack_cell_act_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)s, X, (long)ldx, Xp, (int)B, (int)K);
+    MSTTS_CHECK_LAUNCH("pack_cell_act");
+    return MSTTS_OK;
+}
+
+namespace mstts {
+int packed_dst_from(const mstts_cell_packed_dst* p, int64_t width, PackedDst* o, const char* what) {
+    o->base = p ? p->base : nullptr; o->nit = 0; o->col0 = 0;
+    if (!o->base) return MSTTS_OK;
+    MSTTS_REQUIRE(p->K >= 64 && p->K % 64 == 0 && p->K / 64 <= CELL_MAX_NIT && p->col0 >= 0 && p->col0 + width <= p->K, MSTTS_ERR_SHAPE,
+                  "bad packed destination %s (K %% 64, K <= 2048, col0 + width <= K)", what);
+    o->nit = (int)(p->K / 64); o->col0 = (int)p->col0;
+    return MSTTS_OK;
+}
+}  // namespace mstts
+
+extern "C" int mstts_cell_fwd(const mstts_cell_fwd_desc* q, mstts_stream_t s) {
+    MSTTS_REQUIRE(q && q->Xp && q->Wp && q->c_prev && q->h_prev && q->out && q->c_next && q->h_next, MSTTS_ERR_SHAPE, "cell_fwd: null pointer");
+    MSTTS_REQUIRE(mstts_cell_fwd_supported(q->H, q->K), MSTTS_ERR_SHAPE, "cell_fwd: unsupported shape (H %% 4, K %% 64, K <= 2048)");
+    MSTTS_REQUIRE(q->B >= 1 && aligned16(q->Xp) && aligned16(q->Wp), MSTTS_ERR_ALIGN, "cell_fwd: 16-byte aligned Xp / Wp required");
+    MSTTS_REQUIRE((q->B + 32) * (q->K > 4 * q->H ? q->K : 4 * q->H) < (1LL << 31), MSTTS_ERR_SHAPE, "cell_fwd: block too large for 32-bit indexing");
+    CellFwd d;
+    d.Xp = q->Xp; d.Wp = q->Wp; d.xw = q->xw; d.xw_ld = (int)q->xw_ld; d.bias = q->bias;
+    d.c_prev = q->c_prev; d.h_prev = q->h_prev; d.h_prev_ld = (int)(q->h_prev_ld ? q->h_prev_ld : q->H);
+    d.zc = q->zc; d.zh = q->zh; d.keep = 1.f - q->zoneout;
+    d.out = q->out; d.out_ld = (int)(q->out_ld ? q->out_ld : q->H);
+    d.c_next = q->c_next; d.h_next = q->h_next; d.h_next_ld = (int)(q->h_next_ld ? q->h_next_ld : q->H);
+    d.acts = q->acts; d.c_raw = q->c_raw; d.B = (int)q->B; d.H = (int)q->H; d.K = (int)q->K;
+    int rc = packed_dst_from(&q->out_p, q->H, &d.out_p, "out_p"); if (rc) return rc;
+    rc = packed_dst_from(&q->h_next_p, q->H, &d.h_next_p, "h_next_p"); if (rc) return rc;
+    const dim3 grid((unsigned)(q->H / 4), (unsigned)((q->B + 31) / 32));
+    const int nit = (int)(q->K / 64);
+    const bool two = q->B > 16;
+#define MSTTS_CF(N)                                                                                         \
+    do {                                                                                                    \
+        if (two) hipLaunchKernelGGL((cell_fwd_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)s, d);     \
+        else hipLaunchKernelGGL((cell_fwd_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)s, d);        \
+    } while (0)
+    if (nit == 32) MSTTS_CF(32); else if (nit == 28) MSTTS_CF(28); else MSTTS_CF(0);
+#undef MSTTS_CF
+    MSTTS_CHECK_LAUNCH("cell_fwd");
+    return MSTTS_OK;
+}

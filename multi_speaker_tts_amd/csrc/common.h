@@ -37,6 +37,18 @@ __device__ __forceinline__ float tanhf_(float x) {
     return copysignf(t, x);
 }
 
+// Packed activation block of a fused cell with reduction width K = 64 nit (what cell_fwd_kernel reads, csrc/cell.hip): element
+// (row r, column k) lives where lane (k % 16 / 4) * 16 + r % 16 of wave k / (16 nit) finds it in its float4 number
+// (k % (16 nit)) / 16 for row tile (r % 32) / 16 - every wave load of the consumer is one contiguous 1 KB.  Blocks of 32 rows
+// follow each other.
+__device__ __forceinline__ int cell_act_offset(int r, int k, int nit) {
+    const int blk = r >> 5, rr = r & 31, w = k / (16 * nit), kk = k - w * 16 * nit;
+    return blk * (2048 * nit) + (((w * nit + (kk >> 4)) * 2 + (rr >> 4)) << 8) + ((((kk & 15) >> 2) * 16 + (rr & 15)) << 2) + (kk & 3);
+}
+struct PackedDst { float* base; int nit, col0; };      // packed block of a consumer cell; the producer owns columns col0 ...
+// validates a mstts_cell_packed_dst whose producer writes `width` columns
+int packed_dst_from(const mstts_cell_packed_dst* p, int64_t width, PackedDst* o, const char* what);
+
 // sum of up to MAXP partial slabs p[pp * stride + idx]; all loads are issued before the first add
 // (a runtime-length `for` would serialize one memory round trip per slab)
 template <int MAXP>

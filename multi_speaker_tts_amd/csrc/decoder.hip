@@ -70,6 +70,21 @@ static int zero(float* p, long n, mstts_stream_t s) {
     return MSTTS_OK;
 }
 
+// one fused cell step (product + cell update, cell.hip); out_p / hn_p: packed blocks of the cells that consume m / h' next
+static int cell_step(const float* Xp, const float* Wp, long K, const float* xw, long xw_ld, const float* bias,
+                     const float* c_prev, const float* h_prev, long h_prev_ld, const uint8_t* zc, const uint8_t* zh, float zoneout,
+                     float* out, long out_ld, float* c_next, float* h_next, long h_next_ld, float* acts, float* c_raw, long B, long H,
+                     float* out_p, long out_p_K, long out_p_col0, float* hn_p, long hn_p_K, long hn_p_col0, mstts_stream_t s) {
+    mstts_cell_fwd_desc q;
+    memset(&q, 0, sizeof(q));
+    q.B = B; q.H = H; q.K = K; q.Xp = Xp; q.Wp = Wp; q.xw = xw; q.xw_ld = xw_ld; q.bias = bias;
+    q.c_prev = c_prev; q.h_prev = h_prev; q.h_prev_ld = h_prev_ld; q.zc = zc; q.zh = zh; q.zoneout = zoneout;
+    q.out = out; q.out_ld = out_ld; q.c_next = c_next; q.h_next = h_next; q.h_next_ld = h_next_ld; q.acts = acts; q.c_raw = c_raw;
+    q.out_p.base = out_p; q.out_p.K = out_p_K; q.out_p.col0 = out_p_col0;
+    q.h_next_p.base = hn_p; q.h_next_p.K = hn_p_K; q.h_next_p.col0 = hn_p_col0;
+    return mstts_cell_fwd(&q, s);
+}
+
 // X[M,K] . W[K,N]: skinny K-split kernel when the shape fits (parts slabs in P), else the tiled GEMM
 static int xw_fwd(const float* X, long ldx, const float* W, long ldw, float* P, long M, long N, long K, int splits, int* parts,
                   mstts_stream_t s) {
@@ -274,13 +289,18 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     int32_t bfs[6];
     const bool bf = d->bf_w0f_f && d->bf_w1_f && d->bf_wq_f && mstts_decoder_bf16_splits(H, M, A, bfs);
     const int pg = (sp0 > sp1 ? sp0 : sp1) > 0 ? (sp0 > sp1 ? sp0 : sp1) : 1, pq = spq > 0 ? spq : 1;
+    const int chains = pick_chains(d);
+    const bool fused_lsa = lsa_fused_enabled() && chains == 1;         // (the time-out counter sits after the last row's granules)
+    // fused cell steps need the single-launch attention step (it writes the context into cell 0's packed block)
+    const bool fused_cells = !bf && fused_lsa && d->w0p && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1) &&
+                             M % 4 == 0;
+    const long p0n = mstts_cell_act_floats(B, W0), p1n = mstts_cell_act_floats(B, W1);
+    if (fused_cells) RC(zero(d->act_p, 2 * (p0n + p1n), s));          // step-0 state: zero context / hidden states
     RC(zero(d->in0, B * W0, s));
     RC(zero(d->in1, B * W1, s));
     RC(zero(d->c0, BH, s));
     RC(zero(d->c1, BH, s));
     RC(zero(d->cum_hist, B * T, s));
-    const int chains = pick_chains(d);
-    const bool fused_lsa = lsa_fused_enabled() && chains == 1;         // (the time-out counter sits after the last row's granules)
     if (fused_lsa) RC(zero(d->energy_ws, 2 * B * T + 2, s));           // granules + time-out counter of mstts_lsa_step_fwd
     const long Bc = B / chains;
     mstts_stream_t cs[MAX_CHAINS];
@@ -296,6 +316,7 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             lc.B = Bc; lc.keys += b0 * T * A; lc.values += b0 * T * M;
             if (lc.lengths) lc.lengths += b0;
             mstts_lstm_point_fwd_desc p;
+            mstts_cell_packed_dst ctx_p = {nullptr, 0, 0};
             int parts = 1;
             // ---- cell 0: gates = [ctx | h0] . w0f + xw0[st]
             const float* in0 = d->in0 + (st * B + b0) * W0;
@@ -304,6 +325,22 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             float* in1w = d->in1 + (st * B + b0) * W1;
             float* in1n = d->in1 + ((st + 1) * B + b0) * W1;
             float* pj = d->pj + (st * B + b0) * WP;
+            if (fused_cells) {
+                // packed activation blocks, ping-pong by step parity: P0 = [ctx | h0] of cell 0, P1 = [m0 | h1] of cell 1.
+                // cell 0 (step st) reads P0[st&1], writes m0 -> P1[st&1] and h0' -> P0[~st&1]; cell 1 reads P1[st&1], writes
+                // h1' -> P1[~st&1]; the attention step writes ctx -> P0[~st&1].
+                float* P0c = d->act_p + (st & 1) * p0n; float* P0n = d->act_p + ((st + 1) & 1) * p0n;
+                float* P1c = d->act_p + 2 * p0n + (st & 1) * p1n; float* P1n = d->act_p + 2 * p0n + ((st + 1) & 1) * p1n;
+                PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, cell_step(P0c, d->w0p, W0, d->xw0 + (st * B + b0) * 4 * H, 4 * H, nullptr,
+                       d->c0 + (st * B + b0) * H, in0 + M, W0, d->zc0 ? d->zc0 + (st * B + b0) * H : nullptr, d->zh0 ? d->zh0 + (st * B + b0) * H : nullptr,
+                       d->zoneout, in1w, W1, d->c0 + ((st + 1) * B + b0) * H, in0n + M, W0, d->acts0 + (st * B + b0) * 4 * H,
+                       d->craw0 + (st * B + b0) * H, Bc, H, P1c, W1, 0, P0n, W0, M, q_s));
+                PROBED(MSTTS_PROBE_CELL1_GEMM, q_s, cell_step(P1c, d->w1p, W1, nullptr, 0, d->b1,
+                       d->c1 + (st * B + b0) * H, in1 + H, W1, d->zc1 ? d->zc1 + (st * B + b0) * H : nullptr, d->zh1 ? d->zh1 + (st * B + b0) * H : nullptr,
+                       d->zoneout, pj, WP, d->c1 + ((st + 1) * B + b0) * H, in1n + H, W1, d->acts1 + (st * B + b0) * 4 * H,
+                       d->craw1 + (st * B + b0) * H, Bc, H, nullptr, 0, 0, P1n, W1, H, q_s));
+                ctx_p.base = P0n; ctx_p.K = W0; ctx_p.col0 = 0;
+            } else {
             if (bf) { parts = bfs[0]; PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, mstts_skinny_fwd_bf16(in0, W0, d->bf_w0f_f, gates, 0, Bc, 4 * H, W0, bfs[0], q_s)); }
             else PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, xw_fwd(in0, W0, d->w0f, 4 * H, gates, Bc, 4 * H, W0, sp0, &parts, q_s));
             memset(&p, 0, sizeof(p));
@@ -328,6 +365,7 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             p.c_next = d->c1 + ((st + 1) * B + b0) * H; p.h_next = in1n + H; p.h_next_ld = W1;
             p.acts_out = d->acts1 + (st * B + b0) * 4 * H; p.c_raw = d->craw1 + (st * B + b0) * H;
             RC(mstts_lstm_point_fwd(&p, q_s));
+            }
             // ---- query (partials summed inside the energy kernel, which also saves q) + attention
             if (bf) { parts = bfs[2]; RC(mstts_skinny_fwd_bf16(pj, WP, d->bf_wq_f, qws, 0, Bc, A, H, bfs[2], q_s)); }
             else RC(xw_fwd(pj, WP, d->wq, A, qws, Bc, A, H, spq, &parts, q_s));
@@ -335,7 +373,7 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             if (fused_lsa) {
                 PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_step_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum,
                                          d->align_hist + (st * B + b0) * T, d->cum_hist + ((st + 1) * B + b0) * T, in0n, W0, pj + H, WP,
-                                         (unsigned long long*)d->energy_ws + b0 * T, (uint32_t)(st + 1), q_s));
+                                         fused_cells ? &ctx_p : nullptr, (unsigned long long*)d->energy_ws + b0 * T, (uint32_t)(st + 1), q_s));
             } else {
                 PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_energy_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum, energy, q_s));
                 PROBED(MSTTS_PROBE_LSA_CONTEXT, q_s, mstts_lsa_context_fwd(&lc, energy, cum, d->align_hist + (st * B + b0) * T,
@@ -630,7 +668,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
         RC(mstts_lstm_point_fwd(&p, s));
         RC(xw_fwd(d->pj, WP, d->wq, A, q, B, A, H, spq, &parts, s));
         RC(mstts_lsa_step_fwd(&d->lsa, q, parts, B * A, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
-                              in0n + P, W0, d->pj + H, WP, gran, (uint32_t)(st + 1), s));
+                              in0n + P, W0, d->pj + H, WP, nullptr, gran, (uint32_t)(st + 1), s));
         RC(xw_fwd(d->pj, WP, d->wp_pad, NP, pp, B, NP, WP, spp, &parts, s));
         hipLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)((B * (NM + 1) + 255) / 256)), dim3(256), 0, (hipStream_t)s, pp, parts, B * NP, d->bproj,
                            (int)B, (int)NP, (int)NM, d->linear + st * B * NM, d->stop + st * B);
@@ -702,7 +740,7 @@ extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int6
         RC(gemm(d->pj, WP, d->wq, A, 0, q, A, B, A, H, nullptr, 0, 0, s));
         if (fused_lsa) {
             RC(mstts_lsa_step_fwd(&d->lsa, q, 1, 0, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
-                                  in0n, W0, d->pj + H, WP, energy, (uint32_t)(st + 1), s));
+                                  in0n, W0, d->pj + H, WP, nullptr, energy, (uint32_t)(st + 1), s));
         } else {
             RC(mstts_lsa_energy_fwd(&d->lsa, q, 1, 0, nullptr, d->cum + par * BT, energy, s));
             RC(mstts_lsa_context_fwd(&d->lsa, energy, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,

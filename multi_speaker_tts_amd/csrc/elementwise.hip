@@ -61,6 +61,33 @@ __global__ void philox_mask_kernel(uint8_t* __restrict__ out, long n, uint32_t k
     }
 }
 
+// sample-keyed form: out is [outer, B, inner]; the mask of sample b is its own stream, counter = (block, sample0 + b, stream, 0),
+// element (o, c) = draw o * inner + c of it - so a sample's mask does not depend on how the global batch is sharded over ranks
+__global__ void philox_mask_rows_kernel(uint8_t* __restrict__ out, long outer, int B, long inner, uint32_t k0, uint32_t k1, uint32_t stream,
+                                        uint32_t sample0, float keep) {
+    const long n = outer * inner, nblk = (n + 3) >> 2, total = nblk * B;
+    const bool vec = (inner & 3) == 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / nblk);
+        const long blk = i - (long)b * nblk;
+        uint32_t w[4];
+        philox4x32_10((uint32_t)blk, sample0 + (uint32_t)b, stream, 0u, k0, k1, w);
+        uint8_t m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = ((float)(w[j] >> 8) * 5.9604644775390625e-08f < keep) ? 1 : 0;
+        const long e = blk << 2;
+        if (vec) {                      // the four draws stay inside one [inner] run (and n % 4 == 0)
+            const long o = e / inner, c = e - o * inner;
+            *reinterpret_cast<uchar4*>(out + (o * B + b) * inner + c) = make_uchar4(m[0], m[1], m[2], m[3]);
+        } else {
+            for (int j = 0; j < 4 && e + j < n; ++j) {
+                const long o = (e + j) / inner, c = (e + j) - o * inner;
+                out[(o * B + b) * inner + c] = m[j];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // embedding
 // ---------------------------------------------------------------------------------------------
@@ -672,6 +699,18 @@ extern "C" int mstts_philox_keep_mask(uint8_t* out, int64_t n, uint64_t seed, ui
     hipLaunchKernelGGL(philox_mask_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST(s), out, (long)n,
                        (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), stream_id, keep_prob);
     MSTTS_CHECK_LAUNCH("philox_keep_mask");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_philox_keep_mask_rows(uint8_t* out, int64_t outer, int64_t B, int64_t inner, uint64_t seed, uint32_t stream_id,
+                                           uint64_t sample0, float keep_prob, mstts_stream_t s) {
+    MSTTS_REQUIRE(outer >= 0 && B >= 0 && inner >= 0 && (outer * B * inner == 0 || out) && B < (1LL << 31), MSTTS_ERR_SHAPE, "philox rows: bad args");
+    MSTTS_REQUIRE(inner % 4 != 0 || ((uintptr_t)out & 3) == 0, MSTTS_ERR_ALIGN, "philox rows: 4-byte aligned buffer required");
+    if (outer * B * inner == 0) return MSTTS_OK;
+    const long total = ((outer * inner + 3) / 4) * B;
+    hipLaunchKernelGGL(philox_mask_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(s), out, (long)outer, (int)B, (long)inner,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, (uint32_t)sample0, keep_prob);
+    MSTTS_CHECK_LAUNCH("philox_keep_mask_rows");
     return MSTTS_OK;
 }
 

@@ -216,8 +216,8 @@ __device__ __forceinline__ float lsa_energy_serial(const mstts_lsa_const& c, con
 __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
                                                               float* __restrict__ q_sum, const float* cum,
                                                               float* __restrict__ align, float* __restrict__ cum_next,
-                                                              float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld,
-                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int dbg) {
+                                                              float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld, PackedDst ctx_p,
+                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl) {
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
     __shared__ float s_red[FS_TSL][2];
     __shared__ float s_e[T_MAX];
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
 #pragma unroll
     for (int i = 0; i < FS_VPRE; ++i) {
         const int t = vg + ng * i;
-        vv[i] = (vlive && t < len && !(dbg & 1)) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[i] = (vlive && t < len) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // ---- own energy slice
     if (tid < FS_TSL + KS_MAX - 1 + 2) s_cum[tid] = cwin;          // entries past the window are zero
@@ -283,7 +283,6 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     // ---- gather the other slices of the row (the data is the flag)
     for (int t = tid; t < T; t += FS_THREADS) {
         if (t >= t0 && t < t0 + tsl) continue;
-        if (dbg & 2) { s_e[t] = 0.f; continue; }
         unsigned long long x = __hip_atomic_load(g + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
@@ -300,13 +299,6 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         s_e[t] = e;
     }
     __syncthreads();
-    if (dbg & 1) {
-#pragma unroll
-        for (int i = 0; i < FS_VPRE; ++i) {
-            const int t = vg + ng * i;
-            if (vlive && t < len) vv[i] = *reinterpret_cast<const float4*>(v + (long)t * M);
-        }
-    }
     // ---- softmax statistics, redundantly per wave (no further block-wide reduction)
     float mx = -INFINITY;
     for (int t = lane; t < len; t += 64) mx = fmaxf(mx, s_e[t]);
@@ -345,6 +337,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         for (int gq = 0; gq < ng; ++gq) r += s_part[gq * dsl + tid];
         ctx[(long)b * ctx_ld + d0 + tid] = r;
         if (ctx2) ctx2[(long)b * ctx2_ld + d0 + tid] = r;
+        if (ctx_p.base) ctx_p.base[cell_act_offset(b, ctx_p.col0 + d0 + tid, ctx_p.nit)] = r;
     }
 }
 
@@ -862,15 +855,15 @@ static void lsa_step_geometry(long T, long M, int* cs, int* tsl, int* dsl) {
 extern "C" int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T) { return (B * T + 1) * 8; }
 extern "C" int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
                                   const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
-                                  void* granules, uint32_t epoch, mstts_stream_t s) {
+                                  const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_fwd: granule buffer (8-byte aligned) and a non-zero epoch required");
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("MSTTS_LSA_STEP_DEBUG"); dbg = e ? atoi(e) : 0; }
+    PackedDst cp;
+    rc = packed_dst_from(ctx_p, c->M, &cp, "ctx_p"); if (rc) return rc;
     int cs, tsl, dsl;
     lsa_step_geometry(c->T, c->M, &cs, &tsl, &dsl);
     hipLaunchKernelGGL(lsa_step_kernel, dim3((unsigned)cs, (unsigned)c->B), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                       align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, dbg);
+                       align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl);
     MSTTS_CHECK_LAUNCH("lsa_step_fwd");
     return MSTTS_OK;
 }

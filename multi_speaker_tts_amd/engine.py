@@ -80,6 +80,11 @@ class TrainEngine:
         self.dwp_pad = self._f(H + M, self.proj_ld)
         self.dw0f = self._f(M + H, 4 * H)
         self.loc_k, self.loc_b, self.d_loc_k = self._f(d.att_k, d.att), self._f(d.att), self._f(d.att_k, d.att)
+        # fused cell steps (csrc/cell.hip): the two decoder cell kernels in the lanes' consumption order
+        lb = lib.load()
+        self.fused_cells = bool(lb.mstts_cell_fwd_supported(H, M + H)) and bool(lb.mstts_cell_fwd_supported(H, 2 * H))
+        self.w0p = self._f((M + H) * 4 * H) if self.fused_cells else None
+        self.w1p = self._f(2 * H * 4 * H) if self.fused_cells else None
         self.flip = {}
         self._derived_stale = True
         self.recurrent_dtype = (recurrent_dtype or __import__('os').environ.get('MSTTS_RECURRENT_DTYPE', 'f32')).lower()
@@ -112,6 +117,10 @@ class TrainEngine:
         H, M, Pn = d.dec_lstm, d.mem, d.prenet
         k0, o0 = self.P(CELL % 0 + "kernel")
         call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(self.w0f), 2 * M + H, 4 * H, 0, M)
+        if self.fused_cells:
+            k1, o1 = self.P(CELL % 1 + "kernel")
+            call("mstts_pack_cell_fwd", ptr(self.w0f), 4 * H, ptr(self.w0p), M + H, H)
+            call("mstts_pack_cell_fwd", ptr(k1, o1), 4 * H, ptr(self.w1p), 2 * H, H)
         if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
             A_ = d.att
             k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
@@ -175,6 +184,7 @@ class TrainEngine:
         ng, nq = C.c_int64(0), C.c_int64(0)
         lb.mstts_decoder_train_ws_floats(B, H, M, A, C.byref(ng), C.byref(nq))
         w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(2 * B * Te + 4), f(int(nq.value))
+        w.act_p = f(2 * int(lb.mstts_cell_act_floats(B, M + H) + lb.mstts_cell_act_floats(B, 2 * H))) if self.fused_cells else None
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
         # postnet
@@ -331,6 +341,8 @@ class TrainEngine:
         if self.bf is not None:
             dec.bf_w0f_f, dec.bf_w1_f, dec.bf_wq_f = ptr(self.bf["w0f_f"]), ptr(self.bf["w1_f"]), ptr(self.bf["wq_f"])
             dec.bf_w0f_b, dec.bf_w1_b, dec.bf_wq_b = ptr(self.bf["w0f_b"]), ptr(self.bf["w1_b"]), ptr(self.bf["wq_b"])
+        if self.fused_cells and self.bf is None:
+            dec.w0p, dec.w1p, dec.act_p = ptr(self.w0p), ptr(self.w1p), ptr(w.act_p)
         dec.chains = self.chains if (B % max(self.chains, 1) == 0 and B // max(self.chains, 1) >= 8) else 1
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))
@@ -541,6 +553,20 @@ class TrainEngine:
         wr = float(s[3]) * self.wr_rate
         return {"Linear_Loss": float(s[0]), "Postnet_Loss": float(s[1]), "Stop_Loss": float(s[2]),
                 "Weight_Regularization_Loss": wr, "Loss": float(s[0] + s[1] + s[2]) + wr}
+
+    def exchange_timeouts(self, w):
+        """(forward, backward) counts of in-launch exchange time-outs of the single-launch attention kernels in the last step on
+        workspace `w` (csrc/lsa.hip: the word behind the last granule of each buffer).  Always (0, 0) on a healthy run; a
+        non-zero count means a workgroup fell back to its serial recompute.  Synchronises."""
+        d = self.d
+        B, T, H, CH = w.B, w.Te, d.dec_lstm, d.att_ch
+        fwd = int(w.energy_ws.view(torch.int64)[B * T].item())
+        nsl = (T + 7) // 8
+        off = 8 * B * H + 2 * B * T + 2 * B * T * CH            # the d_align block of mstts_decoder_train_bwd's workspace
+        if (B * nsl + 1) * 8 > B * T * 4:                      # geometry without the single-launch backward: no counter
+            return fwd, 0
+        bwd = int(w.dec_bwd_ws[off:off + 2 * (B * nsl + 1)].view(torch.int64)[B * nsl].item())
+        return fwd, bwd
 
     def train_step(self, batch, masks=None, all_reduce=None):
         """One full iteration: forward, loss, backward, (gradient all-reduce), Adam."""

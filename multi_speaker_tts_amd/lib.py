@@ -44,6 +44,17 @@ class LstmPointBwd(C.Structure):
                 ("dgp_sb", i64), ("dgp_st", i64), ("d_c_prev", vp), ("d_h_prev", vp)]
 
 
+class CellPackedDst(C.Structure):
+    _fields_ = [("base", vp), ("K", i64), ("col0", i64)]
+
+
+class CellFwd(C.Structure):
+    _fields_ = [("B", i64), ("H", i64), ("K", i64), ("Xp", vp), ("Wp", vp), ("xw", vp), ("xw_ld", i64), ("bias", vp),
+                ("c_prev", vp), ("h_prev", vp), ("h_prev_ld", i64), ("zc", vp), ("zh", vp), ("zoneout", f32),
+                ("out", vp), ("out_ld", i64), ("c_next", vp), ("h_next", vp), ("h_next_ld", i64), ("acts", vp), ("c_raw", vp),
+                ("out_p", CellPackedDst), ("h_next_p", CellPackedDst)]
+
+
 class LsaConst(C.Structure):
     _fields_ = [("B", i64), ("T", i64), ("A", i64), ("M", i64), ("KS", i64), ("CH", i64),
                 ("keys", vp), ("values", vp), ("lengths", vp),
@@ -70,7 +81,8 @@ class DecoderTrain(C.Structure):
                 ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp),
                 ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
                 ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp), ("chains", i32),
-                ("bf_w0f_f", vp), ("bf_w1_f", vp), ("bf_wq_f", vp), ("bf_w0f_b", vp), ("bf_w1_b", vp), ("bf_wq_b", vp)]
+                ("bf_w0f_f", vp), ("bf_w1_f", vp), ("bf_wq_f", vp), ("bf_w0f_b", vp), ("bf_w1_b", vp), ("bf_wq_b", vp),
+                ("w0p", vp), ("w1p", vp), ("act_p", vp)]
 
 
 class DecoderTrainBwd(C.Structure):
@@ -93,6 +105,7 @@ SIGNATURES = {
     "mstts_abi_version": (i32, []),
     "mstts_gemm_f32": (i32, [P(GemmDesc), vp]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
+    "mstts_philox_keep_mask_rows": (i32, [vp, i64, i64, i64, u64, u32, u64, f32, vp]),
     "mstts_embedding_fwd": (i32, [vp, vp, vp, i64, i64, i64, vp]),
     "mstts_embedding_bwd": (i32, [vp, vp, vp, i64, i64, i64, vp]),
     "mstts_bn_train_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i64, i64, vp, vp]),
@@ -111,12 +124,17 @@ SIGNATURES = {
     "mstts_l1_loss_fwd_bwd": (i32, [vp, vp, i64, vp, vp, vp]),
     "mstts_lstm_point_fwd": (i32, [P(LstmPointFwd), vp]),
     "mstts_lstm_point_bwd": (i32, [P(LstmPointBwd), vp]),
+    "mstts_cell_fwd_supported": (i32, [i64, i64]),
+    "mstts_pack_cell_fwd": (i32, [vp, i64, vp, i64, i64, vp]),
+    "mstts_cell_fwd": (i32, [P(CellFwd), vp]),
+    "mstts_cell_act_floats": (i64, [i64, i64]),
+    "mstts_pack_cell_act": (i32, [vp, i64, vp, i64, i64, vp]),
     "mstts_lsa_energy_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp]),
     "mstts_lsa_context_fwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "mstts_lsa_step_ws_bytes": (i64, [i64, i64]),
     "mstts_lsa_step_bwd_ws_bytes": (i64, [i64, i64]),
     "mstts_lsa_step_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
-    "mstts_lsa_step_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, C.c_uint32, vp]),
+    "mstts_lsa_step_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, vp]),
     "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "mstts_lsa_denergy_bwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, vp, vp, vp]),
     "mstts_lsa_param_bwd": (i32, [P(LsaConst), i64, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -176,12 +194,12 @@ class MsttsError(RuntimeError):
 
 
 def load():
-    """Load (building first when the sources are newer and hipcc is present) the HIP library."""
+    """Load the HIP library, (re)building it first when its sources changed since it was built (multi_speaker_tts_amd/build.py)."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _b
+    from . import build as _b
+    if _b.needs_build():                 # content hashes of the sources vs the ones the library was built from (file-locked)
         _b.build()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():

@@ -2,7 +2,8 @@
 library's Philox4x32-10 kernel.  Replaces the stateful tf.random_uniform draws of
 tf.layers.dropout (Modules.py:41-45,137-141,248-253) and ZoneoutLSTMCell.dropout_no_scale
 (ZoneoutLSTMCell.py:266-271).  Stream ids are part of the library's specification
-(DESIGN.md "Randomness"): element i of mask (seed, stream) is draw i of that Philox stream.
+(DESIGN.md "Randomness"): the mask of global sample g is the Philox stream (seed, stream id, g); element (o, c) of the
+sample's slice is draw o * inner + c of it.
 """
 from __future__ import annotations
 
@@ -14,7 +15,11 @@ from . import lib
 STREAM = {"enc_conv_drop": 1, "enc_zc_fw": 10, "enc_zh_fw": 11, "enc_zc_bw": 12, "enc_zh_bw": 13,
           "prenet_drop": 20, "dec_zc": 30, "dec_zh": 31, "post_drop": 40,
           "v_zc_fw": 50, "v_zh_fw": 51, "v_zc_bw": 52, "v_zh_bw": 53, "s_zc": 60, "s_zh": 61}
-RANK_STRIDE = 1000
+
+
+def batch_axis(name):
+    """Conv-block dropout masks are batch-major [B, T, C] (samples on axis 0); every other mask is step-major [S, B, C]."""
+    return 0 if name.startswith(("enc_conv_drop", "post_drop")) else 1
 
 
 def step_seed(base_seed, step):
@@ -60,9 +65,13 @@ class MaskSet:
             self.buf[name] = torch.empty((n + 3) // 4 * 4, dtype=torch.uint8, device=device)[:n].view(shape)
 
     def draw(self, seed):
+        """Masks are keyed by (seed, stream, GLOBAL sample index, position in the sample): rank r holds the samples
+        r * B .. r * B + B - 1 of the global batch, so 1/2/4/8-rank runs draw the same mask for the same sample."""
         for name, stream, shape, keep in self.spec:
-            lib.call("mstts_philox_keep_mask", lib.ptr(self.buf[name]), int(np.prod(shape)), seed,
-                     stream + RANK_STRIDE * self.rank, float(keep))
+            ax = batch_axis(name)
+            outer, nb = (1, shape[0]) if ax == 0 else (shape[0], shape[1])
+            inner = int(np.prod(shape[ax + 1:]))
+            lib.call("mstts_philox_keep_mask_rows", lib.ptr(self.buf[name]), outer, nb, inner, seed, stream, self.rank * nb, float(keep))
 
     def load(self, masks):
         """Inject externally supplied masks (tests)."""

@@ -52,3 +52,26 @@ def keep_mask(shape, seed, stream, keep_prob):
     w = uniform_words(n, seed, stream)
     u = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
     return (u < np.float32(keep_prob)).astype(np.uint8).reshape(shape)
+
+
+def keep_mask_rows(shape, batch_axis, seed, stream, sample0, keep_prob):
+    """Sample-keyed keep-mask of a 3-D ``shape`` whose ``batch_axis`` (0: [B, T, C], 1: [S, B, C]) indexes the samples of a
+    batch: the mask of sample ``b`` is drawn from its own Philox stream, counter = (block, sample0 + b, stream, 0), element
+    (o, c) of the sample's [outer, inner] slice being draw ``o * inner + c`` of it.  ``sample0`` = the global index of this
+    rank's first sample, so a sample sees the same mask however the global batch is sharded."""
+    if batch_axis == 0:
+        B, outer, inner = int(shape[0]), 1, int(np.prod(shape[1:]))
+    else:
+        outer, B, inner = int(shape[0]), int(shape[1]), int(np.prod(shape[2:]))
+    n = outer * inner
+    nblk = (n + 3) // 4
+    blk = np.arange(nblk, dtype=np.uint32)[None, :].repeat(B, 0)
+    smp = ((int(sample0) + np.arange(B, dtype=np.uint64)) & MASK32).astype(np.uint32)[:, None].repeat(nblk, 1)
+    c2 = np.full((B, nblk), np.uint32(stream & 0xFFFFFFFF), np.uint32)
+    r = philox4x32_10(blk, smp, c2, np.zeros((B, nblk), np.uint32), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    w = np.stack(r, axis=2).reshape(B, -1)[:, :n]
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    m = (u < np.float32(keep_prob)).astype(np.uint8)                      # [B, outer * inner]
+    if batch_axis == 0:
+        return m.reshape(shape)
+    return np.ascontiguousarray(m.reshape(B, outer, inner).transpose(1, 0, 2)).reshape(shape)

@@ -54,9 +54,19 @@ def mask_table(d: M.Dims, B, T_enc, S, training, speaker_windows=0, vocoder=Fals
     return t
 
 
+def mask_batch_axis(name):
+    """Batch-major masks ([B, T, C]: the conv-block dropouts) have their samples on axis 0, step-major ones ([S, B, C]) on axis 1."""
+    return 0 if name.startswith(("enc_conv_drop", "post_drop")) else 1
+
+
 def make_masks(d, B, T_enc, S, training, seed, rank=0, **kw):
-    return {name: torch.from_numpy(rng.keep_mask(shape, seed, stream + 1000 * rank, keep))
-            for name, stream, shape, keep in mask_table(d, B, T_enc, S, training, **kw)}
+    """Every mask is keyed by (seed, stream, GLOBAL sample index, position inside the sample): rank r of a data-parallel run
+    owns the samples r * B ... r * B + B - 1 (for the speaker stack: windows), so 1/2/4/8-rank runs draw identical masks."""
+    out = {}
+    for name, stream, shape, keep in mask_table(d, B, T_enc, S, training, **kw):
+        ax = mask_batch_axis(name)
+        out[name] = torch.from_numpy(rng.keep_mask_rows(shape, ax, seed, stream, rank * shape[ax], keep))
+    return out
 
 
 def learning_rate(step, initial=1e-3, minimum=1e-5, decay_start=0, decay_step=10000, decay_rate=0.5):

@@ -20,8 +20,14 @@ batch = OT.synthetic_batch(d, B, Te, L, seed=seed, ragged=True)
 masks = OT.make_masks(d, B, Te, L + 1, True, seed=OT.step_seed(1234, 0))
 _, _, sc, grads, out = OT.train_step(params, None, d, batch, masks, 0, return_grads=True)
 k = "decoder/decoder/attention_wrapper/multi_rnn_cell/cell_0/zoneout_lstm_cell/kernel"
+# the fixture is self-contained: inputs (variables, batch, keep-masks) and expected outputs, so the GPU test that consumes it
+# (tests/test_gpu_model.py::test_golden_fixture_hip) needs nothing from oracle/
+inputs = {"p/" + n: np.asarray(v) for n, v in params.items()}
+inputs.update({"b/" + n: v.numpy() for n, v in batch.items()})
+inputs.update({"m/" + n: v.numpy() for n, v in masks.items()})
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiny_train_step.npz"),
                     cfg=json.dumps(cfg), seed=seed, B=B, Te=Te, L=L, mel=out["Mel"].numpy(), linear=out["Linear"].numpy(),
                     stop=out["Stop_Logit"].numpy(), align=out["Attention_History"].numpy(), loss=sc["Loss"],
-                    grad_cell0=grads[k].numpy())
+                    scalars=json.dumps({k_: float(v) for k_, v in sc.items()}),
+                    grad_cell0=grads[k].numpy(), **{"g/" + n: v.numpy() for n, v in grads.items()}, **inputs)
 print("wrote golden; loss", sc["Loss"])

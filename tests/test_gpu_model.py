@@ -97,7 +97,7 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     qs = torch.zeros(B, A, device=dev)
     q3 = torch.stack([0.25 * q, 0.5 * q, 0.25 * q]).contiguous()            # the query arrives as split-K partial slabs
     lib.call("mstts_lsa_step_fwd", C.byref(c), lib.ptr(q3), 3, B * A, lib.ptr(qs), lib.ptr(dcum), lib.ptr(al2), lib.ptr(cn2),
-             lib.ptr(cx2), M + 4, lib.ptr(cx3), M, lib.ptr(gran), 7)
+             lib.ptr(cx2), M + 4, lib.ptr(cx3), M, None, lib.ptr(gran), 7)
     assert rel_err(t2n(al2), t2n(align)) < 2e-5 and rel_err(t2n(cn2), t2n(cum_next)) < 2e-5 and rel_err(t2n(cx2[:, :M]), t2n(ctx)) < 2e-5
     assert torch.equal(cx2[:, :M], cx3) and float(cx2[:, M:].abs().max()) == 0.0 and rel_err(t2n(qs), t2n(q)) < 1e-6
     assert int(gran[-1]) == 0 and bool(((gran[:B * T] >> 32) == 7).all())      # no time-outs; every granule carries this epoch
@@ -179,7 +179,7 @@ def test_lsa_step_exchange_under_load(dev):
     X, W, Pw = rn(32, 1024, sc=0.1), rn(1024, 4096, sc=0.05), torch.zeros(16 * 32 * 4096, device=dev)
     for e in range(N):
         lib.call("mstts_lsa_step_fwd", C.byref(c), lib.ptr(qs[e]), 1, 0, None, lib.ptr(cum[e]), lib.ptr(al[e]), lib.ptr(cum[e + 1]),
-                 lib.ptr(cx[e]), M, None, 0, lib.ptr(gran), e + 1)
+                 lib.ptr(cx[e]), M, None, 0, None, lib.ptr(gran), e + 1)
         if e % 3 != 2:      # uneven load between the steps
             lib.call("mstts_skinny_fwd", lib.ptr(X), 1024, lib.ptr(W), 4096, lib.ptr(Pw), 0, 32, 4096, 1024, 4)
     for e in range(N):
@@ -238,7 +238,6 @@ def _engine_vs_oracle(dev, B, Te, L, ragged, seed, recurrent_dtype=None, **dims_
     batch = OT.synthetic_batch(od, B, Te, L, seed=seed, ragged=ragged)
     S = L + 1
     masks = OT.make_masks(od, B, Te, S, True, seed=OT.step_seed(1234, 0))
-    new_p, opt, sc, grads, out = OT.train_step(values, None, od, batch, masks, 0, return_grads=True)
     eng = TrainEngine(pd, device=dev, values=values, recurrent_dtype=recurrent_dtype)
     w = eng.plan(B, Te, L)
     eng.forward(to_dev(batch, dev), w, seed=OT.step_seed(1234, 0))     # masks drawn on the device by Philox
@@ -246,14 +245,29 @@ def _engine_vs_oracle(dev, B, Te, L, ragged, seed, recurrent_dtype=None, **dims_
         assert np.array_equal(t2n(w.masks[name]), m.numpy()), name
     eng.loss_and_backward(w)
     torch.cuda.synchronize()
+    # ReLU pattern of the encoder convolutions, injected into the oracle like the dropout masks (oracle.model.relu_at): with
+    # B*T*C ~ 2M pre-activations per layer a handful sit within fp32 rounding of 0 and the gradient is discontinuous there -
+    # one such element moved a conv-bias gradient by 12 % of its maximum at B = 32, T = 128.  The oracle asserts that the
+    # injected pattern differs from its own only inside +-1e-4.
+    omasks = dict(masks)
+    for i in range(od.enc_conv_n):
+        omasks["relu_enc_%d" % i] = (w.enc_a[i] > 0).reshape(B, Te, od.enc_conv_ch).cpu()
+    new_p, opt, sc, grads, out = OT.train_step(values, None, od, batch, omasks, 0, return_grads=True)
     return eng, w, od, values, batch, sc, grads, out, new_p
 
 
 MID = dict(dec_lstm=64, enc_lstm=32, spk=64, prenet=32)      # shapes on which the skinny K-split kernels are active
 
 
+# the reference's own layer widths (Hyper_Parameters.py:4-62): the skinny<14>/<16> instantiations, the 84-column padded projection,
+# the T=128 single-launch attention geometry and the 512-channel convolutions all meet the oracle end to end in fp32 here; only the
+# frozen vocoder / speaker stacks (not on the gradient path) stay reduced
+REF = dict(emb=512, enc_conv_ch=512, enc_lstm=256, spk=256, prenet=256, dec_lstm=1024, n_mel=80, post_ch=512)
+
+
 @pytest.mark.parametrize("B,Te,L,ragged,kw", [(3, 9, 6, False, {}), (4, 21, 13, True, {}), (5, 18, 9, True, MID), (16, 12, 7, True, MID),
-                                                (1, 2, 1, False, {}), (2, 140, 3, True, MID)])       # smallest batch/lengths; more tokens than one attention pass
+                                                (1, 2, 1, False, {}), (2, 140, 3, True, MID),       # smallest batch/lengths; more tokens than one attention pass
+                                                (32, 128, 4, False, REF), (8, 40, 12, True, REF)])  # fp32 at the reference widths (config-2 geometry / ragged)
 def test_train_step_parity(dev, B, Te, L, ragged, kw):
     eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, ragged, seed=11, **kw)
     tol = 1e-3    # north_star: within 1e-3 relative on fp32 mels
@@ -287,6 +301,78 @@ def test_train_step_parity(dev, B, Te, L, ragged, kw):
         if e > 2e-3:
             bad[k] = e
     assert not bad, bad
+
+
+def test_golden_fixture_hip(dev):
+    """The HIP path against the committed fixture tests/golden/tiny_train_step.npz (inputs AND expected outputs are data in the
+    file: variables, batch, keep-masks -> mel / linear / stop / alignments / loss scalars / every gradient).  Nothing under
+    oracle/ is called here; tests/test_kats.py::test_golden_fixtures_match_oracle keeps the file and the oracle in step."""
+    import json
+    import os
+    from multi_speaker_tts_amd.params import Dims
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_train_step.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    values = {k[2:]: g[k] for k in g.files if k.startswith("p/")}
+    batch = {k[2:]: torch.from_numpy(g[k]).to(dev).contiguous() for k in g.files if k.startswith("b/")}
+    batch = {k: (v.float() if v.is_floating_point() else v) for k, v in batch.items()}
+    masks = {k[2:]: g[k] for k in g.files if k.startswith("m/")}
+    B, Te, L = int(g["B"]), int(g["Te"]), int(g["L"])
+    eng = TrainEngine(Dims(**cfg), device=dev, values=values)
+    w = eng.plan(B, Te, L)
+    eng.forward(batch, w, masks=masks)
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    assert rel_err(t2n(w.mel_out), g["mel"]) < 1e-3 and rel_err(t2n(w.linear), g["linear"]) < 1e-3
+    assert rel_err(t2n(w.stop), g["stop"]) < 1e-3 and rel_err(t2n(w.align_hist).transpose(1, 2, 0), g["align"]) < 1e-3
+    sc, got = json.loads(str(g["scalars"])), eng.scalars(w)
+    for k in ("Linear_Loss", "Postnet_Loss", "Stop_Loss", "Weight_Regularization_Loss", "Loss"):
+        assert abs(got[k] - sc[k]) <= 1e-4 * max(1.0, abs(sc[k])), (k, got[k], sc[k])
+    ggot = eng.params.export(grads=True)
+    bad = {}
+    for k in g.files:
+        if not k.startswith("g/"):
+            continue
+        n = k[2:]
+        mine = ggot[n].astype(np.float64) + (1e-6 * np.asarray(values[n]) if OM.in_weight_reg(n) else 0.0)
+        e = np.abs(mine - g[k]).max() / (np.abs(g[k]).max() + 1e-9)
+        if e > 5e-3:
+            bad[n] = e
+    assert not bad, bad
+
+
+def test_full_size_config2_properties(dev):
+    """BASELINE config 2 at its full size (batch 32 x 128 tokens x 800 frames, reference widths, fp32) - too large for the oracle,
+    so size-independent properties: every output / gradient / updated variable finite, the in-launch exchange of the attention
+    kernels never timed out (forward and backward counters 0), the loss goes down when one batch is repeated, the workspace
+    cache stays bounded, and a second engine fed the same inputs reproduces the forward bit for bit (no run-to-run
+    nondeterminism on the forward path)."""
+    import bench
+    from multi_speaker_tts_amd import engine as E
+    from multi_speaker_tts_amd.params import Dims
+    d = Dims()
+    eng = TrainEngine(d, device=dev, seed=1)
+    batch = bench.synthetic_batch(d, 32, 128, 800, 1, 0, dev)
+    losses = []
+    for i in range(4):
+        w = eng.train_step(batch)
+        torch.cuda.synchronize()
+        s = eng.scalars(w)
+        losses.append(s["Loss"])
+        assert all(np.isfinite(v) for v in s.values()), s
+        assert bool(torch.isfinite(eng.params.grad).all()) and bool(torch.isfinite(eng.params.train).all())
+        assert bool(torch.isfinite(w.mel_out).all()) and bool(torch.isfinite(w.align_hist).all())
+        assert eng.exchange_timeouts(w) == (0, 0)
+        assert len(eng._plans) <= E.MAX_PLANS
+    assert w.mel_out.shape == (32, 801, 80) and losses[-1] < losses[0], losses
+    a = t2n(w.align_hist)                                              # every alignment row is a distribution over the 128 tokens
+    assert np.abs(a.sum(-1) - 1.0).max() < 1e-4 and a.min() >= 0.0
+    eng2 = TrainEngine(d, device=dev, seed=1)
+    w2 = eng2.plan(32, 128, 800)
+    eng2.forward(batch, w2, seed=7)
+    lin_a = w2.linear.clone()
+    eng2.forward(batch, w2, seed=7)
+    torch.cuda.synchronize()
+    assert torch.equal(lin_a, w2.linear)
 
 
 @pytest.mark.parametrize("B,Te,L,kw", [(5, 18, 9, MID), (32, 24, 6, dict(dec_lstm=1024, enc_lstm=256, spk=256, prenet=256, n_mel=80))])

@@ -185,6 +185,69 @@ def test_skinny_bwd(dev, M, R, N):
     assert rel_err(t2n(P).astype(np.float64).sum(0), ref) < TOL
 
 
+@pytest.mark.parametrize("B,H,K,mode", [(32, 1024, 1792, "xw"), (32, 1024, 2048, "bias"), (5, 64, 192, "xw"), (17, 8, 64, "bias"), (40, 16, 128, "none"),
+                                         (16, 1024, 2048, "bias")])
+def test_cell_fwd_fused(dev, B, H, K, mode):
+    """Fused cell step (gates product + zoneout-LSTM update in one launch, packed kernel) vs the cell in fp64
+    (ZoneoutLSTMCell.py:228-271): output m, zoned state, saved activations / raw cell state."""
+    L = lib.load()
+    assert L.mstts_cell_fwd_supported(H, K) == 1 and L.mstts_cell_fwd_supported(H, K + 16) == 0
+    ldx, hld, old = K + 8, H + 4, H + 12
+    X = _r(dev, B, ldx, seed=1)
+    W = _r(dev, K, 4 * H, seed=2, scale=1.0 / np.sqrt(K))
+    Wp = torch.zeros(K * 4 * H, device=dev)
+    lib.call("mstts_pack_cell_fwd", lib.ptr(W), 4 * H, lib.ptr(Wp), K, H)
+    assert sorted(t2n(Wp).tolist()) == sorted(t2n(W).reshape(-1).tolist())          # a permutation of the kernel
+    xw = _r(dev, B, 4 * H, seed=3) if mode == "xw" else None
+    bias = _r(dev, 4 * H, seed=4, scale=0.3) if mode == "bias" else None
+    cp, hp = _r(dev, B, H, seed=5), _r(dev, B, hld, seed=6)
+    g = np.random.default_rng(7)
+    zc = torch.tensor(g.integers(0, 2, (B, H)).astype(np.uint8), device=dev)
+    zh = torch.tensor(g.integers(0, 2, (B, H)).astype(np.uint8), device=dev)
+    out, cn, hn = torch.zeros(B, old, device=dev), torch.zeros(B, H, device=dev), torch.zeros(B, hld, device=dev)
+    acts, craw = torch.zeros(B, 4 * H, device=dev), torch.zeros(B, H, device=dev)
+    Xp = torch.full((int(L.mstts_cell_act_floats(B, K)),), float("nan"), device=dev)
+    lib.call("mstts_pack_cell_act", lib.ptr(X), ldx, lib.ptr(Xp), B, K)
+    assert sorted(t2n(Xp)[t2n(Xp) != 0].tolist()) == sorted(t2n(X)[:, :K].reshape(-1).tolist())       # a permutation of the block (+ zero rows)
+    K2, c0 = 2 * K if 2 * K <= 2048 else K, 64 if H + 64 <= K else 0
+    outp = torch.zeros(int(L.mstts_cell_act_floats(B, K2)), device=dev)
+    hnp = torch.zeros(int(L.mstts_cell_act_floats(B, K)), device=dev)
+    d = lib.CellFwd()
+    d.B, d.H, d.K, d.Xp, d.Wp = B, H, K, lib.ptr(Xp), lib.ptr(Wp)
+    if H <= K:               # packed copies of m (into a block of width K2 at column 0) and h' (width K at column c0)
+        d.out_p.base, d.out_p.K, d.out_p.col0 = lib.ptr(outp), K2, 0
+        if c0 + H <= K:
+            d.h_next_p.base, d.h_next_p.K, d.h_next_p.col0 = lib.ptr(hnp), K, c0
+    d.xw, d.xw_ld, d.bias = lib.ptr(xw), 4 * H, lib.ptr(bias)
+    d.c_prev, d.h_prev, d.h_prev_ld, d.zc, d.zh, d.zoneout = lib.ptr(cp), lib.ptr(hp), hld, lib.ptr(zc), lib.ptr(zh), 0.1
+    d.out, d.out_ld, d.c_next, d.h_next, d.h_next_ld, d.acts, d.c_raw = lib.ptr(out), old, lib.ptr(cn), lib.ptr(hn), hld, lib.ptr(acts), lib.ptr(craw)
+    lib.call("mstts_cell_fwd", C.byref(d))
+    gates = t2n(X)[:, :K].astype(np.float64) @ t2n(W).astype(np.float64)
+    if xw is not None:
+        gates = gates + t2n(xw)
+    if bias is not None:
+        gates = gates + t2n(bias)
+    sg = lambda x: 1.0 / (1.0 + np.exp(-x))
+    i, j, f, o = np.split(gates, 4, axis=1)
+    c = sg(f + 1.0) * t2n(cp) + sg(i) * np.tanh(j)
+    m = sg(o) * np.tanh(c)
+    c2 = 0.9 * t2n(zc) * (c - t2n(cp)) + t2n(cp)
+    h2 = 0.9 * t2n(zh) * (m - t2n(hp)[:, :H]) + t2n(hp)[:, :H]
+    assert rel_err(t2n(out)[:, :H], m) < TOL and rel_err(t2n(cn), c2) < TOL and rel_err(t2n(hn)[:, :H], h2) < TOL
+    assert float(out[:, H:].abs().max()) == 0.0 and float(hn[:, H:].abs().max()) == 0.0                # nothing written past the H columns
+    assert rel_err(t2n(craw), c) < TOL and rel_err(t2n(acts), np.concatenate([sg(i), np.tanh(j), sg(f + 1.0), sg(o)], 1)) < TOL
+    if H <= K:               # the packed copies hold exactly what the row-major outputs hold
+        ref = torch.zeros(B, K2, device=dev); ref[:, :H] = out[:, :H]
+        chk = torch.zeros_like(outp)
+        lib.call("mstts_pack_cell_act", lib.ptr(ref), K2, lib.ptr(chk), B, K2)
+        assert torch.equal(chk, outp)
+        if c0 + H <= K:
+            ref = torch.zeros(B, K, device=dev); ref[:, c0:c0 + H] = hn[:, :H]
+            chk = torch.zeros_like(hnp)
+            lib.call("mstts_pack_cell_act", lib.ptr(ref), K, lib.ptr(chk), B, K)
+            assert torch.equal(chk, hnp)
+
+
 def _bf(t):
     return t.to(torch.bfloat16).to(torch.float64)
 

@@ -22,7 +22,7 @@ gran = torch.zeros(B * T + 1, dtype=torch.int64, device=dev)
 ep = [0]
 def step():
     ep[0] += 1
-    lib.call("mstts_lsa_step_fwd", C.byref(c), lib.ptr(q), 8, B * A, None, lib.ptr(cum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0, lib.ptr(gran), ep[0])
+    lib.call("mstts_lsa_step_fwd", C.byref(c), lib.ptr(q), 8, B * A, None, lib.ptr(cum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0, None, lib.ptr(gran), ep[0])
 def two():
     lib.call("mstts_lsa_energy_fwd", C.byref(c), lib.ptr(q), 8, B * A, None, lib.ptr(cum), lib.ptr(en))
     lib.call("mstts_lsa_context_fwd", C.byref(c), lib.ptr(en), lib.ptr(cum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0)

@@ -148,6 +148,10 @@ typedef struct {
     float* dgates;                   /* [B,4H] step-major */
     float* dgates_pos; int64_t dgp_sb, dgp_st;     /* optional second copy at (b,pos) or NULL */
     float* d_c_prev; float* d_h_prev;               /* [B,H]; d_h_prev gets only the direct (zoneout bypass) part */
+    /* optional third addend of the output grad, computed in the launch: dq[B,A] . Wq[H,A]^T - the attention query layer's data
+     * gradient (q = m . Wq, Location_Sensitive_Attention.py:46) folded into the cell update.  wq_t = a derived copy of Wq laid out
+     * [A/4][H][4] (mstts_transpose01(Wq, wq_t, H, A/4, 4)); A must be 128 */
+    const float* dq; const float* wq_t; int64_t A;
 } mstts_lstm_point_bwd_desc;
 int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_stream_t s);
 
@@ -303,6 +307,11 @@ int mstts_skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, f
 int32_t mstts_skinny_bwd_splits(int64_t R, int64_t N);
 int mstts_skinny_bwd(const float* dG, int64_t ldg, const float* W, int64_t ldw, float* P, int64_t pstride, int64_t M, int64_t R,
                      int64_t N, int32_t nsplit, mstts_stream_t s);
+/* the same product against a derived copy of W in the kernel's lane order (R % 32 == 0; made by mstts_pack_skinny_bwd for the same
+ * nsplit, R*N floats; refresh after every optimizer step): every wave load is one contiguous 1 KB instead of 16 rows x 64 B */
+int mstts_pack_skinny_bwd(const float* W, int64_t ldw, float* Wp, int64_t R, int64_t N, int32_t nsplit, mstts_stream_t s);
+int mstts_skinny_bwd_packed(const float* dG, int64_t ldg, const float* Wp, float* P, int64_t pstride, int64_t M, int64_t R,
+                            int64_t N, int32_t nsplit, mstts_stream_t s);
 
 /* ---- WaveGlow vocoder, inference direction (WaveGlow/Modules.py:177-208,210-327,354-371; Inv1x1.py:9-41).  The contractions run
  * on mstts_gemm_f32 (win_dil for the dilated K=3 convs); these are the remaining pieces, all [rows, channels] row-major.
@@ -421,6 +430,10 @@ typedef struct {
     /* optional fused cell steps (fp32): w0f / w1 packed by mstts_pack_cell_fwd; both non-NULL and
      * mstts_cell_fwd_supported(H, M+H) && (H, 2H) -> each cell is one mstts_cell_fwd launch instead of product + pointwise */
     const float* w0p; const float* w1p;
+    /* optional packed kernels of the BPTT data-gradient products (mstts_pack_skinny_bwd with the split counts of
+     * mstts_skinny_bwd_splits(M+H, 4H) / (2H, 4H) / (H, A)); NULL -> the row-major kernels are streamed */
+    const float* w0f_bp; const float* w1_bp; const float* wq_bp;
+    const float* wq_t;  /* optional [A/4,H,4] re-layout of wq (mstts_transpose01(wq, wq_t, H, A/4, 4)): the query layer's data gradient is folded into cell 1's pointwise backward */
     float* act_p;      /* ... and their packed activation blocks: 2 * (mstts_cell_act_floats(B, M+H) + mstts_cell_act_floats(B, 2H)) floats */
 } mstts_decoder_train_desc;
 int32_t mstts_decoder_bf16_splits(int64_t H, int64_t M, int64_t A, int32_t* out6);

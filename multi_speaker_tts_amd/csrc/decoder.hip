@@ -95,9 +95,13 @@ static int xw_fwd(const float* X, long ldx, const float* W, long ldw, float* P, 
     *parts = 1;
     return gemm(X, ldx, W, ldw, 0, P, N, M, N, K, nullptr, 0, 0, s);
 }
-// dG[M,N] . W[R,N]^T
+// dG[M,N] . W[R,N]^T   (Wp: optional packed copy of W for exactly `splits` slices)
 static int xw_bwd(const float* dG, long ldg, const float* W, long ldw, float* P, long pstride, long M, long R, long N, int splits,
-                  int* parts, mstts_stream_t s) {
+                  int* parts, mstts_stream_t s, const float* Wp = nullptr) {
+    if (Wp && splits > 0 && R % 32 == 0 && ldg % 4 == 0 && aligned16(dG) && aligned16(Wp)) {
+        *parts = splits;
+        return mstts_skinny_bwd_packed(dG, ldg, Wp, P, pstride, M, R, N, splits, s);
+    }
     if (splits > 0 && ldg % 4 == 0 && ldw % 4 == 0 && aligned16(dG) && aligned16(W)) {
         *parts = splits;
         return mstts_skinny_bwd(dG, ldg, W, ldw, P, pstride, M, R, N, splits, s);
@@ -413,6 +417,8 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     const long ws_per_row = 8 * H + 2 * T + 2 * T * CH + T + (long)np1 * W1 + (long)npq * H;
     // single-launch attention backward: its granules (B*ceil(T/8)+1 8-byte words) live in the d_align block (B*T floats)
     const bool fused_lsa = lsa_fused_enabled() && chains == 1 && mstts_lsa_step_bwd_ws_bytes(B, T) <= B * T * 4;
+    // query-layer data gradient inside cell 1's pointwise kernel: fp32 mode, A == 128, slab counts the lean kernel is built for
+    const bool fuse_q = !bf && d->wq_t && A == 128 && (np1 == 8 || np1 == 4 || np1 == 2 || np1 == 1) && B * H * 4 < (1LL << 30);
     RC(zero(bd->ws, ws_per_row * B, s));
     mstts_stream_t cs[MAX_CHAINS];
     RC(chain_fork(chains, s, cs));
@@ -457,14 +463,16 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
                                          d->cum_hist + (st * B + b0) * T, bd->de_hist + (st * B + b0) * T, bd->dq_hist + (st * B + b0) * A, k.df[nxt], q_s));
             }
             // d_m1 (query path) = dq . Wq^T  -> slabs consumed by the cell-1 pointwise kernel
-            if (bf) { k.partsq = bfs[5]; RC(mstts_skinny_bwd_bf16(bd->dq_hist + (st * B + b0) * A, A, d->bf_wq_b, k.dqm, 0, Bc, H, A, bfs[5], q_s)); }
-            else RC(xw_bwd(bd->dq_hist + (st * B + b0) * A, A, d->wq, A, k.dqm, 0, Bc, H, A, spq, &k.partsq, q_s));
+            if (fuse_q) {}          // folded into the cell-1 pointwise kernel below
+            else if (bf) { k.partsq = bfs[5]; RC(mstts_skinny_bwd_bf16(bd->dq_hist + (st * B + b0) * A, A, d->bf_wq_b, k.dqm, 0, Bc, H, A, bfs[5], q_s)); }
+            else RC(xw_bwd(bd->dq_hist + (st * B + b0) * A, A, d->wq, A, k.dqm, 0, Bc, H, A, spq, &k.partsq, q_s, d->wq_bp));
             // ---- cell 1 backward
             mstts_lstm_point_bwd_desc p;
             memset(&p, 0, sizeof(p));
             p.B = Bc; p.H = H;
             p.d_out = dpj; p.dout_sb = WP; p.dout_st = 0;
-            p.d_out2 = k.dqm; p.dout2_parts = k.partsq; p.dout2_pstride = BcH;
+            if (fuse_q) { p.dq = bd->dq_hist + (st * B + b0) * A; p.wq_t = d->wq_t; p.A = A; }
+            else { p.d_out2 = k.dqm; p.dout2_parts = k.partsq; p.dout2_pstride = BcH; }
             p.d_c_state = k.dc1[cur]; p.d_h_state = k.dh1[cur];
             p.d_h_state2 = last ? nullptr : k.tmp1 + H; p.dhs2_ld = W1; p.dhs2_parts = k.parts1; p.dhs2_pstride = Bc * W1;
             p.acts = d->acts1 + (st * B + b0) * 4 * H; p.c_raw = d->craw1 + (st * B + b0) * H; p.c_prev = d->c1 + (st * B + b0) * H;
@@ -475,7 +483,7 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
             RC(mstts_lstm_point_bwd(&p, q_s));
             // [d_m0 | d_h1 state] = dg1 . w1^T
             if (bf) { k.parts1 = bfs[4]; PROBED(MSTTS_PROBE_CELL1_DGEMM, q_s, mstts_skinny_bwd_bf16(p.dgates, 4 * H, d->bf_w1_b, k.tmp1, 0, Bc, W1, 4 * H, bfs[4], q_s)); }
-            else PROBED(MSTTS_PROBE_CELL1_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w1, 4 * H, k.tmp1, 0, Bc, W1, 4 * H, sp1, &k.parts1, q_s));
+            else PROBED(MSTTS_PROBE_CELL1_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w1, 4 * H, k.tmp1, 0, Bc, W1, 4 * H, sp1, &k.parts1, q_s, d->w1_bp));
             // ---- cell 0 backward
             memset(&p, 0, sizeof(p));
             p.B = Bc; p.H = H;
@@ -492,7 +500,7 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
             if (bf) { k.parts0 = bfs[3]; PROBED(MSTTS_PROBE_CELL0_DGEMM, q_s, mstts_skinny_bwd_bf16(p.dgates, 4 * H, d->bf_w0f_b, bd->d_in0 + (st * B + b0) * W0,
                                                                                                    d_in0_slab, Bc, W0, 4 * H, bfs[3], q_s)); }
             else PROBED(MSTTS_PROBE_CELL0_DGEMM, q_s, xw_bwd(p.dgates, 4 * H, d->w0f, 4 * H, bd->d_in0 + (st * B + b0) * W0, d_in0_slab, Bc, W0, 4 * H,
-                                                            sp0, &k.parts0, q_s));
+                                                            sp0, &k.parts0, q_s, d->w0f_bp));
         }
         cur = nxt;
     }

@@ -493,10 +493,14 @@ struct PointBwdFast {
     float* dgates; float* d_c_prev; float* d_h_prev;
     const int32_t* lengths; int step, reverse;                     // SEQ only
     float* dgates_pos; int dgp_ld, dgp_st;                         // SEQ only (or null)
+    const float* dq; const float* wq_t;                            // FUSE_Q only: [B][QA], [QA/4][H][4]
     int B, H;
 };
+constexpr int QA = 128;        // attention units of the fused query-layer gradient (hp.Attention.Memory_Size)
 
-template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ>
+// FUSE_Q: the output gradient also gets dq[b,:] . Wq[u,:] (the attention query layer's data gradient, q = m1 . Wq), computed here from
+// the transposed kernel instead of by a product launch of its own; all QA loads of a thread are issued before the first FMA
+template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, bool FUSE_Q = false>
 __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d) {
     const int i = blockIdx.x * 128 + threadIdx.x;
     const int H = d.H;
@@ -508,6 +512,14 @@ __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d
         const int len = d.lengths ? d.lengths[b] : 0x7fffffff;
         live = d.step < len;
         pos = (d.reverse && live) ? len - 1 - d.step : d.step;
+    }
+    float4 wqv[FUSE_Q ? QA / 4 : 1], dqv[FUSE_Q ? QA / 4 : 1];
+    if (FUSE_Q) {                 // wq_t is [QA/4][H][4]: consecutive units are consecutive float4 - 1 KB per wave load
+#pragma unroll
+        for (int a = 0; a < QA / 4; ++a) {
+            wqv[a] = reinterpret_cast<const float4*>(d.wq_t)[a * H + u];
+            dqv[a] = reinterpret_cast<const float4*>(d.dq)[b * (QA / 4) + a];
+        }
     }
     float dhs = d.d_h_state[i];
     if (d.dhs2) {
@@ -531,6 +543,12 @@ __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d
     if (d.d_out2) {
 #pragma unroll
         for (int pp = 0; pp < P_OUT2; ++pp) dm += d.d_out2[pp * d.dout2_pstride + i];
+    }
+    if (FUSE_Q) {
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+        for (int a = 0; a < QA / 4; ++a) { q0 += dqv[a].x * wqv[a].x; q1 += dqv[a].y * wqv[a].y; q2 += dqv[a].z * wqv[a].z; q3 += dqv[a].w * wqv[a].w; }
+        dm += (q0 + q1) + (q2 + q3);
     }
     const float mh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
     const float mc = d.zc ? (d.zc[i] ? d.keep : 0.f) : d.keep;
@@ -911,16 +929,23 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
         const bool seq = d->lengths || d->reverse || d->dgates_pos || d->dout_st != 0;
         const bool small = d->B * d->H * 4 < (1LL << 30) && (long)po * d->dout_pstride < (1LL << 30) && (d->B + 1) * d->dout_sb < (1LL << 30) &&
                            (d->B + 1) * d->dgp_sb < (1LL << 30);
+        const bool fuse_q = d->dq && d->wq_t;
+        MSTTS_REQUIRE(!fuse_q || (aligned16(d->dq) && aligned16(d->wq_t)), MSTTS_ERR_ALIGN, "lstm_point_bwd: dq / wq_t must be 16-byte aligned");
+        MSTTS_REQUIRE(!fuse_q || (d->A == QA && !d->d_out2 && !d->lengths && !d->reverse && !d->dgates_pos && d->dout_st == 0), MSTTS_ERR_SHAPE,
+                      "lstm_point_bwd: the fused query-layer gradient needs A == %d, no d_out2 and the plain (non-sequence) form", QA);
         int shape = -1;      // (P_OUT, P_OUT2, P_DHS)
-        if (po == 1 && po2 == 1 && ph == 1) shape = 0;
+        if (fuse_q) shape = (po == 1 && ph == 8) ? 10 : (po == 1 && ph == 1) ? 11 : (po == 1 && ph == 4) ? 12 : (po == 1 && ph == 2) ? 13 : -2;
+        else if (po == 1 && po2 == 1 && ph == 1) shape = 0;
         else if (po == 1 && po2 == 1 && ph == 4) shape = 1;
         else if (po == 4 && po2 == 1 && ph == 4) shape = 2;
         else if (po == 1 && po2 == 1 && ph == 8) shape = 3;
         else if (po == 8 && po2 == 1 && ph == 8) shape = 4;
         else if (po == 8 && po2 == 1 && ph == 1) shape = 5;
         else if (po == 1 && po2 == 1 && ph == 2) shape = 6;
+        MSTTS_REQUIRE(!fuse_q || (small && shape >= 10), MSTTS_ERR_SHAPE, "lstm_point_bwd: fused query-layer gradient not available for this slab geometry");
         if (small && shape >= 0) {
             PointBwdFast f;
+            f.dq = d->dq; f.wq_t = d->wq_t;
             f.d_out = d->d_out; f.dout_ld = (int)d->dout_sb; f.dout_st = (int)d->dout_st; f.dout_parts = po; f.dout_pstride = (int)d->dout_pstride;
             f.d_out2 = d->d_out2; f.dout2_parts = po2; f.dout2_pstride = (int)d->dout2_pstride;
             f.d_c_state = d->d_c_state; f.d_h_state = d->d_h_state;
@@ -941,6 +966,10 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
                 case 3: MSTTS_PB(1, 1, 8); break;
                 case 4: MSTTS_PB(8, 1, 8); break;
                 case 5: MSTTS_PB(8, 1, 1); break;
+                case 10: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 8, false, true>), grid, dim3(128), 0, ST(s), f); break;
+                case 11: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 1, false, true>), grid, dim3(128), 0, ST(s), f); break;
+                case 12: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 4, false, true>), grid, dim3(128), 0, ST(s), f); break;
+                case 13: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 2, false, true>), grid, dim3(128), 0, ST(s), f); break;
                 default: MSTTS_PB(1, 1, 2); break;
             }
 #undef MSTTS_PB

@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 // backward: strip of 32 kernel rows, N-slice of NL columns (NL % 32 == 0, NL <= 1024).
 // wave w: row tile (w & 1) of 16 rows, column half (w >> 1) of the slice.
 // ---------------------------------------------------------------------------------------------
-template <int NIT, bool TWO>
+// PACKED: W is a derived copy in the lanes' consumption order (mstts_pack_skinny_bwd): wave w / iteration it / lane l of
+// workgroup (strip, slice) finds its float4 at ((((strip * nsplit + slice) * 4 + w) * nit + it) * 64 + l) * 4 - one contiguous
+// 1 KB per wave load.  From the row-major kernel the same load touches 16 rows x 64 B, four cache lines per 4-lane group.
+template <int NIT, bool TWO, bool PACKED>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ dG, long ldg, const float* __restrict__ W, long ldw,
                                                          float* __restrict__ P, long pstride, int M, int R, int N, int NL) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -156,13 +159,15 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
         if (c4 < nl4 && srow_live) st[q] = *reinterpret_cast<const f32x4*>(gr + c4 * 4);
     }
     // 2) all weight loads: row r0 + 16*rt + j, columns nb + c0 + 16*it .. +3
-    const bool row_ok = r0 + 16 * rt + j < R;
-    const float* wp = W + (long)(r0 + 16 * rt + j) * ldw + nb + c0;
+    const bool row_ok = PACKED || r0 + 16 * rt + j < R;
+    const float* wp = PACKED ? W + ((((long)blockIdx.x * gridDim.y + ns) * 4 + wave) * nit) * 256 + lane * 4
+                             : W + (long)(r0 + 16 * rt + j) * ldw + nb + c0;
+    constexpr int WSTEP = PACKED ? 256 : 16;
     f32x4 wreg[UNROLL];
 #pragma unroll
     for (int it = 0; it < UNROLL; ++it) {
         wreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if ((EXACT || it < nit) && row_ok) wreg[it] = *reinterpret_cast<const f32x4*>(wp + 16 * it);
+        if ((EXACT || it < nit) && row_ok) wreg[it] = *reinterpret_cast<const f32x4*>(wp + WSTEP * it);
     }
     // 3) LDS writes of the slice (second round only when NL > 512)
 #pragma unroll
@@ -224,12 +229,29 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
     }
 }
 
+// row-major W[R, N] (row stride ldw) -> consumption order of skinny_bwd_kernel<.., PACKED> for `nsplit` column slices
+__global__ void pack_skinny_bwd_kernel(const float* __restrict__ W, long ldw, float* __restrict__ Wp, int R, int N, int nsplit) {
+    const int NL = N / nsplit, nit = NL / 32, hl = NL / 2;
+    const long n = (long)R * N;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(p & 3), lane = (int)((p >> 2) & 63);
+        long r = p >> 8;
+        const int it = (int)(r % nit); r /= nit;
+        const int wave = (int)(r & 3); r >>= 2;
+        const int ns = (int)(r % nsplit), strip = (int)(r / nsplit);
+        const int j = lane & 15, kq = lane >> 4, rt = wave & 1, half = wave >> 1;
+        const int row = strip * 32 + 16 * rt + j, col = ns * NL + half * hl + 4 * kq + 16 * it + e;
+        Wp[p] = W[(long)row * ldw + col];
+    }
+}
+
 static bool g_attr_set = false;
 static void set_lds_attr() {
     if (g_attr_set) return;
 #define MSTTS_SK_ATTR(N, T)                                                                                                   \
     hipFuncSetAttribute((const void*)skinny_fwd_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
-    hipFuncSetAttribute((const void*)skinny_bwd_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)skinny_bwd_kernel<N, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipFuncSetAttribute((const void*)skinny_bwd_kernel<N, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     MSTTS_SK_ATTR(0, true) MSTTS_SK_ATTR(0, false) MSTTS_SK_ATTR(2, true) MSTTS_SK_ATTR(2, false) MSTTS_SK_ATTR(4, true) MSTTS_SK_ATTR(4, false)
     MSTTS_SK_ATTR(8, true) MSTTS_SK_ATTR(8, false) MSTTS_SK_ATTR(14, true) MSTTS_SK_ATTR(14, false) MSTTS_SK_ATTR(16, true) MSTTS_SK_ATTR(16, false)
     MSTTS_SK_ATTR(28, true) MSTTS_SK_ATTR(28, false) MSTTS_SK_ATTR(32, true) MSTTS_SK_ATTR(32, false)
@@ -238,26 +260,29 @@ static void set_lds_attr() {
 }
 
 // pick the guard-free instantiation when the trip count is one of the shapes the model produces
+#define SK_FWD(N, T) skinny_fwd_kernel<N, T>
+#define SK_BWD(N, T) skinny_bwd_kernel<N, T, false>
+#define SK_BWD_PACKED(N, T) skinny_bwd_kernel<N, T, true>
 #define MSTTS_SK_DISPATCH(KERNEL, nit, two, ...)                                                       \
     do {                                                                                               \
         if (two) {                                                                                     \
-            if (nit == 32) hipLaunchKernelGGL((KERNEL<32, true>), __VA_ARGS__);                        \
-            else if (nit == 28) hipLaunchKernelGGL((KERNEL<28, true>), __VA_ARGS__);                   \
-            else if (nit == 16) hipLaunchKernelGGL((KERNEL<16, true>), __VA_ARGS__);                   \
-            else if (nit == 14) hipLaunchKernelGGL((KERNEL<14, true>), __VA_ARGS__);                   \
-            else if (nit == 8) hipLaunchKernelGGL((KERNEL<8, true>), __VA_ARGS__);                     \
-            else if (nit == 4) hipLaunchKernelGGL((KERNEL<4, true>), __VA_ARGS__);                     \
-            else if (nit == 2) hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__);                     \
-            else hipLaunchKernelGGL((KERNEL<0, true>), __VA_ARGS__);                                   \
+            if (nit == 32) hipLaunchKernelGGL((KERNEL(32, true)), __VA_ARGS__);                        \
+            else if (nit == 28) hipLaunchKernelGGL((KERNEL(28, true)), __VA_ARGS__);                   \
+            else if (nit == 16) hipLaunchKernelGGL((KERNEL(16, true)), __VA_ARGS__);                   \
+            else if (nit == 14) hipLaunchKernelGGL((KERNEL(14, true)), __VA_ARGS__);                   \
+            else if (nit == 8) hipLaunchKernelGGL((KERNEL(8, true)), __VA_ARGS__);                     \
+            else if (nit == 4) hipLaunchKernelGGL((KERNEL(4, true)), __VA_ARGS__);                     \
+            else if (nit == 2) hipLaunchKernelGGL((KERNEL(2, true)), __VA_ARGS__);                     \
+            else hipLaunchKernelGGL((KERNEL(0, true)), __VA_ARGS__);                                   \
         } else {                                                                                       \
-            if (nit == 32) hipLaunchKernelGGL((KERNEL<32, false>), __VA_ARGS__);                       \
-            else if (nit == 28) hipLaunchKernelGGL((KERNEL<28, false>), __VA_ARGS__);                  \
-            else if (nit == 16) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
-            else if (nit == 14) hipLaunchKernelGGL((KERNEL<14, false>), __VA_ARGS__);                  \
-            else if (nit == 8) hipLaunchKernelGGL((KERNEL<8, false>), __VA_ARGS__);                    \
-            else if (nit == 4) hipLaunchKernelGGL((KERNEL<4, false>), __VA_ARGS__);                    \
-            else if (nit == 2) hipLaunchKernelGGL((KERNEL<2, false>), __VA_ARGS__);                    \
-            else hipLaunchKernelGGL((KERNEL<0, false>), __VA_ARGS__);                                  \
+            if (nit == 32) hipLaunchKernelGGL((KERNEL(32, false)), __VA_ARGS__);                       \
+            else if (nit == 28) hipLaunchKernelGGL((KERNEL(28, false)), __VA_ARGS__);                  \
+            else if (nit == 16) hipLaunchKernelGGL((KERNEL(16, false)), __VA_ARGS__);                  \
+            else if (nit == 14) hipLaunchKernelGGL((KERNEL(14, false)), __VA_ARGS__);                  \
+            else if (nit == 8) hipLaunchKernelGGL((KERNEL(8, false)), __VA_ARGS__);                    \
+            else if (nit == 4) hipLaunchKernelGGL((KERNEL(4, false)), __VA_ARGS__);                    \
+            else if (nit == 2) hipLaunchKernelGGL((KERNEL(2, false)), __VA_ARGS__);                    \
+            else hipLaunchKernelGGL((KERNEL(0, false)), __VA_ARGS__);                                  \
         }                                                                                              \
     } while (0)
 
@@ -308,7 +333,7 @@ extern "C" int mstts_skinny_fwd(const float* X, int64_t ldx, const float* W, int
     set_lds_attr();
     const int nit = KL / 16;
     const bool two = M > 16;      // blocks of 32 rows; with M <= 16 the second 16-row MFMA tile is all padding
-    MSTTS_SK_DISPATCH(skinny_fwd_kernel, nit, two, grid, dim3(256), lds, (hipStream_t)s, X, (long)ldx, W, (long)ldw, P,
+    MSTTS_SK_DISPATCH(SK_FWD, nit, two, grid, dim3(256), lds, (hipStream_t)s, X, (long)ldx, W, (long)ldw, P,
                       (long)(pstride > 0 ? pstride : M * N), (int)M, (int)N, (int)K, KL);
     MSTTS_CHECK_LAUNCH("skinny_fwd");
     return MSTTS_OK;
@@ -347,8 +372,38 @@ extern "C" int mstts_skinny_bwd(const float* dG, int64_t ldg, const float* W, in
     set_lds_attr();
     const int nit = NL / 32;
     const bool two = M > 16;
-    MSTTS_SK_DISPATCH(skinny_bwd_kernel, nit, two, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, W, (long)ldw, P,
+    MSTTS_SK_DISPATCH(SK_BWD, nit, two, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, W, (long)ldw, P,
                       (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL);
     MSTTS_CHECK_LAUNCH("skinny_bwd");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_pack_skinny_bwd(const float* W, int64_t ldw, float* Wp, int64_t R, int64_t N, int32_t nsplit, mstts_stream_t s) {
+    MSTTS_REQUIRE(W && Wp && R >= 32 && R % 32 == 0 && nsplit >= 1 && N % (nsplit * 32L) == 0 && N / nsplit <= 1024 && R * N < (1LL << 31), MSTTS_ERR_SHAPE,
+                  "pack_skinny_bwd: R %% 32 == 0 and N a multiple of 32*nsplit with slices of at most 1024 columns required");
+    const long n = R * N;
+    hipLaunchKernelGGL(pack_skinny_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)s, W, (long)ldw, Wp,
+                       (int)R, (int)N, (int)nsplit);
+    MSTTS_CHECK_LAUNCH("pack_skinny_bwd");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_skinny_bwd_packed(const float* dG, int64_t ldg, const float* Wp, float* P, int64_t pstride, int64_t M, int64_t R,
+                                       int64_t N, int32_t nsplit, mstts_stream_t s) {
+    MSTTS_REQUIRE(dG && Wp && P && M >= 1 && R >= 32 && R % 32 == 0, MSTTS_ERR_SHAPE, "skinny_bwd_packed: bad arguments (R %% 32 == 0)");
+    MSTTS_REQUIRE(nsplit >= 1 && N % (nsplit * 32L) == 0 && N / nsplit <= 1024, MSTTS_ERR_SHAPE,
+                  "skinny_bwd_packed: N must be a multiple of 32*nsplit with slices of at most 1024 columns");
+    MSTTS_REQUIRE(ldg % 4 == 0 && aligned16(dG) && aligned16(Wp), MSTTS_ERR_ALIGN, "skinny_bwd_packed: float4 alignment");
+    const int NL = (int)(N / nsplit);
+    size_t lds = sizeof(float) * (size_t)32 * (NL + 4);
+    const size_t red = sizeof(float) * 4 * 32 * 17;
+    if (lds < red) lds = red;
+    dim3 grid((unsigned)(R / 32), (unsigned)nsplit, (unsigned)((M + 31) / 32));
+    set_lds_attr();
+    const int nit = NL / 32;
+    const bool two = M > 16;
+    MSTTS_SK_DISPATCH(SK_BWD_PACKED, nit, two, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, Wp, 0L, P,
+                      (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL);
+    MSTTS_CHECK_LAUNCH("skinny_bwd_packed");
     return MSTTS_OK;
 }

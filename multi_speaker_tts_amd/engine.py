@@ -85,6 +85,13 @@ class TrainEngine:
         self.fused_cells = bool(lb.mstts_cell_fwd_supported(H, M + H)) and bool(lb.mstts_cell_fwd_supported(H, 2 * H))
         self.w0p = self._f((M + H) * 4 * H) if self.fused_cells else None
         self.w1p = self._f(2 * H * 4 * H) if self.fused_cells else None
+        # packed kernels of the BPTT data-gradient products (csrc/skinny.hip, PACKED form)
+        self.bwd_splits = (int(lb.mstts_skinny_bwd_splits(M + H, 4 * H)), int(lb.mstts_skinny_bwd_splits(2 * H, 4 * H)), int(lb.mstts_skinny_bwd_splits(H, d.att)))
+        ok = lambda R, sp: sp > 0 and R % 32 == 0
+        self.w0f_bp = self._f((M + H) * 4 * H) if ok(M + H, self.bwd_splits[0]) else None
+        self.w1_bp = self._f(2 * H * 4 * H) if ok(2 * H, self.bwd_splits[1]) else None
+        self.wq_bp = self._f(H * d.att) if ok(H, self.bwd_splits[2]) else None
+        self.wq_t = self._f(d.att * H) if d.att == 128 else None         # query kernel as [A/4, H, 4] (fused query-layer data gradient)
         self.flip = {}
         self._derived_stale = True
         self.recurrent_dtype = (recurrent_dtype or __import__('os').environ.get('MSTTS_RECURRENT_DTYPE', 'f32')).lower()
@@ -121,6 +128,15 @@ class TrainEngine:
             k1, o1 = self.P(CELL % 1 + "kernel")
             call("mstts_pack_cell_fwd", ptr(self.w0f), 4 * H, ptr(self.w0p), M + H, H)
             call("mstts_pack_cell_fwd", ptr(k1, o1), 4 * H, ptr(self.w1p), 2 * H, H)
+        k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
+        if self.w0f_bp is not None:
+            call("mstts_pack_skinny_bwd", ptr(self.w0f), 4 * H, ptr(self.w0f_bp), M + H, 4 * H, self.bwd_splits[0])
+        if self.w1_bp is not None:
+            call("mstts_pack_skinny_bwd", ptr(k1, o1), 4 * H, ptr(self.w1_bp), 2 * H, 4 * H, self.bwd_splits[1])
+        if self.wq_bp is not None:
+            call("mstts_pack_skinny_bwd", ptr(wq_, oq_), d.att, ptr(self.wq_bp), H, d.att, self.bwd_splits[2])
+        if self.wq_t is not None:
+            call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
         if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
             A_ = d.att
             k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
@@ -341,6 +357,7 @@ class TrainEngine:
         if self.bf is not None:
             dec.bf_w0f_f, dec.bf_w1_f, dec.bf_wq_f = ptr(self.bf["w0f_f"]), ptr(self.bf["w1_f"]), ptr(self.bf["wq_f"])
             dec.bf_w0f_b, dec.bf_w1_b, dec.bf_wq_b = ptr(self.bf["w0f_b"]), ptr(self.bf["w1_b"]), ptr(self.bf["wq_b"])
+        dec.w0f_bp, dec.w1_bp, dec.wq_bp, dec.wq_t = ptr(self.w0f_bp), ptr(self.w1_bp), ptr(self.wq_bp), ptr(self.wq_t)
         if self.fused_cells and self.bf is None:
             dec.w0p, dec.w1p, dec.act_p = ptr(self.w0p), ptr(self.w1p), ptr(w.act_p)
         dec.chains = self.chains if (B % max(self.chains, 1) == 0 and B // max(self.chains, 1) >= 8) else 1
@@ -431,24 +448,19 @@ class TrainEngine:
         db.fwd = C.pointer(w.dec)
         db.d_pj, db.dg0, db.dg1, db.dq_hist, db.de_hist, db.d_in0, db.ws = (ptr(w.d_pj), ptr(w.dg0), ptr(w.dg1), ptr(w.dq_hist),
                                                                              ptr(w.de_hist), ptr(w.d_in0), ptr(w.dec_bwd_ws))
-        call("mstts_decoder_train_bwd", C.byref(db))
         SB = S * B
-        # cell 1: dW1 = in1^T . dg1 ; db1 = colsum(dg1)
-        g1, og1 = self.G(CELL % 1 + "kernel"); gb1, ogb1 = self.G(CELL % 1 + "bias")
-        gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, SB, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, SB), accumulate=True, c_off=og1)
-        call("mstts_colsum", ptr(w.dg1), SB, 4 * H, 4 * H, ptr(gb1, ogb1), 1)
-        # cell 0: folded rows -> both context row blocks, recurrent rows, prenet rows
-        g0, og0 = self.G(CELL % 0 + "kernel"); gb0, ogb0 = self.G(CELL % 0 + "bias")
         self.dw0f.zero_()
-        gemm(w.in0, w.dg0, self.dw0f, M + H, 4 * H, SB, M + H, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(M + H, 4 * H, SB)))
+        w.d_keys.zero_()
+        self.d_loc_k.zero_()
+        call("mstts_decoder_train_bwd", C.byref(db))
+        # hoisted weight gradients of the loop.  (Running them chunk by chunk on a second stream under BPTT was measured: the
+        # GEMMs' MFMA traffic slows every latency-bound loop kernel by 25-35 %, 105.4 vs 102.2 ms per step - not kept.)
+        self._recurrent_wgrads(w, 0, S)
+        g0, og0 = self.G(CELL % 0 + "kernel")
         call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + Pn * 4 * H), 4 * H, M, 4 * H, 1)
         call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + (Pn + M) * 4 * H), 4 * H, M, 4 * H, 1)
         call("mstts_copy2d", ptr(self.dw0f, M * 4 * H), 4 * H, ptr(g0, og0 + (Pn + 2 * M) * 4 * H), 4 * H, H, 4 * H, 1)
-        gemm(w.pre_d[-1], w.dg0, g0, Pn, 4 * H, SB, Pn, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(Pn, 4 * H, SB)), c_off=og0)
-        call("mstts_colsum", ptr(w.dg0), SB, 4 * H, 4 * H, ptr(gb0, ogb0), 1)
-        # prenet backward
-        k0, o0 = self.P(CELL % 0 + "kernel")
-        gemm(w.dg0, k0, w.d_pre, SB, Pn, 4 * H, 4 * H, 4 * H, Pn, trans_b=True, b_off=o0)
+        # prenet backward (d_pre = dg0 . W0[:P]^T was produced per chunk above)
         dcur, dnxt = w.d_pre, w.d_pre2
         for i in range(d.prenet_n - 1, -1, -1):
             cin = d.n_mel if i == 0 else Pn
@@ -461,19 +473,11 @@ class TrainEngine:
                 k, ok = self.P("decoder/decoder/prenet_%d/dense/kernel" % i)
                 gemm(dcur, k, dnxt, SB, cin, Pn, Pn, Pn, cin, trans_b=True, b_off=ok)
                 dcur, dnxt = dnxt, dcur
-        # query layer: dWq = m1^T . dq
-        gq, ogq = self.G(LSA + "query_layer/kernel")
-        gemm(w.pj, w.dq_hist, gq, H, A, SB, H + M, A, A, trans_a=True, split_k=max(2, _split_k(H, A, SB)), c_off=ogq)
-        # attention parameter grads + d_keys
-        w.d_keys.zero_()
         gs = {}
         for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
                             ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
             t, o = self.G(LSA + name)
             gs[field] = ptr(t, o)
-        self.d_loc_k.zero_()
-        call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), S, ptr(w.q_hist), ptr(w.cum_hist), ptr(w.de_hist), ptr(w.d_keys),
-             ptr(self.d_loc_k), gs["score_w"], gs["score_b"])
         ls = w.dec.lsa
         call("mstts_lsa_unfold_location_grad", ls.conv_k, ls.conv_b, ls.dense_k, ptr(self.d_loc_k), gs["score_b"],
              gs["conv_k"], gs["conv_b"], gs["dense_k"], d.att_k, d.att_ch, d.att)
@@ -524,6 +528,33 @@ class TrainEngine:
         call("mstts_embedding_bwd", ptr(tok), ptr(dy), ptr(ge, oge), B * Te, d.n_tok, d.emb)
         if on_ready is not None:
             on_ready(*self._grad_range("encoder/"))
+
+    def _recurrent_wgrads(self, w, lo, hi):
+        """Weight gradients of the decoder loop summed over the steps [lo, hi) (accumulating into the gradient slab):
+        dW1, db1, dw0f (folded cell-0 rows), cell-0 prenet rows, db0, dWq, the attention parameter gradients and d_keys; also
+        that range of d_pre = dg0 . W0[:P]^T for the prenet backward."""
+        d = self.d
+        B, Te = w.B, w.Te
+        H, M, A, Pn = d.dec_lstm, d.mem, d.att, d.prenet
+        n = (hi - lo) * B
+        r = lo * B                                           # first row of the range in the step-major histories
+        g1, og1 = self.G(CELL % 1 + "kernel"); gb1, ogb1 = self.G(CELL % 1 + "bias")
+        gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, n, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, n), accumulate=True,
+             a_off=r * 2 * H, b_off=r * 4 * H, c_off=og1)
+        call("mstts_colsum", ptr(w.dg1, r * 4 * H), n, 4 * H, 4 * H, ptr(gb1, ogb1), 1)
+        g0, og0 = self.G(CELL % 0 + "kernel"); gb0, ogb0 = self.G(CELL % 0 + "bias")
+        gemm(w.in0, w.dg0, self.dw0f, M + H, 4 * H, n, M + H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(M + H, 4 * H, n), accumulate=True,
+             a_off=r * (M + H), b_off=r * 4 * H)
+        gemm(w.pre_d[-1], w.dg0, g0, Pn, 4 * H, n, Pn, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(Pn, 4 * H, n)),
+             a_off=r * Pn, b_off=r * 4 * H, c_off=og0)
+        call("mstts_colsum", ptr(w.dg0, r * 4 * H), n, 4 * H, 4 * H, ptr(gb0, ogb0), 1)
+        k0, o0 = self.P(CELL % 0 + "kernel")
+        gemm(w.dg0, k0, w.d_pre, n, Pn, 4 * H, 4 * H, 4 * H, Pn, trans_b=True, a_off=r * 4 * H, b_off=o0, c_off=r * Pn)
+        gq, ogq = self.G(LSA + "query_layer/kernel")
+        gemm(w.pj, w.dq_hist, gq, H, A, n, H + M, A, A, trans_a=True, split_k=max(2, _split_k(H, A, n)), a_off=r * (H + M), b_off=r * A, c_off=ogq)
+        gsw, ogsw = self.G(LSA + "score_layer/weight_w"); gsb, ogsb = self.G(LSA + "score_layer/bias_b")
+        call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), hi - lo, ptr(w.q_hist, r * A), ptr(w.cum_hist, r * Te), ptr(w.de_hist, r * Te), ptr(w.d_keys),
+             ptr(self.d_loc_k), ptr(gsw, ogsw), ptr(gsb, ogsb))
 
     def _grad_range(self, *prefixes):
         """[lo, hi) of the gradient slab covered by the trainable variables whose names start with one of `prefixes` (the

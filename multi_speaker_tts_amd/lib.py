@@ -41,7 +41,7 @@ class LstmPointBwd(C.Structure):
                 ("d_c_state", vp), ("d_h_state", vp), ("d_h_state2", vp), ("dhs2_ld", i64), ("dhs2_parts", i32), ("dhs2_pstride", i64),
                 ("acts", vp), ("c_raw", vp), ("c_prev", vp), ("zc", vp), ("zh", vp), ("zoneout", f32),
                 ("lengths", vp), ("step", i32), ("reverse", i32), ("dgates", vp), ("dgates_pos", vp),
-                ("dgp_sb", i64), ("dgp_st", i64), ("d_c_prev", vp), ("d_h_prev", vp)]
+                ("dgp_sb", i64), ("dgp_st", i64), ("d_c_prev", vp), ("d_h_prev", vp), ("dq", vp), ("wq_t", vp), ("A", i64)]
 
 
 class CellPackedDst(C.Structure):
@@ -82,7 +82,7 @@ class DecoderTrain(C.Structure):
                 ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
                 ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp), ("chains", i32),
                 ("bf_w0f_f", vp), ("bf_w1_f", vp), ("bf_wq_f", vp), ("bf_w0f_b", vp), ("bf_w1_b", vp), ("bf_wq_b", vp),
-                ("w0p", vp), ("w1p", vp), ("act_p", vp)]
+                ("w0p", vp), ("w1p", vp), ("w0f_bp", vp), ("w1_bp", vp), ("wq_bp", vp), ("wq_t", vp), ("act_p", vp)]
 
 
 class DecoderTrainBwd(C.Structure):
@@ -179,6 +179,8 @@ SIGNATURES = {
     "mstts_skinny_fwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_skinny_bwd_splits": (i32, [i64, i64]),
     "mstts_skinny_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
+    "mstts_pack_skinny_bwd": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "mstts_skinny_bwd_packed": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_decoder_infer_fast": (i32, [i64, i64, i64, i64, i64, i64]),
     "mstts_decoder_infer_steps": (i32, [P(DecoderInfer), i64, i64, vp]),
     "mstts_decoder_infer_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),

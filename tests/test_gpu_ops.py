@@ -183,6 +183,12 @@ def test_skinny_bwd(dev, M, R, N):
     lib.call("mstts_skinny_bwd", lib.ptr(dG), N, lib.ptr(W), N, lib.ptr(P), 0, M, R, N, ns)
     ref = t2n(dG).astype(np.float64) @ t2n(W).astype(np.float64).T
     assert rel_err(t2n(P).astype(np.float64).sum(0), ref) < TOL
+    if R % 32 == 0:          # the same product against the packed kernel: identical arithmetic, bit-identical slabs
+        Wp = torch.zeros(R * N, device=dev)
+        lib.call("mstts_pack_skinny_bwd", lib.ptr(W), N, lib.ptr(Wp), R, N, ns)
+        P2 = torch.zeros(ns, M, R, device=dev)
+        lib.call("mstts_skinny_bwd_packed", lib.ptr(dG), N, lib.ptr(Wp), lib.ptr(P2), 0, M, R, N, ns)
+        assert torch.equal(P, P2)
 
 
 @pytest.mark.parametrize("B,H,K,mode", [(32, 1024, 1792, "xw"), (32, 1024, 2048, "bias"), (5, 64, 192, "xw"), (17, 8, 64, "bias"), (40, 16, 128, "none"),

@@ -2,7 +2,7 @@
 """Headline benchmark: mel-frames/sec of one Tacotron2 train step (forward + backward + TF-Adam) at
 per-GPU batch 32 x (128 tokens, 800 mel frames), fp32, synthetic data (BASELINE.json configs[1]).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: spawns one rank per GPU itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  `roofline` is the location-sensitive-attention step (the kernel
@@ -87,6 +87,26 @@ def cpu_baseline(budget_s=15.0, timeout_s=240):
     return {"value": None, "unit": "mel-frames/s", "cores": threads, "kind": "port", "sample": "oracle did not finish within %d s" % timeout_s}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: spawn N copies of this script, one per GPU, with the environment
+    torch.distributed.run would export (rendezvous on 127.0.0.1), and wait for them."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,9 +121,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world == 1 and args.gpus > 1:
+        # not started by torch.distributed.run: launch the ranks ourselves (one process per GPU, rank 0's JSON line passes through)
+        return self_launch(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None

@@ -10,8 +10,10 @@
  *   - plain pointers + sizes; every pointer is DEVICE memory unless marked host;
  *   - activations [B,T,C] row-major (NWC), conv kernels [K,Cin,Cout], dense [in,out],
  *     LSTM kernels [in+H,4H] gate order i,j,f,o - the reference's layouts;
- *   - the caller owns every buffer (workspaces included); the library allocates nothing and
- *     keeps no mutable global state, so calls are re-entrant across streams/threads;
+ *   - the caller owns every buffer (workspaces included); the library allocates no device memory and the compute entry points
+ *     keep no mutable state, so they are re-entrant across streams/threads.  The single exception is the profiling facility
+ *     mstts_probe_* at the end of this header (process-global event list, armed only by bench.py, not thread-safe);
+ *   - no environment variable changes what a kernel computes or which kernel runs;
  *   - asynchronous on the given hipStream_t (passed as void*), no implicit synchronisation;
  *   - returns 0 or a negative MSTTS_ERR_* code; mstts_last_error() gives thread-local text.
  */

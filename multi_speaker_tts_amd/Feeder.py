@@ -180,9 +180,15 @@ class Feeder:
     (Pattern_Generate.py:245-274): a daemon thread keeps up to hp.Train.Max_Pattern_Queue padded batches ready
     (Feeder.py:89-184).  Without pattern files the feeder serves the synthetic benchmark pattern."""
 
-    def __init__(self, is_Training=False, device="cuda", seed=None):
+    def __init__(self, is_Training=False, device="cuda", seed=None, rank=0, world=1):
+        """rank / world: data-parallel sharding - every rank walks the same shuffled batch list of an epoch (so the seed must be
+        shared: it defaults to 1234 when world > 1) and takes the batches rank, rank + world, ..."""
         self.is_Training = is_Training
         self.device = device
+        self.rank, self.world = rank, world
+        if world > 1 and seed is None:
+            seed = 1234
+        self._producer_error = {}
         self.placeholder_Dict = {name: name for name in PLACEHOLDERS}
         self.metadata_Dict = {"Token_Index_Dict": load_token_dict()}
         self.pattern_Queue = None
@@ -219,15 +225,21 @@ class Feeder:
               "Use pattern count: {}".format(len(order)), "\n",
               "Excluded pattern count: {}".format(len(self.metadata_Dict["Mel_Length_Dict"]) - len(order)))
         root = hp.Train.Pattern_Path
-        while order and not self._stop:
-            for names in epoch_batches(order, rng):
+        if not order:
+            self._producer_error[is_Pre_Train] = "no pattern file passes the dataset / length filters (hp.Train.*_Dataset_List, Use_Wav_Length_Range)"
+            return
+        while not self._stop:
+            batches = epoch_batches(order, rng)
+            mine = batches[self.rank::self.world] if len(batches) >= self.world else batches       # tiny sets: every rank takes all
+            for names in mine:
                 while len(queue) >= hp.Train.Max_Pattern_Queue and not self._stop:
                     time.sleep(0.1)
                 if self._stop:
                     return
                 try:
                     queue.append(load_pattern_batch(names, self.metadata_Dict["Token_Index_Dict"], pattern_path=root))
-                except OSError as e:
+                except Exception as e:                  # a dead producer must not leave Get_Train_Pattern spinning forever
+                    self._producer_error[is_Pre_Train] = "{}: {}".format(type(e).__name__, e)
                     print("Pattern producer stopped: {}".format(e))
                     return
 
@@ -263,8 +275,12 @@ class Feeder:
         pattern of the benchmark shape."""
         if self.pattern_Queue is not None and batch_Size is None:
             import time
+            if is_Pre_Train and not hasattr(self, "pre_Pattern_Queue"):
+                raise RuntimeError("pre-train patterns requested but hp.Train.Use_Pre_in_Main_Train is off")
             queue = self.pre_Pattern_Queue if is_Pre_Train else self.pattern_Queue
             while len(queue) == 0:
+                if is_Pre_Train in self._producer_error:
+                    raise RuntimeError("training pattern producer stopped: " + self._producer_error[is_Pre_Train])
                 time.sleep(0.01)
             return queue.popleft()
         B = batch_Size or hp.Train.Batch_Size

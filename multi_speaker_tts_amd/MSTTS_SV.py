@@ -25,19 +25,38 @@ INFERENCE_KEYS = ("Global_Step", "Linear", "Mel", "Stop", "Attention_History", "
 
 
 class Tacotron2:
-    def __init__(self, is_Training=False, device="cuda", seed=1234, dims: Dims = None):
+    def __init__(self, is_Training=False, device="cuda", seed=1234, dims: Dims = None, allow_random_init=False):
+        """allow_random_init: the reference REQUIRES trained speaker-encoder and vocoder checkpoints and raises ValueError
+        without them (MSTTS_SV.py:223-242); pass True to run on their random initialisation instead (tests, benchmarks).
+
+        Data parallel: started one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, as
+        torch.distributed.run exports them) the instance joins the RCCL group, takes rank 0's variables, feeds every rank a
+        different shard of each epoch's batches, all-reduces the gradients inside Train_Step and lets only rank 0 write
+        checkpoints (after averaging the BN moving statistics)."""
+        from . import dist as _dist
         self.is_Training = is_Training
+        self.allow_random_init = allow_random_init
+        self.rank, local_rank, self.world = _dist.env_ranks()
+        if self.world > 1:
+            if str(device) == "cuda":
+                device = "cuda:%d" % local_rank
+            torch.cuda.set_device(torch.device(device))
+            _dist.init_process_group(device=device)
         self.device = device
-        self.feeder = _Feeder.Feeder(is_Training=is_Training, device=device)
-        self.train_engine = TrainEngine(dims, device=device, seed=seed)
+        self.feeder = _Feeder.Feeder(is_Training=is_Training, device=device, rank=self.rank, world=self.world)
+        self.train_engine = TrainEngine(dims, device=device, seed=seed, rank=self.rank, world=self.world)
         self.params = self.train_engine.params
         self.infer_engine = InferEngine(self.train_engine.d, device=device, seed=seed, params=self.params)
         self.train_Tensor_Dict = {k: k for k in TRAIN_KEYS} if is_Training else None
         self.inference_Tensor_Dict = {k: k for k in INFERENCE_KEYS}
         self.Speaker_Embedding_Load()
         self.Vocoder_Load()
+        self._reducer = None
+        if self.world > 1:
+            self.train_engine.broadcast_state(src=0)
+            self._reducer = _dist.GradAllReduce(self.params.grad, self.world)
 
-    # ---- checkpoints: torch files holding the two flat slabs (no TF checkpoint reader exists here)
+    # ---- checkpoints: torch files holding the two flat slabs; the reference's own TF V2 bundles are read / written by tf_checkpoint.py
     @property
     def global_step(self):
         return self.train_engine.global_step
@@ -60,8 +79,10 @@ class Tacotron2:
             if os.path.exists(f):
                 values = {k: np.asarray(v) for k, v in torch.load(f, map_location="cpu").items()}
                 print("waveglow checkpoint '%s' is loaded." % f)
+            elif not self.allow_random_init:
+                raise ValueError("There is no WaveGlow checkpoint.")          # MSTTS_SV.py:239-240
             else:
-                print("No waveglow checkpoint at '%s': keeping the random initialisation." % f)
+                print("No waveglow checkpoint at '%s': keeping the random initialisation (allow_random_init)." % f)
             self.waveglow = WaveGlowEngine(WGDims.from_hp(hp), device=self.device, values=values)
         else:
             raise ValueError("hp.Use_Vocoder must be 'Taco1_Mel_to_Spect' or 'WaveGlow'")
@@ -76,7 +97,9 @@ class Tacotron2:
                 self.params.load({k: v for k, v in vars_.items() if k.startswith(scope)})
                 print("%s TF checkpoint '%s' is loaded." % (scope, prefix))
                 return
-            print("No %s checkpoint at '%s': keeping the random initialisation." % (scope, f))
+            if not self.allow_random_init:       # MSTTS_SV.py:226-227,239-240: a Tacotron2 without its trained sub-models is an error
+                raise ValueError("There is no {} checkpoint.".format("speaker embedding" if scope == "speaker_embedding" else "Mel to Spect"))
+            print("No %s checkpoint at '%s': keeping the random initialisation (allow_random_init)." % (scope, f))
             return
         values = torch.load(f, map_location="cpu")
         self.params.load({k: v for k, v in values.items() if k.startswith(scope)})
@@ -129,8 +152,9 @@ class Tacotron2:
             print("  not in the checkpoint (kept as initialised): %s%s" % (", ".join(missing[:5]), " ..." if len(missing) > 5 else ""))
 
     def Export_TF_Checkpoint(self, directory=None):
-        """Write the tacotron variables, Adam slots and global_step as a TF V2 checkpoint `CHECKPOINT-<step>` the
-        reference's Saver can restore (MSTTS_SV.py:289)."""
+        """Write the tacotron variables, Adam slots (under the optimizer's `loss/` scope, with the beta power accumulators) and
+        global_step as a TF V2 checkpoint `CHECKPOINT-<step>` with the variable names of the reference's Saver (MSTTS_SV.py:30-40,
+        289).  PARITY UNPINNED: no real TF checkpoint listing exists here to compare the name set against."""
         from . import tf_checkpoint as tfc
         d = directory or self._ckpt_dir()
         out = {k: v for k, v in self.params.export().items() if not k.startswith(("speaker_embedding", "mel_to_spectrogram", "waveglow"))}
@@ -138,14 +162,25 @@ class Tacotron2:
         for n, _, _ in self.params.table:
             if self.params.trainable[n]:
                 o, sz = self.params.offset[n], int(np.prod(self.params.shape[n]))
-                out[n + "/Adam"] = m[o:o + sz].reshape(self.params.shape[n])
-                out[n + "/Adam_1"] = v[o:o + sz].reshape(self.params.shape[n])
+                # the reference builds its AdamOptimizer inside tf.variable_scope('loss') (MSTTS_SV.py:127,171-176), so the Saver's
+                # slot variables are loss/<var>/Adam, loss/<var>/Adam_1 and the two power accumulators loss/beta{1,2}_power
+                out["loss/" + n + "/Adam"] = m[o:o + sz].reshape(self.params.shape[n])
+                out["loss/" + n + "/Adam_1"] = v[o:o + sz].reshape(self.params.shape[n])
+        b1, b2, _ = self.train_engine.adam
+        out["loss/beta1_power"] = np.array(b1 ** (self.global_step + 1), np.float32)     # TF keeps beta^t for the NEXT step t = step + 1
+        out["loss/beta2_power"] = np.array(b2 ** (self.global_step + 1), np.float32)
         out["global_step"] = np.array(self.global_step, np.int64)
         prefix = os.path.join(d, "CHECKPOINT-%d" % self.global_step)
         tfc.write_checkpoint(prefix, out)
         return prefix
 
     def Save(self, keep=5):
+        """tf.train.Saver(max_to_keep=5).save (MSTTS_SV.py:287-289).  Data parallel: the BN moving statistics are averaged over
+        the ranks first (a collective: every rank must call Save), then rank 0 alone writes."""
+        if self.world > 1:
+            self.train_engine.sync_statistics()
+            if self.rank != 0:
+                return
         d = self._ckpt_dir()
         os.makedirs(d, exist_ok=True)
         tacotron = {k: torch.from_numpy(v) for k, v in self.params.export().items()
@@ -164,17 +199,27 @@ class Tacotron2:
                  "Mel": t(pattern["Mel"], torch.float32), "Mel_Length": t(pattern["Mel_Length"], torch.int32)}
         if "Speaker_Embedding" in pattern:
             batch["Speaker_Embedding"] = t(pattern["Speaker_Embedding"], torch.float32)
-        else:   # frozen speaker encoder forward (MSTTS_SV.py:49-56); deterministic-zoneout inference mode
+        else:   # frozen speaker encoder forward (MSTTS_SV.py:49-56) with TRAINING-mode zoneout: Is_Training is fed to this stack too
+            from .masks import MaskSet, step_seed
             self.infer_engine._keep = []
-            batch["Speaker_Embedding"] = self.infer_engine.speaker_embedding(t(pattern["Speaker_Embedding_Mel"], torch.float32)).clone()
+            mel = t(pattern["Speaker_Embedding_Mel"], torch.float32)
+            nb = int(mel.shape[0])
+            if getattr(self, "_spk_masks_nb", None) != nb:
+                self._spk_masks = MaskSet(self.train_engine.d, 1, 1, 1, True, dev, rank=self.rank, speaker_windows=nb)
+                self._spk_masks_nb = nb
+            self._spk_masks.draw(step_seed(self.train_engine.seed, self.global_step))
+            batch["Speaker_Embedding"] = self.infer_engine.speaker_embedding(mel, masks=self._spk_masks).clone()
         return batch
 
-    def Train_Step(self, pattern=None):
-        """One iteration of the reference's `while True` body; returns the train_Tensor_Dict results."""
-        pattern = pattern or self.feeder.Get_Train_Pattern()
+    def Train_Step(self, pattern=None, is_Pre_Train=False):
+        """One iteration of the reference's `while True` body (MSTTS_SV.py:268-273); returns the train_Tensor_Dict results.  In
+        a data-parallel job the gradients are all-reduced inside the step and the returned losses are the mean over the ranks."""
+        pattern = pattern or self.feeder.Get_Train_Pattern(is_Pre_Train=is_Pre_Train)
         step = self.global_step
-        w = self.train_engine.train_step(self._to_device_batch(pattern))
-        res = self.train_engine.scalars(w)
+        w = self.train_engine.train_step(self._to_device_batch(pattern), all_reduce=self._reducer)
+        res = self.train_engine.scalars(w, average=self.world > 1)
+        if not np.isfinite(res["Loss"]):
+            raise FloatingPointError("non-finite loss at global step %d: %r" % (step, res))
         res.update({"Global_Step": step, "Learning_Rate": learning_rate(step), "Train_OP": None})
         return res
 
@@ -208,19 +253,47 @@ class Tacotron2:
                 print("Inference export skipped: {}".format(e))
         return res
 
-    def Train(self, max_steps=None, pattern_fn=None):
-        """MSTTS_SV.py:268-293: loop forever (or `max_steps`), print the reference's log line, checkpoint
-        every hp.Train.Checkpoint_Save_Timing steps."""
+    def Run_Inference(self, sentence_file="Inference_Sentence_in_Train.txt"):
+        """MSTTS_SV.py:254-265: synthesise the `wav path <TAB> sentence` lines of Inference_Sentence_in_Train.txt.  The reference
+        fails when the file or a wav is missing; a missing file is reported and skipped here (rank 0 only in a data-parallel job)."""
+        if self.rank != 0:
+            return None
+        if not os.path.exists(sentence_file):
+            print("'{}' not found: in-training inference skipped.".format(sentence_file))
+            return None
+        paths, sentences = [], []
+        with open(sentence_file, "r") as f:
+            for line in f.readlines():
+                if not line.strip():
+                    continue
+                embedding_Path, sentence = line.strip().split("\t")
+                paths.append(embedding_Path)
+                sentences.append(sentence)
+        return self.Inference(paths, sentences)
+
+    def Train(self, max_steps=None, pattern_fn=None, run_inference=True):
+        """MSTTS_SV.py:253-293: an inference pass first, then loop forever (or `max_steps`): pre-train patterns while
+        hp.Train.Use_Pre_in_Main_Train and the step is below hp.Train.Pre_Step, the reference's log line, a checkpoint every
+        hp.Train.Checkpoint_Save_Timing steps and an inference pass every hp.Train.Inference_Timing steps."""
+        if run_inference:
+            self.Run_Inference()
         n = 0
+        current = self.global_step
         while max_steps is None or n < max_steps:
             t0 = time.time()
-            r = self.Train_Step(pattern_fn() if pattern_fn else None)
-            print("\t\t".join(["Time: {:0.3f}".format(time.time() - t0), "Global step: {}".format(r["Global_Step"]), "Mode: Main",
-                               "Learning rate: {:0.5f}".format(r["Learning_Rate"]), "Linear loss: {:0.5f}".format(r["Linear_Loss"]),
-                               "Postnet loss: {:0.5f}".format(r["Postnet_Loss"]), "Stop loss: {:0.5f}".format(r["Stop_Loss"]),
-                               "WR loss: {:0.5f}".format(r["Weight_Regularization_Loss"])]))
+            pre = bool(hp.Train.Use_Pre_in_Main_Train and current < hp.Train.Pre_Step)
+            r = self.Train_Step(pattern_fn() if pattern_fn else None, is_Pre_Train=pre)
+            if self.rank == 0:
+                print("\t\t".join(["Time: {:0.3f}".format(time.time() - t0), "Global step: {}".format(r["Global_Step"]),
+                                   "Mode: {}".format("Pre-train" if current < hp.Train.Pre_Step else "Main"),
+                                   "Learning rate: {:0.5f}".format(r["Learning_Rate"]), "Linear loss: {:0.5f}".format(r["Linear_Loss"]),
+                                   "Postnet loss: {:0.5f}".format(r["Postnet_Loss"]), "Stop loss: {:0.5f}".format(r["Stop_Loss"]),
+                                   "WR loss: {:0.5f}".format(r["Weight_Regularization_Loss"])]))
             if (r["Global_Step"] + 1) % hp.Train.Checkpoint_Save_Timing == 0:
                 self.Save()
+            if run_inference and (r["Global_Step"] + 1) % hp.Train.Inference_Timing == 0:
+                self.Run_Inference()
+            current = r["Global_Step"]
             n += 1
 
     # ---- inference (MSTTS_SV.py:295-323,391-400)

@@ -217,12 +217,6 @@ extern "C" int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream
 // ---------------------------------------------------------------------------------------------
 // teacher-forced decoder loop
 // ---------------------------------------------------------------------------------------------
-static bool lsa_fused_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MSTTS_LSA_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
-
 extern "C" int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q) {
     int p0 = mstts_skinny_fwd_splits(4 * H, M + H), p1 = mstts_skinny_fwd_splits(4 * H, 2 * H), pq = mstts_skinny_fwd_splits(A, H);
     int pg = p0 > p1 ? p0 : p1;
@@ -233,54 +227,9 @@ extern "C" int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, in
     return MSTTS_OK;
 }
 
-// ---- row chains ------------------------------------------------------------------------------
-// Batch rows never interact inside the decoder loop, and every per-step kernel is latency-bound (a
-// few hundred KB, one wave per SIMD).  The drivers therefore split the rows into `chains` groups and
-// run each group's dependent kernel chain on its own HIP stream: two chains hide each other's
-// launch/memory latency.  Chain 0 uses the caller's stream; the side streams are created lazily and
-// fork/join with events (also valid under stream capture).
-namespace {
-constexpr int MAX_CHAINS = 4;
-struct SideStreams {
-    bool init = false;
-    hipStream_t st[MAX_CHAINS - 1];
-    hipEvent_t fork, join[MAX_CHAINS - 1];
-} g_side;
-int side_init() {
-    if (g_side.init) return MSTTS_OK;
-    for (int i = 0; i < MAX_CHAINS - 1; ++i) {
-        if (hipStreamCreateWithFlags(&g_side.st[i], hipStreamNonBlocking) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "side stream create failed");
-        if (hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "event create failed");
-    }
-    if (hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "event create failed");
-    g_side.init = true;
-    return MSTTS_OK;
-}
-int chain_fork(int chains, mstts_stream_t s, mstts_stream_t* out) {
-    out[0] = s;
-    if (chains <= 1) return MSTTS_OK;
-    RC(side_init());
-    if (hipEventRecord(g_side.fork, (hipStream_t)s) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "fork record failed");
-    for (int c = 1; c < chains; ++c) {
-        if (hipStreamWaitEvent(g_side.st[c - 1], g_side.fork, 0) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "fork wait failed");
-        out[c] = (mstts_stream_t)g_side.st[c - 1];
-    }
-    return MSTTS_OK;
-}
-int chain_join(int chains, mstts_stream_t s) {
-    for (int c = 1; c < chains; ++c) {
-        if (hipEventRecord(g_side.join[c - 1], g_side.st[c - 1]) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "join record failed");
-        if (hipStreamWaitEvent((hipStream_t)s, g_side.join[c - 1], 0) != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "join wait failed");
-    }
-    return MSTTS_OK;
-}
-inline int pick_chains(const mstts_decoder_train_desc* d) {
-    int c = d->chains > 1 ? d->chains : 1;
-    if (c > MAX_CHAINS) c = MAX_CHAINS;
-    while (c > 1 && d->B % c != 0) --c;
-    return c;
-}
-}  // namespace
+// (Row chains - splitting the batch rows into groups whose kernel chains run on separate HIP streams - were built and measured
+// in round 1: correct, but slower (eager: host-bound; graph: branches serialised).  Removed; `chains` in the descriptor is ignored.)
+constexpr int MAX_CHAINS = 1;
 
 extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s) {
     MSTTS_REQUIRE(d && d->xw0 && d->w0f && d->w1 && d->b1 && d->wq && d->in0 && d->in1 && d->pj && d->c0 && d->c1 &&
@@ -293,8 +242,8 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     int32_t bfs[6];
     const bool bf = d->bf_w0f_f && d->bf_w1_f && d->bf_wq_f && mstts_decoder_bf16_splits(H, M, A, bfs);
     const int pg = (sp0 > sp1 ? sp0 : sp1) > 0 ? (sp0 > sp1 ? sp0 : sp1) : 1, pq = spq > 0 ? spq : 1;
-    const int chains = pick_chains(d);
-    const bool fused_lsa = lsa_fused_enabled() && chains == 1;         // (the time-out counter sits after the last row's granules)
+    const int chains = 1;
+    const bool fused_lsa = true;         // (the time-out counter sits after the last row's granules)
     // fused cell steps need the single-launch attention step (it writes the context into cell 0's packed block)
     const bool fused_cells = !bf && fused_lsa && d->w0p && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1) &&
                              M % 4 == 0;
@@ -307,8 +256,7 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     RC(zero(d->cum_hist, B * T, s));
     if (fused_lsa) RC(zero(d->energy_ws, 2 * B * T + 2, s));           // granules + time-out counter of mstts_lsa_step_fwd
     const long Bc = B / chains;
-    mstts_stream_t cs[MAX_CHAINS];
-    RC(chain_fork(chains, s, cs));
+    mstts_stream_t cs[MAX_CHAINS] = {s};
     for (long st = 0; st < S; ++st) {
         for (int c = 0; c < chains; ++c) {
             const long b0 = c * Bc;
@@ -385,7 +333,6 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             }
         }
     }
-    RC(chain_join(chains, s));
     return MSTTS_OK;
 }
 
@@ -412,16 +359,15 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     int32_t bfs[6];
     const bool bf = d->bf_w0f_b && d->bf_w1_b && d->bf_wq_b && mstts_decoder_bf16_splits(H, M, A, bfs);
     const long d_in0_slab = S * B * W0;
-    const int chains = pick_chains(d);
+    const int chains = 1;
     const long Bc = B / chains, BcH = Bc * H, BcT = Bc * T;
     const long ws_per_row = 8 * H + 2 * T + 2 * T * CH + T + (long)np1 * W1 + (long)npq * H;
     // single-launch attention backward: its granules (B*ceil(T/8)+1 8-byte words) live in the d_align block (B*T floats)
-    const bool fused_lsa = lsa_fused_enabled() && chains == 1 && mstts_lsa_step_bwd_ws_bytes(B, T) <= B * T * 4;
+    const bool fused_lsa = true && mstts_lsa_step_bwd_ws_bytes(B, T) <= B * T * 4;
     // query-layer data gradient inside cell 1's pointwise kernel: fp32 mode, A == 128, slab counts the lean kernel is built for
     const bool fuse_q = !bf && d->wq_t && A == 128 && (np1 == 8 || np1 == 4 || np1 == 2 || np1 == 1) && B * H * 4 < (1LL << 30);
     RC(zero(bd->ws, ws_per_row * B, s));
-    mstts_stream_t cs[MAX_CHAINS];
-    RC(chain_fork(chains, s, cs));
+    mstts_stream_t cs[MAX_CHAINS] = {s};
     struct ChainWs { float *dc0[2], *dh0[2], *dc1[2], *dh1[2], *G[2], *df[2], *d_align, *tmp1, *dqm; int parts0, parts1, partsq; } cw[MAX_CHAINS];
     for (int c = 0; c < chains; ++c) {
         float* w = bd->ws + ws_per_row * (c * Bc);
@@ -504,7 +450,6 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
         }
         cur = nxt;
     }
-    RC(chain_join(chains, s));
     return MSTTS_OK;
 }
 
@@ -700,7 +645,7 @@ extern "C" int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int6
     if (d->w0s && d->wp_pad && mstts_decoder_infer_fast(d->B, d->H, d->P, d->lsa.M, d->lsa.A, d->n_mel)) return infer_steps_fast(d, step0, n, s);
     const long B = d->B, H = d->H, P = d->P, NM = d->n_mel, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
     const long BH = B * H, W0 = M + H, W1 = 2 * H, WP = H + M, BT = B * T;
-    const bool fused_lsa = lsa_fused_enabled();
+    const bool fused_lsa = true;
     float* w = d->pre_ws;
     float* pa = w;          w += B * P;
     float* pb = w;          w += B * P;

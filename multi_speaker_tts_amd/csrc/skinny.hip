@@ -289,17 +289,8 @@ static void set_lds_attr() {
 }  // namespace mstts
 using namespace mstts;
 
-// workgroups a skinny launch aims for (default 512 = two per CU); row-chain mode lowers it so that
-// kernels of different chains co-reside.  Development knob: MSTTS_SKINNY_TARGET_WGS.
-static long target_wgs() {
-    static long t = 0;
-    if (t == 0) {
-        const char* e = getenv("MSTTS_SKINNY_TARGET_WGS");
-        t = e ? atol(e) : 512;
-        if (t < 32) t = 32;
-    }
-    return t;
-}
+// workgroups a skinny launch aims for: two per CU (one computes while the other waits on its loads)
+static long target_wgs() { return 512; }
 
 extern "C" int32_t mstts_skinny_fwd_splits(int64_t N, int64_t K) {
     // K-splits so that strips * splits ~ 256 workgroups; each slice a multiple of 32 rows, <= 512 rows

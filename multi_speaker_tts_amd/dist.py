@@ -13,9 +13,55 @@ from __future__ import annotations
 import torch
 
 
+def env_ranks():
+    """(rank, local_rank, world) of this process as torch.distributed.run / bench.py's own launcher export them."""
+    import os
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_process_group(backend=None, device=None):
+    """One process per GPU: join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (RCCL when a device is given,
+    gloo otherwise).  No-op when the group exists already or the job has a single process and no MASTER_PORT."""
+    import os
+    import torch.distributed as dist
+    rank, local_rank, world = env_ranks()
+    if dist.is_initialized():
+        return rank, local_rank, world
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        return rank, local_rank, world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = backend or ("nccl" if device is not None and torch.device(device).type == "cuda" else "gloo")
+    kw = {"device_id": torch.device(device)} if backend == "nccl" and device is not None else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def broadcast_(tensors, src=0, group=None):
+    """Make every rank start from rank `src`'s copy (initial variables, Adam slots, BN statistics)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return
+    for t in tensors:
+        dist.broadcast(t, src=src, group=group)
+
+
+def average_(tensors, group=None):
+    """In-place mean over the ranks (BN moving statistics, the loss scalars: SURVEY 8e)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.mul_(1.0 / world)
+
+
 class GradAllReduce:
-    def __init__(self, grad_slab: torch.Tensor, world: int, bucket_mb: float = 32.0, group=None):
+    def __init__(self, grad_slab: torch.Tensor, world: int, bucket_mb: float = 32.0, group=None, force: bool = False):
+        """force: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)."""
         self.world, self.group = world, group
+        self.active = world > 1 or force
         n = grad_slab.numel()
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         self.bounds = [(s, min(n, s + per)) for s in range(0, n, per)]
@@ -32,7 +78,7 @@ class GradAllReduce:
         """Asynchronously sum grad_slab[lo:hi] over the ranks (in <= bucket-size pieces).  Call it at the point of the
         backward pass where that range is final: the collective is ordered after everything enqueued so far on the
         current stream and runs beside what is enqueued next."""
-        if self.world <= 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         import torch.distributed as dist
         per = self.bounds[0][1] - self.bounds[0][0]
@@ -43,7 +89,7 @@ class GradAllReduce:
 
     def finish(self, grad_slab: torch.Tensor):
         """Wait for every started piece; ranges that were never started are reduced now (so the slab is always complete)."""
-        if self.world <= 1:
+        if not self.active:
             return
         covered, pos = sorted(self._done), 0
         for a, b in covered + [(self.n, self.n)]:

@@ -57,16 +57,18 @@ class _WS:
 
 class TrainEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, rank=0, world=1, values=None,
-                 update_vocoder_bn=True, use_l1=True, wr_rate=1e-6, adam=(0.9, 0.999, 1e-6), recurrent_dtype=None):
+                 update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None):
         """recurrent_dtype: 'f32' (default; BASELINE config 2) or 'bf16' (config 3: the decoder's recurrent products run on
-        bf16 copies of the fp32 master weights with fp32 accumulation; env MSTTS_RECURRENT_DTYPE sets the default)."""
+        bf16 copies of the fp32 master weights with fp32 accumulation)."""
         lib.load()
         self.d = dims or Dims()
         self.device = torch.device(device)
         self.seed, self.rank, self.world = seed, rank, world
         self.update_vocoder_bn = update_vocoder_bn
-        self.chains = int(__import__('os').environ.get('MSTTS_DECODER_CHAINS', '1'))
-        self.use_l1, self.wr_rate, self.adam = use_l1, wr_rate, adam
+        from . import Hyper_Parameters as hp           # None = the drop-in hyper parameters (MSTTS_SV.py:138-176)
+        self.use_l1 = bool(hp.Train.Use_L1_Loss) if use_l1 is None else use_l1
+        self.wr_rate = float(hp.Train.Weight_Regularization_Rate) if wr_rate is None else wr_rate
+        self.adam = (hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2, hp.Train.ADAM.Epsilon) if adam is None else adam
         self.params = ParamStore(self.d, self.device, seed=seed, values=values)
         self._plans = {}          # workspace sets keyed by batch shape, least recently used first (at most MAX_PLANS kept)
         self.global_step = 0
@@ -94,7 +96,7 @@ class TrainEngine:
         self.wq_t = self._f(d.att * H) if d.att == 128 else None         # query kernel as [A/4, H, 4] (fused query-layer data gradient)
         self.flip = {}
         self._derived_stale = True
-        self.recurrent_dtype = (recurrent_dtype or __import__('os').environ.get('MSTTS_RECURRENT_DTYPE', 'f32')).lower()
+        self.recurrent_dtype = (recurrent_dtype or "f32").lower()
         if self.recurrent_dtype not in ("f32", "bf16"):
             raise ValueError("recurrent_dtype must be 'f32' or 'bf16'")
         self.bf = None
@@ -360,7 +362,7 @@ class TrainEngine:
         dec.w0f_bp, dec.w1_bp, dec.wq_bp, dec.wq_t = ptr(self.w0f_bp), ptr(self.w1_bp), ptr(self.wq_bp), ptr(self.wq_t)
         if self.fused_cells and self.bf is None:
             dec.w0p, dec.w1p, dec.act_p = ptr(self.w0p), ptr(self.w1p), ptr(w.act_p)
-        dec.chains = self.chains if (B % max(self.chains, 1) == 0 and B // max(self.chains, 1) >= 8) else 1
+        dec.chains = 1
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))
         call("mstts_decoder_train_fwd", C.byref(dec))
@@ -579,8 +581,35 @@ class TrainEngine:
         self.refresh_derived()
         return lr
 
-    def scalars(self, w):
-        s = w.scalars.detach().cpu().numpy()
+    def moving_stat_ranges(self):
+        """Merged [lo, hi) ranges of the non-trainable slab that hold batch-norm moving statistics (the only per-rank state of a
+        data-parallel run besides the loss scalars)."""
+        ps = self.params
+        r = sorted((ps.offset[n], ps.offset[n] + (int(np.prod(ps.shape[n])) + 3) // 4 * 4) for n, _, _ in ps.table
+                   if not ps.trainable[n] and n.endswith(("moving_mean", "moving_variance")))
+        out = []
+        for lo, hi in r:
+            if out and out[-1][1] == lo:
+                out[-1][1] = hi
+            else:
+                out.append([lo, hi])
+        return [tuple(x) for x in out]
+
+    def sync_statistics(self, group=None):
+        """Average the BN moving statistics over the ranks (batch statistics stay per rank - each rank is the reference
+        at batch 32 - but what gets reported / checkpointed must not depend on which rank writes it)."""
+        from .dist import average_
+        average_([self.params.frozen[lo:hi] for lo, hi in self.moving_stat_ranges()], group=group)
+
+    def scalars(self, w, average=False, group=None):
+        """Loss scalars of the last step on `w`; average=True: mean over the data-parallel ranks."""
+        if average:
+            from .dist import average_
+            avg = w.scalars.clone()
+            average_([avg], group=group)
+            s = avg.cpu().numpy()
+        else:
+            s = w.scalars.detach().cpu().numpy()
         wr = float(s[3]) * self.wr_rate
         return {"Linear_Loss": float(s[0]), "Postnet_Loss": float(s[1]), "Stop_Loss": float(s[2]),
                 "Weight_Regularization_Loss": wr, "Loss": float(s[0] + s[1] + s[2]) + wr}
@@ -598,6 +627,15 @@ class TrainEngine:
             return fwd, 0
         bwd = int(w.dec_bwd_ws[off:off + 2 * (B * nsl + 1)].view(torch.int64)[B * nsl].item())
         return fwd, bwd
+
+    def broadcast_state(self, src=0, group=None):
+        """Data-parallel start: every rank takes rank `src`'s variables, Adam slots and statistics."""
+        from .dist import broadcast_
+        ps = self.params
+        step = torch.tensor([self.global_step], dtype=torch.int64, device=self.device)
+        broadcast_([ps.train, ps.frozen, ps.adam_m, ps.adam_v, step], src=src, group=group)
+        self.global_step = int(step.item())
+        self._derived_stale = True
 
     def train_step(self, batch, masks=None, all_reduce=None):
         """One full iteration: forward, loss, backward, (gradient all-reduce), Adam."""

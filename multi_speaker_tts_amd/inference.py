@@ -63,8 +63,9 @@ class InferEngine:
         call("mstts_bn_infer_fwd", ptr(a), ptr(g, og), ptr(be, obe), ptr(mm, omm), ptr(mv, omv), ptr(y), BN_EPS, rows, cout)
         return y
 
-    def _lstm_seq(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, lengths=None, reverse=0, residual=None):
-        """One ZoneoutLSTMCell over a sequence in inference mode (no masks: 0.9*new + 0.1*old)."""
+    def _lstm_seq(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, lengths=None, reverse=0, residual=None, zc=None, zh=None):
+        """One ZoneoutLSTMCell over a sequence: inference mode without masks (0.9*new + 0.1*old), training-mode zoneout with
+        keep-masks zc / zh [T, B, H] (ZoneoutLSTMCell.py:259-271)."""
         k, ok = self.P(cell_prefix + "kernel"); b, ob = self.P(cell_prefix + "bias")
         xw = self._f(B * T, 4 * H)
         gemm(x, k, xw, B * T, 4 * H, cin, cin, 4 * H, 4 * H, bias=b, b_off=ok, bias_off=ob)
@@ -76,6 +77,7 @@ class InferEngine:
             self._keep.append(lengths)
         q.lengths = ptr(lengths); q.reverse = reverse; q.zoneout = self.d.zoneout
         q.residual = ptr(residual)
+        q.zc, q.zh = ptr(zc), ptr(zh)
         q.out = ptr(out, out_off); q.out_sb = out_sb; q.out_st = out_st
         ch, hh = self._f(T + 1, B, H), self._f(T + 1, B, H)
         q.c_hist, q.h_hist = ptr(ch), ptr(hh)
@@ -83,8 +85,10 @@ class InferEngine:
         call("mstts_lstm_seq_fwd", C.byref(q))
 
     # ------------------------------------------------------------------ sub-graphs
-    def speaker_embedding(self, spk_mel):
-        """[5B,64,80] float32 device tensor -> [B, spk] (MSTTS_SV.py:49-56)."""
+    def speaker_embedding(self, spk_mel, masks=None):
+        """[5B,64,80] float32 device tensor -> [B, spk] (MSTTS_SV.py:49-56).  masks: optional {'s_zc_<i>', 's_zh_<i>'} uint8
+        keep-masks [64, 5B, cell] - the reference feeds Is_Training into this (frozen) stack too, so a Tacotron2 TRAIN step sees
+        stochastic zoneout in the speaker encoder (MSTTS_SV.py:49-56, ZoneoutLSTMCell.py:259-260)."""
         d = self.d
         NB, T, _ = spk_mel.shape
         B = NB // d.spk_samples
@@ -93,7 +97,8 @@ class InferEngine:
         for i in range(d.spk_lstm_n):
             y = self._f(NB, T, d.spk_lstm)
             self._lstm_seq(x, NB, T, d.spk, d.spk_lstm, SPK_CELL % (i, i), y, T * d.spk_lstm, d.spk_lstm,
-                           residual=x if i < d.spk_lstm_n - 1 else None)
+                           residual=x if i < d.spk_lstm_n - 1 else None,
+                           zc=masks["s_zc_%d" % i] if masks is not None else None, zh=masks["s_zh_%d" % i] if masks is not None else None)
             x = y
         e = self._f(B, d.spk)
         call("mstts_speaker_finalize", ptr(x), ptr(e), B, d.spk_samples, T, d.spk)

@@ -75,3 +75,22 @@ def test_variable_table_counts():
     assert [(n, tuple(s)) for n, s, _ in t] == [(n, tuple(s)) for n, s, _ in OM.param_specs(OM.Dims())]
     a, b = PP.initial_values(PP.Dims(emb=8, enc_conv_ch=8), 3), OM.init_params(OM.Dims(emb=8, enc_conv_ch=8), 3)
     assert all(np.allclose(a[k], b[k].astype(np.float32)) for k in a)
+
+
+def test_top_level_drop_in_names():
+    """`from MSTTS_SV import Tacotron2` / `import Hyper_Parameters as hp` work unchanged from the repo root."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    hp_top = importlib.import_module("Hyper_Parameters")
+    from multi_speaker_tts_amd import Hyper_Parameters as hp_pkg
+    assert hp_top is hp_pkg and hp_top.Sound.Mel_Dim == 80
+    mod = importlib.import_module("MSTTS_SV")
+    from multi_speaker_tts_amd.MSTTS_SV import Tacotron2
+    assert mod.Tacotron2 is Tacotron2
+    import inspect
+    sig = inspect.signature(Tacotron2.__init__)
+    assert list(sig.parameters)[:2] == ["self", "is_Training"] and sig.parameters["is_Training"].default is False
+    for name in ("Restore", "Train", "Inference"):
+        assert callable(getattr(Tacotron2, name))
+    assert list(inspect.signature(Tacotron2.Inference).parameters)[:4] == ["self", "path_List", "text_List", "file_Prefix"]

@@ -172,3 +172,46 @@ def test_waveglow_chunking_kats():
         assert [c.shape[0] for c in chunks] == [40, 40, 15, 40, 3] and index == [(0, 3), (3, 4), (4, 5)]
         assert mod.export_length([.1, .2, .6, .9], 12.5, 22050) == int(2 * 12.5 / 1000 * 22050) == 551
         assert mod.export_length([.1, .2, .3], 12.5, 22050) == int(3 * 12.5 / 1000 * 22050)
+
+
+def test_second_restatement_of_the_train_step():
+    """oracle/np_ops.py restates the whole TRAIN forward (encoder incl. length-reversed BiLSTM, doubled context Q1, max(L)+1 steps
+    and teacher-forcing shift Q7, postnet), the losses (Q8, Q19) and TF-Adam (Q18) independently of oracle/model.py / train.py in
+    NumPy fp64: both must agree to 1e-9 on ragged inputs, and so must the optimizer step built on model.py's gradients."""
+    from oracle import np_ops as NP
+    cfg = dict(emb=12, enc_conv_ch=12, enc_lstm=6, spk=8, prenet=7, dec_lstm=10, n_mel=5, post_ch=9, bank_ch=4, proj1_ch=6, birnn=4, n_spec=9, spk_lstm=8)
+    d = OM.Dims(**cfg)
+    g = np.random.default_rng(17)
+    params = OM.init_params(d, 17)
+    for k in params:                                     # nothing left at its trivial initial value
+        if k.endswith(("bias", "beta", "bias_b", "moving_mean")):
+            params[k] = g.normal(0, 0.2, params[k].shape)
+        if k.endswith(("gamma", "moving_variance")):
+            params[k] = 1.0 + 0.3 * g.random(params[k].shape)
+    B, Te, L = 3, 9, 6
+    batch = OT.synthetic_batch(d, B, Te, L, seed=17, ragged=True)
+    assert len(set(batch["Token_Length"].tolist())) > 1 and len(set(batch["Mel_Length"].tolist())) > 1
+    masks = OT.make_masks(d, B, Te, L + 1, True, seed=5)
+    new_p, opt, sc, grads, out = OT.train_step(params, None, d, batch, masks, 0, return_grads=True)
+    npb = {k: v.numpy() for k, v in batch.items()}
+    npm = {k: v.numpy().astype(np.float64) for k, v in masks.items()}
+    npp = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    mine = NP.tacotron_train_forward(npp, d, npb, npm)
+    for key in ("Linear", "Mel", "Stop_Logit", "Attention_History"):
+        assert mine[key].shape == tuple(out[key].shape) and np.abs(mine[key] - out[key].numpy()).max() < 1e-9, key
+    assert mine["Linear"].shape[1] == int(batch["Mel_Length"].max()) + 1                          # Q7
+    ls = NP.tacotron_losses(npp, mine, npb)
+    for key in ("Loss", "Linear_Loss", "Postnet_Loss", "Stop_Loss", "Weight_Regularization_Loss"):
+        assert abs(ls[key] - sc[key]) < 1e-10, key
+    assert all(NP.weight_regularised(k) == OM.in_weight_reg(k) for k in params)
+    for k, v in mine["stats"].items():                                                             # BN moving statistics (Q11)
+        assert np.abs(v - new_p[k].numpy()).max() < 1e-10, k
+    # TF-Adam on model.py's gradients, two consecutive steps of one variable with non-zero slots
+    k = "decoder/decoder/prenet_1/dense/kernel"
+    gr = grads[k].numpy()
+    p1, m1, v1 = NP.tf_adam(npp[k], gr, np.zeros_like(gr), np.zeros_like(gr), 0, NP.tf_learning_rate(0))
+    assert np.abs(p1 - new_p[k].numpy()).max() < 1e-12 and np.abs(m1 - opt["m"][k].numpy()).max() < 1e-15
+    p2a, m2a, v2a = NP.tf_adam(p1, 0.5 * gr, m1, v1, 1, NP.tf_learning_rate(1))
+    p2b, m2b, v2b = OT.adam_tf(torch.tensor(p1), torch.tensor(0.5 * gr), torch.tensor(m1), torch.tensor(v1), 2, OT.learning_rate(1))
+    assert np.abs(p2a - p2b.numpy()).max() < 1e-12 and np.abs(v2a - v2b.numpy()).max() < 1e-18
+    assert NP.tf_learning_rate(10000) == OT.learning_rate(10000) == 5e-4 and NP.tf_learning_rate(10 ** 7) == 1e-5

@@ -474,6 +474,32 @@ def test_inference_decode_full_width(dev):
     assert rel_err(got["Attention_History"], t2n(ref["Attention_History"])) < 1e-3
 
 
+def test_speaker_encoder_training_zoneout(dev):
+    """The frozen speaker encoder inside a TRAIN step runs with stochastic zoneout (the reference feeds Is_Training into it,
+    MSTTS_SV.py:49-56): HIP forward with Philox masks drawn on the device vs the oracle's training-mode speaker encoder."""
+    from multi_speaker_tts_amd.inference import InferEngine
+    from multi_speaker_tts_amd.masks import MaskSet
+    pd, od = dims_pair(spk=32, spk_lstm=32)
+    values = OM.init_params(od, 3)
+    g = np.random.default_rng(4)
+    B = 3
+    NB = B * od.spk_samples
+    mel = np.clip(g.normal(0, 1.5, (NB, od.spk_frames, od.n_mel)), -4, 4).astype(np.float32)
+    masks = OT.make_masks(od, 1, 1, 1, True, seed=99, speaker_windows=NB)
+    ref = OM.speaker_encoder(OM.to_torch(values), od, torch.tensor(mel, dtype=torch.float64), True, masks)
+    ref_inf = OM.speaker_encoder(OM.to_torch(values), od, torch.tensor(mel, dtype=torch.float64), False, masks)
+    eng = InferEngine(pd, device=dev, values=values)
+    ms = MaskSet(pd, 1, 1, 1, True, dev, speaker_windows=NB)
+    ms.draw(99)
+    for k in ("s_zc_0", "s_zh_2"):
+        assert np.array_equal(t2n(ms[k]), masks[k].numpy())
+    got = eng.speaker_embedding(torch.tensor(mel, device=dev), masks=ms)
+    got_inf = eng.speaker_embedding(torch.tensor(mel, device=dev))
+    torch.cuda.synchronize()
+    assert rel_err(t2n(got), t2n(ref)) < 1e-4 and rel_err(t2n(got_inf), t2n(ref_inf)) < 1e-4
+    assert rel_err(t2n(got), t2n(ref_inf)) > 1e-3             # the two modes really differ
+
+
 def test_tacotron2_surface(dev, tmp_path, monkeypatch):
     """Drop-in surface: Tacotron2(is_Training).Train_Step / Inference / Save / Restore round trip."""
     from multi_speaker_tts_amd import Hyper_Parameters as hp
@@ -483,7 +509,11 @@ def test_tacotron2_surface(dev, tmp_path, monkeypatch):
     monkeypatch.setattr(hp, "Inference_Path", str(tmp_path / "inf"))
     dims = Dims(emb=32, enc_conv_ch=32, enc_lstm=16, spk=256, prenet=16, dec_lstm=32, post_ch=16, bank_ch=8, proj1_ch=16, birnn=8, n_spec=20,
                 spk_lstm=256, max_inf=6)
-    t = Tacotron2(is_Training=True, device=dev, dims=dims)
+    monkeypatch.setattr(hp.Speaker_Embedding, "Checkpoint_Path", str(tmp_path / "no_spk"))
+    monkeypatch.setattr(hp.Taco1_Mel_to_Spect, "Checkpoint_Path", str(tmp_path / "no_voc"))
+    with pytest.raises(ValueError):            # MSTTS_SV.py:226-227,239-240: missing sub-model checkpoints are an error
+        Tacotron2(is_Training=True, device=dev, dims=dims)
+    t = Tacotron2(is_Training=True, device=dev, dims=dims, allow_random_init=True)
     pat = t.feeder.Get_Train_Pattern(batch_Size=2, token_Length=9, mel_Length=200)
     r0 = t.Train_Step(pat)
     assert set(TRAIN_KEYS) <= set(r0) and r0["Global_Step"] == 0 and np.isfinite(r0["Loss"])

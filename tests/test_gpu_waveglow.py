@@ -123,7 +123,7 @@ def test_tacotron2_inference_waveglow_surface(dev, tmp_path, monkeypatch):
     monkeypatch.setattr(hp.WaveGlow, "Checkpoint_Path", str(tmp_path / "wg"))
     dims = Dims(emb=32, enc_conv_ch=32, enc_lstm=16, spk=256, prenet=16, dec_lstm=32, post_ch=16, bank_ch=8, proj1_ch=16, birnn=8, n_spec=20,
                 spk_lstm=256, max_inf=6)
-    t = Tacotron2(is_Training=False, device=dev, dims=dims)
+    t = Tacotron2(is_Training=False, device=dev, dims=dims, allow_random_init=True)
     assert t.waveglow is not None
     mels = [np.clip(np.random.default_rng(i).normal(0, 1.5, (230, 80)), -4, 4).astype(np.float32) for i in range(2)]
     res = t.Inference(None, ["Please call Stella.", "Who knows?"], speaker_Mel_List=mels, file_Prefix="wg")

@@ -244,6 +244,15 @@ int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_c
                        int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
                        const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
                        void* granules, uint32_t epoch, mstts_stream_t s);
+/* Test entries for the time-out paths of the two single-launch kernels: the same launches without the workgroups of one slice, which
+ * forces the rest of each row to time out (milliseconds) and fall back to its serial recompute; the counters behind the granules
+ * then read > 0.  The skipped slice's own outputs are not written. */
+int mstts_lsa_step_fwd_selftest(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                                const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, void* granules,
+                                uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
+int mstts_lsa_step_bwd_selftest(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* G_next, const float* d_f_next,
+                                float* G, const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
+                                void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
 /* post-loop parameter gradients over all S steps (recomputes tanh tiles from the saved d_e):
  * hist pointers are [S,B,*]; outputs accumulate (atomic): d_keys[B,T,A], d_loc_k[KS,A], d_score_w[A], d_score_b[A]
  * (d_loc_b equals d_score_b); unfold d_loc_k with mstts_lsa_unfold_location_grad. */

@@ -213,11 +213,15 @@ __device__ __forceinline__ float lsa_energy_serial(const mstts_lsa_const& c, con
     return e;
 }
 
+// SELFTEST instantiation (mstts_lsa_step_fwd_selftest only): the workgroup of slice `skip` leaves at once, so the rest of its row must take
+// the time-out path - the only way to exercise it, since on a healthy chip no workgroup ever times out
+template <bool SELFTEST>
 __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
                                                               float* __restrict__ q_sum, const float* cum,
                                                               float* __restrict__ align, float* __restrict__ cum_next,
                                                               float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld, PackedDst ctx_p,
-                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl) {
+                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int skip) {
+    if (SELFTEST && (int)blockIdx.x == skip) return;
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
     __shared__ float s_red[FS_TSL][2];
     __shared__ float s_e[T_MAX];
@@ -539,15 +543,46 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
 // block ids.  The only quantity a workgroup needs from the rest of its row is the softmax-backward scalar
 // dot(a, d_a); each workgroup publishes its slice's partial as ONE {epoch,value} granule right after the d_align
 // phase, recomputes its tanh terms while the granules travel, then gathers the T/TS partials (relaxed agent-scope
-// loads, bounded spin).  d_align never goes to memory.  A workgroup that times out poisons its outputs with NaN and
-// counts the event in the word after the last granule (fails loudly, never hangs).
+// loads, bounded spin).  d_align never goes to memory.  A workgroup that times out recomputes the missing partial itself
+// (serially: slow but correct, like the forward kernel) and counts the event in the word after the last granule, so a launch can
+// neither hang nor poison the gradients.
 // ---------------------------------------------------------------------------------------------
+// time-out fallback of lsa_step_bwd_kernel: sum over the TS positions from t0 of a[t] * d_align[t], d_align = G + values . d_ctx with
+// G[t] = G_next[t] + sum_j h_next[t + pad - j][j] - the same quantities the owning workgroup would have published, one thread, no LDS
+__device__ __noinline__ float lsa_dot_partial_serial(const mstts_lsa_const& c, const float* d_ctx, long d_ctx_ld, const float* d_ctx2, long d_ctx2_ld,
+                                                     int d_ctx2_parts, long d_ctx2_pstride, const float* G_next, const float* h_next,
+                                                     const float* align, int b, int t0) {
+    const int T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
+    const int len = c.lengths ? c.lengths[b] : T;
+    float tot = 0.f;
+    for (int t = t0; t < t0 + TS && t < T; ++t) {
+        float g = G_next ? G_next[(long)b * T + t] : 0.f;
+        if (h_next)
+            for (int j = 0; j < KS; ++j) {
+                const int tau = t + pad - j;
+                if (tau >= 0 && tau < T) g += h_next[((long)b * T + tau) * HLD + j];
+            }
+        float acc = 0.f;
+        if (t < len)
+            for (int i = 0; i < M; ++i) {
+                float y = d_ctx[(long)b * d_ctx_ld + i];
+                if (d_ctx2)
+                    for (int pp = 0; pp < max(d_ctx2_parts, 1); ++pp) y += d_ctx2[pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i];
+                acc += c.values[((long)b * T + t) * M + i] * y;
+            }
+        tot += align[(long)b * T + t] * (g + acc);
+    }
+    return tot;
+}
+
+template <bool SELFTEST>
 __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, const float* __restrict__ d_ctx, long d_ctx_ld,
                                                            const float* __restrict__ d_ctx2, long d_ctx2_ld, int d_ctx2_parts, long d_ctx2_pstride,
                                                            const float* __restrict__ G_next, const float* __restrict__ h_next, float* __restrict__ G,
                                                            const float* __restrict__ align, const float* __restrict__ q, const float* __restrict__ cum,
                                                            float* __restrict__ d_e_out, float* __restrict__ dq, float* __restrict__ h,
-                                                           unsigned long long* gran, unsigned epoch) {
+                                                           unsigned long long* gran, unsigned epoch, int skip) {
+    if (SELFTEST && (int)blockIdx.x == skip) return;
     __shared__ float s_gG[TS];
     __shared__ float s_da[TS];
     __shared__ float s_cum[TS + KS_MAX - 1];
@@ -699,7 +734,11 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
                 ++spins;
             }
             if ((unsigned)(x >> 32) == epoch) part = __uint_as_float((unsigned)x);
-            else { part = __builtin_nanf(""); atomicAdd(gran + (long)c.B * nsl, 1ull); }
+            else {          // the slice never arrived: recompute its part of dot(a, d_a) here (serial, slow, correct) and count the event
+                part = lsa_dot_partial_serial(c, d_ctx, d_ctx_ld, d_ctx2, d_ctx2_ld, d_ctx2_parts, d_ctx2_pstride, G_next, h_next, align, b,
+                                              (int)threadIdx.x * TS);
+                atomicAdd(gran + (long)c.B * nsl, 1ull);
+            }
         }
     }
     if (threadIdx.x == 0) part += p_own;                      // thread 0 is lane 0 of wave 0: holds the own partial
@@ -853,19 +892,36 @@ static void lsa_step_geometry(long T, long M, int* cs, int* tsl, int* dsl) {
     *dsl = (int)(cdiv(cdiv(M, n), 4) * 4);
 }
 extern "C" int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T) { return (B * T + 1) * 8; }
-extern "C" int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
-                                  const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
-                                  const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, mstts_stream_t s) {
+static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                               const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                               const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int skip, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_fwd: granule buffer (8-byte aligned) and a non-zero epoch required");
     PackedDst cp;
     rc = packed_dst_from(ctx_p, c->M, &cp, "ctx_p"); if (rc) return rc;
     int cs, tsl, dsl;
     lsa_step_geometry(c->T, c->M, &cs, &tsl, &dsl);
-    hipLaunchKernelGGL(lsa_step_kernel, dim3((unsigned)cs, (unsigned)c->B), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                       align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl);
+    if (skip >= 0)
+        hipLaunchKernelGGL(lsa_step_kernel<true>, dim3((unsigned)cs, (unsigned)c->B), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, skip);
+    else
+        hipLaunchKernelGGL(lsa_step_kernel<false>, dim3((unsigned)cs, (unsigned)c->B), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, -1);
     MSTTS_CHECK_LAUNCH("lsa_step_fwd");
     return MSTTS_OK;
+}
+extern "C" int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                                  const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                                  const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, mstts_stream_t s) {
+    return lsa_step_fwd_launch(c, q, q_parts, q_pstride, q_sum, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch, -1, s);
+}
+/* test entry: same launch with the workgroups of slice `skip_slice` (0 .. slices-1) removed, which forces every other workgroup of each row
+ * through its time-out path (takes milliseconds); the skipped slice's own outputs are not written */
+extern "C" int mstts_lsa_step_fwd_selftest(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
+                                           const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, void* granules,
+                                           uint32_t epoch, int32_t skip_slice, mstts_stream_t s) {
+    MSTTS_REQUIRE(skip_slice >= 0, MSTTS_ERR_SHAPE, "lsa_step_fwd_selftest: skip_slice must be >= 0");
+    return lsa_step_fwd_launch(c, q, q_parts, q_pstride, q_sum, cum, align, cum_next, ctx, ctx_ld, nullptr, 0, nullptr, granules, epoch, skip_slice, s);
 }
 extern "C" int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
                                     int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s) {
@@ -885,19 +941,39 @@ extern "C" int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* alig
     return MSTTS_OK;
 }
 extern "C" int64_t mstts_lsa_step_bwd_ws_bytes(int64_t B, int64_t T) { return (B * cdiv(T, TS) + 1) * 8; }
-extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
-                                  int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
-                                  const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
-                                  void* granules, uint32_t epoch, mstts_stream_t s) {
+static int lsa_step_bwd_launch(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
+                               int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
+                               const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
+                               void* granules, uint32_t epoch, int skip, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(aligned16(d_ctx) && aligned16(d_ctx2) && d_ctx_ld % 4 == 0 && d_ctx2_ld % 4 == 0, MSTTS_ERR_ALIGN,
                   "lsa_step_bwd: d_ctx rows must be 16-byte aligned");
     MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_bwd: granule buffer (8-byte aligned) and a non-zero epoch required");
-    hipLaunchKernelGGL(lsa_step_bwd_kernel, dim3(cdiv(c->T, TS), (unsigned)c->B), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
-                       (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
-                       (unsigned long long*)granules, (unsigned)epoch);
+    if (skip >= 0)
+        hipLaunchKernelGGL(lsa_step_bwd_kernel<true>, dim3(cdiv(c->T, TS), (unsigned)c->B), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
+                           (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
+                           (unsigned long long*)granules, (unsigned)epoch, skip);
+    else
+        hipLaunchKernelGGL(lsa_step_bwd_kernel<false>, dim3(cdiv(c->T, TS), (unsigned)c->B), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
+                           (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
+                           (unsigned long long*)granules, (unsigned)epoch, -1);
     MSTTS_CHECK_LAUNCH("lsa_step_bwd");
     return MSTTS_OK;
+}
+extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
+                                  int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
+                                  const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
+                                  void* granules, uint32_t epoch, mstts_stream_t s) {
+    return lsa_step_bwd_launch(c, d_ctx, d_ctx_ld, d_ctx2, d_ctx2_ld, d_ctx2_parts, d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
+                               granules, epoch, -1, s);
+}
+/* test entry: the same launch without the workgroups of slice `skip_slice`, so every other workgroup of a row times out on that slice and
+ * recomputes its part of dot(a, d_a); the skipped slice's own outputs (d_e / d_f rows, its dq share) are not produced */
+extern "C" int mstts_lsa_step_bwd_selftest(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* G_next, const float* d_f_next,
+                                           float* G, const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
+                                           void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s) {
+    MSTTS_REQUIRE(skip_slice >= 0, MSTTS_ERR_SHAPE, "lsa_step_bwd_selftest: skip_slice must be >= 0");
+    return lsa_step_bwd_launch(c, d_ctx, d_ctx_ld, nullptr, 0, 0, 0, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f, granules, epoch, skip_slice, s);
 }
 extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
                                    float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, mstts_stream_t s) {

@@ -115,7 +115,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--frames", type=int, default=L_MEL, help=argparse.SUPPRESS)
-    ap.add_argument("--recurrent-dtype", default="f32", choices=("f32", "bf16"), help=argparse.SUPPRESS)   # bf16 = BASELINE config 3 mode; never the headline
+    ap.add_argument("--recurrent-dtype", default="f32", choices=("f32", "bf16"), help=argparse.SUPPRESS)   # bf16 recurrent products only
+    ap.add_argument("--config3", action="store_true", help="BASELINE config 3 arithmetic (bf16 operands everywhere, fp32 master/accumulate); never the headline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -142,7 +143,10 @@ def main():
 
     dims = Dims()
     L = args.frames
-    eng = TrainEngine(dims, device=device, seed=1234, rank=rank, world=world, recurrent_dtype=args.recurrent_dtype)
+    if args.config3:
+        args.recurrent_dtype = "bf16"
+    eng = TrainEngine(dims, device=device, seed=1234, rank=rank, world=world, recurrent_dtype=args.recurrent_dtype,
+                      gemm_dtype="bf16" if args.config3 else "f32")
     batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
     reducer = GradAllReduce(eng.params.grad, world) if world > 1 else None
 
@@ -169,7 +173,9 @@ def main():
     out = {"metric": "mel-frames/sec (train step) at batch 32x(128 tok,800 mel)", "value": value, "unit": "mel-frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if args.recurrent_dtype == "f32" else "f32 + bf16 recurrent products (config 3 mode, not the headline)", "data": "synthetic",
+           "dtype": ("f32" if args.recurrent_dtype == "f32" else
+                     "bf16 operands, f32 accumulate + f32 master (BASELINE config 3 arithmetic, not the headline)" if args.config3 else
+                     "f32 + bf16 recurrent products (not the headline)"), "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[1]: Tacotron2 train step (fwd+bwd+TF-Adam), per-GPU batch %d x (%d tokens, %d mel frames), random speaker embeddings, fp32"
                                   % (B_PER_GPU, T_ENC, L),
                       "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world}}

@@ -53,6 +53,9 @@ typedef struct {
     int32_t win_dil;
 } mstts_gemm_desc;
 int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
+/* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes. */
+int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t s);
 
 /* ---- randomness: Philox4x32-10 keep-masks (replaces tf.random_uniform inside
  * tf.layers.dropout, Modules.py:41-45,137-141,248-253, and ZoneoutLSTMCell.py:266-271) ---- */

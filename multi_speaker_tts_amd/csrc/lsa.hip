@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
 // ---------------------------------------------------------------------------------------------
 // time-out fallback of lsa_step_bwd_kernel: sum over the TS positions from t0 of a[t] * d_align[t], d_align = G + values . d_ctx with
 // G[t] = G_next[t] + sum_j h_next[t + pad - j][j] - the same quantities the owning workgroup would have published, one thread, no LDS
-__device__ __noinline__ float lsa_dot_partial_serial(const mstts_lsa_const& c, const float* d_ctx, long d_ctx_ld, const float* d_ctx2, long d_ctx2_ld,
+__device__ __forceinline__ float lsa_dot_partial_serial(const mstts_lsa_const& c, const float* d_ctx, long d_ctx_ld, const float* d_ctx2, long d_ctx2_ld,
                                                      int d_ctx2_parts, long d_ctx2_pstride, const float* G_next, const float* h_next,
                                                      const float* align, int b, int t0) {
     const int T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;

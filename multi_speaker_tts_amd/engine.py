@@ -57,7 +57,7 @@ class _WS:
 
 class TrainEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, rank=0, world=1, values=None,
-                 update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None):
+                 update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None, gemm_dtype=None):
         """recurrent_dtype: 'f32' (default; BASELINE config 2) or 'bf16' (config 3: the decoder's recurrent products run on
         bf16 copies of the fp32 master weights with fp32 accumulation)."""
         lib.load()
@@ -96,6 +96,9 @@ class TrainEngine:
         self.wq_t = self._f(d.att * H) if d.att == 128 else None         # query kernel as [A/4, H, 4] (fused query-layer data gradient)
         self.flip = {}
         self._derived_stale = True
+        self.gemm_dtype = (gemm_dtype or "f32").lower()
+        if self.gemm_dtype not in ("f32", "bf16"):
+            raise ValueError("gemm_dtype must be 'f32' or 'bf16'")
         self.recurrent_dtype = (recurrent_dtype or "f32").lower()
         if self.recurrent_dtype not in ("f32", "bf16"):
             raise ValueError("recurrent_dtype must be 'f32' or 'bf16'")
@@ -112,6 +115,13 @@ class TrainEngine:
     def _f(self, *shape):
         n = int(np.prod(shape))
         return torch.zeros((n + 3) // 4 * 4, dtype=torch.float32, device=self.device)[:n].view(shape)
+
+    def _gemm(self, *a, exact=False, **k):
+        """Every dense / conv contraction of the step.  gemm_dtype 'bf16' (BASELINE config 3) rounds both operands to bf16 for the
+        matrix cores (fp32 accumulate, fp32 master weights / activations / gradients in memory); exact=True keeps the few
+        contractions that have no dense-layer counterpart in the reference graph (d_values from the alignments, the vocoder's
+        statistics side effect) in fp32 in either mode."""
+        return gemm(*a, bf16=(self.gemm_dtype == "bf16" and not exact), **k)
 
     def P(self, name):
         return self.params.p(name)
@@ -258,7 +268,7 @@ class TrainEngine:
     def _conv_fwd(self, x, x_off, rows, T, cin, cout, K, kname, bname, out, act):
         k, ok = self.P(kname)
         b, ob = self.P(bname)
-        gemm(x, k, out, rows, cout, K * cin, cin, cout, cout, bias=b, act=act, win=(T, cin, (K - 1) // 2),
+        self._gemm(x, k, out, rows, cout, K * cin, cin, cout, cout, bias=b, act=act, win=(T, cin, (K - 1) // 2),
              a_off=x_off, b_off=ok, bias_off=ob)
 
     def _bn_fwd(self, prefix, a, y, mean, rstd, mask, keep, rows, C, ws):
@@ -278,7 +288,7 @@ class TrainEngine:
              ptr(gg, ogg), ptr(gb, ogb), ptr(gbias, ogbias), rows, cout, ptr(self._bnws))
         gk, ogk = self.G(prefix + "conv1d/kernel")
         pad = (K - 1) // 2
-        gemm(x_in, dz, gk, K * cin, cout, rows, cin, cout, cout, trans_a=True, win=(T, cin, pad),
+        self._gemm(x_in, dz, gk, K * cin, cout, rows, cin, cout, cout, trans_a=True, win=(T, cin, pad),
              split_k=max(2, _split_k(K * cin, cout, rows)), c_off=ogk)
         if dx is not None:
             k, ok = self.P(prefix + "conv1d/kernel")
@@ -287,7 +297,7 @@ class TrainEngine:
                 self.flip[key] = self._f(K, cout, cin)
             wt = self.flip[key]
             call("mstts_conv_kernel_flip", ptr(k, ok), ptr(wt), K, cin, cout)
-            gemm(dz, wt, dx, rows, cin, K * cout, cout, cin, cin, win=(T, cout, K - 1 - pad))
+            self._gemm(dz, wt, dx, rows, cin, K * cout, cout, cin, cin, win=(T, cout, K - 1 - pad))
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch, w, seed=None, masks=None):
@@ -317,7 +327,7 @@ class TrainEngine:
             x, cin = w.enc_y[i], d.enc_conv_ch
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(ENC_CELL % dr + "kernel"); b, ob = self.P(ENC_CELL % dr + "bias")
-            gemm(x, k, w.enc_xw[dr], B * Te, 4 * He, cin, cin, 4 * He, 4 * He, bias=b, b_off=ok, bias_off=ob)
+            self._gemm(x, k, w.enc_xw[dr], B * Te, 4 * He, cin, cin, 4 * He, 4 * He, bias=b, b_off=ok, bias_off=ob)
             q = lib.LstmSeqFwd()
             q.B, q.T, q.H = B, Te, He
             q.xw = ptr(w.enc_xw[dr]); q.wh = ptr(k, ok + cin * 4 * He); q.wh_ld = 4 * He
@@ -330,17 +340,17 @@ class TrainEngine:
         # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
         call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
         wm, owm = self.P("attention/memory_layer/kernel")
-        gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)
+        self._gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)
         # ---- hoisted prenet over all S frames (Modules.py:239-255) and cell-0 input product
         call("mstts_shift_frames", ptr(mel), ptr(w.frames), B, L, d.n_mel)
         x, cin = w.frames, d.n_mel
         for i in range(d.prenet_n):
             k, ok = self.P("decoder/decoder/prenet_%d/dense/kernel" % i); b, ob = self.P("decoder/decoder/prenet_%d/dense/bias" % i)
-            gemm(x, k, w.pre_a[i], S * B, Pn, cin, cin, Pn, Pn, bias=b, act=ACT_RELU, b_off=ok, bias_off=ob)
+            self._gemm(x, k, w.pre_a[i], S * B, Pn, cin, cin, Pn, Pn, bias=b, act=ACT_RELU, b_off=ok, bias_off=ob)
             call("mstts_dropout", ptr(w.pre_a[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(w.pre_d[i]), S * B * Pn)
             x, cin = w.pre_d[i], Pn
         k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
-        gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
+        self._gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
         # ---- decoder loop
         dec = w.dec
         dec.B, dec.S, dec.H, dec.P = B, S, H, Pn
@@ -367,7 +377,7 @@ class TrainEngine:
             setattr(dec, nm, ptr(getattr(w, nm)))
         call("mstts_decoder_train_fwd", C.byref(dec))
         # ---- projection (Modules.py:309-321) on all steps at once, then batch-major linear/stop
-        gemm(w.pj, self.wp_pad, w.proj, S * B, self.proj_ld, H + M, H + M, self.proj_ld, self.proj_ld, bias=self.bp_pad)
+        self._gemm(w.pj, self.wp_pad, w.proj, S * B, self.proj_ld, H + M, H + M, self.proj_ld, self.proj_ld, bias=self.bp_pad)
         call("mstts_unpack_proj", ptr(w.proj), self.proj_ld, ptr(w.linear), ptr(w.stop), B, S, d.n_mel)
         # ---- postnet (Modules.py:121-143) + residual
         x, cin = w.linear, d.n_mel
@@ -391,19 +401,19 @@ class TrainEngine:
         for k in range(1, d.bank_k + 1):
             sfx = bank_suffix(k)
             kk, ok = self.P(VOC + "convbank_0/conv1d%s/kernel" % sfx); b, ob = self.P(VOC + "convbank_0/conv1d%s/bias" % sfx)
-            gemm(w.mel_out, kk, w.v_tmp, rows, d.bank_ch, k * d.n_mel, d.n_mel, d.bank_ch, d.bank_ch, bias=b, act=ACT_RELU,
-                 win=(S, d.n_mel, (k - 1) // 2), b_off=ok, bias_off=ob)
+            self._gemm(w.mel_out, kk, w.v_tmp, rows, d.bank_ch, k * d.n_mel, d.n_mel, d.bank_ch, d.bank_ch, bias=b, act=ACT_RELU,
+                 win=(S, d.n_mel, (k - 1) // 2), b_off=ok, bias_off=ob, exact=True)
             self._bn_fwd(VOC + "convbank_0/batch_normalization%s/" % sfx, w.v_tmp, w.v_tmp2, w.v_stat, w.v_stat[d.bank_ch:], None, 1.0, rows, d.bank_ch, w.bn_ws)
             call("mstts_copy2d", ptr(w.v_tmp2), d.bank_ch, ptr(w.v_cat, (k - 1) * d.bank_ch), d.bank_k * d.bank_ch, rows, d.bank_ch, 0)
         C1 = d.bank_k * d.bank_ch
         call("mstts_maxpool2_same", ptr(w.v_cat), ptr(w.v_pool), B, S, C1)
         kk, ok = self.P(VOC + "convbank_0/conv1d_8/kernel"); b, ob = self.P(VOC + "convbank_0/conv1d_8/bias")
-        gemm(w.v_pool, kk, w.v_p1, rows, d.proj1_ch, d.proj1_k * C1, C1, d.proj1_ch, d.proj1_ch, bias=b, act=ACT_RELU,
-             win=(S, C1, (d.proj1_k - 1) // 2), b_off=ok, bias_off=ob)
+        self._gemm(w.v_pool, kk, w.v_p1, rows, d.proj1_ch, d.proj1_k * C1, C1, d.proj1_ch, d.proj1_ch, bias=b, act=ACT_RELU,
+             win=(S, C1, (d.proj1_k - 1) // 2), b_off=ok, bias_off=ob, exact=True)
         self._bn_fwd(VOC + "convbank_0/batch_normalization_8/", w.v_p1, w.v_p1y, w.v_stat, w.v_stat[d.proj1_ch:], None, 1.0, rows, d.proj1_ch, w.bn_ws)
         kk, ok = self.P(VOC + "convbank_0/conv1d_9/kernel"); b, ob = self.P(VOC + "convbank_0/conv1d_9/bias")
-        gemm(w.v_p1y, kk, w.v_p2, rows, d.n_mel, d.proj2_k * d.proj1_ch, d.proj1_ch, d.n_mel, d.n_mel, bias=b,
-             win=(S, d.proj1_ch, (d.proj2_k - 1) // 2), b_off=ok, bias_off=ob)
+        self._gemm(w.v_p1y, kk, w.v_p2, rows, d.n_mel, d.proj2_k * d.proj1_ch, d.proj1_ch, d.n_mel, d.n_mel, bias=b,
+             win=(S, d.proj1_ch, (d.proj2_k - 1) // 2), b_off=ok, bias_off=ob, exact=True)
         self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.bn_ws)
 
     # ------------------------------------------------------------------ loss + backward
@@ -437,13 +447,13 @@ class TrainEngine:
         # ---- projection backward
         call("mstts_pack_dproj", ptr(w.d_linear), ptr(w.d_stop), ptr(w.d_proj), self.proj_ld, B, S, d.n_mel)
         self.dwp_pad.zero_()
-        gemm(w.pj, w.d_proj, self.dwp_pad, H + M, self.proj_ld, S * B, H + M, self.proj_ld, self.proj_ld, trans_a=True,
+        self._gemm(w.pj, w.d_proj, self.dwp_pad, H + M, self.proj_ld, S * B, H + M, self.proj_ld, self.proj_ld, trans_a=True,
              split_k=max(2, _split_k(H + M, self.proj_ld, S * B)))
         gwp, ogwp = self.G("decoder/decoder/linear_projection/dense/kernel")
         gbp, ogbp = self.G("decoder/decoder/linear_projection/dense/bias")
         call("mstts_copy2d", ptr(self.dwp_pad), self.proj_ld, ptr(gwp, ogwp), d.n_mel + 1, H + M, d.n_mel + 1, 1)
         call("mstts_colsum", ptr(w.d_proj), S * B, d.n_mel + 1, self.proj_ld, ptr(gbp, ogbp), 1)
-        gemm(w.d_proj, self.wp_pad, w.d_pj, S * B, H + M, self.proj_ld, self.proj_ld, self.proj_ld, H + M, trans_b=True)
+        self._gemm(w.d_proj, self.wp_pad, w.d_pj, S * B, H + M, self.proj_ld, self.proj_ld, self.proj_ld, H + M, trans_b=True)
         # ---- decoder loop backward
         w.dq_hist.zero_()
         db = w.dec_b
@@ -469,11 +479,11 @@ class TrainEngine:
             x_in = w.frames if i == 0 else w.pre_d[i - 1]
             call("mstts_relu_dropout_bwd", ptr(dcur), ptr(w.pre_d[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(dcur), SB * Pn)
             gk, ogk = self.G("decoder/decoder/prenet_%d/dense/kernel" % i); gb, ogb = self.G("decoder/decoder/prenet_%d/dense/bias" % i)
-            gemm(x_in, dcur, gk, cin, Pn, SB, cin, Pn, Pn, trans_a=True, split_k=max(2, _split_k(cin, Pn, SB)), c_off=ogk)
+            self._gemm(x_in, dcur, gk, cin, Pn, SB, cin, Pn, Pn, trans_a=True, split_k=max(2, _split_k(cin, Pn, SB)), c_off=ogk)
             call("mstts_colsum", ptr(dcur), SB, Pn, Pn, ptr(gb, ogb), 1)
             if i > 0:
                 k, ok = self.P("decoder/decoder/prenet_%d/dense/kernel" % i)
-                gemm(dcur, k, dnxt, SB, cin, Pn, Pn, Pn, cin, trans_b=True, b_off=ok)
+                self._gemm(dcur, k, dnxt, SB, cin, Pn, Pn, Pn, cin, trans_b=True, b_off=ok)
                 dcur, dnxt = dnxt, dcur
         gs = {}
         for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
@@ -484,16 +494,16 @@ class TrainEngine:
         call("mstts_lsa_unfold_location_grad", ls.conv_k, ls.conv_b, ls.dense_k, ptr(self.d_loc_k), gs["score_b"],
              gs["conv_k"], gs["conv_b"], gs["dense_k"], d.att_k, d.att_ch, d.att)
         # d_values[b] = sum_s align[s,b,:]^T (d_ctx from projection + d_ctx from next step's cell 0)
-        gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
-             strides=(Te, H + M, Te * M), b_off=H)
+        self._gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
+                   strides=(Te, H + M, Te * M), b_off=H, exact=True)
         if S > 1:
             for part in range(w.d_in0_parts):
-                gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
-                     strides=(Te, M + H, Te * M), b_off=(part * S + 1) * B * (M + H), accumulate=True)
+                self._gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
+                           strides=(Te, M + H, Te * M), b_off=(part * S + 1) * B * (M + H), accumulate=True, exact=True)
         # memory layer
         wm, owm = self.P("attention/memory_layer/kernel"); gwm, ogwm = self.G("attention/memory_layer/kernel")
-        gemm(w.values, w.d_keys, gwm, M, A, B * Te, M, A, A, trans_a=True, split_k=max(2, _split_k(M, A, B * Te)), c_off=ogwm)
-        gemm(w.d_keys, wm, w.d_values, B * Te, M, A, A, A, M, trans_b=True, accumulate=True, b_off=owm)
+        self._gemm(w.values, w.d_keys, gwm, M, A, B * Te, M, A, A, trans_a=True, split_k=max(2, _split_k(M, A, B * Te)), c_off=ogwm)
+        self._gemm(w.d_keys, wm, w.d_values, B * Te, M, A, A, A, M, trans_b=True, accumulate=True, b_off=owm)
         if on_ready is not None:             # decoder + attention gradients are final: overlaps the encoder backward
             on_ready(*self._grad_range("attention/", "decoder/decoder"))
         # ---- encoder BiLSTM backward
@@ -510,12 +520,12 @@ class TrainEngine:
             q.dgates_step = ptr(w.enc_dgs[dr]); q.dgates_pos = ptr(w.enc_dgp[dr]); q.ws = ptr(w.enc_bwd_ws)
             call("mstts_lstm_seq_bwd", C.byref(q))
             gk, ogk = self.G(ENC_CELL % dr + "kernel"); gb, ogb = self.G(ENC_CELL % dr + "bias")
-            gemm(x_in, w.enc_dgp[dr], gk, cin, 4 * He, B * Te, cin, 4 * He, 4 * He, trans_a=True,
+            self._gemm(x_in, w.enc_dgp[dr], gk, cin, 4 * He, B * Te, cin, 4 * He, 4 * He, trans_a=True,
                  split_k=max(2, _split_k(cin, 4 * He, B * Te)), c_off=ogk)
-            gemm(w.enc_h[dr], w.enc_dgs[dr], gk, He, 4 * He, Te * B, He, 4 * He, 4 * He, trans_a=True,
+            self._gemm(w.enc_h[dr], w.enc_dgs[dr], gk, He, 4 * He, Te * B, He, 4 * He, 4 * He, trans_a=True,
                  split_k=max(2, _split_k(He, 4 * He, B * Te)), c_off=ogk + cin * 4 * He)
             call("mstts_colsum", ptr(w.enc_dgs[dr]), Te * B, 4 * He, 4 * He, ptr(gb, ogb), 1)
-            gemm(w.enc_dgp[dr], k, w.enc_dy, B * Te, cin, 4 * He, 4 * He, 4 * He, cin, trans_b=True, accumulate=(di == 1), b_off=ok)
+            self._gemm(w.enc_dgp[dr], k, w.enc_dy, B * Te, cin, 4 * He, 4 * He, 4 * He, cin, trans_b=True, accumulate=(di == 1), b_off=ok)
         # ---- encoder conv backward
         dy = w.enc_dy
         bufs = [w.enc_dx, w.enc_dy]
@@ -541,19 +551,19 @@ class TrainEngine:
         n = (hi - lo) * B
         r = lo * B                                           # first row of the range in the step-major histories
         g1, og1 = self.G(CELL % 1 + "kernel"); gb1, ogb1 = self.G(CELL % 1 + "bias")
-        gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, n, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, n), accumulate=True,
+        self._gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, n, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, n), accumulate=True,
              a_off=r * 2 * H, b_off=r * 4 * H, c_off=og1)
         call("mstts_colsum", ptr(w.dg1, r * 4 * H), n, 4 * H, 4 * H, ptr(gb1, ogb1), 1)
         g0, og0 = self.G(CELL % 0 + "kernel"); gb0, ogb0 = self.G(CELL % 0 + "bias")
-        gemm(w.in0, w.dg0, self.dw0f, M + H, 4 * H, n, M + H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(M + H, 4 * H, n), accumulate=True,
+        self._gemm(w.in0, w.dg0, self.dw0f, M + H, 4 * H, n, M + H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(M + H, 4 * H, n), accumulate=True,
              a_off=r * (M + H), b_off=r * 4 * H)
-        gemm(w.pre_d[-1], w.dg0, g0, Pn, 4 * H, n, Pn, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(Pn, 4 * H, n)),
+        self._gemm(w.pre_d[-1], w.dg0, g0, Pn, 4 * H, n, Pn, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(Pn, 4 * H, n)),
              a_off=r * Pn, b_off=r * 4 * H, c_off=og0)
         call("mstts_colsum", ptr(w.dg0, r * 4 * H), n, 4 * H, 4 * H, ptr(gb0, ogb0), 1)
         k0, o0 = self.P(CELL % 0 + "kernel")
-        gemm(w.dg0, k0, w.d_pre, n, Pn, 4 * H, 4 * H, 4 * H, Pn, trans_b=True, a_off=r * 4 * H, b_off=o0, c_off=r * Pn)
+        self._gemm(w.dg0, k0, w.d_pre, n, Pn, 4 * H, 4 * H, 4 * H, Pn, trans_b=True, a_off=r * 4 * H, b_off=o0, c_off=r * Pn)
         gq, ogq = self.G(LSA + "query_layer/kernel")
-        gemm(w.pj, w.dq_hist, gq, H, A, n, H + M, A, A, trans_a=True, split_k=max(2, _split_k(H, A, n)), a_off=r * (H + M), b_off=r * A, c_off=ogq)
+        self._gemm(w.pj, w.dq_hist, gq, H, A, n, H + M, A, A, trans_a=True, split_k=max(2, _split_k(H, A, n)), a_off=r * (H + M), b_off=r * A, c_off=ogq)
         gsw, ogsw = self.G(LSA + "score_layer/weight_w"); gsb, ogsb = self.G(LSA + "score_layer/bias_b")
         call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), hi - lo, ptr(w.q_hist, r * A), ptr(w.cum_hist, r * Te), ptr(w.de_hist, r * Te), ptr(w.d_keys),
              ptr(self.d_loc_k), ptr(gsw, ogsw), ptr(gsb, ogsb))

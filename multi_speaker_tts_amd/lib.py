@@ -104,6 +104,7 @@ SIGNATURES = {
     "mstts_last_error": (C.c_char_p, []),
     "mstts_abi_version": (i32, []),
     "mstts_gemm_f32": (i32, [P(GemmDesc), vp]),
+    "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
     "mstts_philox_keep_mask_rows": (i32, [vp, i64, i64, i64, u64, u32, u64, f32, vp]),
     "mstts_embedding_fwd": (i32, [vp, vp, vp, i64, i64, i64, vp]),
@@ -234,8 +235,9 @@ def call(name, *args):
 
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, bias=None, trans_a=False, trans_b=False, act=ACT_NONE, accumulate=False,
-         split_k=1, win=None, batch=1, strides=(0, 0, 0), alpha=1.0, a_off=0, b_off=0, c_off=0, bias_off=0):
-    """Thin wrapper over mstts_gemm_f32.  A/B/Cm/bias are tensors (used only for their pointers)."""
+         split_k=1, win=None, batch=1, strides=(0, 0, 0), alpha=1.0, a_off=0, b_off=0, c_off=0, bias_off=0, bf16=False):
+    """Thin wrapper over mstts_gemm_f32 (bf16=True: mstts_gemm_bf16, operands rounded to bf16, fp32 accumulate).
+    A/B/Cm/bias are tensors (used only for their pointers)."""
     d = GemmDesc()
     d.A, d.B, d.C, d.bias = ptr(A, a_off), ptr(B, b_off), ptr(Cm, c_off), ptr(bias, bias_off)
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
@@ -246,4 +248,4 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, bias=None, trans_a=False, trans_b=Fal
     d.act, d.accumulate, d.split_k = act, int(accumulate), split_k
     d.batch, d.stride_a, d.stride_b, d.stride_c = batch, strides[0], strides[1], strides[2]
     d.alpha = alpha
-    call("mstts_gemm_f32", C.byref(d))
+    call("mstts_gemm_bf16" if bf16 else "mstts_gemm_f32", C.byref(d))

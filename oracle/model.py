@@ -221,15 +221,16 @@ def to_torch(params, dtype=torch.float64, requires_grad=False):
 # --------------------------------------------------------------------------------------------
 # primitive layers
 # --------------------------------------------------------------------------------------------
-def conv1d_same(x, kernel, bias=None):
+def conv1d_same(x, kernel, bias=None, engine_gemm=False):
     """tf.layers.conv1d(padding='same', strides=1) on [B,T,Cin] with kernel [K,Cin,Cout].
-    SAME padding: left=(K-1)//2, right=K-1-left (quirk Q12)."""
+    SAME padding: left=(K-1)//2, right=K-1-left (quirk Q12).  engine_gemm: one of the convolutions the HIP train engine runs as an
+    implicit-im2col GEMM (rounded operands under GEMM_BF16)."""
     K, cin, cout = kernel.shape
     left = (K - 1) // 2
     xp = F.pad(x, (0, 0, left, K - 1 - left))
     win = xp.unfold(1, K, 1)                       # [B,T,Cin,K]
     win = win.permute(0, 1, 3, 2).reshape(x.shape[0], x.shape[1], K * cin)
-    y = win @ kernel.reshape(K * cin, cout)
+    y = gmm(win, kernel.reshape(K * cin, cout)) if engine_gemm else win @ kernel.reshape(K * cin, cout)
     return y if bias is None else y + bias
 
 
@@ -275,9 +276,50 @@ class _BF16MatMul(torch.autograd.Function):
         return _bf(g) @ _bf(w).t(), x.t() @ g
 
 
+# Full config-3 emulation: additionally every dense / conv contraction the HIP engine issues through its GEMM entry point (conv fwd /
+# data gradient / weight gradient, prenet, hoisted cell-0 input product, projection, memory layer, encoder LSTM input product, and
+# ALL hoisted weight-gradient GEMMs incl. the recurrent kernels') multiplies bf16-rounded operands, fp32/fp64 accumulate.
+GEMM_BF16 = False
+
+
+class _BF16MatMulFull(torch.autograd.Function):
+    """y = bf(x) . bf(w); dx = bf(g) . bf(w)^T; dw = bf(x)^T . bf(g)   (x may carry leading batch dims)."""
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _bf(x) @ _bf(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        x2, g2 = x.reshape(-1, x.shape[-1]), g.reshape(-1, g.shape[-1])
+        return _bf(g) @ _bf(w).t(), _bf(x2).t() @ _bf(g2)
+
+
+class _MatMulWgradBF16(torch.autograd.Function):
+    """Recurrent product that stays fp32 in the loop (encoder BiLSTM h . Wh: exact forward and data gradient) but whose hoisted
+    weight gradient runs on the bf16 GEMM: dw = bf(x)^T . bf(g)."""
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return g @ w.t(), _bf(x).t() @ _bf(g)
+
+
+def gmm(x, w):
+    """A contraction the HIP engine runs through its GEMM entry point."""
+    return _BF16MatMulFull.apply(x, w) if GEMM_BF16 else x @ w
+
+
 def rmm(x, w):
-    """Recurrent matmul of the decoder loop."""
-    return _BF16MatMul.apply(x, w) if RECURRENT_BF16 else x @ w
+    """Recurrent matmul of the decoder loop (bf16 skinny kernels in config-3 mode; its hoisted weight gradient is a GEMM)."""
+    if RECURRENT_BF16:
+        return _BF16MatMulFull.apply(x, w) if GEMM_BF16 else _BF16MatMul.apply(x, w)
+    return _MatMulWgradBF16.apply(x, w) if GEMM_BF16 else x @ w
 
 
 def zoneout_lstm_cell(x, c_prev, h_prev, kernel, bias, zc, zh, rate, training, gates=None):
@@ -294,7 +336,7 @@ def zoneout_lstm_cell(x, c_prev, h_prev, kernel, bias, zc, zh, rate, training, g
     return m, (1.0 - rate) * dc + c_prev, (1.0 - rate) * dm + h_prev
 
 
-def run_lstm(x, lengths, kernel, bias, H, zc, zh, rate, training, reverse=False, residual=False):
+def run_lstm(x, lengths, kernel, bias, H, zc, zh, rate, training, reverse=False, residual=False, engine_gemm=False):
     """tf.nn.dynamic_rnn over one ZoneoutLSTMCell on [B,T,Cin]: past ``lengths`` the output is
     zero and the state is carried through unchanged; ``reverse`` = tf.reverse_sequence by length
     before and after (bidirectional_dynamic_rnn backward direction).  zc/zh: [T,B,H] in
@@ -311,9 +353,13 @@ def run_lstm(x, lengths, kernel, bias, H, zc, zh, rate, training, reverse=False,
         x = torch.gather(x, 1, idx[:, :, None].expand(-1, -1, x.shape[2]))
     outs = []
     for t in range(T):
+        gates = None
+        if engine_gemm and GEMM_BF16:        # the train engine hoists x . Wx into one GEMM (rounded operands); h . Wh stays fp32 in the loop
+            cin = x.shape[2]
+            gates = gmm(x[:, t], kernel[:cin]) + _MatMulWgradBF16.apply(h, kernel[cin:]) + bias
         m, c2, h2 = zoneout_lstm_cell(x[:, t], c, h, kernel, bias,
                                       None if zc is None else zc[t], None if zh is None else zh[t],
-                                      rate, training)
+                                      rate, training, gates=gates)
         if residual:
             m = m + x[:, t]
         live = (t < lengths)[:, None]
@@ -354,7 +400,7 @@ def encoder(p, d: Dims, token, token_length, training, masks, stats_out=None):
     x = p["encoder/embedding_variable"][token.long()]
     for i in range(d.enc_conv_n):
         pre = "encoder/conv_%d/" % i
-        x = relu_at(conv1d_same(x, p[pre + "conv1d/kernel"], p[pre + "conv1d/bias"]), masks.get("relu_enc_%d" % i) if masks else None)
+        x = relu_at(conv1d_same(x, p[pre + "conv1d/kernel"], p[pre + "conv1d/bias"], engine_gemm=True), masks.get("relu_enc_%d" % i) if masks else None)
         x = batch_norm(x, p, pre + "batch_normalization/", training, stats_out)
         if training:
             x = dropout(x, masks["enc_conv_drop_%d" % i], d.conv_drop)
@@ -362,7 +408,7 @@ def encoder(p, d: Dims, token, token_length, training, masks, stats_out=None):
     for dr in ("fw", "bw"):
         outs.append(run_lstm(x, token_length, p[P_ENC_CELL % dr + "kernel"], p[P_ENC_CELL % dr + "bias"],
                              d.enc_lstm, masks.get("enc_zc_" + dr), masks.get("enc_zh_" + dr),
-                             d.zoneout, training, reverse=(dr == "bw")))
+                             d.zoneout, training, reverse=(dr == "bw"), engine_gemm=True))
     return torch.cat(outs, dim=2)
 
 
@@ -371,7 +417,7 @@ def prenet(p, d: Dims, x, masks, step):
     masks 'prenet_drop_%d' [S,B,P] indexed by decoder step."""
     for i in range(d.prenet_n):
         pre = "decoder/decoder/prenet_%d/dense/" % i
-        x = torch.relu(x @ p[pre + "kernel"] + p[pre + "bias"])
+        x = torch.relu(gmm(x, p[pre + "kernel"]) + p[pre + "bias"])
         x = dropout(x, masks["prenet_drop_%d" % i][step], d.prenet_drop)
     return x
 
@@ -399,7 +445,7 @@ def attention_memory(p, memory, token_length):
     B, T, _ = memory.shape
     mask = torch.arange(T)[None, :] < token_length.long()[:, None]
     values = memory * mask[:, :, None].to(memory.dtype)
-    keys = values @ p["attention/memory_layer/kernel"]
+    keys = gmm(values, p["attention/memory_layer/kernel"])
     return keys, values, mask
 
 
@@ -428,12 +474,12 @@ def decoder(p, d: Dims, memory, token_length, mel, mel_length, training, masks):
         x = torch.cat([pre, ctx, ctx], dim=1)            # quirk Q1: context enters twice
         for l in range(d.dec_lstm_n):
             gates = None
-            if RECURRENT_BF16:      # the products the HIP path runs in bf16: [ctx | h0] on the FOLDED cell-0 kernel, [m0 | h1] on cell 1
-                K, bb = p[P_CELL % l + "kernel"], p[P_CELL % l + "bias"]
+            if RECURRENT_BF16 or GEMM_BF16:      # the products as the HIP path forms them: the hoisted prenet part of cell 0 is a GEMM,
+                K, bb = p[P_CELL % l + "kernel"], p[P_CELL % l + "bias"]     # [ctx | h0] runs on the FOLDED cell-0 kernel, [m0 | h1] on cell 1
                 if l == 0:
                     Pn, Mm = d.prenet, d.mem
                     fold = torch.cat([K[Pn:Pn + Mm] + K[Pn + Mm:Pn + 2 * Mm], K[Pn + 2 * Mm:]], dim=0)
-                    gates = pre @ K[:Pn] + bb + rmm(torch.cat([ctx, h[0]], dim=1), fold)
+                    gates = gmm(pre, K[:Pn]) + bb + rmm(torch.cat([ctx, h[0]], dim=1), fold)
                 else:
                     gates = rmm(torch.cat([x, h[l]], dim=1), K) + bb
             x, c[l], h[l] = zoneout_lstm_cell(
@@ -441,7 +487,7 @@ def decoder(p, d: Dims, memory, token_length, mel, mel_length, training, masks):
                 masks["dec_zc_%d" % l][t] if training else None,
                 masks["dec_zh_%d" % l][t] if training else None, d.zoneout, training, gates=gates)
         align, cum, ctx = lsa_step(p, d, keys, values, lmask, x, cum)
-        proj = torch.cat([x, ctx], dim=1) @ p["decoder/decoder/linear_projection/dense/kernel"] \
+        proj = gmm(torch.cat([x, ctx], dim=1), p["decoder/decoder/linear_projection/dense/kernel"]) \
             + p["decoder/decoder/linear_projection/dense/bias"]
         lin, st = proj[:, :d.n_mel], proj[:, d.n_mel]
         linear.append(lin); stop.append(st); aligns.append(align)
@@ -462,7 +508,7 @@ def postnet(p, d: Dims, x, training, masks, stats_out=None):
     """Decoder_Conv (Modules.py:121-143; quirk Q10): conv -> tanh -> BN -> dropout, all 5 layers."""
     for i in range(d.post_n):
         pre = "decoder/conv_%d/" % i
-        x = torch.tanh(conv1d_same(x, p[pre + "conv1d/kernel"], p[pre + "conv1d/bias"]))
+        x = torch.tanh(conv1d_same(x, p[pre + "conv1d/kernel"], p[pre + "conv1d/bias"], engine_gemm=True))
         x = batch_norm(x, p, pre + "batch_normalization/", training, stats_out)
         if training:
             x = dropout(x, masks["post_drop_%d" % i], d.conv_drop)

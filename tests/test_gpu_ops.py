@@ -13,6 +13,10 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
 def _r(dev, *shape, seed=0, scale=1.0):
     g = np.random.default_rng(seed)
     return torch.tensor(g.normal(0, scale, size=shape), dtype=torch.float32, device=dev)
@@ -159,6 +163,55 @@ def test_adam_tf(dev):
     assert rel_err(t2n(m), mr) < 1e-6 and rel_err(t2n(v), vr) < 1e-6
 
 
+def _gemm_call(name, A, B, Cm, M, N, K, lda, ldb, ldc, **kw):
+    d = lib.GemmDesc()
+    d.A, d.B, d.C, d.bias = lib.ptr(A), lib.ptr(B), lib.ptr(Cm), lib.ptr(kw.get("bias"))
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+    d.trans_a, d.trans_b = int(kw.get("ta", 0)), int(kw.get("tb", 0))
+    if kw.get("win"):
+        d.win_T, d.win_C, d.win_pad = kw["win"]
+        d.win_dil = 1
+    d.act, d.accumulate, d.split_k = kw.get("act", 0), int(kw.get("accumulate", 0)), kw.get("split_k", 1)
+    d.batch, d.alpha = 1, 1.0
+    lib.call(name, C.byref(d))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 36), (300, 84, 64), (17, 81, 100), (1024, 512, 2560)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_layouts(dev, M, N, K, ta, tb):
+    """mstts_gemm_bf16 = fp32-accumulated product of the bf16-ROUNDED operands (config 3), every layout incl. ragged edges."""
+    A = _r(dev, *((K, M) if ta else (M, K)), seed=1)
+    B = _r(dev, *((N, K) if tb else (K, N)), seed=2, scale=1.0 / np.sqrt(K))
+    Cm = torch.zeros(M, N, device=dev)
+    bias = _r(dev, N, seed=3)
+    _gemm_call("mstts_gemm_bf16", A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, bias=bias, act=2)
+    a = _bf(A).cpu().numpy(); b = _bf(B).cpu().numpy()
+    ref = np.tanh((a.T if ta else a) @ (b.T if tb else b) + t2n(bias).astype(np.float64))
+    assert rel_err(t2n(Cm), ref) < TOL
+    if (M, N, K) == (256, 256, 128):          # ... and it really is a different product from the fp32 one
+        C32 = torch.zeros(M, N, device=dev)
+        _gemm_call("mstts_gemm_f32", A, B, C32, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, bias=bias, act=2)
+        assert rel_err(t2n(C32), ref) > 1e-4
+
+
+def test_gemm_bf16_conv_window_splitk(dev):
+    """Implicit-im2col conv forward, weight gradient (transposed window, split-K atomics) and accumulate on the bf16 GEMM."""
+    B_, T, cin, cout, K = 3, 37, 16, 24, 5
+    x = _r(dev, B_ * T, cin, seed=4); w = _r(dev, K * cin, cout, seed=5, scale=0.2)
+    y = torch.zeros(B_ * T, cout, device=dev)
+    _gemm_call("mstts_gemm_bf16", x, w, y, B_ * T, cout, K * cin, cin, cout, cout, win=(T, cin, (K - 1) // 2))
+    xb = _bf(x).cpu().reshape(B_, T, cin); wb = _bf(w).cpu().reshape(K, cin, cout)
+    ref = torch.nn.functional.conv1d(xb.transpose(1, 2), wb.permute(2, 1, 0), padding=(K - 1) // 2).transpose(1, 2).reshape(B_ * T, cout)
+    assert rel_err(t2n(y), ref.numpy()) < TOL
+    dy = _r(dev, B_ * T, cout, seed=6)
+    dw = torch.ones(K * cin, cout, device=dev)            # accumulate onto ones through split-K atomics
+    _gemm_call("mstts_gemm_bf16", x, dy, dw, K * cin, cout, B_ * T, cin, cout, cout, ta=1, win=(T, cin, (K - 1) // 2), split_k=3)
+    xpad = torch.nn.functional.pad(xb, (0, 0, (K - 1) // 2, K - 1 - (K - 1) // 2))
+    winm = xpad.unfold(1, K, 1).permute(0, 1, 3, 2).reshape(B_ * T, K * cin)
+    refw = 1.0 + winm.t() @ _bf(dy).cpu()
+    assert rel_err(t2n(dw), refw.numpy()) < TOL
+
+
 @pytest.mark.parametrize("M,N,K", [(32, 4096, 1792), (32, 4096, 2048), (32, 128, 1024), (5, 256, 192), (40, 132, 64)])
 def test_skinny_fwd(dev, M, N, K):
     L = lib.load()
@@ -254,8 +307,6 @@ def test_cell_fwd_fused(dev, B, H, K, mode):
             assert torch.equal(chk, hnp)
 
 
-def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float64)
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 4096, 1792), (32, 4096, 2048), (16, 128, 1024), (5, 256, 192), (32, 64, 64), (40, 128, 512)])

@@ -26,9 +26,24 @@ import torch
 
 B_PER_GPU, T_ENC, L_MEL = 32, 128, 800
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM-side bytes of one attention step (lsa_step_kernel) from the PMC passes committed in
-# profiles/r01c_pmc_fetch_write_per_kernel.csv: FETCH_SIZE 8520.82 KB x 2 (gfx950 correction) + WRITE_SIZE 272 KB
-ATTENTION_STEP_PMC_BYTES = (17041.65 + 272.0) * 1024
+# HBM-side traffic per launch comes from the committed rocprofv3 PMC passes of THIS kernel version (separate --pmc FETCH_SIZE /
+# --pmc WRITE_SIZE runs with --kernel-trace only, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; collected by
+# tools/profile_round.sh, aggregated by tools/pmc_summary.py).  No file / no row -> traffic is reported as null.
+PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_kernel.csv")
+
+
+def pmc_traffic_bytes(kernel_prefix):
+    """2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch of the kernel whose name starts with `kernel_prefix`, or None."""
+    import csv
+    if not os.path.exists(PMC_TRAFFIC_CSV):
+        return None
+    for r in csv.DictReader(open(PMC_TRAFFIC_CSV)):
+        if r["kernel"].startswith(kernel_prefix):
+            try:
+                return (float(r["avg_FETCH_SIZE_KB_x2_gfx950_correction"]) + float(r["avg_WRITE_SIZE_KB"])) * 1024.0
+            except (KeyError, ValueError):
+                return None
+    return None
 
 
 def synthetic_batch(dims, B, Te, L, seed, rank, device):
@@ -65,12 +80,48 @@ def _cpu_baseline_worker(threads, budget_s):
     if t < 0.5 * budget_s:                              # fast host: spend the budget on a longer sample
         L = int(min(L_MEL, L * budget_s / t))
         t = run(L)
-    return {"value": B_PER_GPU * L / t, "unit": "mel-frames/s", "cores": threads, "kind": "port",
-            "sample": "1 train step (fwd+bwd+TF-Adam) of the torch-CPU fp32 oracle at batch %d x (%d tokens, first %d of %d mel frames) on %d of %d host threads, %.1f s"
-                      % (B_PER_GPU, T_ENC, L, L_MEL, threads, os.cpu_count(), t)}
+    out = {"value": B_PER_GPU * L / t, "unit": "mel-frames/s", "cores": threads, "kind": "port",
+           "sample": "1 train step (fwd+bwd+TF-Adam) of the torch-CPU fp32 oracle at batch %d x (%d tokens, first %d of %d mel frames) on %d of %d host threads, %.1f s"
+                     % (B_PER_GPU, T_ENC, L, L_MEL, threads, os.cpu_count(), t),
+           "sample_frames": L, "full_frames": L_MEL, "extrapolation_factor": L_MEL / float(L), "sample_seconds": t}
+    out["config1"] = _cpu_config1(d, params)
+    return out
 
 
-def cpu_baseline(budget_s=15.0, timeout_s=240):
+def _cpu_config1(d, params):
+    """BASELINE configs[0]: one utterance, 64 tokens -> 400 mel frames free-running forward of the oracle (speaker
+    embedding given, Taco1 vocoder included) and a 100-iteration Griffin-Lim on the [400, 1025] spectrogram (host NumPy)."""
+    from oracle import model as OM, train as OT
+    from multi_speaker_tts_amd import Audio
+    import dataclasses
+    dd = dataclasses.replace(d, max_inf=399)
+    p = dict(params)
+    pb = np.array(p["decoder/decoder/linear_projection/dense/bias"], np.float32).copy()
+    pb[-1] = -20.0                                      # never stop early: exactly max_inf + 1 = 400 steps
+    p["decoder/decoder/linear_projection/dense/bias"] = pb
+    g = np.random.default_rng(7)
+    tok = g.integers(2, dd.n_tok, size=(1, 64)).astype(np.int32)
+    tok[:, 0], tok[:, -1] = 0, 1
+    spk = g.normal(0, 1, (1, dd.spk)); spk = (spk / np.sqrt((spk ** 2).sum())).astype(np.float32)
+    batch = {"Token": torch.tensor(tok), "Token_Length": torch.tensor([64], dtype=torch.int32), "Mel": torch.zeros(1, 1, dd.n_mel),
+             "Mel_Length": torch.zeros(1, dtype=torch.int32), "Speaker_Embedding": torch.tensor(spk)}
+    masks = OT.make_masks(dd, 1, 64, 400, False, seed=5)
+    pt = OM.to_torch(p, dtype=torch.float32)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = OM.forward(pt, dd, batch, False, masks, with_vocoder=True)
+    t_fwd = time.perf_counter() - t0
+    frames = int(out["Linear"].shape[1])
+    spec = np.clip(out["Spectrogram"][0].numpy().astype(np.float64), 0.0, 1.0)
+    t0 = time.perf_counter()
+    wav = Audio.Griffin_Lim(spec, rng=np.random.RandomState(0))
+    t_gl = time.perf_counter() - t0
+    return {"workload": "1 utterance, 64 tokens -> %d mel frames, oracle forward (fp32, incl. Taco1 vocoder) + 100-iteration Griffin-Lim on [%d,1025]" % (frames, frames),
+            "forward_seconds": t_fwd, "griffin_lim_seconds": t_gl, "wav_samples": int(wav.shape[0]),
+            "mel_frames_per_s_forward": frames / t_fwd, "mel_frames_per_s_end_to_end": frames / (t_fwd + t_gl)}
+
+
+def cpu_baseline(budget_s=25.0, timeout_s=300):
     """Run the worker in a subprocess with a hard time limit (a huge host can thrash torch's
     intra-op pool on the small per-step GEMMs; threads are capped at 32)."""
     import subprocess
@@ -213,7 +264,8 @@ def main():
         out["roofline"] = {"kernel": ("lsa_step_kernel (energies + in-launch exchange + softmax + context; one decoder step, B=32)" if fused
                                       else "lsa_energy_kernel + lsa_context_kernel (one decoder step, B=32)"),
                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": ATTENTION_STEP_PMC_BYTES if (L == L_MEL and world == 1) else None, "algorithmic_bytes_per_launch": att_bytes,
+                           "traffic": pmc_traffic_bytes("lsa_step_kernel") if (L == L_MEL and world == 1) else None,
+                           "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT), "algorithmic_bytes_per_launch": att_bytes,
                            "avg_launch_us": att_us, "event_bracket_us": raw_us["lsa_step_fwd"], "empty_bracket_us": empty_us["lsa_step_fwd"]}
         w0 = (M + H) * 4 * H * 4
         w1 = 2 * H * 4 * H * 4

@@ -88,14 +88,69 @@ def stop_cut(stop):
     return int(hit[0]) if hit.size else int(stop.shape[0])
 
 
+def read_sphere(path, start_time=None, end_time=None):
+    """NIST SPHERE file (TIMIT's .WAV, TEDLIUM's .sph; the reference reads these through `sphfile`, Pattern_Generate.py:80-83):
+    1024-byte-granular ASCII header `NIST_1A / <header bytes> / key -type value ... / end_head`, then uncompressed PCM.
+    Returns (sample_rate, int16/int32 array [n] or [n, channels]), optionally cut to [start_time, end_time) seconds."""
+    with open(path, "rb") as f:
+        magic = f.readline().strip()
+        if magic != b"NIST_1A":
+            raise ValueError("'{}' is not a NIST SPHERE file".format(path))
+        header_bytes = int(f.readline().strip())
+        f.seek(0)
+        header = f.read(header_bytes).decode("ascii", "replace")
+        fields = {}
+        for line in header.splitlines()[2:]:
+            parts = line.strip().split(None, 2)
+            if not parts or parts[0] == "end_head":
+                break
+            if len(parts) == 3:
+                fields[parts[0]] = int(parts[2]) if parts[1] == "-i" else float(parts[2]) if parts[1] == "-r" else parts[2]
+        coding = str(fields.get("sample_coding", "pcm"))
+        if "shorten" in coding or "ulaw" in coding or "alaw" in coding:
+            raise ValueError("SPHERE sample_coding '{}' is not supported (uncompressed pcm only)".format(coding))
+        width = int(fields.get("sample_n_bytes", 2))
+        order = "<" if str(fields.get("sample_byte_format", "01")).startswith("01") else ">"
+        raw = np.frombuffer(f.read(), dtype=np.dtype("%si%d" % (order, width)))
+    ch = int(fields.get("channel_count", 1))
+    n = int(fields.get("sample_count", raw.shape[0] // ch))
+    data = raw[:n * ch].astype(np.int16 if width == 2 else np.int32)
+    if ch > 1:
+        data = data.reshape(-1, ch)
+    rate = int(fields["sample_rate"])
+    if start_time is not None or end_time is not None:
+        a = int(round((start_time or 0.0) * rate))
+        b = data.shape[0] if end_time is None else int(round(end_time * rate))
+        data = data[a:b]
+    return rate, data
+
+
+def read_audio(path):
+    """(sample_rate, samples) of a .wav (RIFF or - as in TIMIT - SPHERE behind a .WAV name), .sph, or, when the optional `soundfile`
+    module is present, .flac / .m4a file (the reference goes through librosa.core.load, Pattern_Generate.py:36)."""
+    ext = os.path.splitext(path)[1].lower()
+    with open(path, "rb") as f:
+        head = f.read(8)
+    if head.startswith(b"NIST_1A"):
+        return read_sphere(path)
+    if ext == ".wav" or head.startswith(b"RIFF"):
+        from scipy.io import wavfile
+        return wavfile.read(path)
+    try:
+        import soundfile
+    except ImportError:
+        raise ValueError("'{}': decoding {} needs the optional `soundfile` module; convert the corpus to .wav".format(path, ext))
+    data, rate = soundfile.read(path, dtype="float32")
+    return rate, data
+
+
 def load_wav(path, sample_rate=None, top_db=15.0, frame=32, hop=16):
     """Speaker wav -> float mono at hp.Sound.Sample_Rate, silence-trimmed, scaled by 0.99
     (Feeder.py:213-215 plumbing: scipy.io.wavfile + polyphase resampling + a frame_length=32 /
     hop_length=16 RMS trim standing in for librosa.effects.trim)."""
-    from scipy.io import wavfile
     from scipy.signal import resample_poly
     sr = sample_rate or hp.Sound.Sample_Rate
-    rate, data = wavfile.read(path)
+    rate, data = read_audio(path)
     if data.dtype.kind == "i":
         data = data.astype(np.float32) / float(np.iinfo(data.dtype).max)
     elif data.dtype.kind == "u":

@@ -1,8 +1,9 @@
 """The on-disk training-pattern format of the reference (Pattern_Generate.py:14-76,245-274): one pickle (protocol 2) per
 utterance holding {'Token': int32[T_tok], 'Mel': float32[T_mel, 80], 'Text': str, 'Dataset': str}, named
 '<DATASET>.<prefix><wav basename>.PICKLE', plus METADATA.PICKLE with the hyper parameters the set was made with and the
-per-file lengths.  The dataset directory walkers (LJ / VCTK / TIMIT layouts, .sph decoding) are not rebuilt; this module is
-what turns (wav, text) pairs into pattern files the feeder can train from.
+per-file lengths, the corpus walkers of Pattern_Generate.py:115-243 (LJSpeech, VCTK, LibriSpeech, TEDLIUM, TIMIT directory
+layouts -> (audio path, filtered text) pairs) and the reference's command line (`-lj -vctk -ls -tl -timit -all`, :277-285).
+Mel extraction runs on the GPU (mstts_stft_mel); file decoding is scipy / the SPHERE reader in Feeder.read_sphere.
 """
 from __future__ import annotations
 
@@ -90,3 +91,189 @@ def Metadata_Generate(token_Index_Dict=None, pattern_path=None):
         pickle.dump(md, f, protocol=2)
     print("Metadata generate done.")
     return md
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# corpus walkers (Pattern_Generate.py:115-243): each returns (path list, {path: text}) - for TEDLIUM {path: [(start, end, text)]}
+# ---------------------------------------------------------------------------------------------------------------------
+using_Extension = [x.upper() for x in [".wav", ".m4a", ".flac"]]
+
+
+def _slash(*parts):
+    return os.path.join(*parts).replace("\\", "/")
+
+
+def _audio_files(root_dir):
+    """Every file under root_dir (sorted walk) whose extension is one the reference accepts."""
+    for root, dirs, files in os.walk(root_dir):
+        dirs.sort()
+        for name in sorted(files):
+            if os.path.splitext(name)[1].upper() in using_Extension:
+                yield root.replace("\\", "/"), name
+
+
+def LJ_Info_Load(lj_Path):
+    """LJSpeech: metadata.csv rows `id|raw text|normalised text`; wavs/<id>.wav (Pattern_Generate.py:115-140)."""
+    paths, texts = [], {}
+    with open(_slash(lj_Path, "metadata.csv"), "r", encoding="utf-8-sig") as f:
+        rows = [[x.strip() for x in line.split("|")] for line in f.readlines() if line.strip()]
+    for row in rows:
+        wav = _slash(lj_Path, "wavs", "{}.wav".format(row[0]))
+        text = Text_Filtering(row[2]) if len(row) > 2 else None
+        if text is None or not os.path.exists(wav):
+            continue
+        if wav not in texts:
+            paths.append(wav)
+        texts[wav] = text
+    print("LJ info generated.")
+    return paths, texts
+
+
+def VCTK_Info_Load(vctk_Path):
+    """VCTK: wav48/<speaker>/<utt>.wav with its transcript at txt/<speaker>/<utt>.txt (Pattern_Generate.py:142-164)."""
+    wav_root, txt_root = _slash(vctk_Path, "wav48"), _slash(vctk_Path, "txt")
+    paths, texts = [], {}
+    for root, name in _audio_files(wav_root):
+        wav = _slash(root, name)
+        txt = os.path.splitext(wav.replace(wav_root, txt_root, 1))[0] + ".txt"
+        if not os.path.exists(txt):
+            continue
+        with open(txt, "r") as f:
+            text = Text_Filtering(f.read().strip())
+        if text is None:
+            continue
+        paths.append(wav)
+        texts[wav] = text
+    print("VCTK info generated.")
+    return paths, texts
+
+
+def LS_Info_Load(ls_Path):
+    """LibriSpeech: <speaker>/<chapter>/<speaker>-<chapter>.trans.txt lists `<utt id> <TEXT>`; audio beside it (Pattern_Generate.py:166-196)."""
+    paths, texts = [], {}
+    for root, name in _audio_files(ls_Path):
+        speaker, chapter = root.split("/")[-2:]
+        trans = _slash(root, "{}-{}.trans.txt".format(speaker, chapter))
+        if not os.path.exists(trans):
+            continue
+        table = {}
+        with open(trans, "r") as f:
+            for line in f.readlines():
+                parts = line.strip().split(" ")
+                table[parts[0]] = " ".join(parts[1:])
+        key = os.path.splitext(name)[0]
+        text = Text_Filtering(table[key]) if key in table else None
+        if text is None:
+            continue
+        wav = _slash(root, name)
+        paths.append(wav)
+        texts[wav] = text
+    print("LS info generated.")
+    return paths, texts
+
+
+def TL_Info_Load(tl_Path):
+    """TEDLIUM: sph/<talk>.sph with segments in stm/<talk>.stm (`talk ch speaker start end <tags> words...`); segments holding <UNK>
+    are dropped (Pattern_Generate.py:198-222)."""
+    sph_root, stm_root = _slash(tl_Path, "sph"), _slash(tl_Path, "stm")
+    paths, segs = [], {}
+    for root, dirs, files in os.walk(sph_root):
+        dirs.sort()
+        for name in sorted(files):
+            sph = _slash(root, name)
+            paths.append(sph)
+            stm = os.path.splitext(sph.replace(sph_root, stm_root, 1))[0] + ".stm"
+            if not os.path.exists(stm):
+                continue
+            segs[sph] = []
+            with open(stm, "r", encoding="utf-8-sig") as f:
+                for words in [x.strip().upper().split(" ") for x in f.readlines() if x.strip()]:
+                    if "<UNK>" in words:
+                        continue
+                    text = Text_Filtering(" ".join(words[6:]).replace(" '", "'"))
+                    if text is not None:
+                        segs[sph].append((float(words[3]), float(words[4]), text))
+    print("TL info generated.")
+    return paths, segs
+
+
+def TIMIT_Info_Load(timit_Path):
+    """TIMIT: <dialect>/<speaker>/<utt>.WAV (SPHERE) with <utt>.TXT = `start end words...` (Pattern_Generate.py:224-243)."""
+    paths, texts = [], {}
+    for root, name in _audio_files(timit_Path):
+        wav = _slash(root, name)
+        base, ext = os.path.splitext(wav)
+        txt = base + (".TXT" if ext.isupper() else ".txt")
+        if not os.path.exists(txt):
+            continue
+        with open(txt, "r") as f:
+            text = Text_Filtering(" ".join(f.read().strip().split(" ")[2:]).strip())
+        if text is None:
+            continue
+        paths.append(wav)
+        texts[wav] = text
+    print("TIMIT info generated.")
+    return paths, texts
+
+
+def Pattern_File_Generate_from_SPH(path, text_List, token_Index_Dict, dataset, range_Ignore=False, device="cuda"):
+    """Pattern_Generate.py:80-113: one pattern per (start, end, text) segment of a SPHERE recording, named
+    <DATASET>.<basename>.<index>.PICKLE.  Returns the names written."""
+    from scipy.io import wavfile
+    import tempfile
+    names = []
+    for index, (start, end, text) in enumerate(text_List):
+        rate, data = _Feeder.read_sphere(path, start, end)
+        with tempfile.NamedTemporaryFile(suffix=".wav", delete=False) as tf:
+            tmp = tf.name
+        try:
+            wavfile.write(tmp, rate, data)
+            mel = Mel_Generate(tmp, range_Ignore, device=device)
+        finally:
+            os.remove(tmp)
+        if mel is None:
+            continue
+        name = "{}.{}.{}.PICKLE".format(dataset, os.path.splitext(os.path.basename(path))[0], index).upper()
+        Pattern_File_Write(name, text, mel, token_Index_Dict, dataset)
+        names.append(name)
+    return names
+
+
+def main(argv=None, device="cuda"):
+    """The reference's command line (Pattern_Generate.py:277-404): walk the given corpora, write one pattern per utterance into
+    hp.Train.Pattern_Path, then METADATA.PICKLE.  `-all`: keep utterances outside hp.Train.Use_Wav_Length_Range as well."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-lj", "--lj_path", required=False)
+    ap.add_argument("-vctk", "--vctk_path", required=False)
+    ap.add_argument("-ls", "--ls_path", required=False)
+    ap.add_argument("-tl", "--tl_path", required=False)
+    ap.add_argument("-timit", "--timit_path", required=False)
+    ap.add_argument("-all", "--all_save", action="store_true")
+    args = ap.parse_args(argv)
+    token_Index_Dict = _Feeder.load_token_dict()
+    jobs = []                                            # (dataset, path, text or segment list)
+    for dataset, root, loader in (("LJ", args.lj_path, LJ_Info_Load), ("VCTK", args.vctk_path, VCTK_Info_Load), ("LS", args.ls_path, LS_Info_Load),
+                                  ("TL", args.tl_path, TL_Info_Load), ("TIMIT", args.timit_path, TIMIT_Info_Load)):
+        if root is None:
+            continue
+        paths, table = loader(root)
+        jobs += [(dataset, p, table[p]) for p in paths if p in table]
+    if not jobs:
+        raise ValueError("Total pattern count is zero.")
+    os.makedirs(hp.Train.Pattern_Path, exist_ok=True)
+    written = 0
+    for i, (dataset, path, what) in enumerate(jobs):
+        if dataset == "TL":
+            names = Pattern_File_Generate_from_SPH(path, what, token_Index_Dict, dataset, range_Ignore=args.all_save, device=device)
+        else:
+            name = Pattern_File_Generate(path, what, token_Index_Dict, dataset, range_Ignore=args.all_save, device=device)
+            names = [name] if name else []
+        written += len(names)
+        print("[{} {:05d}/{:05d}]".format(dataset, i, len(jobs)), path, "->", ", ".join(names) if names else "Ignored because of length.")
+    Metadata_Generate(token_Index_Dict)
+    return written
+
+
+if __name__ == "__main__":
+    main()

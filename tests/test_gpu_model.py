@@ -1,5 +1,6 @@
 """Parity of the recurrent kernels, the attention step and the whole train step against the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -618,6 +619,45 @@ def test_tacotron2_surface(dev, tmp_path, monkeypatch):
     assert len(res["Cut"]) == 2 and res["Cut"][1]["Attention_History"].shape[0] == len("Who knows?") + 2
     with pytest.raises(KeyError):
         t.Inference(None, ["ünknown"], speaker_Mel_List=mels[:1])
+
+
+def test_pattern_generate_cli_to_training(dev, tmp_path, monkeypatch):
+    """SURVEY 8(f).2 end to end: `Pattern_Generate -lj <corpus>` (corpus walker -> GPU mel extraction -> pattern pickles ->
+    METADATA.PICKLE), then Tacotron2.Train reads those patterns through the feeder's producer thread and takes two steps."""
+    from scipy.io import wavfile
+    from multi_speaker_tts_amd import Hyper_Parameters as hp
+    from multi_speaker_tts_amd import Pattern_Generate as PG
+    from multi_speaker_tts_amd.MSTTS_SV import Tacotron2
+    from multi_speaker_tts_amd.params import Dims
+    lj = tmp_path / "LJ"
+    (lj / "wavs").mkdir(parents=True)
+    rows = []
+    sentences = ["Please call Stella.", "Who knows much believes the less.", "His voice is tested now.", "Things are always at their best."]
+    for i, text in enumerate(sentences):
+        t = np.arange(int((0.7 + 0.1 * i) * 16000)) / 16000.0
+        y = 0.4 * np.sin(2 * np.pi * (180 + 40 * i) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t))
+        wavfile.write(str(lj / "wavs" / ("LJ001-%04d.wav" % i)), 16000, (y * 32767).astype(np.int16))
+        rows.append("LJ001-%04d|%s|%s" % (i, text, text))
+    (lj / "metadata.csv").write_text("\n".join(rows) + "\n", encoding="utf-8")
+    monkeypatch.setattr(hp.Train, "Pattern_Path", str(tmp_path / "patterns"))
+    monkeypatch.setattr(hp.Train, "Main_Train_Dataset_List", ["LJ"])
+    monkeypatch.setattr(hp.Train, "Batch_Size", 2)
+    monkeypatch.setattr(hp, "Checkpoint_Path", str(tmp_path / "ckpt"))
+    assert PG.main(["-lj", str(lj)], device=dev) == 4
+    names = sorted(os.listdir(tmp_path / "patterns"))
+    assert "METADATA.PICKLE" in names and "LJ.LJ001-0002.PICKLE" in names and len(names) == 5
+    import pickle
+    with open(tmp_path / "patterns" / "LJ.LJ001-0000.PICKLE", "rb") as f:
+        pat = pickle.load(f)
+    assert pat["Text"] == "PLEASE CALL STELLA." and pat["Dataset"] == "LJ" and pat["Mel"].shape[1] == 80 and pat["Mel"].shape[0] == 1 + int(0.7 * 16000 * 0.99 / 0.99) // 200
+    assert list(pat["Token"]) == [29, 25, 18, 14, 32, 18, 2, 16, 14, 25, 25, 2, 32, 33, 18, 25, 25, 14, 10]         # SURVEY A.3 without <S>/<E>
+    dims = Dims(emb=32, enc_conv_ch=32, enc_lstm=16, spk=256, prenet=16, dec_lstm=32, post_ch=16, bank_ch=8, proj1_ch=16, birnn=8, n_spec=20, spk_lstm=256)
+    t = Tacotron2(is_Training=True, device=dev, dims=dims, allow_random_init=True)
+    try:
+        t.Train(max_steps=2, run_inference=False)
+    finally:
+        t.feeder.close()
+    assert t.global_step == 2
 
 
 def test_variable_length_training_and_convergence(dev):

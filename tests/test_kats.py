@@ -226,3 +226,73 @@ def test_tf_checkpoint_bundle_format(tmp_path):
     open(prefix + ".index", "wb").write(bytes(idx))
     with pytest.raises(ValueError):
         tfc.read_table(prefix + ".index")
+
+
+def _write_wav(path, seconds=0.6, rate=16000, seed=0):
+    from scipy.io import wavfile
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    t = np.arange(int(seconds * rate)) / rate
+    y = (0.4 * np.sin(2 * np.pi * (200 + 20 * seed) * t) * 32767).astype(np.int16)
+    wavfile.write(path, rate, y)
+    return y
+
+
+def _write_sphere(path, samples, rate=16000):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    head = "NIST_1A\n   1024\nchannel_count -i 1\nsample_count -i %d\nsample_rate -i %d\nsample_n_bytes -i 2\nsample_byte_format -s2 01\nsample_coding -s3 pcm\nend_head\n" % (len(samples), rate)
+    with open(path, "wb") as f:
+        f.write(head.encode("ascii").ljust(1024, b" "))
+        f.write(np.asarray(samples, "<i2").tobytes())
+
+
+def test_corpus_walkers(tmp_path):
+    """The five corpus layouts of Pattern_Generate.py:115-243 on miniature trees: which (audio, text) pairs come out, with
+    Text_Filtering applied, missing audio / transcripts skipped, TEDLIUM <UNK> segments dropped, TIMIT's SPHERE-in-.WAV decoded."""
+    from multi_speaker_tts_amd import Pattern_Generate as PG
+    from multi_speaker_tts_amd import Feeder as F
+    # LJSpeech
+    lj = tmp_path / "LJ"
+    _write_wav(str(lj / "wavs" / "LJ001-0001.wav"))
+    _write_wav(str(lj / "wavs" / "LJ001-0003.wav"))
+    (lj / "metadata.csv").write_text("LJ001-0001|Printing, in 1 sense|Printing, in the only sense\nLJ001-0002|no audio|no audio for this one\n"
+                                     "LJ001-0003|bad ü char|bad ü char\n", encoding="utf-8")
+    paths, texts = PG.LJ_Info_Load(str(lj))
+    assert [os.path.basename(p) for p in paths] == ["LJ001-0001.wav"] and texts[paths[0]] == "PRINTING, IN THE ONLY SENSE"
+    # VCTK
+    vc = tmp_path / "VCTK"
+    _write_wav(str(vc / "wav48" / "p225" / "p225_001.wav"))
+    _write_wav(str(vc / "wav48" / "p225" / "p225_002.wav"))
+    os.makedirs(vc / "txt" / "p225")
+    (vc / "txt" / "p225" / "p225_001.txt").write_text("Please call Stella.\n")
+    paths, texts = PG.VCTK_Info_Load(str(vc))
+    assert [os.path.basename(p) for p in paths] == ["p225_001.wav"] and texts[paths[0]] == "PLEASE CALL STELLA."
+    # LibriSpeech (wav stand-ins for the flac files)
+    ls = tmp_path / "LS"
+    _write_wav(str(ls / "17" / "363" / "17-363-0001.wav"))
+    _write_wav(str(ls / "17" / "363" / "17-363-0002.wav"))
+    (ls / "17" / "363" / "17-363.trans.txt").write_text("17-363-0001 WHO KNOWS MUCH BELIEVES THE LESS\n17-363-0002 A 2ND LINE WITH A DIGIT\n")
+    paths, texts = PG.LS_Info_Load(str(ls))
+    assert [os.path.basename(p) for p in paths] == ["17-363-0001.wav"] and texts[paths[0]] == "WHO KNOWS MUCH BELIEVES THE LESS"
+    # TIMIT: NIST SPHERE behind a .WAV name, transcript `start end words`
+    ti = tmp_path / "TIMIT"
+    y = (np.arange(8000) % 200 - 100).astype(np.int16)
+    _write_sphere(str(ti / "DR1" / "FCJF0" / "SA1.WAV"), y)
+    (ti / "DR1" / "FCJF0" / "SA1.TXT").write_text("0 46797 She had your dark suit in greasy wash water all year.\n")
+    paths, texts = PG.TIMIT_Info_Load(str(ti))
+    assert len(paths) == 1 and texts[paths[0]] == "SHE HAD YOUR DARK SUIT IN GREASY WASH WATER ALL YEAR."
+    rate, data = F.read_audio(paths[0])
+    assert rate == 16000 and np.array_equal(data, y)
+    assert F.load_wav(paths[0]).shape[0] > 0
+    # TEDLIUM: segments from the stm file; <unk> segments dropped; SPHERE cut by time
+    tl = tmp_path / "TL"
+    _write_sphere(str(tl / "sph" / "talk1.sph"), np.arange(32000, dtype=np.int16))
+    os.makedirs(tl / "stm")
+    (tl / "stm" / "talk1.stm").write_text("talk1 1 spk 0.50 1.00 <o,f0,male> hello there it 's me\ntalk1 1 spk 1.00 1.50 <o,f0,male> this has <unk> inside\n")
+    paths, segs = PG.TL_Info_Load(str(tl))
+    assert len(paths) == 1 and segs[paths[0]] == [(0.5, 1.0, "HELLO THERE IT'S ME")]
+    rate, cut = F.read_sphere(paths[0], 0.5, 1.0)
+    assert rate == 16000 and cut.shape[0] == 8000 and int(cut[0]) == 8000
+    # command line: nothing to do is an error, exactly like the reference
+    import pytest
+    with pytest.raises(ValueError):
+        PG.main([], device="cpu")

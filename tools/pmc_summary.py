@@ -18,7 +18,7 @@ with open(out, "w", newline="") as fh:
     w = csv.writer(fh)
     hdr = ["kernel", "grid_size", "calls"]
     for c in counters:
-        hdr.append("avg_%s_KB" % c)
+        hdr.append("avg_%s%s" % (c, "_KB" if c in ("FETCH_SIZE", "WRITE_SIZE") else ""))
         if c == "FETCH_SIZE":
             hdr.append("avg_FETCH_SIZE_KB_x2_gfx950_correction")
     w.writerow(hdr)

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything the round's profiles/ directory is built from, run on the GPU box:  bash tools/profile_round.sh r02
+#   1. bench line (fp32 headline) and the config-3 line
+#   2. rocprofv3 --kernel-trace of the same bench command -> per-kernel stats CSV
+#   3. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE (HBM-side traffic per kernel), then
+#      SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE (matrix-core busy) - all at the FULL config-2 size
+#   4. Audio.melspectrogram timing + its kernel rows
+# Outputs land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $ROOT/bench.py --steps 10 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench_line.err
+python $ROOT/bench.py --steps 10 --warmup 3 --config3 --no-cpu-baseline > $OUT/bench_line_config3.json 2>> $OUT/bench_line.err
+rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/kt.log 2>&1
+python $ROOT/tools/rocpd_stats.py $OUT/kt/kt_results.db $OUT/train_step_kernel_stats.csv
+rocprofv3 --kernel-trace -d $OUT/kt3 -o kt -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --config3 > $OUT/kt3.log 2>&1
+python $ROOT/tools/rocpd_stats.py $OUT/kt3/kt_results.db $OUT/train_step_kernel_stats_config3.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$c.log 2>&1
+done
+python $ROOT/tools/pmc_summary.py $OUT/pmc_fetch_write_per_kernel.csv $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmcm_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmcm_$c.log 2>&1
+done
+python $ROOT/tools/pmc_summary.py $OUT/pmc_mfma_busy_per_kernel.csv $OUT/pmcm_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmcm_SQ_BUSY_CYCLES $OUT/pmcm_GRBM_GUI_ACTIVE
+python $ROOT/tools/stft_bench.py > $OUT/stft_mel_line.json 2> $OUT/stft.err
+rocprofv3 --kernel-trace -d $OUT/kt_stft -o kt -- python $ROOT/tools/stft_bench.py > $OUT/kt_stft.log 2>&1
+python $ROOT/tools/rocpd_stats.py $OUT/kt_stft/kt_results.db $OUT/stft_mel_kernel_stats.csv
+rm -rf $OUT/kt $OUT/kt3 $OUT/kt_stft $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcm_*
+ls -la $OUT

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, con
 // ---------------------------------------------------------------------------------------------
 // forward, single launch: energies -> (in-launch exchange) -> softmax -> cumulative alignment -> context.
 //
-// grid (CS, B): the CS workgroups of a row have adjacent block ids, so a row is dispatched together and the
-// rows ahead of it are complete rows (no workgroup ever waits on one that cannot become resident).  Workgroup
+// 1-D grid of CS x B workgroups, all co-resident (<= 2 per CU at the reference shape), the workgroups of a row placed on one XCD
+// (row_slice_of_block).  Workgroup
 // cs computes the energies of its own slice of <= 16 encoder positions, publishes them as 8-byte {epoch, value}
 // granules with relaxed agent-scope (write-through, sc1) stores, and gathers the rest of the row with relaxed
 // agent-scope loads until every tag equals this launch's epoch - the data is the flag, no fence, no counter
@@ -191,6 +191,20 @@ __global__ __launch_bounds__(256) void lsa_context_kernel(mstts_lsa_const c, con
 // neither hang nor return a stale value.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+// 1-D grid of B x nsl workgroups -> (row b, slice sl).  Block i runs on XCD i % 8 (observed, not guaranteed - used for speed only):
+// with B % 8 == 0 every workgroup of row b gets an id == b (mod 8), so a row's keys / values / gradient slabs are fetched into ONE
+// XCD's L2 (not eight) and its in-launch exchange stays inside that XCD; the XCD holds B/8 rows (1.8 MB at B = 32, T = 128).
+__device__ __forceinline__ void row_slice_of_block(int id, int nsl, int B, int* b, int* sl) {
+    if ((B & 7) == 0) {
+        const int x = id & 7, r = id >> 3;
+        *sl = r % nsl;
+        *b = (r / nsl) * 8 + x;
+    } else {
+        *b = id / nsl;
+        *sl = id - *b * nsl;
+    }
+}
 constexpr int FS_THREADS = 512;
 constexpr int FS_TSL = 16;        // encoder positions per workgroup (energy slice)
 constexpr int FS_DSL = 96;        // memory columns per workgroup (context slice), at most
@@ -220,13 +234,15 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
                                                               float* __restrict__ q_sum, const float* cum,
                                                               float* __restrict__ align, float* __restrict__ cum_next,
                                                               float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld, PackedDst ctx_p,
-                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int skip) {
-    if (SELFTEST && (int)blockIdx.x == skip) return;
+                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int ncs, int skip) {
+    int cs, b;
+    row_slice_of_block(blockIdx.x, ncs, (int)c.B, &b, &cs);
+    if (SELFTEST && cs == skip) return;
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
     __shared__ float s_red[FS_TSL][2];
     __shared__ float s_e[T_MAX];
     __shared__ __attribute__((aligned(16))) float s_part[FS_THREADS * 4];
-    const int cs = blockIdx.x, b = blockIdx.y, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
+    const int T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int t0 = cs * tsl, d0 = cs * dsl;
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = tid & (A_ - 1), tg = tid >> 7;                // energy role: unit k, positions t0 + 4*tg + {0..3}
@@ -581,8 +597,10 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
                                                            const float* __restrict__ G_next, const float* __restrict__ h_next, float* __restrict__ G,
                                                            const float* __restrict__ align, const float* __restrict__ q, const float* __restrict__ cum,
                                                            float* __restrict__ d_e_out, float* __restrict__ dq, float* __restrict__ h,
-                                                           unsigned long long* gran, unsigned epoch, int skip) {
-    if (SELFTEST && (int)blockIdx.x == skip) return;
+                                                           unsigned long long* gran, unsigned epoch, int nsl, int skip) {
+    int sl, b;
+    row_slice_of_block(blockIdx.x, nsl, (int)c.B, &b, &sl);
+    if (SELFTEST && sl == skip) return;
     __shared__ float s_gG[TS];
     __shared__ float s_da[TS];
     __shared__ float s_cum[TS + KS_MAX - 1];
@@ -591,8 +609,7 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     __shared__ float s_de[TS];
     __shared__ float s_dq[A_];
     __shared__ float scratch[16];
-    const int sl = blockIdx.x, b = blockIdx.y, t0 = sl * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
-    const int nsl = gridDim.x;
+    const int t0 = sl * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
     const int len = c.lengths ? c.lengths[b] : T;
@@ -902,11 +919,11 @@ static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t
     int cs, tsl, dsl;
     lsa_step_geometry(c->T, c->M, &cs, &tsl, &dsl);
     if (skip >= 0)
-        hipLaunchKernelGGL(lsa_step_kernel<true>, dim3((unsigned)cs, (unsigned)c->B), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, skip);
+        hipLaunchKernelGGL(lsa_step_kernel<true>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip);
     else
-        hipLaunchKernelGGL(lsa_step_kernel<false>, dim3((unsigned)cs, (unsigned)c->B), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, -1);
+        hipLaunchKernelGGL(lsa_step_kernel<false>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1);
     MSTTS_CHECK_LAUNCH("lsa_step_fwd");
     return MSTTS_OK;
 }
@@ -950,13 +967,13 @@ static int lsa_step_bwd_launch(const mstts_lsa_const* c, const float* d_ctx, int
                   "lsa_step_bwd: d_ctx rows must be 16-byte aligned");
     MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_bwd: granule buffer (8-byte aligned) and a non-zero epoch required");
     if (skip >= 0)
-        hipLaunchKernelGGL(lsa_step_bwd_kernel<true>, dim3(cdiv(c->T, TS), (unsigned)c->B), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
+        hipLaunchKernelGGL(lsa_step_bwd_kernel<true>, dim3((unsigned)(cdiv(c->T, TS) * c->B)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
                            (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
-                           (unsigned long long*)granules, (unsigned)epoch, skip);
+                           (unsigned long long*)granules, (unsigned)epoch, cdiv(c->T, TS), skip);
     else
-        hipLaunchKernelGGL(lsa_step_bwd_kernel<false>, dim3(cdiv(c->T, TS), (unsigned)c->B), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
+        hipLaunchKernelGGL(lsa_step_bwd_kernel<false>, dim3((unsigned)(cdiv(c->T, TS) * c->B)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
                            (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
-                           (unsigned long long*)granules, (unsigned)epoch, -1);
+                           (unsigned long long*)granules, (unsigned)epoch, cdiv(c->T, TS), -1);
     MSTTS_CHECK_LAUNCH("lsa_step_bwd");
     return MSTTS_OK;
 }

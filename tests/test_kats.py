@@ -296,3 +296,67 @@ def test_corpus_walkers(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         PG.main([], device="cpu")
+
+
+def test_tf_bundle_reader_against_hand_assembled_bytes(tmp_path):
+    """A checkpoint assembled BYTE BY BYTE here from the published formats (LevelDB table_format.md: prefix-compressed entries,
+    restart array, 1-byte compression tag + masked CRC-32C trailer, 48-byte footer with magic 0xdb4775248b80fb57;
+    tensor_bundle.proto: BundleHeaderProto / BundleEntryProto field numbers) - nothing of tf_checkpoint's writer is used, and the
+    CRC is an independent bitwise implementation - must read back through read_checkpoint."""
+    import struct
+    from multi_speaker_tts_amd import tf_checkpoint as tfc
+
+    def crc32c_bitwise(data):                              # reflected CRC-32C, polynomial 0x1EDC6F41
+        crc = 0xFFFFFFFF
+        for byte in data:
+            crc ^= byte
+            for _ in range(8):
+                crc = (crc >> 1) ^ (0x82F63B78 & -(crc & 1))
+        return crc ^ 0xFFFFFFFF
+
+    def masked(crc):
+        return (((crc >> 15) | ((crc << 17) & 0xFFFFFFFF)) + 0xA282EAD8) & 0xFFFFFFFF
+
+    def with_trailer(block):                                # block | compression type 0 | masked crc32c(block + type)
+        return block + b"\x00" + struct.pack("<I", masked(crc32c_bitwise(block + b"\x00")))
+
+    assert crc32c_bitwise(b"123456789") == 0xE3069283
+    w = np.array([[1.5, -2.0, 3.25], [0.0, 7.0, -8.5]], "<f4")
+    n = np.array([7, -9], "<i4")
+    data = w.tobytes() + n.tobytes()
+    # BundleEntryProto: 1 dtype (varint), 2 shape (TensorShapeProto: 2 dim {1 size}), 4 offset, 5 size, 6 crc32c (fixed32)
+    entry_w = bytes([0x08, 0x01, 0x12, 0x08, 0x12, 0x02, 0x08, 0x02, 0x12, 0x02, 0x08, 0x03, 0x28, 0x18, 0x35]) + struct.pack("<I", masked(crc32c_bitwise(w.tobytes())))
+    entry_n = bytes([0x08, 0x03, 0x12, 0x04, 0x12, 0x02, 0x08, 0x02, 0x20, 0x18, 0x28, 0x08, 0x35]) + struct.pack("<I", masked(crc32c_bitwise(n.tobytes())))
+    header = bytes([0x08, 0x01, 0x1A, 0x02, 0x08, 0x01])   # num_shards = 1, version { producer = 1 }; endianness LITTLE = default 0
+    # data block: entries (shared, non_shared, value_len, key suffix, value); "a/c" shares the 2-byte prefix "a/" with "a/b"
+    block = (bytes([0, 0, len(header)]) + header +
+             bytes([0, 3, len(entry_w)]) + b"a/b" + entry_w +
+             bytes([2, 1, len(entry_n)]) + b"c" + entry_n +
+             struct.pack("<II", 0, 1))                      # one restart point at offset 0, restart count 1
+    out = with_trailer(block)
+    meta_off = len(out)
+    meta = struct.pack("<II", 0, 1)                         # empty metaindex block
+    out += with_trailer(meta)
+    index_off = len(out)
+    handle = bytes([0x00, len(block)])                      # BlockHandle = varint offset 0, varint size
+    index = bytes([0, 3, len(handle)]) + b"a/d" + handle + struct.pack("<II", 0, 1)     # separator key >= last key of the block
+    out += with_trailer(index)
+    footer = bytes([meta_off, len(meta), index_off, len(index)])
+    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    prefix = str(tmp_path / "HAND-1")
+    with open(prefix + ".index", "wb") as f:
+        f.write(out)
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(data)
+    listing = tfc.list_variables(prefix)
+    assert listing["__num_shards__"] == 1 and listing["a/b"]["shape"] == (2, 3) and listing["a/c"]["offset"] == 24
+    got = tfc.read_checkpoint(prefix)
+    assert set(got) == {"a/b", "a/c"} and np.array_equal(got["a/b"], w) and np.array_equal(got["a/c"], n) and got["a/c"].dtype == np.int32
+    # ... and the module's writer produces a file this same reader and the hand rules agree on: footer magic, trailer CRCs
+    tfc.write_checkpoint(str(tmp_path / "w" / "W-2"), {"a/b": w, "a/c": n})
+    raw = open(str(tmp_path / "w" / "W-2.index"), "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57
+    first = raw.index(b"a/b")                               # the first data block starts at 0; find its extent from the footer's index handle
+    _, p = tfc._get_varint(raw[-48:], 0); _, p = tfc._get_varint(raw[-48:], p)
+    ioff, p = tfc._get_varint(raw[-48:], p); isize, p = tfc._get_varint(raw[-48:], p)
+    assert first > 0 and struct.unpack("<I", raw[ioff + isize + 1:ioff + isize + 5])[0] == masked(crc32c_bitwise(raw[ioff:ioff + isize + 1]))

@@ -159,6 +159,9 @@ typedef struct {
     const float* dq; const float* wq_t; int64_t A;
 } mstts_lstm_point_bwd_desc;
 int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_stream_t s);
+/* two independent cells of the same shape in one launch (sequence form without d_out slabs / d_out2 / dq); MSTTS_ERR_SHAPE when the
+ * geometry is not covered */
+int mstts_lstm_point_bwd_pair(const mstts_lstm_point_bwd_desc* a, const mstts_lstm_point_bwd_desc* b, mstts_stream_t s);
 
 /* ---- fused zoneout-LSTM cell step for [B, K] x [K, 4H] cells (ZoneoutLSTMCell.py:228-271 in ONE launch: the gates
  * product and the cell update; no partial slabs).  Needs mstts_cell_fwd_supported(H, K) == 1 (H % 4 == 0, K % 64 == 0,
@@ -185,12 +188,18 @@ typedef struct {
     float* c_next; float* h_next; int64_t h_next_ld;
     float* acts; float* c_raw;
     mstts_cell_packed_dst out_p, h_next_p;
+    /* tf.nn.dynamic_rnn form (all zero / NULL = plain cell): row b is live while step < lengths[b] (past it: output 0, state carried
+     * through); reverse reads / writes position lengths[b] - 1 - step; xw and out rows are indexed (b, pos) with strides
+     * (xw_ld, xw_st) and (out_ld, out_st) */
+    const int32_t* lengths; int32_t step, reverse; int64_t xw_st, out_st;
 } mstts_cell_fwd_desc;
 int32_t mstts_cell_fwd_supported(int64_t H, int64_t K);
 int mstts_pack_cell_fwd(const float* W, int64_t ldw, float* Wp, int64_t K, int64_t H, mstts_stream_t s);
 int64_t mstts_cell_act_floats(int64_t B, int64_t K);
 int mstts_pack_cell_act(const float* X, int64_t ldx, float* Xp, int64_t B, int64_t K, mstts_stream_t s);
 int mstts_cell_fwd(const mstts_cell_fwd_desc* d, mstts_stream_t s);
+/* two independent cells of identical (B, H, K) in one launch: the two directions of a BiLSTM step (Modules.py:49-73) */
+int mstts_cell_fwd_pair(const mstts_cell_fwd_desc* a, const mstts_cell_fwd_desc* b, mstts_stream_t s);
 
 /* ---- Location_Sensitive_Attention step (Location_Sensitive_Attention.py:43-85 + TF
  * BahdanauAttention masking/softmax + AttentionWrapper context).  Two launches:
@@ -324,6 +333,8 @@ int mstts_skinny_bwd(const float* dG, int64_t ldg, const float* W, int64_t ldw, 
 /* the same product against a derived copy of W in the kernel's lane order (R % 32 == 0; made by mstts_pack_skinny_bwd for the same
  * nsplit, R*N floats; refresh after every optimizer step): every wave load is one contiguous 1 KB instead of 16 rows x 64 B */
 int mstts_pack_skinny_bwd(const float* W, int64_t ldw, float* Wp, int64_t R, int64_t N, int32_t nsplit, mstts_stream_t s);
+int mstts_skinny_bwd_pair(const float* dG, const float* dG2, int64_t ldg, const float* W, const float* W2, int64_t ldw, float* P, float* P2,
+                          int64_t pstride, int64_t M, int64_t R, int64_t N, int32_t nsplit, mstts_stream_t s);   /* two same-shape products, one launch */
 int mstts_skinny_bwd_packed(const float* dG, int64_t ldg, const float* Wp, float* P, int64_t pstride, int64_t M, int64_t R,
                             int64_t N, int32_t nsplit, mstts_stream_t s);
 
@@ -388,8 +399,15 @@ typedef struct {
     float* out; int64_t out_sb, out_st;
     float* c_hist; float* h_hist; float* acts; float* c_raw;
     float* gates_ws;                 /* mstts_lstm_seq_ws_floats(B, H, 0) floats */
+    /* optional fused steps (mstts_cell_fwd: recurrent product + cell update in one launch): wh_p = the [H,4H] recurrent rows packed by
+     * mstts_pack_cell_fwd(wh, wh_ld, wh_p, H, H); h_p = 2 * mstts_cell_act_floats(B, H) floats of scratch.  Used when both are
+     * non-NULL, mstts_cell_fwd_supported(H, H) and there is no residual input; otherwise product + pointwise launches. */
+    const float* wh_p; float* h_p;
 } mstts_lstm_seq_fwd_desc;
 int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s);
+/* the two directions of a bidirectional layer (same B, T, H) advanced together: one launch per step for both when the fused form is
+ * available (else the two sequences run one after the other) */
+int mstts_lstm_seq_fwd_pair(const mstts_lstm_seq_fwd_desc* a, const mstts_lstm_seq_fwd_desc* b, mstts_stream_t s);
 /* floats needed for gates_ws (backward = 0) or for the BPTT ws (backward = 1) */
 int64_t mstts_lstm_seq_ws_floats(int64_t B, int64_t H, int32_t backward);
 
@@ -409,6 +427,8 @@ typedef struct {
     float* ws;
 } mstts_lstm_seq_bwd_desc;
 int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream_t s);
+/* BPTT of the two directions together: two launches per step (pointwise pair + product pair) instead of four */
+int mstts_lstm_seq_bwd_pair(const mstts_lstm_seq_bwd_desc* a, const mstts_lstm_seq_bwd_desc* b, mstts_stream_t s);
 
 /* ---- Decoder_LSTM / Decoder_Dynamic_Decode in teacher-forcing mode (Modules.py:76-119,323-472
  * with the TF AttentionWrapper step).  Everything that does not depend on the

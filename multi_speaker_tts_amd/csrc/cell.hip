@@ -37,11 +37,16 @@ struct CellFwd {
     float* c_next; float* h_next; int h_next_ld;
     float* acts; float* c_raw;                  // [B][4H] gate activations, [B][H] raw cell state (BPTT); may be null
     PackedDst out_p, h_next_p;                  // optional packed copies of m / h' for the cells that consume them next
+    const int32_t* lengths; int step, reverse;  // SEQ: tf.nn.dynamic_rnn semantics (row b live while step < lengths[b]; reversed direction)
+    int xw_st, out_st;                          // SEQ: position strides of xw / out (row b, position pos at b * ld + pos * st)
     int B, H, K;
 };
+struct CellFwdPair { CellFwd d[2]; };           // two independent cells in one launch (blockIdx.z): the two BiLSTM directions
 
-template <int NIT, bool TWO>                     // NIT > 0: exact trip count; TWO: rows 16..31 exist
-__global__ __launch_bounds__(256) void cell_fwd_kernel(CellFwd d) {
+// SEQ = dynamic_rnn semantics (Modules.py:49-73): past its length a row's output is zero and its state is carried through
+// unchanged; the reversed direction reads / writes position len - 1 - step.  PAIR = two cells per launch.
+template <int NIT, bool TWO, bool SEQ, bool PAIR>
+__device__ __forceinline__ void cell_fwd_body(const CellFwd& d) {
     __shared__ float red[4][32][17];
     const int g = blockIdx.x, m0 = blockIdx.y * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -57,14 +62,21 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellFwd d) {
     // (raw values only: anything computed from them here would make the compiler wait for the round trip before the main loads go out)
     float cp = 0.f, hp = 0.f, xwv[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
     uint8_t zcv = 1, zhv = 1;
+    int pos = 0;
+    bool rlive = true;                           // SEQ: this row still inside its sequence
     if (elive) {
+        if (SEQ) {
+            const int len = d.lengths ? d.lengths[eb] : 0x7fffffff;
+            rlive = d.step < len;
+            pos = (d.reverse && rlive) ? len - 1 - d.step : d.step;
+        }
         cp = d.c_prev[eb * H + eu];
         hp = d.h_prev[eb * d.h_prev_ld + eu];
         if (d.zc) zcv = d.zc[eb * H + eu];
         if (d.zh) zhv = d.zh[eb * H + eu];
         if (d.xw) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xwv[q] = d.xw[eb * d.xw_ld + q * H + eu];
+            for (int q = 0; q < 4; ++q) xwv[q] = d.xw[eb * d.xw_ld + (SEQ ? pos * d.xw_st : 0) + q * H + eu];
         }
         if (d.bias) {
 #pragma unroll
@@ -126,18 +138,24 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(CellFwd d) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) g4[q] = ((red[0][er][4 * q + ec] + red[1][er][4 * q + ec]) + (red[2][er][4 * q + ec] + red[3][er][4 * q + ec])) + (xwv[q] + bv[q]);
     const float kc = zcv ? d.keep : 0.f, kh = zhv ? d.keep : 0.f;
-    const float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
-    const float c = sf * cp + si * tj;
-    const float m = so * tanhf(c);
-    const float hn = kh * (m - hp) + hp;
-    d.c_next[eb * H + eu] = kc * (c - cp) + cp;
+    float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
+    float c = sf * cp + si * tj;
+    float m = so * tanhf(c);
+    float hn = kh * (m - hp) + hp, cn = kc * (c - cp) + cp;
+    if (SEQ && !rlive) { m = 0.f; hn = hp; cn = cp; si = 0.f; tj = 0.f; sf = 0.f; so = 0.f; c = cp; }
+    d.c_next[eb * H + eu] = cn;
     d.h_next[eb * d.h_next_ld + eu] = hn;
-    d.out[eb * d.out_ld + eu] = m;
+    d.out[eb * d.out_ld + (SEQ ? pos * d.out_st : 0) + eu] = m;
     if (d.out_p.base) d.out_p.base[cell_act_offset(eb, d.out_p.col0 + eu, d.out_p.nit)] = m;
     if (d.h_next_p.base) d.h_next_p.base[cell_act_offset(eb, d.h_next_p.col0 + eu, d.h_next_p.nit)] = hn;
     if (d.acts) { float* a = d.acts + eb * 4 * H + eu; a[0] = si; a[H] = tj; a[2 * H] = sf; a[3 * H] = so; }
     if (d.c_raw) d.c_raw[eb * H + eu] = c;
 }
+
+template <int NIT, bool TWO, bool SEQ>
+__global__ __launch_bounds__(256) void cell_fwd_kernel(CellFwd d) { cell_fwd_body<NIT, TWO, SEQ, false>(d); }
+template <int NIT, bool TWO, bool SEQ>
+__global__ __launch_bounds__(256) void cell_fwd_pair_kernel(CellFwdPair p) { cell_fwd_body<NIT, TWO, SEQ, true>(p.d[blockIdx.z]); }
 
 // row-major X[B, K] (row stride ldx) -> packed activation block (rows B .. 32*ceil(B/32)-1 are written as zeros)
 __global__ void pack_cell_act_kernel(const float* __restrict__ X, long ldx, float* __restrict__ Xp, int B, int K) {
@@ -202,30 +220,56 @@ int packed_dst_from(const mstts_cell_packed_dst* p, int64_t width, PackedDst* o,
 }
 }  // namespace mstts
 
-extern "C" int mstts_cell_fwd(const mstts_cell_fwd_desc* q, mstts_stream_t s) {
+static int cell_args(const mstts_cell_fwd_desc* q, CellFwd* out) {
     MSTTS_REQUIRE(q && q->Xp && q->Wp && q->c_prev && q->h_prev && q->out && q->c_next && q->h_next, MSTTS_ERR_SHAPE, "cell_fwd: null pointer");
     MSTTS_REQUIRE(mstts_cell_fwd_supported(q->H, q->K), MSTTS_ERR_SHAPE, "cell_fwd: unsupported shape (H %% 4, K %% 64, K <= 2048)");
     MSTTS_REQUIRE(q->B >= 1 && aligned16(q->Xp) && aligned16(q->Wp), MSTTS_ERR_ALIGN, "cell_fwd: 16-byte aligned Xp / Wp required");
-    MSTTS_REQUIRE((q->B + 32) * (q->K > 4 * q->H ? q->K : 4 * q->H) < (1LL << 31), MSTTS_ERR_SHAPE, "cell_fwd: block too large for 32-bit indexing");
-    CellFwd d;
+    const int64_t widest = q->K > 4 * q->H ? q->K : 4 * q->H;
+    const int64_t span = (q->xw_ld > q->out_ld ? q->xw_ld : q->out_ld) > widest ? (q->xw_ld > q->out_ld ? q->xw_ld : q->out_ld) : widest;
+    MSTTS_REQUIRE((q->B + 32) * span < (1LL << 31), MSTTS_ERR_SHAPE, "cell_fwd: block too large for 32-bit indexing");
+    CellFwd& d = *out;
     d.Xp = q->Xp; d.Wp = q->Wp; d.xw = q->xw; d.xw_ld = (int)q->xw_ld; d.bias = q->bias;
     d.c_prev = q->c_prev; d.h_prev = q->h_prev; d.h_prev_ld = (int)(q->h_prev_ld ? q->h_prev_ld : q->H);
     d.zc = q->zc; d.zh = q->zh; d.keep = 1.f - q->zoneout;
     d.out = q->out; d.out_ld = (int)(q->out_ld ? q->out_ld : q->H);
     d.c_next = q->c_next; d.h_next = q->h_next; d.h_next_ld = (int)(q->h_next_ld ? q->h_next_ld : q->H);
     d.acts = q->acts; d.c_raw = q->c_raw; d.B = (int)q->B; d.H = (int)q->H; d.K = (int)q->K;
+    d.lengths = q->lengths; d.step = q->step; d.reverse = q->reverse; d.xw_st = (int)q->xw_st; d.out_st = (int)q->out_st;
     int rc = packed_dst_from(&q->out_p, q->H, &d.out_p, "out_p"); if (rc) return rc;
-    rc = packed_dst_from(&q->h_next_p, q->H, &d.h_next_p, "h_next_p"); if (rc) return rc;
+    return packed_dst_from(&q->h_next_p, q->H, &d.h_next_p, "h_next_p");
+}
+static bool cell_is_seq(const mstts_cell_fwd_desc* q) { return q->lengths || q->reverse || q->xw_st != 0 || q->out_st != 0; }
+
+#define MSTTS_CF_LAUNCH(KERN, N, ARG)                                                                                   \
+    do {                                                                                                                \
+        if (two && seq) hipLaunchKernelGGL((KERN<N, true, true>), grid, dim3(256), 0, (hipStream_t)s, ARG);             \
+        else if (two) hipLaunchKernelGGL((KERN<N, true, false>), grid, dim3(256), 0, (hipStream_t)s, ARG);              \
+        else if (seq) hipLaunchKernelGGL((KERN<N, false, true>), grid, dim3(256), 0, (hipStream_t)s, ARG);              \
+        else hipLaunchKernelGGL((KERN<N, false, false>), grid, dim3(256), 0, (hipStream_t)s, ARG);                      \
+    } while (0)
+
+extern "C" int mstts_cell_fwd(const mstts_cell_fwd_desc* q, mstts_stream_t s) {
+    CellFwd d;
+    int rc = cell_args(q, &d); if (rc) return rc;
     const dim3 grid((unsigned)(q->H / 4), (unsigned)((q->B + 31) / 32));
     const int nit = (int)(q->K / 64);
-    const bool two = q->B > 16;
-#define MSTTS_CF(N)                                                                                         \
-    do {                                                                                                    \
-        if (two) hipLaunchKernelGGL((cell_fwd_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)s, d);     \
-        else hipLaunchKernelGGL((cell_fwd_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)s, d);        \
-    } while (0)
-    if (nit == 32) MSTTS_CF(32); else if (nit == 28) MSTTS_CF(28); else MSTTS_CF(0);
-#undef MSTTS_CF
+    const bool two = q->B > 16, seq = cell_is_seq(q);
+    if (nit == 32) MSTTS_CF_LAUNCH(cell_fwd_kernel, 32, d); else if (nit == 28) MSTTS_CF_LAUNCH(cell_fwd_kernel, 28, d); else MSTTS_CF_LAUNCH(cell_fwd_kernel, 0, d);
     MSTTS_CHECK_LAUNCH("cell_fwd");
     return MSTTS_OK;
 }
+
+/* two independent cells of the same shape (B, H, K) in ONE launch - the forward and backward direction of a BiLSTM step */
+extern "C" int mstts_cell_fwd_pair(const mstts_cell_fwd_desc* a, const mstts_cell_fwd_desc* b, mstts_stream_t s) {
+    CellFwdPair p;
+    int rc = cell_args(a, &p.d[0]); if (rc) return rc;
+    rc = cell_args(b, &p.d[1]); if (rc) return rc;
+    MSTTS_REQUIRE(a->B == b->B && a->H == b->H && a->K == b->K, MSTTS_ERR_SHAPE, "cell_fwd_pair: the two cells must have the same B, H, K");
+    const dim3 grid((unsigned)(a->H / 4), (unsigned)((a->B + 31) / 32), 2);
+    const int nit = (int)(a->K / 64);
+    const bool two = a->B > 16, seq = true;            // (the sequence form also covers plain cells: lengths NULL, strides 0)
+    if (nit == 32) MSTTS_CF_LAUNCH(cell_fwd_pair_kernel, 32, p); else if (nit == 28) MSTTS_CF_LAUNCH(cell_fwd_pair_kernel, 28, p); else MSTTS_CF_LAUNCH(cell_fwd_pair_kernel, 0, p);
+    MSTTS_CHECK_LAUNCH("cell_fwd_pair");
+    return MSTTS_OK;
+}
+#undef MSTTS_CF_LAUNCH

@@ -148,6 +148,10 @@ extern "C" int32_t mstts_decoder_bf16_splits(int64_t H, int64_t M, int64_t A, in
     return ok;
 }
 
+static bool seq_fused_ok(const mstts_lstm_seq_fwd_desc* d);
+static void seq_cell_desc(const mstts_lstm_seq_fwd_desc* d, long t, mstts_cell_fwd_desc* q);
+static int seq_fused_begin(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s);
+
 extern "C" int64_t mstts_lstm_seq_ws_floats(int64_t B, int64_t H, int32_t backward) {
     int p = backward ? mstts_skinny_bwd_splits(H, 4 * H) : mstts_skinny_fwd_splits(4 * H, H);
     if (p < 1) p = 1;
@@ -158,6 +162,15 @@ extern "C" int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream
     MSTTS_REQUIRE(d && d->xw && d->wh && d->c_hist && d->h_hist && d->gates_ws, MSTTS_ERR_SHAPE, "lstm_seq_fwd: null pointer");
     MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_fwd: reverse needs a lengths array (pass T for every row)");
     const long B = d->B, T = d->T, H = d->H, BH = B * H;
+    if (seq_fused_ok(d)) {
+        RC(seq_fused_begin(d, s));
+        for (long t = 0; t < T; ++t) {
+            mstts_cell_fwd_desc q;
+            seq_cell_desc(d, t, &q);
+            RC(mstts_cell_fwd(&q, s));
+        }
+        return MSTTS_OK;
+    }
     const int sp = mstts_skinny_fwd_splits(4 * H, H);
     RC(zero(d->c_hist, BH, s));
     RC(zero(d->h_hist, BH, s));
@@ -177,6 +190,93 @@ extern "C" int mstts_lstm_seq_fwd(const mstts_lstm_seq_fwd_desc* d, mstts_stream
         p.acts_out = d->acts ? d->acts + t * 4 * BH : nullptr;
         p.c_raw = d->c_raw ? d->c_raw + t * BH : nullptr;
         RC(mstts_lstm_point_fwd(&p, s));
+    }
+    return MSTTS_OK;
+}
+
+// ---- fused sequence steps: one mstts_cell_fwd launch per step (recurrent product + cell update), h carried in packed blocks
+static bool seq_fused_ok(const mstts_lstm_seq_fwd_desc* d) {
+    return d->wh_p && d->h_p && !d->residual && mstts_cell_fwd_supported(d->H, d->H);
+}
+static void seq_cell_desc(const mstts_lstm_seq_fwd_desc* d, long t, mstts_cell_fwd_desc* q) {
+    const long B = d->B, T = d->T, H = d->H, BH = B * H, blk = mstts_cell_act_floats(B, H);
+    memset(q, 0, sizeof(*q));
+    q->B = B; q->H = H; q->K = H;
+    q->Xp = d->h_p + (t & 1) * blk; q->Wp = d->wh_p;
+    q->xw = d->xw; q->xw_ld = T * 4 * H; q->xw_st = 4 * H;
+    q->c_prev = d->c_hist + t * BH; q->h_prev = d->h_hist + t * BH; q->h_prev_ld = H;
+    q->zc = d->zc ? d->zc + t * BH : nullptr; q->zh = d->zh ? d->zh + t * BH : nullptr; q->zoneout = d->zoneout;
+    q->out = d->out; q->out_ld = d->out_sb; q->out_st = d->out_st;
+    q->c_next = d->c_hist + (t + 1) * BH; q->h_next = d->h_hist + (t + 1) * BH; q->h_next_ld = H;
+    q->acts = d->acts ? d->acts + t * 4 * BH : nullptr; q->c_raw = d->c_raw ? d->c_raw + t * BH : nullptr;
+    q->h_next_p.base = d->h_p + ((t + 1) & 1) * blk; q->h_next_p.K = H; q->h_next_p.col0 = 0;
+    q->lengths = d->lengths; q->step = (int)t; q->reverse = d->reverse;
+}
+static int seq_fused_begin(const mstts_lstm_seq_fwd_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(d->xw && d->c_hist && d->h_hist && d->out, MSTTS_ERR_SHAPE, "lstm_seq_fwd: null pointer");
+    MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_fwd: reverse needs a lengths array (pass T for every row)");
+    RC(zero(d->c_hist, d->B * d->H, s));
+    RC(zero(d->h_hist, d->B * d->H, s));
+    return zero(d->h_p, 2 * mstts_cell_act_floats(d->B, d->H), s);
+}
+
+extern "C" int mstts_lstm_seq_fwd_pair(const mstts_lstm_seq_fwd_desc* a, const mstts_lstm_seq_fwd_desc* b, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && b, MSTTS_ERR_SHAPE, "lstm_seq_fwd_pair: null descriptor");
+    if (!(a->B == b->B && a->T == b->T && a->H == b->H && seq_fused_ok(a) && seq_fused_ok(b))) {
+        RC(mstts_lstm_seq_fwd(a, s));
+        return mstts_lstm_seq_fwd(b, s);
+    }
+    RC(seq_fused_begin(a, s));
+    RC(seq_fused_begin(b, s));
+    for (long t = 0; t < a->T; ++t) {
+        mstts_cell_fwd_desc qa, qb;
+        seq_cell_desc(a, t, &qa);
+        seq_cell_desc(b, t, &qb);
+        RC(mstts_cell_fwd_pair(&qa, &qb, s));
+    }
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_lstm_seq_bwd_pair(const mstts_lstm_seq_bwd_desc* a, const mstts_lstm_seq_bwd_desc* b, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && b, MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair: null descriptor");
+    const long B = a->B, T = a->T, H = a->H, BH = B * H;
+    const int sp = mstts_skinny_bwd_splits(H, 4 * H);
+    const bool pair_ok = a->B == b->B && a->T == b->T && a->H == b->H && sp > 0 && a->wh_ld == b->wh_ld && a->wh_ld % 4 == 0 && aligned16(a->wh) &&
+                         aligned16(b->wh) && (sp == 1 || sp == 2 || sp == 4 || sp == 8) && a->dgates_step && b->dgates_step;
+    if (!pair_ok) {
+        RC(mstts_lstm_seq_bwd(a, s));
+        return mstts_lstm_seq_bwd(b, s);
+    }
+    const mstts_lstm_seq_bwd_desc* dd[2] = {a, b};
+    for (int k = 0; k < 2; ++k) {
+        MSTTS_REQUIRE(dd[k]->wh && dd[k]->d_out && dd[k]->c_hist && dd[k]->acts && dd[k]->c_raw && dd[k]->ws, MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair: null pointer");
+        MSTTS_REQUIRE(!(dd[k]->reverse && !dd[k]->lengths), MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair: reverse needs a lengths array");
+        RC(zero(dd[k]->ws, 4 * BH, s));
+    }
+    int cur = 0;
+    for (long t = T - 1; t >= 0; --t) {
+        const int nxt = cur ^ 1;
+        mstts_lstm_point_bwd_desc p[2];
+        for (int k = 0; k < 2; ++k) {
+            const mstts_lstm_seq_bwd_desc* d = dd[k];
+            float* dc[2] = {d->ws, d->ws + BH};
+            float* dh[2] = {d->ws + 2 * BH, d->ws + 3 * BH};
+            float* dhg = d->ws + 4 * BH;
+            memset(&p[k], 0, sizeof(p[k]));
+            p[k].B = B; p[k].H = H;
+            p[k].d_out = d->d_out; p[k].dout_sb = d->dout_sb; p[k].dout_st = d->dout_st;
+            p[k].d_c_state = dc[cur]; p[k].d_h_state = dh[cur];
+            p[k].d_h_state2 = (t == T - 1) ? nullptr : dhg; p[k].dhs2_ld = H; p[k].dhs2_parts = sp; p[k].dhs2_pstride = BH;
+            p[k].acts = d->acts + t * 4 * BH; p[k].c_raw = d->c_raw + t * BH; p[k].c_prev = d->c_hist + t * BH;
+            p[k].zc = d->zc ? d->zc + t * BH : nullptr; p[k].zh = d->zh ? d->zh + t * BH : nullptr;
+            p[k].zoneout = d->zoneout; p[k].lengths = d->lengths; p[k].step = (int)t; p[k].reverse = d->reverse;
+            p[k].dgates = d->dgates_step + t * 4 * BH;
+            p[k].dgates_pos = d->dgates_pos; p[k].dgp_sb = T * 4 * H; p[k].dgp_st = 4 * H;
+            p[k].d_c_prev = dc[nxt]; p[k].d_h_prev = dh[nxt];
+        }
+        RC(mstts_lstm_point_bwd_pair(&p[0], &p[1], s));
+        RC(mstts_skinny_bwd_pair(p[0].dgates, p[1].dgates, 4 * H, a->wh, b->wh, a->wh_ld, a->ws + 4 * BH, b->ws + 4 * BH, 0, B, H, 4 * H, sp, s));
+        cur = nxt;
     }
     return MSTTS_OK;
 }

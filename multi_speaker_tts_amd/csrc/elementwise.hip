@@ -500,8 +500,10 @@ constexpr int QA = 128;        // attention units of the fused query-layer gradi
 
 // FUSE_Q: the output gradient also gets dq[b,:] . Wq[u,:] (the attention query layer's data gradient, q = m1 . Wq), computed here from
 // the transposed kernel instead of by a product launch of its own; all QA loads of a thread are issued before the first FMA
+struct PointBwdFastPair { PointBwdFast d[2]; };      // two independent cells per launch (blockIdx.y): the two BiLSTM directions
+
 template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, bool FUSE_Q = false>
-__global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d) {
+__device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) {
     const int i = blockIdx.x * 128 + threadIdx.x;
     const int H = d.H;
     if (i >= d.B * H) return;
@@ -564,6 +566,10 @@ __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d
     d.d_c_prev[i] = dcs * (1.f - mc) + dc * sf;
     d.d_h_prev[i] = dhs * (1.f - mh);
 }
+template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, bool FUSE_Q = false>
+__global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d) { lstm_point_bwd_fast_body<P_OUT, P_OUT2, P_DHS, SEQ, FUSE_Q>(d); }
+template <int P_DHS>
+__global__ __launch_bounds__(128) void lstm_point_bwd_fast_pair_kernel(PointBwdFastPair p) { lstm_point_bwd_fast_body<1, 1, P_DHS, true, false>(p.d[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------------------------
 // losses
@@ -919,6 +925,42 @@ extern "C" int mstts_lstm_point_fwd(const mstts_lstm_point_fwd_desc* d, mstts_st
     MSTTS_CHECK_LAUNCH("lstm_point_fwd");
     return MSTTS_OK;
 }
+static void point_bwd_fill(const mstts_lstm_point_bwd_desc* d, PointBwdFast& f) {
+    const int po = d->dout_parts > 1 ? d->dout_parts : 1, po2 = d->dout2_parts > 1 ? d->dout2_parts : 1, ph = d->dhs2_parts > 1 ? d->dhs2_parts : 1;
+    f.dq = d->dq; f.wq_t = d->wq_t;
+    f.d_out = d->d_out; f.dout_ld = (int)d->dout_sb; f.dout_st = (int)d->dout_st; f.dout_parts = po; f.dout_pstride = (int)d->dout_pstride;
+    f.d_out2 = d->d_out2; f.dout2_parts = po2; f.dout2_pstride = (int)d->dout2_pstride;
+    f.d_c_state = d->d_c_state; f.d_h_state = d->d_h_state;
+    f.dhs2 = d->d_h_state2; f.dhs2_ld = (int)d->dhs2_ld; f.dhs2_parts = ph; f.dhs2_pstride = (long)d->dhs2_pstride;
+    f.acts = d->acts; f.c_raw = d->c_raw; f.c_prev = d->c_prev; f.zc = d->zc; f.zh = d->zh; f.keep = 1.f - d->zoneout;
+    f.dgates = d->dgates; f.d_c_prev = d->d_c_prev; f.d_h_prev = d->d_h_prev;
+    f.lengths = d->lengths; f.step = d->step; f.reverse = d->reverse;
+    f.dgates_pos = d->dgates_pos; f.dgp_ld = (int)d->dgp_sb; f.dgp_st = (int)d->dgp_st;
+    f.B = (int)d->B; f.H = (int)d->H;
+}
+
+/* the pointwise backward of two independent cells of the same shape in ONE launch (the two directions of a BiLSTM step, sequence
+ * form: lengths / reverse / dgates_pos as in mstts_lstm_point_bwd; no d_out slabs, no d_out2; dhs2 slabs 1, 2, 4 or 8).  Returns
+ * MSTTS_ERR_SHAPE when the pair form is not available for the geometry - the caller then issues two single calls. */
+extern "C" int mstts_lstm_point_bwd_pair(const mstts_lstm_point_bwd_desc* a, const mstts_lstm_point_bwd_desc* b, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && b && a->B == b->B && a->H == b->H, MSTTS_ERR_SHAPE, "lstm_point_bwd_pair: the two cells must have the same shape");
+    const int ph = a->dhs2_parts > 1 ? a->dhs2_parts : 1, phb = b->dhs2_parts > 1 ? b->dhs2_parts : 1;
+    const bool ok = ph == phb && (ph == 1 || ph == 2 || ph == 4 || ph == 8) && a->dout_parts <= 1 && b->dout_parts <= 1 && !a->d_out2 && !b->d_out2 &&
+                    !a->dq && !b->dq && a->B * a->H * 4 < (1LL << 30) && (a->B + 1) * a->dout_sb < (1LL << 30) && (a->B + 1) * a->dgp_sb < (1LL << 30) &&
+                    (!a->d_h_state2) == (!b->d_h_state2);
+    MSTTS_REQUIRE(ok, MSTTS_ERR_SHAPE, "lstm_point_bwd_pair: geometry not covered by the pair kernel");
+    PointBwdFastPair p;
+    point_bwd_fill(a, p.d[0]);
+    point_bwd_fill(b, p.d[1]);
+    dim3 grid((unsigned)((a->B * a->H + 127) / 128), 2);
+    if (ph == 8) hipLaunchKernelGGL((lstm_point_bwd_fast_pair_kernel<8>), grid, dim3(128), 0, ST(s), p);
+    else if (ph == 4) hipLaunchKernelGGL((lstm_point_bwd_fast_pair_kernel<4>), grid, dim3(128), 0, ST(s), p);
+    else if (ph == 2) hipLaunchKernelGGL((lstm_point_bwd_fast_pair_kernel<2>), grid, dim3(128), 0, ST(s), p);
+    else hipLaunchKernelGGL((lstm_point_bwd_fast_pair_kernel<1>), grid, dim3(128), 0, ST(s), p);
+    MSTTS_CHECK_LAUNCH("lstm_point_bwd_pair");
+    return MSTTS_OK;
+}
+
 extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_stream_t s) {
     MSTTS_REQUIRE(d && d->d_c_state && d->d_h_state && d->acts && d->c_raw && d->c_prev && d->dgates && d->d_c_prev && d->d_h_prev,
                   MSTTS_ERR_SHAPE, "lstm_point_bwd: null pointer");

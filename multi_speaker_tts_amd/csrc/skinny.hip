@@ -130,11 +130,15 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 // PACKED: W is a derived copy in the lanes' consumption order (mstts_pack_skinny_bwd): wave w / iteration it / lane l of
 // workgroup (strip, slice) finds its float4 at ((((strip * nsplit + slice) * 4 + w) * nit + it) * 64 + l) * 4 - one contiguous
 // 1 KB per wave load.  From the row-major kernel the same load touches 16 rows x 64 B, four cache lines per 4-lane group.
+// pair form (the two directions of a BiLSTM step in one launch): blockIdx.z >= nmb selects a second, independent problem of the same
+// shape whose operands sit pair_dg / pair_w / pair_p floats behind the first one's
 template <int NIT, bool TWO, bool PACKED>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ dG, long ldg, const float* __restrict__ W, long ldw,
-                                                         float* __restrict__ P, long pstride, int M, int R, int N, int NL) {
+                                                         float* __restrict__ P, long pstride, int M, int R, int N, int NL,
+                                                         int nmb, long pair_dg, long pair_w, long pair_p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int r0 = blockIdx.x * 32, ns = blockIdx.y, m0 = blockIdx.z * 32;
+    if ((int)blockIdx.z >= nmb) { dG += pair_dg; W += pair_w; P += pair_p; }
+    const int r0 = blockIdx.x * 32, ns = blockIdx.y, m0 = ((int)blockIdx.z % nmb) * 32;
     const int nb = ns * NL;
     const int lds_ld = NL + 4;                         // row stride == 1 (mod 16) in 16-byte slots: b128 reads spread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -364,7 +368,7 @@ extern "C" int mstts_skinny_bwd(const float* dG, int64_t ldg, const float* W, in
     const int nit = NL / 32;
     const bool two = M > 16;
     MSTTS_SK_DISPATCH(SK_BWD, nit, two, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, W, (long)ldw, P,
-                      (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL);
+                      (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL, (int)grid.z, 0L, 0L, 0L);
     MSTTS_CHECK_LAUNCH("skinny_bwd");
     return MSTTS_OK;
 }
@@ -394,7 +398,30 @@ extern "C" int mstts_skinny_bwd_packed(const float* dG, int64_t ldg, const float
     const int nit = NL / 32;
     const bool two = M > 16;
     MSTTS_SK_DISPATCH(SK_BWD_PACKED, nit, two, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, Wp, 0L, P,
-                      (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL);
+                      (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL, (int)grid.z, 0L, 0L, 0L);
     MSTTS_CHECK_LAUNCH("skinny_bwd_packed");
+    return MSTTS_OK;
+}
+
+/* two products of identical shape in one launch (the two directions of a BiLSTM backward step): problem 2's operands are given by
+ * their own pointers; both must satisfy mstts_skinny_bwd's requirements */
+extern "C" int mstts_skinny_bwd_pair(const float* dG, const float* dG2, int64_t ldg, const float* W, const float* W2, int64_t ldw, float* P, float* P2,
+                                     int64_t pstride, int64_t M, int64_t R, int64_t N, int32_t nsplit, mstts_stream_t s) {
+    MSTTS_REQUIRE(dG && W && P && dG2 && W2 && P2 && M >= 1 && R >= 1, MSTTS_ERR_SHAPE, "skinny_bwd_pair: bad arguments");
+    MSTTS_REQUIRE(nsplit >= 1 && N % (nsplit * 32L) == 0 && N / nsplit <= 1024, MSTTS_ERR_SHAPE,
+                  "skinny_bwd_pair: N must be a multiple of 32*nsplit with slices of at most 1024 columns");
+    MSTTS_REQUIRE(ldw % 4 == 0 && ldg % 4 == 0 && aligned16(dG) && aligned16(W) && aligned16(dG2) && aligned16(W2), MSTTS_ERR_ALIGN, "skinny_bwd_pair: float4 alignment");
+    const int NL = (int)(N / nsplit);
+    size_t lds = sizeof(float) * (size_t)32 * (NL + 4);
+    const size_t red = sizeof(float) * 4 * 32 * 17;
+    if (lds < red) lds = red;
+    const unsigned nmb = (unsigned)((M + 31) / 32);
+    dim3 grid((unsigned)((R + 31) / 32), (unsigned)nsplit, 2 * nmb);
+    set_lds_attr();
+    const int nit = NL / 32;
+    const bool two = M > 16;
+    MSTTS_SK_DISPATCH(SK_BWD, nit, two, grid, dim3(256), lds, (hipStream_t)s, dG, (long)ldg, W, (long)ldw, P,
+                      (long)(pstride > 0 ? pstride : M * R), (int)M, (int)R, (int)N, NL, (int)nmb, (long)(dG2 - dG), (long)(W2 - W), (long)(P2 - P));
+    MSTTS_CHECK_LAUNCH("skinny_bwd_pair");
     return MSTTS_OK;
 }

@@ -93,6 +93,8 @@ class TrainEngine:
         self.w0f_bp = self._f((M + H) * 4 * H) if ok(M + H, self.bwd_splits[0]) else None
         self.w1_bp = self._f(2 * H * 4 * H) if ok(2 * H, self.bwd_splits[1]) else None
         self.wq_bp = self._f(H * d.att) if ok(H, self.bwd_splits[2]) else None
+        He = d.enc_lstm
+        self.enc_whp = {dr: self._f(He * 4 * He) for dr in ("fw", "bw")} if lb.mstts_cell_fwd_supported(He, He) else None
         self.wq_t = self._f(d.att * H) if d.att == 128 else None         # query kernel as [A/4, H, 4] (fused query-layer data gradient)
         self.flip = {}
         self._derived_stale = True
@@ -147,6 +149,11 @@ class TrainEngine:
             call("mstts_pack_skinny_bwd", ptr(k1, o1), 4 * H, ptr(self.w1_bp), 2 * H, 4 * H, self.bwd_splits[1])
         if self.wq_bp is not None:
             call("mstts_pack_skinny_bwd", ptr(wq_, oq_), d.att, ptr(self.wq_bp), H, d.att, self.bwd_splits[2])
+        if self.enc_whp is not None:
+            cin_e, He = d.enc_conv_ch, d.enc_lstm
+            for dr in ("fw", "bw"):
+                ke, oke = self.P(ENC_CELL % dr + "kernel")
+                call("mstts_pack_cell_fwd", ptr(ke, oke + cin_e * 4 * He), 4 * He, ptr(self.enc_whp[dr]), He, He)
         if self.wq_t is not None:
             call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
         if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
@@ -195,7 +202,8 @@ class TrainEngine:
         w.enc_h = {dr: f(Te + 1, B, He) for dr in ("fw", "bw")}
         w.enc_acts = {dr: f(Te, B, 4 * He) for dr in ("fw", "bw")}
         w.enc_craw = {dr: f(Te, B, He) for dr in ("fw", "bw")}
-        w.enc_gates = f(int(lib.load().mstts_lstm_seq_ws_floats(B, He, 0)))
+        w.enc_gates = {dr: f(int(lib.load().mstts_lstm_seq_ws_floats(B, He, 0))) for dr in ("fw", "bw")}
+        w.enc_hp = {dr: f(2 * int(lib.load().mstts_cell_act_floats(B, He))) for dr in ("fw", "bw")} if self.enc_whp is not None else None
         w.values = f(B, Te, M)
         w.keys = f(B, Te, A)
         # decoder
@@ -254,7 +262,7 @@ class TrainEngine:
         w.d_values = f(B, Te, M)
         w.enc_dgs = {dr: f(Te, B, 4 * He) for dr in ("fw", "bw")}
         w.enc_dgp = {dr: f(B, Te, 4 * He) for dr in ("fw", "bw")}
-        w.enc_bwd_ws = f(int(lb.mstts_lstm_seq_ws_floats(B, He, 1)))
+        w.enc_bwd_ws = {dr: f(int(lb.mstts_lstm_seq_ws_floats(B, He, 1))) for dr in ("fw", "bw")}
         w.enc_dy = f(B * Te, max(d.enc_conv_ch, d.emb))
         w.enc_dz = f(B * Te, d.enc_conv_ch)
         w.enc_dx = f(B * Te, max(d.enc_conv_ch, d.emb))
@@ -325,6 +333,7 @@ class TrainEngine:
             self._bn_fwd(pre + "batch_normalization/", w.enc_a[i], w.enc_y[i], w.enc_mean[i], w.enc_rstd[i],
                          mk["enc_conv_drop_%d" % i], 1 - d.conv_drop, B * Te, d.enc_conv_ch, w.bn_ws)
             x, cin = w.enc_y[i], d.enc_conv_ch
+        seqs = []
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(ENC_CELL % dr + "kernel"); b, ob = self.P(ENC_CELL % dr + "bias")
             self._gemm(x, k, w.enc_xw[dr], B * Te, 4 * He, cin, cin, 4 * He, 4 * He, bias=b, b_off=ok, bias_off=ob)
@@ -335,8 +344,11 @@ class TrainEngine:
             q.zc = ptr(mk["enc_zc_" + dr]); q.zh = ptr(mk["enc_zh_" + dr])
             q.out = ptr(w.values, di * He); q.out_sb = Te * M; q.out_st = M
             q.c_hist = ptr(w.enc_c[dr]); q.h_hist = ptr(w.enc_h[dr]); q.acts = ptr(w.enc_acts[dr]); q.c_raw = ptr(w.enc_craw[dr])
-            q.gates_ws = ptr(w.enc_gates)
-            call("mstts_lstm_seq_fwd", C.byref(q))
+            q.gates_ws = ptr(w.enc_gates[dr])
+            if self.enc_whp is not None:                 # fused steps: packed recurrent kernel + packed h blocks
+                q.wh_p, q.h_p = ptr(self.enc_whp[dr]), ptr(w.enc_hp[dr])
+            seqs.append(q)
+        call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
         # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
         call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
         wm, owm = self.P("attention/memory_layer/kernel")
@@ -508,6 +520,7 @@ class TrainEngine:
             on_ready(*self._grad_range("attention/", "decoder/decoder"))
         # ---- encoder BiLSTM backward
         x_in, cin = w.enc_y[-1], d.enc_conv_ch
+        bseqs = []
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(ENC_CELL % dr + "kernel")
             q = lib.LstmSeqBwd()
@@ -517,8 +530,11 @@ class TrainEngine:
             q.zc = ptr(mk["enc_zc_" + dr]); q.zh = ptr(mk["enc_zh_" + dr])
             q.d_out = ptr(w.d_values, di * He); q.dout_sb = Te * M; q.dout_st = M
             q.c_hist = ptr(w.enc_c[dr]); q.acts = ptr(w.enc_acts[dr]); q.c_raw = ptr(w.enc_craw[dr])
-            q.dgates_step = ptr(w.enc_dgs[dr]); q.dgates_pos = ptr(w.enc_dgp[dr]); q.ws = ptr(w.enc_bwd_ws)
-            call("mstts_lstm_seq_bwd", C.byref(q))
+            q.dgates_step = ptr(w.enc_dgs[dr]); q.dgates_pos = ptr(w.enc_dgp[dr]); q.ws = ptr(w.enc_bwd_ws[dr])
+            bseqs.append(q)
+        call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
+        for di, dr in enumerate(("fw", "bw")):
+            k, ok = self.P(ENC_CELL % dr + "kernel")
             gk, ogk = self.G(ENC_CELL % dr + "kernel"); gb, ogb = self.G(ENC_CELL % dr + "bias")
             self._gemm(x_in, w.enc_dgp[dr], gk, cin, 4 * He, B * Te, cin, 4 * He, 4 * He, trans_a=True,
                  split_k=max(2, _split_k(cin, 4 * He, B * Te)), c_off=ogk)

@@ -52,7 +52,8 @@ class CellFwd(C.Structure):
     _fields_ = [("B", i64), ("H", i64), ("K", i64), ("Xp", vp), ("Wp", vp), ("xw", vp), ("xw_ld", i64), ("bias", vp),
                 ("c_prev", vp), ("h_prev", vp), ("h_prev_ld", i64), ("zc", vp), ("zh", vp), ("zoneout", f32),
                 ("out", vp), ("out_ld", i64), ("c_next", vp), ("h_next", vp), ("h_next_ld", i64), ("acts", vp), ("c_raw", vp),
-                ("out_p", CellPackedDst), ("h_next_p", CellPackedDst)]
+                ("out_p", CellPackedDst), ("h_next_p", CellPackedDst),
+                ("lengths", vp), ("step", i32), ("reverse", i32), ("xw_st", i64), ("out_st", i64)]
 
 
 class LsaConst(C.Structure):
@@ -65,7 +66,7 @@ class LstmSeqFwd(C.Structure):
     _fields_ = [("B", i64), ("T", i64), ("H", i64), ("xw", vp), ("wh", vp), ("wh_ld", i64), ("lengths", vp),
                 ("reverse", i32), ("zoneout", f32), ("zc", vp), ("zh", vp), ("residual", vp),
                 ("out", vp), ("out_sb", i64), ("out_st", i64),
-                ("c_hist", vp), ("h_hist", vp), ("acts", vp), ("c_raw", vp), ("gates_ws", vp)]
+                ("c_hist", vp), ("h_hist", vp), ("acts", vp), ("c_raw", vp), ("gates_ws", vp), ("wh_p", vp), ("h_p", vp)]
 
 
 class LstmSeqBwd(C.Structure):
@@ -128,6 +129,7 @@ SIGNATURES = {
     "mstts_cell_fwd_supported": (i32, [i64, i64]),
     "mstts_pack_cell_fwd": (i32, [vp, i64, vp, i64, i64, vp]),
     "mstts_cell_fwd": (i32, [P(CellFwd), vp]),
+    "mstts_cell_fwd_pair": (i32, [P(CellFwd), P(CellFwd), vp]),
     "mstts_cell_act_floats": (i64, [i64, i64]),
     "mstts_pack_cell_act": (i32, [vp, i64, vp, i64, i64, vp]),
     "mstts_lsa_energy_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp]),
@@ -172,6 +174,10 @@ SIGNATURES = {
     "mstts_philox_normal": (i32, [vp, i64, u64, u32, f32, vp]),
     "mstts_lstm_seq_fwd": (i32, [P(LstmSeqFwd), vp]),
     "mstts_lstm_seq_bwd": (i32, [P(LstmSeqBwd), vp]),
+    "mstts_lstm_seq_fwd_pair": (i32, [P(LstmSeqFwd), P(LstmSeqFwd), vp]),
+    "mstts_lstm_seq_bwd_pair": (i32, [P(LstmSeqBwd), P(LstmSeqBwd), vp]),
+    "mstts_lstm_point_bwd_pair": (i32, [P(LstmPointBwd), P(LstmPointBwd), vp]),
+    "mstts_skinny_bwd_pair": (i32, [vp, vp, i64, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_lstm_seq_ws_floats": (i64, [i64, i64, i32]),
     "mstts_decoder_train_fwd": (i32, [P(DecoderTrain), vp]),
     "mstts_decoder_train_bwd": (i32, [P(DecoderTrainBwd), vp]),

@@ -345,3 +345,69 @@ def test_skinny_bf16_bwd(dev, M, R, N):
     ref = _bf(dG) @ _bf(W).t()
     got = P.sum(0).double().cpu()
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("B,T,H", [(5, 9, 64), (32, 12, 256)])
+def test_lstm_seq_fused_and_pair_forms(dev, B, T, H):
+    """dynamic_rnn drivers: the fused-step form (one mstts_cell_fwd launch per step, packed recurrent kernel / packed h) and the
+    two-directions-per-launch pair forms give what the plain product + pointwise launches give - ragged lengths, reversed direction,
+    outputs / histories / BPTT saves forward; dgates / d_h chains backward."""
+    L = lib.load()
+    assert L.mstts_cell_fwd_supported(H, H) == 1
+    g = np.random.default_rng(3)
+    lengths = torch.tensor(np.concatenate([[T], g.integers(1, T + 1, B - 1)]).astype(np.int32), device=dev)
+    BH = B * H
+
+    def make(direction, fused):
+        xw = _r(dev, B, T, 4 * H, seed=10 + direction)
+        wh = _r(dev, H, 4 * H, seed=20 + direction, scale=1.0 / np.sqrt(H))
+        zc = torch.tensor(np.random.default_rng(30 + direction).integers(0, 2, (T, B, H)).astype(np.uint8), device=dev)
+        zh = torch.tensor(np.random.default_rng(40 + direction).integers(0, 2, (T, B, H)).astype(np.uint8), device=dev)
+        t = dict(xw=xw, wh=wh, zc=zc, zh=zh, out=torch.zeros(B, T, 2 * H, device=dev), c=torch.zeros(T + 1, B, H, device=dev),
+                 h=torch.zeros(T + 1, B, H, device=dev), acts=torch.zeros(T, B, 4 * H, device=dev), craw=torch.zeros(T, B, H, device=dev),
+                 ws=torch.zeros(int(L.mstts_lstm_seq_ws_floats(B, H, 0)), device=dev))
+        q = lib.LstmSeqFwd()
+        q.B, q.T, q.H = B, T, H
+        q.xw, q.wh, q.wh_ld, q.lengths, q.reverse, q.zoneout = lib.ptr(xw), lib.ptr(wh), 4 * H, lib.ptr(lengths), direction, 0.1
+        q.zc, q.zh = lib.ptr(zc), lib.ptr(zh)
+        q.out, q.out_sb, q.out_st = lib.ptr(t["out"], direction * H), T * 2 * H, 2 * H
+        q.c_hist, q.h_hist, q.acts, q.c_raw, q.gates_ws = lib.ptr(t["c"]), lib.ptr(t["h"]), lib.ptr(t["acts"]), lib.ptr(t["craw"]), lib.ptr(t["ws"])
+        if fused:
+            t["whp"] = torch.zeros(H * 4 * H, device=dev)
+            lib.call("mstts_pack_cell_fwd", lib.ptr(wh), 4 * H, lib.ptr(t["whp"]), H, H)
+            t["hp"] = torch.zeros(2 * int(L.mstts_cell_act_floats(B, H)), device=dev)
+            q.wh_p, q.h_p = lib.ptr(t["whp"]), lib.ptr(t["hp"])
+        return q, t
+
+    ref = [make(0, False), make(1, False)]
+    for q, _ in ref:
+        lib.call("mstts_lstm_seq_fwd", C.byref(q))
+    one = [make(0, True), make(1, True)]
+    for q, _ in one:
+        lib.call("mstts_lstm_seq_fwd", C.byref(q))                         # fused steps, one direction at a time
+    pair = [make(0, True), make(1, True)]
+    lib.call("mstts_lstm_seq_fwd_pair", C.byref(pair[0][0]), C.byref(pair[1][0]))
+    torch.cuda.synchronize()
+    for (_, a), (_, b), (_, c_) in zip(ref, one, pair):
+        for k in ("out", "c", "h", "acts", "craw"):
+            assert rel_err(t2n(b[k]), t2n(a[k])) < TOL and torch.equal(b[k], c_[k]), k
+    # backward: pair driver vs two single calls on the same saved forward
+    def make_bwd(direction, fwd):
+        t = dict(dout=_r(dev, B, T, 2 * H, seed=50 + direction), dgs=torch.zeros(T, B, 4 * H, device=dev), dgp=torch.zeros(B, T, 4 * H, device=dev),
+                 ws=torch.zeros(int(L.mstts_lstm_seq_ws_floats(B, H, 1)), device=dev))
+        q = lib.LstmSeqBwd()
+        q.B, q.T, q.H = B, T, H
+        q.wh, q.wh_ld, q.lengths, q.reverse, q.zoneout = lib.ptr(fwd["wh"]), 4 * H, lib.ptr(lengths), direction, 0.1
+        q.zc, q.zh = lib.ptr(fwd["zc"]), lib.ptr(fwd["zh"])
+        q.d_out, q.dout_sb, q.dout_st = lib.ptr(t["dout"], direction * H), T * 2 * H, 2 * H
+        q.c_hist, q.acts, q.c_raw = lib.ptr(fwd["c"]), lib.ptr(fwd["acts"]), lib.ptr(fwd["craw"])
+        q.dgates_step, q.dgates_pos, q.ws = lib.ptr(t["dgs"]), lib.ptr(t["dgp"]), lib.ptr(t["ws"])
+        return q, t
+    single = [make_bwd(0, ref[0][1]), make_bwd(1, ref[1][1])]
+    for q, _ in single:
+        lib.call("mstts_lstm_seq_bwd", C.byref(q))
+    both = [make_bwd(0, ref[0][1]), make_bwd(1, ref[1][1])]
+    lib.call("mstts_lstm_seq_bwd_pair", C.byref(both[0][0]), C.byref(both[1][0]))
+    torch.cuda.synchronize()
+    for (_, a), (_, b) in zip(single, both):
+        assert float(a["dgs"].abs().max()) > 0 and torch.equal(a["dgs"], b["dgs"]) and torch.equal(a["dgp"], b["dgp"])

@@ -157,6 +157,7 @@ typedef struct {
      * gradient (q = m . Wq, Location_Sensitive_Attention.py:46) folded into the cell update.  wq_t = a derived copy of Wq laid out
      * [A/4][H][4] (mstts_transpose01(Wq, wq_t, H, A/4, 4)); A must be 128 */
     const float* dq; const float* wq_t; int64_t A;
+    int32_t dq_bf16;        /* multiply bf16-rounded dq / Wq values (config 3 arithmetic) */
 } mstts_lstm_point_bwd_desc;
 int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_stream_t s);
 /* two independent cells of the same shape in one launch (sequence form without d_out slabs / d_out2 / dq); MSTTS_ERR_SHAPE when the
@@ -175,6 +176,7 @@ int mstts_lstm_point_bwd_pair(const mstts_lstm_point_bwd_desc* a, const mstts_ls
 typedef struct {
     float* base;            /* packed activation block of the consuming cell (NULL = none) */
     int64_t K, col0;        /* its reduction width and the first of the H columns this producer owns in it */
+    int32_t bf16;           /* the block is in the bf16 form (values stored rounded to bf16): consumer is a bf16 cell */
 } mstts_cell_packed_dst;
 typedef struct {
     int64_t B, H, K;
@@ -192,11 +194,17 @@ typedef struct {
      * through); reverse reads / writes position lengths[b] - 1 - step; xw and out rows are indexed (b, pos) with strides
      * (xw_ld, xw_st) and (out_ld, out_st) */
     const int32_t* lengths; int32_t step, reverse; int64_t xw_st, out_st;
+    /* bf16 != 0 (BASELINE config 3): Xp / Wp are bf16 copies (mstts_pack_cell_act_bf16 / mstts_pack_cell_fwd_bf16; K % 128 == 0),
+     * the product runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; everything after it is fp32 as above.  No sequence form. */
+    int32_t bf16;
 } mstts_cell_fwd_desc;
 int32_t mstts_cell_fwd_supported(int64_t H, int64_t K);
 int mstts_pack_cell_fwd(const float* W, int64_t ldw, float* Wp, int64_t K, int64_t H, mstts_stream_t s);
 int64_t mstts_cell_act_floats(int64_t B, int64_t K);
 int mstts_pack_cell_act(const float* X, int64_t ldx, float* Xp, int64_t B, int64_t K, mstts_stream_t s);
+int32_t mstts_cell_fwd_bf16_supported(int64_t H, int64_t K);
+int mstts_pack_cell_fwd_bf16(const float* W, int64_t ldw, void* Wp16, int64_t K, int64_t H, mstts_stream_t s);    /* K*4H bf16 */
+int mstts_pack_cell_act_bf16(const float* X, int64_t ldx, void* Xp16, int64_t B, int64_t K, mstts_stream_t s);    /* mstts_cell_act_floats(B,K) bf16 */
 int mstts_cell_fwd(const mstts_cell_fwd_desc* d, mstts_stream_t s);
 /* two independent cells of identical (B, H, K) in one launch: the two directions of a BiLSTM step (Modules.py:49-73) */
 int mstts_cell_fwd_pair(const mstts_cell_fwd_desc* a, const mstts_cell_fwd_desc* b, mstts_stream_t s);
@@ -464,6 +472,7 @@ typedef struct {
     /* optional fused cell steps (fp32): w0f / w1 packed by mstts_pack_cell_fwd; both non-NULL and
      * mstts_cell_fwd_supported(H, M+H) && (H, 2H) -> each cell is one mstts_cell_fwd launch instead of product + pointwise */
     const float* w0p; const float* w1p;
+    const void* w0p16; const void* w1p16;   /* ... or, in the bf16 mode, their mstts_pack_cell_fwd_bf16 copies (fused bf16 cell steps) */
     /* optional packed kernels of the BPTT data-gradient products (mstts_pack_skinny_bwd with the split counts of
      * mstts_skinny_bwd_splits(M+H, 4H) / (2H, 4H) / (H, A)); NULL -> the row-major kernels are streamed */
     const float* w0f_bp; const float* w1_bp; const float* wq_bp;

@@ -45,7 +45,17 @@ __device__ __forceinline__ int cell_act_offset(int r, int k, int nit) {
     const int blk = r >> 5, rr = r & 31, w = k / (16 * nit), kk = k - w * 16 * nit;
     return blk * (2048 * nit) + (((w * nit + (kk >> 4)) * 2 + (rr >> 4)) << 8) + ((((kk & 15) >> 2) * 16 + (rr & 15)) << 2) + (kk & 3);
 }
-struct PackedDst { float* base; int nit, col0; };      // packed block of a consumer cell; the producer owns columns col0 ...
+// bf16 form (config 3): 16-byte lane fragments of v_mfma_f32_16x16x32_bf16 - wave k / (K/4), 32-k step (k % (K/4)) / 32, lane
+// ((k % 32) / 8) * 16 + r % 16 holds 8 consecutive k; nit = K / 128.  Offsets in bf16 elements.
+__device__ __forceinline__ int cell_act_offset_bf16(int r, int k, int nit) {
+    const int blk = r >> 5, rr = r & 31, w = k / (32 * nit), kk = k - w * 32 * nit;
+    return blk * (4096 * nit) + (((w * nit + (kk >> 5)) * 2 + (rr >> 4)) << 9) + ((((kk & 31) >> 3) * 16 + (rr & 15)) << 3) + (kk & 7);
+}
+struct PackedDst { float* base; int nit, col0, bf; };  // packed block of a consumer cell (bf: bf16 form); the producer owns columns col0 ...
+__device__ __forceinline__ void packed_store(const PackedDst& p, int r, int c, float v) {
+    if (p.bf) reinterpret_cast<__bf16*>(p.base)[cell_act_offset_bf16(r, p.col0 + c, p.nit)] = (__bf16)v;
+    else p.base[cell_act_offset(r, p.col0 + c, p.nit)] = v;
+}
 // validates a mstts_cell_packed_dst whose producer writes `width` columns
 int packed_dst_from(const mstts_cell_packed_dst* p, int64_t width, PackedDst* o, const char* what);
 

@@ -74,9 +74,10 @@ static int zero(float* p, long n, mstts_stream_t s) {
 static int cell_step(const float* Xp, const float* Wp, long K, const float* xw, long xw_ld, const float* bias,
                      const float* c_prev, const float* h_prev, long h_prev_ld, const uint8_t* zc, const uint8_t* zh, float zoneout,
                      float* out, long out_ld, float* c_next, float* h_next, long h_next_ld, float* acts, float* c_raw, long B, long H,
-                     float* out_p, long out_p_K, long out_p_col0, float* hn_p, long hn_p_K, long hn_p_col0, mstts_stream_t s) {
+                     float* out_p, long out_p_K, long out_p_col0, float* hn_p, long hn_p_K, long hn_p_col0, mstts_stream_t s, int bf16 = 0) {
     mstts_cell_fwd_desc q;
     memset(&q, 0, sizeof(q));
+    q.bf16 = bf16; q.out_p.bf16 = bf16; q.h_next_p.bf16 = bf16;
     q.B = B; q.H = H; q.K = K; q.Xp = Xp; q.Wp = Wp; q.xw = xw; q.xw_ld = xw_ld; q.bias = bias;
     q.c_prev = c_prev; q.h_prev = h_prev; q.h_prev_ld = h_prev_ld; q.zc = zc; q.zh = zh; q.zoneout = zoneout;
     q.out = out; q.out_ld = out_ld; q.c_next = c_next; q.h_next = h_next; q.h_next_ld = h_next_ld; q.acts = acts; q.c_raw = c_raw;
@@ -345,8 +346,11 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     const int chains = 1;
     const bool fused_lsa = true;         // (the time-out counter sits after the last row's granules)
     // fused cell steps need the single-launch attention step (it writes the context into cell 0's packed block)
-    const bool fused_cells = !bf && fused_lsa && d->w0p && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1) &&
-                             M % 4 == 0;
+    const bool fused_cells = fused_lsa && d->act_p && M % 4 == 0 &&
+                             (bf ? (d->w0p16 && d->w1p16 && mstts_cell_fwd_bf16_supported(H, W0) && mstts_cell_fwd_bf16_supported(H, W1))
+                                 : (d->w0p && d->w1p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1)));
+    const float* w0pk = bf ? (const float*)d->w0p16 : d->w0p;
+    const float* w1pk = bf ? (const float*)d->w1p16 : d->w1p;
     const long p0n = mstts_cell_act_floats(B, W0), p1n = mstts_cell_act_floats(B, W1);
     if (fused_cells) RC(zero(d->act_p, 2 * (p0n + p1n), s));          // step-0 state: zero context / hidden states
     RC(zero(d->in0, B * W0, s));
@@ -368,7 +372,7 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             lc.B = Bc; lc.keys += b0 * T * A; lc.values += b0 * T * M;
             if (lc.lengths) lc.lengths += b0;
             mstts_lstm_point_fwd_desc p;
-            mstts_cell_packed_dst ctx_p = {nullptr, 0, 0};
+            mstts_cell_packed_dst ctx_p = {nullptr, 0, 0, 0};
             int parts = 1;
             // ---- cell 0: gates = [ctx | h0] . w0f + xw0[st]
             const float* in0 = d->in0 + (st * B + b0) * W0;
@@ -383,15 +387,15 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
                 // h1' -> P1[~st&1]; the attention step writes ctx -> P0[~st&1].
                 float* P0c = d->act_p + (st & 1) * p0n; float* P0n = d->act_p + ((st + 1) & 1) * p0n;
                 float* P1c = d->act_p + 2 * p0n + (st & 1) * p1n; float* P1n = d->act_p + 2 * p0n + ((st + 1) & 1) * p1n;
-                PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, cell_step(P0c, d->w0p, W0, d->xw0 + (st * B + b0) * 4 * H, 4 * H, nullptr,
+                PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, cell_step(P0c, w0pk, W0, d->xw0 + (st * B + b0) * 4 * H, 4 * H, nullptr,
                        d->c0 + (st * B + b0) * H, in0 + M, W0, d->zc0 ? d->zc0 + (st * B + b0) * H : nullptr, d->zh0 ? d->zh0 + (st * B + b0) * H : nullptr,
                        d->zoneout, in1w, W1, d->c0 + ((st + 1) * B + b0) * H, in0n + M, W0, d->acts0 + (st * B + b0) * 4 * H,
-                       d->craw0 + (st * B + b0) * H, Bc, H, P1c, W1, 0, P0n, W0, M, q_s));
-                PROBED(MSTTS_PROBE_CELL1_GEMM, q_s, cell_step(P1c, d->w1p, W1, nullptr, 0, d->b1,
+                       d->craw0 + (st * B + b0) * H, Bc, H, P1c, W1, 0, P0n, W0, M, q_s, bf ? 1 : 0));
+                PROBED(MSTTS_PROBE_CELL1_GEMM, q_s, cell_step(P1c, w1pk, W1, nullptr, 0, d->b1,
                        d->c1 + (st * B + b0) * H, in1 + H, W1, d->zc1 ? d->zc1 + (st * B + b0) * H : nullptr, d->zh1 ? d->zh1 + (st * B + b0) * H : nullptr,
                        d->zoneout, pj, WP, d->c1 + ((st + 1) * B + b0) * H, in1n + H, W1, d->acts1 + (st * B + b0) * 4 * H,
-                       d->craw1 + (st * B + b0) * H, Bc, H, nullptr, 0, 0, P1n, W1, H, q_s));
-                ctx_p.base = P0n; ctx_p.K = W0; ctx_p.col0 = 0;
+                       d->craw1 + (st * B + b0) * H, Bc, H, nullptr, 0, 0, P1n, W1, H, q_s, bf ? 1 : 0));
+                ctx_p.base = P0n; ctx_p.K = W0; ctx_p.col0 = 0; ctx_p.bf16 = bf ? 1 : 0;
             } else {
             if (bf) { parts = bfs[0]; PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, mstts_skinny_fwd_bf16(in0, W0, d->bf_w0f_f, gates, 0, Bc, 4 * H, W0, bfs[0], q_s)); }
             else PROBED(MSTTS_PROBE_CELL0_GEMM, q_s, xw_fwd(in0, W0, d->w0f, 4 * H, gates, Bc, 4 * H, W0, sp0, &parts, q_s));
@@ -465,7 +469,9 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     // single-launch attention backward: its granules (B*ceil(T/8)+1 8-byte words) live in the d_align block (B*T floats)
     const bool fused_lsa = true && mstts_lsa_step_bwd_ws_bytes(B, T) <= B * T * 4;
     // query-layer data gradient inside cell 1's pointwise kernel: fp32 mode, A == 128, slab counts the lean kernel is built for
-    const bool fuse_q = !bf && d->wq_t && A == 128 && (np1 == 8 || np1 == 4 || np1 == 2 || np1 == 1) && B * H * 4 < (1LL << 30);
+    // (bf16 mode: the kernel rounds both operands to bf16 first - the same products as the bf16 product launch it replaces)
+    const int np1_eff = bf ? bfs[4] : np1;
+    const bool fuse_q = d->wq_t && A == 128 && H % 128 == 0 && (np1_eff == 8 || np1_eff == 4 || np1_eff == 2 || np1_eff == 1) && B * H * 4 < (1LL << 30);
     RC(zero(bd->ws, ws_per_row * B, s));
     mstts_stream_t cs[MAX_CHAINS] = {s};
     struct ChainWs { float *dc0[2], *dh0[2], *dc1[2], *dh1[2], *G[2], *df[2], *d_align, *tmp1, *dqm; int parts0, parts1, partsq; } cw[MAX_CHAINS];
@@ -517,7 +523,7 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
             memset(&p, 0, sizeof(p));
             p.B = Bc; p.H = H;
             p.d_out = dpj; p.dout_sb = WP; p.dout_st = 0;
-            if (fuse_q) { p.dq = bd->dq_hist + (st * B + b0) * A; p.wq_t = d->wq_t; p.A = A; }
+            if (fuse_q) { p.dq = bd->dq_hist + (st * B + b0) * A; p.wq_t = d->wq_t; p.A = A; p.dq_bf16 = bf ? 1 : 0; }
             else { p.d_out2 = k.dqm; p.dout2_parts = k.partsq; p.dout2_pstride = BcH; }
             p.d_c_state = k.dc1[cur]; p.d_h_state = k.dh1[cur];
             p.d_h_state2 = last ? nullptr : k.tmp1 + H; p.dhs2_ld = W1; p.dhs2_parts = k.parts1; p.dhs2_pstride = Bc * W1;

@@ -502,12 +502,14 @@ constexpr int QA = 128;        // attention units of the fused query-layer gradi
 // the transposed kernel instead of by a product launch of its own; all QA loads of a thread are issued before the first FMA
 struct PointBwdFastPair { PointBwdFast d[2]; };      // two independent cells per launch (blockIdx.y): the two BiLSTM directions
 
-template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, bool FUSE_Q = false>
+template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, int FUSE_Q = 0>        // FUSE_Q: 0 off, 1 fp32, 2 bf16-rounded operands
 __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) {
     const int i = blockIdx.x * 128 + threadIdx.x;
     const int H = d.H;
     if (i >= d.B * H) return;
-    const int b = i / H, u = i - b * H;
+    // fused form: H % 128 == 0 (checked by the host), so the 128 threads of a block share one row - a block-uniform index lets the dq
+    // row come through scalar loads
+    const int b = FUSE_Q ? (int)(blockIdx.x * 128) / H : i / H, u = i - b * H;
     int pos = 0;
     bool live = true;
     if (SEQ) {
@@ -549,7 +551,12 @@ __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) 
     if (FUSE_Q) {
         float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
-        for (int a = 0; a < QA / 4; ++a) { q0 += dqv[a].x * wqv[a].x; q1 += dqv[a].y * wqv[a].y; q2 += dqv[a].z * wqv[a].z; q3 += dqv[a].w * wqv[a].w; }
+        for (int a = 0; a < QA / 4; ++a) {
+            if (FUSE_Q == 2) {
+                auto r = [](float x) { return (float)(__bf16)x; };
+                q0 += r(dqv[a].x) * r(wqv[a].x); q1 += r(dqv[a].y) * r(wqv[a].y); q2 += r(dqv[a].z) * r(wqv[a].z); q3 += r(dqv[a].w) * r(wqv[a].w);
+            } else { q0 += dqv[a].x * wqv[a].x; q1 += dqv[a].y * wqv[a].y; q2 += dqv[a].z * wqv[a].z; q3 += dqv[a].w * wqv[a].w; }
+        }
         dm += (q0 + q1) + (q2 + q3);
     }
     const float mh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
@@ -566,10 +573,10 @@ __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) 
     d.d_c_prev[i] = dcs * (1.f - mc) + dc * sf;
     d.d_h_prev[i] = dhs * (1.f - mh);
 }
-template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, bool FUSE_Q = false>
+template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, int FUSE_Q = 0>
 __global__ __launch_bounds__(128) void lstm_point_bwd_fast_kernel(PointBwdFast d) { lstm_point_bwd_fast_body<P_OUT, P_OUT2, P_DHS, SEQ, FUSE_Q>(d); }
 template <int P_DHS>
-__global__ __launch_bounds__(128) void lstm_point_bwd_fast_pair_kernel(PointBwdFastPair p) { lstm_point_bwd_fast_body<1, 1, P_DHS, true, false>(p.d[blockIdx.y]); }
+__global__ __launch_bounds__(128) void lstm_point_bwd_fast_pair_kernel(PointBwdFastPair p) { lstm_point_bwd_fast_body<1, 1, P_DHS, true, 0>(p.d[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------------------------
 // losses
@@ -973,6 +980,7 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
                            (d->B + 1) * d->dgp_sb < (1LL << 30);
         const bool fuse_q = d->dq && d->wq_t;
         MSTTS_REQUIRE(!fuse_q || (aligned16(d->dq) && aligned16(d->wq_t)), MSTTS_ERR_ALIGN, "lstm_point_bwd: dq / wq_t must be 16-byte aligned");
+        MSTTS_REQUIRE(!fuse_q || d->H % 128 == 0, MSTTS_ERR_SHAPE, "lstm_point_bwd: the fused query-layer gradient needs H %% 128 == 0");
         MSTTS_REQUIRE(!fuse_q || (d->A == QA && !d->d_out2 && !d->lengths && !d->reverse && !d->dgates_pos && d->dout_st == 0), MSTTS_ERR_SHAPE,
                       "lstm_point_bwd: the fused query-layer gradient needs A == %d, no d_out2 and the plain (non-sequence) form", QA);
         int shape = -1;      // (P_OUT, P_OUT2, P_DHS)
@@ -1008,10 +1016,13 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
                 case 3: MSTTS_PB(1, 1, 8); break;
                 case 4: MSTTS_PB(8, 1, 8); break;
                 case 5: MSTTS_PB(8, 1, 1); break;
-                case 10: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 8, false, true>), grid, dim3(128), 0, ST(s), f); break;
-                case 11: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 1, false, true>), grid, dim3(128), 0, ST(s), f); break;
-                case 12: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 4, false, true>), grid, dim3(128), 0, ST(s), f); break;
-                case 13: hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, 2, false, true>), grid, dim3(128), 0, ST(s), f); break;
+#define MSTTS_PBQ(PH) do { if (d->dq_bf16) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, PH, false, 2>), grid, dim3(128), 0, ST(s), f);     \
+                           else hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<1, 1, PH, false, 1>), grid, dim3(128), 0, ST(s), f); } while (0)
+                case 10: MSTTS_PBQ(8); break;
+                case 11: MSTTS_PBQ(1); break;
+                case 12: MSTTS_PBQ(4); break;
+                case 13: MSTTS_PBQ(2); break;
+#undef MSTTS_PBQ
                 default: MSTTS_PB(1, 1, 2); break;
             }
 #undef MSTTS_PB

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         for (int gq = 0; gq < ng; ++gq) r += s_part[gq * dsl + tid];
         ctx[(long)b * ctx_ld + d0 + tid] = r;
         if (ctx2) ctx2[(long)b * ctx2_ld + d0 + tid] = r;
-        if (ctx_p.base) ctx_p.base[cell_act_offset(b, ctx_p.col0 + d0 + tid, ctx_p.nit)] = r;
+        if (ctx_p.base) packed_store(ctx_p, b, d0 + tid, r);
     }
 }
 

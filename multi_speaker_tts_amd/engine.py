@@ -87,6 +87,7 @@ class TrainEngine:
         self.fused_cells = bool(lb.mstts_cell_fwd_supported(H, M + H)) and bool(lb.mstts_cell_fwd_supported(H, 2 * H))
         self.w0p = self._f((M + H) * 4 * H) if self.fused_cells else None
         self.w1p = self._f(2 * H * 4 * H) if self.fused_cells else None
+        self.w0p16 = self.w1p16 = None          # bf16 copies for the fused cell steps of the config-3 mode (allocated below)
         # packed kernels of the BPTT data-gradient products (csrc/skinny.hip, PACKED form)
         self.bwd_splits = (int(lb.mstts_skinny_bwd_splits(M + H, 4 * H)), int(lb.mstts_skinny_bwd_splits(2 * H, 4 * H)), int(lb.mstts_skinny_bwd_splits(H, d.att)))
         ok = lambda R, sp: sp > 0 and R % 32 == 0
@@ -105,6 +106,9 @@ class TrainEngine:
         if self.recurrent_dtype not in ("f32", "bf16"):
             raise ValueError("recurrent_dtype must be 'f32' or 'bf16'")
         self.bf = None
+        if self.recurrent_dtype == "bf16" and lb.mstts_cell_fwd_bf16_supported(H, M + H) and lb.mstts_cell_fwd_bf16_supported(H, 2 * H):
+            self.w0p16 = torch.zeros((M + H) * 4 * H, dtype=torch.int16, device=self.device)
+            self.w1p16 = torch.zeros(2 * H * 4 * H, dtype=torch.int16, device=self.device)
         if self.recurrent_dtype == "bf16":
             sp = (C.c_int32 * 6)()
             if not lib.load().mstts_decoder_bf16_splits(H, M, d.att, sp):
@@ -138,10 +142,14 @@ class TrainEngine:
         H, M, Pn = d.dec_lstm, d.mem, d.prenet
         k0, o0 = self.P(CELL % 0 + "kernel")
         call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(self.w0f), 2 * M + H, 4 * H, 0, M)
-        if self.fused_cells:
+        if self.fused_cells and self.bf is None:
             k1, o1 = self.P(CELL % 1 + "kernel")
             call("mstts_pack_cell_fwd", ptr(self.w0f), 4 * H, ptr(self.w0p), M + H, H)
             call("mstts_pack_cell_fwd", ptr(k1, o1), 4 * H, ptr(self.w1p), 2 * H, H)
+        if self.w0p16 is not None:
+            k1, o1 = self.P(CELL % 1 + "kernel")
+            call("mstts_pack_cell_fwd_bf16", ptr(self.w0f), 4 * H, ptr(self.w0p16), M + H, H)
+            call("mstts_pack_cell_fwd_bf16", ptr(k1, o1), 4 * H, ptr(self.w1p16), 2 * H, H)
         k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
         if self.w0f_bp is not None:
             call("mstts_pack_skinny_bwd", ptr(self.w0f), 4 * H, ptr(self.w0f_bp), M + H, 4 * H, self.bwd_splits[0])
@@ -384,6 +392,8 @@ class TrainEngine:
         dec.w0f_bp, dec.w1_bp, dec.wq_bp, dec.wq_t = ptr(self.w0f_bp), ptr(self.w1_bp), ptr(self.wq_bp), ptr(self.wq_t)
         if self.fused_cells and self.bf is None:
             dec.w0p, dec.w1p, dec.act_p = ptr(self.w0p), ptr(self.w1p), ptr(w.act_p)
+        if self.w0p16 is not None and self.bf is not None and w.act_p is not None:
+            dec.w0p16, dec.w1p16, dec.act_p = ptr(self.w0p16), ptr(self.w1p16), ptr(w.act_p)
         dec.chains = 1
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))

@@ -41,11 +41,11 @@ class LstmPointBwd(C.Structure):
                 ("d_c_state", vp), ("d_h_state", vp), ("d_h_state2", vp), ("dhs2_ld", i64), ("dhs2_parts", i32), ("dhs2_pstride", i64),
                 ("acts", vp), ("c_raw", vp), ("c_prev", vp), ("zc", vp), ("zh", vp), ("zoneout", f32),
                 ("lengths", vp), ("step", i32), ("reverse", i32), ("dgates", vp), ("dgates_pos", vp),
-                ("dgp_sb", i64), ("dgp_st", i64), ("d_c_prev", vp), ("d_h_prev", vp), ("dq", vp), ("wq_t", vp), ("A", i64)]
+                ("dgp_sb", i64), ("dgp_st", i64), ("d_c_prev", vp), ("d_h_prev", vp), ("dq", vp), ("wq_t", vp), ("A", i64), ("dq_bf16", i32)]
 
 
 class CellPackedDst(C.Structure):
-    _fields_ = [("base", vp), ("K", i64), ("col0", i64)]
+    _fields_ = [("base", vp), ("K", i64), ("col0", i64), ("bf16", i32)]
 
 
 class CellFwd(C.Structure):
@@ -53,7 +53,7 @@ class CellFwd(C.Structure):
                 ("c_prev", vp), ("h_prev", vp), ("h_prev_ld", i64), ("zc", vp), ("zh", vp), ("zoneout", f32),
                 ("out", vp), ("out_ld", i64), ("c_next", vp), ("h_next", vp), ("h_next_ld", i64), ("acts", vp), ("c_raw", vp),
                 ("out_p", CellPackedDst), ("h_next_p", CellPackedDst),
-                ("lengths", vp), ("step", i32), ("reverse", i32), ("xw_st", i64), ("out_st", i64)]
+                ("lengths", vp), ("step", i32), ("reverse", i32), ("xw_st", i64), ("out_st", i64), ("bf16", i32)]
 
 
 class LsaConst(C.Structure):
@@ -83,7 +83,7 @@ class DecoderTrain(C.Structure):
                 ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
                 ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp), ("chains", i32),
                 ("bf_w0f_f", vp), ("bf_w1_f", vp), ("bf_wq_f", vp), ("bf_w0f_b", vp), ("bf_w1_b", vp), ("bf_wq_b", vp),
-                ("w0p", vp), ("w1p", vp), ("w0f_bp", vp), ("w1_bp", vp), ("wq_bp", vp), ("wq_t", vp), ("act_p", vp)]
+                ("w0p", vp), ("w1p", vp), ("w0p16", vp), ("w1p16", vp), ("w0f_bp", vp), ("w1_bp", vp), ("wq_bp", vp), ("wq_t", vp), ("act_p", vp)]
 
 
 class DecoderTrainBwd(C.Structure):
@@ -129,6 +129,9 @@ SIGNATURES = {
     "mstts_cell_fwd_supported": (i32, [i64, i64]),
     "mstts_pack_cell_fwd": (i32, [vp, i64, vp, i64, i64, vp]),
     "mstts_cell_fwd": (i32, [P(CellFwd), vp]),
+    "mstts_cell_fwd_bf16_supported": (i32, [i64, i64]),
+    "mstts_pack_cell_fwd_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
+    "mstts_pack_cell_act_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
     "mstts_cell_fwd_pair": (i32, [P(CellFwd), P(CellFwd), vp]),
     "mstts_cell_act_floats": (i64, [i64, i64]),
     "mstts_pack_cell_act": (i32, [vp, i64, vp, i64, i64, vp]),

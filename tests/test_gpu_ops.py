@@ -411,3 +411,46 @@ def test_lstm_seq_fused_and_pair_forms(dev, B, T, H):
     torch.cuda.synchronize()
     for (_, a), (_, b) in zip(single, both):
         assert float(a["dgs"].abs().max()) > 0 and torch.equal(a["dgs"], b["dgs"]) and torch.equal(a["dgp"], b["dgp"])
+
+
+@pytest.mark.parametrize("B,H,K", [(32, 1024, 1792), (32, 1024, 2048), (9, 32, 128), (20, 64, 384)])
+def test_cell_fwd_fused_bf16(dev, B, H, K):
+    """bf16 form of the fused cell step (config 3): bf16 copies of kernel and activation block, v_mfma_f32_16x16x32_bf16 with fp32
+    accumulation - equals the cell evaluated in fp64 on the bf16-ROUNDED operands; the packed bf16 copies it writes for the next
+    cells hold exactly the rounded outputs."""
+    L = lib.load()
+    assert L.mstts_cell_fwd_bf16_supported(H, K) == 1 and L.mstts_cell_fwd_bf16_supported(H, K + 64) == 0
+    X = _r(dev, B, K + 8, seed=1)
+    W = _r(dev, K, 4 * H, seed=2, scale=1.0 / np.sqrt(K))
+    Wp = torch.zeros(K * 4 * H, dtype=torch.int16, device=dev)
+    Xp = torch.zeros(int(L.mstts_cell_act_floats(B, K)), dtype=torch.int16, device=dev)
+    lib.call("mstts_pack_cell_fwd_bf16", lib.ptr(W), 4 * H, lib.ptr(Wp), K, H)
+    lib.call("mstts_pack_cell_act_bf16", lib.ptr(X), K + 8, lib.ptr(Xp), B, K)
+    bias = _r(dev, 4 * H, seed=4, scale=0.3)
+    cp, hp = _r(dev, B, H, seed=5), _r(dev, B, H, seed=6)
+    g = np.random.default_rng(7)
+    zc = torch.tensor(g.integers(0, 2, (B, H)).astype(np.uint8), device=dev)
+    zh = torch.tensor(g.integers(0, 2, (B, H)).astype(np.uint8), device=dev)
+    out, cn, hn = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+    acts, craw = torch.zeros(B, 4 * H, device=dev), torch.zeros(B, H, device=dev)
+    K2 = 2 * K if 2 * K <= 2048 else K
+    outp = torch.zeros(int(L.mstts_cell_act_floats(B, K2)), dtype=torch.int16, device=dev)
+    d = lib.CellFwd()
+    d.B, d.H, d.K, d.Xp, d.Wp, d.bias, d.bf16 = B, H, K, lib.ptr(Xp), lib.ptr(Wp), lib.ptr(bias), 1
+    d.c_prev, d.h_prev, d.h_prev_ld, d.zc, d.zh, d.zoneout = lib.ptr(cp), lib.ptr(hp), H, lib.ptr(zc), lib.ptr(zh), 0.1
+    d.out, d.out_ld, d.c_next, d.h_next, d.h_next_ld, d.acts, d.c_raw = lib.ptr(out), H, lib.ptr(cn), lib.ptr(hn), H, lib.ptr(acts), lib.ptr(craw)
+    if H <= K2:
+        d.out_p.base, d.out_p.K, d.out_p.col0, d.out_p.bf16 = lib.ptr(outp), K2, 0, 1
+    lib.call("mstts_cell_fwd", C.byref(d))
+    gates = _bf(X[:, :K]).cpu().numpy() @ _bf(W).cpu().numpy() + t2n(bias)
+    sg = lambda x: 1.0 / (1.0 + np.exp(-x))
+    i, j, f, o = np.split(gates, 4, axis=1)
+    c = sg(f + 1.0) * t2n(cp) + sg(i) * np.tanh(j)
+    m = sg(o) * np.tanh(c)
+    assert rel_err(t2n(out), m) < TOL and rel_err(t2n(cn), 0.9 * t2n(zc) * (c - t2n(cp)) + t2n(cp)) < TOL
+    assert rel_err(t2n(hn), 0.9 * t2n(zh) * (m - t2n(hp)) + t2n(hp)) < TOL and rel_err(t2n(craw), c) < TOL
+    if H <= K2:
+        ref = torch.zeros(B, K2, device=dev); ref[:, :H] = out
+        chk = torch.zeros_like(outp)
+        lib.call("mstts_pack_cell_act_bf16", lib.ptr(ref), K2, lib.ptr(chk), B, K2)
+        assert torch.equal(chk, outp)

@@ -255,24 +255,20 @@ int mstts_lsa_dalign_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d
                          int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G, float* d_align, mstts_stream_t s);
 int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* align, const float* d_align, const float* q, const float* cum,
                           float* d_e, float* dq, float* d_f, mstts_stream_t s);
-/* Single-launch form of dalign + denergy (d_align stays on chip; the row-wide dot(a, d_a) is exchanged inside the launch
- * through {epoch,value} words in `granules`: mstts_lsa_step_bwd_ws_bytes(B,T) bytes, zeroed before the first step of a
- * sequence, distinct non-zero epoch per call).  A workgroup that times out waiting writes NaN and counts the event in
- * the word after the last granule. */
-int64_t mstts_lsa_step_bwd_ws_bytes(int64_t B, int64_t T);
+/* Single-launch form of dalign + denergy (d_align stays on chip).  The row-wide softmax-backward scalar dot(a, d_a) needs NO exchange:
+ * with d_a = G + values . d_ctx it equals dot(a, G) + ctx . d_ctx, ctx = this step's FORWARD context [B, M] (row stride ctx_fwd_ld), which
+ * the caller kept from the forward pass - every workgroup forms it from data it can read directly. */
 int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
                        int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
-                       const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
-                       void* granules, uint32_t epoch, mstts_stream_t s);
-/* Test entries for the time-out paths of the two single-launch kernels: the same launches without the workgroups of one slice, which
- * forces the rest of each row to time out (milliseconds) and fall back to its serial recompute; the counters behind the granules
- * then read > 0.  The skipped slice's own outputs are not written. */
+                       const float* align, const float* q, const float* cum, const float* ctx_fwd, int64_t ctx_fwd_ld,
+                       float* d_e, float* dq, float* d_f, mstts_stream_t s);
+/* Test entry for the time-out path of the single-launch forward kernel: the same launch without the workgroups of one slice, which
+ * forces the rest of each row to time out (milliseconds) and fall back to its serial recompute; the counter behind the granules
+ * then reads > 0.  The skipped slice's own outputs are not written. */
 int mstts_lsa_step_fwd_selftest(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
                                 const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, void* granules,
                                 uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
-int mstts_lsa_step_bwd_selftest(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* G_next, const float* d_f_next,
-                                float* G, const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
-                                void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
+
 /* post-loop parameter gradients over all S steps (recomputes tanh tiles from the saved d_e):
  * hist pointers are [S,B,*]; outputs accumulate (atomic): d_keys[B,T,A], d_loc_k[KS,A], d_score_w[A], d_score_b[A]
  * (d_loc_b equals d_score_b); unfold d_loc_k with mstts_lsa_unfold_location_grad. */

@@ -467,7 +467,7 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
     const long Bc = B / chains, BcH = Bc * H, BcT = Bc * T;
     const long ws_per_row = 8 * H + 2 * T + 2 * T * CH + T + (long)np1 * W1 + (long)npq * H;
     // single-launch attention backward: its granules (B*ceil(T/8)+1 8-byte words) live in the d_align block (B*T floats)
-    const bool fused_lsa = true && mstts_lsa_step_bwd_ws_bytes(B, T) <= B * T * 4;
+    const bool fused_lsa = WP % 4 == 0 && H % 4 == 0;            // (the single-launch backward reads the forward context rows as float4)
     // query-layer data gradient inside cell 1's pointwise kernel: fp32 mode, A == 128, slab counts the lean kernel is built for
     // (bf16 mode: the kernel rounds both operands to bf16 first - the same products as the bf16 product launch it replaces)
     const int np1_eff = bf ? bfs[4] : np1;
@@ -503,11 +503,11 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
             float* dpj = bd->d_pj + (st * B + b0) * WP;
             const float* d_in0_next = last ? nullptr : bd->d_in0 + ((st + 1) * B + b0) * W0;
             // ---- attention backward
-            if (fused_lsa) {        // d_align stays on chip; its workspace row block holds the exchange granules instead
+            if (fused_lsa) {        // d_align stays on chip
                 PROBED(MSTTS_PROBE_LSA_DALIGN, q_s, mstts_lsa_step_bwd(&lc, dpj + H, WP, d_in0_next, W0, k.parts0, d_in0_slab,
                                         last ? nullptr : k.G[cur], last ? nullptr : k.df[cur], k.G[nxt], d->align_hist + (st * B + b0) * T,
-                                        d->q_hist + (st * B + b0) * A, d->cum_hist + (st * B + b0) * T, bd->de_hist + (st * B + b0) * T,
-                                        bd->dq_hist + (st * B + b0) * A, k.df[nxt], k.d_align, (uint32_t)(st + 1), q_s));
+                                        d->q_hist + (st * B + b0) * A, d->cum_hist + (st * B + b0) * T, d->pj + (st * B + b0) * WP + H, WP,
+                                        bd->de_hist + (st * B + b0) * T, bd->dq_hist + (st * B + b0) * A, k.df[nxt], q_s));
             } else {
                 PROBED(MSTTS_PROBE_LSA_DALIGN, q_s, mstts_lsa_dalign_bwd(&lc, dpj + H, WP, d_in0_next, W0, k.parts0, d_in0_slab,
                                         last ? nullptr : k.G[cur], last ? nullptr : k.df[cur], k.G[nxt], k.d_align, q_s));

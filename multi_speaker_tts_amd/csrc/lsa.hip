@@ -7,8 +7,8 @@
 //       positions (folded 31-tap location filter -> tanh -> wave shuffle reduction), the workgroups of a row exchange
 //       their slices inside the launch as 8-byte {epoch, value} granules, then each runs the row softmax and streams its
 //       96-column slice of values[b].
-//   backward, one launch (lsa_step_bwd_kernel, grid (T/8, B)): d_align = G + values . d_ctx, the row-wide dot(a, d_a)
-//       exchanged the same way, d_energy, d_query (atomics), and the filter-transpose operand h for the previous step.
+//   backward, one launch (lsa_step_bwd_kernel, B x T/8 workgroups): d_align = G + values . d_ctx, the row-wide dot(a, d_a) formed
+//       locally as dot(a, G) + ctx . d_ctx (no exchange), d_energy, d_query (atomics), the filter-transpose operand h.
 //   The two-launch forms (lsa_energy + lsa_context, lsa_dalign + lsa_denergy) are kept: they need no granule buffer, are
 //   what the single-launch kernels are tested against, and serve sequences that do not fit the single-launch geometry.
 //   Parameter gradients are hoisted out of the time loop into one batched recompute kernel (lsa_param_bwd), so the
@@ -563,45 +563,25 @@ __global__ __launch_bounds__(256) void lsa_denergy_kernel(mstts_lsa_const c, con
 // (serially: slow but correct, like the forward kernel) and counts the event in the word after the last granule, so a launch can
 // neither hang nor poison the gradients.
 // ---------------------------------------------------------------------------------------------
-// time-out fallback of lsa_step_bwd_kernel: sum over the TS positions from t0 of a[t] * d_align[t], d_align = G + values . d_ctx with
-// G[t] = G_next[t] + sum_j h_next[t + pad - j][j] - the same quantities the owning workgroup would have published, one thread, no LDS
-__device__ __forceinline__ float lsa_dot_partial_serial(const mstts_lsa_const& c, const float* d_ctx, long d_ctx_ld, const float* d_ctx2, long d_ctx2_ld,
-                                                     int d_ctx2_parts, long d_ctx2_pstride, const float* G_next, const float* h_next,
-                                                     const float* align, int b, int t0) {
-    const int T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
-    const int len = c.lengths ? c.lengths[b] : T;
-    float tot = 0.f;
-    for (int t = t0; t < t0 + TS && t < T; ++t) {
-        float g = G_next ? G_next[(long)b * T + t] : 0.f;
-        if (h_next)
-            for (int j = 0; j < KS; ++j) {
-                const int tau = t + pad - j;
-                if (tau >= 0 && tau < T) g += h_next[((long)b * T + tau) * HLD + j];
-            }
-        float acc = 0.f;
-        if (t < len)
-            for (int i = 0; i < M; ++i) {
-                float y = d_ctx[(long)b * d_ctx_ld + i];
-                if (d_ctx2)
-                    for (int pp = 0; pp < max(d_ctx2_parts, 1); ++pp) y += d_ctx2[pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i];
-                acc += c.values[((long)b * T + t) * M + i] * y;
-            }
-        tot += align[(long)b * T + t] * (g + acc);
-    }
-    return tot;
-}
-
-template <bool SELFTEST>
+// ---------------------------------------------------------------------------------------------
+// backward, single launch, NO exchange: the two kernels above in one, grid B x T/TS workgroups.  The only row-wide quantity of the
+// softmax backward is dot(a, d_a), and with d_a = G + values . d_ctx it splits into
+//     dot(a, d_a) = dot(a, G) + (sum_t a[t] values[t]) . d_ctx = dot(a, G) + ctx . d_ctx
+// where ctx is the FORWARD context of this step (kept in the projection history) - so every workgroup forms the scalar itself from
+// 128 + 768 floats it can read directly (plus the row's G, a 128 x 31 filter-transpose sum it recomputes redundantly), and nothing
+// has to cross workgroups inside the launch.  d_align never goes to memory.  (The exchanged form of round 1 cost 13.5 us per step.)
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, const float* __restrict__ d_ctx, long d_ctx_ld,
                                                            const float* __restrict__ d_ctx2, long d_ctx2_ld, int d_ctx2_parts, long d_ctx2_pstride,
                                                            const float* __restrict__ G_next, const float* __restrict__ h_next, float* __restrict__ G,
                                                            const float* __restrict__ align, const float* __restrict__ q, const float* __restrict__ cum,
-                                                           float* __restrict__ d_e_out, float* __restrict__ dq, float* __restrict__ h,
-                                                           unsigned long long* gran, unsigned epoch, int nsl, int skip) {
+                                                           const float* __restrict__ ctx_fwd, long ctx_fwd_ld,
+                                                           float* __restrict__ d_e_out, float* __restrict__ dq, float* __restrict__ h, int nsl) {
     int sl, b;
     row_slice_of_block(blockIdx.x, nsl, (int)c.B, &b, &sl);
-    if (SELFTEST && sl == skip) return;
-    __shared__ float s_gG[TS];
+    __shared__ float s_G[TS];                                 // G of this slice's positions
+    __shared__ float s_a[T_MAX];                              // the row's alignments
+    __shared__ __attribute__((aligned(16))) float s_dc[256 * MROW];  // the row's total d_ctx (first 1024 columns)
     __shared__ float s_da[TS];
     __shared__ float s_cum[TS + KS_MAX - 1];
     __shared__ __attribute__((aligned(16))) float s_g[TS][A_];
@@ -609,28 +589,46 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     __shared__ float s_de[TS];
     __shared__ float s_dq[A_];
     __shared__ float scratch[16];
+    __shared__ float s_dot2;
     const int t0 = sl * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
     const int len = c.lengths ? c.lengths[b] : T;
-    // ---- every global load, back to back: d_align phase ...
-    constexpr int LPR = 256 / TS;
+    // ---- every global load, back to back: the row's G operands ...
+    constexpr int LPR = 256 / TS;                             // 32 lanes per position: lane j of position tt takes tap j
     const int tt_h = threadIdx.x / LPR, jh = threadIdx.x % LPR;
-    float hv = 0.f;
+    float hv = 0.f;                                           // this slice's G: one diagonal tap per lane
     if (h_next && jh < KS) {
         const int tau = t0 + tt_h + pad - jh;
         if (tau >= 0 && tau < T) hv = h_next[((long)b * T + tau) * HLD + jh];
     }
-    float gn = 0.f;
-    if (threadIdx.x < TS && G_next && t0 + threadIdx.x < T) gn = G_next[(long)b * T + t0 + threadIdx.x];
-    float4 dcv[MROW], val[TS / 4][MROW];
-    const float* dc = d_ctx + (long)b * d_ctx_ld;
+    // the whole h_next[b] tile, coalesced (for dot(a, G) only): rows of HLD = 32 floats, 8 float4 per row, HT4 float4 per thread
+    constexpr int HT4 = 4;                                    // covers T <= 128; longer rows loop below
+    float4 ht[HT4];
 #pragma unroll
-    for (int m = 0; m < MROW; ++m) {
-        const int i = lane * 4 + 256 * m;
-        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < HT4; ++i) {
+        const int e = threadIdx.x + 256 * i;                  // float4 index in the tile: row e / 8, taps 4 (e % 8) ..
+        ht[i] = (h_next && (e >> 3) < T) ? reinterpret_cast<const float4*>(h_next + (long)b * T * HLD)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float av[T_MAX / 256], gnv[T_MAX / 256];
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        av[i] = (t < T) ? align[(long)b * T + t] : 0.f;
+        gnv[i] = (t < T && G_next) ? G_next[(long)b * T + t] : 0.f;
+    }
+    const float a_own = (threadIdx.x < TS && t0 + threadIdx.x < T) ? align[(long)b * T + t0 + threadIdx.x] : 0.f;
+    const float gn_own = (threadIdx.x < TS && t0 + threadIdx.x < T && G_next) ? G_next[(long)b * T + t0 + threadIdx.x] : 0.f;
+    // ... d_ctx (+ its partial slabs: wave m sums chunk m of the row once for the whole workgroup, shared through LDS below - every
+    // wave loading all nine vectors itself was 36 float4 per lane and most of this kernel's L2 traffic), the forward context, this
+    // slice's value rows ...
+    float4 dcv[MROW], cxv[MROW], val[TS / 4][MROW];
+    const float* dc = d_ctx + (long)b * d_ctx_ld;
+    float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int i = lane * 4 + 256 * w;                     // MROW == 4 == waves per workgroup: wave w owns columns [256 w, 256 w + 256)
         if (i < M) {
-            y = *reinterpret_cast<const float4*>(dc + i);
+            dsum = *reinterpret_cast<const float4*>(dc + i);
             if (d_ctx2) {
                 float4 y2[8];
 #pragma unroll
@@ -638,10 +636,14 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
                     y2[pp] = (pp == 0 || pp < d_ctx2_parts) ? *reinterpret_cast<const float4*>(d_ctx2 + pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i)
                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int pp = 0; pp < 8; ++pp) { y.x += y2[pp].x; y.y += y2[pp].y; y.z += y2[pp].z; y.w += y2[pp].w; }
+                for (int pp = 0; pp < 8; ++pp) { dsum.x += y2[pp].x; dsum.y += y2[pp].y; dsum.z += y2[pp].z; dsum.w += y2[pp].w; }
             }
         }
-        dcv[m] = y;
+    }
+#pragma unroll
+    for (int m = 0; m < MROW; ++m) {
+        const int i = lane * 4 + 256 * m;
+        cxv[m] = (w == 0 && i < M) ? *reinterpret_cast<const float4*>(ctx_fwd + (long)b * ctx_fwd_ld + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int r = 0; r < TS / 4; ++r) {
@@ -653,9 +655,7 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    // ---- ... and d_energy phase
-    float a_own = 0.f;
-    if (threadIdx.x < TS && t0 + threadIdx.x < T) a_own = align[(long)b * T + t0 + threadIdx.x];
+    // ... and the d_energy phase
     float cwin = 0.f;
     if (threadIdx.x < TS + KS - 1) {
         const int t = t0 - pad + threadIdx.x;
@@ -674,13 +674,61 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
     const float qk = q[(long)b * A_ + k] + c.score_b[k] + c.loc_b[k];
     const float wk = c.score_w[k];
-    // ---- G for the TS rows, then d_align = G + values . d_ctx (kept in LDS)
+    // ---- this slice's G (32-lane sums of the diagonal taps) and the row's alignments in LDS
+    {
+        float x = hv;
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) hv += __shfl_xor(hv, o, 64);
-    if (jh == 0) s_gG[tt_h] = hv;
+        for (int o = LPR / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (jh == 0) s_G[tt_h] = x;
+    }
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        if (t < T) s_a[t] = av[i];
+    }
+    *reinterpret_cast<float4*>(&s_dc[lane * 4 + 256 * w]) = dsum;
     __syncthreads();
-    if (threadIdx.x < TS) s_gG[threadIdx.x] += gn;
-    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MROW; ++m) dcv[m] = *reinterpret_cast<const float4*>(&s_dc[lane * 4 + 256 * m]);
+    // dot(a, G) = dot(a, G_next) + sum_{tau, j} h_next[tau][j] a[tau - pad + j]   (G[t] = G_next[t] + sum_j h_next[t + pad - j][j])
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < T_MAX / 256; ++i) part += av[i] * gnv[i];
+    auto tile_dot = [&](const float4& hq, int e) {
+        const int tau = e >> 3, j0 = (e & 7) * 4, t = tau - pad + j0;
+        float r = 0.f;
+        if (j0 < KS && t >= 0 && t < T) r += hq.x * s_a[t];
+        if (j0 + 1 < KS && t + 1 >= 0 && t + 1 < T) r += hq.y * s_a[t + 1];
+        if (j0 + 2 < KS && t + 2 >= 0 && t + 2 < T) r += hq.z * s_a[t + 2];
+        if (j0 + 3 < KS && t + 3 >= 0 && t + 3 < T) r += hq.w * s_a[t + 3];
+        return r;
+    };
+#pragma unroll
+    for (int i = 0; i < HT4; ++i) part += tile_dot(ht[i], threadIdx.x + 256 * i);
+    if (h_next)
+        for (int e = threadIdx.x + 256 * HT4; (e >> 3) < T; e += 256)            // T > 128 only
+            part += tile_dot(reinterpret_cast<const float4*>(h_next + (long)b * T * HLD)[e], e);
+    // ctx . d_ctx on wave 0 (its lanes hold both vectors in the same layout)
+    if (w == 0) {
+        float p2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MROW; ++m) p2 += cxv[m].x * dcv[m].x + cxv[m].y * dcv[m].y + cxv[m].z * dcv[m].z + cxv[m].w * dcv[m].w;
+        for (int i = lane * 4 + 256 * MROW; i < M; i += 256) {            // M > 1024 only
+            const float4 x = *reinterpret_cast<const float4*>(ctx_fwd + (long)b * ctx_fwd_ld + i);
+            float4 y = *reinterpret_cast<const float4*>(dc + i);
+            if (d_ctx2)
+                for (int pp = 0; pp < max(d_ctx2_parts, 1); ++pp) {
+                    const float4 y2 = *reinterpret_cast<const float4*>(d_ctx2 + pp * d_ctx2_pstride + (long)b * d_ctx2_ld + i);
+                    y.x += y2.x; y.y += y2.y; y.z += y2.z; y.w += y2.w;
+                }
+            p2 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        p2 = wave_sum(p2);
+        if (lane == 0) s_dot2 = p2;
+    }
+    if (threadIdx.x < TS) s_G[threadIdx.x] += gn_own;         // (written before the barrier above, read after the ones inside block_sum)
+    const float dot = block_sum(part, scratch) + s_dot2;      // block_sum synchronises: s_G and s_dot2 are complete behind it
+    // ---- d_align = G + values . d_ctx for this slice's rows (kept in LDS)
 #pragma unroll
     for (int r = 0; r < TS / 4; ++r) {
         const int tt = w + 4 * r, t = t0 + tt;
@@ -702,12 +750,12 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
         }
         acc = wave_sum(acc);
         if (lane == 0) {
-            const float g = s_gG[tt];
+            const float g = (t < T) ? s_G[tt] : 0.f;
             if (t < T) G[(long)b * T + t] = g;
             s_da[tt] = (t < T) ? g + acc : 0.f;
         }
     }
-    // stage the filter / window for the tanh recompute while the last wave finishes
+    // stage the filter / window for the tanh recompute
 #pragma unroll
     for (int i = 0; i < NLK; ++i) {
         const int e = threadIdx.x + 256 * i;
@@ -715,17 +763,12 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     }
     if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;
     __syncthreads();
-    // ---- publish this slice's part of dot(a, d_a)
-    gu64* g64 = (gu64*)(gran + (long)b * nsl);
-    float p_own = 0.f;
-    if (w == 0) {
-        p_own = (lane < TS) ? a_own * s_da[lane] : 0.f;
-#pragma unroll
-        for (int o = TS / 2; o > 0; o >>= 1) p_own += __shfl_xor(p_own, o, 64);
-        if (lane == 0)
-            __hip_atomic_store(g64 + sl, ((unsigned long long)epoch << 32) | __float_as_uint(p_own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < TS) {
+        const int t = t0 + threadIdx.x;
+        const float de = (t < T) ? a_own * (s_da[threadIdx.x] - dot) : 0.f;
+        if (t < T) d_e_out[(long)b * T + t] = de;
+        s_de[threadIdx.x] = de;
     }
-    // ---- tanh terms (independent of the dot) while the granules travel
     float lk[KS_MAX];
 #pragma unroll
     for (int j = 0; j < KS_MAX; ++j) lk[j] = s_lk[j][k];
@@ -738,33 +781,6 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
         for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * lk[j];
         const float u = fast_tanh(pre);
         fac[i] = (t0 + tt < T) ? wk * (1.f - u * u) : 0.f;
-    }
-    // ---- gather the row's partials
-    float part = 0.f;
-    if (threadIdx.x < nsl && threadIdx.x != sl) {             // nsl <= T_MAX / TS = 128
-        {
-            unsigned long long x = __hip_atomic_load(g64 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
-                __builtin_amdgcn_s_sleep(1);
-                x = __hip_atomic_load(g64 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++spins;
-            }
-            if ((unsigned)(x >> 32) == epoch) part = __uint_as_float((unsigned)x);
-            else {          // the slice never arrived: recompute its part of dot(a, d_a) here (serial, slow, correct) and count the event
-                part = lsa_dot_partial_serial(c, d_ctx, d_ctx_ld, d_ctx2, d_ctx2_ld, d_ctx2_parts, d_ctx2_pstride, G_next, h_next, align, b,
-                                              (int)threadIdx.x * TS);
-                atomicAdd(gran + (long)c.B * nsl, 1ull);
-            }
-        }
-    }
-    if (threadIdx.x == 0) part += p_own;                      // thread 0 is lane 0 of wave 0: holds the own partial
-    const float dot = block_sum(part, scratch);
-    if (threadIdx.x < TS) {
-        const int t = t0 + threadIdx.x;
-        const float de = (t < T) ? a_own * (s_da[threadIdx.x] - dot) : 0.f;
-        if (t < T) d_e_out[(long)b * T + t] = de;
-        s_de[threadIdx.x] = de;
     }
     __syncthreads();
     float dq_acc = 0.f;
@@ -957,40 +973,19 @@ extern "C" int mstts_lsa_denergy_bwd(const mstts_lsa_const* c, const float* alig
     MSTTS_CHECK_LAUNCH("lsa_denergy_bwd");
     return MSTTS_OK;
 }
-extern "C" int64_t mstts_lsa_step_bwd_ws_bytes(int64_t B, int64_t T) { return (B * cdiv(T, TS) + 1) * 8; }
-static int lsa_step_bwd_launch(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
-                               int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
-                               const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
-                               void* granules, uint32_t epoch, int skip, mstts_stream_t s) {
+extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
+                                  int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
+                                  const float* align, const float* q, const float* cum, const float* ctx_fwd, int64_t ctx_fwd_ld,
+                                  float* d_e, float* dq, float* d_f, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(aligned16(d_ctx) && aligned16(d_ctx2) && d_ctx_ld % 4 == 0 && d_ctx2_ld % 4 == 0, MSTTS_ERR_ALIGN,
                   "lsa_step_bwd: d_ctx rows must be 16-byte aligned");
-    MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_bwd: granule buffer (8-byte aligned) and a non-zero epoch required");
-    if (skip >= 0)
-        hipLaunchKernelGGL(lsa_step_bwd_kernel<true>, dim3((unsigned)(cdiv(c->T, TS) * c->B)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
-                           (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
-                           (unsigned long long*)granules, (unsigned)epoch, cdiv(c->T, TS), skip);
-    else
-        hipLaunchKernelGGL(lsa_step_bwd_kernel<false>, dim3((unsigned)(cdiv(c->T, TS) * c->B)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
-                           (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
-                           (unsigned long long*)granules, (unsigned)epoch, cdiv(c->T, TS), -1);
+    MSTTS_REQUIRE(ctx_fwd && aligned16(ctx_fwd) && ctx_fwd_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_bwd: the forward context rows (16-byte aligned) are required");
+    hipLaunchKernelGGL(lsa_step_bwd_kernel, dim3((unsigned)(cdiv(c->T, TS) * c->B)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
+                       (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, ctx_fwd, (long)ctx_fwd_ld, d_e, dq, d_f,
+                       cdiv(c->T, TS));
     MSTTS_CHECK_LAUNCH("lsa_step_bwd");
     return MSTTS_OK;
-}
-extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* d_ctx2, int64_t d_ctx2_ld,
-                                  int32_t d_ctx2_parts, int64_t d_ctx2_pstride, const float* G_next, const float* d_f_next, float* G,
-                                  const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
-                                  void* granules, uint32_t epoch, mstts_stream_t s) {
-    return lsa_step_bwd_launch(c, d_ctx, d_ctx_ld, d_ctx2, d_ctx2_ld, d_ctx2_parts, d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f,
-                               granules, epoch, -1, s);
-}
-/* test entry: the same launch without the workgroups of slice `skip_slice`, so every other workgroup of a row times out on that slice and
- * recomputes its part of dot(a, d_a); the skipped slice's own outputs (d_e / d_f rows, its dq share) are not produced */
-extern "C" int mstts_lsa_step_bwd_selftest(const mstts_lsa_const* c, const float* d_ctx, int64_t d_ctx_ld, const float* G_next, const float* d_f_next,
-                                           float* G, const float* align, const float* q, const float* cum, float* d_e, float* dq, float* d_f,
-                                           void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s) {
-    MSTTS_REQUIRE(skip_slice >= 0, MSTTS_ERR_SHAPE, "lsa_step_bwd_selftest: skip_slice must be >= 0");
-    return lsa_step_bwd_launch(c, d_ctx, d_ctx_ld, nullptr, 0, 0, 0, G_next, d_f_next, G, align, q, cum, d_e, dq, d_f, granules, epoch, skip_slice, s);
 }
 extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
                                    float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, mstts_stream_t s) {

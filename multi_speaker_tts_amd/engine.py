@@ -651,18 +651,10 @@ class TrainEngine:
                 "Weight_Regularization_Loss": wr, "Loss": float(s[0] + s[1] + s[2]) + wr}
 
     def exchange_timeouts(self, w):
-        """(forward, backward) counts of in-launch exchange time-outs of the single-launch attention kernels in the last step on
-        workspace `w` (csrc/lsa.hip: the word behind the last granule of each buffer).  Always (0, 0) on a healthy run; a
-        non-zero count means a workgroup fell back to its serial recompute.  Synchronises."""
-        d = self.d
-        B, T, H, CH = w.B, w.Te, d.dec_lstm, d.att_ch
-        fwd = int(w.energy_ws.view(torch.int64)[B * T].item())
-        nsl = (T + 7) // 8
-        off = 8 * B * H + 2 * B * T + 2 * B * T * CH            # the d_align block of mstts_decoder_train_bwd's workspace
-        if (B * nsl + 1) * 8 > B * T * 4:                      # geometry without the single-launch backward: no counter
-            return fwd, 0
-        bwd = int(w.dec_bwd_ws[off:off + 2 * (B * nsl + 1)].view(torch.int64)[B * nsl].item())
-        return fwd, bwd
+        """Count of in-launch exchange time-outs of the single-launch forward attention kernel in the last step on workspace `w`
+        (csrc/lsa.hip: the word behind the last granule).  Always 0 on a healthy run; non-zero means a workgroup fell back to its
+        serial recompute.  (The backward kernel needs no exchange.)  Synchronises."""
+        return int(w.energy_ws.view(torch.int64)[w.B * w.Te].item())
 
     def broadcast_state(self, src=0, group=None):
         """Data-parallel start: every rank takes rank `src`'s variables, Adam slots and statistics."""

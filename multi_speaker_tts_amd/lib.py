@@ -138,11 +138,9 @@ SIGNATURES = {
     "mstts_lsa_energy_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp]),
     "mstts_lsa_context_fwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     "mstts_lsa_step_ws_bytes": (i64, [i64, i64]),
-    "mstts_lsa_step_bwd_ws_bytes": (i64, [i64, i64]),
-    "mstts_lsa_step_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
+    "mstts_lsa_step_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "mstts_lsa_step_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, vp]),
     "mstts_lsa_step_fwd_selftest": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, C.c_uint32, i32, vp]),
-    "mstts_lsa_step_bwd_selftest": (i32, [P(LsaConst), vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, i32, vp]),
     "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "mstts_lsa_denergy_bwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, vp, vp, vp]),
     "mstts_lsa_param_bwd": (i32, [P(LsaConst), i64, vp, vp, vp, vp, vp, vp, vp, vp]),

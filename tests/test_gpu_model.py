@@ -122,14 +122,14 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al), lib.ptr(da), lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dq), lib.ptr(hh))
     # single-launch form of the two calls above (row-wide dot(a, d_a) exchanged inside the launch)
     G2, de2, dq2, hh2 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, 32, device=dev)
-    granb = torch.zeros(int(lib.load().mstts_lsa_step_bwd_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    ctx_f = f32(t2n(ctx))                                   # this step's forward context: dot(a, d_a) = dot(a, G) + ctx . d_ctx inside the kernel
     lib.call("mstts_lsa_step_bwd", C.byref(c), lib.ptr(d_ctx_d), M, None, 0, 0, 0, lib.ptr(G_next_d), lib.ptr(h_next_d), lib.ptr(G2),
-             lib.ptr(al), lib.ptr(q), lib.ptr(dcum), lib.ptr(de2), lib.ptr(dq2), lib.ptr(hh2), lib.ptr(granb), 3)
-    assert torch.equal(G2, G) and int(granb[-1]) == 0
+             lib.ptr(al), lib.ptr(q), lib.ptr(dcum), lib.ptr(ctx_f), M, lib.ptr(de2), lib.ptr(dq2), lib.ptr(hh2))
+    assert rel_err(t2n(G2), t2n(G)) < 1e-6
     assert rel_err(t2n(de2), t2n(de)) < 1e-5 and rel_err(t2n(dq2), t2n(dq)) < 1e-5 and rel_err(t2n(hh2), t2n(hh)) < 1e-5
     if (B, T, M) == (2, 128, 768):
-        # time-out paths (never taken on a healthy chip): remove one slice's workgroups; the rest of each row waits out its bounded spin,
-        # recomputes the missing energies / dot(a, d_a) part serially and must still produce the same results; both counters read > 0
+        # time-out path of the forward kernel (never taken on a healthy chip): remove one slice's workgroups; the rest of each row waits
+        # out its bounded spin, recomputes the missing energies serially and must still produce the same results; the counter reads > 0
         skip = 3
         al3, cn3, cx3b = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
         gran3 = torch.zeros_like(gran)
@@ -140,13 +140,6 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
         assert int(gran3[-1]) > 0
         assert rel_err(t2n(al3)[:, keep_t], t2n(align)[:, keep_t]) < 2e-5 and rel_err(t2n(cx3b)[:, keep_m], t2n(ctx)[:, keep_m]) < 2e-5
         assert float(al3[:, ~torch.tensor(keep_t)].abs().max()) == 0.0             # the removed slice wrote nothing
-        G3, de3, dq3, hh3 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, A, device=dev), torch.zeros(B, T, 32, device=dev)
-        granb3 = torch.zeros_like(granb)
-        lib.call("mstts_lsa_step_bwd_selftest", C.byref(c), lib.ptr(d_ctx_d), M, lib.ptr(G_next_d), lib.ptr(h_next_d), lib.ptr(G3),
-                 lib.ptr(al), lib.ptr(q), lib.ptr(dcum), lib.ptr(de3), lib.ptr(dq3), lib.ptr(hh3), lib.ptr(granb3), 5, skip)
-        keep_t = np.ones(T, bool); keep_t[8 * skip:8 * skip + 8] = False
-        assert int(granb3[-1]) > 0 and bool(torch.isfinite(de3).all())
-        assert rel_err(t2n(de3)[:, keep_t], t2n(de)[:, keep_t]) < 1e-5 and rel_err(t2n(hh3)[:, keep_t], t2n(hh)[:, keep_t]) < 1e-5
     dquery = t2n(dq).astype(np.float64) @ p[LSA + "query_layer/kernel"].T
     assert rel_err(dquery, t2n(qt.grad)) < 5e-5
     # grad wrt cum = G (carried) + filter-transpose of h
@@ -212,24 +205,23 @@ def test_lsa_step_exchange_under_load(dev):
     worst = max(rel_err(t2n(al[e]), t2n(al_r[e])) for e in range(N))
     assert worst < 1e-4, worst
     assert rel_err(t2n(cx), t2n(cx_r)) < 1e-4 and rel_err(t2n(cum[1:]), t2n(cum_r[1:])) < 1e-4
-    # backward exchange, same regime: a different upstream gradient every epoch
+    # backward kernel, same regime: a different upstream gradient every epoch
     dctx = rn(N, B, M); Gn, hn = rn(B, T), rn(B, T, 32)
     G1, G2 = torch.zeros(B, T, device=dev), torch.zeros(N, B, T, device=dev)
     da = torch.zeros(B, T, device=dev)
     de1, de2 = torch.zeros(N, B, T, device=dev), torch.zeros(N, B, T, device=dev)
     dq1, dq2 = torch.zeros(N, B, A, device=dev), torch.zeros(N, B, A, device=dev)
     h1, h2 = torch.zeros(N, B, T, 32, device=dev), torch.zeros(N, B, T, 32, device=dev)
-    granb = torch.zeros(B * (T // 8) + 1, dtype=torch.int64, device=dev)
-    for e in range(N):
+    for e in range(N):              # (no exchange in the backward kernel: the forward context of the same epoch closes the row-wide dot)
         lib.call("mstts_lsa_step_bwd", C.byref(c), lib.ptr(dctx[e]), M, None, 0, 0, 0, lib.ptr(Gn), lib.ptr(hn), lib.ptr(G2[e]),
-                 lib.ptr(al[e]), lib.ptr(qs[e]), lib.ptr(cum[e]), lib.ptr(de2[e]), lib.ptr(dq2[e]), lib.ptr(h2[e]), lib.ptr(granb), e + 1)
+                 lib.ptr(al[e]), lib.ptr(qs[e]), lib.ptr(cum[e]), lib.ptr(cx[e]), M, lib.ptr(de2[e]), lib.ptr(dq2[e]), lib.ptr(h2[e]))
         if e % 3 != 2:
             lib.call("mstts_skinny_fwd", lib.ptr(X), 1024, lib.ptr(W), 4096, lib.ptr(Pw), 0, 32, 4096, 1024, 4)
     for e in range(N):
         lib.call("mstts_lsa_dalign_bwd", C.byref(c), lib.ptr(dctx[e]), M, None, 0, 0, 0, lib.ptr(Gn), lib.ptr(hn), lib.ptr(G1), lib.ptr(da))
         lib.call("mstts_lsa_denergy_bwd", C.byref(c), lib.ptr(al[e]), lib.ptr(da), lib.ptr(qs[e]), lib.ptr(cum[e]), lib.ptr(de1[e]), lib.ptr(dq1[e]), lib.ptr(h1[e]))
     torch.cuda.synchronize()
-    assert int(granb[-1]) == 0 and bool(torch.isfinite(de2).all())
+    assert bool(torch.isfinite(de2).all())
     worst = max(rel_err(t2n(de2[e]), t2n(de1[e])) for e in range(N))
     assert worst < 1e-4, worst
     assert rel_err(t2n(dq2), t2n(dq1)) < 1e-4 and rel_err(t2n(h2), t2n(h1)) < 1e-4
@@ -382,7 +374,7 @@ def test_full_size_config2_properties(dev):
         assert all(np.isfinite(v) for v in s.values()), s
         assert bool(torch.isfinite(eng.params.grad).all()) and bool(torch.isfinite(eng.params.train).all())
         assert bool(torch.isfinite(w.mel_out).all()) and bool(torch.isfinite(w.align_hist).all())
-        assert eng.exchange_timeouts(w) == (0, 0)
+        assert eng.exchange_timeouts(w) == 0
         assert len(eng._plans) <= E.MAX_PLANS
     assert w.mel_out.shape == (32, 801, 80) and losses[-1] < losses[0], losses
     a = t2n(w.align_hist)                                              # every alignment row is a distribution over the 128 tokens

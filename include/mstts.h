@@ -517,6 +517,9 @@ typedef struct {
     /* optional, enable the weight-streaming path when mstts_decoder_infer_fast(...) == 1:
      * w0s = [wx0 ; w0f] stacked [P+M+H, 4H]; wp_pad = wproj zero-padded to [H+M, 4*ceil((n_mel+1)/4)] columns */
     const float* w0s; const float* wp_pad;
+    /* optional fused cell steps on that path: w0sp / w1p = w0s / w1 packed by mstts_pack_cell_fwd, act_p = 2 * (mstts_cell_act_floats(B, P+M+H)
+     * + mstts_cell_act_floats(B, 2H)) floats of scratch: each cell becomes one launch (7 launches per frame instead of 9) */
+    const float* w0sp; const float* w1p; float* act_p;
 } mstts_decoder_infer_desc;
 int32_t mstts_decoder_infer_fast(int64_t B, int64_t H, int64_t P, int64_t M, int64_t A, int64_t n_mel);
 int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);

@@ -573,7 +573,7 @@ typedef float pn_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restrict__ frame, int NM, const float* __restrict__ w0,
                                                           const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, float inv_keep,
-                                                          int B, int P, float* __restrict__ out, long out_ld) {
+                                                          int B, int P, float* __restrict__ out, long out_ld, PackedDst out_p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldx = NM + 1, ldh = P + 1;
     float* s_x = sm;                               // [32][NM + 1]
@@ -657,7 +657,9 @@ __global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restric
         const int b = e / PN_COLS, cc = e % PN_COLS;
         if (c0 + cc >= P) continue;
         const float v = s_r[b * 17 + cc] + s_r[(32 + b) * 17 + cc] + s_r[(64 + b) * 17 + cc] + s_r[(96 + b) * 17 + cc] + b1[c0 + cc];
-        out[(long)b * out_ld + c0 + cc] = m1[(long)b * P + c0 + cc] ? fmaxf(v, 0.f) * inv_keep : 0.f;
+        const float y = m1[(long)b * P + c0 + cc] ? fmaxf(v, 0.f) * inv_keep : 0.f;
+        out[(long)b * out_ld + c0 + cc] = y;
+        if (out_p.base) packed_store(out_p, b, c0 + cc, y);          // the fused cell-0 step reads its input row from the packed block
     }
 }
 // [parts][B][NP] projection partial slabs + bias -> linear[B][NM], stop[B] (column NM)
@@ -703,16 +705,39 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
         RC(zero(gran, 2 * BT + 2, s));
     }
     const size_t pn_lds = sizeof(float) * (size_t)(PN_MAXB * (NM + 1) + PN_MAXB * (P + 1) + 4 * 32 * 17);
+    // fused cell steps (cell.hip): packed kernels given and shapes covered -> 7 launches per frame instead of 9
+    const bool fused = d->w0sp && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1);
+    const long p0n = mstts_cell_act_floats(B, W0), p1n = mstts_cell_act_floats(B, W1);
+    if (fused && step0 == 0) RC(zero(d->act_p, 2 * (p0n + p1n), s));
     for (long st = step0; st < step0 + n; ++st) {
         const int par = (int)(st & 1), nx = par ^ 1;
         const float* frame = (st == 0) ? zero_frame : d->linear + (st - 1) * B * NM;
         float* in0c = d->in0 + par * B * W0; float* in0n = d->in0 + nx * B * W0;      // rows [prenet P | ctx M | h0 H]
         float* in1c = d->in1 + par * B * W1; float* in1n = d->in1 + nx * B * W1;      // rows [m0 H | h1 H]
+        float* P0c = fused ? d->act_p + par * p0n : nullptr; float* P0n = fused ? d->act_p + nx * p0n : nullptr;
+        float* P1c = fused ? d->act_p + 2 * p0n + par * p1n : nullptr; float* P1n = fused ? d->act_p + 2 * p0n + nx * p1n : nullptr;
+        PackedDst pre_p;
+        pre_p.base = P0c; pre_p.nit = (int)(W0 / 64); pre_p.col0 = 0; pre_p.bf = 0;
         hipLaunchKernelGGL(prenet_step_kernel, dim3((unsigned)((P + PN_COLS - 1) / PN_COLS)), dim3(256), pn_lds, (hipStream_t)s, frame, (int)NM,
-                           d->pw0, d->pb0, d->pw1, d->pb1, d->pm0 + st * B * P, d->pm1 + st * B * P, 1.f / d->prenet_keep, (int)B, (int)P, in0c, W0);
+                           d->pw0, d->pb0, d->pw1, d->pb1, d->pm0 + st * B * P, d->pm1 + st * B * P, 1.f / d->prenet_keep, (int)B, (int)P, in0c, W0, pre_p);
         MSTTS_CHECK_LAUNCH("prenet_step");
         mstts_lstm_point_fwd_desc p;
         int parts = 1;
+        if (fused) {
+            RC(cell_step(P0c, d->w0sp, W0, nullptr, 0, d->b0, d->c0 + par * BH, in0c + P + M, W0, nullptr, nullptr, d->zoneout,
+                         in1c, W1, d->c0 + nx * BH, in0n + P + M, W0, nullptr, nullptr, B, H, P1c, W1, 0, P0n, W0, P + M, s));
+            RC(cell_step(P1c, d->w1p, W1, nullptr, 0, d->b1, d->c1 + par * BH, in1c + H, W1, nullptr, nullptr, d->zoneout,
+                         d->pj, WP, d->c1 + nx * BH, in1n + H, W1, nullptr, nullptr, B, H, nullptr, 0, 0, P1n, W1, H, s));
+            RC(xw_fwd(d->pj, WP, d->wq, A, q, B, A, H, spq, &parts, s));
+            mstts_cell_packed_dst ctx_p = {P0n, W0, P, 0};
+            RC(mstts_lsa_step_fwd(&d->lsa, q, parts, B * A, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
+                                  in0n + P, W0, d->pj + H, WP, &ctx_p, gran, (uint32_t)(st + 1), s));
+            RC(xw_fwd(d->pj, WP, d->wp_pad, NP, pp, B, NP, WP, spp, &parts, s));
+            hipLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)((B * (NM + 1) + 255) / 256)), dim3(256), 0, (hipStream_t)s, pp, parts, B * NP, d->bproj,
+                               (int)B, (int)NP, (int)NM, d->linear + st * B * NM, d->stop + st * B);
+            MSTTS_CHECK_LAUNCH("proj_finish");
+            continue;
+        }
         RC(xw_fwd(in0c, W0, d->w0s, 4 * H, gates, B, 4 * H, W0, sp0, &parts, s));
         memset(&p, 0, sizeof(p));
         p.B = B; p.H = H; p.gates_h = gates; p.gates_parts = parts; p.gates_pstride = 4 * BH; p.bias = d->b0;

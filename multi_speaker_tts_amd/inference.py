@@ -172,6 +172,15 @@ class InferEngine:
             wpj, owpj = self.P("decoder/decoder/linear_projection/dense/kernel")
             call("mstts_copy2d", ptr(wpj, owpj), NM + 1, ptr(wp_pad), npad, H + M, NM + 1, 0)
             q.w0s, q.wp_pad = ptr(w0s), ptr(wp_pad)
+            L_ = lib.load()
+            if L_.mstts_cell_fwd_supported(H, Pn + M + H) and L_.mstts_cell_fwd_supported(H, 2 * H):
+                # fused cell steps: both cell kernels in the lanes' order + packed activation blocks (csrc/cell.hip)
+                w0sp, w1p = self._f((Pn + M + H) * 4 * H), self._f(2 * H * 4 * H)
+                k1, o1 = self.P(CELL % 1 + "kernel")
+                call("mstts_pack_cell_fwd", ptr(w0s), 4 * H, ptr(w0sp), Pn + M + H, H)
+                call("mstts_pack_cell_fwd", ptr(k1, o1), 4 * H, ptr(w1p), 2 * H, H)
+                act_p = self._f(2 * int(L_.mstts_cell_act_floats(B, Pn + M + H) + L_.mstts_cell_act_floats(B, 2 * H)))
+                q.w0sp, q.w1p, q.act_p = ptr(w0sp), ptr(w1p), ptr(act_p)
         q.c0, q.c1, q.cum = ptr(self._f(2, B, H)), ptr(self._f(2, B, H)), ptr(self._f(2, B, T))
         q.pre_ws = ptr(self._f(int(lib.load().mstts_decoder_infer_ws_floats(B, H, Pn, T, A, NM))))
         linear, stop, align = self._f(Smax, B, NM), self._f(Smax, B), self._f(Smax, B, T)

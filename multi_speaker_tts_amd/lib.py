@@ -96,7 +96,7 @@ class DecoderInfer(C.Structure):
                 ("pw0", vp), ("pb0", vp), ("pw1", vp), ("pb1", vp), ("pm0", vp), ("pm1", vp), ("prenet_keep", f32),
                 ("wx0", vp), ("b0", vp), ("w0f", vp), ("w1", vp), ("b1", vp), ("wq", vp), ("wproj", vp), ("bproj", vp),
                 ("zoneout", f32), ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp), ("cum", vp),
-                ("pre_ws", vp), ("linear", vp), ("stop", vp), ("align_hist", vp), ("w0s", vp), ("wp_pad", vp)]
+                ("pre_ws", vp), ("linear", vp), ("stop", vp), ("align_hist", vp), ("w0s", vp), ("wp_pad", vp), ("w0sp", vp), ("w1p", vp), ("act_p", vp)]
 
 
 P = C.POINTER

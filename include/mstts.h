@@ -323,6 +323,18 @@ int mstts_stft_mel(const float* wav, int64_t n, float preemph, const float* dft_
                    int64_t frames, mstts_stream_t s);
 int64_t mstts_stft_mel_ws_floats(int64_t n, int32_t n_fft, int64_t frames);
 
+/* The same transform (Audio.py:19-22,29-40,42-48,62-96) as ONE launch for nw waveforms: a workgroup per frame, real FFT in LDS
+ * (n_fft a power of two in [512, 4096]; mstts_stft_fft_supported).  wav = the waveforms back to back; wav_off[nw+1] / frame_off[nw+1] =
+ * DEVICE arrays of sample / frame offsets (frames of waveform w = 1 + len_w / hop, len_w > n_fft / 2); window[win] = the periodic Hann
+ * window; twiddle[n_fft/2] = (cos, -sin)(2 pi k / n_fft) pairs; mel_basis[n_mel, n_fft/2+1] row-major with mel_rng[n_mel][2] = each
+ * filter's [first, last+1) non-zero bin.  mel_out [total_frames, n_mel] = Audio.melspectrogram's symmetric normalisation,
+ * spec_out [total_frames, n_fft/2+1] = Audio.spectrogram's [0, 1] normalisation with ref_level_db; either may be NULL. */
+int mstts_stft_fft_supported(int32_t n_fft, int32_t win);
+int mstts_stft_fft(const float* wav, const int64_t* wav_off, const int64_t* frame_off, int32_t nw, float preemph, const float* window,
+                   const float* twiddle, const float* mel_basis, const int32_t* mel_rng, int32_t n_fft, int32_t hop, int32_t win,
+                   int32_t n_mel, float max_abs, float ref_level_db, float* mel_out, float* spec_out, int64_t total_frames,
+                   mstts_stream_t s);
+
 /* ---- skinny (M <= 32 rows per block) weight-streaming products of the recurrent steps -------------
  * fwd: P[ks][M][N] = X[M, K-slice ks] . W[K-slice ks, N]   (W row-major [K,N], ld ldw); ksplit from
  *      mstts_skinny_fwd_splits (0 = shape not supported -> use mstts_gemm_f32).

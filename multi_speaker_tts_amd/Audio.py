@@ -64,13 +64,95 @@ def _constants(num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_rate,
             torch.tensor(fb_t, dtype=torch.float32, device=dev))
 
 
+@functools.lru_cache(maxsize=8)
+def _fft_constants(num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_rate, device):
+    """Tables of the one-launch FFT path (mstts_stft_fft): periodic Hann window, e^{-2 pi i k / n_fft} twiddles, the mel filterbank
+    row-major with each filter's non-zero bin range - all built in float64."""
+    n_fft, hop, win = _stft_parameters(num_freq, frame_shift_ms, frame_length_ms, sample_rate)
+    dev = torch.device(device)
+    n = np.arange(win)
+    hann = 0.5 - 0.5 * np.cos(2 * np.pi * n / win)
+    k = np.arange(n_fft // 2)
+    tw = np.stack([np.cos(2 * np.pi * k / n_fft), -np.sin(2 * np.pi * k / n_fft)], axis=1)
+    fb = mel_filterbank(sample_rate, n_fft, num_mels).astype(np.float32)
+    rng = np.zeros((num_mels, 2), np.int32)
+    for c in range(num_mels):
+        nz = np.nonzero(fb[c])[0]
+        if len(nz):
+            rng[c] = (nz[0], nz[-1] + 1)
+    t = lambda a, dt: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    return n_fft, hop, win, t(hann, torch.float32), t(tw, torch.float32), t(fb, torch.float32), t(rng, torch.int32)
+
+
+def stft_features(wavs, num_freq, frame_shift_ms, frame_length_ms, sample_rate, num_mels=None, max_abs_value=4, ref_level_db=20,
+                  want_mel=True, want_spec=False, device="cuda"):
+    """Mel and / or linear spectrogram features of SEVERAL waveforms in one kernel launch (mstts_stft_fft): returns a list of
+    (mel [frames, num_mels] or None, spec [frames, num_freq] or None) device tensors, one pair per waveform."""
+    n_fft, hop, win, hann, tw, fb, rng = _fft_constants(num_freq, frame_shift_ms, frame_length_ms, num_mels or 1, sample_rate, str(device))
+    dev = hann.device
+    ws = [torch.as_tensor(np.asarray(y, dtype=np.float32)) if not torch.is_tensor(y) else y.to(torch.float32).reshape(-1) for y in wavs]
+    lens = [int(w.numel()) for w in ws]
+    if any(n <= n_fft // 2 for n in lens):
+        raise ValueError("waveform shorter than the STFT's reflect padding (%d samples)" % (n_fft // 2))
+    frames = [1 + n // hop for n in lens]
+    woff = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=dev)
+    foff = torch.tensor(np.concatenate([[0], np.cumsum(frames)]), dtype=torch.int64, device=dev)
+    cat = torch.cat([w.to(dev) for w in ws]).contiguous()
+    total = int(sum(frames))
+    mel = torch.empty(total, num_mels, dtype=torch.float32, device=dev) if want_mel else None
+    spec = torch.empty(total, n_fft // 2 + 1, dtype=torch.float32, device=dev) if want_spec else None
+    lib.call("mstts_stft_fft", lib.ptr(cat), lib.ptr(woff), lib.ptr(foff), len(ws), 0.97, lib.ptr(hann), lib.ptr(tw),
+             lib.ptr(fb) if want_mel else None, lib.ptr(rng) if want_mel else None, n_fft, hop, win, int(num_mels or 0),
+             float(max_abs_value), float(ref_level_db), lib.ptr(mel) if want_mel else None, lib.ptr(spec) if want_spec else None, total)
+    out, f0 = [], 0
+    for fr in frames:
+        out.append((mel[f0:f0 + fr] if want_mel else None, spec[f0:f0 + fr] if want_spec else None))
+        f0 += fr
+    return out
+
+
+def _fft_ok(num_freq, frame_shift_ms, frame_length_ms, sample_rate):
+    n_fft, hop, win = _stft_parameters(num_freq, frame_shift_ms, frame_length_ms, sample_rate)
+    return bool(lib.load().mstts_stft_fft_supported(n_fft, win))
+
+
+def spectrogram(y, num_freq, frame_shift_ms, frame_length_ms, sample_rate, ref_level_db=20, spectral_subtract=False, device="cuda",
+                return_tensor=False):
+    """Audio.py:19-22: normalised linear spectrogram [num_freq, frames] in [0, 1]."""
+    if spectral_subtract:
+        raise NotImplementedError("spectral_subtract is never enabled on the reference's TTS path")
+    (_, spec), = stft_features([y], num_freq, frame_shift_ms, frame_length_ms, sample_rate, ref_level_db=ref_level_db, want_mel=False,
+                               want_spec=True, device=device)
+    spec = spec.t()
+    return spec if return_tensor else spec.cpu().numpy()
+
+
+def spectrogram_and_mel(y, num_freq, frame_shift_ms, frame_length_ms, sample_rate, spect_ref_level_db=20, num_mels=80, max_abs_mels=None,
+                        spectral_subtract=False, device="cuda", return_tensor=False):
+    """Audio.py:34-40: both features from one STFT -> (spectrogram [num_freq, frames], mel [num_mels, frames])."""
+    if spectral_subtract:
+        raise NotImplementedError("spectral_subtract is never enabled on the reference's TTS path")
+    if max_abs_mels is None:
+        raise NotImplementedError("only the symmetric mel normalisation used by the TTS path (Max_Abs_Mel) is built")
+    (mel, spec), = stft_features([y], num_freq, frame_shift_ms, frame_length_ms, sample_rate, num_mels=num_mels, max_abs_value=max_abs_mels,
+                                 ref_level_db=spect_ref_level_db, want_mel=True, want_spec=True, device=device)
+    spec, mel = spec.t(), mel.t()
+    return (spec, mel) if return_tensor else (spec.cpu().numpy(), mel.cpu().numpy())
+
+
 def melspectrogram(y, num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_rate, max_abs_value=None,
-                   spectral_subtract=False, device="cuda", return_tensor=False):
-    """Same signature and result layout ([num_mels, frames]) as the reference function."""
+                   spectral_subtract=False, device="cuda", return_tensor=False, use_fft=True):
+    """Same signature and result layout ([num_mels, frames]) as the reference function.  One launch (FFT in LDS) when n_fft is a
+    power of two - the reference's 2048 is; the DFT-as-GEMM form below covers any other size (use_fft=False forces it)."""
     if spectral_subtract:
         raise NotImplementedError("spectral_subtract is never enabled on the reference's TTS path")
     if max_abs_value is None:
         raise NotImplementedError("only the symmetric normalisation used by the TTS path (Max_Abs_Mel) is built")
+    if use_fft and _fft_ok(num_freq, frame_shift_ms, frame_length_ms, sample_rate):
+        (mel, _), = stft_features([y], num_freq, frame_shift_ms, frame_length_ms, sample_rate, num_mels=num_mels, max_abs_value=max_abs_value,
+                                  device=device)
+        mel = mel.t()
+        return mel if return_tensor else mel.cpu().numpy()
     n_fft, hop, win, nb, basis, fb_t = _constants(num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_rate, str(device))
     wav = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(basis.device) if not torch.is_tensor(y) else y.to(basis.device, torch.float32)
     wav = wav.contiguous()

@@ -35,8 +35,118 @@ __global__ void db_normalize_kernel(float* __restrict__ mel, long n, float max_a
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same transform as ONE launch: a workgroup per frame, real FFT in LDS.
+//   x[i] = window[i - off] * preemph(reflect(f*hop + i - n_fft/2))   (0 outside the window)       Audio.py:42-48,62-64
+//   z[m] = x[2m] + i x[2m+1]  ->  Stockham radix-2 FFT of n_fft/2 complex points (ping-pong LDS buffers, twiddles from a table
+//   built in fp64 on the host)  ->  X[k] = E[k] + e^{-2 pi i k / n_fft} O[k]  ->  |X[k]|, k = 0 .. n_fft/2
+//   spec_out = clip((20 log10(max(1e-5, |X|)) - ref_db + 100) / 100, 0, 1)                          Audio.py:19-22,91-92
+//   mel_out  = symmetric-normalised dB of mel_basis . |X| over each filter's non-zero bin range     Audio.py:29-32,78-80,94-96
+// Several waveforms per launch: frame g belongs to waveform w with frame_off[w] <= g < frame_off[w + 1].
+// Algorithmic bytes per frame: hop new samples in, n_mel (+ n_fft/2 + 1) floats out; 5 N log2 N flops - the kernel is bound by
+// LDS round trips (log2(N/2) stages), a few microseconds per workgroup, 4+ workgroups resident per CU.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__ wav, const long* __restrict__ wav_off,
+                                                       const long* __restrict__ frame_off, int nw, float coef,
+                                                       const float* __restrict__ window, const float2* __restrict__ tw,
+                                                       const float* __restrict__ mel_basis, const int* __restrict__ mel_rng, int n_fft, int hop,
+                                                       int win, int n_mel, float max_abs, float ref_db, float* __restrict__ mel_out,
+                                                       float* __restrict__ spec_out) {
+    extern __shared__ __attribute__((aligned(16))) float2 fft_lds[];
+    const int N2 = n_fft >> 1, tid = threadIdx.x;
+    float2* bufa = fft_lds;
+    float2* bufb = fft_lds + N2;
+    const long g = blockIdx.x;
+    int w = 0;
+    for (int lo = 0, hi = nw; hi - lo > 1;) {            // uniform binary search: frame_off[w] <= g
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] <= g) lo = mid; else hi = mid;
+        w = lo;
+    }
+    const long f = g - frame_off[w], n = wav_off[w + 1] - wav_off[w];
+    const float* x = wav + wav_off[w];
+    const int off = (n_fft - win) >> 1, pad = n_fft >> 1;
+    auto sample = [&](int i) -> float {                  // windowed, pre-emphasised, reflect-padded sample i of this frame
+        if (i < off || i >= off + win) return 0.f;
+        long j = f * hop + i - pad;
+        if (j < 0) j = -j;
+        if (j >= n) j = 2 * (n - 1) - j;
+        if (j < 0) j = 0;
+        const float prev = j > 0 ? x[j - 1] : 0.f;
+        return window[i - off] * (x[j] - coef * prev);
+    };
+    for (int m = tid; m < N2; m += 256) bufa[m] = make_float2(sample(2 * m), sample(2 * m + 1));
+    __syncthreads();
+    const int tstep = 2;                                 // tw[k] = e^{-2 pi i k / n_fft}; the half-size transform uses every second entry
+    for (int Ns = 1; Ns < N2; Ns <<= 1) {
+        const int tmul = (N2 / (2 * Ns)) * tstep;
+        for (int j = tid; j < (N2 >> 1); j += 256) {
+            const int k = j & (Ns - 1);
+            const float2 a = bufa[j], b = bufa[j + (N2 >> 1)], t = tw[k * tmul];
+            const float2 bt = make_float2(b.x * t.x - b.y * t.y, b.x * t.y + b.y * t.x);
+            const int j0 = ((j - k) << 1) + k;
+            bufb[j0] = make_float2(a.x + bt.x, a.y + bt.y);
+            bufb[j0 + Ns] = make_float2(a.x - bt.x, a.y - bt.y);
+        }
+        __syncthreads();
+        float2* t_ = bufa; bufa = bufb; bufb = t_;
+    }
+    // real-input post-processing -> magnitudes in LDS (bufb is free)
+    float* mag = reinterpret_cast<float*>(bufb);
+    const int NB = N2 + 1;
+    for (int k = tid; k < NB; k += 256) {
+        const float2 zk = bufa[k & (N2 - 1)], zc = bufa[(N2 - k) & (N2 - 1)];
+        const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);           // E = (Z[k] + conj(Z[N2-k])) / 2
+        const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);         // O = -i (Z[k] - conj(Z[N2-k])) / 2
+        const float2 t = k < N2 ? tw[k] : make_float2(-1.f, 0.f);
+        const float re = er + orr * t.x - oi * t.y, im = ei + orr * t.y + oi * t.x;
+        const float m = sqrtf(re * re + im * im);
+        mag[k] = m;
+        if (spec_out) {
+            const float db = 20.f * log10f(fmaxf(1e-5f, m)) - ref_db;
+            spec_out[g * NB + k] = fminf(fmaxf((db + 100.f) * 0.01f, 0.f), 1.f);
+        }
+    }
+    __syncthreads();
+    if (!mel_out) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c = wave; c < n_mel; c += 4) {
+        const int lo = mel_rng[2 * c], hi = mel_rng[2 * c + 1];
+        const float* row = mel_basis + (long)c * NB;
+        float acc = 0.f;
+        for (int b = lo + lane; b < hi; b += 64) acc = fmaf(row[b], mag[b], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            const float db = 20.f * log10f(fmaxf(1e-5f, acc));
+            const float v = (2.f * max_abs) * ((db + 100.f) * 0.01f) - max_abs;
+            mel_out[g * n_mel + c] = fminf(fmaxf(v, -max_abs), max_abs);
+        }
+    }
+}
+
 }  // namespace mstts
 using namespace mstts;
+
+extern "C" int mstts_stft_fft_supported(int32_t n_fft, int32_t win) {
+    return n_fft >= 512 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0 && win >= 2 && win <= n_fft;
+}
+
+extern "C" int mstts_stft_fft(const float* wav, const int64_t* wav_off, const int64_t* frame_off, int32_t nw, float preemph,
+                              const float* window, const float* twiddle, const float* mel_basis, const int32_t* mel_rng, int32_t n_fft,
+                              int32_t hop, int32_t win, int32_t n_mel, float max_abs, float ref_level_db, float* mel_out, float* spec_out,
+                              int64_t total_frames, mstts_stream_t s) {
+    MSTTS_REQUIRE(wav && wav_off && frame_off && window && twiddle && (mel_out || spec_out), MSTTS_ERR_SHAPE, "stft_fft: null pointer");
+    MSTTS_REQUIRE(!mel_out || (mel_basis && mel_rng && n_mel >= 1), MSTTS_ERR_SHAPE, "stft_fft: mel output needs the filterbank and its ranges");
+    MSTTS_REQUIRE(mstts_stft_fft_supported(n_fft, win) && hop >= 1 && nw >= 1, MSTTS_ERR_SHAPE, "stft_fft: n_fft must be a power of two in [512, 4096]");
+    MSTTS_REQUIRE(total_frames >= 0 && total_frames < (1LL << 31), MSTTS_ERR_SHAPE, "stft_fft: frame count");
+    if (total_frames == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)total_frames), dim3(256), sizeof(float2) * (size_t)n_fft, (hipStream_t)s, wav,
+                       (const long*)wav_off, (const long*)frame_off, (int)nw, preemph, window, (const float2*)twiddle, mel_basis,
+                       (const int*)mel_rng, (int)n_fft, (int)hop, (int)win, (int)n_mel, max_abs, ref_level_db, mel_out, spec_out);
+    MSTTS_CHECK_LAUNCH("stft_fft");
+    return MSTTS_OK;
+}
 
 static inline long nb_of(int n_fft) { return ((n_fft / 2 + 1) + 3) / 4 * 4; }
 

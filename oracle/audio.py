@@ -87,3 +87,18 @@ def melspectrogram(y, num_freq=1025, frame_shift_ms=12.5, frame_length_ms=50, nu
     if max_abs_value is None:
         return np.clip((S + 100) / 100, 0, 1)
     return np.clip((2 * max_abs_value) * ((S + 100) / 100) - max_abs_value, -max_abs_value, max_abs_value)
+
+
+def spectrogram(y, num_freq=1025, frame_shift_ms=12.5, frame_length_ms=50, sample_rate=16000, ref_level_db=20):
+    """Audio.py:19-22 (+ :42-44, :88-92) -> normalised linear spectrogram [num_freq, frames] in [0, 1]."""
+    n_fft, hop, win = stft_parameters(num_freq, frame_shift_ms, frame_length_ms, sample_rate)
+    M = np.abs(stft(preemphasis(y), n_fft, hop, win))
+    S = 20 * np.log10(np.maximum(1e-5, M)) - ref_level_db
+    return np.clip((S + 100) / 100, 0, 1)
+
+
+def spectrogram_and_mel(y, num_freq=1025, frame_shift_ms=12.5, frame_length_ms=50, sample_rate=16000, spect_ref_level_db=20, num_mels=80,
+                        max_abs_mels=4):
+    """Audio.py:34-40: both features of one STFT."""
+    return (spectrogram(y, num_freq, frame_shift_ms, frame_length_ms, sample_rate, spect_ref_level_db),
+            melspectrogram(y, num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_rate, max_abs_mels))

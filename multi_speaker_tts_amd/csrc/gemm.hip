@@ -12,6 +12,7 @@
 // ZoneoutLSTMCell.py:228) and their autodiff gradients.
 #include "common.h"
 #include <type_traits>
+#include <cmath>
 
 namespace mstts {
 
@@ -47,22 +48,34 @@ struct LoaderKC {
     static constexpr int NV = R * BK / 4 / 256;      // float4 per thread
     float4 reg[NV];
     // window: element (row, k) is tap j = k / C of a dilated 'same' conv: source row = row + (j - pad) * dil, valid iff it
-    // stays inside the row's length-T sequence (dil == 1: the taps of a row are contiguous, address = (row - pad) * ld + k)
+    // stays inside the row's length-T sequence (dil == 1: the taps of a row are contiguous, address = (row - pad) * ld + k).
+    // The divisions are hoisted: a thread's rows never change (t_row = row % T once) and k advances by BK per load (tap / kc kept
+    // incrementally) - prepare() once, then load() for k0, k0 + BK, ...
+    int t_row[NV], tap, kc;
+    __device__ __forceinline__ void prepare(int row0, int k0, int wT, int wC) {
+        if (wT > 0) {
+            const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t_row[i] = (row0 + r + i * 32) % wT;
+            const int k = k0 + k4 * 4;
+            tap = k / wC; kc = k - tap * wC;
+        }
+    }
     __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int row0, int k0,
                                          int rows, int kmax, int wT, int wC, int wpad, int wdil) {
         const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
+        const int k = k0 + k4 * 4;
+        const int sh = wT > 0 ? (tap - wpad) * wdil : 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int row = row0 + r + i * 32;
-            const int k = k0 + k4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             bool ok = row < rows && k < kmax;
             long off = (long)row * ld + k;
             if (wT > 0) {
-                const int sh = (k / wC - wpad) * wdil;
-                const int t = row % wT + sh;
+                const int t = t_row[i] + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)row + sh) * ld + k % wC;
+                off = ((long)row + sh) * ld + kc;
             }
             if (ok) {
                 if (VEC) {
@@ -75,6 +88,10 @@ struct LoaderKC {
                 }
             }
             reg[i] = v;
+        }
+        if (wT > 0) {                                  // next call is for k0 + BK
+            kc += BK;
+            while (kc >= wC) { kc -= wC; ++tap; }
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ s, int ldS) const {
@@ -95,21 +112,34 @@ struct LoaderMC {
     float4 reg[NV];
     // window (A only): element (m, kk) with kk=(b,t) row index, m=(tap, c):
     //   valid iff 0 <= (kk % T) + m / C - pad < T; address = base[(kk - pad) * ld + m]
+    // hoisted like LoaderKC: a thread's column (tap, c) is fixed, its k-rows advance by BK per load.
+    int sh, cm, t_k[NV];
+    __device__ __forceinline__ void prepare(int col0, int k0, int wT, int wC, int wpad, int wdil) {
+        if (wT > 0) {
+            const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
+            const int col = col0 + c4 * 4;
+            const int tp = col / wC;
+            sh = (tp - wpad) * wdil; cm = col - tp * wC;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t_k[i] = (k0 + kr + i * KR) % wT;
+        }
+    }
     __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int col0, int k0,
                                          int cols, int kmax, int wT, int wC, int wpad, int wdil) {
         const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
+        const int col = col0 + c4 * 4;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int k = k0 + kr + i * KR;
-            const int col = col0 + c4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             bool ok = k < kmax && col < cols;
             long off = (long)k * ld + col;
             if (wT > 0) {
-                const int sh = (col / wC - wpad) * wdil;
-                const int t = k % wT + sh;
+                const int t = t_k[i] + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)k + sh) * ld + col % wC;
+                off = ((long)k + sh) * ld + cm;
+                t_k[i] += BK;                          // next call is for k0 + BK
+                while (t_k[i] >= wT) t_k[i] -= wT;
             }
             if (ok) {
                 if (VEC) {
@@ -165,8 +195,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     LA la; LB lb;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // wave tiling: BM=128 -> 2x2 waves of 64x64 ; BM=32 -> 1x4 waves of 32x32
-    constexpr int WM = (BM == 128) ? 2 : 1;           // 32-row MFMA tiles per wave
+    // wave tiling: BM=128 -> 2x2 waves of 64x64 ; BM=64 -> 1x4 waves of 64x32 ; BM=32 -> 1x4 waves of 32x32
+    constexpr int WM = (BM >= 64) ? 2 : 1;            // 32-row MFMA tiles per wave
     constexpr int WN = (BM == 128) ? 2 : 1;
     const int wm = (BM == 128) ? (wave >> 1) : 0;
     const int wn = (BM == 128) ? (wave & 1) : wave;
@@ -180,6 +210,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (TA) la.prepare(m0, kbeg, g.win_T, g.win_C, g.win_pad, g.win_dil);
+    else la.prepare(m0, kbeg, g.win_T, g.win_C);
     if (kbeg < kend) {
         la.load(A, g.lda, m0, kbeg, g.M, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
         lb.load(B, g.ldb, n0, kbeg, g.N, kend, 0, 1, 0, 1);
@@ -278,7 +310,15 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     vec = vec && (d->trans_b ? (d->K % 4 == 0) : (d->N % 4 == 0));
     if (d->win_T > 0) vec = vec && (d->win_C % 4 == 0);
     const bool skinny = d->M <= 32;
-    const int bm = skinny ? 32 : 128;
+    // 128-row tiles unless 64-row tiles fill the 256 CUs' rounds visibly better (25 632 x 512: 804 tiles = 3.14 rounds -> 4, but
+    // 1 608 half tiles = 6.28 -> 7; 4 096 x 512: 128 tiles use half the chip, 256 half tiles all of it); the half tile re-reads
+    // the B operand twice as often, so it has to win by more than 5 %
+    int bm = skinny ? 32 : 128;
+    if (!skinny) {
+        const double t128 = (double)cdiv(d->M, 128) * cdiv(d->N, BN) * batch * split, t64 = (double)cdiv(d->M, 64) * cdiv(d->N, BN) * batch * split;
+        const double e128 = t128 / (ceil(t128 / 256.0) * 256.0), e64 = t64 / (ceil(t64 / 256.0) * 256.0);
+        if (e64 * 0.95 > e128) bm = 64;
+    }
     dim3 grid(cdiv(d->M, bm) * cdiv(d->N, BN), 1, batch * split);
     hipStream_t st = (hipStream_t)stream;
     const bool ta = d->trans_a != 0, tb = d->trans_b != 0;
@@ -287,6 +327,11 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
         else if (!ta && tb) launch_gemm<32, false, true>(g, vec, grid, st);
         else if (ta && !tb) launch_gemm<32, true, false>(g, vec, grid, st);
         else launch_gemm<32, true, true>(g, vec, grid, st);
+    } else if (bm == 64) {
+        if (!ta && !tb) launch_gemm<64, false, false>(g, vec, grid, st);
+        else if (!ta && tb) launch_gemm<64, false, true>(g, vec, grid, st);
+        else if (ta && !tb) launch_gemm<64, true, false>(g, vec, grid, st);
+        else launch_gemm<64, true, true>(g, vec, grid, st);
     } else {
         if (!ta && !tb) launch_gemm<128, false, false>(g, vec, grid, st);
         else if (!ta && tb) launch_gemm<128, false, true>(g, vec, grid, st);

@@ -267,8 +267,9 @@ def main():
                            "traffic": pmc_traffic_bytes("lsa_step_kernel") if (L == L_MEL and world == 1) else None,
                            "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT), "algorithmic_bytes_per_launch": att_bytes,
                            "avg_launch_us": att_us, "event_bracket_us": raw_us["lsa_step_fwd"], "empty_bracket_us": empty_us["lsa_step_fwd"]}
-        w0 = (M + H) * 4 * H * 4
-        w1 = 2 * H * 4 * H * 4
+        wb = 2 if args.recurrent_dtype == "bf16" else 4          # the recurrent kernels stream bf16 copies in that mode
+        w0 = (M + H) * 4 * H * wb
+        w1 = 2 * H * 4 * H * wb
         extra = []
         for nm, byts in (("cell0_gemm_fwd", w0), ("cell1_gemm_fwd", w1), ("cell0_dgemm_bwd", w0), ("cell1_dgemm_bwd", w1)):
             a = byts / (avg_us[nm] * 1e-6) / 1e9

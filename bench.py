@@ -199,7 +199,8 @@ def main():
     eng = TrainEngine(dims, device=device, seed=1234, rank=rank, world=world, recurrent_dtype=args.recurrent_dtype,
                       gemm_dtype="bf16" if args.config3 else "f32")
     batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
-    reducer = GradAllReduce(eng.params.grad, world) if world > 1 else None
+    # config 3: bf16 gradient message with fp32 accumulation on receipt; the fp32 headline keeps the fp32 all-reduce
+    reducer = GradAllReduce(eng.params.grad, world, comm_dtype="bf16" if args.config3 else "f32") if world > 1 else None
 
     def sync():
         if dist is not None:

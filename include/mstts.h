@@ -537,6 +537,12 @@ int32_t mstts_decoder_infer_fast(int64_t B, int64_t H, int64_t P, int64_t M, int
 int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);
 int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel);
 
+/* ---- bf16 gradient exchange (BASELINE config 3, dist.GradAllReduce(comm_dtype="bf16")): the message is bf16, the sum is fp32.
+ * f32_to_bf16 rounds to nearest even; bf16_chunks_sum: out[i] = bf16(sum_r float(chunks[r*stride + i])), r = 0..nchunks-1 in order. */
+int mstts_f32_to_bf16(const float* x, void* y_bf16, int64_t n, mstts_stream_t s);
+int mstts_bf16_to_f32(const void* x_bf16, float* y, int64_t n, mstts_stream_t s);
+int mstts_bf16_chunks_sum(const void* chunks_bf16, int32_t nchunks, int64_t stride, int64_t n, void* out_bf16, mstts_stream_t s);
+
 /* ---- profiling probes (bench.py only; process-global, not thread-safe, never armed on the product
  * path): HIP events bracket every launch of one kernel kind inside the decoder loop drivers, on the
  * launch stream.  begin(kind, max_launches) arms (kind 0 disarms); after a stream synchronise,

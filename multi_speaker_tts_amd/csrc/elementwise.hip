@@ -919,6 +919,46 @@ extern "C" int mstts_relu_dropout_bwd(const float* dy, const float* y_saved, con
     MSTTS_CHECK_LAUNCH("relu_dropout_bwd");
     return MSTTS_OK;
 }
+// ---- bf16 gradient exchange (BASELINE config 3: bf16 message, fp32 accumulation on receipt) ----------------------------------
+namespace mstts {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (__bf16)x[i];   // RNE
+}
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+// out[i] = bf16( sum_r float(chunks[r * stride + i]) ), the sum in fp32 in rank order (deterministic)
+__global__ void bf16_chunks_sum_kernel(const __bf16* __restrict__ chunks, int nchunks, long stride, long n, __bf16* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int r = 0; r < nchunks; ++r) a += (float)chunks[r * stride + i];
+        out[i] = (__bf16)a;
+    }
+}
+}  // namespace mstts
+extern "C" int mstts_f32_to_bf16(const float* x, void* y, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    MSTTS_REQUIRE(x && y, MSTTS_ERR_SHAPE, "f32_to_bf16: null pointer");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), x, (__bf16*)y, (long)n);
+    MSTTS_CHECK_LAUNCH("f32_to_bf16");
+    return MSTTS_OK;
+}
+extern "C" int mstts_bf16_to_f32(const void* x, float* y, int64_t n, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    MSTTS_REQUIRE(x && y, MSTTS_ERR_SHAPE, "bf16_to_f32: null pointer");
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), (const __bf16*)x, y, (long)n);
+    MSTTS_CHECK_LAUNCH("bf16_to_f32");
+    return MSTTS_OK;
+}
+extern "C" int mstts_bf16_chunks_sum(const void* chunks, int32_t nchunks, int64_t stride, int64_t n, void* out, mstts_stream_t s) {
+    if (n == 0) return MSTTS_OK;
+    MSTTS_REQUIRE(chunks && out && nchunks >= 1 && stride >= n, MSTTS_ERR_SHAPE, "bf16_chunks_sum: bad arguments");
+    hipLaunchKernelGGL(bf16_chunks_sum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), (const __bf16*)chunks, (int)nchunks, (long)stride, (long)n,
+                       (__bf16*)out);
+    MSTTS_CHECK_LAUNCH("bf16_chunks_sum");
+    return MSTTS_OK;
+}
+
 extern "C" int mstts_add(const float* a, const float* b, float* y, int64_t n, mstts_stream_t s) {
     if (n == 0) return MSTTS_OK;
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), a, b, y, (long)n);

@@ -58,21 +58,65 @@ def average_(tensors, group=None):
 
 
 class GradAllReduce:
-    def __init__(self, grad_slab: torch.Tensor, world: int, bucket_mb: float = 32.0, group=None, force: bool = False):
-        """force: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)."""
+    def __init__(self, grad_slab: torch.Tensor, world: int, bucket_mb: float = 32.0, group=None, force: bool = False,
+                 comm_dtype: str = "f32"):
+        """force: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU).
+        comm_dtype "bf16" (BASELINE config 3): the message is bf16, the accumulation fp32 - each piece is rounded to bf16, every
+        rank receives its 1/world shard of every rank's piece (all-to-all), sums the shards in fp32 in rank order, rounds the sum
+        once and all-gathers it: half the bytes of the fp32 all-reduce on every xGMI link, and no bf16 partial sums anywhere.
+        The exchange runs on its own stream (ordered after the producing kernels, joined in finish())."""
+        if comm_dtype not in ("f32", "bf16"):
+            raise ValueError("comm_dtype must be 'f32' or 'bf16'")
         self.world, self.group = world, group
         self.active = world > 1 or force
+        self.bf16 = comm_dtype == "bf16"
         n = grad_slab.numel()
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         self.bounds = [(s, min(n, s + per)) for s in range(0, n, per)]
 
         self.n = n
         self._works, self._done = [], []
+        self._side = None
+        if self.bf16 and self.active:
+            import torch.distributed as dist
+            self._nr = dist.get_world_size(group)                      # ranks in the exchange (1 in the forced one-rank form)
+            cap = (per + self._nr - 1) // self._nr * self._nr        # a piece padded to a multiple of the rank count
+            z = lambda m: torch.zeros(m, dtype=torch.bfloat16, device=grad_slab.device)
+            self._send, self._recv, self._shard, self._out = z(cap), z(cap), z(cap // self._nr), z(cap)
+            if grad_slab.is_cuda:
+                self._side = torch.cuda.Stream(device=grad_slab.device)
 
     def __call__(self, grad_slab: torch.Tensor):
         """Whole slab at once (after backward)."""
         self.start(grad_slab, 0, self.n)
         self.finish(grad_slab)
+
+    # -- bf16 message, fp32 accumulate: one piece, on the current stream (the side stream on a GPU) --
+    def _exchange_bf16(self, g: torch.Tensor):
+        import torch.distributed as dist
+        m, nr = g.numel(), self._nr
+        chunk = (m + nr - 1) // nr
+        send, recv, shard, out = self._send[:chunk * nr], self._recv[:chunk * nr], self._shard[:chunk], self._out[:chunk * nr]
+        if g.is_cuda:
+            from . import lib
+            lib.call("mstts_f32_to_bf16", lib.ptr(g), lib.ptr(send), m)
+            if chunk * nr > m:
+                send[m:].zero_()
+            dist.all_to_all_single(recv, send, group=self.group)                    # recv[r*chunk:(r+1)*chunk] = rank r's shard for me
+            lib.call("mstts_bf16_chunks_sum", lib.ptr(recv), nr, chunk, chunk, lib.ptr(shard))
+            dist.all_gather_into_tensor(out, shard, group=self.group)
+            lib.call("mstts_bf16_to_f32", lib.ptr(out), lib.ptr(g), m)
+        else:                               # CPU tensors (the gloo tests): the same arithmetic with torch ops
+            send[:m] = g.to(torch.bfloat16)
+            send[m:].zero_()
+            dist.all_to_all_single(recv, send, group=self.group)
+            acc = torch.zeros(chunk, dtype=torch.float32)
+            for r in range(nr):
+                acc += recv[r * chunk:(r + 1) * chunk].float()
+            shard.copy_(acc.to(torch.bfloat16))
+            parts = [torch.empty_like(shard) for _ in range(nr)]
+            dist.all_gather(parts, shard, group=self.group)
+            g.copy_(torch.cat(parts)[:m].float())
 
     def start(self, grad_slab: torch.Tensor, lo: int, hi: int):
         """Asynchronously sum grad_slab[lo:hi] over the ranks (in <= bucket-size pieces).  Call it at the point of the
@@ -82,6 +126,17 @@ class GradAllReduce:
             return
         import torch.distributed as dist
         per = self.bounds[0][1] - self.bounds[0][0]
+        if self.bf16:
+            if self._side is not None:
+                self._side.wait_stream(torch.cuda.current_stream(grad_slab.device))
+                with torch.cuda.stream(self._side):
+                    for a in range(lo, hi, per):
+                        self._exchange_bf16(grad_slab[a:min(hi, a + per)])
+            else:
+                for a in range(lo, hi, per):
+                    self._exchange_bf16(grad_slab[a:min(hi, a + per)])
+            self._done += [(a, min(hi, a + per)) for a in range(lo, hi, per)]
+            return
         for a in range(lo, hi, per):
             b = min(hi, a + per)
             self._works.append(dist.all_reduce(grad_slab[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -98,4 +153,6 @@ class GradAllReduce:
             pos = max(pos, b)
         for w in self._works:
             w.wait()
+        if self._side is not None:
+            torch.cuda.current_stream(grad_slab.device).wait_stream(self._side)
         self._works, self._done = [], []

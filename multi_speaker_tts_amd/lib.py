@@ -196,6 +196,9 @@ SIGNATURES = {
     "mstts_decoder_infer_fast": (i32, [i64, i64, i64, i64, i64, i64]),
     "mstts_decoder_infer_steps": (i32, [P(DecoderInfer), i64, i64, vp]),
     "mstts_decoder_infer_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
+    "mstts_f32_to_bf16": (i32, [vp, vp, i64, vp]),
+    "mstts_bf16_to_f32": (i32, [vp, vp, i64, vp]),
+    "mstts_bf16_chunks_sum": (i32, [vp, i32, i64, i64, vp, vp]),
     "mstts_probe_begin": (i32, [i32, i64]),
     "mstts_probe_result": (i64, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -64,6 +64,18 @@ def _worker_helpers(rank, world, port, q, tmp):
     red = D.GradAllReduce(g, world, force=True)
     red(g)
     assert torch.equal(g, torch.full((10,), 3.0))
+    # config-3 exchange: bf16 message, fp32 accumulation in rank order, one rounding of the sum; pieces that do not divide by the
+    # rank count, started out of order like the train step does
+    base = torch.linspace(-3.0, 3.0, 1001) * 1.2345
+    mine = base * (rank + 1) + 0.001 * rank
+    want = ((base * 1 + 0.0).to(torch.bfloat16).float() + (base * 2 + 0.001).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    h = mine.clone()
+    red16 = D.GradAllReduce(h, world, bucket_mb=0.001, comm_dtype="bf16")      # 262-element pieces
+    assert red16.bf16 and len(red16.bounds) > 2
+    red16.start(h, 500, 1001)
+    red16.start(h, 100, 500)
+    red16.finish(h)
+    assert torch.equal(h, want), (h - want).abs().max()
     # feeder sharding: the ranks walk the same shuffled batch list of an epoch and take disjoint, interleaved parts of it
     import pickle
     import random

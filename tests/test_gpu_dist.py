@@ -50,6 +50,21 @@ def test_train_step_through_rccl_one_rank(dev):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
         sa, sb = plain.scalars(wa), dp.scalars(wb, average=True)          # averaged scalars: an all-reduce of four floats
         assert abs(sa["Loss"] - sb["Loss"]) < 1e-4 * abs(sa["Loss"])
+        # config-3 exchange on real RCCL (all-to-all + all-gather of bf16 on the exchange's own stream, HIP pack / sum / unpack
+        # kernels): over one rank the result is the gradient rounded to bf16, and the step after it must stay finite
+        g = dp.params.grad
+        dp.forward(batch, wb)
+        dp.loss_and_backward(wb)
+        ref16 = g.clone().to(torch.bfloat16).float()
+        red16 = D.GradAllReduce(g, 1, bucket_mb=0.25, force=True, comm_dtype="bf16")
+        red16.start(g, g.numel() // 2, g.numel())
+        red16.start(g, 0, g.numel() // 3)
+        red16.finish(g)                                                   # picks up the middle third itself
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref16)
+        wc = dp.train_step(batch, all_reduce=red16)
+        torch.cuda.synchronize()
+        assert np.isfinite(dp.scalars(wc)["Loss"]) and bool(torch.isfinite(dp.params.train).all())
         before = dp.params.frozen.clone()
         dp.sync_statistics()                                              # BN moving statistics averaged over (one) rank
         assert len(dp.moving_stat_ranges()) >= 2 and torch.allclose(before, dp.params.frozen)

@@ -814,75 +814,94 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
 //   d_keys[b,t,k] += g ; d_loc_k[j,k] += cum[t+j-pad] g ; d_score_w[k] += d_e u ; d_score_b[k] += g
 // (d_loc_b == d_score_b: both biases add to the same pre-activation)
 // ---------------------------------------------------------------------------------------------
+// Both contractions with the 31-tap window are matrix products and run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
+// fp32): for one (b, s) and a tile of 32 encoder positions, with W[t][j] = cum[t + j - pad] (a 32 x 32 Toeplitz tile read straight
+// from the LDS window),
+//     L  = W . loc_k          [32 t x 32 j] . [32 j x 128 a]      -> pre-activation -> u, g (VALU, in the MFMA C layout)
+//     dK = W^T . g            [32 j x 32 t] . [32 t x 128 a]      -> d_loc_k
+// The reduction order over t in the second product is free, so its k-step r takes the rows the C layout already holds in register r
+// (lane half h: row (r&3) + 8(r>>2) + 4h) - g never leaves its registers.  Wave w owns attention units 32w .. 32w+31; a workgroup
+// walks a chunk of steps for one (row, tile); accumulators (d_keys tile, d_loc_k, d_score_w/b) stay in registers over the chunk.
+constexpr int PT = 32;                      // encoder positions per workgroup
+typedef float lp_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, int S, int steps_per_block,
                                                             const float* __restrict__ q_hist, const float* __restrict__ cum_hist,
                                                             const float* __restrict__ de_hist, float* __restrict__ d_keys,
                                                             float* __restrict__ d_loc_k, float* __restrict__ d_score_w,
                                                             float* __restrict__ d_score_b) {
-    __shared__ float s_cum[2][TS + KS_MAX - 1];
-    __shared__ float s_de[2][TS];
-    const int b = blockIdx.x, t0 = blockIdx.y * TS, T = (int)c.T, B = (int)c.B, KS = (int)c.KS, pad = (KS - 1) / 2;
+    __shared__ float s_win[2][PT + 32];     // cum[t0 - pad + i], i < PT + KS - 1 (zero outside the sequence and past the window)
+    __shared__ float s_de[2][PT];
+    const int b = blockIdx.x, t0 = blockIdx.y * PT, T = (int)c.T, B = (int)c.B, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int s_beg = blockIdx.z * steps_per_block, s_end = min(S, s_beg + steps_per_block);
-    const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
-    float lk[KS_MAX], acc_lk[KS_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int a = wave * 32 + l31;
+    // B operand of the first product: loc_k rows 2kk + kh of this wave's 32 columns (zero rows beyond the KS taps)
+    float lkb[16];
 #pragma unroll
-    for (int j = 0; j < KS_MAX; ++j) { lk[j] = (j < KS) ? c.loc_k[j * A_ + k] : 0.f; acc_lk[j] = 0.f; }
-    const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
-    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
-    float key_v[TS / 2], acc_keys[TS / 2];
+    for (int kk = 0; kk < 16; ++kk) lkb[kk] = (2 * kk + kh < KS) ? c.loc_k[(2 * kk + kh) * A_ + a] : 0.f;
+    const float sb = c.score_b[a] + c.loc_b[a], wk = c.score_w[a];
+    float key_v[16];
+    lp_f32x16 acc_keys, acc_lk;
 #pragma unroll
-    for (int i = 0; i < TS / 2; ++i) { key_v[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f; acc_keys[i] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        key_v[r] = t < T ? c.keys[((long)b * T + t) * A_ + a] : 0.f;
+        acc_keys[r] = 0.f; acc_lk[r] = 0.f;
+    }
     float acc_w = 0.f, acc_b = 0.f;
-    // software pipeline: the window / d_e / q of step s+1 are loaded while step s is processed
-    auto load_cum = [&](int s) -> float {
+    auto load_win = [&](int s) -> float {      // threads 0 .. PT+31: window; threads 128 .. 128+PT-1: d_e
         float v = 0.f;
-        if (threadIdx.x < TS + KS - 1) {
+        if (threadIdx.x < PT + KS - 1) {
             const int t = t0 - pad + threadIdx.x;
             if (t >= 0 && t < T) v = cum_hist[((long)s * B + b) * T + t];
+        } else if (threadIdx.x >= 128 && threadIdx.x < 128 + PT) {
+            const int t = t0 + (threadIdx.x - 128);
+            if (t < T) v = de_hist[((long)s * B + b) * T + t];
         }
         return v;
     };
-    auto load_de = [&](int s) -> float {
-        const int t = t0 + (threadIdx.x - 128);
-        return (threadIdx.x >= 128 && threadIdx.x < 128 + TS && t < T) ? de_hist[((long)s * B + b) * T + t] : 0.f;
-    };
-    float ncum = 0.f, nde = 0.f, nq = 0.f;
-    if (s_beg < s_end) { ncum = load_cum(s_beg); nde = load_de(s_beg); nq = q_hist[((long)s_beg * B + b) * A_ + k]; }
+    float nv = 0.f, nq = 0.f;
+    if (s_beg < s_end) { nv = load_win(s_beg); nq = q_hist[((long)s_beg * B + b) * A_ + a]; }
     int buf = 0;
     for (int s = s_beg; s < s_end; ++s, buf ^= 1) {
-        if (threadIdx.x < TS + KS_MAX - 1) s_cum[buf][threadIdx.x] = ncum;   // zero past the KS-tap window
-        if (threadIdx.x >= 128 && threadIdx.x < 128 + TS) s_de[buf][threadIdx.x - 128] = nde;
+        if (threadIdx.x < PT + 32) s_win[buf][threadIdx.x] = nv;
+        else if (threadIdx.x >= 128 && threadIdx.x < 128 + PT) s_de[buf][threadIdx.x - 128] = nv;
         const float qk = nq + sb;
-        if (s + 1 < s_end) { ncum = load_cum(s + 1); nde = load_de(s + 1); nq = q_hist[((long)(s + 1) * B + b) * A_ + k]; }
+        if (s + 1 < s_end) { nv = load_win(s + 1); nq = q_hist[((long)(s + 1) * B + b) * A_ + a]; }
         __syncthreads();                    // buf written; the other buffer is free to be rewritten next iteration
+        const float* win = s_win[buf];
+        lp_f32x16 L;
 #pragma unroll
-        for (int i = 0; i < TS / 2; ++i) {
-            const int tt = grp + 2 * i;
-            if (t0 + tt < T) {
-                float pre = key_v[i] + qk;
+        for (int r = 0; r < 16; ++r) L[r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < KS_MAX; ++j) pre += s_cum[buf][tt + j] * lk[j];
-                const float u = fast_tanh(pre);
-                const float de = s_de[buf][tt];
-                const float g = de * wk * (1.f - u * u);
-                acc_w += de * u;
-                acc_b += g;
-                acc_keys[i] += g;
+        for (int kk = 0; kk < 16; ++kk)      // A[t = l31][j = 2kk + kh] = win[l31 + 2kk + kh]
+            L = __builtin_amdgcn_mfma_f32_32x32x2f32(win[l31 + 2 * kk + kh], lkb[kk], L, 0, 0, 0);
+        float g[16];
 #pragma unroll
-                for (int j = 0; j < KS_MAX; ++j) acc_lk[j] += s_cum[buf][tt + j] * g;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float de = s_de[buf][(r & 3) + 8 * (r >> 2) + 4 * kh];          // 0 beyond T
+            const float u = fast_tanh(L[r] + key_v[r] + qk);
+            g[r] = de * wk * (1.f - u * u);
+            acc_w += de * u;
+            acc_b += g[r];
+            acc_keys[r] += g[r];
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)         // k-step r: rows t = (r&3) + 8(r>>2) + 4kh; A[j = l31][t] = win[t + l31]
+            acc_lk = __builtin_amdgcn_mfma_f32_32x32x2f32(win[(r & 3) + 8 * (r >> 2) + 4 * kh + l31], g[r], acc_lk, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < TS / 2; ++i) {
-        const int tt = grp + 2 * i;
-        if (t0 + tt < T) atomicAdd(d_keys + ((long)b * T + t0 + tt) * A_ + k, acc_keys[i]);
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (t0 + row < T) atomicAdd(d_keys + ((long)b * T + t0 + row) * A_ + a, acc_keys[r]);
+        if (row < KS) atomicAdd(d_loc_k + row * A_ + a, acc_lk[r]);                 // row = tap j here
     }
-#pragma unroll
-    for (int j = 0; j < KS_MAX; ++j)
-        if (j < KS) atomicAdd(d_loc_k + j * A_ + k, acc_lk[j]);
-    atomicAdd(d_score_w + k, acc_w);
-    atomicAdd(d_score_b + k, acc_b);
+    acc_w += __shfl_xor(acc_w, 32);
+    acc_b += __shfl_xor(acc_b, 32);
+    if (kh == 0) {
+        atomicAdd(d_score_w + a, acc_w);
+        atomicAdd(d_score_b + a, acc_b);
+    }
 }
 
 static int check_const(const mstts_lsa_const* c) {
@@ -991,7 +1010,7 @@ extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const fl
                                    float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     if (S <= 0) return MSTTS_OK;
-    const int nt = cdiv(c->T, TS);
+    const int nt = cdiv(c->T, PT);
     int chunks = (int)(2048 / (c->B * nt));
     if (chunks < 1) chunks = 1;
     if (chunks > S) chunks = (int)S;

@@ -4,8 +4,8 @@
 // way into LDS.  Inputs and outputs stay fp32 in memory - master weights, activations, gradients and the accumulators never
 // leave fp32; only the multiplicands are 8-bit-mantissa.  16x the fp32 MFMA rate, so these launches become memory/LDS-bound.
 //
-// Tile 128 x 128 x 32 per 256-thread workgroup (4 wave64 as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles).  LDS image of an operand:
-// [128 rows][32 k] bf16, row stride 80 B, i.e. k CONTIGUOUS per row whatever the operand's memory layout - an MFMA fragment
+// Tile 128 x 128 x 64 per 256-thread workgroup (4 wave64 as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles).  LDS image of an operand:
+// [128 rows][64 k] bf16, row stride 144 B, i.e. k CONTIGUOUS per row whatever the operand's memory layout - an MFMA fragment
 // (lane l: row l & 31, k = 8 (l >> 5) .. + 7) is then one conflict-free ds_read_b128.  The transposition this needs for operands
 // that are contiguous along their M/N index is done in registers: a thread loads a 4 (k) x 4 (rows) block as four float4 and
 // writes four 8-byte k-runs.  The next K-tile is prefetched into registers while the current one is multiplied.
@@ -18,8 +18,8 @@ typedef float gb_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gb_bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GB_BK = 32, GB_BM = 128, GB_BN = 128;
-constexpr int GB_LD = 40;                 // LDS row stride in bf16 elements (80 B): 16-byte aligned rows, b128 reads conflict-free
+constexpr int GB_BK = 64, GB_BM = 128, GB_BN = 128;
+constexpr int GB_LD = 72;                 // LDS row stride in bf16 elements (144 B = 36 words, 36 mod 32 = 4): 16-byte aligned rows, b128 reads conflict-free
 
 struct GemmBfArgs {
     const float* A; const float* B; float* C; const float* bias;
@@ -42,26 +42,37 @@ __device__ __forceinline__ gb_bf16x4 gb_round4(float a, float b, float c, float 
     return (gb_bf16x4){(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
 }
 
-// operand contiguous along k in memory (A row-major, or B given as [N,K]): thread (k4 = tid & 7, r = tid >> 3) takes the float4
-// k-run k4 of rows r, r + 32, r + 64, r + 96
+// operand contiguous along k in memory (A row-major, or B given as [N,K]): thread (k4 = tid & 15, r = tid >> 4) takes the float4
+// k-run k4 of rows r, r + 16, .., r + 112.  Window arithmetic is hoisted like in gemm.hip: prepare() once, then load() for
+// k0, k0 + GB_BK, ... (a thread's rows are fixed, its k advances by GB_BK per call).
 template <bool VEC>
 struct GbLoaderKC {
-    float4 reg[4];
+    float4 reg[8];
+    int t_row[8], tap, kc;
+    __device__ __forceinline__ void prepare(int row0, int k0, int wT, int wC) {
+        if (wT > 0) {
+            const int k4 = threadIdx.x & 15, r = threadIdx.x >> 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t_row[i] = (row0 + r + i * 16) % wT;
+            const int k = k0 + k4 * 4;
+            tap = k / wC; kc = k - tap * wC;
+        }
+    }
     __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int row0, int k0, int rows, int kmax,
                                          int wT, int wC, int wpad, int wdil) {
-        const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
+        const int k4 = threadIdx.x & 15, r = threadIdx.x >> 4;
+        const int k = k0 + k4 * 4;
+        const int sh = wT > 0 ? (tap - wpad) * wdil : 0;     // tap j = k / C of a dilated 'same' conv: source row = row + (j - pad) * dil
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + r + i * 32;
-            const int k = k0 + k4 * 4;
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + r + i * 16;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             bool ok = row < rows && k < kmax;
             long off = (long)row * ld + k;
-            if (wT > 0) {                  // tap j = k / C of a dilated 'same' conv: source row = row + (j - pad) * dil inside the sequence
-                const int sh = (k / wC - wpad) * wdil;
-                const int t = row % wT + sh;
+            if (wT > 0) {
+                const int t = t_row[i] + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)row + sh) * ld + k % wC;
+                off = ((long)row + sh) * ld + kc;
             }
             if (ok) {
                 if (VEC) v = *reinterpret_cast<const float4*>(base + off);
@@ -74,35 +85,51 @@ struct GbLoaderKC {
             }
             reg[i] = v;
         }
+        if (wT > 0) {
+            kc += GB_BK;
+            while (kc >= wC) { kc -= wC; ++tap; }
+        }
     }
     __device__ __forceinline__ void store(__bf16* __restrict__ s) const {
-        const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
+        const int k4 = threadIdx.x & 15, r = threadIdx.x >> 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<gb_bf16x4*>(s + (r + i * 32) * GB_LD + k4 * 4) = gb_round4(reg[i].x, reg[i].y, reg[i].z, reg[i].w);
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<gb_bf16x4*>(s + (r + i * 16) * GB_LD + k4 * 4) = gb_round4(reg[i].x, reg[i].y, reg[i].z, reg[i].w);
     }
 };
 
-// operand contiguous along its M/N index (B row-major [K,N], or A given as [K,M]): thread (c4 = tid & 31, kq = tid >> 5) takes the
-// 4 x 4 block of k rows 4 kq .. 4 kq + 3 x columns 4 c4 .. 4 c4 + 3 and writes it transposed
+// operand contiguous along its M/N index (B row-major [K,N], or A given as [K,M]): thread (c4 = tid & 31, kq = tid >> 5) takes, in
+// each of the two 32-k halves, the 4 x 4 block of k rows 4 kq .. 4 kq + 3 x columns 4 c4 .. 4 c4 + 3 and writes it transposed
 template <bool VEC>
 struct GbLoaderMC {
-    float4 reg[4];
+    float4 reg[8];
+    int sh, cm, t_k[8];
+    __device__ __forceinline__ void prepare(int col0, int k0, int wT, int wC, int wpad, int wdil) {
+        if (wT > 0) {
+            const int c4 = threadIdx.x & 31, kq = threadIdx.x >> 5;
+            const int col = col0 + c4 * 4;
+            const int tp = col / wC;
+            sh = (tp - wpad) * wdil; cm = col - tp * wC;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t_k[i] = (k0 + (i >> 2) * 32 + kq * 4 + (i & 3)) % wT;
+        }
+    }
     __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int col0, int k0, int cols, int kmax,
                                          int wT, int wC, int wpad, int wdil) {
         const int c4 = threadIdx.x & 31, kq = threadIdx.x >> 5;
+        const int col = col0 + c4 * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + kq * 4 + i;
-            const int col = col0 + c4 * 4;
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + (i >> 2) * 32 + kq * 4 + (i & 3);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             bool ok = k < kmax && col < cols;
             long off = (long)k * ld + col;
             if (wT > 0) {                  // window (A only): element (m, kk) with kk = (b, t) row index, m = (tap, c)
-                const int sh = (col / wC - wpad) * wdil;
-                const int t = k % wT + sh;
+                const int t = t_k[i] + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)k + sh) * ld + col % wC;
+                off = ((long)k + sh) * ld + cm;
+                t_k[i] += GB_BK;
+                while (t_k[i] >= wT) t_k[i] -= wT;
             }
             if (ok) {
                 if (VEC) v = *reinterpret_cast<const float4*>(base + off);
@@ -118,11 +145,15 @@ struct GbLoaderMC {
     }
     __device__ __forceinline__ void store(__bf16* __restrict__ s) const {
         const int c4 = threadIdx.x & 31, kq = threadIdx.x >> 5;
-        __bf16* p = s + (c4 * 4) * GB_LD + kq * 4;
-        *reinterpret_cast<gb_bf16x4*>(p) = gb_round4(reg[0].x, reg[1].x, reg[2].x, reg[3].x);
-        *reinterpret_cast<gb_bf16x4*>(p + GB_LD) = gb_round4(reg[0].y, reg[1].y, reg[2].y, reg[3].y);
-        *reinterpret_cast<gb_bf16x4*>(p + 2 * GB_LD) = gb_round4(reg[0].z, reg[1].z, reg[2].z, reg[3].z);
-        *reinterpret_cast<gb_bf16x4*>(p + 3 * GB_LD) = gb_round4(reg[0].w, reg[1].w, reg[2].w, reg[3].w);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __bf16* p = s + (c4 * 4) * GB_LD + h * 32 + kq * 4;
+            const float4 *q = reg + 4 * h;
+            *reinterpret_cast<gb_bf16x4*>(p) = gb_round4(q[0].x, q[1].x, q[2].x, q[3].x);
+            *reinterpret_cast<gb_bf16x4*>(p + GB_LD) = gb_round4(q[0].y, q[1].y, q[2].y, q[3].y);
+            *reinterpret_cast<gb_bf16x4*>(p + 2 * GB_LD) = gb_round4(q[0].z, q[1].z, q[2].z, q[3].z);
+            *reinterpret_cast<gb_bf16x4*>(p + 3 * GB_LD) = gb_round4(q[0].w, q[1].w, q[2].w, q[3].w);
+        }
     }
 };
 
@@ -162,6 +193,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (TA) la.prepare(m0, kbeg, g.win_T, g.win_C, g.win_pad, g.win_dil);
+    else la.prepare(m0, kbeg, g.win_T, g.win_C);
     if (kbeg < kend) {
         la.load(A, g.lda, m0, kbeg, g.M, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
         lb.load(B, g.ldb, n0, kbeg, g.N, kend, 0, 1, 0, 1);

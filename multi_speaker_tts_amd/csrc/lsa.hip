@@ -594,7 +594,28 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
     const int len = c.lengths ? c.lengths[b] : T;
-    // ---- every global load, back to back: the row's G operands ...
+    // ---- every global load, back to back.  First the small operands of the tanh recompute (window, folded filter, this slice's
+    // keys, query): loads return in order, so with these ahead of the 12.6 MB of value rows the recompute below runs while the
+    // values are still in flight ...
+    float cwin = 0.f;
+    if (threadIdx.x < TS + KS - 1) {
+        const int t = t0 - pad + threadIdx.x;
+        if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
+    }
+    constexpr int NLK = (KS_MAX * A_ + 255) / 256;
+    float lkv[NLK];
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        lkv[i] = (e < KS * A_) ? c.loc_k[e] : 0.f;
+    }
+    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
+    float kv[TS / 2];
+#pragma unroll
+    for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
+    const float qk = q[(long)b * A_ + k] + c.score_b[k] + c.loc_b[k];
+    const float wk = c.score_w[k];
+    // ... the row's G operands ...
     constexpr int LPR = 256 / TS;                             // 32 lanes per position: lane j of position tt takes tap j
     const int tt_h = threadIdx.x / LPR, jh = threadIdx.x % LPR;
     float hv = 0.f;                                           // this slice's G: one diagonal tap per lane
@@ -655,25 +676,6 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    // ... and the d_energy phase
-    float cwin = 0.f;
-    if (threadIdx.x < TS + KS - 1) {
-        const int t = t0 - pad + threadIdx.x;
-        if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
-    }
-    constexpr int NLK = (KS_MAX * A_ + 255) / 256;
-    float lkv[NLK];
-#pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        lkv[i] = (e < KS * A_) ? c.loc_k[e] : 0.f;
-    }
-    const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
-    float kv[TS / 2];
-#pragma unroll
-    for (int i = 0; i < TS / 2; ++i) kv[i] = (t0 + grp + 2 * i < T) ? keys[(long)(grp + 2 * i) * A_] : 0.f;
-    const float qk = q[(long)b * A_ + k] + c.score_b[k] + c.loc_b[k];
-    const float wk = c.score_w[k];
     // ---- this slice's G (32-lane sums of the diagonal taps) and the row's alignments in LDS
     {
         float x = hv;
@@ -687,7 +689,30 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
         if (t < T) s_a[t] = av[i];
     }
     *reinterpret_cast<float4*>(&s_dc[lane * 4 + 256 * w]) = dsum;
+    // the filter / window of the tanh recompute
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < KS_MAX * A_) s_lk[e / A_][e % A_] = lkv[i];
+    }
+    if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;
     __syncthreads();
+    // tanh terms of this slice (independent of everything row-wide): u = tanh(keys + q + location filter), fac = w (1 - u^2)
+    float fac[TS / 2];
+    {
+        float lk[KS_MAX];
+#pragma unroll
+        for (int j = 0; j < KS_MAX; ++j) lk[j] = s_lk[j][k];
+#pragma unroll
+        for (int i = 0; i < TS / 2; ++i) {
+            const int tt = grp + 2 * i;
+            float pre = kv[i] + qk;
+#pragma unroll
+            for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * lk[j];
+            const float u = fast_tanh(pre);
+            fac[i] = (t0 + tt < T) ? wk * (1.f - u * u) : 0.f;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MROW; ++m) dcv[m] = *reinterpret_cast<const float4*>(&s_dc[lane * 4 + 256 * m]);
     // dot(a, G) = dot(a, G_next) + sum_{tau, j} h_next[tau][j] a[tau - pad + j]   (G[t] = G_next[t] + sum_j h_next[t + pad - j][j])
@@ -755,32 +780,12 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
             s_da[tt] = (t < T) ? g + acc : 0.f;
         }
     }
-    // stage the filter / window for the tanh recompute
-#pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        if (e < KS_MAX * A_) s_lk[e / A_][e % A_] = lkv[i];
-    }
-    if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;
     __syncthreads();
     if (threadIdx.x < TS) {
         const int t = t0 + threadIdx.x;
         const float de = (t < T) ? a_own * (s_da[threadIdx.x] - dot) : 0.f;
         if (t < T) d_e_out[(long)b * T + t] = de;
         s_de[threadIdx.x] = de;
-    }
-    float lk[KS_MAX];
-#pragma unroll
-    for (int j = 0; j < KS_MAX; ++j) lk[j] = s_lk[j][k];
-    float fac[TS / 2];
-#pragma unroll
-    for (int i = 0; i < TS / 2; ++i) {
-        const int tt = grp + 2 * i;
-        float pre = kv[i] + qk;
-#pragma unroll
-        for (int j = 0; j < KS_MAX; ++j) pre += s_cum[tt + j] * lk[j];
-        const float u = fast_tanh(pre);
-        fac[i] = (t0 + tt < T) ? wk * (1.f - u * u) : 0.f;
     }
     __syncthreads();
     float dq_acc = 0.f;

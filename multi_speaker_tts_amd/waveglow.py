@@ -118,7 +118,7 @@ class WaveGlowEngine:
             raise ValueError("WaveGlow variables missing: %s ..." % missing[:3])
         self.load(vals)
         self._keep = []
-        self.split_in = 0          # 0 = choose per call so that the dilated-conv GEMM fills the chip (see infer)
+        self.split_in = 0          # > 1: split the dilated-conv GEMM's reduction (atomic accumulation); 0 / 1 = off (see infer)
 
     # ------------------------------------------------------------------ checkpoint constants, folded on the host once
     def _dev(self, a):
@@ -186,11 +186,10 @@ class WaveGlowEngine:
         x, z, out = self._f(rows, ch), self._f(rows, ch), self._f(rows, ch)
         cond, rs = self._f(rows, d.layers * 2 * ch), self._f(rows, 2 * ch)
         ldc = d.layers * 2 * ch
-        # The [rows, 3*ch] x [3*ch, 2*ch] conv GEMM has only ceil(rows/128) * (2*ch/128) output tiles (344 at batch 4 x 40 frames
-        # on 256 CUs); split its reduction (atomic accumulation onto the conditioning block, which it adds to anyway) until
-        # there are ~2 tiles per CU: 42.1 -> 35.6 ms per batch.  Costs run-to-run bit reproducibility (fp32 atomics).
-        tiles = -(-rows // 128) * -(-2 * ch // 128)
-        split_in = self.split_in or (1 if tiles >= 512 else max(1, min(4, 700 // tiles, (d.k * ch) // 256)))
+        # The [rows, 3*ch] x [3*ch, 2*ch] conv GEMM has only ceil(rows/128) * (2*ch/128) = 344 output tiles of 128 rows at batch 4 x 40
+        # frames on 256 CUs; mstts_gemm_f32 switches to 64-row tiles for such shapes (688 tiles), which beats the split-K form
+        # used before (33.0 vs 33.6 ms per batch) and keeps the launch free of atomics - results are bit-reproducible run to run.
+        split_in = self.split_in or 1
         for f in reversed(range(d.flows)):
             F = self.flow[f]
             c = F["c"]

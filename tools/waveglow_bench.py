@@ -6,6 +6,7 @@ from multi_speaker_tts_amd.waveglow import WaveGlowEngine, WGDims
 dev = torch.device("cuda:0")
 d = WGDims()
 eng = WaveGlowEngine(d, device=dev)
+eng.split_in = int(os.environ.get("SPLIT_IN", 0))
 N, T = int(os.environ.get("N", 4)), 40
 mel = np.clip(np.random.default_rng(0).normal(0, 1.5, (N, T, d.n_mel)), -4, 4).astype(np.float32)
 L = (T - 1) * d.up_stride + d.up_k

@@ -327,13 +327,16 @@ int64_t mstts_stft_mel_ws_floats(int64_t n, int32_t n_fft, int64_t frames);
  * (n_fft a power of two in [512, 4096]; mstts_stft_fft_supported).  wav = the waveforms back to back; wav_off[nw+1] / frame_off[nw+1] =
  * DEVICE arrays of sample / frame offsets (frames of waveform w = 1 + len_w / hop, len_w > n_fft / 2); window[win] = the periodic Hann
  * window; twiddle[n_fft/2] = (cos, -sin)(2 pi k / n_fft) pairs; mel_basis[n_mel, n_fft/2+1] row-major with mel_rng[n_mel][2] = each
- * filter's [first, last+1) non-zero bin.  mel_out [total_frames, n_mel] = Audio.melspectrogram's symmetric normalisation,
- * spec_out [total_frames, n_fft/2+1] = Audio.spectrogram's [0, 1] normalisation with ref_level_db; either may be NULL. */
+ * filter's [first, last+1) non-zero bin.  mel_out [total_frames, n_mel] = Audio.melspectrogram's symmetric normalisation (flags & 1:
+ * its [0, 1] normalisation, max_abs_value None), spec_out [total_frames, n_fft/2+1] = Audio.spectrogram's [0, 1] normalisation with
+ * ref_level_db (flags & 2: the raw magnitudes instead); either may be NULL.  mag_in != NULL: no transform - the magnitudes are read
+ * from mag_in [total_frames, n_fft/2+1] and sub[n_fft/2+1] * sub_scale (sub may be NULL) is subtracted, clipped at 0: the second pass
+ * of spectral_subtract (Audio.py:45-46; sub = the per-bin sum over the waveform's frames from mstts_colsum, sub_scale = 0.1 / frames). */
 int mstts_stft_fft_supported(int32_t n_fft, int32_t win);
 int mstts_stft_fft(const float* wav, const int64_t* wav_off, const int64_t* frame_off, int32_t nw, float preemph, const float* window,
                    const float* twiddle, const float* mel_basis, const int32_t* mel_rng, int32_t n_fft, int32_t hop, int32_t win,
                    int32_t n_mel, float max_abs, float ref_level_db, float* mel_out, float* spec_out, int64_t total_frames,
-                   mstts_stream_t s);
+                   const float* mag_in, const float* sub, float sub_scale, int32_t flags, mstts_stream_t s);
 
 /* ---- skinny (M <= 32 rows per block) weight-streaming products of the recurrent steps -------------
  * fwd: P[ks][M][N] = X[M, K-slice ks] . W[K-slice ks, N]   (W row-major [K,N], ld ldw); ksplit from

@@ -85,9 +85,12 @@ def _fft_constants(num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_r
 
 
 def stft_features(wavs, num_freq, frame_shift_ms, frame_length_ms, sample_rate, num_mels=None, max_abs_value=4, ref_level_db=20,
-                  want_mel=True, want_spec=False, device="cuda"):
+                  want_mel=True, want_spec=False, spectral_subtract=False, device="cuda"):
     """Mel and / or linear spectrogram features of SEVERAL waveforms in one kernel launch (mstts_stft_fft): returns a list of
-    (mel [frames, num_mels] or None, spec [frames, num_freq] or None) device tensors, one pair per waveform."""
+    (mel [frames, num_mels] or None, spec [frames, num_freq] or None) device tensors, one pair per waveform.
+    max_abs_value None: the mel is normalised to [0, 1] (Audio._normalize) instead of symmetrically.  spectral_subtract
+    (Audio.py:45-46): a first launch leaves the raw magnitudes, a tenth of each waveform's per-bin time mean is subtracted
+    (clipped at 0) by a second launch that finishes the features - three launches per waveform instead of one for the batch."""
     n_fft, hop, win, hann, tw, fb, rng = _fft_constants(num_freq, frame_shift_ms, frame_length_ms, num_mels or 1, sample_rate, str(device))
     dev = hann.device
     ws = [torch.as_tensor(np.asarray(y, dtype=np.float32)) if not torch.is_tensor(y) else y.to(torch.float32).reshape(-1) for y in wavs]
@@ -98,12 +101,28 @@ def stft_features(wavs, num_freq, frame_shift_ms, frame_length_ms, sample_rate, 
     woff = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=dev)
     foff = torch.tensor(np.concatenate([[0], np.cumsum(frames)]), dtype=torch.int64, device=dev)
     cat = torch.cat([w.to(dev) for w in ws]).contiguous()
-    total = int(sum(frames))
+    total, nb = int(sum(frames)), n_fft // 2 + 1
     mel = torch.empty(total, num_mels, dtype=torch.float32, device=dev) if want_mel else None
-    spec = torch.empty(total, n_fft // 2 + 1, dtype=torch.float32, device=dev) if want_spec else None
-    lib.call("mstts_stft_fft", lib.ptr(cat), lib.ptr(woff), lib.ptr(foff), len(ws), 0.97, lib.ptr(hann), lib.ptr(tw),
-             lib.ptr(fb) if want_mel else None, lib.ptr(rng) if want_mel else None, n_fft, hop, win, int(num_mels or 0),
-             float(max_abs_value), float(ref_level_db), lib.ptr(mel) if want_mel else None, lib.ptr(spec) if want_spec else None, total)
+    spec = torch.empty(total, nb, dtype=torch.float32, device=dev) if want_spec else None
+    flags = 1 if max_abs_value is None else 0
+    mabs = float(max_abs_value) if max_abs_value is not None else 1.0
+    common = (lib.ptr(fb) if want_mel else None, lib.ptr(rng) if want_mel else None, n_fft, hop, win, int(num_mels or 0), mabs, float(ref_level_db))
+    if not spectral_subtract:
+        lib.call("mstts_stft_fft", lib.ptr(cat), lib.ptr(woff), lib.ptr(foff), len(ws), 0.97, lib.ptr(hann), lib.ptr(tw), *common,
+                 lib.ptr(mel) if want_mel else None, lib.ptr(spec) if want_spec else None, total, None, None, 0.0, flags)
+    else:
+        mag = torch.empty(total, nb, dtype=torch.float32, device=dev)
+        lib.call("mstts_stft_fft", lib.ptr(cat), lib.ptr(woff), lib.ptr(foff), len(ws), 0.97, lib.ptr(hann), lib.ptr(tw), None, None,
+                 n_fft, hop, win, 0, mabs, float(ref_level_db), None, lib.ptr(mag), total, None, None, 0.0, 2)
+        sub = torch.empty(nb, dtype=torch.float32, device=dev)
+        one = torch.tensor([0, 0], dtype=torch.int64, device=dev)
+        f0 = 0
+        for fr in frames:                                   # the mean runs over one waveform's frames
+            lib.call("mstts_colsum", lib.ptr(mag, f0 * nb), fr, nb, nb, lib.ptr(sub), 0)
+            lib.call("mstts_stft_fft", lib.ptr(cat), lib.ptr(one), lib.ptr(one), 1, 0.97, lib.ptr(hann), lib.ptr(tw), *common,
+                     lib.ptr(mel, f0 * num_mels) if want_mel else None, lib.ptr(spec, f0 * nb) if want_spec else None, fr,
+                     lib.ptr(mag, f0 * nb), lib.ptr(sub), 0.1 / fr, flags)
+            f0 += fr
     out, f0 = [], 0
     for fr in frames:
         out.append((mel[f0:f0 + fr] if want_mel else None, spec[f0:f0 + fr] if want_spec else None))
@@ -119,10 +138,8 @@ def _fft_ok(num_freq, frame_shift_ms, frame_length_ms, sample_rate):
 def spectrogram(y, num_freq, frame_shift_ms, frame_length_ms, sample_rate, ref_level_db=20, spectral_subtract=False, device="cuda",
                 return_tensor=False):
     """Audio.py:19-22: normalised linear spectrogram [num_freq, frames] in [0, 1]."""
-    if spectral_subtract:
-        raise NotImplementedError("spectral_subtract is never enabled on the reference's TTS path")
     (_, spec), = stft_features([y], num_freq, frame_shift_ms, frame_length_ms, sample_rate, ref_level_db=ref_level_db, want_mel=False,
-                               want_spec=True, device=device)
+                               want_spec=True, spectral_subtract=spectral_subtract, device=device)
     spec = spec.t()
     return spec if return_tensor else spec.cpu().numpy()
 
@@ -130,12 +147,9 @@ def spectrogram(y, num_freq, frame_shift_ms, frame_length_ms, sample_rate, ref_l
 def spectrogram_and_mel(y, num_freq, frame_shift_ms, frame_length_ms, sample_rate, spect_ref_level_db=20, num_mels=80, max_abs_mels=None,
                         spectral_subtract=False, device="cuda", return_tensor=False):
     """Audio.py:34-40: both features from one STFT -> (spectrogram [num_freq, frames], mel [num_mels, frames])."""
-    if spectral_subtract:
-        raise NotImplementedError("spectral_subtract is never enabled on the reference's TTS path")
-    if max_abs_mels is None:
-        raise NotImplementedError("only the symmetric mel normalisation used by the TTS path (Max_Abs_Mel) is built")
     (mel, spec), = stft_features([y], num_freq, frame_shift_ms, frame_length_ms, sample_rate, num_mels=num_mels, max_abs_value=max_abs_mels,
-                                 ref_level_db=spect_ref_level_db, want_mel=True, want_spec=True, device=device)
+                                 ref_level_db=spect_ref_level_db, want_mel=True, want_spec=True, spectral_subtract=spectral_subtract,
+                                 device=device)
     spec, mel = spec.t(), mel.t()
     return (spec, mel) if return_tensor else (spec.cpu().numpy(), mel.cpu().numpy())
 
@@ -144,15 +158,13 @@ def melspectrogram(y, num_freq, frame_shift_ms, frame_length_ms, num_mels, sampl
                    spectral_subtract=False, device="cuda", return_tensor=False, use_fft=True):
     """Same signature and result layout ([num_mels, frames]) as the reference function.  One launch (FFT in LDS) when n_fft is a
     power of two - the reference's 2048 is; the DFT-as-GEMM form below covers any other size (use_fft=False forces it)."""
-    if spectral_subtract:
-        raise NotImplementedError("spectral_subtract is never enabled on the reference's TTS path")
-    if max_abs_value is None:
-        raise NotImplementedError("only the symmetric normalisation used by the TTS path (Max_Abs_Mel) is built")
-    if use_fft and _fft_ok(num_freq, frame_shift_ms, frame_length_ms, sample_rate):
+    if (use_fft or spectral_subtract or max_abs_value is None) and _fft_ok(num_freq, frame_shift_ms, frame_length_ms, sample_rate):
         (mel, _), = stft_features([y], num_freq, frame_shift_ms, frame_length_ms, sample_rate, num_mels=num_mels, max_abs_value=max_abs_value,
-                                  device=device)
+                                  spectral_subtract=spectral_subtract, device=device)
         mel = mel.t()
         return mel if return_tensor else mel.cpu().numpy()
+    if spectral_subtract or max_abs_value is None:
+        raise ValueError("spectral_subtract / the [0, 1] normalisation need a power-of-two transform size (the one-launch FFT path)")
     n_fft, hop, win, nb, basis, fb_t = _constants(num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_rate, str(device))
     wav = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(basis.device) if not torch.is_tensor(y) else y.to(basis.device, torch.float32)
     wav = wav.contiguous()

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__
                                                        const float* __restrict__ window, const float2* __restrict__ tw,
                                                        const float* __restrict__ mel_basis, const int* __restrict__ mel_rng, int n_fft, int hop,
                                                        int win, int n_mel, float max_abs, float ref_db, float* __restrict__ mel_out,
-                                                       float* __restrict__ spec_out) {
+                                                       float* __restrict__ spec_out, const float* __restrict__ mag_in,
+                                                       const float* __restrict__ sub, float sub_scale, int flags) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_lds[];
     const int N2 = n_fft >> 1, tid = threadIdx.x;
     float2* bufa = fft_lds;
@@ -75,6 +76,20 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__
         const float prev = j > 0 ? x[j - 1] : 0.f;
         return window[i - off] * (x[j] - coef * prev);
     };
+    const int NB = N2 + 1;
+    float* mag = reinterpret_cast<float*>(bufb);
+    if (mag_in) {
+        // second pass of the spectral-subtraction form (Audio.py:45-46): magnitudes of the first pass minus sub[k], clipped at 0
+        for (int k = tid; k < NB; k += 256) {
+            const float m = fmaxf(mag_in[g * NB + k] - (sub ? sub[k] * sub_scale : 0.f), 0.f);
+            mag[k] = m;
+            if (spec_out) {
+                const float db = 20.f * log10f(fmaxf(1e-5f, m)) - ref_db;
+                spec_out[g * NB + k] = fminf(fmaxf((db + 100.f) * 0.01f, 0.f), 1.f);
+            }
+        }
+        __syncthreads();
+    } else {
     for (int m = tid; m < N2; m += 256) bufa[m] = make_float2(sample(2 * m), sample(2 * m + 1));
     __syncthreads();
     const int tstep = 2;                                 // tw[k] = e^{-2 pi i k / n_fft}; the half-size transform uses every second entry
@@ -92,8 +107,7 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__
         float2* t_ = bufa; bufa = bufb; bufb = t_;
     }
     // real-input post-processing -> magnitudes in LDS (bufb is free)
-    float* mag = reinterpret_cast<float*>(bufb);
-    const int NB = N2 + 1;
+    mag = reinterpret_cast<float*>(bufb);
     for (int k = tid; k < NB; k += 256) {
         const float2 zk = bufa[k & (N2 - 1)], zc = bufa[(N2 - k) & (N2 - 1)];
         const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);           // E = (Z[k] + conj(Z[N2-k])) / 2
@@ -103,11 +117,15 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__
         const float m = sqrtf(re * re + im * im);
         mag[k] = m;
         if (spec_out) {
-            const float db = 20.f * log10f(fmaxf(1e-5f, m)) - ref_db;
-            spec_out[g * NB + k] = fminf(fmaxf((db + 100.f) * 0.01f, 0.f), 1.f);
+            if (flags & 2) spec_out[g * NB + k] = m;                    // raw magnitudes (first pass of the spectral-subtraction form)
+            else {
+                const float db = 20.f * log10f(fmaxf(1e-5f, m)) - ref_db;
+                spec_out[g * NB + k] = fminf(fmaxf((db + 100.f) * 0.01f, 0.f), 1.f);
+            }
         }
     }
     __syncthreads();
+    }
     if (!mel_out) return;
     const int lane = tid & 63, wave = tid >> 6;
     for (int c = wave; c < n_mel; c += 4) {
@@ -119,8 +137,11 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
         if (lane == 0) {
             const float db = 20.f * log10f(fmaxf(1e-5f, acc));
-            const float v = (2.f * max_abs) * ((db + 100.f) * 0.01f) - max_abs;
-            mel_out[g * n_mel + c] = fminf(fmaxf(v, -max_abs), max_abs);
+            if (flags & 1) mel_out[g * n_mel + c] = fminf(fmaxf((db + 100.f) * 0.01f, 0.f), 1.f);          // Audio._normalize
+            else {
+                const float v = (2.f * max_abs) * ((db + 100.f) * 0.01f) - max_abs;                        // Audio._symmetric_normalize
+                mel_out[g * n_mel + c] = fminf(fmaxf(v, -max_abs), max_abs);
+            }
         }
     }
 }
@@ -135,7 +156,7 @@ extern "C" int mstts_stft_fft_supported(int32_t n_fft, int32_t win) {
 extern "C" int mstts_stft_fft(const float* wav, const int64_t* wav_off, const int64_t* frame_off, int32_t nw, float preemph,
                               const float* window, const float* twiddle, const float* mel_basis, const int32_t* mel_rng, int32_t n_fft,
                               int32_t hop, int32_t win, int32_t n_mel, float max_abs, float ref_level_db, float* mel_out, float* spec_out,
-                              int64_t total_frames, mstts_stream_t s) {
+                              int64_t total_frames, const float* mag_in, const float* sub, float sub_scale, int32_t flags, mstts_stream_t s) {
     MSTTS_REQUIRE(wav && wav_off && frame_off && window && twiddle && (mel_out || spec_out), MSTTS_ERR_SHAPE, "stft_fft: null pointer");
     MSTTS_REQUIRE(!mel_out || (mel_basis && mel_rng && n_mel >= 1), MSTTS_ERR_SHAPE, "stft_fft: mel output needs the filterbank and its ranges");
     MSTTS_REQUIRE(mstts_stft_fft_supported(n_fft, win) && hop >= 1 && nw >= 1, MSTTS_ERR_SHAPE, "stft_fft: n_fft must be a power of two in [512, 4096]");
@@ -143,7 +164,7 @@ extern "C" int mstts_stft_fft(const float* wav, const int64_t* wav_off, const in
     if (total_frames == 0) return MSTTS_OK;
     hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)total_frames), dim3(256), sizeof(float2) * (size_t)n_fft, (hipStream_t)s, wav,
                        (const long*)wav_off, (const long*)frame_off, (int)nw, preemph, window, (const float2*)twiddle, mel_basis,
-                       (const int*)mel_rng, (int)n_fft, (int)hop, (int)win, (int)n_mel, max_abs, ref_level_db, mel_out, spec_out);
+                       (const int*)mel_rng, (int)n_fft, (int)hop, (int)win, (int)n_mel, max_abs, ref_level_db, mel_out, spec_out, mag_in, sub, sub_scale, (int)flags);
     MSTTS_CHECK_LAUNCH("stft_fft");
     return MSTTS_OK;
 }

@@ -159,7 +159,7 @@ SIGNATURES = {
     "mstts_stft_mel": (i32, [vp, i64, f32, vp, vp, i32, i32, i32, i32, f32, vp, vp, i64, vp]),
     "mstts_stft_mel_ws_floats": (i64, [i64, i32, i64]),
     "mstts_stft_fft_supported": (i32, [i32, i32]),
-    "mstts_stft_fft": (i32, [vp, vp, vp, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp]),
+    "mstts_stft_fft": (i32, [vp, vp, vp, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp, vp, f32, i32, vp]),
     "mstts_fold_rows": (i32, [vp, vp, i64, i64, i64, i64, vp]),
     "mstts_decoder_bf16_splits": (i32, [i64, i64, i64, P(i32)]),
     "mstts_skinny_bf16_fwd_splits": (i32, [i64, i64]),

@@ -79,20 +79,29 @@ def mel_basis(sr, n_fft, n_mels=80, fmin=0.0, fmax=None):
     return weights * enorm[:, None]
 
 
-def melspectrogram(y, num_freq=1025, frame_shift_ms=12.5, frame_length_ms=50, num_mels=80, sample_rate=16000, max_abs_value=4):
+def magnitude(y, n_fft, hop, win, spectral_subtract=False):
+    """Audio.py:42-48: |STFT| of the pre-emphasised signal; spectral_subtract removes a tenth of each bin's time mean, clipped at 0."""
+    M = np.abs(stft(preemphasis(y), n_fft, hop, win))
+    if spectral_subtract:
+        M = np.clip(M - np.mean(M, axis=1, keepdims=True) / 10, a_min=0.0, a_max=np.inf)
+    return M
+
+
+def melspectrogram(y, num_freq=1025, frame_shift_ms=12.5, frame_length_ms=50, num_mels=80, sample_rate=16000, max_abs_value=4,
+                   spectral_subtract=False):
     """Audio.py:29-32 -> [num_mels, frames]."""
     n_fft, hop, win = stft_parameters(num_freq, frame_shift_ms, frame_length_ms, sample_rate)
-    M = np.abs(stft(preemphasis(y), n_fft, hop, win))
+    M = magnitude(y, n_fft, hop, win, spectral_subtract)
     S = 20 * np.log10(np.maximum(1e-5, mel_basis(sample_rate, n_fft, num_mels) @ M))
     if max_abs_value is None:
         return np.clip((S + 100) / 100, 0, 1)
     return np.clip((2 * max_abs_value) * ((S + 100) / 100) - max_abs_value, -max_abs_value, max_abs_value)
 
 
-def spectrogram(y, num_freq=1025, frame_shift_ms=12.5, frame_length_ms=50, sample_rate=16000, ref_level_db=20):
-    """Audio.py:19-22 (+ :42-44, :88-92) -> normalised linear spectrogram [num_freq, frames] in [0, 1]."""
+def spectrogram(y, num_freq=1025, frame_shift_ms=12.5, frame_length_ms=50, sample_rate=16000, ref_level_db=20, spectral_subtract=False):
+    """Audio.py:19-22 (+ :42-48, :88-92) -> normalised linear spectrogram [num_freq, frames] in [0, 1]."""
     n_fft, hop, win = stft_parameters(num_freq, frame_shift_ms, frame_length_ms, sample_rate)
-    M = np.abs(stft(preemphasis(y), n_fft, hop, win))
+    M = magnitude(y, n_fft, hop, win, spectral_subtract)
     S = 20 * np.log10(np.maximum(1e-5, M)) - ref_level_db
     return np.clip((S + 100) / 100, 0, 1)
 

@@ -265,6 +265,14 @@ def test_stft_fft_batch_spectrogram_and_sizes(dev):
         assert np.abs(got - ref).max() < 2e-3, num_freq
     with pytest.raises(ValueError):
         Audio.melspectrogram(wavs[0][:1024], 1025, 12.5, 50, 80, 16000, max_abs_value=4, device=dev)
+    # the two options the reference's signature carries (Audio.py:29-32,45-46): [0, 1] normalisation and spectral subtraction
+    got = Audio.melspectrogram(wavs[2], 1025, 12.5, 50, 80, 16000, max_abs_value=None, device=dev)
+    assert np.abs(got - OA.melspectrogram(wavs[2], max_abs_value=None)).max() < 5e-4 and got.min() >= 0.0 and got.max() <= 1.0
+    got = Audio.melspectrogram(wavs[2], 1025, 12.5, 50, 80, 16000, max_abs_value=4, spectral_subtract=True, device=dev)
+    assert np.abs(got - OA.melspectrogram(wavs[2], spectral_subtract=True)).max() < 2e-3
+    sgot = Audio.spectrogram(wavs[2], 1025, 12.5, 50, 16000, spectral_subtract=True, device=dev)
+    sref = OA.spectrogram(wavs[2], spectral_subtract=True)
+    assert np.mean(np.abs(sgot - sref)) < 1e-4 and np.abs(sgot - sref).max() < 2e-2      # a bin clipped to the floor on one side only moves by a few dB
 
 
 def _engine_vs_oracle(dev, B, Te, L, ragged, seed, recurrent_dtype=None, **dims_kw):

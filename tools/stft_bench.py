@@ -37,7 +37,7 @@ foff = torch.tensor([0, frames], dtype=torch.int64, device=dev)
 mel = torch.empty(frames, 80, device=dev)
 from multi_speaker_tts_amd import lib
 fft_call = lambda: lib.call("mstts_stft_fft", lib.ptr(y), lib.ptr(woff), lib.ptr(foff), 1, 0.97, lib.ptr(hann), lib.ptr(tw), lib.ptr(fb), lib.ptr(rng),
-                            n_fft, hop, win, 80, 4.0, 20.0, lib.ptr(mel), None, frames)
+                            n_fft, hop, win, 80, 4.0, 20.0, lib.ptr(mel), None, frames, None, None, 0.0, 0)
 us_fft = timed(fft_call)
 # 32 utterances per launch (a feeder batch)
 yy = y.repeat(32)
@@ -45,7 +45,7 @@ woff32 = torch.arange(33, dtype=torch.int64, device=dev) * y.numel()
 foff32 = torch.arange(33, dtype=torch.int64, device=dev) * frames
 mel32 = torch.empty(32 * frames, 80, device=dev)
 us_fft32 = timed(lambda: lib.call("mstts_stft_fft", lib.ptr(yy), lib.ptr(woff32), lib.ptr(foff32), 32, 0.97, lib.ptr(hann), lib.ptr(tw), lib.ptr(fb),
-                                  lib.ptr(rng), n_fft, hop, win, 80, 4.0, 20.0, lib.ptr(mel32), None, 32 * frames))
+                                  lib.ptr(rng), n_fft, hop, win, 80, 4.0, 20.0, lib.ptr(mel32), None, 32 * frames, None, None, 0.0, 0))
 # (2) the DFT-as-GEMM form (5 launches) through the Python surface
 us_gemm = timed(lambda: Audio.melspectrogram(y, 1025, 12.5, 50, 80, sr, max_abs_value=4, device=dev, return_tensor=True, use_fft=False))
 alg = y.numel() * 4 + frames * 80 * 4

@@ -34,9 +34,9 @@ def Text_Filtering(text):
     return found[0]
 
 
-def Mel_Generate(path, range_Ignore=False, device="cuda"):
-    """Pattern_Generate.py:33-58: load at hp.Sound.Sample_Rate, trim (top_db 15, librosa's default 2048/512 frames),
-    scale by 0.99, reject by duration, mel through the HIP STFT kernel."""
+def Mel_Generate(path, spectral_Subtract=False, range_Ignore=False, device="cuda"):
+    """Pattern_Generate.py:33-58 (same positional order): load at hp.Sound.Sample_Rate, trim (top_db 15, librosa's default
+    2048/512 frames), scale by 0.99, reject by duration, mel through the HIP STFT kernel."""
     from . import Audio
     sig = _Feeder.load_wav(path, frame=2048, hop=512)
     ms = sig.shape[0] / hp.Sound.Sample_Rate * 1000
@@ -44,7 +44,8 @@ def Mel_Generate(path, range_Ignore=False, device="cuda"):
         return None
     return np.transpose(Audio.melspectrogram(y=sig, num_freq=hp.Sound.Spectrogram_Dim, frame_shift_ms=hp.Sound.Frame_Shift,
                                              frame_length_ms=hp.Sound.Frame_Length, num_mels=hp.Sound.Mel_Dim, sample_rate=hp.Sound.Sample_Rate,
-                                             max_abs_value=hp.Sound.Max_Abs_Mel, device=device)).astype(np.float32)
+                                             max_abs_value=hp.Sound.Max_Abs_Mel, spectral_subtract=spectral_Subtract,
+                                             device=device)).astype(np.float32)
 
 
 def Pattern_File_Write(file_Name, text, mel, token_Index_Dict, dataset, pattern_path=None):
@@ -56,10 +57,11 @@ def Pattern_File_Write(file_Name, text, mel, token_Index_Dict, dataset, pattern_
         pickle.dump({"Token": token, "Mel": np.asarray(mel, np.float32), "Text": text, "Dataset": dataset}, f, protocol=2)
 
 
-def Pattern_File_Generate(path, text, token_Index_Dict, dataset, file_Prefix="", range_Ignore=False, device="cuda"):
+def Pattern_File_Generate(path, text, token_Index_Dict, dataset, spectral_Subtract=False, file_Prefix="", display_Prefix="", range_Ignore=False,
+                          device="cuda"):
     """Pattern_Generate.py:60-82 for one (wav, text) pair; returns the pickle name or None when the utterance is skipped."""
     text = Text_Filtering(text)
-    mel = Mel_Generate(path, range_Ignore, device=device) if text is not None else None
+    mel = Mel_Generate(path, spectral_Subtract, range_Ignore, device=device) if text is not None else None
     if mel is None:
         return None
     name = "{}.{}{}.PICKLE".format(dataset, file_Prefix, os.path.splitext(os.path.basename(path))[0]).upper()
@@ -216,7 +218,8 @@ def TIMIT_Info_Load(timit_Path):
     return paths, texts
 
 
-def Pattern_File_Generate_from_SPH(path, text_List, token_Index_Dict, dataset, range_Ignore=False, device="cuda"):
+def Pattern_File_Generate_from_SPH(path, text_List, token_Index_Dict, dataset, spectral_Subtract=False, display_Prefix="", range_Ignore=False,
+                                   device="cuda"):
     """Pattern_Generate.py:80-113: one pattern per (start, end, text) segment of a SPHERE recording, named
     <DATASET>.<basename>.<index>.PICKLE.  Returns the names written."""
     from scipy.io import wavfile
@@ -228,7 +231,7 @@ def Pattern_File_Generate_from_SPH(path, text_List, token_Index_Dict, dataset, r
             tmp = tf.name
         try:
             wavfile.write(tmp, rate, data)
-            mel = Mel_Generate(tmp, range_Ignore, device=device)
+            mel = Mel_Generate(tmp, spectral_Subtract, range_Ignore, device=device)
         finally:
             os.remove(tmp)
         if mel is None:

@@ -15,6 +15,7 @@ shapes = [  # name, M, N, K, trans_a, trans_b, win(T, C, pad) or None, split_k, 
     ("postnet conv fwd 512->512", SB, 512, 2560, 0, 0, (S, 512, 2), 1, 3),
     ("postnet conv dgrad 512->512", SB, 512, 2560, 0, 0, (S, 512, 2), 1, 3),
     ("postnet conv wgrad 512->512", 2560, 512, SB, 1, 0, (S, 512, 2), max(2, _split_k(2560, 512, SB)), 3),
+    ("  (same shape, plain A, no window)", SB, 512, 2560, 0, 0, None, 1, 0),
     ("postnet conv fwd 80->512", SB, 512, 400, 0, 0, (S, 80, 2), 1, 1),
     ("postnet conv fwd 512->80", SB, 80, 2560, 0, 0, (S, 512, 2), 1, 1),
     ("postnet conv wgrad 512->80", 2560, 80, SB, 1, 0, (S, 512, 2), max(2, _split_k(2560, 80, SB)), 1),

@@ -326,7 +326,7 @@ int64_t mstts_stft_mel_ws_floats(int64_t n, int32_t n_fft, int64_t frames);
 /* The same transform (Audio.py:19-22,29-40,42-48,62-96) as ONE launch for nw waveforms: a workgroup per frame, real FFT in LDS
  * (n_fft a power of two in [512, 4096]; mstts_stft_fft_supported).  wav = the waveforms back to back; wav_off[nw+1] / frame_off[nw+1] =
  * DEVICE arrays of sample / frame offsets (frames of waveform w = 1 + len_w / hop, len_w > n_fft / 2); window[win] = the periodic Hann
- * window; twiddle[n_fft/2] = (cos, -sin)(2 pi k / n_fft) pairs; mel_basis[n_mel, n_fft/2+1] row-major with mel_rng[n_mel][2] = each
+ * window; twiddle[n_fft] = (cos, -sin)(2 pi k / n_fft) pairs, k < n_fft; mel_basis[n_mel, n_fft/2+1] row-major with mel_rng[n_mel][2] = each
  * filter's [first, last+1) non-zero bin.  mel_out [total_frames, n_mel] = Audio.melspectrogram's symmetric normalisation (flags & 1:
  * its [0, 1] normalisation, max_abs_value None), spec_out [total_frames, n_fft/2+1] = Audio.spectrogram's [0, 1] normalisation with
  * ref_level_db (flags & 2: the raw magnitudes instead); either may be NULL.  mag_in != NULL: no transform - the magnitudes are read

@@ -72,7 +72,7 @@ def _fft_constants(num_freq, frame_shift_ms, frame_length_ms, num_mels, sample_r
     dev = torch.device(device)
     n = np.arange(win)
     hann = 0.5 - 0.5 * np.cos(2 * np.pi * n / win)
-    k = np.arange(n_fft // 2)
+    k = np.arange(n_fft)
     tw = np.stack([np.cos(2 * np.pi * k / n_fft), -np.sin(2 * np.pi * k / n_fft)], axis=1)
     fb = mel_filterbank(sample_rate, n_fft, num_mels).astype(np.float32)
     rng = np.zeros((num_mels, 2), np.int32)

@@ -38,13 +38,13 @@ __global__ void db_normalize_kernel(float* __restrict__ mel, long n, float max_a
 // ---------------------------------------------------------------------------------------------
 // The same transform as ONE launch: a workgroup per frame, real FFT in LDS.
 //   x[i] = window[i - off] * preemph(reflect(f*hop + i - n_fft/2))   (0 outside the window)       Audio.py:42-48,62-64
-//   z[m] = x[2m] + i x[2m+1]  ->  Stockham radix-2 FFT of n_fft/2 complex points (ping-pong LDS buffers, twiddles from a table
+//   z[m] = x[2m] + i x[2m+1]  ->  Stockham radix-4 FFT of n_fft/2 complex points (ping-pong LDS buffers, twiddles from a table
 //   built in fp64 on the host)  ->  X[k] = E[k] + e^{-2 pi i k / n_fft} O[k]  ->  |X[k]|, k = 0 .. n_fft/2
 //   spec_out = clip((20 log10(max(1e-5, |X|)) - ref_db + 100) / 100, 0, 1)                          Audio.py:19-22,91-92
 //   mel_out  = symmetric-normalised dB of mel_basis . |X| over each filter's non-zero bin range     Audio.py:29-32,78-80,94-96
 // Several waveforms per launch: frame g belongs to waveform w with frame_off[w] <= g < frame_off[w + 1].
 // Algorithmic bytes per frame: hop new samples in, n_mel (+ n_fft/2 + 1) floats out; 5 N log2 N flops - the kernel is bound by
-// LDS round trips (log2(N/2) stages), a few microseconds per workgroup, 4+ workgroups resident per CU.
+// LDS round trips (log4(N/2) stages), a few microseconds per workgroup, 4+ workgroups resident per CU.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__ wav, const long* __restrict__ wav_off,
                                                        const long* __restrict__ frame_off, int nw, float coef,
@@ -92,16 +92,39 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__
     } else {
     for (int m = tid; m < N2; m += 256) bufa[m] = make_float2(sample(2 * m), sample(2 * m + 1));
     __syncthreads();
-    const int tstep = 2;                                 // tw[k] = e^{-2 pi i k / n_fft}; the half-size transform uses every second entry
-    for (int Ns = 1; Ns < N2; Ns <<= 1) {
-        const int tmul = (N2 / (2 * Ns)) * tstep;
-        for (int j = tid; j < (N2 >> 1); j += 256) {
-            const int k = j & (Ns - 1);
-            const float2 a = bufa[j], b = bufa[j + (N2 >> 1)], t = tw[k * tmul];
+    // Stockham autosort, radix 4 while it fits and one radix-2 stage for the odd power (N2 = 512, 2048).  Stage with sub-transform
+    // size p: thread i takes x[i + m t], m < radix, t = N2 / radix, twiddles e^{-2 pi i m k / (radix p)} = tw[m k n_fft / (radix p)]
+    // (tw has n_fft entries; 3 m k n_fft / (4 p) < 3 n_fft / 4).
+    int p = 1;
+    for (; p * 4 <= N2; p <<= 2) {
+        const int t4 = N2 >> 2, tmul = n_fft / (4 * p);
+        for (int i = tid; i < t4; i += 256) {
+            const int k = i & (p - 1), m = k * tmul;         // e^{-2 pi i k / (4 p)} = tw[k n_fft / (4 p)]
+            const float2 w1 = tw[m], w2 = tw[2 * m], w3 = tw[3 * m];
+            const float2 x0 = bufa[i], x1 = bufa[i + t4], x2 = bufa[i + 2 * t4], x3 = bufa[i + 3 * t4];
+            const float2 u1 = make_float2(x1.x * w1.x - x1.y * w1.y, x1.x * w1.y + x1.y * w1.x);
+            const float2 u2 = make_float2(x2.x * w2.x - x2.y * w2.y, x2.x * w2.y + x2.y * w2.x);
+            const float2 u3 = make_float2(x3.x * w3.x - x3.y * w3.y, x3.x * w3.y + x3.y * w3.x);
+            const float2 v0 = make_float2(x0.x + u2.x, x0.y + u2.y), v1 = make_float2(x0.x - u2.x, x0.y - u2.y);
+            const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y), v3 = make_float2(u1.y - u3.y, u3.x - u1.x);   // (u1 - u3) * (-i)
+            const int j0 = ((i - k) << 2) + k;
+            bufb[j0] = make_float2(v0.x + v2.x, v0.y + v2.y);
+            bufb[j0 + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
+            bufb[j0 + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
+            bufb[j0 + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
+        }
+        __syncthreads();
+        float2* t_ = bufa; bufa = bufb; bufb = t_;
+    }
+    if (p < N2) {                                            // p == N2 / 2: the last radix-2 stage
+        const int tmul = n_fft / (2 * p);
+        for (int i = tid; i < (N2 >> 1); i += 256) {
+            const int k = i & (p - 1);
+            const float2 a = bufa[i], b = bufa[i + (N2 >> 1)], t = tw[k * tmul];
             const float2 bt = make_float2(b.x * t.x - b.y * t.y, b.x * t.y + b.y * t.x);
-            const int j0 = ((j - k) << 1) + k;
+            const int j0 = ((i - k) << 1) + k;
             bufb[j0] = make_float2(a.x + bt.x, a.y + bt.y);
-            bufb[j0 + Ns] = make_float2(a.x - bt.x, a.y - bt.y);
+            bufb[j0 + p] = make_float2(a.x - bt.x, a.y - bt.y);
         }
         __syncthreads();
         float2* t_ = bufa; bufa = bufb; bufb = t_;
@@ -127,22 +150,31 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const float* __restrict__
     __syncthreads();
     }
     if (!mel_out) return;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < n_mel; c += 4) {
-        const int lo = mel_rng[2 * c], hi = mel_rng[2 * c + 1];
-        const float* row = mel_basis + (long)c * NB;
-        float acc = 0.f;
-        for (int b = lo + lane; b < hi; b += 64) acc = fmaf(row[b], mag[b], acc);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) {
-            const float db = 20.f * log10f(fmaxf(1e-5f, acc));
-            if (flags & 1) mel_out[g * n_mel + c] = fminf(fmaxf((db + 100.f) * 0.01f, 0.f), 1.f);          // Audio._normalize
+    // mel: three threads per filter, each sums every third bin of the filter's non-zero range; the three partial sums are
+    // combined in fixed order (bit-reproducible).  No wave reductions: twenty dependent shuffle chains per wave cost more than
+    // the transform itself.
+    float* part = reinterpret_cast<float*>(bufa);             // the spectrum has been consumed
+    for (int c0 = 0; c0 < n_mel; c0 += 85) {                   // 85 filters x 3 threads per pass
+        const int c = c0 + tid / 3, q = tid - (tid / 3) * 3;
+        if (tid < 255 && c < n_mel) {
+            const int lo = mel_rng[2 * c], hi = mel_rng[2 * c + 1];
+            const float* row = mel_basis + (long)c * NB;
+            float acc = 0.f;
+            for (int b = lo + q; b < hi; b += 3) acc = fmaf(row[b], mag[b], acc);
+            part[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < 85 && c0 + tid < n_mel) {
+            const int cc = c0 + tid;
+            const float m = (part[3 * tid] + part[3 * tid + 1]) + part[3 * tid + 2];
+            const float db = 20.f * log10f(fmaxf(1e-5f, m));
+            if (flags & 1) mel_out[g * n_mel + cc] = fminf(fmaxf((db + 100.f) * 0.01f, 0.f), 1.f);          // Audio._normalize
             else {
                 const float v = (2.f * max_abs) * ((db + 100.f) * 0.01f) - max_abs;                        // Audio._symmetric_normalize
-                mel_out[g * n_mel + c] = fminf(fmaxf(v, -max_abs), max_abs);
+                mel_out[g * n_mel + cc] = fminf(fmaxf(v, -max_abs), max_abs);
             }
         }
+        __syncthreads();
     }
 }
 

@@ -49,8 +49,8 @@ us_fft32 = timed(lambda: lib.call("mstts_stft_fft", lib.ptr(yy), lib.ptr(woff32)
 # (2) the DFT-as-GEMM form (5 launches) through the Python surface
 us_gemm = timed(lambda: Audio.melspectrogram(y, 1025, 12.5, 50, 80, sr, max_abs_value=4, device=dev, return_tensor=True, use_fft=False))
 alg = y.numel() * 4 + frames * 80 * 4
-tables_fft = (800 + 2048 + 80 * 1025) * 4
-flop_fft = frames * (5 * 1024 * 10 + 8 * 1025 + 2 * 2100)
+tables_fft = (800 + 2 * 2048 + 80 * 1025) * 4
+flop_fft = frames * (5 * 1024 * 10 + 8 * 1025 + 2 * 2100)   # 5 N log2 N convention
 print(json.dumps({"kernel": "mstts_stft_fft (one launch: window + real FFT in LDS + magnitude + mel + dB/normalise)", "audio_seconds": secs, "frames": frames,
                   "us_per_call": us_fft, "x_realtime": secs / (us_fft * 1e-6), "algorithmic_bytes": alg, "constant_table_bytes": tables_fft,
                   "hbm_roofline_us_at_8TBs": alg / 8e12 * 1e6, "achieved_GBs_on_algorithmic": alg / (us_fft * 1e-6) / 1e9,

@@ -226,18 +226,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             lb.load(B, g.ldb, n0, k0 + BK, g.N, kend, 0, 1, 0, 1);
         }
         const int kh = lane >> 5, l31 = lane & 31;
+        // operands of k-step kk + 2 are read from LDS BEFORE the MFMAs of k-step kk issue (two register sets, the scheduler is told
+        // to keep that order): left to itself the compiler reuses one register pair for every k-step and waits for each LDS read
+        // behind the previous MFMA group - an LDS round trip of dead matrix-core time per k-step (128 -> 14x TFLOP/s on dW shapes)
+        float a[2][WM], b[2][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[0][i] = As[kh * LDA_S + wrow + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[0][j] = Bs[kh * LDB_S + wcol + j * 32 + l31];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[WM], b[WN];
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = As[(kk + kh) * LDA_S + wrow + i * 32 + l31];
+                for (int i = 0; i < WM; ++i) a[nxt][i] = As[(kk + 2 + kh) * LDA_S + wrow + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = Bs[(kk + kh) * LDB_S + wcol + j * 32 + l31];
+                for (int j = 0; j < WN; ++j) b[nxt][j] = Bs[(kk + 2 + kh) * LDB_S + wcol + j * 32 + l31];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -43,55 +43,71 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // "KC": operand contiguous along k in memory (A row-major, or B given as [N,K]).
 //   rows = the M (or N) index, R rows per tile.  reg[] holds R*BK/256/4 float4 per thread.
 // "MC": operand contiguous along its M/N index (B row-major [K,N], or A given as [K,M]).
+// Out-of-range elements are read from this zero block instead of being skipped: the loads stay unconditional (no exec-mask
+// branches in the K loop, the scheduler can hide them behind the MFMAs) and the padding is zero without a select on the data.
+__device__ __attribute__((aligned(16))) const float gemm_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// Addressing: every load is  uniform base (SGPRs, advanced once per K-tile)  +  a 32-bit per-thread offset fixed at prepare()  -
+// no 64-bit address arithmetic and no bounds arithmetic beyond one compare in the K loop (it cost 9 % of the matrix-core time).
 template <int R, bool VEC>
 struct LoaderKC {
     static constexpr int NV = R * BK / 4 / 256;      // float4 per thread
     float4 reg[NV];
     // window: element (row, k) is tap j = k / C of a dilated 'same' conv: source row = row + (j - pad) * dil, valid iff it
-    // stays inside the row's length-T sequence (dil == 1: the taps of a row are contiguous, address = (row - pad) * ld + k).
-    // The divisions are hoisted: a thread's rows never change (t_row = row % T once) and k advances by BK per load (tap / kc kept
-    // incrementally) - prepare() once, then load() for k0, k0 + BK, ...
-    int t_row[NV], tap, kc;
-    __device__ __forceinline__ void prepare(int row0, int k0, int wT, int wC) {
-        if (wT > 0) {
-            const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) t_row[i] = (row0 + r + i * 32) % wT;
-            const int k = k0 + k4 * 4;
-            tap = k / wC; kc = k - tap * wC;
-        }
-    }
-    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int row0, int k0,
-                                         int rows, int kmax, int wT, int wC, int wpad, int wdil) {
+    // stays inside the row's length-T sequence.  A thread's rows never change (t_row = row % T once) and k advances by BK per
+    // load (tap / kc kept incrementally): prepare() once, then load() for k0, k0 + BK, ...
+    const float* ubase;                               // non-window: base + row0 ld + k0 ; window: base + (row0 - pad dil) ld
+    unsigned voff[NV], rmask;                         // (r + 32 i) ld (+ 4 k4 without window); bit i: row inside the operand
+    int t_row[NV], tap, kc, ld_;
+    __device__ __forceinline__ void prepare(const float* __restrict__ base, long ld, int row0, int k0, int rows,
+                                            int wT, int wC, int wpad, int wdil) {
         const int k4 = threadIdx.x & 7, r = threadIdx.x >> 3;
-        const int k = k0 + k4 * 4;
-        const int sh = wT > 0 ? (tap - wpad) * wdil : 0;
+        rmask = 0; ld_ = (int)ld;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int row = row0 + r + i * 32;
+            if (row < rows) rmask |= 1u << i;
+            voff[i] = (unsigned)((r + i * 32) * (int)ld) + (wT > 0 ? 0u : (unsigned)(k4 * 4));
+            if (wT > 0) t_row[i] = row % wT;
+        }
+        if (wT > 0) {
+            const int k = k0 + k4 * 4;
+            tap = k / wC; kc = k - tap * wC;
+            ubase = base + ((long)row0 - (long)wpad * wdil) * ld;
+        } else {
+            ubase = base + (long)row0 * ld + k0;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kmax, int wT, int wC, int wpad, int wdil) {
+        const int k4 = threadIdx.x & 7;
+        const int k = k0 + k4 * 4;
+        const bool kok = k < kmax;
+        const int sh = wT > 0 ? (tap - wpad) * wdil : 0;
+        const unsigned wadd = wT > 0 ? (unsigned)(tap * wdil * ld_ + kc) : 0u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool ok = row < rows && k < kmax;
-            long off = (long)row * ld + k;
+            bool ok = kok && ((rmask >> i) & 1u);
             if (wT > 0) {
                 const int t = t_row[i] + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)row + sh) * ld + kc;
             }
-            if (ok) {
-                if (VEC) {
-                    v = *reinterpret_cast<const float4*>(base + off);
-                } else {
-                    v.x = base[off];
-                    if (k + 1 < kmax) v.y = base[off + 1];
-                    if (k + 2 < kmax) v.z = base[off + 2];
-                    if (k + 3 < kmax) v.w = base[off + 3];
-                }
+            if (VEC) {
+                v = *reinterpret_cast<const float4*>(ok ? ubase + (voff[i] + wadd) : gemm_zero16);
+            } else if (ok) {
+                const float* p = ubase + (voff[i] + wadd);
+                v.x = p[0];
+                if (k + 1 < kmax) v.y = p[1];
+                if (k + 2 < kmax) v.z = p[2];
+                if (k + 3 < kmax) v.w = p[3];
             }
             reg[i] = v;
         }
         if (wT > 0) {                                  // next call is for k0 + BK
             kc += BK;
             while (kc >= wC) { kc -= wC; ++tap; }
+        } else {
+            ubase += BK;
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ s, int ldS) const {
@@ -111,48 +127,58 @@ struct LoaderMC {
     static constexpr int NV = BK / KR;
     float4 reg[NV];
     // window (A only): element (m, kk) with kk=(b,t) row index, m=(tap, c):
-    //   valid iff 0 <= (kk % T) + m / C - pad < T; address = base[(kk - pad) * ld + m]
-    // hoisted like LoaderKC: a thread's column (tap, c) is fixed, its k-rows advance by BK per load.
-    int sh, cm, t_k[NV];
-    __device__ __forceinline__ void prepare(int col0, int k0, int wT, int wC, int wpad, int wdil) {
-        if (wT > 0) {
-            const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
-            const int col = col0 + c4 * 4;
-            const int tp = col / wC;
-            sh = (tp - wpad) * wdil; cm = col - tp * wC;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) t_k[i] = (k0 + kr + i * KR) % wT;
-        }
-    }
-    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int col0, int k0,
-                                         int cols, int kmax, int wT, int wC, int wpad, int wdil) {
+    //   valid iff 0 <= (kk % T) + m / C - pad < T; address = base[(kk + (tap - pad) dil) * ld + c]
+    // a thread's column (tap, c) is fixed, its k-rows advance by BK per load.
+    const float* ubase;                               // base + k0 ld + col0 (window: base + (k0 - pad dil) ld), advanced by BK ld per load
+    unsigned voff[NV];
+    int sh, t_k[NV], cols_left;                       // cols_left: columns of the operand from this thread's first one (<= 0: none)
+    __device__ __forceinline__ void prepare(const float* __restrict__ base, long ld, int col0, int k0, int cols,
+                                            int wT, int wC, int wpad, int wdil) {
         const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
         const int col = col0 + c4 * 4;
+        cols_left = cols - col;
+        if (wT > 0) {
+            const int tp = col / wC, cm = col - tp * wC;
+            sh = (tp - wpad) * wdil;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                t_k[i] = (k0 + kr + i * KR) % wT;
+                voff[i] = (unsigned)((kr + i * KR + tp * wdil) * (int)ld + cm);
+            }
+            ubase = base + ((long)k0 - (long)wpad * wdil) * ld;
+        } else {
+            sh = 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) voff[i] = (unsigned)((kr + i * KR) * (int)ld + c4 * 4);
+            ubase = base + (long)k0 * ld + col0;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kmax, long ld, int wT) {
+        const int kr = threadIdx.x / C4;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int k = k0 + kr + i * KR;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool ok = k < kmax && col < cols;
-            long off = (long)k * ld + col;
+            bool ok = k < kmax && cols_left > 0;
             if (wT > 0) {
                 const int t = t_k[i] + sh;
                 ok = ok && t >= 0 && t < wT;
-                off = ((long)k + sh) * ld + cm;
                 t_k[i] += BK;                          // next call is for k0 + BK
-                while (t_k[i] >= wT) t_k[i] -= wT;
+                if (wT >= BK) t_k[i] -= (t_k[i] >= wT) ? wT : 0;      // one wrap at most (every real sequence is longer than a K-tile)
+                else while (t_k[i] >= wT) t_k[i] -= wT;
             }
-            if (ok) {
-                if (VEC) {
-                    v = *reinterpret_cast<const float4*>(base + off);
-                } else {
-                    v.x = base[off];
-                    if (col + 1 < cols) v.y = base[off + 1];
-                    if (col + 2 < cols) v.z = base[off + 2];
-                    if (col + 3 < cols) v.w = base[off + 3];
-                }
+            if (VEC) {
+                v = *reinterpret_cast<const float4*>(ok ? ubase + voff[i] : gemm_zero16);
+            } else if (ok) {
+                const float* p = ubase + voff[i];
+                v.x = p[0];
+                if (cols_left > 1) v.y = p[1];
+                if (cols_left > 2) v.z = p[2];
+                if (cols_left > 3) v.w = p[3];
             }
             reg[i] = v;
         }
+        ubase += BK * ld;
     }
     __device__ __forceinline__ void store(float* __restrict__ s, int ldS) const {
         const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
@@ -210,11 +236,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (TA) la.prepare(m0, kbeg, g.win_T, g.win_C, g.win_pad, g.win_dil);
-    else la.prepare(m0, kbeg, g.win_T, g.win_C);
+    auto load_a = [&](int k) {
+        if constexpr (TA) la.load(k, kend, g.lda, g.win_T);
+        else la.load(k, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
+    };
+    auto load_b = [&](int k) {
+        if constexpr (TB) lb.load(k, kend, 0, 1, 0, 1);
+        else lb.load(k, kend, g.ldb, 0);
+    };
+    la.prepare(A, g.lda, m0, kbeg, g.M, g.win_T, g.win_C, g.win_pad, g.win_dil);
+    lb.prepare(B, g.ldb, n0, kbeg, g.N, 0, 1, 0, 1);
     if (kbeg < kend) {
-        la.load(A, g.lda, m0, kbeg, g.M, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
-        lb.load(B, g.ldb, n0, kbeg, g.N, kend, 0, 1, 0, 1);
+        load_a(kbeg);
+        load_b(kbeg);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                       // previous tile fully consumed
@@ -222,8 +256,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         lb.store(Bs, LDB_S);
         __syncthreads();
         if (k0 + BK < kend) {                  // prefetch next tile while this one is multiplied
-            la.load(A, g.lda, m0, k0 + BK, g.M, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
-            lb.load(B, g.ldb, n0, k0 + BK, g.N, kend, 0, 1, 0, 1);
+            load_a(k0 + BK);
+            load_b(k0 + BK);
         }
         const int kh = lane >> 5, l31 = lane & 31;
         // operands of k-step kk + 2 are read from LDS BEFORE the MFMAs of k-step kk issue (two register sets, the scheduler is told
@@ -295,6 +329,8 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     if (d->M == 0 || d->N == 0) return MSTTS_OK;
     MSTTS_REQUIRE(d->A && d->B && d->C, MSTTS_ERR_SHAPE, "gemm: null operand");
     MSTTS_REQUIRE(d->M < (1LL << 31) && d->N < (1LL << 31) && d->K < (1LL << 31), MSTTS_ERR_SHAPE, "gemm: dims exceed int32");
+    MSTTS_REQUIRE(d->lda >= 0 && d->ldb >= 0 && d->lda < (1 << 24) && d->ldb < (1 << 24), MSTTS_ERR_SHAPE,
+                  "gemm: row strides must be below 2^24 elements (tile-relative offsets are 32-bit)");
     const int batch = d->batch > 0 ? (int)d->batch : 1;
     int split = d->split_k > 1 ? d->split_k : 1;
     MSTTS_REQUIRE(split == 1 || (d->act == MSTTS_ACT_NONE), MSTTS_ERR_SHAPE,

@@ -9,7 +9,7 @@ import torch
 
 from multi_speaker_tts_amd.engine import TrainEngine
 from oracle import train as OT
-from tests.helpers import dims_pair, t2n, to_dev
+from tests.helpers import dims_pair, rel_err, t2n, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -70,3 +70,96 @@ def test_train_step_through_rccl_one_rank(dev):
         assert len(dp.moving_stat_ranges()) >= 2 and torch.allclose(before, dp.params.frozen)
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, cfg, B, Te, L, q):
+    """One data-parallel rank of a 2-rank job; both ranks share the one GPU of the box, the collectives go through gloo (which
+    stages device tensors through the host) - everything else is the product path: sample-keyed masks, broadcast of rank 0's
+    state, gradient all-reduce overlapped with the backward pass, 1/world folded into Adam, statistics averaging."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from multi_speaker_tts_amd import dist as D
+    from multi_speaker_tts_amd.engine import TrainEngine as TE
+    from tests.helpers import dims_pair as dp_, to_dev as td_
+    from oracle import model as OM_, train as OT_
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pd, od = dp_(**cfg)
+        values = OM_.init_params(od, 21 + rank)                      # ranks start DIFFERENT: the broadcast must fix that
+        eng = TE(pd, device=dev, values=values, seed=1234, rank=rank, world=world)
+        eng.broadcast_state(src=0)
+        full = OT_.synthetic_batch(od, world * B, Te, L, seed=9, ragged=True)
+        mine = {k: v[rank * B:(rank + 1) * B] for k, v in full.items()}
+        # a rank pads to ITS longest sequence; give every rank the global maximum so the shards line up with the oracle's
+        red = D.GradAllReduce(eng.params.grad, world, bucket_mb=0.25)
+        w = eng.train_step(td_(mine, dev), all_reduce=red)
+        eng.sync_statistics()
+        torch.cuda.synchronize()
+        sc = eng.scalars(w, average=True)
+        q.put((rank, eng.params.export(), sc["Loss"], eng.exchange_timeouts(w)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_against_oracle(dev):
+    """N = 2 data parallel end to end on the hardware at hand: two processes on the one GPU, gloo collectives.  Expected result
+    from the oracle: every rank's gradient on its shard (masks keyed by global sample index, per-rank BN batch statistics), the
+    mean of the two, ONE TF-Adam update from rank 0's initial state; BN moving statistics = mean of the ranks' updates."""
+    import torch.multiprocessing as mp
+    from oracle import model as OM
+    cfg = dict(dec_lstm=64, enc_lstm=32, spk=64, prenet=32)
+    B, Te, L, world = 3, 11, 7, 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, cfg, B, Te, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, params, loss, timeouts = q.get(timeout=600)
+        got[r] = (params, loss, timeouts)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # ---- the same step in the oracle
+    pd, od = dims_pair(**cfg)
+    values = OM.init_params(od, 21)                                   # rank 0's state
+    full = OT.synthetic_batch(od, world * B, Te, L, seed=9, ragged=True)
+    grads, stats, losses = [], [], []
+    for r in range(world):
+        mine = {k: v[r * B:(r + 1) * B] for k, v in full.items()}
+        S = int(mine["Mel"].shape[1]) + 1
+        masks = OT.make_masks(od, B, Te, S, True, seed=OT.step_seed(1234, 0), rank=r)
+        new_p, _, sc, g, _ = OT.train_step(values, None, od, mine, masks, 0, return_grads=True)
+        grads.append(g); stats.append(new_p); losses.append(sc["Loss"])
+    lr = OT.learning_rate(0)
+    for r in range(world):
+        params, loss, timeouts = got[r]
+        assert timeouts == 0
+        assert abs(loss - float(np.mean(losses))) < 2e-4 * max(1.0, abs(float(np.mean(losses))))
+        bad = {}
+        for k in values:
+            if k.startswith("speaker_embedding"):
+                continue
+            p0 = torch.tensor(np.asarray(values[k]), dtype=torch.float64)
+            if k in grads[0]:
+                gm = sum(g[k] for g in grads) / world
+                want, _, _ = OT.adam_tf(p0, gm, torch.zeros_like(p0), torch.zeros_like(p0), 1, lr)
+            elif OM.is_trainable(k):
+                want = p0
+            else:
+                want = sum(s[k].double() if torch.is_tensor(s[k]) else torch.tensor(np.asarray(s[k])) for s in stats) / world
+            e = rel_err(params[k], want.numpy())
+            if e > 2e-3:
+                bad[k] = e
+        assert not bad, (r, bad)
+    # both ranks end with the same variables, bit for bit
+    for k in got[0][0]:
+        assert np.array_equal(got[0][0][k], got[1][0][k]), k

@@ -73,15 +73,36 @@ __device__ __forceinline__ float sum_parts(const float* __restrict__ p, int part
 }
 constexpr int MSTTS_MAX_PARTS = 16;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide reductions on the DPP path (row operations inside the VALU, a few cycles each) instead of ds_bpermute shuffles (an
+// LDS round trip per step: six dependent steps were ~0.25 us on the critical path of the latency-bound per-step kernels).
+//   quad_perm 1,0,3,2 / 2,3,0,1 -> quads ; row_half_mirror -> 8 ; row_mirror -> rows of 16 ; row_bcast15 (rows 1, 3) -> halves of 32
+//   in lanes 16-31 / 48-63 ; row_bcast31 (rows 2, 3) -> the wave's total in row 3 ; readlane 63 broadcasts it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sums of the two 32-lane halves: valid in lanes 31 (lanes 0-31) and 63 (lanes 32-63)
+__device__ __forceinline__ float half_sum_in_last_lane(float v) {
+    v += dpp_mov<0xB1, 0xf>(0.f, v);
+    v += dpp_mov<0x4E, 0xf>(0.f, v);
+    v += dpp_mov<0x141, 0xf>(0.f, v);
+    v += dpp_mov<0x140, 0xf>(0.f, v);
+    v += dpp_mov<0x142, 0xa>(0.f, v);
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    v = half_sum_in_last_lane(v);
+    v += dpp_mov<0x143, 0xc>(0.f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x4E, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x141, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x140, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_mov<0x143, 0xc>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); scratch needs 16 floats of LDS

@@ -418,9 +418,9 @@ __global__ __launch_bounds__(256) void lsa_dalign_kernel(mstts_lsa_const c, cons
         }
     }
     // ---- G for the TS rows: 32-lane sums of the diagonal taps
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) hv += __shfl_xor(hv, o, 64);
-    if (jh == 0) s_g[tt_h] = hv;
+    static_assert(LPR == 32, "half_sum_in_last_lane sums 32-lane groups");
+    hv = half_sum_in_last_lane(hv);
+    if (jh == LPR - 1) s_g[tt_h] = hv;
     __syncthreads();
     if (threadIdx.x < TS) s_g[threadIdx.x] += gn;
     __syncthreads();
@@ -678,10 +678,9 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     }
     // ---- this slice's G (32-lane sums of the diagonal taps) and the row's alignments in LDS
     {
-        float x = hv;
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        if (jh == 0) s_G[tt_h] = x;
+        static_assert(LPR == 32, "half_sum_in_last_lane sums 32-lane groups");
+        const float x = half_sum_in_last_lane(hv);
+        if (jh == LPR - 1) s_G[tt_h] = x;
     }
 #pragma unroll
     for (int i = 0; i < T_MAX / 256; ++i) {
@@ -901,7 +900,7 @@ __global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, i
         if (t0 + row < T) atomicAdd(d_keys + ((long)b * T + t0 + row) * A_ + a, acc_keys[r]);
         if (row < KS) atomicAdd(d_loc_k + row * A_ + a, acc_lk[r]);                 // row = tap j here
     }
-    acc_w += __shfl_xor(acc_w, 32);
+    acc_w += __shfl_xor(acc_w, 32);            // (once per workgroup, off any per-step path)
     acc_b += __shfl_xor(acc_b, 32);
     if (kh == 0) {
         atomicAdd(d_score_w + a, acc_w);

@@ -175,9 +175,11 @@ __device__ __forceinline__ void cell_fwd_body(const CellFwd& d) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) g4[q] = ((red[0][er][4 * q + ec] + red[1][er][4 * q + ec]) + (red[2][er][4 * q + ec] + red[3][er][4 * q + ec])) + (xwv[q] + bv[q]);
     const float kc = zcv ? d.keep : 0.f, kh = zhv ? d.keep : 0.f;
-    float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
+    // activations through one hardware exp each (v_exp_f32, ~1e-7 relative): the library forms are 3-4x the instructions on the
+    // tail of a latency-bound kernel
+    float si = sigmoidf_(g4[0]), tj = tanhf_(g4[1]), sf = sigmoidf_(g4[2] + 1.0f), so = sigmoidf_(g4[3]);
     float c = sf * cp + si * tj;
-    float m = so * tanhf(c);
+    float m = so * tanhf_(c);
     float hn = kh * (m - hp) + hp, cn = kc * (c - cp) + cp;
     if (SEQ && !rlive) { m = 0.f; hn = hp; cn = cp; si = 0.f; tj = 0.f; sf = 0.f; so = 0.f; c = cp; }
     d.c_next[eb * H + eu] = cn;

@@ -407,9 +407,9 @@ __global__ void lstm_point_fwd_kernel(mstts_lstm_point_fwd_desc d) {
             if (d.bias) v += d.bias[g * H + u];
             g4[g] = v;
         }
-        const float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
+        const float si = sigmoidf_(g4[0]), tj = tanhf_(g4[1]), sf = sigmoidf_(g4[2] + 1.0f), so = sigmoidf_(g4[3]);
         const float c = sf * cp + si * tj;
-        const float m = so * tanhf(c);
+        const float m = so * tanhf_(c);
         float dc = c - cp, dm = m - hp;
         if (d.zc) dc = d.zc[i] ? dc : 0.f;
         if (d.zh) dm = d.zh[i] ? dm : 0.f;
@@ -463,7 +463,7 @@ __global__ void lstm_point_bwd_kernel(mstts_lstm_point_bwd_desc d) {
         const float* a = d.acts + (long)b * 4 * H + u;
         const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
         const float c = d.c_raw[i], cp = d.c_prev[i];
-        const float tc = tanhf(c);
+        const float tc = tanhf_(c);
         const float dc = dm * so * (1.f - tc * tc) + mc * dcs;
         const float d_o = dm * tc * so * (1.f - so);
         const float d_i = dc * tj * si * (1.f - si);
@@ -534,9 +534,9 @@ __global__ __launch_bounds__(128) void lstm_point_fwd_fast_kernel(PointFwdFast d
     }
     const float kc = d.zc ? (d.zc[i] ? d.keep : 0.f) : d.keep;
     const float kh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
-    const float si = sigmoid_acc(g4[0]), tj = tanhf(g4[1]), sf = sigmoid_acc(g4[2] + 1.0f), so = sigmoid_acc(g4[3]);
+    const float si = sigmoidf_(g4[0]), tj = tanhf_(g4[1]), sf = sigmoidf_(g4[2] + 1.0f), so = sigmoidf_(g4[3]);
     const float c = sf * cp + si * tj;
-    const float m = so * tanhf(c);
+    const float m = so * tanhf_(c);
     d.c_next[i] = kc * (c - cp) + cp;
     d.h_next[b * d.h_next_ld + u] = kh * (m - hp) + hp;
     float o = m;
@@ -628,7 +628,7 @@ __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) 
     const float* a = d.acts + b * 4 * H + u;
     const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
     const float c = d.c_raw[i], cp = d.c_prev[i];
-    const float tc = tanhf(c);
+    const float tc = tanhf_(c);
     const float dc = dm * so * (1.f - tc * tc) + mc * dcs;
     const float d_i = dc * tj * si * (1.f - si), d_j = dc * si * (1.f - tj * tj), d_f = dc * cp * sf * (1.f - sf), d_o = dm * tc * so * (1.f - so);
     dg[0] = d_i; dg[H] = d_j; dg[2 * H] = d_f; dg[3 * H] = d_o;

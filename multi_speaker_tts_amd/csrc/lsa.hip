@@ -590,6 +590,7 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     __shared__ float s_dq[A_];
     __shared__ float scratch[16];
     __shared__ float s_dot2;
+    __shared__ float s_gn[TS];
     const int t0 = sl * TS, T = (int)c.T, M = (int)c.M, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k = threadIdx.x & (A_ - 1), grp = threadIdx.x >> 7;
@@ -688,6 +689,7 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
         if (t < T) s_a[t] = av[i];
     }
     *reinterpret_cast<float4*>(&s_dc[lane * 4 + 256 * w]) = dsum;
+    if (threadIdx.x < TS) s_gn[threadIdx.x] = gn_own;
     // the filter / window of the tanh recompute
 #pragma unroll
     for (int i = 0; i < NLK; ++i) {
@@ -750,8 +752,10 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
         p2 = wave_sum(p2);
         if (lane == 0) s_dot2 = p2;
     }
-    if (threadIdx.x < TS) s_G[threadIdx.x] += gn_own;         // (written before the barrier above, read after the ones inside block_sum)
-    const float dot = block_sum(part, scratch) + s_dot2;      // block_sum synchronises: s_G and s_dot2 are complete behind it
+    // (no barrier here: the per-wave partial sums of dot(a, G), ctx . d_ctx and the d_align rows all meet behind the ONE barrier below -
+    // the kernel had six barriers, each an LDS round trip on its critical path; it has three)
+    part = wave_sum(part);
+    if (lane == 0) scratch[w] = part;
     // ---- d_align = G + values . d_ctx for this slice's rows (kept in LDS)
 #pragma unroll
     for (int r = 0; r < TS / 4; ++r) {
@@ -774,24 +778,23 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
         }
         acc = wave_sum(acc);
         if (lane == 0) {
-            const float g = (t < T) ? s_G[tt] : 0.f;
+            const float g = (t < T) ? s_G[tt] + s_gn[tt] : 0.f;
             if (t < T) G[(long)b * T + t] = g;
             s_da[tt] = (t < T) ? g + acc : 0.f;
         }
     }
     __syncthreads();
+    const float dot = ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) + s_dot2;
     if (threadIdx.x < TS) {
         const int t = t0 + threadIdx.x;
-        const float de = (t < T) ? a_own * (s_da[threadIdx.x] - dot) : 0.f;
-        if (t < T) d_e_out[(long)b * T + t] = de;
-        s_de[threadIdx.x] = de;
+        if (t < T) d_e_out[(long)b * T + t] = a_own * (s_da[threadIdx.x] - dot);
     }
-    __syncthreads();
     float dq_acc = 0.f;
 #pragma unroll
     for (int i = 0; i < TS / 2; ++i) {
         const int tt = grp + 2 * i;
-        const float g = s_de[tt] * fac[i];
+        const float de = (t0 + tt < T) ? s_a[t0 + tt] * (s_da[tt] - dot) : 0.f;     // every thread forms the d_e of its own positions
+        const float g = de * fac[i];
         s_g[tt][k] = g;
         dq_acc += g;
     }

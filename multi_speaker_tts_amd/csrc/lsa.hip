@@ -273,7 +273,9 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
 #pragma unroll
     for (int i = 0; i < FS_VPRE; ++i) {
         const int t = vg + ng * i;
-        vv[i] = (vlive && t < len) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (bounded by T, not by the row's length: `len` is itself a load, and the 12.6 MB of values must not wait for it - rows
+        // between len and T are real memory and get a zero alignment below)
+        vv[i] = (vlive && t < T) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // ---- own energy slice
     if (tid < FS_TSL + KS_MAX - 1 + 2) s_cum[tid] = cwin;          // entries past the window are zero
@@ -673,8 +675,8 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
 #pragma unroll
         for (int m = 0; m < MROW; ++m) {
             const int i = lane * 4 + 256 * m;
-            val[r][m] = (t < len && i < M) ? *reinterpret_cast<const float4*>(c.values + ((long)b * T + t) * M + i)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            val[r][m] = (t < T && i < M) ? *reinterpret_cast<const float4*>(c.values + ((long)b * T + t) * M + i)     // (T, not len:
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);                                                // a[t] = 0 there)
         }
     }
     // ---- this slice's G (32-lane sums of the diagonal taps) and the row's alignments in LDS

@@ -29,7 +29,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM-side traffic per launch comes from the committed rocprofv3 PMC passes of THIS kernel version (separate --pmc FETCH_SIZE /
 # --pmc WRITE_SIZE runs with --kernel-trace only, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; collected by
 # tools/profile_round.sh, aggregated by tools/pmc_summary.py).  No file / no row -> traffic is reported as null.
-PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_kernel.csv")
+def _latest_pmc_csv():
+    """The newest round's committed FETCH/WRITE pass (profiles/rNN_pmc_fetch_write_per_kernel.csv)."""
+    import glob
+    import re
+    best, best_n = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_kernel.csv"), -1
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_per_kernel.csv")):
+        m = re.match(r"r(\d+)_pmc_fetch_write_per_kernel\.csv$", os.path.basename(f))
+        if m and int(m.group(1)) > best_n:
+            best, best_n = f, int(m.group(1))
+    return best
+
+
+PMC_TRAFFIC_CSV = _latest_pmc_csv()
 
 
 def pmc_traffic_bytes(kernel_prefix):

@@ -56,7 +56,8 @@ struct LoaderKC {
     // window: element (row, k) is tap j = k / C of a dilated 'same' conv: source row = row + (j - pad) * dil, valid iff it
     // stays inside the row's length-T sequence.  A thread's rows never change (t_row = row % T once) and k advances by BK per
     // load (tap / kc kept incrementally): prepare() once, then load() for k0, k0 + BK, ...
-    const float* ubase;                               // non-window: base + row0 ld + k0 ; window: base + (row0 - pad dil) ld
+    const float* ubase;                               // non-window: base + row0 ld + k0 ; window: base + (row0 - pad dil) ld (for the
+                                                      // first tile that is in front of the operand: only ever added to offsets of valid taps)
     unsigned voff[NV], rmask;                         // (r + 32 i) ld (+ 4 k4 without window); bit i: row inside the operand
     int t_row[NV], tap, kc, ld_;
     __device__ __forceinline__ void prepare(const float* __restrict__ base, long ld, int row0, int k0, int rows,

@@ -219,11 +219,16 @@ typedef struct {
     const float* keys; const float* values; const int32_t* lengths;
     const float* conv_k; const float* conv_b; const float* dense_k; const float* score_w; const float* score_b;
     const float* loc_k; const float* loc_b;   /* folded location filter [KS,A], [A] (mstts_lsa_fold_location) */
+    const float* loc_kt;                      /* optional: the same filter by unit, [A,36] (taps >= KS zero; mstts_lsa_filter_by_unit) - the
+                                                 single-launch forward step then reads a unit's taps as 8 float4 instead of 31 words */
 } mstts_lsa_const;
 /* The location conv (KS taps, 1 -> CH, +bias) and the bias-free dense CH -> A that follows it are one linear map;
  * the step kernels use it folded: loc_k = conv_k . dense_k, loc_b = conv_b . dense_k.  Refresh after the variables change. */
 int mstts_lsa_fold_location(const float* conv_k, const float* conv_b, const float* dense_k, float* loc_k, float* loc_b,
                             int64_t KS, int64_t CH, int64_t A, mstts_stream_t s);
+/* loc_kt[a*36 + j] = loc_k[j*A + a] for j < KS, 0 for KS <= j < 36 (KS <= 31; 36 * A floats, 16-byte aligned): the by-unit copy
+ * mstts_lsa_const.loc_kt points to */
+int mstts_lsa_filter_by_unit(const float* loc_k, float* loc_kt, int64_t KS, int64_t A, mstts_stream_t s);
 /* accumulate the gradients of conv_k / conv_b / dense_k from d_loc_k [KS,A] and d_loc_b [A] (= d_score_b) */
 int mstts_lsa_unfold_location_grad(const float* conv_k, const float* conv_b, const float* dense_k, const float* d_loc_k,
                                    const float* d_loc_b, float* d_conv_k, float* d_conv_b, float* d_dense_k,

@@ -82,6 +82,7 @@ class TrainEngine:
         self.dwp_pad = self._f(H + M, self.proj_ld)
         self.dw0f = self._f(M + H, 4 * H)
         self.loc_k, self.loc_b, self.d_loc_k = self._f(d.att_k, d.att), self._f(d.att), self._f(d.att_k, d.att)
+        self.loc_kt = self._f(d.att, 36) if d.att_k <= 31 else None       # the folded filter by unit (forward attention step)
         # fused cell steps (csrc/cell.hip): the two decoder cell kernels in the lanes' consumption order
         lb = lib.load()
         self.fused_cells = bool(lb.mstts_cell_fwd_supported(H, M + H)) and bool(lb.mstts_cell_fwd_supported(H, 2 * H))
@@ -184,6 +185,8 @@ class TrainEngine:
         ck, ock = self.P(LSA + "attention_convolution_dense_layer/conv1d/kernel"); cb, ocb = self.P(LSA + "attention_convolution_dense_layer/conv1d/bias")
         dk, odk = self.P(LSA + "attention_convolution_dense_layer/dense/kernel")
         call("mstts_lsa_fold_location", ptr(ck, ock), ptr(cb, ocb), ptr(dk, odk), ptr(self.loc_k), ptr(self.loc_b), d.att_k, d.att_ch, d.att)
+        if self.loc_kt is not None:
+            call("mstts_lsa_filter_by_unit", ptr(self.loc_k), ptr(self.loc_kt), d.att_k, d.att)
         self._derived_stale = False
 
     def plan(self, B, Te, L):
@@ -381,7 +384,7 @@ class TrainEngine:
                             ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
             t, o = self.P(LSA + name)
             setattr(ls, field, ptr(t, o))
-        ls.loc_k, ls.loc_b = ptr(self.loc_k), ptr(self.loc_b)
+        ls.loc_k, ls.loc_b, ls.loc_kt = ptr(self.loc_k), ptr(self.loc_b), ptr(self.loc_kt)
         k1, o1 = self.P(CELL % 1 + "kernel"); b1, ob1 = self.P(CELL % 1 + "bias"); wq, oq = self.P(LSA + "query_layer/kernel")
         dec.xw0, dec.w0f, dec.w1, dec.b1, dec.wq = ptr(w.xw0), ptr(self.w0f), ptr(k1, o1), ptr(b1, ob1), ptr(wq, oq)
         dec.zc0, dec.zh0, dec.zc1, dec.zh1 = ptr(mk["dec_zc_0"]), ptr(mk["dec_zh_0"]), ptr(mk["dec_zc_1"]), ptr(mk["dec_zh_1"])

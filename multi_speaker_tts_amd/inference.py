@@ -152,6 +152,10 @@ class InferEngine:
         loc_k, loc_b = self._f(d.att_k, A), self._f(A)
         call("mstts_lsa_fold_location", ls.conv_k, ls.conv_b, ls.dense_k, ptr(loc_k), ptr(loc_b), d.att_k, d.att_ch, A)
         ls.loc_k, ls.loc_b = ptr(loc_k), ptr(loc_b)
+        if d.att_k <= 31:
+            loc_kt = self._f(A, 36)
+            call("mstts_lsa_filter_by_unit", ptr(loc_k), ptr(loc_kt), d.att_k, A)
+            ls.loc_kt = ptr(loc_kt)
         for field, name in (("pw0", "decoder/decoder/prenet_0/dense/kernel"), ("pb0", "decoder/decoder/prenet_0/dense/bias"),
                             ("pw1", "decoder/decoder/prenet_1/dense/kernel"), ("pb1", "decoder/decoder/prenet_1/dense/bias"),
                             ("w1", CELL % 1 + "kernel"), ("b1", CELL % 1 + "bias"), ("wq", LSA + "query_layer/kernel"),

@@ -59,7 +59,7 @@ class CellFwd(C.Structure):
 class LsaConst(C.Structure):
     _fields_ = [("B", i64), ("T", i64), ("A", i64), ("M", i64), ("KS", i64), ("CH", i64),
                 ("keys", vp), ("values", vp), ("lengths", vp),
-                ("conv_k", vp), ("conv_b", vp), ("dense_k", vp), ("score_w", vp), ("score_b", vp), ("loc_k", vp), ("loc_b", vp)]
+                ("conv_k", vp), ("conv_b", vp), ("dense_k", vp), ("score_w", vp), ("score_b", vp), ("loc_k", vp), ("loc_b", vp), ("loc_kt", vp)]
 
 
 class LstmSeqFwd(C.Structure):
@@ -145,6 +145,7 @@ SIGNATURES = {
     "mstts_lsa_denergy_bwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, vp, vp, vp]),
     "mstts_lsa_param_bwd": (i32, [P(LsaConst), i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mstts_lsa_fold_location": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "mstts_lsa_filter_by_unit": (i32, [vp, vp, i64, i64, vp]),
     "mstts_lsa_unfold_location_grad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "mstts_tts_loss_fwd_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i32, f32, vp, vp, vp, vp, vp]),
     "mstts_l2_loss_acc": (i32, [vp, vp, i64, vp, vp]),

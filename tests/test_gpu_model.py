@@ -85,6 +85,10 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     loc_k, loc_b = torch.zeros(KS, A, device=dev), torch.zeros(A, device=dev)
     lib.call("mstts_lsa_fold_location", c.conv_k, c.conv_b, c.dense_k, lib.ptr(loc_k), lib.ptr(loc_b), KS, CH, A)
     c.loc_k, c.loc_b = lib.ptr(loc_k), lib.ptr(loc_b)
+    loc_kt = torch.full((A, 36), 7.0, device=dev)              # the by-unit copy the single-launch forward step prefers
+    lib.call("mstts_lsa_filter_by_unit", lib.ptr(loc_k), lib.ptr(loc_kt), KS, A)
+    assert torch.equal(loc_kt[:, :KS], loc_k.t()) and float(loc_kt[:, KS:].abs().max()) == 0.0
+    c.loc_kt = lib.ptr(loc_kt)
     wc = p[LSA + "attention_convolution_dense_layer/conv1d/kernel"][:, 0, :]
     assert rel_err(t2n(loc_k), wc @ p[LSA + "attention_convolution_dense_layer/dense/kernel"]) < 2e-6
     q = f32(query @ p[LSA + "query_layer/kernel"]); dcum = f32(cum)

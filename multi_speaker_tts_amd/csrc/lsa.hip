@@ -614,12 +614,12 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
         const int t = t0 - pad + threadIdx.x;
         if (t >= 0 && t < T) cwin = cum[(long)b * T + t];
     }
-    constexpr int NLK = (KS_MAX * A_ + 255) / 256;
-    float lkv[NLK];
+    constexpr int NLK4 = (KS_MAX * A_ / 4 + 255) / 256;   // the filter as float4: 4 loads per thread instead of 16 words
+    float4 lkv[NLK4];
 #pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        lkv[i] = (e < KS * A_) ? c.loc_k[e] : 0.f;
+    for (int i = 0; i < NLK4; ++i) {
+        const int e4 = threadIdx.x + 256 * i;
+        lkv[i] = (e4 * 4 < KS * A_) ? reinterpret_cast<const float4*>(c.loc_k)[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float* keys = c.keys + ((long)b * T + t0) * A_ + k;
     float kv[TS / 2];
@@ -703,9 +703,9 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
     if (threadIdx.x < TS) s_gn[threadIdx.x] = gn_own;
     // the filter / window of the tanh recompute
 #pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        if (e < KS_MAX * A_) s_lk[e / A_][e % A_] = lkv[i];
+    for (int i = 0; i < NLK4; ++i) {
+        const int e = (threadIdx.x + 256 * i) * 4;
+        if (e < KS_MAX * A_) *reinterpret_cast<float4*>(&s_lk[e / A_][e % A_]) = lkv[i];
     }
     if (threadIdx.x < TS + KS_MAX - 1) s_cum[threadIdx.x] = cwin;
     __syncthreads();
@@ -1021,6 +1021,7 @@ extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, 
     MSTTS_REQUIRE(aligned16(d_ctx) && aligned16(d_ctx2) && d_ctx_ld % 4 == 0 && d_ctx2_ld % 4 == 0, MSTTS_ERR_ALIGN,
                   "lsa_step_bwd: d_ctx rows must be 16-byte aligned");
     MSTTS_REQUIRE(ctx_fwd && aligned16(ctx_fwd) && ctx_fwd_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_bwd: the forward context rows (16-byte aligned) are required");
+    MSTTS_REQUIRE(aligned16(c->loc_k), MSTTS_ERR_ALIGN, "lsa_step_bwd: the folded filter loc_k must be 16-byte aligned");
     hipLaunchKernelGGL(lsa_step_bwd_kernel, dim3((unsigned)(cdiv(c->T, TS) * c->B)), dim3(256), 0, ST(s), *c, d_ctx, (long)d_ctx_ld, d_ctx2,
                        (long)d_ctx2_ld, (int)d_ctx2_parts, (long)d_ctx2_pstride, G_next, d_f_next, G, align, q, cum, ctx_fwd, (long)ctx_fwd_ld, d_e, dq, d_f,
                        cdiv(c->T, TS));

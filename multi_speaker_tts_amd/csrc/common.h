@@ -42,13 +42,15 @@ __device__ __forceinline__ float tanhf_(float x) {
 // (k % (16 nit)) / 16 for row tile (r % 32) / 16 - every wave load of the consumer is one contiguous 1 KB.  Blocks of 32 rows
 // follow each other.
 __device__ __forceinline__ int cell_act_offset(int r, int k, int nit) {
-    const int blk = r >> 5, rr = r & 31, w = k / (16 * nit), kk = k - w * 16 * nit;
+    const int q = 16 * nit, blk = r >> 5, rr = r & 31;
+    const int w = (k >= q) + (k >= 2 * q) + (k >= 3 * q), kk = k - w * q;    // k / q without a division (k < 4 q; this sits on producers' tails)
     return blk * (2048 * nit) + (((w * nit + (kk >> 4)) * 2 + (rr >> 4)) << 8) + ((((kk & 15) >> 2) * 16 + (rr & 15)) << 2) + (kk & 3);
 }
 // bf16 form (config 3): 16-byte lane fragments of v_mfma_f32_16x16x32_bf16 - wave k / (K/4), 32-k step (k % (K/4)) / 32, lane
 // ((k % 32) / 8) * 16 + r % 16 holds 8 consecutive k; nit = K / 128.  Offsets in bf16 elements.
 __device__ __forceinline__ int cell_act_offset_bf16(int r, int k, int nit) {
-    const int blk = r >> 5, rr = r & 31, w = k / (32 * nit), kk = k - w * 32 * nit;
+    const int q = 32 * nit, blk = r >> 5, rr = r & 31;
+    const int w = (k >= q) + (k >= 2 * q) + (k >= 3 * q), kk = k - w * q;
     return blk * (4096 * nit) + (((w * nit + (kk >> 5)) * 2 + (rr >> 4)) << 9) + ((((kk & 31) >> 3) * 16 + (rr & 15)) << 3) + (kk & 7);
 }
 struct PackedDst { float* base; int nit, col0, bf; };  // packed block of a consumer cell (bf: bf16 form); the producer owns columns col0 ...

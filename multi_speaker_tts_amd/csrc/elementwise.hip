@@ -558,6 +558,7 @@ struct PointBwdFast {
     float* dgates_pos; int dgp_ld, dgp_st;                         // SEQ only (or null)
     const float* dq; const float* wq_t;                            // FUSE_Q only: [B][QA], [QA/4][H][4]
     int B, H;
+    int row2d;                                                     // grid (H / 128, B): the row is blockIdx.y - no division in front of the loads
 };
 constexpr int QA = 128;        // attention units of the fused query-layer gradient (hp.Attention.Memory_Size)
 
@@ -567,12 +568,16 @@ struct PointBwdFastPair { PointBwdFast d[2]; };      // two independent cells pe
 
 template <int P_OUT, int P_OUT2, int P_DHS, bool SEQ, int FUSE_Q = 0>        // FUSE_Q: 0 off, 1 fp32, 2 bf16-rounded operands
 __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) {
-    const int i = blockIdx.x * 128 + threadIdx.x;
     const int H = d.H;
-    if (i >= d.B * H) return;
     // fused form: H % 128 == 0 (checked by the host), so the 128 threads of a block share one row - a block-uniform index lets the dq
     // row come through scalar loads
-    const int b = FUSE_Q ? (int)(blockIdx.x * 128) / H : i / H, u = i - b * H;
+    int i, b, u;
+    if (d.row2d) { b = blockIdx.y; u = blockIdx.x * 128 + threadIdx.x; i = b * H + u; }
+    else {
+        i = blockIdx.x * 128 + threadIdx.x;
+        if (i >= d.B * H) return;
+        b = FUSE_Q ? (int)(blockIdx.x * 128) / H : i / H; u = i - b * H;
+    }
     int pos = 0;
     bool live = true;
     if (SEQ) {
@@ -1060,7 +1065,7 @@ static void point_bwd_fill(const mstts_lstm_point_bwd_desc* d, PointBwdFast& f) 
     f.dgates = d->dgates; f.d_c_prev = d->d_c_prev; f.d_h_prev = d->d_h_prev;
     f.lengths = d->lengths; f.step = d->step; f.reverse = d->reverse;
     f.dgates_pos = d->dgates_pos; f.dgp_ld = (int)d->dgp_sb; f.dgp_st = (int)d->dgp_st;
-    f.B = (int)d->B; f.H = (int)d->H;
+    f.B = (int)d->B; f.H = (int)d->H; f.row2d = 0;
 }
 
 /* the pointwise backward of two independent cells of the same shape in ONE launch (the two directions of a BiLSTM step, sequence
@@ -1122,7 +1127,9 @@ extern "C" int mstts_lstm_point_bwd(const mstts_lstm_point_bwd_desc* d, mstts_st
             f.lengths = d->lengths; f.step = d->step; f.reverse = d->reverse;
             f.dgates_pos = d->dgates_pos; f.dgp_ld = (int)d->dgp_sb; f.dgp_st = (int)d->dgp_st;
             f.B = (int)d->B; f.H = (int)d->H;
+            f.row2d = (d->H % 128 == 0 && d->B <= 65535) ? 1 : 0;
             dim3 grid((unsigned)((d->B * d->H + 127) / 128));
+            if (f.row2d) grid = dim3((unsigned)(d->H / 128), (unsigned)d->B);
 #define MSTTS_PB(A1, A2, A3)                                                                                          \
             if (seq) hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<A1, A2, A3, true>), grid, dim3(128), 0, ST(s), f);   \
             else hipLaunchKernelGGL((lstm_point_bwd_fast_kernel<A1, A2, A3, false>), grid, dim3(128), 0, ST(s), f)

@@ -454,3 +454,21 @@ def test_cell_fwd_fused_bf16(dev, B, H, K):
         chk = torch.zeros_like(outp)
         lib.call("mstts_pack_cell_act_bf16", lib.ptr(ref), K2, lib.ptr(chk), B, K2)
         assert torch.equal(chk, outp)
+
+
+def test_bf16_exchange_kernels(dev):
+    """mstts_f32_to_bf16 (round to nearest even) / mstts_bf16_chunks_sum (fp32 accumulation in chunk order, one rounding) /
+    mstts_bf16_to_f32: the three kernels of the config-3 gradient exchange, against torch's bf16 conversions bit for bit."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn(4, 1003, generator=g) * torch.logspace(-6, 3, 1003)).to(dev)
+    x[0, :4] = torch.tensor([1.0 + 2 ** -9, 1.0 + 3 * 2 ** -9, -0.0, 65504.0], device=dev)      # ties to even, signed zero, large
+    y = torch.zeros(4, 1003, dtype=torch.bfloat16, device=dev)
+    lib.call("mstts_f32_to_bf16", lib.ptr(x), lib.ptr(y), x.numel())
+    assert torch.equal(y, x.to(torch.bfloat16))
+    s = torch.zeros(1003, dtype=torch.bfloat16, device=dev)
+    lib.call("mstts_bf16_chunks_sum", lib.ptr(y), 4, 1003, 1003, lib.ptr(s))
+    want = ((y[0].float() + y[1].float()) + y[2].float() + y[3].float()).to(torch.bfloat16)
+    assert torch.equal(s, want)
+    z = torch.zeros(1003, device=dev)
+    lib.call("mstts_bf16_to_f32", lib.ptr(s), lib.ptr(z), 1003)
+    assert torch.equal(z, s.float())

@@ -585,13 +585,14 @@ __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) 
         live = d.step < len;
         pos = (d.reverse && live) ? len - 1 - d.step : d.step;
     }
-    float4 wqv[FUSE_Q ? QA / 4 : 1], dqv[FUSE_Q ? QA / 4 : 1];
+    float4 wqv[FUSE_Q ? QA / 4 : 1], dqv[1];
+    __shared__ float4 s_dq[QA / 4];
     if (FUSE_Q) {                 // wq_t is [QA/4][H][4]: consecutive units are consecutive float4 - 1 KB per wave load
 #pragma unroll
-        for (int a = 0; a < QA / 4; ++a) {
-            wqv[a] = reinterpret_cast<const float4*>(d.wq_t)[a * H + u];
-            dqv[a] = reinterpret_cast<const float4*>(d.dq)[b * (QA / 4) + a];
-        }
+        for (int a = 0; a < QA / 4; ++a) wqv[a] = reinterpret_cast<const float4*>(d.wq_t)[a * H + u];
+        // the row's dq (block-uniform, 128 floats) goes through LDS: as scalar loads it needs 128 SGPRs at once - 79 of them spilled
+        // to VGPR lanes (writelane / readlane pairs) with a wait per batch
+        if (threadIdx.x < QA / 4) s_dq[threadIdx.x] = reinterpret_cast<const float4*>(d.dq)[b * (QA / 4) + threadIdx.x];
     }
     float dhs = d.d_h_state[i];
     if (d.dhs2) {
@@ -617,13 +618,15 @@ __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) 
         for (int pp = 0; pp < P_OUT2; ++pp) dm += d.d_out2[pp * d.dout2_pstride + i];
     }
     if (FUSE_Q) {
+        __syncthreads();
         float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
         for (int a = 0; a < QA / 4; ++a) {
+            dqv[0] = s_dq[a];
             if (FUSE_Q == 2) {
                 auto r = [](float x) { return (float)(__bf16)x; };
-                q0 += r(dqv[a].x) * r(wqv[a].x); q1 += r(dqv[a].y) * r(wqv[a].y); q2 += r(dqv[a].z) * r(wqv[a].z); q3 += r(dqv[a].w) * r(wqv[a].w);
-            } else { q0 += dqv[a].x * wqv[a].x; q1 += dqv[a].y * wqv[a].y; q2 += dqv[a].z * wqv[a].z; q3 += dqv[a].w * wqv[a].w; }
+                q0 += r(dqv[0].x) * r(wqv[a].x); q1 += r(dqv[0].y) * r(wqv[a].y); q2 += r(dqv[0].z) * r(wqv[a].z); q3 += r(dqv[0].w) * r(wqv[a].w);
+            } else { q0 += dqv[0].x * wqv[a].x; q1 += dqv[0].y * wqv[a].y; q2 += dqv[0].z * wqv[a].z; q3 += dqv[0].w * wqv[a].w; }
         }
         dm += (q0 + q1) + (q2 + q3);
     }

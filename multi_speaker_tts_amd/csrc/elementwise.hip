@@ -561,6 +561,8 @@ struct PointBwdFast {
     int row2d;                                                     // grid (H / 128, B): the row is blockIdx.y - no division in front of the loads
 };
 constexpr int QA = 128;        // attention units of the fused query-layer gradient (hp.Attention.Memory_Size)
+__device__ const float pb_zero[1] = {0.f};        // stand-ins for optional operands of the pointwise kernels (see the load block below)
+__device__ const uint8_t pb_one[1] = {1};
 
 // FUSE_Q: the output gradient also gets dq[b,:] . Wq[u,:] (the attention query layer's data gradient, q = m1 . Wq), computed here from
 // the transposed kernel instead of by a product launch of its own; all QA loads of a thread are issued before the first FMA
@@ -594,12 +596,33 @@ __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) 
         // to VGPR lanes (writelane / readlane pairs) with a wait per batch
         if (threadIdx.x < QA / 4) s_dq[threadIdx.x] = reinterpret_cast<const float4*>(d.dq)[b * (QA / 4) + threadIdx.x];
     }
-    float dhs = d.d_h_state[i];
-    if (d.dhs2) {
+    // ---- every operand of the element, requested back to back.  Optional operands (absent slabs, absent masks) are read from a
+    // constant block through a selected pointer rather than skipped: a null check is a branch, and the kernel used to be seven basic
+    // blocks each ending in its own wait - seven dependent memory round trips for 30 floats.
+    const float* p_dhs2 = d.dhs2 ? d.dhs2 + b * d.dhs2_ld + u : pb_zero;
+    const long s_dhs2 = d.dhs2 ? d.dhs2_pstride : 0;
+    const float* p_do = d.d_out ? d.d_out + b * d.dout_ld + pos * d.dout_st + u : pb_zero;
+    const long s_do = d.d_out ? d.dout_pstride : 0;
+    const float* p_do2 = d.d_out2 ? d.d_out2 + i : pb_zero;
+    const long s_do2 = d.d_out2 ? d.dout2_pstride : 0;
+    const uint8_t* p_zh = d.zh ? d.zh + i : pb_one;
+    const uint8_t* p_zc = d.zc ? d.zc + i : pb_one;
+    const float r_dhs = d.d_h_state[i], dcs = d.d_c_state[i];
+    float r_dhs2[P_DHS], r_do[P_OUT], r_do2[P_OUT2];
 #pragma unroll
-        for (int pp = 0; pp < P_DHS; ++pp) dhs += d.dhs2[pp * d.dhs2_pstride + b * d.dhs2_ld + u];
-    }
-    const float dcs = d.d_c_state[i];
+    for (int pp = 0; pp < P_DHS; ++pp) r_dhs2[pp] = p_dhs2[pp * s_dhs2];
+#pragma unroll
+    for (int pp = 0; pp < P_OUT; ++pp) r_do[pp] = p_do[pp * s_do];
+#pragma unroll
+    for (int pp = 0; pp < P_OUT2; ++pp) r_do2[pp] = p_do2[pp * s_do2];
+    const uint8_t r_zh = *p_zh, r_zc = *p_zc;
+    const float* a = d.acts + b * 4 * H + u;
+    const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
+    const float c = d.c_raw[i], cp = d.c_prev[i];
+    __builtin_amdgcn_sched_barrier(0);
+    float dhs = r_dhs;
+#pragma unroll
+    for (int pp = 0; pp < P_DHS; ++pp) dhs += r_dhs2[pp];
     float* dg = d.dgates + b * 4 * H + u;
     float* dgp = (SEQ && d.dgates_pos) ? d.dgates_pos + b * d.dgp_ld + pos * d.dgp_st + u : nullptr;
     if (SEQ && !live) {
@@ -609,33 +632,26 @@ __device__ __forceinline__ void lstm_point_bwd_fast_body(const PointBwdFast& d) 
         return;
     }
     float dm = 0.f;
-    if (d.d_out) {
 #pragma unroll
-        for (int pp = 0; pp < P_OUT; ++pp) dm += d.d_out[pp * d.dout_pstride + b * d.dout_ld + pos * d.dout_st + u];
-    }
-    if (d.d_out2) {
+    for (int pp = 0; pp < P_OUT; ++pp) dm += r_do[pp];
 #pragma unroll
-        for (int pp = 0; pp < P_OUT2; ++pp) dm += d.d_out2[pp * d.dout2_pstride + i];
-    }
+    for (int pp = 0; pp < P_OUT2; ++pp) dm += r_do2[pp];
     if (FUSE_Q) {
         __syncthreads();
         float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
-        for (int a = 0; a < QA / 4; ++a) {
-            dqv[0] = s_dq[a];
+        for (int a_ = 0; a_ < QA / 4; ++a_) {
+            dqv[0] = s_dq[a_];
             if (FUSE_Q == 2) {
                 auto r = [](float x) { return (float)(__bf16)x; };
-                q0 += r(dqv[0].x) * r(wqv[a].x); q1 += r(dqv[0].y) * r(wqv[a].y); q2 += r(dqv[0].z) * r(wqv[a].z); q3 += r(dqv[0].w) * r(wqv[a].w);
-            } else { q0 += dqv[0].x * wqv[a].x; q1 += dqv[0].y * wqv[a].y; q2 += dqv[0].z * wqv[a].z; q3 += dqv[0].w * wqv[a].w; }
+                q0 += r(dqv[0].x) * r(wqv[a_].x); q1 += r(dqv[0].y) * r(wqv[a_].y); q2 += r(dqv[0].z) * r(wqv[a_].z); q3 += r(dqv[0].w) * r(wqv[a_].w);
+            } else { q0 += dqv[0].x * wqv[a_].x; q1 += dqv[0].y * wqv[a_].y; q2 += dqv[0].z * wqv[a_].z; q3 += dqv[0].w * wqv[a_].w; }
         }
         dm += (q0 + q1) + (q2 + q3);
     }
-    const float mh = d.zh ? (d.zh[i] ? d.keep : 0.f) : d.keep;
-    const float mc = d.zc ? (d.zc[i] ? d.keep : 0.f) : d.keep;
+    const float mh = r_zh ? d.keep : 0.f;
+    const float mc = r_zc ? d.keep : 0.f;
     dm += mh * dhs;
-    const float* a = d.acts + b * 4 * H + u;
-    const float si = a[0], tj = a[H], sf = a[2 * H], so = a[3 * H];
-    const float c = d.c_raw[i], cp = d.c_prev[i];
     const float tc = tanhf_(c);
     const float dc = dm * so * (1.f - tc * tc) + mc * dcs;
     const float d_i = dc * tj * si * (1.f - si), d_j = dc * si * (1.f - tj * tj), d_f = dc * cp * sf * (1.f - sf), d_o = dm * tc * so * (1.f - so);

@@ -267,19 +267,39 @@ def main():
             # 3 % on all six loop kernels, DESIGN.md "Measurement"), so half of it is subtracted.
             raw_us[name], empty_us[name] = 1e3 * tot.value / n, 1e3 * emp.value / n
             avg_us[name] = raw_us[name] - 0.5 * empty_us[name]
-        lb.mstts_probe_begin(0, 0)
+        # the attention step alone (query projection as its own launch again): the same kernel without its in-launch query part
+        plain_us = None
         M, A, H = dims.mem, dims.att, dims.dec_lstm
+        fused_query = bool(eng.fuse_query and lb.mstts_lsa_step_q_supported(T_ENC, M, H))
+        if fused_query:
+            eng.fuse_query = False
+            lb.mstts_probe_begin(1, S)
+            eng.forward(batch, w)
+            torch.cuda.synchronize()
+            tot, emp = ctypes.c_double(0.0), ctypes.c_double(0.0)
+            n = lb.mstts_probe_result(ctypes.byref(tot), ctypes.byref(emp))
+            if n:
+                plain_us = 1e3 * tot.value / n - 0.5 * 1e3 * emp.value / n
+            eng.fuse_query = True
+        lb.mstts_probe_begin(0, 0)
         # attention step, algorithmic bytes per row-step: keys + values + cum r/w + alignment write
-        att_bytes = B_PER_GPU * (T_ENC * A * 4 + T_ENC * M * 4 + 3 * T_ENC * 4)
+        att_only_bytes = B_PER_GPU * (T_ENC * A * 4 + T_ENC * M * 4 + 3 * T_ENC * 4)
+        # with the query projection inside the launch the kernel also reads the query kernel once and the cell-1 output row
+        att_bytes = att_only_bytes + ((H * A * 4 + B_PER_GPU * H * 4 + B_PER_GPU * A * 4) if fused_query else 0)
         att_us = avg_us["lsa_step_fwd"] + avg_us.get("lsa_context_fwd", 0.0)
         fused = "lsa_context_fwd" not in avg_us
         ach = att_bytes / (att_us * 1e-6) / 1e9
-        out["roofline"] = {"kernel": ("lsa_step_kernel (energies + in-launch exchange + softmax + context; one decoder step, B=32)" if fused
+        out["roofline"] = {"kernel": ("lsa_step_kernel (in-launch query projection + exchange, energies + exchange, softmax, context; one decoder step, B=32)" if fused and fused_query
+                                      else "lsa_step_kernel (energies + in-launch exchange + softmax + context; one decoder step, B=32)" if fused
                                       else "lsa_energy_kernel + lsa_context_kernel (one decoder step, B=32)"),
                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": pmc_traffic_bytes("lsa_step_kernel") if (L == L_MEL and world == 1) else None,
                            "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT), "algorithmic_bytes_per_launch": att_bytes,
                            "avg_launch_us": att_us, "event_bracket_us": raw_us["lsa_step_fwd"], "empty_bracket_us": empty_us["lsa_step_fwd"]}
+        if plain_us:
+            a2 = att_only_bytes / (plain_us * 1e-6) / 1e9
+            out["roofline"]["attention_only"] = {"note": "the same kernel with the query projection as a launch of its own again, measured in an extra untimed step",
+                                                 "algorithmic_bytes_per_launch": att_only_bytes, "avg_launch_us": plain_us, "achieved": a2, "frac": a2 / HBM_PEAK_GBS}
         wb = 2 if args.recurrent_dtype == "bf16" else 4          # the recurrent kernels stream bf16 copies in that mode
         w0 = (M + H) * 4 * H * wb
         w1 = 2 * H * 4 * H * wb

@@ -251,6 +251,17 @@ int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts
                        const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
                        const mstts_cell_packed_dst* ctx_p,   /* optional third copy of the context, in a fused cell's packed block (or NULL) */
                        void* granules, uint32_t epoch, mstts_stream_t s);
+/* The same step with the query projection q = m1 . Wq inside the launch (one launch less per decoder step): m1 rows [B, H] with row
+ * stride m1_ld, wq [H, A] row-major; q_bf16 != 0 rounds both operands to bf16 first (BASELINE config 3).  Available when
+ * mstts_lsa_step_q_supported(T, M, H) (8 slices: T <= 128, M <= 768; H == 1024) and c->loc_kt is set.  granules =
+ * mstts_lsa_step_q_ws_bytes(B, T) bytes (energy granules, time-out counter, B * A query granules), zeroed before the first step.
+ * q_sum (may be NULL) receives the query.  skip_slice >= 0 = self-test form (the workgroups of that slice leave at once, the others
+ * time out on its query units and energies and recompute them), -1 = normal operation. */
+int32_t mstts_lsa_step_q_supported(int64_t T, int64_t M, int64_t H);
+int64_t mstts_lsa_step_q_ws_bytes(int64_t B, int64_t T);
+int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, int32_t q_bf16, float* q_sum,
+                         const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                         const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
 /* backward of one step, two launches:
  *  dalign : G[t] = G_next[t] + sum_j h_next[t+pad-j][j] ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
  *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); h[t,j] = sum_k g[t,k] loc_k[j,k]
@@ -494,6 +505,10 @@ typedef struct {
     const float* w0f_bp; const float* w1_bp; const float* wq_bp;
     const float* wq_t;  /* optional [A/4,H,4] re-layout of wq (mstts_transpose01(wq, wq_t, H, A/4, 4)): the query layer's data gradient is folded into cell 1's pointwise backward */
     float* act_p;      /* ... and their packed activation blocks: 2 * (mstts_cell_act_floats(B, M+H) + mstts_cell_act_floats(B, 2H)) floats */
+    /* floats available behind energy_ws.  >= mstts_lsa_step_q_ws_bytes(B, T) / 4 (and mstts_lsa_step_q_supported(T, M, H), lsa.loc_kt
+     * set): the query projection runs inside the attention launch (mstts_lsa_step_fwd_q) - 3 launches per forward step instead of 4.
+     * 0 = the 2*B*T+2 floats of the plain form. */
+    int64_t energy_ws_floats;
 } mstts_decoder_train_desc;
 int32_t mstts_decoder_bf16_splits(int64_t H, int64_t M, int64_t A, int32_t* out6);
 /* floats needed for gates_ws (*gates) and q_ws (*q) */

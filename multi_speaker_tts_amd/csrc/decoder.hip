@@ -358,7 +358,10 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
     RC(zero(d->c0, BH, s));
     RC(zero(d->c1, BH, s));
     RC(zero(d->cum_hist, B * T, s));
-    if (fused_lsa) RC(zero(d->energy_ws, 2 * B * T + 2, s));           // granules + time-out counter of mstts_lsa_step_fwd
+    // query projection inside the attention launch: geometry supported, by-unit filter given, granule buffer large enough
+    const bool fused_q = fused_lsa && chains == 1 && mstts_lsa_step_q_supported(T, M, H) && d->lsa.loc_kt && A == 128 &&
+                         d->energy_ws_floats >= mstts_lsa_step_q_ws_bytes(B, T) / 4 && WP % 4 == 0;
+    if (fused_lsa) RC(zero(d->energy_ws, fused_q ? mstts_lsa_step_q_ws_bytes(B, T) / 4 : 2 * B * T + 2, s));   // granules + time-out counter
     const long Bc = B / chains;
     mstts_stream_t cs[MAX_CHAINS] = {s};
     for (long st = 0; st < S; ++st) {
@@ -423,9 +426,15 @@ extern "C" int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_
             RC(mstts_lstm_point_fwd(&p, q_s));
             }
             // ---- query (partials summed inside the energy kernel, which also saves q) + attention
+            const float* cum = d->cum_hist + (st * B + b0) * T;
+            if (fused_q) {          // one launch: the eight slices of a row compute and exchange the query themselves
+                PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_step_fwd_q(&lc, pj, WP, d->wq, H, bf ? 1 : 0, d->q_hist + (st * B + b0) * A, cum,
+                                         d->align_hist + (st * B + b0) * T, d->cum_hist + ((st + 1) * B + b0) * T, in0n, W0, pj + H, WP,
+                                         fused_cells ? &ctx_p : nullptr, (unsigned long long*)d->energy_ws + b0 * T, (uint32_t)(st + 1), -1, q_s));
+                continue;
+            }
             if (bf) { parts = bfs[2]; RC(mstts_skinny_fwd_bf16(pj, WP, d->bf_wq_f, qws, 0, Bc, A, H, bfs[2], q_s)); }
             else RC(xw_fwd(pj, WP, d->wq, A, qws, Bc, A, H, spq, &parts, q_s));
-            const float* cum = d->cum_hist + (st * B + b0) * T;
             if (fused_lsa) {
                 PROBED(MSTTS_PROBE_LSA_ENERGY, q_s, mstts_lsa_step_fwd(&lc, qws, parts, Bc * A, d->q_hist + (st * B + b0) * A, cum,
                                          d->align_hist + (st * B + b0) * T, d->cum_hist + ((st + 1) * B + b0) * T, in0n, W0, pj + H, WP,

@@ -212,13 +212,14 @@ constexpr int FS_DSL = 96;        // memory columns per workgroup (context slice
 constexpr int FS_VPRE = 7;        // value rows per thread preloaded ahead of the exchange
 constexpr unsigned FS_MAX_SPINS = 200000;
 
+// (qb: row index into q - 0 when q is the workgroup's own LDS copy of the row's query)
 __device__ __forceinline__ float lsa_energy_serial(const mstts_lsa_const& c, const float* q, int q_parts, long q_pstride,
-                                                const float* cum, int b, int t) {
+                                                const float* cum, int qb, int t, int b) {
     const int T = (int)c.T, KS = (int)c.KS, pad = (KS - 1) / 2;
     float e = 0.f;
     for (int k = 0; k < A_; ++k) {
         float pre = c.keys[((long)b * T + t) * A_ + k] + c.score_b[k] + c.loc_b[k];
-        for (int pp = 0; pp < q_parts; ++pp) pre += q[pp * q_pstride + (long)b * A_ + k];
+        for (int pp = 0; pp < q_parts; ++pp) pre += q[pp * q_pstride + (long)qb * A_ + k];
         for (int j = 0; j < KS; ++j) {
             const int tau = t + j - pad;
             if (tau >= 0 && tau < T) pre += cum[(long)b * T + tau] * c.loc_k[j * A_ + k];
@@ -228,17 +229,35 @@ __device__ __forceinline__ float lsa_energy_serial(const mstts_lsa_const& c, con
     return e;
 }
 
+// q[b, a] = m1[b, :] . Wq[:, a] recomputed by one thread (time-out path of the in-launch query projection)
+__device__ __forceinline__ float lsa_q_serial(const float* m1, long m1_ld, const float* wq, int H, int b, int a, int q_bf16) {
+    float q = 0.f;
+    for (int j = 0; j < H; ++j) {
+        float x = m1[(long)b * m1_ld + j], w = wq[(long)j * A_ + a];
+        if (q_bf16) { x = (float)(__bf16)x; w = (float)(__bf16)w; }
+        q += x * w;
+    }
+    return q;
+}
+constexpr int QJ = 8;             // hidden units per thread of the in-launch query projection: 128 chunks x 8 = H = 1024
+
+// QIN: the query projection q = m1 . Wq runs inside this launch (it was a launch of its own, 4.9 us of almost pure fixed cost): the
+// workgroup of slice cs computes the 16 units 16 cs .. 16 cs + 15 of its row's query (1/8 of the product: 64 KB of the kernel), the
+// eight slices exchange them through a second granule array exactly like the energies, and the energy phase reads q from LDS.
 // SELFTEST instantiation (mstts_lsa_step_fwd_selftest only): the workgroup of slice `skip` leaves at once, so the rest of its row must take
 // the time-out path - the only way to exercise it, since on a healthy chip no workgroup ever times out
-template <bool SELFTEST, bool LKT = false>
+struct LsaQIn { const float* m1; long m1_ld; const float* wq; int H, bf16; };      // QIN operands: m1 rows [B, >= H], Wq [H, A] row-major
+template <bool SELFTEST, bool LKT = false, bool QIN = false>
 __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
                                                               float* __restrict__ q_sum, const float* cum,
                                                               float* __restrict__ align, float* __restrict__ cum_next,
                                                               float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld, PackedDst ctx_p,
-                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int ncs, int skip) {
+                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int ncs, int skip, LsaQIn qi) {
     int cs, b;
     row_slice_of_block(blockIdx.x, ncs, (int)c.B, &b, &cs);
     if (SELFTEST && cs == skip) return;
+    __shared__ __attribute__((aligned(16))) float s_qp[QIN ? 32 * 16 : 4];     // QIN: per-row-of-16-lanes partial sums of the 16 own units
+    __shared__ float s_q[QIN ? A_ : 1];                                         // QIN: the row's query
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
     __shared__ float s_red[FS_TSL][2];
     __shared__ float s_e[T_MAX];
@@ -275,7 +294,17 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         const int tl = 4 * tg + i;
         kv[i] = (tl < tsl && t0 + tl < T) ? c.keys[((long)b * T + t0 + tl) * A_ + k] : 0.f;
     }
-    const float qv = sum_parts<MSTTS_MAX_PARTS>(q, q_parts, q_pstride, (long)b * A_ + k);
+    float qv = 0.f;
+    float4 qw[QIN ? QJ : 1], qm[QIN ? QJ / 4 : 1];
+    if constexpr (QIN) {                 // thread (a4 = tid & 3, chunk = tid >> 2): units 16 cs + 4 a4 .. + 3, hidden units 8 chunk .. + 7
+        const int a4 = tid & 3, ch = tid >> 2;
+#pragma unroll
+        for (int jj = 0; jj < QJ; ++jj) qw[jj] = *reinterpret_cast<const float4*>(qi.wq + (long)(ch * QJ + jj) * A_ + 16 * cs + 4 * a4);
+#pragma unroll
+        for (int jj = 0; jj < QJ / 4; ++jj) qm[jj] = *reinterpret_cast<const float4*>(qi.m1 + (long)b * qi.m1_ld + ch * QJ + 4 * jj);
+    } else {
+        qv = sum_parts<MSTTS_MAX_PARTS>(q, q_parts, q_pstride, (long)b * A_ + k);
+    }
     const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
     const float* v = c.values + (long)b * T * M + col;
     float4 vv[FS_VPRE];
@@ -288,8 +317,55 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     }
     // ---- own energy slice
     if (tid < FS_TSL + KS_MAX - 1 + 2) s_cum[tid] = cwin;          // entries past the window are zero
+    if constexpr (QIN) {
+        // own 16 units of the query: 8 hidden units per thread, then the 16 chunks of each 16-lane row through DPP row shifts, the 32
+        // rows of the workgroup through LDS
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < QJ; ++jj) {
+            float x = reinterpret_cast<const float*>(qm)[jj];
+            float4 w4 = qw[jj];
+            if (qi.bf16) {
+                x = (float)(__bf16)x;
+                w4 = make_float4((float)(__bf16)w4.x, (float)(__bf16)w4.y, (float)(__bf16)w4.z, (float)(__bf16)w4.w);
+            }
+            acc.x += x * w4.x; acc.y += x * w4.y; acc.z += x * w4.z; acc.w += x * w4.w;
+        }
+        acc.x += dpp_mov<0x114, 0xf>(0.f, acc.x); acc.y += dpp_mov<0x114, 0xf>(0.f, acc.y);       // row_shr:4
+        acc.z += dpp_mov<0x114, 0xf>(0.f, acc.z); acc.w += dpp_mov<0x114, 0xf>(0.f, acc.w);
+        acc.x += dpp_mov<0x118, 0xf>(0.f, acc.x); acc.y += dpp_mov<0x118, 0xf>(0.f, acc.y);       // row_shr:8
+        acc.z += dpp_mov<0x118, 0xf>(0.f, acc.z); acc.w += dpp_mov<0x118, 0xf>(0.f, acc.w);
+        if ((tid & 15) >= 12) *reinterpret_cast<float4*>(&s_qp[(tid >> 4) * 16 + 4 * (tid & 3)]) = acc;   // lanes 12..15 of a row hold its sums
+        __syncthreads();
+        gu64* gq = (gu64*)(gran + (long)c.B * T + 1 + (long)b * A_);
+        if (tid < 16) {
+            float qa = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) qa += s_qp[r * 16 + tid];
+            s_q[16 * cs + tid] = qa;
+            __hip_atomic_store(gq + 16 * cs + tid, ((unsigned long long)epoch << 32) | __float_as_uint(qa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < A_ && (tid >> 4) != cs) {                      // the other slices' units (the data is the flag)
+            unsigned long long x = __hip_atomic_load(gq + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
+                __builtin_amdgcn_s_sleep(1);
+                x = __hip_atomic_load(gq + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++spins;
+            }
+            float qa;
+            if ((unsigned)(x >> 32) == epoch) qa = __uint_as_float((unsigned)x);
+            else {
+                qa = lsa_q_serial(qi.m1, qi.m1_ld, qi.wq, qi.H, b, tid, qi.bf16);
+                atomicAdd(gran + (long)c.B * T, 1ull);
+            }
+            s_q[tid] = qa;
+        }
+        __syncthreads();
+        qv = s_q[k];
+    }
     if (q_sum && cs == 0 && tg == 0) q_sum[(long)b * A_ + k] = qv;
-    __syncthreads();
+    if constexpr (!QIN) __syncthreads();
     {
         float cw[4 + KS_MAX - 1];
 #pragma unroll
@@ -324,7 +400,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         float e;
         if ((unsigned)(x >> 32) == epoch) e = __uint_as_float((unsigned)x);
         else {
-            e = lsa_energy_serial(c, q, q_parts, q_pstride, cum, b, t);
+            e = QIN ? lsa_energy_serial(c, s_q, 1, 0, cum, 0, t, b) : lsa_energy_serial(c, q, q_parts, q_pstride, cum, b, t, b);
             atomicAdd(gran + (long)c.B * T, 1ull);
         }
         s_e[t] = e;
@@ -964,22 +1040,36 @@ static void lsa_step_geometry(long T, long M, int* cs, int* tsl, int* dsl) {
 extern "C" int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T) { return (B * T + 1) * 8; }
 static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
                                const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
-                               const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int skip, mstts_stream_t s) {
+                               const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int skip, mstts_stream_t s,
+                               const LsaQIn* qin = nullptr) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_fwd: granule buffer (8-byte aligned) and a non-zero epoch required");
     PackedDst cp;
     rc = packed_dst_from(ctx_p, c->M, &cp, "ctx_p"); if (rc) return rc;
     int cs, tsl, dsl;
     lsa_step_geometry(c->T, c->M, &cs, &tsl, &dsl);
-    if (skip >= 0)
+    LsaQIn qi;
+    memset(&qi, 0, sizeof(qi));
+    const bool lkt = c->loc_kt && aligned16(c->loc_kt);
+    if (qin) {
+        qi = *qin;
+        MSTTS_REQUIRE(cs == 8 && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_q: needs 8 slices (T <= 128, M <= 768), H == %d and the by-unit filter", 128 * QJ);
+        MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_q: m1 / wq must be 16-byte aligned");
+        if (skip >= 0)
+            hipLaunchKernelGGL((lsa_step_kernel<true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi);
+        else
+            hipLaunchKernelGGL((lsa_step_kernel<false, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi);
+    } else if (skip >= 0)
         hipLaunchKernelGGL(lsa_step_kernel<true>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip);
-    else if (c->loc_kt && aligned16(c->loc_kt))
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi);
+    else if (lkt)
         hipLaunchKernelGGL((lsa_step_kernel<false, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi);
     else
         hipLaunchKernelGGL(lsa_step_kernel<false>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi);
     MSTTS_CHECK_LAUNCH("lsa_step_fwd");
     return MSTTS_OK;
 }
@@ -987,6 +1077,26 @@ extern "C" int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int3
                                   const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
                                   const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, mstts_stream_t s) {
     return lsa_step_fwd_launch(c, q, q_parts, q_pstride, q_sum, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch, -1, s);
+}
+/* The same step with the query projection inside the launch: q = m1 . Wq (m1 rows [B, H] with row stride m1_ld, Wq [H, A] row-major;
+ * q_bf16 != 0 rounds both operands to bf16 first - BASELINE config 3), one launch less per decoder step.  Needs 8 slices (T <= 128,
+ * M <= 768), H == 1024 and c->loc_kt; granules = mstts_lsa_step_q_ws_bytes(B, T) bytes (the energy granules, the time-out counter,
+ * then B * A query granules), zeroed before the first step.  skip_slice >= 0: the self-test form (see below), -1 otherwise. */
+extern "C" int32_t mstts_lsa_step_q_supported(int64_t T, int64_t M, int64_t H) {
+    int cs, tsl, dsl;
+    if (T < 1 || M < 4) return 0;
+    lsa_step_geometry(T, M, &cs, &tsl, &dsl);
+    return cs == 8 && H == 128 * QJ;
+}
+extern "C" int64_t mstts_lsa_step_q_ws_bytes(int64_t B, int64_t T) { return (B * T + 1 + B * A_) * 8; }
+extern "C" int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, int32_t q_bf16,
+                                    float* q_sum, const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2,
+                                    int64_t ctx2_ld, const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice,
+                                    mstts_stream_t s) {
+    LsaQIn qi;
+    qi.m1 = m1; qi.m1_ld = (long)m1_ld; qi.wq = wq; qi.H = (int)H; qi.bf16 = q_bf16 ? 1 : 0;
+    return lsa_step_fwd_launch(c, nullptr, 0, 0, q_sum, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch,
+                               skip_slice >= 0 ? skip_slice : -1, s, &qi);
 }
 /* test entry: same launch with the workgroups of slice `skip_slice` (0 .. slices-1) removed, which forces every other workgroup of each row
  * through its time-out path (takes milliseconds); the skipped slice's own outputs are not written */

@@ -57,7 +57,7 @@ class _WS:
 
 class TrainEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, rank=0, world=1, values=None,
-                 update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None, gemm_dtype=None):
+                 update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None, gemm_dtype=None, fuse_query=True):
         """recurrent_dtype: 'f32' (default; BASELINE config 2) or 'bf16' (config 3: the decoder's recurrent products run on
         bf16 copies of the fp32 master weights with fp32 accumulation)."""
         lib.load()
@@ -65,6 +65,7 @@ class TrainEngine:
         self.device = torch.device(device)
         self.seed, self.rank, self.world = seed, rank, world
         self.update_vocoder_bn = update_vocoder_bn
+        self.fuse_query = bool(fuse_query)     # query projection inside the attention launch when the geometry allows (mstts_lsa_step_fwd_q)
         from . import Hyper_Parameters as hp           # None = the drop-in hyper parameters (MSTTS_SV.py:138-176)
         self.use_l1 = bool(hp.Train.Use_L1_Loss) if use_l1 is None else use_l1
         self.wr_rate = float(hp.Train.Weight_Regularization_Rate) if wr_rate is None else wr_rate
@@ -230,7 +231,8 @@ class TrainEngine:
         lb = lib.load()
         ng, nq = C.c_int64(0), C.c_int64(0)
         lb.mstts_decoder_train_ws_floats(B, H, M, A, C.byref(ng), C.byref(nq))
-        w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(2 * B * Te + 4), f(int(nq.value))
+        w.energy_ws_floats = int(lib.load().mstts_lsa_step_q_ws_bytes(B, Te)) // 4 + 2      # room for the in-launch query exchange
+        w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(w.energy_ws_floats), f(int(nq.value))
         w.act_p = f(2 * int(lb.mstts_cell_act_floats(B, M + H) + lb.mstts_cell_act_floats(B, 2 * H))) if self.fused_cells else None
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
@@ -398,6 +400,7 @@ class TrainEngine:
         if self.w0p16 is not None and self.bf is not None and w.act_p is not None:
             dec.w0p16, dec.w1p16, dec.act_p = ptr(self.w0p16), ptr(self.w1p16), ptr(w.act_p)
         dec.chains = 1
+        dec.energy_ws_floats = w.energy_ws_floats if self.fuse_query else 0
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))
         call("mstts_decoder_train_fwd", C.byref(dec))

@@ -83,7 +83,8 @@ class DecoderTrain(C.Structure):
                 ("acts0", vp), ("acts1", vp), ("craw0", vp), ("craw1", vp),
                 ("q_hist", vp), ("align_hist", vp), ("cum_hist", vp), ("gates_ws", vp), ("energy_ws", vp), ("q_ws", vp), ("chains", i32),
                 ("bf_w0f_f", vp), ("bf_w1_f", vp), ("bf_wq_f", vp), ("bf_w0f_b", vp), ("bf_w1_b", vp), ("bf_wq_b", vp),
-                ("w0p", vp), ("w1p", vp), ("w0p16", vp), ("w1p16", vp), ("w0f_bp", vp), ("w1_bp", vp), ("wq_bp", vp), ("wq_t", vp), ("act_p", vp)]
+                ("w0p", vp), ("w1p", vp), ("w0p16", vp), ("w1p16", vp), ("w0f_bp", vp), ("w1_bp", vp), ("wq_bp", vp), ("wq_t", vp), ("act_p", vp),
+                ("energy_ws_floats", i64)]
 
 
 class DecoderTrainBwd(C.Structure):
@@ -140,6 +141,9 @@ SIGNATURES = {
     "mstts_lsa_step_ws_bytes": (i64, [i64, i64]),
     "mstts_lsa_step_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "mstts_lsa_step_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, vp]),
+    "mstts_lsa_step_q_supported": (i32, [i64, i64, i64]),
+    "mstts_lsa_step_q_ws_bytes": (i64, [i64, i64]),
+    "mstts_lsa_step_fwd_q": (i32, [P(LsaConst), vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
     "mstts_lsa_step_fwd_selftest": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, C.c_uint32, i32, vp]),
     "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "mstts_lsa_denergy_bwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, vp, vp, vp]),

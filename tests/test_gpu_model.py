@@ -171,6 +171,65 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     assert rel_err(t2n(al)[:, :, None] * d_ctx[:, None, :], t2n(vt.grad)) < 5e-5
 
 
+@pytest.mark.parametrize("B,T,bf16", [(5, 128, 0), (32, 113, 0), (3, 40, 1)])
+def test_lsa_step_fwd_q(dev, B, T, bf16):
+    """mstts_lsa_step_fwd_q: the query projection q = m1 . Wq computed and exchanged inside the attention launch.  Against the plain
+    single-launch step fed with the same query (fp64 product, or bf16-rounded operands in the config-3 form), over several steps
+    (distinct epochs on one granule buffer), and once in the self-test form where one slice is missing and the others must recompute
+    its query units and energies."""
+    A, CH, KS, M, H = 128, 32, 31, 768, 1024
+    L = lib.load()
+    assert L.mstts_lsa_step_q_supported(T, M, H) == 1 and L.mstts_lsa_step_q_supported(129, M, H) == 0 and L.mstts_lsa_step_q_supported(T, M, 512) == 0
+    g = np.random.default_rng(17)
+    f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev).contiguous()
+    lengths = np.array([T] + list(g.integers(max(1, T // 2), T + 1, B - 1)), np.int32)
+    mask = np.arange(T)[None, :] < lengths[:, None]
+    dk, dv = f32(g.normal(0, 1, (B, T, A)) * mask[:, :, None]), f32(g.normal(0, 1, (B, T, M)) * mask[:, :, None])
+    conv_k, conv_b, dense_k = f32(g.normal(0, 0.3, (KS, 1, CH))), f32(g.normal(0, 0.1, (CH,))), f32(g.normal(0, 0.3, (CH, A)))
+    score_w, score_b = f32(g.normal(0, 0.5, (A,))), f32(g.normal(0, 0.1, (A,)))
+    dl = torch.tensor(lengths, device=dev)
+    c = lib.LsaConst()
+    c.B, c.T, c.A, c.M, c.KS, c.CH = B, T, A, M, KS, CH
+    c.keys, c.values, c.lengths = lib.ptr(dk), lib.ptr(dv), lib.ptr(dl)
+    c.conv_k, c.conv_b, c.dense_k, c.score_w, c.score_b = lib.ptr(conv_k), lib.ptr(conv_b), lib.ptr(dense_k), lib.ptr(score_w), lib.ptr(score_b)
+    loc_k, loc_b, loc_kt = torch.zeros(KS, A, device=dev), torch.zeros(A, device=dev), torch.zeros(A, 36, device=dev)
+    lib.call("mstts_lsa_fold_location", c.conv_k, c.conv_b, c.dense_k, lib.ptr(loc_k), lib.ptr(loc_b), KS, CH, A)
+    lib.call("mstts_lsa_filter_by_unit", lib.ptr(loc_k), lib.ptr(loc_kt), KS, A)
+    c.loc_k, c.loc_b, c.loc_kt = lib.ptr(loc_k), lib.ptr(loc_b), lib.ptr(loc_kt)
+    wq = f32(g.normal(0, 0.05, (H, A)))
+    WP = H + M                                                   # m1 sits in rows [m1 | ctx] like the decoder's projection input
+    gran_q = torch.zeros(int(L.mstts_lsa_step_q_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    gran = torch.zeros(int(L.mstts_lsa_step_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    for step in range(1, 4):
+        pj = f32(g.normal(0, 1, (B, WP)))
+        cum = f32(np.abs(g.normal(0, 0.5, (B, T))) * mask)
+        if bf16:
+            qref = (pj[:, :H].to(torch.bfloat16).double() @ wq.to(torch.bfloat16).double()).float()
+        else:
+            qref = (pj[:, :H].double() @ wq.double()).float()
+        al, cn, cx, qs = (torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev), torch.zeros(B, A, device=dev))
+        lib.call("mstts_lsa_step_fwd", C.byref(c), lib.ptr(qref.contiguous()), 1, 0, None, lib.ptr(cum), lib.ptr(al), lib.ptr(cn), lib.ptr(cx), M, None, 0,
+                 None, lib.ptr(gran), step)
+        al2, cn2, cx2 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
+        lib.call("mstts_lsa_step_fwd_q", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, bf16, lib.ptr(qs), lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2),
+                 lib.ptr(cx2), M, None, 0, None, lib.ptr(gran_q), step, -1)
+        torch.cuda.synchronize()
+        assert rel_err(t2n(qs), t2n(qref)) < 3e-6
+        assert rel_err(t2n(al2), t2n(al)) < 1e-5 and rel_err(t2n(cn2), t2n(cn)) < 1e-5 and rel_err(t2n(cx2), t2n(cx)) < 1e-5
+        assert int(gran_q[B * T]) == 0                                                  # no time-outs
+        assert bool(((gran_q[B * T + 1:] >> 32) == step).all())                         # every query granule carries this epoch
+    # self-test: slice 3 never runs; every other workgroup times out on its 16 query units and its energies and recomputes them
+    al3, cn3, cx3 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
+    lib.call("mstts_lsa_step_fwd_q", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, bf16, None, lib.ptr(cum), lib.ptr(al3), lib.ptr(cn3),
+             lib.ptr(cx3), M, None, 0, None, lib.ptr(gran_q), 9, 3)
+    torch.cuda.synchronize()
+    assert int(gran_q[B * T]) > 0
+    tsl, dsl = -(-T // 8), 96
+    own = np.ones(T, bool); own[3 * tsl:4 * tsl] = False                                # the missing slice's own outputs are not written
+    ownc = np.ones(M, bool); ownc[3 * dsl:4 * dsl] = False
+    assert rel_err(t2n(al3)[:, own], t2n(al)[:, own]) < 1e-5 and rel_err(t2n(cx3)[:, ownc], t2n(cx)[:, ownc]) < 1e-5
+
+
 def test_lsa_step_exchange_under_load(dev):
     """The in-launch energy exchange of mstts_lsa_step_fwd over 300 consecutive epochs with a different query each
     epoch and a weight-streaming kernel interleaved (uneven load, warm L1/L2): every epoch must equal the two-launch

@@ -711,8 +711,10 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
         RC(zero(d->c1, 2 * BH, s));
         RC(zero(d->cum, 2 * BT, s));
         RC(zero(zero_frame, B * NM, s));
-        RC(zero(gran, 2 * BT + 2, s));
+        RC(zero(gran, 2 * BT + 2 + 2 * B * A, s));      // (+ the query granules of the in-launch projection: they take the head of `q`)
     }
+    // query projection inside the attention launch (its granules follow the energy granules and the counter, i.e. sit in `q`)
+    const bool fused_q = mstts_lsa_step_q_supported(T, M, H) && d->lsa.loc_kt && A == 128 && WP % 4 == 0 && MSTTS_MAX_PARTS >= 2;
     const size_t pn_lds = sizeof(float) * (size_t)(PN_MAXB * (NM + 1) + PN_MAXB * (P + 1) + 4 * 32 * 17);
     // fused cell steps (cell.hip): packed kernels given and shapes covered -> 7 launches per frame instead of 9
     const bool fused = d->w0sp && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1);
@@ -737,10 +739,15 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
                          in1c, W1, d->c0 + nx * BH, in0n + P + M, W0, nullptr, nullptr, B, H, P1c, W1, 0, P0n, W0, P + M, s));
             RC(cell_step(P1c, d->w1p, W1, nullptr, 0, d->b1, d->c1 + par * BH, in1c + H, W1, nullptr, nullptr, d->zoneout,
                          d->pj, WP, d->c1 + nx * BH, in1n + H, W1, nullptr, nullptr, B, H, nullptr, 0, 0, P1n, W1, H, s));
-            RC(xw_fwd(d->pj, WP, d->wq, A, q, B, A, H, spq, &parts, s));
             mstts_cell_packed_dst ctx_p = {P0n, W0, P, 0};
-            RC(mstts_lsa_step_fwd(&d->lsa, q, parts, B * A, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
-                                  in0n + P, W0, d->pj + H, WP, &ctx_p, gran, (uint32_t)(st + 1), s));
+            if (fused_q) {
+                RC(mstts_lsa_step_fwd_q(&d->lsa, d->pj, WP, d->wq, H, 0, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
+                                        in0n + P, W0, d->pj + H, WP, &ctx_p, gran, (uint32_t)(st + 1), -1, s));
+            } else {
+                RC(xw_fwd(d->pj, WP, d->wq, A, q, B, A, H, spq, &parts, s));
+                RC(mstts_lsa_step_fwd(&d->lsa, q, parts, B * A, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
+                                      in0n + P, W0, d->pj + H, WP, &ctx_p, gran, (uint32_t)(st + 1), s));
+            }
             RC(xw_fwd(d->pj, WP, d->wp_pad, NP, pp, B, NP, WP, spp, &parts, s));
             hipLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)((B * (NM + 1) + 255) / 256)), dim3(256), 0, (hipStream_t)s, pp, parts, B * NP, d->bproj,
                                (int)B, (int)NP, (int)NM, d->linear + st * B * NM, d->stop + st * B);

@@ -253,7 +253,7 @@ int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int32_t q_parts
                        void* granules, uint32_t epoch, mstts_stream_t s);
 /* The same step with the query projection q = m1 . Wq inside the launch (one launch less per decoder step): m1 rows [B, H] with row
  * stride m1_ld, wq [H, A] row-major; q_bf16 != 0 rounds both operands to bf16 first (BASELINE config 3).  Available when
- * mstts_lsa_step_q_supported(T, M, H) (8 slices: T <= 128, M <= 768; H == 1024) and c->loc_kt is set.  granules =
+ * mstts_lsa_step_q_supported(T, M, H) (at least 8 slices: T > 112 or M > 672; H == 1024) and c->loc_kt is set.  granules =
  * mstts_lsa_step_q_ws_bytes(B, T) bytes (energy granules, time-out counter, B * A query granules), zeroed before the first step.
  * q_sum (may be NULL) receives the query.  skip_slice >= 0 = self-test form (the workgroups of that slice leave at once, the others
  * time out on its query units and energies and recompute them), -1 = normal operation. */

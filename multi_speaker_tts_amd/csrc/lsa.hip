@@ -298,8 +298,9 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     float4 qw[QIN ? QJ : 1], qm[QIN ? QJ / 4 : 1];
     if constexpr (QIN) {                 // thread (a4 = tid & 3, chunk = tid >> 2): units 16 cs + 4 a4 .. + 3, hidden units 8 chunk .. + 7
         const int a4 = tid & 3, ch = tid >> 2;
+        const int qs = cs < 8 ? cs : 0;      // slices 0..7 own 16 query units each; further slices (T > 128) own none and only gather
 #pragma unroll
-        for (int jj = 0; jj < QJ; ++jj) qw[jj] = *reinterpret_cast<const float4*>(qi.wq + (long)(ch * QJ + jj) * A_ + 16 * cs + 4 * a4);
+        for (int jj = 0; jj < QJ; ++jj) qw[jj] = *reinterpret_cast<const float4*>(qi.wq + (long)(ch * QJ + jj) * A_ + 16 * qs + 4 * a4);
 #pragma unroll
         for (int jj = 0; jj < QJ / 4; ++jj) qm[jj] = *reinterpret_cast<const float4*>(qi.m1 + (long)b * qi.m1_ld + ch * QJ + 4 * jj);
     } else {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         if ((tid & 15) >= 12) *reinterpret_cast<float4*>(&s_qp[(tid >> 4) * 16 + 4 * (tid & 3)]) = acc;   // lanes 12..15 of a row hold its sums
         __syncthreads();
         gu64* gq = (gu64*)(gran + (long)c.B * T + 1 + (long)b * A_);
-        if (tid < 16) {
+        if (tid < 16 && cs < 8) {
             float qa = 0.f;
 #pragma unroll
             for (int r = 0; r < 32; ++r) qa += s_qp[r * 16 + tid];
@@ -1053,7 +1054,7 @@ static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t
     const bool lkt = c->loc_kt && aligned16(c->loc_kt);
     if (qin) {
         qi = *qin;
-        MSTTS_REQUIRE(cs == 8 && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_q: needs 8 slices (T <= 128, M <= 768), H == %d and the by-unit filter", 128 * QJ);
+        MSTTS_REQUIRE(cs >= 8 && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_q: needs at least 8 slices (T > 112 or M > 672), H == %d and the by-unit filter", 128 * QJ);
         MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_q: m1 / wq must be 16-byte aligned");
         if (skip >= 0)
             hipLaunchKernelGGL((lsa_step_kernel<true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
@@ -1079,14 +1080,14 @@ extern "C" int mstts_lsa_step_fwd(const mstts_lsa_const* c, const float* q, int3
     return lsa_step_fwd_launch(c, q, q_parts, q_pstride, q_sum, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch, -1, s);
 }
 /* The same step with the query projection inside the launch: q = m1 . Wq (m1 rows [B, H] with row stride m1_ld, Wq [H, A] row-major;
- * q_bf16 != 0 rounds both operands to bf16 first - BASELINE config 3), one launch less per decoder step.  Needs 8 slices (T <= 128,
- * M <= 768), H == 1024 and c->loc_kt; granules = mstts_lsa_step_q_ws_bytes(B, T) bytes (the energy granules, the time-out counter,
+ * q_bf16 != 0 rounds both operands to bf16 first - BASELINE config 3), one launch less per decoder step.  Needs at least 8 slices
+ * (T > 112 or M > 672: the first eight own 16 query units each), H == 1024 and c->loc_kt; granules = mstts_lsa_step_q_ws_bytes(B, T) bytes (the energy granules, the time-out counter,
  * then B * A query granules), zeroed before the first step.  skip_slice >= 0: the self-test form (see below), -1 otherwise. */
 extern "C" int32_t mstts_lsa_step_q_supported(int64_t T, int64_t M, int64_t H) {
     int cs, tsl, dsl;
     if (T < 1 || M < 4) return 0;
     lsa_step_geometry(T, M, &cs, &tsl, &dsl);
-    return cs == 8 && H == 128 * QJ;
+    return cs >= 8 && H == 128 * QJ;
 }
 extern "C" int64_t mstts_lsa_step_q_ws_bytes(int64_t B, int64_t T) { return (B * T + 1 + B * A_) * 8; }
 extern "C" int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, int32_t q_bf16,

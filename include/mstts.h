@@ -262,6 +262,16 @@ int64_t mstts_lsa_step_q_ws_bytes(int64_t B, int64_t T);
 int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, int32_t q_bf16, float* q_sum,
                          const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
                          const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
+/* ... and with the output projection [m1 | ctx] . wp + bias inside the launch as well (free-running decoder): wp [H + M, NP] row-major,
+ * NP <= 88, columns 0..NM-1 = the mel frame, column NM = the stop logit; bias [NP] or NULL; linear [B, NM], stop [B] receive them.
+ * Slices exchange partial outputs through granules (reduce-scatter: slice s < 8 finishes outputs 11 s .. 11 s + 10).  granules =
+ * mstts_lsa_step_qp_ws_bytes(B, T) bytes, zeroed before the first step.  Same availability as mstts_lsa_step_fwd_q, at most 16 slices. */
+int32_t mstts_lsa_step_qp_supported(int64_t T, int64_t M, int64_t H, int64_t NP);
+int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T);
+int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp,
+                          const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum, float* align,
+                          float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, const mstts_cell_packed_dst* ctx_p,
+                          void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
 /* backward of one step, two launches:
  *  dalign : G[t] = G_next[t] + sum_j h_next[t+pad-j][j] ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
  *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); h[t,j] = sum_k g[t,k] loc_k[j,k]

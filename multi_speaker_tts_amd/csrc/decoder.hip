@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restric
                                                           const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, float inv_keep,
                                                           int B, int P, float* __restrict__ out, long out_ld, PackedDst out_p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ __attribute__((aligned(16))) uint8_t s_m0[PN_MAXB * 64 * PN_MAXTPW];       // first dropout mask, rows >= B zero
     const int ldx = NM + 1, ldh = P + 1;
     float* s_x = sm;                               // [32][NM + 1]
     float* s_h = s_x + PN_MAXB * ldx;              // [32][P + 1]
@@ -599,20 +600,59 @@ __global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restric
         const int e = tid + 256 * i;
         xr[i] = (e < B * NM) ? frame[e] : 0.f;
     }
+    // layer-0 kernel: lane j of wave w holds columns (16 w + j) tpw + t of its tpw column tiles t, so each k row is one 16-byte load
+    // (tpw == 4) instead of four words 64 bytes apart
     float w0r[PN_MAXTPW][PN_MAXNM4];
+    const int colb = (16 * wave + j) * tpw;
+    if (tpw == 4) {
 #pragma unroll
-    for (int t = 0; t < PN_MAXTPW; ++t)
+        for (int it = 0; it < PN_MAXNM4; ++it) {
+            const float4 x = (it < nit0) ? *reinterpret_cast<const float4*>(w0 + (long)(4 * it + kq) * P + colb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w0r[0][it] = x.x; w0r[1][it] = x.y; w0r[2][it] = x.z; w0r[3][it] = x.w;
+        }
+    } else {
 #pragma unroll
-        for (int it = 0; it < PN_MAXNM4; ++it)
-            w0r[t][it] = (t < tpw && it < nit0) ? w0[(long)(4 * it + kq) * P + (wave + 4 * t) * 16 + j] : 0.f;
+        for (int t = 0; t < PN_MAXTPW; ++t)
+#pragma unroll
+            for (int it = 0; it < PN_MAXNM4; ++it)
+                w0r[t][it] = (t < tpw && it < nit0) ? w0[(long)(4 * it + kq) * P + colb + t] : 0.f;
+    }
     float w1r[PN_MAXK1];
 #pragma unroll
     for (int it = 0; it < PN_MAXK1; ++it)
         w1r[it] = (it < nit1 && c0 + j < P) ? w1[(long)(wave * (P / 4) + 4 * it + kq) * P + c0 + j] : 0.f;
+    // (the dropout masks and biases of both layers too: they do not depend on anything computed here, and fetched where they are
+    // used each was a memory round trip of its own on the step's critical path)
+    // the first mask goes to LDS through two 16-byte loads per thread (fetched byte by byte where it is used - 32 loads of one byte per
+    // lane - it cost 4.6 us of the kernel's 13.8)
+    float b0r[PN_MAXTPW];
 #pragma unroll
-    for (int i = 0; i < (PN_MAXB * 4 * PN_MAXNM4 + 255) / 256; ++i) {
-        const int e = tid + 256 * i;
-        if (e < PN_MAXB * NM) s_x[(e / NM) * ldx + e % NM] = xr[i];          // rows >= B are zero
+    for (int t = 0; t < PN_MAXTPW; ++t) b0r[t] = (t < tpw) ? b0[colb + t] : 0.f;
+    uint4 m0q[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = 16 * (tid + 256 * i);
+        m0q[i] = (e < B * P) ? *reinterpret_cast<const uint4*>(m0 + e) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float b1r[2];
+    float m1r[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i, b = e / PN_COLS, cc = e % PN_COLS;
+        const bool live = b < B && c0 + cc < P;
+        b1r[i] = live ? b1[c0 + cc] : 0.f;
+        m1r[i] = live ? (float)m1[(long)b * P + c0 + cc] : 0.f;
+    }
+    {
+        const float inv_nm = 1.f / (float)NM;
+#pragma unroll
+        for (int i = 0; i < (PN_MAXB * 4 * PN_MAXNM4 + 255) / 256; ++i) {
+            const int e = tid + 256 * i;
+            const int row = (int)(((float)e + 0.5f) * inv_nm);               // e / NM without the integer division (e < 2560: exact)
+            if (e < PN_MAXB * NM) s_x[row * ldx + e - row * NM] = xr[i];     // rows >= B are zero
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) reinterpret_cast<uint4*>(s_m0)[tid + 256 * i] = m0q[i];
     }
     __syncthreads();
     // ---- layer 0
@@ -633,13 +673,13 @@ __global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restric
                     if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[it], w0r[t][it], acc1, 0, 0, 0);
                 }
             }
-            const int col = (wave + 4 * t) * 16 + j;
-            const float bj = b0[col];
+            const int col = colb + t;
+            const float bj = b0r[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = kq * 4 + r;
-                s_h[row * ldh + col] = (row < B && m0[(long)row * P + col]) ? fmaxf(acc0[r] + bj, 0.f) * inv_keep : 0.f;
-                s_h[(16 + row) * ldh + col] = (16 + row < B && m0[(long)(16 + row) * P + col]) ? fmaxf(acc1[r] + bj, 0.f) * inv_keep : 0.f;
+                s_h[row * ldh + col] = s_m0[row * P + col] ? fmaxf(acc0[r] + bj, 0.f) * inv_keep : 0.f;
+                s_h[(16 + row) * ldh + col] = s_m0[(16 + row) * P + col] ? fmaxf(acc1[r] + bj, 0.f) * inv_keep : 0.f;
             }
         }
     }
@@ -662,11 +702,12 @@ __global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int e = tid; e < B * PN_COLS; e += 256) {
-        const int b = e / PN_COLS, cc = e % PN_COLS;
-        if (c0 + cc >= P) continue;
-        const float v = s_r[b * 17 + cc] + s_r[(32 + b) * 17 + cc] + s_r[(64 + b) * 17 + cc] + s_r[(96 + b) * 17 + cc] + b1[c0 + cc];
-        const float y = m1[(long)b * P + c0 + cc] ? fmaxf(v, 0.f) * inv_keep : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i, b = e / PN_COLS, cc = e % PN_COLS;
+        if (b >= B || c0 + cc >= P) continue;
+        const float v = s_r[b * 17 + cc] + s_r[(32 + b) * 17 + cc] + s_r[(64 + b) * 17 + cc] + s_r[(96 + b) * 17 + cc] + b1r[i];
+        const float y = fmaxf(v, 0.f) * (fminf(m1r[i], 1.f) * inv_keep);
         out[(long)b * out_ld + c0 + cc] = y;
         if (out_p.base) packed_store(out_p, b, c0 + cc, y);          // the fused cell-0 step reads its input row from the packed block
     }
@@ -700,7 +741,8 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
               spp = mstts_skinny_fwd_splits(NP, WP);
     float* w = d->pre_ws;
     float* gates = w;       w += (long)MSTTS_MAX_PARTS * 4 * BH;
-    float* gran = w;        w += 2 * BT + 2;
+    const long gran_n = mstts_lsa_step_qp_ws_bytes(B, T) / 4;       // energy granules + counter, then the query and projection granules
+    float* gran = w;        w += gran_n;
     float* q = w;           w += (long)MSTTS_MAX_PARTS * B * A;
     float* pp = w;          w += (long)MSTTS_MAX_PARTS * B * NP;
     float* zero_frame = w;  w += B * NM;
@@ -711,10 +753,11 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
         RC(zero(d->c1, 2 * BH, s));
         RC(zero(d->cum, 2 * BT, s));
         RC(zero(zero_frame, B * NM, s));
-        RC(zero(gran, 2 * BT + 2 + 2 * B * A, s));      // (+ the query granules of the in-launch projection: they take the head of `q`)
+        RC(zero(gran, gran_n, s));
     }
-    // query projection inside the attention launch (its granules follow the energy granules and the counter, i.e. sit in `q`)
-    const bool fused_q = mstts_lsa_step_q_supported(T, M, H) && d->lsa.loc_kt && A == 128 && WP % 4 == 0 && MSTTS_MAX_PARTS >= 2;
+    // query projection inside the attention launch, and the output projection too where the slice count allows
+    const bool fused_q = mstts_lsa_step_q_supported(T, M, H) && d->lsa.loc_kt && A == 128 && WP % 4 == 0;
+    const bool fused_qp = fused_q && mstts_lsa_step_qp_supported(T, M, H, NP);
     const size_t pn_lds = sizeof(float) * (size_t)(PN_MAXB * (NM + 1) + PN_MAXB * (P + 1) + 4 * 32 * 17);
     // fused cell steps (cell.hip): packed kernels given and shapes covered -> 7 launches per frame instead of 9
     const bool fused = d->w0sp && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1);
@@ -740,6 +783,12 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
             RC(cell_step(P1c, d->w1p, W1, nullptr, 0, d->b1, d->c1 + par * BH, in1c + H, W1, nullptr, nullptr, d->zoneout,
                          d->pj, WP, d->c1 + nx * BH, in1n + H, W1, nullptr, nullptr, B, H, nullptr, 0, 0, P1n, W1, H, s));
             mstts_cell_packed_dst ctx_p = {P0n, W0, P, 0};
+            if (fused_qp) {
+                RC(mstts_lsa_step_fwd_qp(&d->lsa, d->pj, WP, d->wq, H, d->wp_pad, d->bproj, NP, NM, d->linear + st * B * NM, d->stop + st * B,
+                                         d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT, in0n + P, W0, d->pj + H, WP, &ctx_p, gran,
+                                         (uint32_t)(st + 1), -1, s));
+                continue;
+            }
             if (fused_q) {
                 RC(mstts_lsa_step_fwd_q(&d->lsa, d->pj, WP, d->wq, H, 0, nullptr, d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT,
                                         in0n + P, W0, d->pj + H, WP, &ctx_p, gran, (uint32_t)(st + 1), -1, s));
@@ -780,7 +829,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
 extern "C" int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel) {
     const long np = (n_mel + 1 + 3) / 4 * 4;
     const long slow = 2 * B * P + 8 * B * H + (2 * B * T + 2) + B * A + B * n_mel;
-    const long fast = (long)MSTTS_MAX_PARTS * (4 * B * H + B * A + B * np) + (2 * B * T + 2) + B * n_mel;
+    const long fast = (long)MSTTS_MAX_PARTS * (4 * B * H + B * A + B * np) + mstts_lsa_step_qp_ws_bytes(B, T) / 4 + B * n_mel;
     return slow > fast ? slow : fast;
 }
 

@@ -247,15 +247,40 @@ constexpr int QJ = 8;             // hidden units per thread of the in-launch qu
 // SELFTEST instantiation (mstts_lsa_step_fwd_selftest only): the workgroup of slice `skip` leaves at once, so the rest of its row must take
 // the time-out path - the only way to exercise it, since on a healthy chip no workgroup ever times out
 struct LsaQIn { const float* m1; long m1_ld; const float* wq; int H, bf16; };      // QIN operands: m1 rows [B, >= H], Wq [H, A] row-major
-template <bool SELFTEST, bool LKT = false, bool QIN = false>
+// PROJ (free-running decoder): the output projection [m1 | ctx] . Wp + bias also runs in this launch.  Every slice multiplies its own
+// context columns (and, slices 0..7, 128 of the m1 units) into NP partial outputs, publishes them as granules, and slice s < 8 adds up
+// outputs 11 s .. 11 s + 10 of all slices and writes that part of the row's linear frame / stop logit.
+constexpr int PJ_NP_MAX = 96, PJ_SL_MAX = 16, PJ_OWN = 11, PJ_PARTS = 6;
+constexpr int PJ_ITM = 22, PJ_ITC = 16;       // rows of Wp per thread: PJ_PARTS * PJ_ITM >= 128 m1 units, PJ_PARTS * PJ_ITC >= FS_DSL context columns
+struct LsaProj { const float* wp; const float* bias; int NP, NM; float* linear; float* stop; unsigned long long* gp; };
+__device__ __noinline__ float lsa_proj_partial_serial(const mstts_lsa_const& c, const LsaQIn& qi, const LsaProj& pj, int b, int sl, int o, int dsl,
+                                                     const float* s_e, float mx, float inv, int len) {
+    // the partial output o of slice sl recomputed by one thread: its context columns from the alignments, its m1 units from memory
+    const int T = (int)c.T, M = (int)c.M, H = qi.H;
+    float acc = 0.f;
+    for (int cc = sl * dsl; cc < min((sl + 1) * dsl, M); ++cc) {
+        float x = 0.f;
+        for (int t = 0; t < len; ++t) x += __expf(s_e[t] - mx) * inv * c.values[((long)b * T + t) * M + cc];
+        acc += x * pj.wp[(long)(H + cc) * pj.NP + o];
+    }
+    if (sl < 8)
+        for (int j = 128 * sl; j < 128 * sl + 128; ++j) acc += qi.m1[(long)b * qi.m1_ld + j] * pj.wp[(long)j * pj.NP + o];
+    return acc;
+}
+template <bool SELFTEST, bool LKT = false, bool QIN = false, bool PROJ = false>
 __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
                                                               float* __restrict__ q_sum, const float* cum,
                                                               float* __restrict__ align, float* __restrict__ cum_next,
                                                               float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld, PackedDst ctx_p,
-                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int ncs, int skip, LsaQIn qi) {
+                                                              unsigned long long* gran, unsigned epoch, int tsl, int dsl, int ncs, int skip, LsaQIn qi,
+                                                              LsaProj pjx) {
     int cs, b;
     row_slice_of_block(blockIdx.x, ncs, (int)c.B, &b, &cs);
     if (SELFTEST && cs == skip) return;
+    __shared__ float s_px[PROJ ? FS_DSL + PJ_PARTS * PJ_ITM : 1];               // PROJ: this slice's context columns, then its m1 units
+    __shared__ float s_pp[PROJ ? PJ_PARTS * PJ_NP_MAX : 1];
+    __shared__ float s_po[PROJ ? PJ_NP_MAX : 1];
+    __shared__ float s_pf[PROJ ? PJ_SL_MAX * PJ_OWN : 1];
     __shared__ __attribute__((aligned(16))) float s_qp[QIN ? 32 * 16 : 4];     // QIN: per-row-of-16-lanes partial sums of the 16 own units
     __shared__ float s_q[QIN ? A_ : 1];                                         // QIN: the row's query
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
@@ -306,6 +331,21 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     } else {
         qv = sum_parts<MSTTS_MAX_PARTS>(q, q_parts, q_pstride, (long)b * A_ + k);
     }
+    // PROJ: the rows of Wp this thread multiplies (output o = tid % NP, rows part + PJ_PARTS it of the slice's 128 m1 units and of its
+    // context columns) are requested here, with everything else: the tail of the kernel then has no memory round trip of its own
+    float wm[PROJ ? PJ_ITM : 1], wc[PROJ ? PJ_ITC : 1], pm = 0.f, pbias = 0.f, pacc = 0.f;
+    const int po = PROJ ? tid % pjx.NP : 0, ppart = PROJ ? tid / pjx.NP : 0;
+    if constexpr (PROJ) {
+        const int NP = pjx.NP, ncol = max(0, min(dsl, M - d0));
+        const bool act = ppart < PJ_PARTS;
+#pragma unroll
+        for (int it = 0; it < PJ_ITM; ++it) {
+            const int r = ppart + PJ_PARTS * it;
+            wm[it] = (act && cs < 8 && r < 128) ? pjx.wp[(long)(128 * cs + r) * NP + po] : 0.f;
+        }
+        if (cs < 8 && tid < 128) pm = qi.m1[(long)b * qi.m1_ld + 128 * cs + tid];
+        if (cs < 8 && tid < PJ_OWN && PJ_OWN * cs + tid <= pjx.NM && pjx.bias) pbias = pjx.bias[PJ_OWN * cs + tid];
+    }
     const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
     const float* v = c.values + (long)b * T * M + col;
     float4 vv[FS_VPRE];
@@ -316,8 +356,19 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         // between len and T are real memory and get a zero alignment below)
         vv[i] = (vlive && t < T) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if constexpr (PROJ) {
+        const int NP = pjx.NP, ncol = max(0, min(dsl, M - d0));
+#pragma unroll
+        for (int it = 0; it < PJ_ITC; ++it) {
+            const int r = ppart + PJ_PARTS * it;
+            wc[it] = (ppart < PJ_PARTS && r < ncol) ? pjx.wp[(long)(qi.H + d0 + r) * NP + po] : 0.f;
+        }
+    }
     // ---- own energy slice
     if (tid < FS_TSL + KS_MAX - 1 + 2) s_cum[tid] = cwin;          // entries past the window are zero
+    if constexpr (PROJ) {
+        if (tid < PJ_PARTS * PJ_ITM) s_px[FS_DSL + tid] = pm;       // (zero past the 128 units, and for slices that own none)
+    }
     if constexpr (QIN) {
         // own 16 units of the query: 8 hidden units per thread, then the 16 chunks of each 16-lane row through DPP row shifts, the 32
         // rows of the workgroup through LDS
@@ -388,6 +439,10 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         s_e[t0 + tid] = e;
         __hip_atomic_store(g + t0 + tid, ((unsigned long long)epoch << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if constexpr (PROJ) {             // the m1 part of this thread's partial output, while the row's energies travel
+#pragma unroll
+        for (int it = 0; it < PJ_ITM; ++it) pacc += s_px[FS_DSL + ppart + PJ_PARTS * it] * wm[it];
+    }
     // ---- gather the other slices of the row (the data is the flag)
     for (int t = tid; t < T; t += FS_THREADS) {
         if (t >= t0 && t < t0 + tsl) continue;
@@ -446,6 +501,60 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         ctx[(long)b * ctx_ld + d0 + tid] = r;
         if (ctx2) ctx2[(long)b * ctx2_ld + d0 + tid] = r;
         if (ctx_p.base) packed_store(ctx_p, b, d0 + tid, r);
+        if constexpr (PROJ) pm = r;
+    }
+    if constexpr (PROJ) {
+        const int NP = pjx.NP;
+        if (tid < FS_DSL) s_px[tid] = (tid < dsl && d0 + tid < M) ? pm : 0.f;
+        __syncthreads();
+        if (ppart < PJ_PARTS) {
+#pragma unroll
+            for (int it = 0; it < PJ_ITC; ++it) pacc += s_px[ppart + PJ_PARTS * it] * wc[it];
+            s_pp[ppart * PJ_NP_MAX + po] = pacc;
+        }
+        __syncthreads();
+        gu64* gp = (gu64*)(pjx.gp + ((long)b * PJ_SL_MAX + cs) * PJ_NP_MAX);
+        if (tid < NP) {
+            float v2 = 0.f;
+#pragma unroll
+            for (int q2 = 0; q2 < PJ_PARTS; ++q2) v2 += s_pp[q2 * PJ_NP_MAX + tid];
+            s_po[tid] = v2;
+            __hip_atomic_store(gp + tid, ((unsigned long long)epoch << 32) | __float_as_uint(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cs < 8) {                                                // owner of outputs PJ_OWN cs .. PJ_OWN cs + PJ_OWN - 1
+            __syncthreads();
+            if (tid < ncs * PJ_OWN) {
+                const int sl = tid / PJ_OWN, oo = PJ_OWN * cs + tid % PJ_OWN;
+                float v2 = 0.f;
+                if (oo < NP) {
+                    if (sl == cs) v2 = s_po[oo];
+                    else {
+                        const gu64* gs = (const gu64*)(pjx.gp + ((long)b * PJ_SL_MAX + sl) * PJ_NP_MAX) + oo;
+                        unsigned long long x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned spins = 0;
+                        while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
+                            __builtin_amdgcn_s_sleep(1);
+                            x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ++spins;
+                        }
+                        if ((unsigned)(x >> 32) == epoch) v2 = __uint_as_float((unsigned)x);
+                        else {
+                            v2 = lsa_proj_partial_serial(c, qi, pjx, b, sl, oo, dsl, s_e, mx, inv, len);
+                            atomicAdd(gran + (long)c.B * T, 1ull);
+                        }
+                    }
+                }
+                s_pf[sl * PJ_OWN + tid % PJ_OWN] = v2;
+            }
+            __syncthreads();
+            if (tid < PJ_OWN && PJ_OWN * cs + tid < NP) {
+                const int oo = PJ_OWN * cs + tid;
+                float v2 = pbias;
+                for (int sl = 0; sl < ncs; ++sl) v2 += s_pf[sl * PJ_OWN + tid];
+                if (oo < pjx.NM) pjx.linear[(long)b * pjx.NM + oo] = v2;
+                else if (oo == pjx.NM) pjx.stop[b] = v2;
+            }
+        }
     }
 }
 
@@ -1042,7 +1151,7 @@ extern "C" int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T) { return (B * T
 static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
                                const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
                                const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int skip, mstts_stream_t s,
-                               const LsaQIn* qin = nullptr) {
+                               const LsaQIn* qin = nullptr, const LsaProj* proj = nullptr) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_fwd: granule buffer (8-byte aligned) and a non-zero epoch required");
     PackedDst cp;
@@ -1051,26 +1160,40 @@ static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t
     lsa_step_geometry(c->T, c->M, &cs, &tsl, &dsl);
     LsaQIn qi;
     memset(&qi, 0, sizeof(qi));
+    LsaProj pz;
+    memset(&pz, 0, sizeof(pz));
     const bool lkt = c->loc_kt && aligned16(c->loc_kt);
-    if (qin) {
+    if (qin && proj) {
+        qi = *qin; pz = *proj;
+        MSTTS_REQUIRE(cs >= 8 && cs <= PJ_SL_MAX && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: needs 8..%d slices, H == %d and the by-unit filter", PJ_SL_MAX, 128 * QJ);
+        MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_qp: m1 / wq must be 16-byte aligned");
+        MSTTS_REQUIRE(pz.wp && pz.linear && pz.stop && pz.gp && pz.NP >= 1 && pz.NP <= PJ_NP_MAX && pz.NP <= 8 * PJ_OWN && pz.NM < pz.NP &&
+                      PJ_PARTS * pz.NP <= FS_THREADS && dsl <= FS_DSL, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: projection width must be <= %d columns", 8 * PJ_OWN);
+        if (skip >= 0)
+            hipLaunchKernelGGL((lsa_step_kernel<true, true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz);
+        else
+            hipLaunchKernelGGL((lsa_step_kernel<false, true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
+    } else if (qin) {
         qi = *qin;
         MSTTS_REQUIRE(cs >= 8 && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_q: needs at least 8 slices (T > 112 or M > 672), H == %d and the by-unit filter", 128 * QJ);
         MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_q: m1 / wq must be 16-byte aligned");
         if (skip >= 0)
             hipLaunchKernelGGL((lsa_step_kernel<true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
-                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi);
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz);
         else
             hipLaunchKernelGGL((lsa_step_kernel<false, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
-                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi);
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
     } else if (skip >= 0)
         hipLaunchKernelGGL(lsa_step_kernel<true>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz);
     else if (lkt)
         hipLaunchKernelGGL((lsa_step_kernel<false, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
     else
         hipLaunchKernelGGL(lsa_step_kernel<false>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
     MSTTS_CHECK_LAUNCH("lsa_step_fwd");
     return MSTTS_OK;
 }
@@ -1098,6 +1221,29 @@ extern "C" int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, i
     qi.m1 = m1; qi.m1_ld = (long)m1_ld; qi.wq = wq; qi.H = (int)H; qi.bf16 = q_bf16 ? 1 : 0;
     return lsa_step_fwd_launch(c, nullptr, 0, 0, q_sum, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch,
                                skip_slice >= 0 ? skip_slice : -1, s, &qi);
+}
+/* ... and with the output projection [m1 | ctx] . wp + bias inside the launch too (free-running decoder: the frame is needed by the next
+ * step's prenet, nothing else waits for it): wp [H + M, NP] row-major (NP <= 88, columns 0..NM-1 = mel frame, column NM = stop logit),
+ * bias [NP] or NULL; linear [B, NM], stop [B].  granules = mstts_lsa_step_qp_ws_bytes(B, T) bytes, zeroed before the first step. */
+extern "C" int32_t mstts_lsa_step_qp_supported(int64_t T, int64_t M, int64_t H, int64_t NP) {
+    int cs, tsl, dsl;
+    if (T < 1 || M < 4) return 0;
+    lsa_step_geometry(T, M, &cs, &tsl, &dsl);
+    return cs >= 8 && cs <= PJ_SL_MAX && dsl <= FS_DSL && H == 128 * QJ && NP >= 2 && NP <= 8 * PJ_OWN && PJ_PARTS * NP <= FS_THREADS;
+}
+extern "C" int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T) { return (B * T + 1 + B * A_ + B * PJ_SL_MAX * PJ_NP_MAX) * 8; }
+extern "C" int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp,
+                                     const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum, float* align,
+                                     float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, const mstts_cell_packed_dst* ctx_p,
+                                     void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s) {
+    MSTTS_REQUIRE(c && granules, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: null pointer");
+    LsaQIn qi;
+    qi.m1 = m1; qi.m1_ld = (long)m1_ld; qi.wq = wq; qi.H = (int)H; qi.bf16 = 0;
+    LsaProj pj;
+    pj.wp = wp; pj.bias = bias; pj.NP = (int)NP; pj.NM = (int)NM; pj.linear = linear; pj.stop = stop;
+    pj.gp = (unsigned long long*)granules + (c->B * c->T + 1 + c->B * A_);
+    return lsa_step_fwd_launch(c, nullptr, 0, 0, nullptr, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch,
+                               skip_slice >= 0 ? skip_slice : -1, s, &qi, &pj);
 }
 /* test entry: same launch with the workgroups of slice `skip_slice` (0 .. slices-1) removed, which forces every other workgroup of each row
  * through its time-out path (takes milliseconds); the skipped slice's own outputs are not written */

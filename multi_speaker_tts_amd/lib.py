@@ -143,6 +143,9 @@ SIGNATURES = {
     "mstts_lsa_step_fwd": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, vp]),
     "mstts_lsa_step_q_supported": (i32, [i64, i64, i64]),
     "mstts_lsa_step_q_ws_bytes": (i64, [i64, i64]),
+    "mstts_lsa_step_qp_supported": (i32, [i64, i64, i64, i64]),
+    "mstts_lsa_step_qp_ws_bytes": (i64, [i64, i64]),
+    "mstts_lsa_step_fwd_qp": (i32, [P(LsaConst), vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
     "mstts_lsa_step_fwd_q": (i32, [P(LsaConst), vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
     "mstts_lsa_step_fwd_selftest": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, C.c_uint32, i32, vp]),
     "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),

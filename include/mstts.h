@@ -262,16 +262,18 @@ int64_t mstts_lsa_step_q_ws_bytes(int64_t B, int64_t T);
 int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, int32_t q_bf16, float* q_sum,
                          const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
                          const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
-/* ... and with the output projection [m1 | ctx] . wp + bias inside the launch as well (free-running decoder): wp [H + M, NP] row-major,
- * NP <= 88, columns 0..NM-1 = the mel frame, column NM = the stop logit; bias [NP] or NULL; linear [B, NM], stop [B] receive them.
- * Slices exchange partial outputs through granules (reduce-scatter: slice s < 8 finishes outputs 11 s .. 11 s + 10).  granules =
- * mstts_lsa_step_qp_ws_bytes(B, T) bytes, zeroed before the first step.  Same availability as mstts_lsa_step_fwd_q, at most 16 slices. */
+/* ... and with the output projection [m1 | ctx] . Wp + bias out of the same launch (free-running decoder), with no exchange of its own:
+ * ctx . Wp[H:, :] = sum_t a[t] vp[t] with vp [B, T, NP] = values . Wp[H:, :] (loop invariant like the keys: one GEMM per utterance), formed
+ * by slice s < 8 for outputs 11 s .. 11 s + 10 from its own softmax weights; m1 . Wp[:H, :] for those outputs rides on the query
+ * projection through wp_own = mstts_lsa_proj_pack(Wp[:H, :]) (mstts_lsa_proj_pack_floats() floats).  bias [NM + 1] or NULL; columns
+ * 0..NM-1 -> linear [B, NM], column NM -> stop [B]; NP <= 88.  Availability, granules and skip_slice as mstts_lsa_step_fwd_q. */
 int32_t mstts_lsa_step_qp_supported(int64_t T, int64_t M, int64_t H, int64_t NP);
-int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T);
-int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp,
-                          const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum, float* align,
-                          float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, const mstts_cell_packed_dst* ctx_p,
-                          void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
+int64_t mstts_lsa_proj_pack_floats(void);
+int mstts_lsa_proj_pack(const float* wp, int64_t ld, int64_t H, int64_t NP, float* wp_own, mstts_stream_t s);
+int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp_own,
+                          const float* vp, const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum,
+                          float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                          const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
 /* backward of one step, two launches:
  *  dalign : G[t] = G_next[t] + sum_j h_next[t+pad-j][j] ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
  *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); h[t,j] = sum_k g[t,k] loc_k[j,k]
@@ -565,6 +567,9 @@ typedef struct {
     /* optional fused cell steps on that path: w0sp / w1p = w0s / w1 packed by mstts_pack_cell_fwd, act_p = 2 * (mstts_cell_act_floats(B, P+M+H)
      * + mstts_cell_act_floats(B, 2H)) floats of scratch: each cell becomes one launch (7 launches per frame instead of 9) */
     const float* w0sp; const float* w1p; float* act_p;
+    /* optional, with the fused cell steps: the output projection inside the attention launch (mstts_lsa_step_fwd_qp) -
+     * wp_own = mstts_lsa_proj_pack(wproj rows 0..H-1), vp [B, T, 4*ceil((n_mel+1)/4)] = values . wp_pad[H:, :] for this utterance batch */
+    const float* wp_own; const float* vp;
 } mstts_decoder_infer_desc;
 int32_t mstts_decoder_infer_fast(int64_t B, int64_t H, int64_t P, int64_t M, int64_t A, int64_t n_mel);
 int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);

@@ -741,7 +741,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
               spp = mstts_skinny_fwd_splits(NP, WP);
     float* w = d->pre_ws;
     float* gates = w;       w += (long)MSTTS_MAX_PARTS * 4 * BH;
-    const long gran_n = mstts_lsa_step_qp_ws_bytes(B, T) / 4;       // energy granules + counter, then the query and projection granules
+    const long gran_n = mstts_lsa_step_q_ws_bytes(B, T) / 4;        // energy granules + counter, then the query granules
     float* gran = w;        w += gran_n;
     float* q = w;           w += (long)MSTTS_MAX_PARTS * B * A;
     float* pp = w;          w += (long)MSTTS_MAX_PARTS * B * NP;
@@ -757,7 +757,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
     }
     // query projection inside the attention launch, and the output projection too where the slice count allows
     const bool fused_q = mstts_lsa_step_q_supported(T, M, H) && d->lsa.loc_kt && A == 128 && WP % 4 == 0;
-    const bool fused_qp = fused_q && mstts_lsa_step_qp_supported(T, M, H, NP);
+    const bool fused_qp = fused_q && d->wp_own && d->vp && mstts_lsa_step_qp_supported(T, M, H, NP);
     const size_t pn_lds = sizeof(float) * (size_t)(PN_MAXB * (NM + 1) + PN_MAXB * (P + 1) + 4 * 32 * 17);
     // fused cell steps (cell.hip): packed kernels given and shapes covered -> 7 launches per frame instead of 9
     const bool fused = d->w0sp && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1);
@@ -784,7 +784,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
                          d->pj, WP, d->c1 + nx * BH, in1n + H, W1, nullptr, nullptr, B, H, nullptr, 0, 0, P1n, W1, H, s));
             mstts_cell_packed_dst ctx_p = {P0n, W0, P, 0};
             if (fused_qp) {
-                RC(mstts_lsa_step_fwd_qp(&d->lsa, d->pj, WP, d->wq, H, d->wp_pad, d->bproj, NP, NM, d->linear + st * B * NM, d->stop + st * B,
+                RC(mstts_lsa_step_fwd_qp(&d->lsa, d->pj, WP, d->wq, H, d->wp_own, d->vp, d->bproj, NP, NM, d->linear + st * B * NM, d->stop + st * B,
                                          d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT, in0n + P, W0, d->pj + H, WP, &ctx_p, gran,
                                          (uint32_t)(st + 1), -1, s));
                 continue;
@@ -829,7 +829,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
 extern "C" int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel) {
     const long np = (n_mel + 1 + 3) / 4 * 4;
     const long slow = 2 * B * P + 8 * B * H + (2 * B * T + 2) + B * A + B * n_mel;
-    const long fast = (long)MSTTS_MAX_PARTS * (4 * B * H + B * A + B * np) + mstts_lsa_step_qp_ws_bytes(B, T) / 4 + B * n_mel;
+    const long fast = (long)MSTTS_MAX_PARTS * (4 * B * H + B * A + B * np) + mstts_lsa_step_q_ws_bytes(B, T) / 4 + B * n_mel;
     return slow > fast ? slow : fast;
 }
 

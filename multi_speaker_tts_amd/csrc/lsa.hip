@@ -247,26 +247,13 @@ constexpr int QJ = 8;             // hidden units per thread of the in-launch qu
 // SELFTEST instantiation (mstts_lsa_step_fwd_selftest only): the workgroup of slice `skip` leaves at once, so the rest of its row must take
 // the time-out path - the only way to exercise it, since on a healthy chip no workgroup ever times out
 struct LsaQIn { const float* m1; long m1_ld; const float* wq; int H, bf16; };      // QIN operands: m1 rows [B, >= H], Wq [H, A] row-major
-// PROJ (free-running decoder): the output projection [m1 | ctx] . Wp + bias also runs in this launch.  Every slice multiplies its own
-// context columns (and, slices 0..7, 128 of the m1 units) into NP partial outputs, publishes them as granules, and slice s < 8 adds up
-// outputs 11 s .. 11 s + 10 of all slices and writes that part of the row's linear frame / stop logit.
-constexpr int PJ_NP_MAX = 96, PJ_SL_MAX = 16, PJ_OWN = 11, PJ_PARTS = 6;
-constexpr int PJ_ITM = 22, PJ_ITC = 16;       // rows of Wp per thread: PJ_PARTS * PJ_ITM >= 128 m1 units, PJ_PARTS * PJ_ITC >= FS_DSL context columns
-struct LsaProj { const float* wp; const float* bias; int NP, NM; float* linear; float* stop; unsigned long long* gp; };
-__device__ __noinline__ float lsa_proj_partial_serial(const mstts_lsa_const& c, const LsaQIn& qi, const LsaProj& pj, int b, int sl, int o, int dsl,
-                                                     const float* s_e, float mx, float inv, int len) {
-    // the partial output o of slice sl recomputed by one thread: its context columns from the alignments, its m1 units from memory
-    const int T = (int)c.T, M = (int)c.M, H = qi.H;
-    float acc = 0.f;
-    for (int cc = sl * dsl; cc < min((sl + 1) * dsl, M); ++cc) {
-        float x = 0.f;
-        for (int t = 0; t < len; ++t) x += __expf(s_e[t] - mx) * inv * c.values[((long)b * T + t) * M + cc];
-        acc += x * pj.wp[(long)(H + cc) * pj.NP + o];
-    }
-    if (sl < 8)
-        for (int j = 128 * sl; j < 128 * sl + 128; ++j) acc += qi.m1[(long)b * qi.m1_ld + j] * pj.wp[(long)j * pj.NP + o];
-    return acc;
-}
+// PROJ (free-running decoder): the output projection [m1 | ctx] . Wp + bias also comes out of this launch, with no exchange of its own:
+//   ctx . Wp_c = sum_t a[t] (values[t] . Wp_c) = sum_t a[t] vp[t]   - the projected values vp [B, T, NP] are loop invariants like the keys,
+//   so once the row's energies are known slice s < 8 forms outputs 11 s .. 11 s + 10 from its own softmax weights (128 x 11 products);
+//   m1 . Wp_m for those 11 outputs rides on the query projection (same m1 registers, a by-owner packed copy wp_own of the kernel rows,
+//   mstts_lsa_proj_pack), reduced the same way while the query granules travel.
+constexpr int PJ_OWN = 11, PJ_OW = 12, PJ_TG = 42, PJ_VPRE = 4;      // outputs per owner slice (padded to 12), position groups, prefetched positions per thread
+struct LsaProj { const float* wp_own; const float* vp; const float* bias; int NP, NM; float* linear; float* stop; };
 template <bool SELFTEST, bool LKT = false, bool QIN = false, bool PROJ = false>
 __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
                                                               float* __restrict__ q_sum, const float* cum,
@@ -277,10 +264,9 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     int cs, b;
     row_slice_of_block(blockIdx.x, ncs, (int)c.B, &b, &cs);
     if (SELFTEST && cs == skip) return;
-    __shared__ float s_px[PROJ ? FS_DSL + PJ_PARTS * PJ_ITM : 1];               // PROJ: this slice's context columns, then its m1 units
-    __shared__ float s_pp[PROJ ? PJ_PARTS * PJ_NP_MAX : 1];
-    __shared__ float s_po[PROJ ? PJ_NP_MAX : 1];
-    __shared__ float s_pf[PROJ ? PJ_SL_MAX * PJ_OWN : 1];
+    __shared__ float s_pq[PROJ ? 32 * PJ_OW : 1];                               // PROJ: per-row-of-16-lanes partial sums of m1 . Wp_m (own outputs)
+    __shared__ float s_pm[PROJ ? PJ_OW : 1];                                    //       m1 . Wp_m of the own outputs
+    __shared__ float s_pv[PROJ ? (PJ_TG + 1) * PJ_OW : 1];                      //       per-position-group partial sums of sum_t a[t] vp[t]
     __shared__ __attribute__((aligned(16))) float s_qp[QIN ? 32 * 16 : 4];     // QIN: per-row-of-16-lanes partial sums of the 16 own units
     __shared__ float s_q[QIN ? A_ : 1];                                         // QIN: the row's query
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
@@ -331,20 +317,26 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     } else {
         qv = sum_parts<MSTTS_MAX_PARTS>(q, q_parts, q_pstride, (long)b * A_ + k);
     }
-    // PROJ: the rows of Wp this thread multiplies (output o = tid % NP, rows part + PJ_PARTS it of the slice's 128 m1 units and of its
-    // context columns) are requested here, with everything else: the tail of the kernel then has no memory round trip of its own
-    float wm[PROJ ? PJ_ITM : 1], wc[PROJ ? PJ_ITC : 1], pm = 0.f, pbias = 0.f, pacc = 0.f;
-    const int po = PROJ ? tid % pjx.NP : 0, ppart = PROJ ? tid / pjx.NP : 0;
+    // PROJ operands, requested with everything else (owners only): the packed kernel rows of this thread's 8 hidden units x 3 outputs,
+    // its share of the projected values, the bias
+    float pw[PROJ ? QJ : 1][3], pv[PROJ ? PJ_VPRE : 1], pbias = 0.f;
+    const int pol = PROJ ? tid % PJ_OW : 0, ptg = PROJ ? tid / PJ_OW : 0;
+    const bool pv_live = PROJ && cs < 8 && ptg < PJ_TG && pol < PJ_OWN && PJ_OWN * cs + pol < pjx.NP;
     if constexpr (PROJ) {
-        const int NP = pjx.NP, ncol = max(0, min(dsl, M - d0));
-        const bool act = ppart < PJ_PARTS;
+        const int a4 = tid & 3, ch = tid >> 2;
 #pragma unroll
-        for (int it = 0; it < PJ_ITM; ++it) {
-            const int r = ppart + PJ_PARTS * it;
-            wm[it] = (act && cs < 8 && r < 128) ? pjx.wp[(long)(128 * cs + r) * NP + po] : 0.f;
+        for (int jj = 0; jj < QJ; ++jj) {
+            const float* w3 = pjx.wp_own + ((long)((cs & 7) * QJ + jj) * 128 + ch) * PJ_OW + 3 * a4;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pw[jj][i] = (cs < 8) ? w3[i] : 0.f;
         }
-        if (cs < 8 && tid < 128) pm = qi.m1[(long)b * qi.m1_ld + 128 * cs + tid];
-        if (cs < 8 && tid < PJ_OWN && PJ_OWN * cs + tid <= pjx.NM && pjx.bias) pbias = pjx.bias[PJ_OWN * cs + tid];
+#pragma unroll
+        for (int i = 0; i < PJ_VPRE; ++i) {
+            const int t = ptg + PJ_TG * i;
+            pv[i] = (pv_live && t < T) ? pjx.vp[((long)b * T + t) * pjx.NP + PJ_OWN * cs + pol] : 0.f;
+        }
+        const int ob = PJ_OWN * cs + tid - (FS_THREADS - PJ_OW);
+        if (cs < 8 && tid >= FS_THREADS - PJ_OW && tid < FS_THREADS - PJ_OW + PJ_OWN && ob <= pjx.NM && pjx.bias) pbias = pjx.bias[ob];
     }
     const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
     const float* v = c.values + (long)b * T * M + col;
@@ -356,19 +348,8 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         // between len and T are real memory and get a zero alignment below)
         vv[i] = (vlive && t < T) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if constexpr (PROJ) {
-        const int NP = pjx.NP, ncol = max(0, min(dsl, M - d0));
-#pragma unroll
-        for (int it = 0; it < PJ_ITC; ++it) {
-            const int r = ppart + PJ_PARTS * it;
-            wc[it] = (ppart < PJ_PARTS && r < ncol) ? pjx.wp[(long)(qi.H + d0 + r) * NP + po] : 0.f;
-        }
-    }
     // ---- own energy slice
     if (tid < FS_TSL + KS_MAX - 1 + 2) s_cum[tid] = cwin;          // entries past the window are zero
-    if constexpr (PROJ) {
-        if (tid < PJ_PARTS * PJ_ITM) s_px[FS_DSL + tid] = pm;       // (zero past the 128 units, and for slices that own none)
-    }
     if constexpr (QIN) {
         // own 16 units of the query: 8 hidden units per thread, then the 16 chunks of each 16-lane row through DPP row shifts, the 32
         // rows of the workgroup through LDS
@@ -397,6 +378,26 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
             s_q[16 * cs + tid] = qa;
             __hip_atomic_store(gq + 16 * cs + tid, ((unsigned long long)epoch << 32) | __float_as_uint(qa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if constexpr (PROJ) {                                    // m1 . Wp_m for the own outputs, reduced like the query units
+            if (cs < 8) {
+                float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < QJ; ++jj) {
+                    const float x = reinterpret_cast<const float*>(qm)[jj];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) a3[i] += x * pw[jj][i];
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    a3[i] += dpp_mov<0x114, 0xf>(0.f, a3[i]);
+                    a3[i] += dpp_mov<0x118, 0xf>(0.f, a3[i]);
+                }
+                if ((tid & 15) >= 12) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) s_pq[(tid >> 4) * PJ_OW + 3 * (tid & 3) + i] = a3[i];
+                }
+            }
+        }
         if (tid < A_ && (tid >> 4) != cs) {                      // the other slices' units (the data is the flag)
             unsigned long long x = __hip_atomic_load(gq + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
@@ -415,6 +416,14 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         }
         __syncthreads();
         qv = s_q[k];
+        if constexpr (PROJ) {
+            if (cs < 8 && tid >= FS_THREADS - PJ_OW) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) a += s_pq[r * PJ_OW + tid - (FS_THREADS - PJ_OW)];
+                s_pm[tid - (FS_THREADS - PJ_OW)] = a;              // (read back by the same thread in the tail)
+            }
+        }
     }
     if (q_sum && cs == 0 && tg == 0) q_sum[(long)b * A_ + k] = qv;
     if constexpr (!QIN) __syncthreads();
@@ -438,10 +447,6 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         const float e = s_red[tid][0] + s_red[tid][1];
         s_e[t0 + tid] = e;
         __hip_atomic_store(g + t0 + tid, ((unsigned long long)epoch << 32) | __float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if constexpr (PROJ) {             // the m1 part of this thread's partial output, while the row's energies travel
-#pragma unroll
-        for (int it = 0; it < PJ_ITM; ++it) pacc += s_px[FS_DSL + ppart + PJ_PARTS * it] * wm[it];
     }
     // ---- gather the other slices of the row (the data is the flag)
     for (int t = tid; t < T; t += FS_THREADS) {
@@ -494,67 +499,36 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         }
     }
     if (vg < ng) *reinterpret_cast<float4*>(&s_part[(vg * nc4 + c4) * 4]) = acc;
+    if constexpr (PROJ) {
+        if (cs < 8 && ptg < PJ_TG) {
+            float pa = 0.f;
+#pragma unroll
+            for (int i = 0; i < PJ_VPRE; ++i) {
+                const int t = ptg + PJ_TG * i;
+                if (t < len) pa += __expf(s_e[t] - mx) * inv * pv[i];
+            }
+            if (pv_live)
+                for (int t = ptg + PJ_TG * PJ_VPRE; t < len; t += PJ_TG)
+                    pa += __expf(s_e[t] - mx) * inv * pjx.vp[((long)b * T + t) * pjx.NP + PJ_OWN * cs + pol];
+            s_pv[ptg * PJ_OW + pol] = pa;
+        }
+    }
     __syncthreads();
+    if constexpr (PROJ) {
+        const int ol = tid - (FS_THREADS - PJ_OW), oo = PJ_OWN * cs + ol;
+        if (cs < 8 && ol >= 0 && ol < PJ_OWN && oo < pjx.NP) {
+            float v2 = pbias + s_pm[ol];
+            for (int gq = 0; gq < PJ_TG; ++gq) v2 += s_pv[gq * PJ_OW + ol];
+            if (oo < pjx.NM) pjx.linear[(long)b * pjx.NM + oo] = v2;
+            else if (oo == pjx.NM) pjx.stop[b] = v2;
+        }
+    }
     if (tid < dsl && d0 + tid < M) {
         float r = 0.f;
         for (int gq = 0; gq < ng; ++gq) r += s_part[gq * dsl + tid];
         ctx[(long)b * ctx_ld + d0 + tid] = r;
         if (ctx2) ctx2[(long)b * ctx2_ld + d0 + tid] = r;
         if (ctx_p.base) packed_store(ctx_p, b, d0 + tid, r);
-        if constexpr (PROJ) pm = r;
-    }
-    if constexpr (PROJ) {
-        const int NP = pjx.NP;
-        if (tid < FS_DSL) s_px[tid] = (tid < dsl && d0 + tid < M) ? pm : 0.f;
-        __syncthreads();
-        if (ppart < PJ_PARTS) {
-#pragma unroll
-            for (int it = 0; it < PJ_ITC; ++it) pacc += s_px[ppart + PJ_PARTS * it] * wc[it];
-            s_pp[ppart * PJ_NP_MAX + po] = pacc;
-        }
-        __syncthreads();
-        gu64* gp = (gu64*)(pjx.gp + ((long)b * PJ_SL_MAX + cs) * PJ_NP_MAX);
-        if (tid < NP) {
-            float v2 = 0.f;
-#pragma unroll
-            for (int q2 = 0; q2 < PJ_PARTS; ++q2) v2 += s_pp[q2 * PJ_NP_MAX + tid];
-            s_po[tid] = v2;
-            __hip_atomic_store(gp + tid, ((unsigned long long)epoch << 32) | __float_as_uint(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (cs < 8) {                                                // owner of outputs PJ_OWN cs .. PJ_OWN cs + PJ_OWN - 1
-            __syncthreads();
-            if (tid < ncs * PJ_OWN) {
-                const int sl = tid / PJ_OWN, oo = PJ_OWN * cs + tid % PJ_OWN;
-                float v2 = 0.f;
-                if (oo < NP) {
-                    if (sl == cs) v2 = s_po[oo];
-                    else {
-                        const gu64* gs = (const gu64*)(pjx.gp + ((long)b * PJ_SL_MAX + sl) * PJ_NP_MAX) + oo;
-                        unsigned long long x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        unsigned spins = 0;
-                        while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
-                            __builtin_amdgcn_s_sleep(1);
-                            x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ++spins;
-                        }
-                        if ((unsigned)(x >> 32) == epoch) v2 = __uint_as_float((unsigned)x);
-                        else {
-                            v2 = lsa_proj_partial_serial(c, qi, pjx, b, sl, oo, dsl, s_e, mx, inv, len);
-                            atomicAdd(gran + (long)c.B * T, 1ull);
-                        }
-                    }
-                }
-                s_pf[sl * PJ_OWN + tid % PJ_OWN] = v2;
-            }
-            __syncthreads();
-            if (tid < PJ_OWN && PJ_OWN * cs + tid < NP) {
-                const int oo = PJ_OWN * cs + tid;
-                float v2 = pbias;
-                for (int sl = 0; sl < ncs; ++sl) v2 += s_pf[sl * PJ_OWN + tid];
-                if (oo < pjx.NM) pjx.linear[(long)b * pjx.NM + oo] = v2;
-                else if (oo == pjx.NM) pjx.stop[b] = v2;
-            }
-        }
     }
 }
 
@@ -1165,10 +1139,10 @@ static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t
     const bool lkt = c->loc_kt && aligned16(c->loc_kt);
     if (qin && proj) {
         qi = *qin; pz = *proj;
-        MSTTS_REQUIRE(cs >= 8 && cs <= PJ_SL_MAX && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: needs 8..%d slices, H == %d and the by-unit filter", PJ_SL_MAX, 128 * QJ);
+        MSTTS_REQUIRE(cs >= 8 && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: needs >= 8 slices, H == %d and the by-unit filter", 128 * QJ);
         MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_qp: m1 / wq must be 16-byte aligned");
-        MSTTS_REQUIRE(pz.wp && pz.linear && pz.stop && pz.gp && pz.NP >= 1 && pz.NP <= PJ_NP_MAX && pz.NP <= 8 * PJ_OWN && pz.NM < pz.NP &&
-                      PJ_PARTS * pz.NP <= FS_THREADS && dsl <= FS_DSL, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: projection width must be <= %d columns", 8 * PJ_OWN);
+        MSTTS_REQUIRE(pz.wp_own && pz.vp && pz.linear && pz.stop && pz.NP >= 2 && pz.NP <= 8 * PJ_OWN && pz.NM < pz.NP, MSTTS_ERR_SHAPE,
+                      "lsa_step_fwd_qp: projection width must be 2..%d columns", 8 * PJ_OWN);
         if (skip >= 0)
             hipLaunchKernelGGL((lsa_step_kernel<true, true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
                                align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz);
@@ -1222,26 +1196,40 @@ extern "C" int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, i
     return lsa_step_fwd_launch(c, nullptr, 0, 0, q_sum, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch,
                                skip_slice >= 0 ? skip_slice : -1, s, &qi);
 }
-/* ... and with the output projection [m1 | ctx] . wp + bias inside the launch too (free-running decoder: the frame is needed by the next
- * step's prenet, nothing else waits for it): wp [H + M, NP] row-major (NP <= 88, columns 0..NM-1 = mel frame, column NM = stop logit),
- * bias [NP] or NULL; linear [B, NM], stop [B].  granules = mstts_lsa_step_qp_ws_bytes(B, T) bytes, zeroed before the first step. */
+/* ... and with the output projection [m1 | ctx] . Wp + bias out of the same launch (free-running decoder): no further exchange -
+ *   vp [B, T, NP] = values . Wp[H:, :] (the projected values: once per utterance, any GEMM), wp_own = mstts_lsa_proj_pack(Wp[:H, :]);
+ *   bias [NM + 1] or NULL; linear [B, NM] <- columns 0..NM-1, stop [B] <- column NM.  NP <= 88.
+ * Same availability and granules as mstts_lsa_step_fwd_q. */
 extern "C" int32_t mstts_lsa_step_qp_supported(int64_t T, int64_t M, int64_t H, int64_t NP) {
-    int cs, tsl, dsl;
-    if (T < 1 || M < 4) return 0;
-    lsa_step_geometry(T, M, &cs, &tsl, &dsl);
-    return cs >= 8 && cs <= PJ_SL_MAX && dsl <= FS_DSL && H == 128 * QJ && NP >= 2 && NP <= 8 * PJ_OWN && PJ_PARTS * NP <= FS_THREADS;
+    return mstts_lsa_step_q_supported(T, M, H) && NP >= 2 && NP <= 8 * PJ_OWN;
 }
-extern "C" int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T) { return (B * T + 1 + B * A_ + B * PJ_SL_MAX * PJ_NP_MAX) * 8; }
-extern "C" int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp,
-                                     const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum, float* align,
-                                     float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld, const mstts_cell_packed_dst* ctx_p,
-                                     void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s) {
+extern "C" int64_t mstts_lsa_proj_pack_floats(void) { return 8L * QJ * 128 * PJ_OW; }
+namespace mstts {
+__global__ void lsa_proj_pack_kernel(const float* __restrict__ wp, long ld, int NP, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 8 * QJ * 128 * PJ_OW) return;
+    const int i = idx % PJ_OW, ch = (idx / PJ_OW) % 128, jj = (idx / (PJ_OW * 128)) % QJ, cs = idx / (PJ_OW * 128 * QJ);
+    const int o = PJ_OWN * cs + i;
+    out[idx] = (i < PJ_OWN && o < NP) ? wp[(long)(QJ * ch + jj) * ld + o] : 0.f;
+}
+}  // namespace mstts
+/* wp [1024, >= NP] (row stride ld) -> wp_own [8 owners][8][128][12]: owner s holds columns 11 s .. 11 s + 10 in the order its lanes read them */
+extern "C" int mstts_lsa_proj_pack(const float* wp, int64_t ld, int64_t H, int64_t NP, float* wp_own, mstts_stream_t s) {
+    MSTTS_REQUIRE(wp && wp_own && H == 128 * QJ && NP >= 1 && NP <= 8 * PJ_OWN && ld >= NP, MSTTS_ERR_SHAPE, "lsa_proj_pack: needs H == %d and NP <= %d", 128 * QJ, 8 * PJ_OWN);
+    const int n = 8 * QJ * 128 * PJ_OW;
+    hipLaunchKernelGGL(mstts::lsa_proj_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(s), wp, (long)ld, (int)NP, wp_own);
+    MSTTS_CHECK_LAUNCH("lsa_proj_pack");
+    return MSTTS_OK;
+}
+extern "C" int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp_own,
+                                     const float* vp, const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum,
+                                     float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
+                                     const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s) {
     MSTTS_REQUIRE(c && granules, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: null pointer");
     LsaQIn qi;
     qi.m1 = m1; qi.m1_ld = (long)m1_ld; qi.wq = wq; qi.H = (int)H; qi.bf16 = 0;
     LsaProj pj;
-    pj.wp = wp; pj.bias = bias; pj.NP = (int)NP; pj.NM = (int)NM; pj.linear = linear; pj.stop = stop;
-    pj.gp = (unsigned long long*)granules + (c->B * c->T + 1 + c->B * A_);
+    pj.wp_own = wp_own; pj.vp = vp; pj.bias = bias; pj.NP = (int)NP; pj.NM = (int)NM; pj.linear = linear; pj.stop = stop;
     return lsa_step_fwd_launch(c, nullptr, 0, 0, nullptr, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch,
                                skip_slice >= 0 ? skip_slice : -1, s, &qi, &pj);
 }

@@ -185,6 +185,13 @@ class InferEngine:
                 call("mstts_pack_cell_fwd", ptr(k1, o1), 4 * H, ptr(w1p), 2 * H, H)
                 act_p = self._f(2 * int(L_.mstts_cell_act_floats(B, Pn + M + H) + L_.mstts_cell_act_floats(B, 2 * H)))
                 q.w0sp, q.w1p, q.act_p = ptr(w0sp), ptr(w1p), ptr(act_p)
+                if L_.mstts_lsa_step_qp_supported(T, M, H, npad):
+                    # output projection inside the attention launch: the projected values (loop invariant, like the keys) and the
+                    # m1 rows of the kernel packed by owner slice
+                    wp_own, vp = self._f(int(L_.mstts_lsa_proj_pack_floats())), self._f(B * T, npad)
+                    call("mstts_lsa_proj_pack", ptr(wp_pad), npad, H, npad, ptr(wp_own))
+                    gemm(values, wp_pad, vp, B * T, npad, M, M, npad, npad, b_off=H * npad)
+                    q.wp_own, q.vp = ptr(wp_own), ptr(vp)
         q.c0, q.c1, q.cum = ptr(self._f(2, B, H)), ptr(self._f(2, B, H)), ptr(self._f(2, B, T))
         q.pre_ws = ptr(self._f(int(lib.load().mstts_decoder_infer_ws_floats(B, H, Pn, T, A, NM))))
         linear, stop, align = self._f(Smax, B, NM), self._f(Smax, B), self._f(Smax, B, T)

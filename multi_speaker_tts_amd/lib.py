@@ -97,7 +97,7 @@ class DecoderInfer(C.Structure):
                 ("pw0", vp), ("pb0", vp), ("pw1", vp), ("pb1", vp), ("pm0", vp), ("pm1", vp), ("prenet_keep", f32),
                 ("wx0", vp), ("b0", vp), ("w0f", vp), ("w1", vp), ("b1", vp), ("wq", vp), ("wproj", vp), ("bproj", vp),
                 ("zoneout", f32), ("in0", vp), ("in1", vp), ("pj", vp), ("c0", vp), ("c1", vp), ("cum", vp),
-                ("pre_ws", vp), ("linear", vp), ("stop", vp), ("align_hist", vp), ("w0s", vp), ("wp_pad", vp), ("w0sp", vp), ("w1p", vp), ("act_p", vp)]
+                ("pre_ws", vp), ("linear", vp), ("stop", vp), ("align_hist", vp), ("w0s", vp), ("wp_pad", vp), ("w0sp", vp), ("w1p", vp), ("act_p", vp), ("wp_own", vp), ("vp", vp)]
 
 
 P = C.POINTER
@@ -144,8 +144,9 @@ SIGNATURES = {
     "mstts_lsa_step_q_supported": (i32, [i64, i64, i64]),
     "mstts_lsa_step_q_ws_bytes": (i64, [i64, i64]),
     "mstts_lsa_step_qp_supported": (i32, [i64, i64, i64, i64]),
-    "mstts_lsa_step_qp_ws_bytes": (i64, [i64, i64]),
-    "mstts_lsa_step_fwd_qp": (i32, [P(LsaConst), vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
+    "mstts_lsa_proj_pack_floats": (i64, []),
+    "mstts_lsa_proj_pack": (i32, [vp, i64, i64, i64, vp, vp]),
+    "mstts_lsa_step_fwd_qp": (i32, [P(LsaConst), vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
     "mstts_lsa_step_fwd_q": (i32, [P(LsaConst), vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
     "mstts_lsa_step_fwd_selftest": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, C.c_uint32, i32, vp]),
     "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),

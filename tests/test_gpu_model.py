@@ -231,12 +231,16 @@ def test_lsa_step_fwd_q(dev, B, T, bf16):
     assert rel_err(t2n(al3)[:, own], t2n(al)[:, own]) < 1e-5 and rel_err(t2n(cx3)[:, ownc], t2n(cx)[:, ownc]) < 1e-5
     if bf16:
         return
-    # mstts_lsa_step_fwd_qp: the output projection [m1 | ctx] . Wp + bias inside the same launch (free-running decoder), partial outputs
-    # exchanged through a third granule array; against the fp64 product over the context the plain step produced
+    # mstts_lsa_step_fwd_qp: the output projection [m1 | ctx] . Wp + bias out of the same launch (free-running decoder) - the context part
+    # from the projected values vp = values . Wp[H:, :], the m1 part on the query projection through the by-owner packed kernel rows;
+    # against the fp64 product over the context the plain step produced
     NM, NP = 80, 84
     assert L.mstts_lsa_step_qp_supported(T, M, H, NP) == 1 and L.mstts_lsa_step_qp_supported(T, M, H, 92) == 0
     wp, bias = f32(g.normal(0, 0.05, (WP, NP))), f32(g.normal(0, 0.1, (NM + 1,)))
-    gran_p = torch.zeros(int(L.mstts_lsa_step_qp_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    wp_own = torch.zeros(int(L.mstts_lsa_proj_pack_floats()), device=dev)
+    lib.call("mstts_lsa_proj_pack", lib.ptr(wp), NP, H, NP, lib.ptr(wp_own))
+    vp = (dv.double().reshape(B * T, M) @ wp[H:].double()).float().contiguous()
+    gran_p = torch.zeros(int(L.mstts_lsa_step_q_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
     for step in range(1, 4):
         pj = f32(g.normal(0, 1, (B, WP)))
         cum = f32(np.abs(g.normal(0, 0.5, (B, T))) * mask)
@@ -248,17 +252,18 @@ def test_lsa_step_fwd_q(dev, B, T, bf16):
         ref[:, :NM + 1] += bias.double()
         al2, cn2, cx2 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
         lin, stop = torch.full((B, NM), 7.0, device=dev), torch.full((B,), 7.0, device=dev)
-        lib.call("mstts_lsa_step_fwd_qp", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, lib.ptr(wp), lib.ptr(bias), NP, NM, lib.ptr(lin), lib.ptr(stop),
-                 lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2), lib.ptr(cx2), M, lib.ptr(pj[:, H:]), WP, None, lib.ptr(gran_p), step, -1)
+        lib.call("mstts_lsa_step_fwd_qp", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, lib.ptr(wp_own), lib.ptr(vp), lib.ptr(bias), NP, NM,
+                 lib.ptr(lin), lib.ptr(stop), lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2), lib.ptr(cx2), M, lib.ptr(pj[:, H:]), WP, None,
+                 lib.ptr(gran_p), step, -1)
         torch.cuda.synchronize()
         assert int(gran_p[B * T]) == 0
         assert rel_err(t2n(al2), t2n(al)) < 1e-5 and rel_err(t2n(cn2), t2n(cn)) < 1e-5 and rel_err(t2n(cx2), t2n(cx)) < 1e-5
         assert rel_err(t2n(pj[:, H:]), t2n(cx)) < 1e-5                                  # second context destination (the projection input rows)
         assert rel_err(t2n(lin), t2n(ref[:, :NM])) < 1e-5 and rel_err(t2n(stop), t2n(ref[:, NM])) < 1e-5
-    # self-test: slice 3 missing -> its partial outputs are recomputed by the owners, its own outputs 33..43 stay unwritten
+    # self-test form: slice 3 missing -> the other owners still produce their outputs (from recomputed energies), outputs 33..43 stay unwritten
     lin3, stop3 = torch.full((B, NM), 7.0, device=dev), torch.full((B,), 7.0, device=dev)
-    lib.call("mstts_lsa_step_fwd_qp", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, lib.ptr(wp), lib.ptr(bias), NP, NM, lib.ptr(lin3), lib.ptr(stop3),
-             lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2), lib.ptr(cx2), M, None, 0, None, lib.ptr(gran_p), 9, 3)
+    lib.call("mstts_lsa_step_fwd_qp", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, lib.ptr(wp_own), lib.ptr(vp), lib.ptr(bias), NP, NM,
+             lib.ptr(lin3), lib.ptr(stop3), lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2), lib.ptr(cx2), M, None, 0, None, lib.ptr(gran_p), 9, 3)
     torch.cuda.synchronize()
     assert int(gran_p[B * T]) > 0
     keep = np.ones(NM, bool); keep[33:44] = False

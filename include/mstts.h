@@ -266,14 +266,28 @@ int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, int64_t m1_l
  * ctx . Wp[H:, :] = sum_t a[t] vp[t] with vp [B, T, NP] = values . Wp[H:, :] (loop invariant like the keys: one GEMM per utterance), formed
  * by slice s < 8 for outputs 11 s .. 11 s + 10 from its own softmax weights; m1 . Wp[:H, :] for those outputs rides on the query
  * projection through wp_own = mstts_lsa_proj_pack(Wp[:H, :]) (mstts_lsa_proj_pack_floats() floats).  bias [NM + 1] or NULL; columns
- * 0..NM-1 -> linear [B, NM], column NM -> stop [B]; NP <= 88.  Availability, granules and skip_slice as mstts_lsa_step_fwd_q. */
+ * 0..NM-1 -> linear [B, NM], column NM -> stop [B]; NP <= 88.  Availability and skip_slice as mstts_lsa_step_fwd_q; granules = mstts_lsa_step_qp_ws_bytes(B, T) bytes, zeroed before the first step. */
 int32_t mstts_lsa_step_qp_supported(int64_t T, int64_t M, int64_t H, int64_t NP);
+int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T);
 int64_t mstts_lsa_proj_pack_floats(void);
 int mstts_lsa_proj_pack(const float* wp, int64_t ld, int64_t H, int64_t NP, float* wp_own, mstts_stream_t s);
+/* optional last stage of mstts_lsa_step_fwd_qp: the prenet of the NEXT decoder step (two dense layers, relu, dropout always on -
+ * Modules.py:239-255) applied to the frame this step produces, in the same launch.  The owner slices publish their frame values as
+ * granules AHEAD of their context phase (the frame does not depend on the context), request the prenet's kernel rows at the same point,
+ * and after the context phase each gathers the row's frame, computes the whole first layer and 32 of the 256 columns of the second.
+ * w0 [n_mel, P], w1 [P, P] row-major, P == 256, n_mel <= 80 (mstts_lsa_step_prenet_supported); m0 / m1 [B, P] = the NEXT step's masks;
+ * out rows [B, >= P] (stride out_ld) receive the result, out_p (base NULL = none) a copy in a fused cell's packed block. */
+typedef struct {
+    const float* w0; const float* b0; const float* w1; const float* b1;
+    const uint8_t* m0; const uint8_t* m1; float inv_keep; int32_t P;
+    float* out; int64_t out_ld; mstts_cell_packed_dst out_p;
+} mstts_lsa_prenet;
+int32_t mstts_lsa_step_prenet_supported(int64_t P, int64_t n_mel);
 int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp_own,
                           const float* vp, const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum,
                           float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
-                          const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
+                          const mstts_cell_packed_dst* ctx_p, const mstts_lsa_prenet* pre /* or NULL */, void* granules, uint32_t epoch,
+                          int32_t skip_slice, mstts_stream_t s);
 /* backward of one step, two launches:
  *  dalign : G[t] = G_next[t] + sum_j h_next[t+pad-j][j] ; d_a[b,t] = G[b,t] + values[b,t,:] . d_ctx[b,:]
  *  denergy: d_e = a*(d_a - sum a d_a); g = d_e*w*(1-u^2); dq[b,:] += sum_t g (atomic); h[t,j] = sum_k g[t,k] loc_k[j,k]

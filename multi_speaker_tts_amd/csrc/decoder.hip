@@ -6,6 +6,7 @@
 //                                   [Modules.py:76-119,323-472 + TF AttentionWrapper]
 //   mstts_decoder_infer_steps     - the free-running loop            [Modules.py:212-237]
 #include "common.h"
+#include "prenet_body.h"
 
 using namespace mstts;
 
@@ -572,145 +573,14 @@ extern "C" int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* bd, m
 // free-running decoder steps
 // ---------------------------------------------------------------------------------------------
 namespace mstts {
-// Two-layer prenet of one decoder step for B <= 32 rows in ONE launch (Modules.py:239-255; dropout always on):
-//   h1 = drop0(relu(frame . W0 + b0)),  out[:, c0:c0+16] = drop1(relu(h1 . W1[:, c0:c0+16] + b1)).
-// grid = P/16 workgroups of 4 waves; every workgroup recomputes the small first layer (wave w owns column tiles w, w+4, ..)
-// and owns one 16-column tile of the second (its reduction split over the 4 waves).  fp32 MFMA 16x16x4, the kernel
-// operands go global -> registers in one round trip issued before anything else.
-constexpr int PN_MAXB = 32, PN_COLS = 16, PN_MAXNM4 = 20, PN_MAXTPW = 4, PN_MAXK1 = 16;
-typedef float pn_f32x4 __attribute__((ext_vector_type(4)));
+// Two-layer prenet of one decoder step for B <= 32 rows in ONE launch (prenet_body.h), the frame read from memory
 __global__ __launch_bounds__(256) void prenet_step_kernel(const float* __restrict__ frame, int NM, const float* __restrict__ w0,
                                                           const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, float inv_keep,
                                                           int B, int P, float* __restrict__ out, long out_ld, PackedDst out_p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ __attribute__((aligned(16))) uint8_t s_m0[PN_MAXB * 64 * PN_MAXTPW];       // first dropout mask, rows >= B zero
-    const int ldx = NM + 1, ldh = P + 1;
-    float* s_x = sm;                               // [32][NM + 1]
-    float* s_h = s_x + PN_MAXB * ldx;              // [32][P + 1]
-    float* s_r = s_h + PN_MAXB * ldh;              // [4][32][17]
-    const int c0 = blockIdx.x * PN_COLS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, kq = lane >> 4;
-    const int nit0 = NM / 4, tpw = P / 64, nit1 = P / 16;          // k-steps of layer 0; column tiles per wave; k-steps per wave of layer 1
-    const bool two = B > 16;
-    // ---- loads first
-    float xr[(PN_MAXB * 4 * PN_MAXNM4 + 255) / 256];
-#pragma unroll
-    for (int i = 0; i < (PN_MAXB * 4 * PN_MAXNM4 + 255) / 256; ++i) {
-        const int e = tid + 256 * i;
-        xr[i] = (e < B * NM) ? frame[e] : 0.f;
-    }
-    // layer-0 kernel: lane j of wave w holds columns (16 w + j) tpw + t of its tpw column tiles t, so each k row is one 16-byte load
-    // (tpw == 4) instead of four words 64 bytes apart
-    float w0r[PN_MAXTPW][PN_MAXNM4];
-    const int colb = (16 * wave + j) * tpw;
-    if (tpw == 4) {
-#pragma unroll
-        for (int it = 0; it < PN_MAXNM4; ++it) {
-            const float4 x = (it < nit0) ? *reinterpret_cast<const float4*>(w0 + (long)(4 * it + kq) * P + colb) : make_float4(0.f, 0.f, 0.f, 0.f);
-            w0r[0][it] = x.x; w0r[1][it] = x.y; w0r[2][it] = x.z; w0r[3][it] = x.w;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < PN_MAXTPW; ++t)
-#pragma unroll
-            for (int it = 0; it < PN_MAXNM4; ++it)
-                w0r[t][it] = (t < tpw && it < nit0) ? w0[(long)(4 * it + kq) * P + colb + t] : 0.f;
-    }
-    float w1r[PN_MAXK1];
-#pragma unroll
-    for (int it = 0; it < PN_MAXK1; ++it)
-        w1r[it] = (it < nit1 && c0 + j < P) ? w1[(long)(wave * (P / 4) + 4 * it + kq) * P + c0 + j] : 0.f;
-    // (the dropout masks and biases of both layers too: they do not depend on anything computed here, and fetched where they are
-    // used each was a memory round trip of its own on the step's critical path)
-    // the first mask goes to LDS through two 16-byte loads per thread (fetched byte by byte where it is used - 32 loads of one byte per
-    // lane - it cost 4.6 us of the kernel's 13.8)
-    float b0r[PN_MAXTPW];
-#pragma unroll
-    for (int t = 0; t < PN_MAXTPW; ++t) b0r[t] = (t < tpw) ? b0[colb + t] : 0.f;
-    uint4 m0q[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = 16 * (tid + 256 * i);
-        m0q[i] = (e < B * P) ? *reinterpret_cast<const uint4*>(m0 + e) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    float b1r[2];
-    float m1r[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + 256 * i, b = e / PN_COLS, cc = e % PN_COLS;
-        const bool live = b < B && c0 + cc < P;
-        b1r[i] = live ? b1[c0 + cc] : 0.f;
-        m1r[i] = live ? (float)m1[(long)b * P + c0 + cc] : 0.f;
-    }
-    {
-        const float inv_nm = 1.f / (float)NM;
-#pragma unroll
-        for (int i = 0; i < (PN_MAXB * 4 * PN_MAXNM4 + 255) / 256; ++i) {
-            const int e = tid + 256 * i;
-            const int row = (int)(((float)e + 0.5f) * inv_nm);               // e / NM without the integer division (e < 2560: exact)
-            if (e < PN_MAXB * NM) s_x[row * ldx + e - row * NM] = xr[i];     // rows >= B are zero
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) reinterpret_cast<uint4*>(s_m0)[tid + 256 * i] = m0q[i];
-    }
-    __syncthreads();
-    // ---- layer 0
-    float a0[PN_MAXNM4], a1[PN_MAXNM4];
-#pragma unroll
-    for (int it = 0; it < PN_MAXNM4; ++it) {
-        a0[it] = (it < nit0) ? s_x[j * ldx + 4 * it + kq] : 0.f;
-        a1[it] = (it < nit0) ? s_x[(16 + j) * ldx + 4 * it + kq] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < PN_MAXTPW; ++t) {
-        if (t < tpw) {
-            pn_f32x4 acc0 = (pn_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-            for (int it = 0; it < PN_MAXNM4; ++it) {
-                if (it < nit0) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[it], w0r[t][it], acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[it], w0r[t][it], acc1, 0, 0, 0);
-                }
-            }
-            const int col = colb + t;
-            const float bj = b0r[t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = kq * 4 + r;
-                s_h[row * ldh + col] = s_m0[row * P + col] ? fmaxf(acc0[r] + bj, 0.f) * inv_keep : 0.f;
-                s_h[(16 + row) * ldh + col] = s_m0[(16 + row) * P + col] ? fmaxf(acc1[r] + bj, 0.f) * inv_keep : 0.f;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- layer 1: this wave's quarter of the reduction
-    {
-        pn_f32x4 acc0 = (pn_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        const float* ha = s_h + j * ldh + wave * (P / 4) + kq;
-#pragma unroll
-        for (int it = 0; it < PN_MAXK1; ++it) {
-            if (it < nit1) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[4 * it], w1r[it], acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[16 * ldh + 4 * it], w1r[it], acc1, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s_r[(wave * 32 + kq * 4 + r) * 17 + j] = acc0[r];
-            s_r[(wave * 32 + 16 + kq * 4 + r) * 17 + j] = acc1[r];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + 256 * i, b = e / PN_COLS, cc = e % PN_COLS;
-        if (b >= B || c0 + cc >= P) continue;
-        const float v = s_r[b * 17 + cc] + s_r[(32 + b) * 17 + cc] + s_r[(64 + b) * 17 + cc] + s_r[(96 + b) * 17 + cc] + b1r[i];
-        const float y = fmaxf(v, 0.f) * (fminf(m1r[i], 1.f) * inv_keep);
-        out[(long)b * out_ld + c0 + cc] = y;
-        if (out_p.base) packed_store(out_p, b, c0 + cc, y);          // the fused cell-0 step reads its input row from the packed block
-    }
+    PnFramePlain src{frame};
+    prenet_body(src, (int)blockIdx.x * PN_COLS, NM, w0, b0, w1, b1, m0, m1, inv_keep, B, P, out, out_ld, out_p, sm);
 }
 // [parts][B][NP] projection partial slabs + bias -> linear[B][NM], stop[B] (column NM)
 __global__ void proj_finish_kernel(const float* __restrict__ P_, int parts, long pstride, const float* __restrict__ bias, int B, int NP, int NM,
@@ -741,7 +611,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
               spp = mstts_skinny_fwd_splits(NP, WP);
     float* w = d->pre_ws;
     float* gates = w;       w += (long)MSTTS_MAX_PARTS * 4 * BH;
-    const long gran_n = mstts_lsa_step_q_ws_bytes(B, T) / 4;        // energy granules + counter, then the query granules
+    const long gran_n = mstts_lsa_step_qp_ws_bytes(B, T) / 4;       // energy granules + counter, then the query and the frame granules
     float* gran = w;        w += gran_n;
     float* q = w;           w += (long)MSTTS_MAX_PARTS * B * A;
     float* pp = w;          w += (long)MSTTS_MAX_PARTS * B * NP;
@@ -758,6 +628,8 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
     // query projection inside the attention launch, and the output projection too where the slice count allows
     const bool fused_q = mstts_lsa_step_q_supported(T, M, H) && d->lsa.loc_kt && A == 128 && WP % 4 == 0;
     const bool fused_qp = fused_q && d->wp_own && d->vp && mstts_lsa_step_qp_supported(T, M, H, NP);
+    // ... and the next step's prenet too (the frame leaves its owners before their context phase): 3 launches per frame
+    const bool fused_pre = fused_qp && mstts_lsa_step_prenet_supported(P, NM);
     const size_t pn_lds = sizeof(float) * (size_t)(PN_MAXB * (NM + 1) + PN_MAXB * (P + 1) + 4 * 32 * 17);
     // fused cell steps (cell.hip): packed kernels given and shapes covered -> 7 launches per frame instead of 9
     const bool fused = d->w0sp && d->w1p && d->act_p && mstts_cell_fwd_supported(H, W0) && mstts_cell_fwd_supported(H, W1);
@@ -772,9 +644,12 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
         float* P1c = fused ? d->act_p + 2 * p0n + par * p1n : nullptr; float* P1n = fused ? d->act_p + 2 * p0n + nx * p1n : nullptr;
         PackedDst pre_p;
         pre_p.base = P0c; pre_p.nit = (int)(W0 / 64); pre_p.col0 = 0; pre_p.bf = 0;
-        hipLaunchKernelGGL(prenet_step_kernel, dim3((unsigned)((P + PN_COLS - 1) / PN_COLS)), dim3(256), pn_lds, (hipStream_t)s, frame, (int)NM,
-                           d->pw0, d->pb0, d->pw1, d->pb1, d->pm0 + st * B * P, d->pm1 + st * B * P, 1.f / d->prenet_keep, (int)B, (int)P, in0c, W0, pre_p);
-        MSTTS_CHECK_LAUNCH("prenet_step");
+        const bool pre_here = fused && fused_pre;        // the previous step's attention launch has left this step's prenet in in0c / P0c
+        if (!pre_here || st == 0) {
+            hipLaunchKernelGGL(prenet_step_kernel, dim3((unsigned)((P + PN_COLS - 1) / PN_COLS)), dim3(256), pn_lds, (hipStream_t)s, frame, (int)NM,
+                               d->pw0, d->pb0, d->pw1, d->pb1, d->pm0 + st * B * P, d->pm1 + st * B * P, 1.f / d->prenet_keep, (int)B, (int)P, in0c, W0, pre_p);
+            MSTTS_CHECK_LAUNCH("prenet_step");
+        }
         mstts_lstm_point_fwd_desc p;
         int parts = 1;
         if (fused) {
@@ -784,9 +659,17 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
                          d->pj, WP, d->c1 + nx * BH, in1n + H, W1, nullptr, nullptr, B, H, nullptr, 0, 0, P1n, W1, H, s));
             mstts_cell_packed_dst ctx_p = {P0n, W0, P, 0};
             if (fused_qp) {
+                mstts_lsa_prenet pn;
+                memset(&pn, 0, sizeof(pn));
+                const bool pre_next = fused_pre && st + 1 < d->Smax;           // (the masks hold Smax steps)
+                if (pre_next) {
+                    pn.w0 = d->pw0; pn.b0 = d->pb0; pn.w1 = d->pw1; pn.b1 = d->pb1; pn.m0 = d->pm0 + (st + 1) * B * P; pn.m1 = d->pm1 + (st + 1) * B * P;
+                    pn.inv_keep = 1.f / d->prenet_keep; pn.P = (int32_t)P; pn.out = in0n; pn.out_ld = W0;
+                    pn.out_p.base = P0n; pn.out_p.K = W0; pn.out_p.col0 = 0; pn.out_p.bf16 = 0;
+                }
                 RC(mstts_lsa_step_fwd_qp(&d->lsa, d->pj, WP, d->wq, H, d->wp_own, d->vp, d->bproj, NP, NM, d->linear + st * B * NM, d->stop + st * B,
-                                         d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT, in0n + P, W0, d->pj + H, WP, &ctx_p, gran,
-                                         (uint32_t)(st + 1), -1, s));
+                                         d->cum + par * BT, d->align_hist + st * BT, d->cum + nx * BT, in0n + P, W0, d->pj + H, WP, &ctx_p,
+                                         pre_next ? &pn : nullptr, gran, (uint32_t)(st + 1), -1, s));
                 continue;
             }
             if (fused_q) {
@@ -829,7 +712,7 @@ static int infer_steps_fast(const mstts_decoder_infer_desc* d, int64_t step0, in
 extern "C" int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel) {
     const long np = (n_mel + 1 + 3) / 4 * 4;
     const long slow = 2 * B * P + 8 * B * H + (2 * B * T + 2) + B * A + B * n_mel;
-    const long fast = (long)MSTTS_MAX_PARTS * (4 * B * H + B * A + B * np) + mstts_lsa_step_q_ws_bytes(B, T) / 4 + B * n_mel;
+    const long fast = (long)MSTTS_MAX_PARTS * (4 * B * H + B * A + B * np) + mstts_lsa_step_qp_ws_bytes(B, T) / 4 + B * n_mel;
     return slow > fast ? slow : fast;
 }
 

@@ -254,19 +254,37 @@ struct LsaQIn { const float* m1; long m1_ld; const float* wq; int H, bf16; };   
 //   mstts_lsa_proj_pack), reduced the same way while the query granules travel.
 constexpr int PJ_OWN = 11, PJ_OW = 12, PJ_TG = 42, PJ_VPRE = 4;      // outputs per owner slice (padded to 12), position groups, prefetched positions per thread
 struct LsaProj { const float* wp_own; const float* vp; const float* bias; int NP, NM; float* linear; float* stop; };
-template <bool SELFTEST, bool LKT = false, bool QIN = false, bool PROJ = false>
+// PRE (with PROJ): the prenet of the NEXT decoder step (Modules.py:239-255, dropout always on) on the frame this step just produced, in
+// the same launch: owners publish their 11 frame values as granules before their context phase (the values travel under it), then every
+// owner slice of the row gathers the frame, computes the whole first layer (NM x 256 - its kernel rows were requested during the softmax)
+// and 32 of the 256 columns of the second.  A granule that never arrives is recomputed from the row's alignment (lsa_frame_serial).
+constexpr int PR_P = 256, PR_K0 = 40, PR_K1 = 16, PR_GLD = 96;       // prenet width; first-layer rows per thread (2 halves); second-layer rows per thread; granules per row
+struct LsaPre { const float* w0; const float* b0; const float* w1; const float* b1; const uint8_t* m0; const uint8_t* m1; float inv_keep;
+                float* out; long out_ld; PackedDst out_p; unsigned long long* gf; };
+// (forceinline like the other serial paths: a call would take the address of the kernel's by-value argument blocks and put them - and
+// every later use of them - into scratch memory)
+__device__ __forceinline__ float lsa_frame_serial(const mstts_lsa_const& c, const LsaQIn& qi, const LsaProj& pj, int b, int o, const float* s_e,
+                                               float mx, float inv, int len) {
+    const int T = (int)c.T, so = o / PJ_OWN, i = o % PJ_OWN;
+    float acc = (pj.bias && o <= pj.NM) ? pj.bias[o] : 0.f;
+    for (int j = 0; j < qi.H; ++j) acc += qi.m1[(long)b * qi.m1_ld + j] * pj.wp_own[((long)(so * QJ + (j & (QJ - 1))) * 128 + (j >> 3)) * PJ_OW + i];
+    for (int t = 0; t < len; ++t) acc += __expf(s_e[t] - mx) * inv * pj.vp[((long)b * T + t) * pj.NP + o];
+    return acc;
+}
+template <bool SELFTEST, bool LKT = false, bool QIN = false, bool PROJ = false, bool PRE = false>
 __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c, const float* __restrict__ q, int q_parts, long q_pstride,
                                                               float* __restrict__ q_sum, const float* cum,
                                                               float* __restrict__ align, float* __restrict__ cum_next,
                                                               float* __restrict__ ctx, long ctx_ld, float* __restrict__ ctx2, long ctx2_ld, PackedDst ctx_p,
                                                               unsigned long long* gran, unsigned epoch, int tsl, int dsl, int ncs, int skip, LsaQIn qi,
-                                                              LsaProj pjx) {
+                                                              LsaProj pjx, LsaPre prx) {
     int cs, b;
     row_slice_of_block(blockIdx.x, ncs, (int)c.B, &b, &cs);
     if (SELFTEST && cs == skip) return;
     __shared__ float s_pq[PROJ ? 32 * PJ_OW : 1];                               // PROJ: per-row-of-16-lanes partial sums of m1 . Wp_m (own outputs)
     __shared__ float s_pm[PROJ ? PJ_OW : 1];                                    //       m1 . Wp_m of the own outputs
     __shared__ float s_pv[PROJ ? (PJ_TG + 1) * PJ_OW : 1];                      //       per-position-group partial sums of sum_t a[t] vp[t]
+    __shared__ float s_fr[PRE ? PR_GLD : 1];                                    // PRE: the row's frame
     __shared__ __attribute__((aligned(16))) float s_qp[QIN ? 32 * 16 : 4];     // QIN: per-row-of-16-lanes partial sums of the 16 own units
     __shared__ float s_q[QIN ? A_ : 1];                                         // QIN: the row's query
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
@@ -481,6 +499,54 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         align[(long)b * T + t] = a;
         cum_next[(long)b * T + t] = s_cum[pad + tid] + a;
     }
+    // PROJ: the frame before the context phase (it does not depend on the context)
+    if constexpr (PROJ) {
+        if (cs < 8 && ptg < PJ_TG) {
+            float pa = 0.f;
+#pragma unroll
+            for (int i = 0; i < PJ_VPRE; ++i) {
+                const int t = ptg + PJ_TG * i;
+                if (t < len) pa += __expf(s_e[t] - mx) * inv * pv[i];
+            }
+            if (pv_live)
+                for (int t = ptg + PJ_TG * PJ_VPRE; t < len; t += PJ_TG)
+                    pa += __expf(s_e[t] - mx) * inv * pjx.vp[((long)b * T + t) * pjx.NP + PJ_OWN * cs + pol];
+            s_pv[ptg * PJ_OW + pol] = pa;
+        }
+    }
+    if constexpr (PROJ) __syncthreads();
+    if constexpr (PROJ) {
+        const int ol = tid - (FS_THREADS - PJ_OW), oo = PJ_OWN * cs + ol;
+        if (cs < 8 && ol >= 0 && ol < PJ_OWN && oo < pjx.NP) {
+            float v2 = pbias + s_pm[ol];
+            for (int gq = 0; gq < PJ_TG; ++gq) v2 += s_pv[gq * PJ_OW + ol];
+            if (oo < pjx.NM) {
+                pjx.linear[(long)b * pjx.NM + oo] = v2;
+                if constexpr (PRE) {
+                    s_fr[oo] = v2;
+                    __hip_atomic_store((gu64*)(prx.gf + (long)b * PR_GLD + oo), ((unsigned long long)epoch << 32) | __float_as_uint(v2), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (oo == pjx.NM) pjx.stop[b] = v2;
+        }
+    }
+    // PRE: operands of the next step's prenet, requested here so that they arrive under the context phase
+    float w0r[PRE ? PR_K0 : 1], w1r[PRE ? PR_K1 : 1], b0r = 0.f, b1r = 0.f, m0r = 0.f, m1r = 0.f;
+    if constexpr (PRE) {
+        if (cs < 8) {
+            const int col = tid & (PR_P - 1), kh = tid >> 8, cl = tid & 31, kp = tid >> 5;
+#pragma unroll
+            // (workgroup-scope relaxed atomic loads = plain loads the optimiser will not sink to their uses at the end of the kernel)
+            for (int i = 0; i < PR_K0; ++i)
+                w0r[i] = (kh * PR_K0 + i < pjx.NM) ? __hip_atomic_load(prx.w0 + (long)(kh * PR_K0 + i) * PR_P + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0.f;
+#pragma unroll
+            for (int i = 0; i < PR_K1; ++i)
+                w1r[i] = __hip_atomic_load(prx.w1 + (long)(kp * PR_K1 + i) * PR_P + 32 * cs + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tid < PR_P) { b0r = prx.b0[tid]; m0r = (float)prx.m0[(long)b * PR_P + tid]; }
+            if (tid < 32) { b1r = prx.b1[32 * cs + tid]; m1r = (float)prx.m1[(long)b * PR_P + 32 * cs + tid]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // (keeps the requests here: sunk to their uses they would cost the tail a round trip)
+    }
     // ---- context slice
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -499,36 +565,64 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         }
     }
     if (vg < ng) *reinterpret_cast<float4*>(&s_part[(vg * nc4 + c4) * 4]) = acc;
-    if constexpr (PROJ) {
-        if (cs < 8 && ptg < PJ_TG) {
-            float pa = 0.f;
-#pragma unroll
-            for (int i = 0; i < PJ_VPRE; ++i) {
-                const int t = ptg + PJ_TG * i;
-                if (t < len) pa += __expf(s_e[t] - mx) * inv * pv[i];
-            }
-            if (pv_live)
-                for (int t = ptg + PJ_TG * PJ_VPRE; t < len; t += PJ_TG)
-                    pa += __expf(s_e[t] - mx) * inv * pjx.vp[((long)b * T + t) * pjx.NP + PJ_OWN * cs + pol];
-            s_pv[ptg * PJ_OW + pol] = pa;
-        }
-    }
     __syncthreads();
-    if constexpr (PROJ) {
-        const int ol = tid - (FS_THREADS - PJ_OW), oo = PJ_OWN * cs + ol;
-        if (cs < 8 && ol >= 0 && ol < PJ_OWN && oo < pjx.NP) {
-            float v2 = pbias + s_pm[ol];
-            for (int gq = 0; gq < PJ_TG; ++gq) v2 += s_pv[gq * PJ_OW + ol];
-            if (oo < pjx.NM) pjx.linear[(long)b * pjx.NM + oo] = v2;
-            else if (oo == pjx.NM) pjx.stop[b] = v2;
-        }
-    }
     if (tid < dsl && d0 + tid < M) {
         float r = 0.f;
         for (int gq = 0; gq < ng; ++gq) r += s_part[gq * dsl + tid];
         ctx[(long)b * ctx_ld + d0 + tid] = r;
         if (ctx2) ctx2[(long)b * ctx2_ld + d0 + tid] = r;
         if (ctx_p.base) packed_store(ctx_p, b, d0 + tid, r);
+    }
+    if constexpr (PRE) {
+        if (cs >= 8) return;
+        // ---- the row's frame: the own 11 values are in s_fr already, the others left their owners before the context phase
+        if (tid < pjx.NM && tid / PJ_OWN != cs) {
+            const gu64* gs = (const gu64*)(prx.gf + (long)b * PR_GLD + tid);
+            unsigned long long x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
+                __builtin_amdgcn_s_sleep(1);
+                x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++spins;
+            }
+            float f;
+            if ((unsigned)(x >> 32) == epoch) f = __uint_as_float((unsigned)x);
+            else {
+                f = lsa_frame_serial(c, qi, pjx, b, tid, s_e, mx, inv, len);
+                atomicAdd(gran + (long)c.B * T, 1ull);
+            }
+            s_fr[tid] = f;
+        }
+        __syncthreads();                 // (also: every context reduction above has read s_part, which the prenet now reuses)
+        float* s_l0 = s_part;            // [2][256] first-layer halves
+        float* s_h = s_part + 2 * PR_P;  // [256]
+        float* s_l1 = s_part + 3 * PR_P; // [16][32] second-layer parts
+        {
+            const int col = tid & (PR_P - 1), kh = tid >> 8;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < PR_K0; ++i) a += ((kh * PR_K0 + i < pjx.NM) ? s_fr[kh * PR_K0 + i] : 0.f) * w0r[i];
+            s_l0[kh * PR_P + col] = a;
+        }
+        __syncthreads();
+        if (tid < PR_P) s_h[tid] = fmaxf(s_l0[tid] + s_l0[PR_P + tid] + b0r, 0.f) * (fminf(m0r, 1.f) * prx.inv_keep);
+        __syncthreads();
+        {
+            const int cl = tid & 31, kp = tid >> 5;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < PR_K1; ++i) a += s_h[kp * PR_K1 + i] * w1r[i];
+            s_l1[kp * 32 + cl] = a;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float a = b1r;
+#pragma unroll
+            for (int kp = 0; kp < 16; ++kp) a += s_l1[kp * 32 + tid];
+            const float y = fmaxf(a, 0.f) * (fminf(m1r, 1.f) * prx.inv_keep);
+            prx.out[(long)b * prx.out_ld + 32 * cs + tid] = y;
+            if (prx.out_p.base) packed_store(prx.out_p, b, 32 * cs + tid, y);
+        }
     }
 }
 
@@ -1125,7 +1219,7 @@ extern "C" int64_t mstts_lsa_step_ws_bytes(int64_t B, int64_t T) { return (B * T
 static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t q_parts, int64_t q_pstride, float* q_sum,
                                const float* cum, float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
                                const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int skip, mstts_stream_t s,
-                               const LsaQIn* qin = nullptr, const LsaProj* proj = nullptr) {
+                               const LsaQIn* qin = nullptr, const LsaProj* proj = nullptr, const mstts_lsa_prenet* pre = nullptr) {
     int rc = check_const(c); if (rc) return rc;
     MSTTS_REQUIRE(granules && epoch != 0 && ((uintptr_t)granules & 7) == 0, MSTTS_ERR_SHAPE, "lsa_step_fwd: granule buffer (8-byte aligned) and a non-zero epoch required");
     PackedDst cp;
@@ -1136,6 +1230,8 @@ static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t
     memset(&qi, 0, sizeof(qi));
     LsaProj pz;
     memset(&pz, 0, sizeof(pz));
+    LsaPre px;
+    memset(&px, 0, sizeof(px));
     const bool lkt = c->loc_kt && aligned16(c->loc_kt);
     if (qin && proj) {
         qi = *qin; pz = *proj;
@@ -1143,31 +1239,44 @@ static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t
         MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_qp: m1 / wq must be 16-byte aligned");
         MSTTS_REQUIRE(pz.wp_own && pz.vp && pz.linear && pz.stop && pz.NP >= 2 && pz.NP <= 8 * PJ_OWN && pz.NM < pz.NP, MSTTS_ERR_SHAPE,
                       "lsa_step_fwd_qp: projection width must be 2..%d columns", 8 * PJ_OWN);
-        if (skip >= 0)
+        if (pre) {
+            MSTTS_REQUIRE(pre->w0 && pre->b0 && pre->w1 && pre->b1 && pre->m0 && pre->m1 && pre->out && pre->P == PR_P && pz.NM <= 2 * PR_K0 &&
+                          pz.NM <= PR_GLD, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: in-launch prenet needs P == %d and n_mel <= %d", PR_P, 2 * PR_K0);
+            px.w0 = pre->w0; px.b0 = pre->b0; px.w1 = pre->w1; px.b1 = pre->b1; px.m0 = pre->m0; px.m1 = pre->m1; px.inv_keep = pre->inv_keep;
+            px.out = pre->out; px.out_ld = (long)pre->out_ld;
+            rc = packed_dst_from(pre->out_p.base ? &pre->out_p : nullptr, PR_P, &px.out_p, "prenet out_p"); if (rc) return rc;
+            px.gf = (unsigned long long*)granules + (c->B * c->T + 1 + c->B * A_);
+            if (skip >= 0)
+                hipLaunchKernelGGL((lsa_step_kernel<true, true, true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
+                                   align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz, px);
+            else
+                hipLaunchKernelGGL((lsa_step_kernel<false, true, true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
+                                   align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz, px);
+        } else if (skip >= 0)
             hipLaunchKernelGGL((lsa_step_kernel<true, true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
-                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz);
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz, px);
         else
             hipLaunchKernelGGL((lsa_step_kernel<false, true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
-                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz, px);
     } else if (qin) {
         qi = *qin;
         MSTTS_REQUIRE(cs >= 8 && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_q: needs at least 8 slices (T > 112 or M > 672), H == %d and the by-unit filter", 128 * QJ);
         MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_q: m1 / wq must be 16-byte aligned");
         if (skip >= 0)
             hipLaunchKernelGGL((lsa_step_kernel<true, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
-                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz);
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz, px);
         else
             hipLaunchKernelGGL((lsa_step_kernel<false, true, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, 0, 0L, q_sum, cum,
-                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
+                               align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz, px);
     } else if (skip >= 0)
         hipLaunchKernelGGL(lsa_step_kernel<true>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, skip, qi, pz, px);
     else if (lkt)
         hipLaunchKernelGGL((lsa_step_kernel<false, true>), dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz, px);
     else
         hipLaunchKernelGGL(lsa_step_kernel<false>, dim3((unsigned)(cs * c->B)), dim3(FS_THREADS), 0, ST(s), *c, q, (int)q_parts, (long)q_pstride, q_sum, cum,
-                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz);
+                           align, cum_next, ctx, (long)ctx_ld, ctx2, (long)ctx2_ld, cp, (unsigned long long*)granules, (unsigned)epoch, tsl, dsl, cs, -1, qi, pz, px);
     MSTTS_CHECK_LAUNCH("lsa_step_fwd");
     return MSTTS_OK;
 }
@@ -1199,10 +1308,13 @@ extern "C" int mstts_lsa_step_fwd_q(const mstts_lsa_const* c, const float* m1, i
 /* ... and with the output projection [m1 | ctx] . Wp + bias out of the same launch (free-running decoder): no further exchange -
  *   vp [B, T, NP] = values . Wp[H:, :] (the projected values: once per utterance, any GEMM), wp_own = mstts_lsa_proj_pack(Wp[:H, :]);
  *   bias [NM + 1] or NULL; linear [B, NM] <- columns 0..NM-1, stop [B] <- column NM.  NP <= 88.
- * Same availability and granules as mstts_lsa_step_fwd_q. */
+ * Same availability as mstts_lsa_step_fwd_q; granules = mstts_lsa_step_qp_ws_bytes(B, T) bytes.
+ * pre != NULL (mstts_lsa_step_prenet_supported(P, NM)): the NEXT step's prenet on this frame in the same launch - see LsaPre above. */
 extern "C" int32_t mstts_lsa_step_qp_supported(int64_t T, int64_t M, int64_t H, int64_t NP) {
     return mstts_lsa_step_q_supported(T, M, H) && NP >= 2 && NP <= 8 * PJ_OWN;
 }
+extern "C" int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T) { return (B * T + 1 + B * A_ + B * PR_GLD) * 8; }
+extern "C" int32_t mstts_lsa_step_prenet_supported(int64_t P, int64_t NM) { return P == PR_P && NM >= 1 && NM <= 2 * PR_K0; }
 extern "C" int64_t mstts_lsa_proj_pack_floats(void) { return 8L * QJ * 128 * PJ_OW; }
 namespace mstts {
 __global__ void lsa_proj_pack_kernel(const float* __restrict__ wp, long ld, int NP, float* __restrict__ out) {
@@ -1224,14 +1336,15 @@ extern "C" int mstts_lsa_proj_pack(const float* wp, int64_t ld, int64_t H, int64
 extern "C" int mstts_lsa_step_fwd_qp(const mstts_lsa_const* c, const float* m1, int64_t m1_ld, const float* wq, int64_t H, const float* wp_own,
                                      const float* vp, const float* bias, int64_t NP, int64_t NM, float* linear, float* stop, const float* cum,
                                      float* align, float* cum_next, float* ctx, int64_t ctx_ld, float* ctx2, int64_t ctx2_ld,
-                                     const mstts_cell_packed_dst* ctx_p, void* granules, uint32_t epoch, int32_t skip_slice, mstts_stream_t s) {
+                                     const mstts_cell_packed_dst* ctx_p, const mstts_lsa_prenet* pre, void* granules, uint32_t epoch,
+                                     int32_t skip_slice, mstts_stream_t s) {
     MSTTS_REQUIRE(c && granules, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: null pointer");
     LsaQIn qi;
     qi.m1 = m1; qi.m1_ld = (long)m1_ld; qi.wq = wq; qi.H = (int)H; qi.bf16 = 0;
     LsaProj pj;
     pj.wp_own = wp_own; pj.vp = vp; pj.bias = bias; pj.NP = (int)NP; pj.NM = (int)NM; pj.linear = linear; pj.stop = stop;
     return lsa_step_fwd_launch(c, nullptr, 0, 0, nullptr, cum, align, cum_next, ctx, ctx_ld, ctx2, ctx2_ld, ctx_p, granules, epoch,
-                               skip_slice >= 0 ? skip_slice : -1, s, &qi, &pj);
+                               skip_slice >= 0 ? skip_slice : -1, s, &qi, &pj, pre);
 }
 /* test entry: same launch with the workgroups of slice `skip_slice` (0 .. slices-1) removed, which forces every other workgroup of each row
  * through its time-out path (takes milliseconds); the skipped slice's own outputs are not written */

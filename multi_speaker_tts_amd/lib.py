@@ -48,6 +48,11 @@ class CellPackedDst(C.Structure):
     _fields_ = [("base", vp), ("K", i64), ("col0", i64), ("bf16", i32)]
 
 
+class LsaPrenet(C.Structure):
+    _fields_ = [("w0", vp), ("b0", vp), ("w1", vp), ("b1", vp), ("m0", vp), ("m1", vp), ("inv_keep", f32), ("P", i32),
+                ("out", vp), ("out_ld", i64), ("out_p", CellPackedDst)]
+
+
 class CellFwd(C.Structure):
     _fields_ = [("B", i64), ("H", i64), ("K", i64), ("Xp", vp), ("Wp", vp), ("xw", vp), ("xw_ld", i64), ("bias", vp),
                 ("c_prev", vp), ("h_prev", vp), ("h_prev_ld", i64), ("zc", vp), ("zh", vp), ("zoneout", f32),
@@ -146,7 +151,10 @@ SIGNATURES = {
     "mstts_lsa_step_qp_supported": (i32, [i64, i64, i64, i64]),
     "mstts_lsa_proj_pack_floats": (i64, []),
     "mstts_lsa_proj_pack": (i32, [vp, i64, i64, i64, vp, vp]),
-    "mstts_lsa_step_fwd_qp": (i32, [P(LsaConst), vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
+    "mstts_lsa_step_qp_ws_bytes": (i64, [i64, i64]),
+    "mstts_lsa_step_prenet_supported": (i32, [i64, i64]),
+    "mstts_lsa_step_fwd_qp": (i32, [P(LsaConst), vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst),
+                                    P(LsaPrenet), vp, C.c_uint32, i32, vp]),
     "mstts_lsa_step_fwd_q": (i32, [P(LsaConst), vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, P(CellPackedDst), vp, C.c_uint32, i32, vp]),
     "mstts_lsa_step_fwd_selftest": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, C.c_uint32, i32, vp]),
     "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),

@@ -240,7 +240,22 @@ def test_lsa_step_fwd_q(dev, B, T, bf16):
     wp_own = torch.zeros(int(L.mstts_lsa_proj_pack_floats()), device=dev)
     lib.call("mstts_lsa_proj_pack", lib.ptr(wp), NP, H, NP, lib.ptr(wp_own))
     vp = (dv.double().reshape(B * T, M) @ wp[H:].double()).float().contiguous()
-    gran_p = torch.zeros(int(L.mstts_lsa_step_q_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    gran_p = torch.zeros(int(L.mstts_lsa_step_qp_ws_bytes(B, T)) // 8, dtype=torch.int64, device=dev)
+    # ... and the next step's prenet on that frame (two dense layers, relu, dropout masks as multipliers) in the same launch
+    PN, keep_p = 256, 0.5
+    assert L.mstts_lsa_step_prenet_supported(PN, NM) == 1 and L.mstts_lsa_step_prenet_supported(128, NM) == 0
+    pw0, pb0 = f32(g.normal(0, 0.2, (NM, PN))), f32(g.normal(0, 0.1, (PN,)))
+    pw1, pb1 = f32(g.normal(0, 0.1, (PN, PN))), f32(g.normal(0, 0.1, (PN,)))
+    pm0 = torch.tensor(g.integers(0, 2, (B, PN)).astype(np.uint8), device=dev)
+    pm1 = torch.tensor(g.integers(0, 2, (B, PN)).astype(np.uint8), device=dev)
+    pre_ld = PN + 44
+    pn = lib.LsaPrenet()
+    pn.w0, pn.b0, pn.w1, pn.b1, pn.m0, pn.m1 = lib.ptr(pw0), lib.ptr(pb0), lib.ptr(pw1), lib.ptr(pb1), lib.ptr(pm0), lib.ptr(pm1)
+    pn.inv_keep, pn.P, pn.out_ld = 1.0 / keep_p, PN, pre_ld
+
+    def prenet_ref(frame):
+        h = torch.relu(frame.double() @ pw0.double() + pb0.double()) * pm0.double() / keep_p
+        return torch.relu(h @ pw1.double() + pb1.double()) * pm1.double() / keep_p
     for step in range(1, 4):
         pj = f32(g.normal(0, 1, (B, WP)))
         cum = f32(np.abs(g.normal(0, 0.5, (B, T))) * mask)
@@ -252,23 +267,36 @@ def test_lsa_step_fwd_q(dev, B, T, bf16):
         ref[:, :NM + 1] += bias.double()
         al2, cn2, cx2 = torch.zeros(B, T, device=dev), torch.zeros(B, T, device=dev), torch.zeros(B, M, device=dev)
         lin, stop = torch.full((B, NM), 7.0, device=dev), torch.full((B,), 7.0, device=dev)
+        pre_out = torch.full((B, pre_ld), 7.0, device=dev)
+        pn.out = lib.ptr(pre_out)
         lib.call("mstts_lsa_step_fwd_qp", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, lib.ptr(wp_own), lib.ptr(vp), lib.ptr(bias), NP, NM,
                  lib.ptr(lin), lib.ptr(stop), lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2), lib.ptr(cx2), M, lib.ptr(pj[:, H:]), WP, None,
-                 lib.ptr(gran_p), step, -1)
+                 C.byref(pn) if step != 2 else None, lib.ptr(gran_p), step, -1)
         torch.cuda.synchronize()
+        if step != 2:
+            assert rel_err(t2n(pre_out[:, :PN]), t2n(prenet_ref(ref[:, :NM]))) < 2e-5
+            assert float((pre_out[:, PN:] - 7.0).abs().max()) == 0.0
+        else:
+            assert float((pre_out - 7.0).abs().max()) == 0.0                           # no prenet requested: nothing written
         assert int(gran_p[B * T]) == 0
         assert rel_err(t2n(al2), t2n(al)) < 1e-5 and rel_err(t2n(cn2), t2n(cn)) < 1e-5 and rel_err(t2n(cx2), t2n(cx)) < 1e-5
         assert rel_err(t2n(pj[:, H:]), t2n(cx)) < 1e-5                                  # second context destination (the projection input rows)
         assert rel_err(t2n(lin), t2n(ref[:, :NM])) < 1e-5 and rel_err(t2n(stop), t2n(ref[:, NM])) < 1e-5
     # self-test form: slice 3 missing -> the other owners still produce their outputs (from recomputed energies), outputs 33..43 stay unwritten
+    # (the prenet of the other owners then needs the missing 11 frame values: recomputed from the row's alignment, lsa_frame_serial)
     lin3, stop3 = torch.full((B, NM), 7.0, device=dev), torch.full((B,), 7.0, device=dev)
+    pre3 = torch.full((B, pre_ld), 7.0, device=dev)
+    pn.out = lib.ptr(pre3)
     lib.call("mstts_lsa_step_fwd_qp", C.byref(c), lib.ptr(pj), WP, lib.ptr(wq), H, lib.ptr(wp_own), lib.ptr(vp), lib.ptr(bias), NP, NM,
-             lib.ptr(lin3), lib.ptr(stop3), lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2), lib.ptr(cx2), M, None, 0, None, lib.ptr(gran_p), 9, 3)
+             lib.ptr(lin3), lib.ptr(stop3), lib.ptr(cum), lib.ptr(al2), lib.ptr(cn2), lib.ptr(cx2), M, None, 0, None, C.byref(pn), lib.ptr(gran_p), 9, 3)
     torch.cuda.synchronize()
     assert int(gran_p[B * T]) > 0
     keep = np.ones(NM, bool); keep[33:44] = False
     assert rel_err(t2n(lin3)[:, keep], t2n(ref[:, :NM])[:, keep]) < 1e-5 and rel_err(t2n(stop3), t2n(ref[:, NM])) < 1e-5
     assert float((lin3[:, 33:44] - 7.0).abs().max()) == 0.0
+    keepc = np.ones(PN, bool); keepc[96:128] = False                                    # the missing slice's 32 prenet columns stay unwritten
+    assert rel_err(t2n(pre3[:, :PN])[:, keepc], t2n(prenet_ref(ref[:, :NM]))[:, keepc]) < 2e-5
+    assert float((pre3[:, 96:128] - 7.0).abs().max()) == 0.0
 
 
 def test_lsa_step_exchange_under_load(dev):

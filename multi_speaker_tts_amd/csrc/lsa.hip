@@ -252,23 +252,27 @@ struct LsaQIn { const float* m1; long m1_ld; const float* wq; int H, bf16; };   
 //   so once the row's energies are known slice s < 8 forms outputs 11 s .. 11 s + 10 from its own softmax weights (128 x 11 products);
 //   m1 . Wp_m for those 11 outputs rides on the query projection (same m1 registers, a by-owner packed copy wp_own of the kernel rows,
 //   mstts_lsa_proj_pack), reduced the same way while the query granules travel.
-constexpr int PJ_OWN = 11, PJ_OW = 12, PJ_TG = 42, PJ_VPRE = 4;      // outputs per owner slice (padded to 12), position groups, prefetched positions per thread
+constexpr int PJ_OWN = 11, PJ_OW = 16, PJ_TG = 32, PJ_VPRE = 4;      // outputs per owner slice (16 slots: one 16-byte load per lane), position groups, prefetched positions per thread
 struct LsaProj { const float* wp_own; const float* vp; const float* bias; int NP, NM; float* linear; float* stop; };
-// PRE (with PROJ): the prenet of the NEXT decoder step (Modules.py:239-255, dropout always on) on the frame this step just produced, in
-// the same launch: owners publish their 11 frame values as granules before their context phase (the values travel under it), then every
-// owner slice of the row gathers the frame, computes the whole first layer (NM x 256 - its kernel rows were requested during the softmax)
-// and 32 of the 256 columns of the second.  A granule that never arrives is recomputed from the row's alignment (lsa_frame_serial).
-constexpr int PR_P = 256, PR_K0 = 40, PR_K1 = 16, PR_GLD = 96;       // prenet width; first-layer rows per thread (2 halves); second-layer rows per thread; granules per row
+// PRE (with PROJ): the prenet of the NEXT decoder step (Modules.py:239-255, dropout always on) on the frame this step produces, in the
+// same launch and with no hand-off beyond the two the attention has anyway.  Every slice knows the row's complete alignment after the
+// energy exchange, so the context part of the WHOLE frame, sum_t a[t] vp[t, 0..NM], is 128 x 81 products any slice can do itself; what it
+// lacks is m1 . Wp_m + b for the outputs of the other owners, and those 11 values per owner exist at the very start of the launch: they
+// are published and gathered together with the query units.  Each owner slice then holds the row's frame, writes its own 11 outputs,
+// computes the whole first prenet layer (NM x 256, its kernel rows requested during the softmax) and 32 of the 256 columns of the second.
+constexpr int PR_P = 256, PR_K0 = 10, PR_K1 = 4, PR_GLD = 96;        // prenet width; first / second layer kernel rows per thread (16-byte loads); granules per row
+constexpr int PF_Q = 21, PF_G = 24, PF_IT = 6;                        // whole-frame form: 16-byte quads of a projected-value row (NP == 84) x position groups x prefetched positions
+// (every operand of these stages is fetched 16 bytes per lane: a wave's load costs the address unit 16 cycles whatever its width, and
+// with one-word loads - 110 per wave in the first version of this kernel - that alone was 6 us of the launch)
 struct LsaPre { const float* w0; const float* b0; const float* w1; const float* b1; const uint8_t* m0; const uint8_t* m1; float inv_keep;
                 float* out; long out_ld; PackedDst out_p; unsigned long long* gf; };
 // (forceinline like the other serial paths: a call would take the address of the kernel's by-value argument blocks and put them - and
 // every later use of them - into scratch memory)
-__device__ __forceinline__ float lsa_frame_serial(const mstts_lsa_const& c, const LsaQIn& qi, const LsaProj& pj, int b, int o, const float* s_e,
-                                               float mx, float inv, int len) {
-    const int T = (int)c.T, so = o / PJ_OWN, i = o % PJ_OWN;
+// m1 . Wp_m[:, o] + bias[o] by one thread (time-out path of the whole-frame form)
+__device__ __forceinline__ float lsa_pm_serial(const LsaQIn& qi, const LsaProj& pj, int b, int o) {
+    const int so = o / PJ_OWN, i = o % PJ_OWN;
     float acc = (pj.bias && o <= pj.NM) ? pj.bias[o] : 0.f;
     for (int j = 0; j < qi.H; ++j) acc += qi.m1[(long)b * qi.m1_ld + j] * pj.wp_own[((long)(so * QJ + (j & (QJ - 1))) * 128 + (j >> 3)) * PJ_OW + i];
-    for (int t = 0; t < len; ++t) acc += __expf(s_e[t] - mx) * inv * pj.vp[((long)b * T + t) * pj.NP + o];
     return acc;
 }
 template <bool SELFTEST, bool LKT = false, bool QIN = false, bool PROJ = false, bool PRE = false>
@@ -281,10 +285,12 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     int cs, b;
     row_slice_of_block(blockIdx.x, ncs, (int)c.B, &b, &cs);
     if (SELFTEST && cs == skip) return;
-    __shared__ float s_pq[PROJ ? 32 * PJ_OW : 1];                               // PROJ: per-row-of-16-lanes partial sums of m1 . Wp_m (own outputs)
+    __shared__ __attribute__((aligned(16))) float s_pq[PROJ ? 32 * PJ_OW : 4];                               // PROJ: per-row-of-16-lanes partial sums of m1 . Wp_m (own outputs)
     __shared__ float s_pm[PROJ ? PJ_OW : 1];                                    //       m1 . Wp_m of the own outputs
     __shared__ float s_pv[PROJ ? (PJ_TG + 1) * PJ_OW : 1];                      //       per-position-group partial sums of sum_t a[t] vp[t]
     __shared__ float s_fr[PRE ? PR_GLD : 1];                                    // PRE: the row's frame
+    __shared__ float s_m[PRE ? PR_GLD : 1];                                     //      m1 . Wp_m + b of every output of the row
+    __shared__ __attribute__((aligned(16))) float s_pvf[PRE ? PF_G * 4 * PF_Q : 4];   //      per-position-group partial sums of sum_t a[t] vp[t, :]
     __shared__ __attribute__((aligned(16))) float s_qp[QIN ? 32 * 16 : 4];     // QIN: per-row-of-16-lanes partial sums of the 16 own units
     __shared__ float s_q[QIN ? A_ : 1];                                         // QIN: the row's query
     __shared__ __attribute__((aligned(16))) float s_cum[FS_TSL + KS_MAX - 1 + 2];
@@ -337,24 +343,33 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     }
     // PROJ operands, requested with everything else (owners only): the packed kernel rows of this thread's 8 hidden units x 3 outputs,
     // its share of the projected values, the bias
-    float pw[PROJ ? QJ : 1][3], pv[PROJ ? PJ_VPRE : 1], pbias = 0.f;
-    const int pol = PROJ ? tid % PJ_OW : 0, ptg = PROJ ? tid / PJ_OW : 0;
-    const bool pv_live = PROJ && cs < 8 && ptg < PJ_TG && pol < PJ_OWN && PJ_OWN * cs + pol < pjx.NP;
+    float4 pw[PROJ ? QJ : 1], pvq[PRE ? PF_IT : 1];
+    float pv[(PROJ && !PRE) ? PJ_VPRE : 1], pbias = 0.f;
+    const int pol = PROJ ? (PRE ? tid % PF_Q : tid % PJ_OW) : 0, ptg = PROJ ? (PRE ? tid / PF_Q : tid / PJ_OW) : 0;
+    const bool pv_live = PRE ? (cs < 8 && ptg < PF_G) : (PROJ && cs < 8 && ptg < PJ_TG && pol < PJ_OWN && PJ_OWN * cs + pol < pjx.NP);
     if constexpr (PROJ) {
         const int a4 = tid & 3, ch = tid >> 2;
 #pragma unroll
-        for (int jj = 0; jj < QJ; ++jj) {
-            const float* w3 = pjx.wp_own + ((long)((cs & 7) * QJ + jj) * 128 + ch) * PJ_OW + 3 * a4;
+        for (int jj = 0; jj < QJ; ++jj)
+            pw[jj] = (cs < 8) ? *reinterpret_cast<const float4*>(pjx.wp_own + ((long)((cs & 7) * QJ + jj) * 128 + ch) * PJ_OW + 4 * a4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PRE) {                // whole frame: output pol of positions ptg + PF_G i
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pw[jj][i] = (cs < 8) ? w3[i] : 0.f;
-        }
+            for (int i = 0; i < PF_IT; ++i) {
+                const int t = ptg + PF_G * i;
+                pvq[i] = (pv_live && t < T) ? *reinterpret_cast<const float4*>(pjx.vp + ((long)b * T + t) * (4 * PF_Q) + 4 * pol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const int ob = PJ_OWN * cs + tid - 32;                 // (threads 32..42 finish m1 . Wp_m + b of the own outputs)
+            if (cs < 8 && tid >= 32 && tid < 32 + PJ_OWN && ob <= pjx.NM && pjx.bias) pbias = pjx.bias[ob];
+        } else {
 #pragma unroll
-        for (int i = 0; i < PJ_VPRE; ++i) {
-            const int t = ptg + PJ_TG * i;
-            pv[i] = (pv_live && t < T) ? pjx.vp[((long)b * T + t) * pjx.NP + PJ_OWN * cs + pol] : 0.f;
+            for (int i = 0; i < PJ_VPRE; ++i) {
+                const int t = ptg + PJ_TG * i;
+                pv[i] = (pv_live && t < T) ? pjx.vp[((long)b * T + t) * pjx.NP + PJ_OWN * cs + pol] : 0.f;
+            }
+            const int ob = PJ_OWN * cs + tid - (FS_THREADS - PJ_OW);
+            if (cs < 8 && tid >= FS_THREADS - PJ_OW && tid < FS_THREADS - PJ_OW + PJ_OWN && ob <= pjx.NM && pjx.bias) pbias = pjx.bias[ob];
         }
-        const int ob = PJ_OWN * cs + tid - (FS_THREADS - PJ_OW);
-        if (cs < 8 && tid >= FS_THREADS - PJ_OW && tid < FS_THREADS - PJ_OW + PJ_OWN && ob <= pjx.NM && pjx.bias) pbias = pjx.bias[ob];
     }
     const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
     const float* v = c.values + (long)b * T * M + col;
@@ -387,6 +402,22 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         acc.x += dpp_mov<0x118, 0xf>(0.f, acc.x); acc.y += dpp_mov<0x118, 0xf>(0.f, acc.y);       // row_shr:8
         acc.z += dpp_mov<0x118, 0xf>(0.f, acc.z); acc.w += dpp_mov<0x118, 0xf>(0.f, acc.w);
         if ((tid & 15) >= 12) *reinterpret_cast<float4*>(&s_qp[(tid >> 4) * 16 + 4 * (tid & 3)]) = acc;   // lanes 12..15 of a row hold its sums
+        if constexpr (PRE) {                                     // whole-frame form: m1 . Wp_m of the own outputs is handed over WITH the query
+            if (cs < 8) {
+                float a3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < QJ; ++jj) {
+                    const float x = reinterpret_cast<const float*>(qm)[jj];
+                    a3[0] += x * pw[jj].x; a3[1] += x * pw[jj].y; a3[2] += x * pw[jj].z; a3[3] += x * pw[jj].w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a3[i] += dpp_mov<0x114, 0xf>(0.f, a3[i]);
+                    a3[i] += dpp_mov<0x118, 0xf>(0.f, a3[i]);
+                }
+                if ((tid & 15) >= 12) *reinterpret_cast<float4*>(&s_pq[(tid >> 4) * PJ_OW + 4 * (tid & 3)]) = make_float4(a3[0], a3[1], a3[2], a3[3]);
+            }
+        }
         __syncthreads();
         gu64* gq = (gu64*)(gran + (long)c.B * T + 1 + (long)b * A_);
         if (tid < 16 && cs < 8) {
@@ -396,24 +427,47 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
             s_q[16 * cs + tid] = qa;
             __hip_atomic_store(gq + 16 * cs + tid, ((unsigned long long)epoch << 32) | __float_as_uint(qa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if constexpr (PROJ) {                                    // m1 . Wp_m for the own outputs, reduced like the query units
+        if constexpr (PROJ && !PRE) {                            // m1 . Wp_m for the own outputs, reduced like the query units
             if (cs < 8) {
-                float a3[3] = {0.f, 0.f, 0.f};
+                float a3[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jj = 0; jj < QJ; ++jj) {
                     const float x = reinterpret_cast<const float*>(qm)[jj];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) a3[i] += x * pw[jj][i];
+                    a3[0] += x * pw[jj].x; a3[1] += x * pw[jj].y; a3[2] += x * pw[jj].z; a3[3] += x * pw[jj].w;
                 }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     a3[i] += dpp_mov<0x114, 0xf>(0.f, a3[i]);
                     a3[i] += dpp_mov<0x118, 0xf>(0.f, a3[i]);
                 }
-                if ((tid & 15) >= 12) {
+                if ((tid & 15) >= 12) *reinterpret_cast<float4*>(&s_pq[(tid >> 4) * PJ_OW + 4 * (tid & 3)]) = make_float4(a3[0], a3[1], a3[2], a3[3]);
+            }
+        }
+        if constexpr (PRE) {
+            gu64* gm = (gu64*)(prx.gf + (long)b * PR_GLD);
+            if (cs < 8 && tid >= 32 && tid < 32 + PJ_OWN && PJ_OWN * cs + tid - 32 <= pjx.NM) {
+                float a = pbias;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) s_pq[(tid >> 4) * PJ_OW + 3 * (tid & 3) + i] = a3[i];
+                for (int r = 0; r < 32; ++r) a += s_pq[r * PJ_OW + tid - 32];
+                s_m[PJ_OWN * cs + tid - 32] = a;
+                __hip_atomic_store(gm + PJ_OWN * cs + tid - 32, ((unsigned long long)epoch << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int o = tid - A_;
+            if (cs < 8 && o >= 0 && o <= pjx.NM && o / PJ_OWN != cs) {
+                unsigned long long x = __hip_atomic_load(gm + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
+                    __builtin_amdgcn_s_sleep(1);
+                    x = __hip_atomic_load(gm + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ++spins;
                 }
+                float a;
+                if ((unsigned)(x >> 32) == epoch) a = __uint_as_float((unsigned)x);
+                else {
+                    a = lsa_pm_serial(qi, pjx, b, o);
+                    atomicAdd(gran + (long)c.B * T, 1ull);
+                }
+                s_m[o] = a;
             }
         }
         if (tid < A_ && (tid >> 4) != cs) {                      // the other slices' units (the data is the flag)
@@ -434,7 +488,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         }
         __syncthreads();
         qv = s_q[k];
-        if constexpr (PROJ) {
+        if constexpr (PROJ && !PRE) {
             if (cs < 8 && tid >= FS_THREADS - PJ_OW) {
                 float a = 0.f;
 #pragma unroll
@@ -500,7 +554,36 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         cum_next[(long)b * T + t] = s_cum[pad + tid] + a;
     }
     // PROJ: the frame before the context phase (it does not depend on the context)
-    if constexpr (PROJ) {
+    if constexpr (PRE) {                 // whole-frame form: every owner slice forms all NM + 1 outputs of the row
+        if (pv_live) {
+            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < PF_IT; ++i) {
+                const int t = ptg + PF_G * i;
+                if (t < len) {
+                    const float a = __expf(s_e[t] - mx) * inv;
+                    pa.x += a * pvq[i].x; pa.y += a * pvq[i].y; pa.z += a * pvq[i].z; pa.w += a * pvq[i].w;
+                }
+            }
+            for (int t = ptg + PF_G * PF_IT; t < len; t += PF_G) {
+                const float a = __expf(s_e[t] - mx) * inv;
+                const float4 x = *reinterpret_cast<const float4*>(pjx.vp + ((long)b * T + t) * (4 * PF_Q) + 4 * pol);
+                pa.x += a * x.x; pa.y += a * x.y; pa.z += a * x.z; pa.w += a * x.w;
+            }
+            *reinterpret_cast<float4*>(&s_pvf[(ptg * PF_Q + pol) * 4]) = pa;
+        }
+        __syncthreads();
+        if (cs < 8 && tid <= pjx.NM) {
+            float f = s_m[tid];
+#pragma unroll
+            for (int gq = 0; gq < PF_G; ++gq) f += s_pvf[gq * 4 * PF_Q + tid];
+            s_fr[tid] = f;                                       // (identical in every slice of the row: same operands, same order)
+            if (tid / PJ_OWN == cs) {
+                if (tid < pjx.NM) pjx.linear[(long)b * pjx.NM + tid] = f;
+                else pjx.stop[b] = f;
+            }
+        }
+    } else if constexpr (PROJ) {
         if (cs < 8 && ptg < PJ_TG) {
             float pa = 0.f;
 #pragma unroll
@@ -513,35 +596,28 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
                     pa += __expf(s_e[t] - mx) * inv * pjx.vp[((long)b * T + t) * pjx.NP + PJ_OWN * cs + pol];
             s_pv[ptg * PJ_OW + pol] = pa;
         }
-    }
-    if constexpr (PROJ) __syncthreads();
-    if constexpr (PROJ) {
+        __syncthreads();
         const int ol = tid - (FS_THREADS - PJ_OW), oo = PJ_OWN * cs + ol;
         if (cs < 8 && ol >= 0 && ol < PJ_OWN && oo < pjx.NP) {
             float v2 = pbias + s_pm[ol];
             for (int gq = 0; gq < PJ_TG; ++gq) v2 += s_pv[gq * PJ_OW + ol];
-            if (oo < pjx.NM) {
-                pjx.linear[(long)b * pjx.NM + oo] = v2;
-                if constexpr (PRE) {
-                    s_fr[oo] = v2;
-                    __hip_atomic_store((gu64*)(prx.gf + (long)b * PR_GLD + oo), ((unsigned long long)epoch << 32) | __float_as_uint(v2), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else if (oo == pjx.NM) pjx.stop[b] = v2;
+            if (oo < pjx.NM) pjx.linear[(long)b * pjx.NM + oo] = v2;
+            else if (oo == pjx.NM) pjx.stop[b] = v2;
         }
     }
     // PRE: operands of the next step's prenet, requested here so that they arrive under the context phase
-    float w0r[PRE ? PR_K0 : 1], w1r[PRE ? PR_K1 : 1], b0r = 0.f, b1r = 0.f, m0r = 0.f, m1r = 0.f;
+    float4 w0r[PRE ? PR_K0 : 1], w1r[PRE ? PR_K1 : 1];
+    float b0r = 0.f, b1r = 0.f, m0r = 0.f, m1r = 0.f;
     if constexpr (PRE) {
         if (cs < 8) {
-            const int col = tid & (PR_P - 1), kh = tid >> 8, cl = tid & 31, kp = tid >> 5;
+            // first layer: thread (column quad cq0 = tid & 63, row group kg0 = tid >> 6) takes rows 10 kg0 .. + 9; second layer (this slice's
+            // 32 columns): thread (column quad cq1 = tid & 7, row group kg1 = tid >> 3) takes rows 4 kg1 .. + 3
+            const int cq0 = tid & 63, kg0 = tid >> 6, cq1 = tid & 7, kg1 = tid >> 3;
 #pragma unroll
-            // (workgroup-scope relaxed atomic loads = plain loads the optimiser will not sink to their uses at the end of the kernel)
             for (int i = 0; i < PR_K0; ++i)
-                w0r[i] = (kh * PR_K0 + i < pjx.NM) ? __hip_atomic_load(prx.w0 + (long)(kh * PR_K0 + i) * PR_P + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0.f;
+                w0r[i] = (kg0 * PR_K0 + i < pjx.NM) ? *reinterpret_cast<const float4*>(prx.w0 + (long)(kg0 * PR_K0 + i) * PR_P + 4 * cq0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < PR_K1; ++i)
-                w1r[i] = __hip_atomic_load(prx.w1 + (long)(kp * PR_K1 + i) * PR_P + 32 * cs + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int i = 0; i < PR_K1; ++i) w1r[i] = *reinterpret_cast<const float4*>(prx.w1 + (long)(kg1 * PR_K1 + i) * PR_P + 32 * cs + 4 * cq1);
             if (tid < PR_P) { b0r = prx.b0[tid]; m0r = (float)prx.m0[(long)b * PR_P + tid]; }
             if (tid < 32) { b1r = prx.b1[32 * cs + tid]; m1r = (float)prx.m1[(long)b * PR_P + 32 * cs + tid]; }
         }
@@ -575,50 +651,43 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
     }
     if constexpr (PRE) {
         if (cs >= 8) return;
-        // ---- the row's frame: the own 11 values are in s_fr already, the others left their owners before the context phase
-        if (tid < pjx.NM && tid / PJ_OWN != cs) {
-            const gu64* gs = (const gu64*)(prx.gf + (long)b * PR_GLD + tid);
-            unsigned long long x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while ((unsigned)(x >> 32) != epoch && spins < FS_MAX_SPINS) {
-                __builtin_amdgcn_s_sleep(1);
-                x = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++spins;
-            }
-            float f;
-            if ((unsigned)(x >> 32) == epoch) f = __uint_as_float((unsigned)x);
-            else {
-                f = lsa_frame_serial(c, qi, pjx, b, tid, s_e, mx, inv, len);
-                atomicAdd(gran + (long)c.B * T, 1ull);
-            }
-            s_fr[tid] = f;
-        }
-        __syncthreads();                 // (also: every context reduction above has read s_part, which the prenet now reuses)
-        float* s_l0 = s_part;            // [2][256] first-layer halves
-        float* s_h = s_part + 2 * PR_P;  // [256]
-        float* s_l1 = s_part + 3 * PR_P; // [16][32] second-layer parts
+        __syncthreads();                 // (every context reduction above has read s_part, which the prenet now reuses; s_fr is long complete)
+        float* s_l0 = s_part;            // [8][256] first-layer partial sums by row group
+        float* s_h = s_pq;               // [256]   (the query-phase scratch is long free)
+        float* s_l1 = s_part;            // [64][32] second-layer partial sums by row group (after the first layer has been reduced)
         {
-            const int col = tid & (PR_P - 1), kh = tid >> 8;
-            float a = 0.f;
+            const int cq0 = tid & 63, kg0 = tid >> 6;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < PR_K0; ++i) a += ((kh * PR_K0 + i < pjx.NM) ? s_fr[kh * PR_K0 + i] : 0.f) * w0r[i];
-            s_l0[kh * PR_P + col] = a;
+            for (int i = 0; i < PR_K0; ++i) {
+                const float x = (kg0 * PR_K0 + i < pjx.NM) ? s_fr[kg0 * PR_K0 + i] : 0.f;
+                a.x += x * w0r[i].x; a.y += x * w0r[i].y; a.z += x * w0r[i].z; a.w += x * w0r[i].w;
+            }
+            *reinterpret_cast<float4*>(&s_l0[kg0 * PR_P + 4 * cq0]) = a;
         }
         __syncthreads();
-        if (tid < PR_P) s_h[tid] = fmaxf(s_l0[tid] + s_l0[PR_P + tid] + b0r, 0.f) * (fminf(m0r, 1.f) * prx.inv_keep);
+        if (tid < PR_P) {
+            float a = b0r;
+#pragma unroll
+            for (int kg = 0; kg < FS_THREADS / 64; ++kg) a += s_l0[kg * PR_P + tid];
+            s_h[tid] = fmaxf(a, 0.f) * (fminf(m0r, 1.f) * prx.inv_keep);
+        }
         __syncthreads();
         {
-            const int cl = tid & 31, kp = tid >> 5;
-            float a = 0.f;
+            const int cq1 = tid & 7, kg1 = tid >> 3;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < PR_K1; ++i) a += s_h[kp * PR_K1 + i] * w1r[i];
-            s_l1[kp * 32 + cl] = a;
+            for (int i = 0; i < PR_K1; ++i) {
+                const float x = s_h[kg1 * PR_K1 + i];
+                a.x += x * w1r[i].x; a.y += x * w1r[i].y; a.z += x * w1r[i].z; a.w += x * w1r[i].w;
+            }
+            *reinterpret_cast<float4*>(&s_l1[kg1 * 32 + 4 * cq1]) = a;
         }
         __syncthreads();
         if (tid < 32) {
             float a = b1r;
 #pragma unroll
-            for (int kp = 0; kp < 16; ++kp) a += s_l1[kp * 32 + tid];
+            for (int kg = 0; kg < FS_THREADS / 8; ++kg) a += s_l1[kg * 32 + tid];
             const float y = fmaxf(a, 0.f) * (fminf(m1r, 1.f) * prx.inv_keep);
             prx.out[(long)b * prx.out_ld + 32 * cs + tid] = y;
             if (prx.out_p.base) packed_store(prx.out_p, b, 32 * cs + tid, y);
@@ -1237,11 +1306,12 @@ static int lsa_step_fwd_launch(const mstts_lsa_const* c, const float* q, int32_t
         qi = *qin; pz = *proj;
         MSTTS_REQUIRE(cs >= 8 && qi.H == 128 * QJ && lkt, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: needs >= 8 slices, H == %d and the by-unit filter", 128 * QJ);
         MSTTS_REQUIRE(qi.m1 && qi.wq && aligned16(qi.m1) && aligned16(qi.wq) && qi.m1_ld % 4 == 0, MSTTS_ERR_ALIGN, "lsa_step_fwd_qp: m1 / wq must be 16-byte aligned");
-        MSTTS_REQUIRE(pz.wp_own && pz.vp && pz.linear && pz.stop && pz.NP >= 2 && pz.NP <= 8 * PJ_OWN && pz.NM < pz.NP, MSTTS_ERR_SHAPE,
+        MSTTS_REQUIRE(pz.wp_own && aligned16(pz.wp_own) && pz.vp && pz.linear && pz.stop && pz.NP >= 2 && pz.NP <= 8 * PJ_OWN && pz.NM < pz.NP, MSTTS_ERR_SHAPE,
                       "lsa_step_fwd_qp: projection width must be 2..%d columns", 8 * PJ_OWN);
         if (pre) {
-            MSTTS_REQUIRE(pre->w0 && pre->b0 && pre->w1 && pre->b1 && pre->m0 && pre->m1 && pre->out && pre->P == PR_P && pz.NM <= 2 * PR_K0 &&
-                          pz.NM <= PR_GLD, MSTTS_ERR_SHAPE, "lsa_step_fwd_qp: in-launch prenet needs P == %d and n_mel <= %d", PR_P, 2 * PR_K0);
+            MSTTS_REQUIRE(pre->w0 && pre->b0 && pre->w1 && pre->b1 && pre->m0 && pre->m1 && pre->out && pre->P == PR_P && pz.NM <= 8 * PR_K0 &&
+                          pz.NM < PR_GLD && pz.NP == 4 * PF_Q && aligned16(pre->w0) && aligned16(pre->w1) && aligned16(pz.vp), MSTTS_ERR_SHAPE,
+                          "lsa_step_fwd_qp: in-launch prenet needs P == %d, n_mel <= %d, NP == %d and 16-byte aligned w0 / w1 / vp", PR_P, 8 * PR_K0, 4 * PF_Q);
             px.w0 = pre->w0; px.b0 = pre->b0; px.w1 = pre->w1; px.b1 = pre->b1; px.m0 = pre->m0; px.m1 = pre->m1; px.inv_keep = pre->inv_keep;
             px.out = pre->out; px.out_ld = (long)pre->out_ld;
             rc = packed_dst_from(pre->out_p.base ? &pre->out_p : nullptr, PR_P, &px.out_p, "prenet out_p"); if (rc) return rc;
@@ -1314,7 +1384,7 @@ extern "C" int32_t mstts_lsa_step_qp_supported(int64_t T, int64_t M, int64_t H, 
     return mstts_lsa_step_q_supported(T, M, H) && NP >= 2 && NP <= 8 * PJ_OWN;
 }
 extern "C" int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T) { return (B * T + 1 + B * A_ + B * PR_GLD) * 8; }
-extern "C" int32_t mstts_lsa_step_prenet_supported(int64_t P, int64_t NM) { return P == PR_P && NM >= 1 && NM <= 2 * PR_K0; }
+extern "C" int32_t mstts_lsa_step_prenet_supported(int64_t P, int64_t NM) { return P == PR_P && NM >= 1 && NM <= 8 * PR_K0 && (NM + 1 + 3) / 4 == PF_Q; }
 extern "C" int64_t mstts_lsa_proj_pack_floats(void) { return 8L * QJ * 128 * PJ_OW; }
 namespace mstts {
 __global__ void lsa_proj_pack_kernel(const float* __restrict__ wp, long ld, int NP, float* __restrict__ out) {
@@ -1325,7 +1395,7 @@ __global__ void lsa_proj_pack_kernel(const float* __restrict__ wp, long ld, int 
     out[idx] = (i < PJ_OWN && o < NP) ? wp[(long)(QJ * ch + jj) * ld + o] : 0.f;
 }
 }  // namespace mstts
-/* wp [1024, >= NP] (row stride ld) -> wp_own [8 owners][8][128][12]: owner s holds columns 11 s .. 11 s + 10 in the order its lanes read them */
+/* wp [1024, >= NP] (row stride ld) -> wp_own [8 owners][8][128][16]: owner s holds columns 11 s .. 11 s + 10 (5 zero slots) in the order its lanes read them */
 extern "C" int mstts_lsa_proj_pack(const float* wp, int64_t ld, int64_t H, int64_t NP, float* wp_own, mstts_stream_t s) {
     MSTTS_REQUIRE(wp && wp_own && H == 128 * QJ && NP >= 1 && NP <= 8 * PJ_OWN && ld >= NP, MSTTS_ERR_SHAPE, "lsa_proj_pack: needs H == %d and NP <= %d", 128 * QJ, 8 * PJ_OWN);
     const int n = 8 * QJ * 128 * PJ_OW;

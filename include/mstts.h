@@ -272,11 +272,12 @@ int64_t mstts_lsa_step_qp_ws_bytes(int64_t B, int64_t T);
 int64_t mstts_lsa_proj_pack_floats(void);
 int mstts_lsa_proj_pack(const float* wp, int64_t ld, int64_t H, int64_t NP, float* wp_own, mstts_stream_t s);
 /* optional last stage of mstts_lsa_step_fwd_qp: the prenet of the NEXT decoder step (two dense layers, relu, dropout always on -
- * Modules.py:239-255) applied to the frame this step produces, in the same launch.  The owner slices publish their frame values as
- * granules AHEAD of their context phase (the frame does not depend on the context), request the prenet's kernel rows at the same point,
- * and after the context phase each gathers the row's frame, computes the whole first layer and 32 of the 256 columns of the second.
- * w0 [n_mel, P], w1 [P, P] row-major, P == 256, n_mel <= 80 (mstts_lsa_step_prenet_supported); m0 / m1 [B, P] = the NEXT step's masks;
- * out rows [B, >= P] (stride out_ld) receive the result, out_p (base NULL = none) a copy in a fused cell's packed block. */
+ * Modules.py:239-255) applied to the frame this step produces, in the same launch and without a hand-off of its own: every slice
+ * knows the row's whole alignment, so each owner slice forms ALL n_mel + 1 outputs (sum_t a[t] vp[t, :] plus the m1 . Wp + b parts of
+ * the other owners, which travel with the query units), writes its own 11, then computes the whole first prenet layer and 32 of
+ * the 256 columns of the second.  w0 [n_mel, P], w1 [P, P] row-major and 16-byte aligned, P == 256, n_mel == 80 (NP == 84:
+ * mstts_lsa_step_prenet_supported); m0 / m1 [B, P] = the NEXT step's masks; out rows [B, >= P] (stride out_ld) receive the result,
+ * out_p (base NULL = none) a copy in a fused cell's packed block. */
 typedef struct {
     const float* w0; const float* b0; const float* w1; const float* b1;
     const uint8_t* m0; const uint8_t* m1; float inv_keep; int32_t P;

@@ -327,7 +327,10 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int tl = 4 * tg + i;
-        kv[i] = (tl < tsl && t0 + tl < T) ? c.keys[((long)b * T + t0 + tl) * A_ + k] : 0.f;
+        // (unconditional, from a clamped position: the energy of a position outside the slice is computed and never read.  A predicated
+        // load costs a branch, a zeroed default and - when the default's register still has an earlier load in flight - a wait in the
+        // middle of the request phase)
+        kv[i] = c.keys[((long)b * T + min(t0 + tl, T - 1)) * A_ + k];
     }
     float qv = 0.f;
     float4 qw[QIN ? QJ : 1], qm[QIN ? QJ / 4 : 1];
@@ -351,13 +354,12 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         const int a4 = tid & 3, ch = tid >> 2;
 #pragma unroll
         for (int jj = 0; jj < QJ; ++jj)
-            pw[jj] = (cs < 8) ? *reinterpret_cast<const float4*>(pjx.wp_own + ((long)((cs & 7) * QJ + jj) * 128 + ch) * PJ_OW + 4 * a4)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            pw[jj] = *reinterpret_cast<const float4*>(pjx.wp_own + ((long)((cs & 7) * QJ + jj) * 128 + ch) * PJ_OW + 4 * a4);   // (used under cs < 8)
         if constexpr (PRE) {                // whole frame: output pol of positions ptg + PF_G i
 #pragma unroll
             for (int i = 0; i < PF_IT; ++i) {
                 const int t = ptg + PF_G * i;
-                pvq[i] = (pv_live && t < T) ? *reinterpret_cast<const float4*>(pjx.vp + ((long)b * T + t) * (4 * PF_Q) + 4 * pol) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pvq[i] = *reinterpret_cast<const float4*>(pjx.vp + ((long)b * T + min(t, T - 1)) * (4 * PF_Q) + 4 * pol);   // (used under pv_live && t < len)
             }
             const int ob = PJ_OWN * cs + tid - 32;                 // (threads 32..42 finish m1 . Wp_m + b of the own outputs)
             if (cs < 8 && tid >= 32 && tid < 32 + PJ_OWN && ob <= pjx.NM && pjx.bias) pbias = pjx.bias[ob];
@@ -372,14 +374,14 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         }
     }
     const float sb = c.score_b[k] + c.loc_b[k], wk = c.score_w[k];
-    const float* v = c.values + (long)b * T * M + col;
+    const float* v = c.values + (long)b * T * M + (vlive ? col : 0);
     float4 vv[FS_VPRE];
 #pragma unroll
     for (int i = 0; i < FS_VPRE; ++i) {
         const int t = vg + ng * i;
         // (bounded by T, not by the row's length: `len` is itself a load, and the 12.6 MB of values must not wait for it - rows
         // between len and T are real memory and get a zero alignment below)
-        vv[i] = (vlive && t < T) ? *reinterpret_cast<const float4*>(v + (long)t * M) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[i] = *reinterpret_cast<const float4*>(v + (long)min(t, T - 1) * M);       // (used only under vlive && t < len)
     }
     // ---- own energy slice
     if (tid < FS_TSL + KS_MAX - 1 + 2) s_cum[tid] = cwin;          // entries past the window are zero
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
             const int cq0 = tid & 63, kg0 = tid >> 6, cq1 = tid & 7, kg1 = tid >> 3;
 #pragma unroll
             for (int i = 0; i < PR_K0; ++i)
-                w0r[i] = (kg0 * PR_K0 + i < pjx.NM) ? *reinterpret_cast<const float4*>(prx.w0 + (long)(kg0 * PR_K0 + i) * PR_P + 4 * cq0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                w0r[i] = *reinterpret_cast<const float4*>(prx.w0 + (long)min(kg0 * PR_K0 + i, pjx.NM - 1) * PR_P + 4 * cq0);   // (rows past NM meet a zero factor)
 #pragma unroll
             for (int i = 0; i < PR_K1; ++i) w1r[i] = *reinterpret_cast<const float4*>(prx.w1 + (long)(kg1 * PR_K1 + i) * PR_P + 32 * cs + 4 * cq1);
             if (tid < PR_P) { b0r = prx.b0[tid]; m0r = (float)prx.m0[(long)b * PR_P + tid]; }

@@ -283,7 +283,7 @@ def test_lsa_step_fwd_q(dev, B, T, bf16):
         assert rel_err(t2n(pj[:, H:]), t2n(cx)) < 1e-5                                  # second context destination (the projection input rows)
         assert rel_err(t2n(lin), t2n(ref[:, :NM])) < 1e-5 and rel_err(t2n(stop), t2n(ref[:, NM])) < 1e-5
     # self-test form: slice 3 missing -> the other owners still produce their outputs (from recomputed energies), outputs 33..43 stay unwritten
-    # (the prenet of the other owners then needs the missing 11 frame values: recomputed from the row's alignment, lsa_frame_serial)
+    # (the other owners then lack the missing slice's m1 . Wp + b values for their copy of the frame: recomputed, lsa_pm_serial)
     lin3, stop3 = torch.full((B, NM), 7.0, device=dev), torch.full((B,), 7.0, device=dev)
     pre3 = torch.full((B, pre_ld), 7.0, device=dev)
     pn.out = lib.ptr(pre3)

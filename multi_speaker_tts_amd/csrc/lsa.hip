@@ -332,7 +332,7 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         // middle of the request phase)
         kv[i] = c.keys[((long)b * T + min(t0 + tl, T - 1)) * A_ + k];
     }
-    float qv = 0.f;
+    float qv = 0.f, pre0[4];
     float4 qw[QIN ? QJ : 1], qm[QIN ? QJ / 4 : 1];
     if constexpr (QIN) {                 // thread (a4 = tid & 3, chunk = tid >> 2): units 16 cs + 4 a4 .. + 3, hidden units 8 chunk .. + 7
         const int a4 = tid & 3, ch = tid >> 2;
@@ -429,6 +429,19 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
             s_q[16 * cs + tid] = qa;
             __hip_atomic_store(gq + 16 * cs + tid, ((unsigned long long)epoch << 32) | __float_as_uint(qa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // the part of the pre-activation that does not need the query (keys + filter . cumulative alignment) while the granules travel
+        {
+            float cw[4 + KS_MAX - 1];
+#pragma unroll
+            for (int i = 0; i < 4 + KS_MAX - 1; ++i) cw[i] = s_cum[4 * tg + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float pre = kv[i] + sb;
+#pragma unroll
+                for (int j = 0; j < KS_MAX; ++j) pre += cw[i + j] * lk[j];
+                pre0[i] = pre;
+            }
+        }
         if constexpr (PROJ && !PRE) {                            // m1 . Wp_m for the own outputs, reduced like the query units
             if (cs < 8) {
                 float a3[4] = {0.f, 0.f, 0.f, 0.f};
@@ -500,20 +513,23 @@ __global__ __launch_bounds__(FS_THREADS) void lsa_step_kernel(mstts_lsa_const c,
         }
     }
     if (q_sum && cs == 0 && tg == 0) q_sum[(long)b * A_ + k] = qv;
-    if constexpr (!QIN) __syncthreads();
-    {
+    if constexpr (!QIN) {
+        __syncthreads();
         float cw[4 + KS_MAX - 1];
 #pragma unroll
         for (int i = 0; i < 4 + KS_MAX - 1; ++i) cw[i] = s_cum[4 * tg + i];
-        const float qk = qv + sb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float pre = kv[i] + qk;
+            float pre = kv[i] + sb;
 #pragma unroll
             for (int j = 0; j < KS_MAX; ++j) pre += cw[i + j] * lk[j];
-            float e = wave_sum(wk * fast_tanh(pre));
-            if (lane == 0) s_red[4 * tg + i][(tid >> 6) & 1] = e;
+            pre0[i] = pre;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float e = wave_sum(wk * fast_tanh(pre0[i] + qv));
+        if (lane == 0) s_red[4 * tg + i][(tid >> 6) & 1] = e;
     }
     __syncthreads();
     gu64* g = (gu64*)(gran + (long)b * T);

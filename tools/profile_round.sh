@@ -5,6 +5,7 @@
 #   3. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE (HBM-side traffic per kernel), then
 #      SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE (matrix-core busy) - all at the FULL config-2 size
 #   4. Audio.melspectrogram timing + its kernel rows
+#   5. free-running decoder (tools/infer_bench.py) timing + its kernel rows
 # Outputs land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -28,5 +29,8 @@ python $ROOT/tools/pmc_summary.py $OUT/pmc_mfma_busy_per_kernel.csv $OUT/pmcm_SQ
 python $ROOT/tools/stft_bench.py > $OUT/stft_mel_line.json 2> $OUT/stft.err
 rocprofv3 --kernel-trace -d $OUT/kt_stft -o kt -- python $ROOT/tools/stft_bench.py > $OUT/kt_stft.log 2>&1
 python $ROOT/tools/rocpd_stats.py $OUT/kt_stft/kt_results.db $OUT/stft_mel_kernel_stats.csv
-rm -rf $OUT/kt $OUT/kt3 $OUT/kt_stft $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcm_*
+python $ROOT/tools/infer_bench.py > $OUT/infer_line.txt 2> $OUT/infer.err
+rocprofv3 --kernel-trace -d $OUT/kt_inf -o kt -- python $ROOT/tools/infer_bench.py > $OUT/kt_inf.log 2>&1
+python $ROOT/tools/rocpd_stats.py $OUT/kt_inf/kt_results.db $OUT/infer_kernel_stats.csv
+rm -rf $OUT/kt $OUT/kt3 $OUT/kt_stft $OUT/kt_inf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcm_*
 ls -la $OUT

@@ -63,9 +63,10 @@ class InferEngine:
         call("mstts_bn_infer_fwd", ptr(a), ptr(g, og), ptr(be, obe), ptr(mm, omm), ptr(mv, omv), ptr(y), BN_EPS, rows, cout)
         return y
 
-    def _lstm_seq(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, lengths=None, reverse=0, residual=None, zc=None, zh=None):
-        """One ZoneoutLSTMCell over a sequence: inference mode without masks (0.9*new + 0.1*old), training-mode zoneout with
-        keep-masks zc / zh [T, B, H] (ZoneoutLSTMCell.py:259-271)."""
+    def _lstm_seq_desc(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, lengths=None, reverse=0, residual=None, zc=None, zh=None):
+        """Descriptor of one ZoneoutLSTMCell over a sequence: inference mode without masks (0.9*new + 0.1*old), training-mode zoneout
+        with keep-masks zc / zh [T, B, H] (ZoneoutLSTMCell.py:259-271).  Where the fused cell step covers the shape (no residual) the
+        packed recurrent kernel and packed h blocks are attached, so every step is one launch."""
         k, ok = self.P(cell_prefix + "kernel"); b, ob = self.P(cell_prefix + "bias")
         xw = self._f(B * T, 4 * H)
         gemm(x, k, xw, B * T, 4 * H, cin, cin, 4 * H, 4 * H, bias=b, b_off=ok, bias_off=ob)
@@ -81,8 +82,23 @@ class InferEngine:
         q.out = ptr(out, out_off); q.out_sb = out_sb; q.out_st = out_st
         ch, hh = self._f(T + 1, B, H), self._f(T + 1, B, H)
         q.c_hist, q.h_hist = ptr(ch), ptr(hh)
-        q.gates_ws = ptr(self._f(int(lib.load().mstts_lstm_seq_ws_floats(B, H, 0))))
-        call("mstts_lstm_seq_fwd", C.byref(q))
+        L_ = lib.load()
+        q.gates_ws = ptr(self._f(int(L_.mstts_lstm_seq_ws_floats(B, H, 0))))
+        if residual is None and L_.mstts_cell_fwd_supported(H, H):
+            whp = self._f(H * 4 * H)             # (packed per call: the parameters may have been reloaded in between; 1 small launch)
+            call("mstts_pack_cell_fwd", ptr(k, ok + cin * 4 * H), 4 * H, ptr(whp), H, H)
+            q.wh_p, q.h_p = ptr(whp), ptr(self._f(2 * int(L_.mstts_cell_act_floats(B, H))))
+        return q
+
+    def _lstm_seq(self, *a, **kw):
+        call("mstts_lstm_seq_fwd", C.byref(self._lstm_seq_desc(*a, **kw)))
+
+    def _bilstm_seq(self, x, B, T, cin, H, cell_fmt, out, out_sb, out_st, lengths=None):
+        """Forward and backward direction of a bidirectional layer advancing together: one launch per step where the fused form applies
+        (mstts_lstm_seq_fwd_pair falls back to two sequential loops otherwise)."""
+        qs = [self._lstm_seq_desc(x, B, T, cin, H, cell_fmt % dr, out, out_sb, out_st, out_off=di * H, lengths=lengths, reverse=di)
+              for di, dr in enumerate(("fw", "bw"))]
+        call("mstts_lstm_seq_fwd_pair", C.byref(qs[0]), C.byref(qs[1]))
 
     # ------------------------------------------------------------------ sub-graphs
     def speaker_embedding(self, spk_mel, masks=None):
@@ -117,8 +133,7 @@ class InferEngine:
             x = self._conv_bn(x, B * T, T, cin, d.enc_conv_ch, d.enc_conv_k, "encoder/conv_%d/" % i, ACT_RELU)
             cin = d.enc_conv_ch
         values = self._f(B, T, M)
-        for di, dr in enumerate(("fw", "bw")):
-            self._lstm_seq(x, B, T, cin, He, ENC_CELL % dr, values, T * M, M, out_off=di * He, lengths=token_length, reverse=di)
+        self._bilstm_seq(x, B, T, cin, He, ENC_CELL, values, T * M, M, lengths=token_length)
         call("mstts_speaker_tile", ptr(spk), ptr(token_length), ptr(values), B, T, M, 2 * He, d.spk)
         keys = self._f(B, T, d.att)
         wm, owm = self.P("attention/memory_layer/kernel")
@@ -251,8 +266,7 @@ class InferEngine:
             call("mstts_highway_combine", ptr(hp_), ptr(tp_), ptr(x), ptr(y), rows * d.n_mel)
             x = y
         rnn = self._f(B, S, 2 * d.birnn)
-        for di, dr in enumerate(("fw", "bw")):
-            self._lstm_seq(x, B, S, d.n_mel, d.birnn, VOC_CELL % dr, rnn, S * 2 * d.birnn, 2 * d.birnn, out_off=di * d.birnn, reverse=di)
+        self._bilstm_seq(x, B, S, d.n_mel, d.birnn, VOC_CELL, rnn, S * 2 * d.birnn, 2 * d.birnn)
         spec = self._f(rows, d.n_spec)
         self._dense(rnn, rows, 2 * d.birnn, d.n_spec, VOC + "dense/kernel", VOC + "dense/bias", spec)
         return spec.view(B, S, d.n_spec)

@@ -23,3 +23,14 @@ for it in range(2):
     lin, stop, al, n = eng.decode(values, keys, t(lens), seed=1, max_steps=S)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("decode: %d steps, batch %d: %.1f ms  (%.1f us/step, %.0f mel-frames/s)" % (n, B, dt * 1e3, dt / n * 1e6, B * n / dt))
+# whole inference forward of BASELINE configs[3] (speaker encoder on 5 x 64-frame mels per utterance, text encoder, free-running decoder to
+# max_steps, postnet, Taco1 mel -> spectrogram), results copied to the host as MSTTS_SV.Inference does
+spk_mel = g.normal(0, 1, (5 * B, 64, d.n_mel)).astype(np.float32)
+pattern = {"Token": tok, "Token_Length": lens, "Speaker_Embedding_Mel": spk_mel}
+for it in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = eng.forward(pattern, seed=1, max_steps=S, with_vocoder=True)
+    dt = time.perf_counter() - t0
+    n = res["Linear"].shape[1]
+    print("forward (speaker encoder + Tacotron2 + Taco1 vocoder, host copies included): %d frames x batch %d: %.1f ms  (%.0f mel-frames/s)"
+          % (n, B, dt * 1e3, B * n / dt))

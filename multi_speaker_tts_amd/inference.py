@@ -90,8 +90,16 @@ class InferEngine:
             q.wh_p, q.h_p = ptr(whp), ptr(self._f(2 * int(L_.mstts_cell_act_floats(B, H))))
         return q
 
-    def _lstm_seq(self, *a, **kw):
-        call("mstts_lstm_seq_fwd", C.byref(self._lstm_seq_desc(*a, **kw)))
+    def _lstm_seq(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, residual=None, **kw):
+        # residual wrapper (output = cell output + input, state untouched): with a dense [B, T, H] output the fused steps run without it
+        # and one add over the whole sequence follows - the same fp32 sum, 2 launches per step less
+        post_add = (residual is not None and out_off == 0 and out_st == H and out_sb == T * H and
+                    bool(lib.load().mstts_cell_fwd_supported(H, H)))
+        dst = self._f(B, T, H) if post_add else out
+        q = self._lstm_seq_desc(x, B, T, cin, H, cell_prefix, dst, out_sb, out_st, out_off=out_off, residual=None if post_add else residual, **kw)
+        call("mstts_lstm_seq_fwd", C.byref(q))
+        if post_add:
+            call("mstts_add", ptr(dst), ptr(residual), ptr(out), B * T * H)
 
     def _bilstm_seq(self, x, B, T, cin, H, cell_fmt, out, out_sb, out_st, lengths=None):
         """Forward and backward direction of a bidirectional layer advancing together: one launch per step where the fused form applies

@@ -82,6 +82,11 @@ class SpeakerTrainEngine:
         w.zh = [torch.zeros(T * N * H, dtype=torch.uint8, device=self.device) for _ in range(L)]
         lb = lib.load()
         w.gates = f(int(lb.mstts_lstm_seq_ws_floats(N, H, 0))); w.bwd_ws = f(int(lb.mstts_lstm_seq_ws_floats(N, H, 1)))
+        # fused cell steps (one launch per step): packed recurrent kernel + packed h blocks; the residual wrapper's sum (output = cell
+        # output + input, state untouched) is then applied once per sequence
+        w.fused = bool(lb.mstts_cell_fwd_supported(H, H)) and d.spk == H
+        if w.fused:
+            w.whp, w.hp, w.y = f(H * 4 * H), f(2 * int(lb.mstts_cell_act_floats(N, H))), f(N, T, H)
         w.lengths = torch.full((N,), T, dtype=torch.int32, device=self.device)
         w.loss_ws = f(int(lb.mstts_ge2e_ws_floats(N, d.spk, 256)))
         w.out3 = f(4)
@@ -114,11 +119,17 @@ class SpeakerTrainEngine:
             q.xw = ptr(w.xw); q.wh = ptr(k, ok + d.spk * 4 * H); q.wh_ld = 4 * H
             q.lengths = ptr(w.lengths); q.reverse = 0; q.zoneout = d.zoneout
             q.zc, q.zh = ptr(w.zc[i]), ptr(w.zh[i])
-            q.residual = ptr(w.x[i]) if i < d.spk_lstm_n - 1 else None
-            q.out = ptr(w.x[i + 1]); q.out_sb = T * H; q.out_st = H
+            res = i < d.spk_lstm_n - 1
+            q.residual = ptr(w.x[i]) if (res and not w.fused) else None
+            q.out = ptr(w.y if (res and w.fused) else w.x[i + 1]); q.out_sb = T * H; q.out_st = H
             q.c_hist, q.h_hist, q.acts, q.c_raw = ptr(w.c[i]), ptr(w.h[i]), ptr(w.acts[i]), ptr(w.craw[i])
             q.gates_ws = ptr(w.gates)
+            if w.fused:
+                call("mstts_pack_cell_fwd", ptr(k, ok + d.spk * 4 * H), 4 * H, ptr(w.whp), H, H)
+                q.wh_p, q.h_p = ptr(w.whp), ptr(w.hp)
             call("mstts_lstm_seq_fwd", C.byref(q))
+            if res and w.fused:
+                call("mstts_add", ptr(w.y), ptr(w.x[i]), ptr(w.x[i + 1]), N * T * H)
         return w.x[-1]
 
     def loss_and_backward(self, w, batch_per_speaker):

@@ -95,7 +95,13 @@ class Taco1TrainEngine:
         w.zc = {dr: torch.zeros(S * B * Hh, dtype=torch.uint8, device=self.device) for dr in ("fw", "bw")}
         w.zh = {dr: torch.zeros(S * B * Hh, dtype=torch.uint8, device=self.device) for dr in ("fw", "bw")}
         lb = lib.load()
-        w.gates = f(int(lb.mstts_lstm_seq_ws_floats(B, Hh, 0))); w.bwd_ws = f(int(lb.mstts_lstm_seq_ws_floats(B, Hh, 1)))
+        w.gates = f(int(lb.mstts_lstm_seq_ws_floats(B, Hh, 0)))
+        w.bwd_ws = {dr: f(int(lb.mstts_lstm_seq_ws_floats(B, Hh, 1))) for dr in ("fw", "bw")}
+        # fused cell steps (one launch per step for both directions): packed recurrent kernels + packed h blocks
+        w.fused = bool(lb.mstts_cell_fwd_supported(Hh, Hh))
+        if w.fused:
+            w.whp = {dr: f(Hh * 4 * Hh) for dr in ("fw", "bw")}
+            w.hp = {dr: f(2 * int(lb.mstts_cell_act_floats(B, Hh))) for dr in ("fw", "bw")}
         w.rnn = f(rows, 2 * Hh)
         w.pred, w.d_pred = f(rows, d.n_spec), f(rows, d.n_spec)
         w.lengths = torch.full((B,), S, dtype=torch.int32, device=self.device)
@@ -176,6 +182,7 @@ class Taco1TrainEngine:
                 gemm(w.hx[i], kk, out, rows, d.n_mel, d.n_mel, d.n_mel, d.n_mel, d.n_mel, bias=b, b_off=ok, bias_off=ob)
             call("mstts_highway_combine", ptr(w.hh[i]), ptr(w.ht[i]), ptr(w.hx[i]), ptr(w.hx[i + 1]), rows * d.n_mel)
         x = w.hx[d.highway_n]
+        seqs = []
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(BIRNN % dr + "kernel"); b, ob = self.P(BIRNN % dr + "bias")
             gemm(x, k, w.xw[dr], rows, 4 * Hh, d.n_mel, d.n_mel, 4 * Hh, 4 * Hh, bias=b, b_off=ok, bias_off=ob)
@@ -187,7 +194,11 @@ class Taco1TrainEngine:
             q.out = ptr(w.rnn, di * Hh); q.out_sb = S * 2 * Hh; q.out_st = 2 * Hh
             q.c_hist, q.h_hist, q.acts, q.c_raw = ptr(w.c[dr]), ptr(w.h[dr]), ptr(w.acts[dr]), ptr(w.craw[dr])
             q.gates_ws = ptr(w.gates)
-            call("mstts_lstm_seq_fwd", C.byref(q))
+            if w.fused:
+                call("mstts_pack_cell_fwd", ptr(k, ok + d.n_mel * 4 * Hh), 4 * Hh, ptr(w.whp[dr]), Hh, Hh)
+                q.wh_p, q.h_p = ptr(w.whp[dr]), ptr(w.hp[dr])
+            seqs.append(q)
+        call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together
         kk, ok = self.P(VOC + "dense/kernel"); b, ob = self.P(VOC + "dense/bias")
         gemm(w.rnn, kk, w.pred, rows, d.n_spec, 2 * Hh, 2 * Hh, d.n_spec, d.n_spec, bias=b, b_off=ok, bias_off=ob)
         return w.pred
@@ -210,6 +221,7 @@ class Taco1TrainEngine:
         # BiLSTM
         x_in = w.hx[d.highway_n]
         dy = w.dx[0]
+        bseqs = []
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(BIRNN % dr + "kernel")
             q = lib.LstmSeqBwd()
@@ -219,8 +231,11 @@ class Taco1TrainEngine:
             q.zc, q.zh = ptr(w.zc[dr]), ptr(w.zh[dr])
             q.d_out = ptr(w.d_rnn, di * Hh); q.dout_sb = S * 2 * Hh; q.dout_st = 2 * Hh
             q.c_hist, q.acts, q.c_raw = ptr(w.c[dr]), ptr(w.acts[dr]), ptr(w.craw[dr])
-            q.dgates_step, q.dgates_pos, q.ws = ptr(w.dgs[dr]), ptr(w.dgp[dr]), ptr(w.bwd_ws)
-            call("mstts_lstm_seq_bwd", C.byref(q))
+            q.dgates_step, q.dgates_pos, q.ws = ptr(w.dgs[dr]), ptr(w.dgp[dr]), ptr(w.bwd_ws[dr])
+            bseqs.append(q)
+        call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))
+        for di, dr in enumerate(("fw", "bw")):
+            k, ok = self.P(BIRNN % dr + "kernel")
             gk, ogk = self.G(BIRNN % dr + "kernel"); gb, ogb = self.G(BIRNN % dr + "bias")
             gemm(x_in, w.dgp[dr], gk, d.n_mel, 4 * Hh, rows, d.n_mel, 4 * Hh, 4 * Hh, trans_a=True,
                  split_k=max(2, _split_k(d.n_mel, 4 * Hh, rows)), c_off=ogk)

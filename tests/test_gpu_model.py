@@ -589,6 +589,44 @@ def test_full_size_config2_properties(dev):
     assert rel_err(t2n(w2.linear), t2n(lin_a)) < 1e-4
 
 
+def test_full_size_config3_properties(dev):
+    """BASELINE config 3's per-GPU workload at its full size (batch 32 x 128 tokens x 800 frames, bf16 operands with fp32 accumulation,
+    fp32 master weights / gradients / Adam): the same size-independent properties as config 2, plus closeness of its forward to the
+    fp32 engine's on the same inputs and masks (the north_star tolerance is quoted for fp32; bf16 operands 801 steps deep stay
+    within a few per cent of the mel range)."""
+    import bench
+    from multi_speaker_tts_amd import engine as E
+    from multi_speaker_tts_amd.params import Dims
+    d = Dims()
+    eng = TrainEngine(d, device=dev, seed=1, recurrent_dtype="bf16", gemm_dtype="bf16")
+    assert eng.bf is not None
+    batch = bench.synthetic_batch(d, 32, 128, 800, 1, 0, dev)
+    losses = []
+    for i in range(4):
+        w = eng.train_step(batch)
+        torch.cuda.synchronize()
+        s = eng.scalars(w)
+        losses.append(s["Loss"])
+        assert all(np.isfinite(v) for v in s.values()), s
+        assert bool(torch.isfinite(eng.params.grad).all()) and bool(torch.isfinite(eng.params.train).all())
+        assert bool(torch.isfinite(w.mel_out).all()) and bool(torch.isfinite(w.align_hist).all())
+        assert eng.exchange_timeouts(w) == 0
+        assert len(eng._plans) <= E.MAX_PLANS
+    assert w.mel_out.shape == (32, 801, 80) and losses[-1] < losses[0], losses
+    a = t2n(w.align_hist)
+    assert np.abs(a.sum(-1) - 1.0).max() < 1e-4 and a.min() >= 0.0
+    # the master weights stay fp32: the bf16 engine and an fp32 engine started from the same seed hold identical variables before a step
+    e16 = TrainEngine(d, device=dev, seed=3, recurrent_dtype="bf16", gemm_dtype="bf16")
+    e32 = TrainEngine(d, device=dev, seed=3)
+    assert torch.equal(e16.params.train, e32.params.train)
+    w16, w32 = e16.plan(32, 128, 800), e32.plan(32, 128, 800)
+    e16.forward(batch, w16, seed=7)
+    lin16 = w16.linear.clone()
+    e32.forward(batch, w32, seed=7)
+    torch.cuda.synchronize()
+    assert rel_err(t2n(lin16), t2n(w32.linear)) < 5e-2
+
+
 @pytest.mark.parametrize("B,Te,L,kw", [(5, 18, 9, MID), (32, 24, 6, dict(dec_lstm=1024, enc_lstm=256, spk=256, prenet=256, n_mel=80))])
 def test_train_step_parity_bf16_recurrent(dev, monkeypatch, B, Te, L, kw):
     """BASELINE config 3 ("bf16 with fp32 master"): the decoder's recurrent products run on packed bf16 copies of the fp32

@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel-argument blocks in device memory (the runtime's default here; see multi_speaker_tts_amd/__init__.py)
+
 import numpy as np
 import torch
 

@@ -15,4 +15,10 @@ at the reference's call sites.  What IS pinned exactly: the integer contracts de
 reference data (Token_Index_Dict.json, Inference_Sentence_in_Train.txt tokenisation, speaker-window
 arithmetic, STFT framing constants, LR schedule constants) - see tests/test_kats.py.  Two
 independent restatements (NumPy fp64 in ``np_ops`` and torch in ``model``) cross-check each other.
+The library semantics that have an independent implementation in this image are additionally pinned
+to it (tests/test_cpu_thirdparty_pins.py): scipy.signal.lfilter (the reference's own pre-emphasis
+call) / get_window / istft, torch.stft / istft / conv1d('same') / batch_norm / nn.LSTM incl. packed
+bidirectional sequences / optim.Adam / loss functionals, transformers' Slaney mel filter bank,
+pyarrow's snappy codec.  That narrows what "unpinned" covers - the attention, zoneout, decoder
+wiring, GE2E and WaveGlow restatements - it does not lift it: the reference itself never ran here.
 """

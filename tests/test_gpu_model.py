@@ -589,6 +589,40 @@ def test_full_size_config2_properties(dev):
     assert rel_err(t2n(w2.linear), t2n(lin_a)) < 1e-4
 
 
+def test_full_size_backward_is_linear_in_the_loss_scale(dev):
+    """Size-independent property of the whole backward pass at BASELINE config 2's full size: BPTT, the attention backward, every
+    hoisted weight-gradient product and the batch-norm backward are linear in the incoming loss gradient, so scaling the loss by a
+    power of two (exact in fp32) scales every one of the 30 M gradient elements by it - up to the order of the atomic split-K sums."""
+    import bench
+    from multi_speaker_tts_amd.params import Dims
+    d = Dims()
+    eng = TrainEngine(d, device=dev, seed=5)
+    batch = bench.synthetic_batch(d, 32, 128, 800, 5, 0, dev)
+    w = eng.plan(32, 128, 800)
+    eng.forward(batch, w, seed=11)
+    eng.loss_and_backward(w, grad_scale=1.0)
+    g1 = eng.params.grad.clone()
+    eng.loss_and_backward(w, grad_scale=0.25)
+    torch.cuda.synchronize()
+    g2 = eng.params.grad
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    # per variable: |g2 - g1 / 4| against that variable's own largest gradient
+    ps = eng.params
+    for name, shape, _ in ps.table:
+        if not ps.trainable[name]:
+            continue
+        off, n = ps.offset[name], int(np.prod(shape))
+        a, b = g1[off:off + n], g2[off:off + n]
+        scale = float(a.abs().max())
+        assert scale > 0 or "moving_" in name, name                 # every trainable variable receives a gradient
+        # 1-D variables (biases, BN offsets) are sums over all 25 632 rows of terms that largely cancel, accumulated by atomic adds in
+        # varying order: their rounding residue is relative to the sum of magnitudes, not to the (much smaller) sum
+        tol = 1e-3 if len(shape) == 1 else 2e-5
+        assert float((b - 0.25 * a).abs().max()) <= tol * scale, name
+    assert float((g2 - 0.25 * g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+    assert eng.exchange_timeouts(w) == 0
+
+
 def test_full_size_config3_properties(dev):
     """BASELINE config 3's per-GPU workload at its full size (batch 32 x 128 tokens x 800 frames, bf16 operands with fp32 accumulation,
     fp32 master weights / gradients / Adam): the same size-independent properties as config 2, plus closeness of its forward to the

@@ -812,6 +812,42 @@ def test_inference_decode_full_width(dev):
     assert rel_err(got["Attention_History"], t2n(ref["Attention_History"])) < 1e-3
 
 
+def test_inference_rows_are_independent_of_their_batch(dev):
+    """Size-independent property of the free-running forward (BASELINE config 4's shape: 16 utterances, texts up to 128 tokens, reference
+    widths): a row decoded alone gives what it gives inside the batch - memory masking (Modules.py:87-93), the -inf score mask, the
+    length-reversed encoder direction and the batch-norm inference path leave no trace of the other rows.  (The padded token columns
+    are kept: the encoder convolutions are not length-aware in the reference, Modules.py:29-36, so a row's result does depend on its
+    own padding.)  The two runs take different launch geometries (batch 16 vs batch 1)."""
+    from multi_speaker_tts_amd.inference import InferEngine
+    pd, od = dims_pair(dec_lstm=1024, prenet=256, enc_lstm=256, spk=256, n_mel=80, max_inf=39)
+    B, Te = 16, 128
+    values = OM.init_params(od, 21)
+    g = np.random.default_rng(8)
+    for k in values:
+        if k.endswith(("bias", "beta")) and "highway" not in k:
+            values[k] = g.normal(0, 0.1, values[k].shape)
+    values["decoder/decoder/linear_projection/dense/bias"][-1] = -8.0           # nobody stops early: 40 steps for every row
+    tok = g.integers(2, od.n_tok, size=(B, Te)).astype(np.int32)
+    lengths = np.concatenate([[Te, 2], g.integers(3, Te, B - 2)]).astype(np.int32)
+    for b in range(B):
+        tok[b, 0] = 0; tok[b, lengths[b] - 1] = 1; tok[b, lengths[b]:] = 1    # <S> ... <E>, padded with <E> like the feeder
+    spk = g.normal(0, 1, (B, od.spk)); spk = (spk / np.sqrt((spk ** 2).sum())).astype(np.float32)
+    masks = {k: v.numpy() for k, v in OT.make_masks(od, B, Te, od.max_inf + 1, False, seed=5).items()}
+    eng = InferEngine(pd, device=dev, values=values)
+    full = eng.forward({"Token": tok, "Token_Length": lengths, "Speaker_Embedding": spk}, masks=masks, with_vocoder=False)
+    assert full["Linear"].shape == (B, od.max_inf + 1, od.n_mel) and np.isfinite(full["Mel"]).all()
+    for b in (0, 1, 5, 15):
+        n = int(lengths[b])
+        one = eng.forward({"Token": tok[b:b + 1].copy(), "Token_Length": lengths[b:b + 1].copy(), "Speaker_Embedding": spk[b:b + 1].copy()},
+                          masks={k: np.ascontiguousarray(np.take(v, [b], axis=OT.mask_batch_axis(k))) for k, v in masks.items()}, with_vocoder=False)
+        assert rel_err(one["Linear"][0], full["Linear"][b]) < 1e-3, b
+        assert rel_err(one["Mel"][0], full["Mel"][b]) < 1e-3, b
+        assert full["Attention_History"].shape == (B, Te, od.max_inf + 1)                    # [row, token, step]
+        assert np.abs(one["Attention_History"][0] - full["Attention_History"][b]).max() < 1e-3, b
+        assert np.abs(full["Attention_History"][b][n:, :]).max(initial=0.0) == 0.0, b      # no weight on the padding
+        assert np.abs(full["Attention_History"][b].sum(0) - 1.0).max() < 1e-4, b
+
+
 def test_speaker_encoder_training_zoneout(dev):
     """The frozen speaker encoder inside a TRAIN step runs with stochastic zoneout (the reference feeds Is_Training into it,
     MSTTS_SV.py:49-56): HIP forward with Philox masks drawn on the device vs the oracle's training-mode speaker encoder."""

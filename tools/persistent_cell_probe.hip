@@ -8,22 +8,32 @@
 // (4 units x 4 gates) of a [2048, 4096] kernel, reads the whole activation block with agent-scope loads, multiplies, applies an
 // LSTM-like epilogue and writes its 32 x 4 outputs write-through into the other buffer's columns 4w .. 4w+3 (the h half of the next
 // stage's input); columns 1024 .. 2047 stay constant (the x half).  Results are checked against a host fp64 recurrence.
-// Three ways to read what the other workgroups wrote: agent-scope loads (past the XCD's L2), an L2 invalidate per round + plain loads,
-// a ring of eight buffers with an L2 invalidate every eighth round.
-// Measured (MI355X, round 2): 11.4-11.8 us per stage with agent-scope loads (9.4-9.9 without the barrier), 18-19 us with an invalidate
-// per round, 12.4-12.5 us with the ring - against 12.1-12.7 us for today's launch per cell step.  The weights stop moving, but every
-// workgroup then has to pull the whole fresh activation block instead (64 MB per stage over the chip, from beyond its own L2), and
-// that costs what the weight stream cost.  (All 64 float4 of a wave in flight at once needs 256 VGPRs of inline-asm destinations -
-// the arch-VGPR limit - and was both wrong and slower.)  A persistent decoder loop is NOT the next step at 32 rows per GPU.
+// Two ways to read what the other workgroups wrote: agent-scope loads (past the XCD's L2), or a ring of eight buffers with plain
+// loads and an L2 invalidate every eighth round.  -DNWAVES=8 builds the 8-wave form (K split eight ways).
+// Measured (MI355X, round 2), per stage, barrier included:
+//   activation block row-major (a wave load touches 16 rows 8 KB apart - the same L2 channel):  11.4-12.2 us
+//   activation block PACKED (a wave load = one contiguous 1 KB, what the production cells use):   8.4 us  (6.5 without the barrier);
+//   ring + plain loads 9.3-10.2 us; 4 or 8 waves make no difference.
+// Today's launch per cell step costs 12.1-12.7 us: a persistent, weights-stationary loop would take about 3.8 us off every cell
+// stage (and the BPTT's pointwise launches would disappear into its stages).  It needs the attention step as a third stage of the
+// same kernel and one cell's slice in registers (246 KB of kernel per CU against 160 KB of LDS) - the next round's first item.
 //   hipcc --offload-arch=gfx950 -O3 tools/persistent_cell_probe.hip -o /tmp/pcp && /tmp/pcp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int WG = 256, TH = 256, ROWS = 32, K = 2048, HU = 1024;      // HU: units = columns rewritten per round
-constexpr int KW = K / 4;                                               // reduction slice of a wave
-constexpr int NCH = KW / 16;                                            // 16-deep chunks per wave (32)
+#ifndef NWAVES
+#define NWAVES 4
+#endif
+constexpr int WG = 256, NWV = NWAVES, TH = 64 * NWV, ROWS = 32, K = 2048, HU = 1024;      // HU: units = columns rewritten per round
+constexpr int KW = K / NWV;                                             // reduction slice of a wave
+constexpr int NCH = KW / 16;                                            // 16-deep chunks per wave (32 with 4 waves, 16 with 8)
+
+// element (row, k) of the [32, K] activation block in the packed order
+__host__ __device__ inline long apos(int row, int k) {
+    return ((((long)(k / KW) * NCH + (k % KW) / 16) * 2 + row / 16) * 256) + (((k % 16) / 4) * 16 + row % 16) * 4 + k % 4;
+}
 
 __device__ __forceinline__ void grid_barrier(unsigned long long* counter, int wg, int r) {
     const int x = wg & 7;
@@ -45,7 +55,7 @@ __device__ __forceinline__ void grid_barrier(unsigned long long* counter, int wg
 // act: two buffers [ROWS][K]; W: [K][16 * WG] row-major (column 16 w + 4 q + u = gate q of unit 4 w + u)
 __global__ __launch_bounds__(TH) void persistent_kernel(float* act, const float* __restrict__ W, unsigned long long* counter, int rounds, int with_barrier, int inv_mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];        // [4 waves][NCH][64 lanes][4] weights = 128 KB, then [4][32][17] reduce
-    float* red = smem + 4 * NCH * 256;
+    float* red = smem + NWV * NCH * 256;
     const int wg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
     // ---- once: this workgroup's kernel slice into LDS in consumption order: (wave, chunk, lane) -> W[wave*KW + 16*chunk + 4*kq + e][16*wg + j]
@@ -62,8 +72,9 @@ __global__ __launch_bounds__(TH) void persistent_kernel(float* act, const float*
         float* dst = act + (long)(r & ring) * ROWS * K;
         // ---- activation rows j and 16 + j, this wave's K slice, 16 bytes per lane and chunk, in four batches of 8 chunks
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        const float* a0 = src + (long)j * K + wave * KW + 4 * kq;
-        const float* a1 = a0 + 16L * K;
+        // packed block (as the production cells use): a wave's load instruction covers one contiguous 1 KB
+        const float* a0 = src + (long)(wave * NCH) * 512 + lane * 4;
+        const float* a1 = a0 + 256;
         // software pipeline: batch b + 1 (8 chunks = 16 loads) is requested before batch b is multiplied; loads return in order, so
         // vmcnt(16) means "everything but the newest batch has arrived".  The waits name the registers they release, so that no MFMA
         // can be scheduled ahead of them.
@@ -71,11 +82,11 @@ __global__ __launch_bounds__(TH) void persistent_kernel(float* act, const float*
 #define PCP_ISSUE(buf, b)                                                                                                   \
         _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                      \
             if (inv_mode) {                                                                                                  \
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pa[buf][c]) : "v"(a0 + 16 * (8 * (b) + c)) : "memory");     \
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pb[buf][c]) : "v"(a1 + 16 * (8 * (b) + c)) : "memory");     \
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pa[buf][c]) : "v"(a0 + 512 * (8 * (b) + c)) : "memory");     \
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pb[buf][c]) : "v"(a1 + 512 * (8 * (b) + c)) : "memory");     \
             } else {                                                                                                         \
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pa[buf][c]) : "v"(a0 + 16 * (8 * (b) + c)) : "memory"); \
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pb[buf][c]) : "v"(a1 + 16 * (8 * (b) + c)) : "memory"); \
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pa[buf][c]) : "v"(a0 + 512 * (8 * (b) + c)) : "memory"); \
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pb[buf][c]) : "v"(a1 + 512 * (8 * (b) + c)) : "memory"); \
             }                                                                                                                \
         }
 #define PCP_WAIT(buf, n)                                                                                                    \
@@ -102,14 +113,19 @@ __global__ __launch_bounds__(TH) void persistent_kernel(float* act, const float*
         PCP_ISSUE(1, 1)
         PCP_WAIT(0, 16);
         PCP_MFMA(0, 0)
-        PCP_ISSUE(0, 2)
-        PCP_WAIT(1, 16);
-        PCP_MFMA(1, 1)
-        PCP_ISSUE(1, 3)
-        PCP_WAIT(0, 16);
-        PCP_MFMA(0, 2)
-        PCP_WAIT(1, 0);
-        PCP_MFMA(1, 3)
+        if (NCH > 16) {
+            PCP_ISSUE(0, 2)
+            PCP_WAIT(1, 16);
+            PCP_MFMA(1, 1)
+            PCP_ISSUE(1, 3)
+            PCP_WAIT(0, 16);
+            PCP_MFMA(0, 2)
+            PCP_WAIT(1, 0);
+            PCP_MFMA(1, 3)
+        } else {                      // 8 waves: the wave's whole slice was in flight from the start
+            PCP_WAIT(1, 0);
+            PCP_MFMA(1, 1)
+        }
         // ---- reduce the four K slices, epilogue, write-through stores of the 32 x 4 outputs
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -121,11 +137,14 @@ __global__ __launch_bounds__(TH) void persistent_kernel(float* act, const float*
             const int row = threadIdx.x >> 2, u = threadIdx.x & 3;
             float g[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = (red[(0 * 32 + row) * 17 + 4 * q + u] + red[(1 * 32 + row) * 17 + 4 * q + u]) +
-                                                 (red[(2 * 32 + row) * 17 + 4 * q + u] + red[(3 * 32 + row) * 17 + 4 * q + u]);
+            for (int q = 0; q < 4; ++q) {
+                g[q] = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < NWV; ++w2) g[q] += red[(w2 * 32 + row) * 17 + 4 * q + u];
+            }
             const float si = 1.f / (1.f + __expf(-g[0])), so = 1.f / (1.f + __expf(-g[3]));
             const float h = so * tanhf(si * tanhf(g[1]) + 0.5f * g[2]);
-            __hip_atomic_store(dst + (long)row * K + 4 * wg + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + apos(row, 4 * wg + u), h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (threadIdx.x < 128 + 32 && r == 1) {
             // the constant x half is copied once into the second buffer by workgroup-owned pieces (round 1 only)
         }
@@ -146,13 +165,17 @@ int main() {
     float *dW, *dA; unsigned long long* counter;
     hipMalloc(&dW, NW * 4); hipMalloc(&dA, 8L * ROWS * K * 4); hipMalloc(&counter, 8 * 16 * 17);
     hipMemcpy(dW, hW.data(), NW * 4, hipMemcpyHostToDevice);
-    const size_t lds = (size_t)(4 * NCH * 256 + 4 * 32 * 17) * 4;
+    const size_t lds = (size_t)(NWV * NCH * 256 + NWV * 32 * 17) * 4;
     hipFuncSetAttribute((const void*)persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int inv_mode = 0; inv_mode < 3; ++inv_mode)
+    for (int inv_mode = 0; inv_mode < 3; inv_mode += 2)
     for (int with_barrier = 1; with_barrier >= 0; --with_barrier)
         for (int rounds : {4, 104, 404}) {
-            hipMemcpy(dA, hA.data(), 8L * ROWS * K * 4, hipMemcpyHostToDevice);
+            {
+                std::vector<float> pk(8L * ROWS * K);
+                for (int q = 0; q < 8; ++q) for (int row = 0; row < ROWS; ++row) for (int k = 0; k < K; ++k) pk[q * (long)ROWS * K + apos(row, k)] = hA[q * (long)ROWS * K + (long)row * K + k];
+                hipMemcpy(dA, pk.data(), 8L * ROWS * K * 4, hipMemcpyHostToDevice);
+            }
             hipMemset(counter, 0, 8 * 16 * 17);
             hipDeviceSynchronize();
             hipEventRecord(e0);
@@ -181,9 +204,9 @@ int main() {
                 const long fin = (inv_mode == 2 ? 4L : 0L) * ROWS * K;       // round 4 writes buffer 4 of the ring, buffer 0 of the pair
                 err = 0;
                 for (int row = 0; row < ROWS; ++row)
-                    for (int unit = 0; unit < HU; ++unit) err = fmax(err, fabs(out[fin + (long)row * K + unit] - a[(long)row * K + unit]));   // round 4 writes buffer 0
+                    for (int unit = 0; unit < HU; ++unit) err = fmax(err, fabs(out[fin + apos(row, unit)] - a[(long)row * K + unit]));   // round 4 writes buffer 0
             }
-            printf("%s %s: %3d stages %8.1f us total, %6.2f us per stage", inv_mode == 2 ? "ring of 8, L2 inv every 8th" : inv_mode ? "L2 invalidate + plain loads" : "agent-scope loads          ", with_barrier ? "with the grid barrier   " : "without (racy, timing only)", rounds, ms * 1e3,
+            printf("%d waves, %s %s: %3d stages %8.1f us total, %6.2f us per stage", NWV, inv_mode == 2 ? "ring of 8, L2 inv every 8th" : inv_mode ? "L2 invalidate + plain loads" : "agent-scope loads          ", with_barrier ? "with the grid barrier   " : "without (racy, timing only)", rounds, ms * 1e3,
                    ms * 1e3 / rounds);
             if (err >= 0) printf("   max |err| vs host fp64 after 4 stages: %.2e", err);
             printf("\n");

@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="gradient all-reduce behind the backward pass instead of overlapped with it (A/B switch)")
+    ap.add_argument("--cpu-budget", type=float, default=0.0, help="seconds for the host baseline; 0 = the full protocol (1 warm-up + 3 timed full steps)")
     ap.add_argument("--frames", type=int, default=L_MEL, help=argparse.SUPPRESS)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help=argparse.SUPPRESS)       # supplementary measurements only: never the headline
     ap.add_argument("--recurrent-dtype", default="f32", choices=("f32", "bf16"), help=argparse.SUPPRESS)   # bf16 recurrent products only
@@ -218,7 +220,7 @@ def main():
                       gemm_dtype="bf16" if args.config3 else "f32")
     batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
     # config 3: bf16 gradient message with fp32 accumulation on receipt; the fp32 headline keeps the fp32 all-reduce
-    reducer = GradAllReduce(eng.params.grad, world, comm_dtype="bf16" if args.config3 else "f32") if world > 1 else None
+    reducer = GradAllReduce(eng.params.grad, world, comm_dtype="bf16" if args.config3 else "f32", overlap=not args.no_overlap) if world > 1 else None
 
     def sync():
         if dist is not None:
@@ -247,76 +249,104 @@ def main():
            "dtype": ("f32" if args.recurrent_dtype == "f32" else
                      "bf16 operands, f32 accumulate + f32 master (BASELINE config 3 arithmetic, not the headline)" if args.config3 else
                      "f32 + bf16 recurrent products (not the headline)"), "data": "synthetic",
-           "config": {"workload": "BASELINE.json configs[1]: Tacotron2 train step (fwd+bwd+TF-Adam), per-GPU batch %d x (%d tokens, %d mel frames), random speaker embeddings, fp32"
-                                  % (B_PER_GPU, T_ENC, L),
+           "config": {"workload": "BASELINE.json configs[%d]: Tacotron2 train step (fwd+bwd+TF-Adam), per-GPU batch %d x (%d tokens, %d mel frames), random speaker embeddings, %s"
+                                  % (2 if args.config3 else 1, B_PER_GPU, T_ENC, L, "bf16 operands with fp32 master / accumulate" if args.config3 else "fp32"),
                       "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world}}
+    if dist is not None:
+        out["rccl_ranks"] = dist.get_world_size()
+        out["allreduce"] = {"overlapped_with_backward": not args.no_overlap, "exposed_ms_per_step": reducer.exposed_ms(),
+                            "message": "bf16, fp32 accumulate" if args.config3 else "fp32", "bytes_per_rank": eng.params.grad.numel() * (2 if args.config3 else 4)}
 
     if rank == 0 and not args.no_roofline:
         w = eng.plan(B_PER_GPU, T_ENC, L)
         S = L + 1
         lb = lib.load()
-        kinds = {"lsa_step_fwd": 1, "lsa_context_fwd": 2, "cell0_gemm_fwd": 3, "cell1_gemm_fwd": 4,
-                 "lsa_step_bwd": 5, "lsa_denergy_bwd": 6, "cell0_dgemm_bwd": 7, "cell1_dgemm_bwd": 8}
-        avg_us, raw_us, empty_us = {}, {}, {}
-        for name, kind in kinds.items():
-            lb.mstts_probe_begin(kind, S)
-            eng.forward(batch, w)
-            if kind >= 5:
-                eng.loss_and_backward(w)
-            torch.cuda.synchronize()
-            tot, emp = ctypes.c_double(0.0), ctypes.c_double(0.0)
-            n = lb.mstts_probe_result(ctypes.byref(tot), ctypes.byref(emp))
-            if n == 0:                      # kernel kind not launched (the attention step is a single launch by default)
-                continue
-            # HIP events bracketing every launch in the live decoder loop.  An event-to-event interval contains the
-            # event packets' own processing; the empty bracket recorded right behind each launch pays that twice
-            # (measured: bracket - empty/2 reproduces the rocprofv3 kernel-trace average of the same kernel to within
-            # 3 % on all six loop kernels, DESIGN.md "Measurement"), so half of it is subtracted.
-            raw_us[name], empty_us[name] = 1e3 * tot.value / n, 1e3 * emp.value / n
-            avg_us[name] = raw_us[name] - 0.5 * empty_us[name]
-        # the attention step alone (query projection as its own launch again): the same kernel without its in-launch query part
-        plain_us = None
         M, A, H = dims.mem, dims.att, dims.dec_lstm
-        fused_query = bool(eng.fuse_query and lb.mstts_lsa_step_q_supported(T_ENC, M, H))
-        if fused_query:
-            eng.fuse_query = False
-            lb.mstts_probe_begin(1, S)
+        # attention step, algorithmic bytes per launch / stage: B x (keys + values + cum r/w + alignment write)
+        att_bytes = B_PER_GPU * (T_ENC * A * 4 + T_ENC * M * 4 + 3 * T_ENC * 4)
+
+        def probe(kinds, backward):
+            """HIP events bracketing every launch of one kernel kind inside the launch-per-step loops, one extra untimed step per kind.
+            An event-to-event interval contains the event packets' own processing; the empty bracket recorded right behind each launch
+            pays that twice, so half of it is subtracted (reproduces the rocprofv3 kernel-trace average within 3 %)."""
+            res = {}
+            for name, kind in kinds.items():
+                lb.mstts_probe_begin(kind, S)
+                eng.forward(batch, w)
+                if backward:
+                    eng.loss_and_backward(w)
+                torch.cuda.synchronize()
+                tot, emp = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                n = lb.mstts_probe_result(ctypes.byref(tot), ctypes.byref(emp))
+                if n:
+                    res[name] = {"avg_us": 1e3 * tot.value / n - 0.5 * 1e3 * emp.value / n, "event_bracket_us": 1e3 * tot.value / n,
+                                 "empty_bracket_us": 1e3 * emp.value / n}
+            lb.mstts_probe_begin(0, 0)
+            return res
+
+        persistent = bool(getattr(w, "persist", False))
+        stage_names = ["shadow: h1 half 2", "wait ctx", "cell0 ctx product + publish", "wait partials0", "cell0 update + publish",
+                       "wait m0", "cell1 m0 product + publish", "stage h0 + h0 half 1", "wait partials1", "cell1 update + publish",
+                       "shadow: h0 half 2", "wait m1 row", "query + partial energies + publish", "stage h1 + h1 half 1", "wait energies",
+                       "softmax + context + publish"]
+        if persistent:
+            # in-kernel stage timing: the persistent launch stamps the 100 MHz wall clock (s_memrealtime) at 16 points of every
+            # step in every workgroup and sums the intervals; one extra, untimed step with the stamping instantiation
+            eng.persist_stamps = torch.zeros(256 * 16, dtype=torch.int64, device=device)
             eng.forward(batch, w)
             torch.cuda.synchronize()
-            tot, emp = ctypes.c_double(0.0), ctypes.c_double(0.0)
-            n = lb.mstts_probe_result(ctypes.byref(tot), ctypes.byref(emp))
-            if n:
-                plain_us = 1e3 * tot.value / n - 0.5 * 1e3 * emp.value / n
-            eng.fuse_query = True
-        lb.mstts_probe_begin(0, 0)
-        # attention step, algorithmic bytes per row-step: keys + values + cum r/w + alignment write
-        att_only_bytes = B_PER_GPU * (T_ENC * A * 4 + T_ENC * M * 4 + 3 * T_ENC * 4)
-        # with the query projection inside the launch the kernel also reads the query kernel once and the cell-1 output row
-        att_bytes = att_only_bytes + ((H * A * 4 + B_PER_GPU * H * 4 + B_PER_GPU * A * 4) if fused_query else 0)
-        att_us = avg_us["lsa_step_fwd"] + avg_us.get("lsa_context_fwd", 0.0)
-        fused = "lsa_context_fwd" not in avg_us
-        ach = att_bytes / (att_us * 1e-6) / 1e9
-        out["roofline"] = {"kernel": ("lsa_step_kernel (in-launch query projection + exchange, energies + exchange, softmax, context; one decoder step, B=32)" if fused and fused_query
-                                      else "lsa_step_kernel (energies + in-launch exchange + softmax + context; one decoder step, B=32)" if fused
-                                      else "lsa_energy_kernel + lsa_context_kernel (one decoder step, B=32)"),
-                           "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic_bytes("lsa_step_kernel") if (L == L_MEL and world == 1) else None,
-                           "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT), "algorithmic_bytes_per_launch": att_bytes,
-                           "avg_launch_us": att_us, "event_bracket_us": raw_us["lsa_step_fwd"], "empty_bracket_us": empty_us["lsa_step_fwd"]}
-        if plain_us:
-            a2 = att_only_bytes / (plain_us * 1e-6) / 1e9
-            out["roofline"]["attention_only"] = {"note": "the same kernel with the query projection as a launch of its own again, measured in an extra untimed step",
-                                                 "algorithmic_bytes_per_launch": att_only_bytes, "avg_launch_us": plain_us, "achieved": a2, "frac": a2 / HBM_PEAK_GBS}
+            ticks = eng.persist_stamps.view(256, 16).double().cpu().numpy()
+            eng.persist_stamps = None
+            per_step_us = ticks.mean(axis=0) * 0.01 / S                 # 10 ns per tick
+            frame_us = float(per_step_us.sum())
+            # the attention STAGE: from the moment the cell-1 outputs (m1) leave their producers to the moment the context has left
+            # this workgroup - the m1 hand-off, the 16 query units, the partial energies, the energy hand-off, softmax, context.  It
+            # contains the recurrent-half products that run in the shadow of its two hand-offs (stages 10 and 13).
+            att_us = float(per_step_us[10:16].sum())
+            ach = att_bytes / (att_us * 1e-6) / 1e9
+            out["roofline"] = {"kernel": "persist_fwd_kernel, attention stage of one decoder step (m1 hand-off, query units, partial energies, energy hand-off, softmax, context; B=32): keys / values stay on chip",
+                               "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "algorithmic_bytes_per_launch": att_bytes, "avg_launch_us": att_us,
+                               "timing": "s_memrealtime stamps inside the launch, mean over 256 workgroups x %d steps" % S,
+                               "stage_us": {n: float(v) for n, v in zip(stage_names, per_step_us)}, "frame_us": frame_us,
+                               "attention_compute_only_us": float(per_step_us[12] + per_step_us[15]),
+                               "persistent_fallbacks": eng.persist_fallbacks}
+            # the launch-per-step loop it replaced, measured the old way for the record
+            w.persist = False
+            fwd = probe({"lsa_step_fwd": 1, "cell0_gemm_fwd": 3, "cell1_gemm_fwd": 4}, False)
+            w.persist = True
+            if "lsa_step_fwd" in fwd:
+                a2 = att_bytes / (fwd["lsa_step_fwd"]["avg_us"] * 1e-6) / 1e9
+                out["roofline"]["launch_per_step"] = {"kernel": "lsa_step_kernel (query projection inside)", "avg_launch_us": fwd["lsa_step_fwd"]["avg_us"],
+                                                      "achieved": a2, "frac": a2 / HBM_PEAK_GBS}
+        else:
+            fwd = probe({"lsa_step_fwd": 1, "lsa_context_fwd": 2, "cell0_gemm_fwd": 3, "cell1_gemm_fwd": 4}, False)
+            att_us = fwd["lsa_step_fwd"]["avg_us"] + fwd.get("lsa_context_fwd", {"avg_us": 0.0})["avg_us"]
+            ach = att_bytes / (att_us * 1e-6) / 1e9
+            fused_query = bool(eng.fuse_query and lb.mstts_lsa_step_q_supported(T_ENC, M, H))
+            out["roofline"] = {"kernel": "lsa_step_kernel (one decoder step, B=%d%s)" % (B_PER_GPU, ", query projection inside the launch" if fused_query else ""),
+                               "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic_bytes("lsa_step_kernel") if (L == L_MEL and world == 1) else None,
+                               "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT), "algorithmic_bytes_per_launch": att_bytes,
+                               "avg_launch_us": att_us, "event_bracket_us": fwd["lsa_step_fwd"]["event_bracket_us"],
+                               "empty_bracket_us": fwd["lsa_step_fwd"]["empty_bracket_us"]}
+            if fused_query:         # as launched the kernel also reads the query kernel and the cell-1 output rows
+                out["roofline"]["as_launched_bytes"] = att_bytes + H * A * 4 + B_PER_GPU * H * 4 + B_PER_GPU * A * 4
+        bwd = probe({"lsa_step_bwd": 5, "lsa_denergy_bwd": 6, "cell0_dgemm_bwd": 7, "cell1_dgemm_bwd": 8}, True)
         wb = 2 if args.recurrent_dtype == "bf16" else 4          # the recurrent kernels stream bf16 copies in that mode
         w0 = (M + H) * 4 * H * wb
         w1 = 2 * H * 4 * H * wb
         extra = []
+        allk = dict(fwd); allk.update(bwd)
         for nm, byts in (("cell0_gemm_fwd", w0), ("cell1_gemm_fwd", w1), ("cell0_dgemm_bwd", w0), ("cell1_dgemm_bwd", w1)):
-            a = byts / (avg_us[nm] * 1e-6) / 1e9
-            extra.append({"kernel": nm, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                          "algorithmic_bytes_per_launch": byts, "avg_launch_us": avg_us[nm]})
+            if nm not in allk:
+                continue
+            a = byts / (allk[nm]["avg_us"] * 1e-6) / 1e9
+            extra.append({"kernel": nm + (" (launch-per-step loop, not on the timed path)" if persistent and nm.endswith("fwd") else ""),
+                          "bound": "weight-stream (Infinity Cache / HBM)", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": a / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts, "avg_launch_us": allk[nm]["avg_us"]})
         out["roofline_other"] = extra
-        out["kernel_avg_us"] = avg_us
+        out["kernel_avg_us"] = {k: v["avg_us"] for k, v in allk.items()}
         out["step_flops_fraction_of_fp32_mfma_peak"] = (4.047e12 * L / L_MEL) / (ms_per_step * 1e-3) / 157.3e12
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

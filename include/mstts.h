@@ -542,6 +542,31 @@ int32_t mstts_decoder_bf16_splits(int64_t H, int64_t M, int64_t A, int32_t* out6
 int mstts_decoder_train_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t* gates, int64_t* q);
 int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s);
 
+/* ---- The same S steps as ONE persistent launch (csrc/persist.hip; Modules.py:397-443 with ZoneoutLSTMCell.py:228-271 and
+ * Location_Sensitive_Attention.py:43-85 inside): 256 co-resident workgroups keep both cell kernels, the query kernel and the row's
+ * keys / values on chip for the whole sequence and hand the recurrent data from CU to CU through small rings in `xch`.  It reads and
+ * writes exactly the buffers of mstts_decoder_train_desc that mstts_decoder_train_fwd does (in0, in1, pj, c0, c1, acts*, craw*, q_hist,
+ * align_hist, cum_hist; the packed blocks and workspaces of the launch-per-step path are not touched), so mstts_decoder_train_bwd
+ * runs behind either.  Reference widths only: mstts_persist_fwd_supported(B <= 32, H == 1024, M == 768, A == 128, T <= 128, KS == 31)
+ * and a device that admits all 256 workgroups at once (occupancy query, >= 256 CUs).
+ *   w0pk / w1pk / wqpk: mstts_persist_pack(w0f, w1, wq) copies (mstts_persist_pack_floats(0 / 1 / 2) floats), refreshed when the
+ *                       variables change;  xch: mstts_persist_fwd_ws_bytes() bytes, 16-byte aligned;  ctrl: 16 uint32.
+ * After the launch: ctrl[1] == 0 and ctrl[2] == 256  <=>  the sequence ran to its end.  Anything else (the workgroups were not
+ * co-resident within the start window, e.g. because another kernel held CUs; or a bounded wait expired) means the outputs are
+ * incomplete: the caller re-runs mstts_decoder_train_fwd, which recomputes every step (abort codes: 1 = start rendezvous timed out,
+ * 2 = a hand-off wait expired, 3 = self-test).  stamps (NULL in production): 256 x 16
+ * uint64 of summed 100 MHz wall-clock ticks per stage and workgroup (bench.py's in-kernel stage timing). */
+typedef struct {
+    const float* w0pk; const float* w1pk; const float* wqpk;
+    float* xch; uint32_t* ctrl; uint64_t* stamps;
+    int32_t selftest_fail_step;   /* 0 in production; k > 0: workgroup 0 raises the abort word at step k - 1 (exercises the fallback) */
+} mstts_persist_desc;
+int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
+int64_t mstts_persist_fwd_ws_bytes(void);
+int64_t mstts_persist_pack_floats(int32_t which);
+int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s);
+int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc* d, const mstts_persist_desc* p, mstts_stream_t s);
+
 /* BPTT through the same S steps.  d_pj [S,B,H+M] holds the projection's input gradient on entry
  * (d_m1 | d_ctx) and is updated in place.  Outputs for the hoisted gradient GEMMs:
  *   dg0/dg1 [S,B,4H], dq_hist [S,B,A] (must be zeroed by the caller), de_hist [S,B,T],

@@ -110,6 +110,8 @@ def read_sphere(path, start_time=None, end_time=None):
         if "shorten" in coding or "ulaw" in coding or "alaw" in coding:
             raise ValueError("SPHERE sample_coding '{}' is not supported (uncompressed pcm only)".format(coding))
         width = int(fields.get("sample_n_bytes", 2))
+        if width not in (2, 4):          # (1-byte SPHERE pcm is offset-coded and 3-byte samples have no NumPy dtype; neither occurs in TIMIT / TEDLIUM)
+            raise ValueError("SPHERE sample_n_bytes {} is not supported (16- or 32-bit pcm only)".format(width))
         order = "<" if str(fields.get("sample_byte_format", "01")).startswith("01") else ">"
         raw = np.frombuffer(f.read(), dtype=np.dtype("%si%d" % (order, width)))
     ch = int(fields.get("channel_count", 1))

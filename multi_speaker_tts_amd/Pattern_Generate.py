@@ -221,7 +221,10 @@ def TIMIT_Info_Load(timit_Path):
 def Pattern_File_Generate_from_SPH(path, text_List, token_Index_Dict, dataset, spectral_Subtract=False, display_Prefix="", range_Ignore=False,
                                    device="cuda"):
     """Pattern_Generate.py:80-113: one pattern per (start, end, text) segment of a SPHERE recording, named
-    <DATASET>.<basename>.<index>.PICKLE.  Returns the names written."""
+    <DATASET>.<basename>.<index>.PICKLE.  Returns the names written.  Two things the reference does here are kept on purpose, so that
+    the TEDLIUM pattern set comes out identical: it calls Mel_Generate with its DEFAULTS (`:91` - the spectral_Subtract / range_Ignore
+    arguments of this function are accepted and ignored, also under `-all`), and it stops at the FIRST segment the length filter
+    rejects (`:92-94`, a `return`, not a `continue`): later segments of that recording produce no pattern."""
     from scipy.io import wavfile
     import tempfile
     names = []
@@ -231,11 +234,11 @@ def Pattern_File_Generate_from_SPH(path, text_List, token_Index_Dict, dataset, s
             tmp = tf.name
         try:
             wavfile.write(tmp, rate, data)
-            mel = Mel_Generate(tmp, spectral_Subtract, range_Ignore, device=device)
+            mel = Mel_Generate(tmp, device=device)
         finally:
             os.remove(tmp)
         if mel is None:
-            continue
+            return names
         name = "{}.{}.{}.PICKLE".format(dataset, os.path.splitext(os.path.basename(path))[0], index).upper()
         Pattern_File_Write(name, text, mel, token_Index_Dict, dataset)
         names.append(name)
@@ -256,6 +259,10 @@ def main(argv=None, device="cuda"):
     args = ap.parse_args(argv)
     token_Index_Dict = _Feeder.load_token_dict()
     jobs = []                                            # (dataset, path, text or segment list)
+    # per corpus, as the reference submits them (Pattern_Generate.py:318-404): LibriSpeech (and TEDLIUM, where the flag is then dropped)
+    # with spectral subtraction, the others without; TIMIT names carry the speaker directory, because its utterance names (SA1, SA2,
+    # SX...) repeat from speaker to speaker
+    spectral = {"LJ": False, "VCTK": False, "LS": True, "TL": True, "TIMIT": False}
     for dataset, root, loader in (("LJ", args.lj_path, LJ_Info_Load), ("VCTK", args.vctk_path, VCTK_Info_Load), ("LS", args.ls_path, LS_Info_Load),
                                   ("TL", args.tl_path, TL_Info_Load), ("TIMIT", args.timit_path, TIMIT_Info_Load)):
         if root is None:
@@ -268,9 +275,10 @@ def main(argv=None, device="cuda"):
     written = 0
     for i, (dataset, path, what) in enumerate(jobs):
         if dataset == "TL":
-            names = Pattern_File_Generate_from_SPH(path, what, token_Index_Dict, dataset, range_Ignore=args.all_save, device=device)
+            names = Pattern_File_Generate_from_SPH(path, what, token_Index_Dict, dataset, spectral[dataset], range_Ignore=args.all_save, device=device)
         else:
-            name = Pattern_File_Generate(path, what, token_Index_Dict, dataset, range_Ignore=args.all_save, device=device)
+            prefix = "{}.".format(path.split("/")[-2]) if dataset == "TIMIT" else ""
+            name = Pattern_File_Generate(path, what, token_Index_Dict, dataset, spectral[dataset], prefix, range_Ignore=args.all_save, device=device)
             names = [name] if name else []
         written += len(names)
         print("[{} {:05d}/{:05d}]".format(dataset, i, len(jobs)), path, "->", ", ".join(names) if names else "Ignored because of length.")

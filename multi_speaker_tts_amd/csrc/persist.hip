@@ -1,0 +1,641 @@
+// Persistent teacher-forced decoder loop for gfx950: ALL S steps of Decoder_Dynamic_Decode.body (Modules.py:397-443 - two
+// ZoneoutLSTMCells, ZoneoutLSTMCell.py:228-271, and the Location_Sensitive_Attention step, Location_Sensitive_Attention.py:43-85)
+// in ONE launch of 256 co-resident workgroups, one per CU.  Nothing recurrent is re-read from memory between steps:
+//
+//   * the two cell kernels (63 MB fp32) live in REGISTERS for the whole sequence: workgroup (i, j) = (id & 7, id >> 3) owns the
+//     [K/8, 128]-tile "reduction slice i x gate-column slice j" of both kernels; each of its 8 waves (two per SIMD) keeps 16 gate
+//     columns of that tile, 120 registers per lane, as MFMA A-operands;
+//   * its 16 query units' slice of the query kernel (64 KB of LDS), its row's key slice (4 registers per lane) and its 96-column
+//     slice of the row's values (48 KB of LDS) stay on chip as well.
+//
+// Per step the only traffic is the recurrent data itself, handed from CU to CU through write-through (sc1) stores and L1-bypassing
+// (sc1) loads on small rings in memory, where THE DATA IS THE FLAG: every ring slot is pre-filled with the bit pattern 0xFFFFFFFF (a
+// NaN no arithmetic here produces), a consumer polls its piece until no word of it reads as that pattern, and the producer re-arms
+// the slot two steps ahead.  No barrier, no counter, no fence on the step path.  Six hand-offs per step:
+//
+//   ctx_{s-1} -> [cell-0 product, context rows]  -> partial gates -> (sum of 8, cell-0 update)  -> m0, h0
+//   m0        -> [cell-1 product, input rows]    -> partial gates -> (sum of 8, cell-1 update)  -> m1, h1
+//   m1 row    -> [16 query units, partial energies over those 16 units for all 128 positions]   -> partial energies
+//   energies  -> (sum of 8, softmax, cumulative alignment, 96 context columns)                   -> ctx_s
+//
+// The recurrent halves of both products (h0_{s-1} . W0[h rows], h1_{s-1} . W1[h rows]) do not depend on the step's own chain and run
+// in the shadow of the hand-offs.  Exact fp32 (v_mfma_f32_16x16x4_f32), fixed summation order (deterministic run to run).
+//
+// Every wait is bounded (wall clock); a workgroup that gives up raises an abort word that all others poll, the launch ends, and the
+// host re-runs the sequence on the launch-per-step path (mstts_decoder_train_fwd).  The same happens when the 256 workgroups do not
+// become co-resident (start rendezvous).
+#include "common.h"
+
+namespace mstts {
+
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef int pi32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PH = 1024, PM = 768, PA = 128, PT = 128, PROWS = 32, PWG = 256, PTH = 512;
+constexpr int PKS = 31;                          // location filter taps (hp.Attention.Conv.Kernel_Size)
+constexpr int PRING = 4;
+constexpr unsigned PSENT = 0xFFFFFFFFu;
+// ring sizes in floats per slot
+constexpr long XCTX = 8L * 128 * 24, XACT = 8L * 128 * 32, XPART = 256L * 8 * 2 * 256, XM1 = 32L * PH, XEN = 32L * 8 * PT;
+constexpr long OFF_CTX = 0, OFF_M0 = OFF_CTX + PRING * XCTX, OFF_H0 = OFF_M0 + PRING * XACT, OFF_H1 = OFF_H0 + PRING * XACT,
+               OFF_M1 = OFF_H1 + PRING * XACT, OFF_EN = OFF_M1 + PRING * XM1, OFF_P0 = OFF_EN + PRING * XEN, OFF_P1 = OFF_P0 + PRING * XPART,
+               XCH_FLOATS = OFF_P1 + PRING * XPART;
+// LDS layout (floats)
+constexpr int LC = 28, LA = 36;                  // padded row strides of the staged activation slices (conflict-free b128 reads)
+// ONE staging buffer serves the four slices a step consumes, in turn: ctx_{s-1} -> m0_s -> h0_s -> h1_s (each is dead before the next arrives)
+// (small arrays first: a DS instruction's immediate offset reaches 64 KB, and every access beyond that needs an address register of its
+//  own, which the compiler hoists out of the step loop - with the two big flat arrays in front the kernel spilled 119 registers)
+constexpr int S_STG = 0, S_RED = S_STG + 128 * LA, S_TR = S_RED + 4 * 2 * 256, S_M1 = S_TR + 2 * 128, S_EN = S_M1 + PH,
+              S_CUM = S_EN + 8 * PT, S_A = S_CUM + 176, S_Q = S_A + PT, S_QF = S_Q + 512, S_CO = S_QF + 16, S_LK = S_CO + 4 * 96,
+              S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_FLOATS = S_WQ + 8 * 512 * 4;
+constexpr unsigned long long PERSIST_TIMEOUT_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock per wait
+constexpr int NSTAMP = 16;
+
+struct PersistFwd {
+    const float* w0pk; const float* w1pk; const float* wqpk;
+    const float* xw0; const float* b1;
+    const uint8_t* zc0; const uint8_t* zh0; const uint8_t* zc1; const uint8_t* zh1; float keep;
+    const float* keys; const float* values; const int32_t* lengths;
+    const float* loc_k; const float* loc_b; const float* score_w; const float* score_b;
+    int B, S, T;
+    float* in0; float* in1; float* pj; float* c0; float* c1; float* acts0; float* acts1; float* craw0; float* craw1;
+    float* q_hist; float* align_hist; float* cum_hist;
+    float* xch; unsigned* ctrl;                  // ctrl[0] arrivals, ctrl[1] abort code, ctrl[2] workgroups that finished all S steps
+    unsigned long long* stamps;                  // PROF: [256][NSTAMP] summed interval ticks
+    int fail_step;                               // self-test: workgroup 0 raises the abort word at this step (-1 = never)
+};
+
+__device__ __forceinline__ bool has_sent(const pf32x4& v) {
+    return (__float_as_uint(v[0]) == PSENT) | (__float_as_uint(v[1]) == PSENT) | (__float_as_uint(v[2]) == PSENT) | (__float_as_uint(v[3]) == PSENT);
+}
+__device__ __forceinline__ pf32x4 xload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(pf32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));       // aux 16 = sc1
+}
+__device__ __forceinline__ void xstore(__amdgpu_buffer_rsrc_t r, unsigned byte_off, pf32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pi32x4, v), r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ pf32x4 sentv() { const float s = __uint_as_float(PSENT); return (pf32x4){s, s, s, s}; }
+
+// Polls N 16-byte pieces per lane until none holds the sentinel.  Returns false on time-out / abort (wave-uniform).
+// (The empty asm with a memory clobber is what makes this a poll: the buffer-load builtin is a plain read to the compiler, which
+//  otherwise proves the re-load redundant and deletes the whole loop.)
+template <int N>
+__device__ __forceinline__ bool gather(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N], const unsigned* ctrl) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < N; ++m) v[m] = xload(r, off[m]);
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        bool miss = false;
+#pragma unroll
+        for (int m = 0; m < N; ++m) miss |= has_sent(v[m]);
+        if (!__builtin_amdgcn_ballot_w64(miss)) return true;
+        if ((++spins & 15u) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        }
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            if (has_sent(v[m])) v[m] = xload(r, off[m]);
+    }
+}
+
+#define PMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// acc[t] += W[k-steps 4 K4A .. 4 K4B) . X[t], X read from the staged LDS slice (row stride LD); the wave's registers w[WOFF + ks]
+template <int K4A, int K4B, int LD, int WOFF, int NW>
+__device__ __forceinline__ void mfma_part(const float (&w)[NW], const float* sx, int lane, pf32x4 (&acc)[2]) {
+    const int row0 = ((lane >> 4) * 2) * 16 + (lane & 15);          // rho of row tile 0; tile 1 is 16 rows further
+#pragma unroll
+    for (int k4 = K4A; k4 < K4B; ++k4) {
+        const pf32x4 x0 = *reinterpret_cast<const pf32x4*>(sx + row0 * LD + 4 * k4);
+        const pf32x4 x1 = *reinterpret_cast<const pf32x4*>(sx + (row0 + 16) * LD + 4 * k4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0] = PMFMA(w[WOFF + 4 * k4 + e], x0[e], acc[0]);
+            acc[1] = PMFMA(w[WOFF + 4 * k4 + e], x1[e], acc[1]);
+        }
+    }
+}
+
+// one slice of a ring slot (128 rows x 4 K4 floats, contiguous) -> the staging buffer (row stride LD); false on time-out
+template <int K4, int LD>
+__device__ __forceinline__ bool stage_slice(__amdgpu_buffer_rsrc_t xr, long slice_float_off, float* stg, int tid, const unsigned* ctrl) {
+    constexpr int NPC = 128 * K4;                                    // 16-byte pieces of the slice: 768 or 1024 for 512 threads
+    unsigned off[2]; pf32x4 v[2];
+    const bool two = tid + PTH < NPC;
+    off[0] = (unsigned)(slice_float_off * 4 + 16 * tid);
+    off[1] = two ? off[0] + 16 * PTH : off[0];
+    const bool ok = gather<2>(xr, off, v, ctrl);
+    {
+        const int rho = tid / K4, k4 = tid - rho * K4;
+        *reinterpret_cast<pf32x4*>(stg + rho * LD + 4 * k4) = v[0];
+    }
+    if (two) {
+        const int p = tid + PTH, rho = p / K4, k4 = p - rho * K4;
+        *reinterpret_cast<pf32x4*>(stg + rho * LD + 4 * k4) = v[1];
+    }
+    return ok;
+}
+
+struct CellOut { float si, tj, sf, so, c, m; };
+// ZoneoutLSTMCell.py:228-271 for one (row, unit): gates i, j, f, o (forget bias 1.0 added here), training-mode zoneout with keep masks
+__device__ __forceinline__ CellOut cell_update(const pf32x4& gs, const float (&add)[4], float& cs, float& hs, float kc, float kh) {
+    CellOut o;
+    o.si = sigmoidf_(gs[0] + add[0]); o.tj = tanhf_(gs[1] + add[1]); o.sf = sigmoidf_(gs[2] + add[2] + 1.0f); o.so = sigmoidf_(gs[3] + add[3]);
+    o.c = o.sf * cs + o.si * o.tj;
+    o.m = o.so * tanhf_(o.c);
+    hs = kh * (o.m - hs) + hs;
+    cs = kc * (o.c - cs) + cs;
+    return o;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int g0 = blockIdx.x, tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    int g = g0, gi = g & 7, gj = g >> 3;
+    int tid = tid0, lane = tid & 63, wave = wave0;
+    const int B = d.B, S = d.S, T = d.T;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(d.xch, 0, (int)(XCH_FLOATS * 4), 0x00020000);
+    unsigned* sflag = reinterpret_cast<unsigned*>(sm + S_FLAG);
+    float* stg = sm + S_STG;
+
+    // ---------------- start rendezvous: all 256 workgroups must be resident before anyone waits for data
+    if (tid == 0) {
+        sflag[0] = 0;
+        __hip_atomic_fetch_add(d.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(d.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PWG) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(d.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(d.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sflag[0] = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (sflag[0]) return;
+
+    // ---------------- once: this workgroup's constants.  Cell kernels -> registers (MFMA A operands), wave v = gate-column group v of the tile:
+    //   w0[ks]: k-steps 0..23 = context rows of reduction slice gi, 24..55 = its h0 rows; w1[ks]: 0..31 = m0 rows, 32..63 = h1 rows
+    float w0[56], w1[64];
+    {
+        const float* p0 = d.w0pk + ((long)(g * 8 + wave) * 56) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 56; ++r) w0[r] = p0[r * 64];
+        const float* p1 = d.w1pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) w1[r] = p1[r * 64];
+    }
+    // attention role: row ab = gj, unit slice gi (query units / key columns 16 gi ..), value columns 96 gi ..
+    int ab = gj;
+    const bool arow = ab < B;
+    const int alen = arow ? (d.lengths ? d.lengths[ab] : T) : 0;
+    int ak = tid & 15, atg = tid >> 4;                           // energy phase: attention unit 16 gi + ak, positions 4 atg .. 4 atg + 3
+    float kreg[4];
+    float asb = 0.f, awk = 0.f;
+    {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int t = 4 * atg + m;
+            kreg[m] = (arow && t < T) ? d.keys[((long)ab * T + t) * PA + 16 * gi + ak] : 0.f;
+        }
+        asb = d.score_b[16 * gi + ak] + d.loc_b[16 * gi + ak];
+        awk = d.score_w[16 * gi + ak];
+        for (int x = tid; x < 32 * 16; x += PTH) sm[S_LK + x] = (x < PKS * 16) ? d.loc_k[(x >> 4) * PA + 16 * gi + (x & 15)] : 0.f;
+        for (int x = tid; x < PT * 96; x += PTH) {
+            const int t = x / 96, c = x - t * 96;
+            sm[S_VAL + x] = (arow && t < alen && t < T) ? d.values[((long)ab * T + t) * PM + 96 * gi + c] : 0.f;
+        }
+        for (int x = tid; x < 176; x += PTH) sm[S_CUM + x] = 0.f;
+        const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqpk) + (long)gi * 8 * 512;      // query kernel slice: [8][512 threads] float4
+        for (int x = tid; x < 8 * 512; x += PTH) reinterpret_cast<pf32x4*>(sm + S_WQ)[x] = wqs[x];
+    }
+    // cell-update role (waves 0, 1): row er, hidden unit eu = 4 g + (lane >> 4); the states stay in registers for all S steps
+    int et = wave & 1, er = 16 * et + (lane & 15), ee = lane >> 4, eu = 4 * g + ee;
+    bool ew = wave < 2, elive = ew && er < B;
+    float c0s = 0.f, h0s = 0.f, c1s = 0.f, h1s = 0.f;
+    float b1v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b1v[q] = d.b1[q * PH + eu];
+    pf32x4 acc0[2], acc1[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { acc0[b] = (pf32x4){0.f, 0.f, 0.f, 0.f}; acc1[b] = acc0[b]; }
+    // PROF: per-stage wall-clock ticks summed in LDS by thread 0 (no registers held across the loop)
+    unsigned long long* sstamp = reinterpret_cast<unsigned long long*>(sm + S_STAMP);
+    unsigned tprev = 0;
+    if (PROF && tid < NSTAMP) sstamp[tid] = 0;
+#define PSTAMP(idx) do { if (PROF && tid == 0) { const unsigned n__ = (unsigned)wall_clock64(); sstamp[idx] += (unsigned)(n__ - tprev); tprev = n__; } } while (0)
+#define PABORT_CHECK() do { __syncthreads(); if (sflag[0]) return; } while (0)
+    // (the first code raised stays: a workgroup that merely found the abort word while waiting does not overwrite it)
+#define PFAIL() do { sflag[0] = 1; unsigned z__ = 0u; __hip_atomic_compare_exchange_strong(d.ctrl + 1, &z__, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+    // this wave's partial gates -> reducer (gate-column group `wave` of column slice gj), as source gi; re-arms the slot two steps ahead
+#define PUBLISH_PARTIAL(OFFP, ACC)                                                                                              \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                             \
+        const long piece = ((long)(gj * 8 + wave) * 8 + gi) * 2 + t;                                                            \
+        xstore(xr, (unsigned)(((OFFP) + slot * XPART + piece * 256) * 4 + 16 * lane), ACC[t]);                                  \
+        xstore(xr, (unsigned)(((OFFP) + rslot * XPART + piece * 256) * 4 + 16 * lane), sentv());                                \
+        ACC[t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                                                                                  \
+    }
+    // waves 0..3 fetch the 8 x 2 partial tiles of this workgroup's 16 gate columns (sources 2 wave, 2 wave + 1) and pre-add the pair
+#define GATHER_PARTIALS(OFFP)                                                                                                   \
+    if (wave < 4) {                                                                                                             \
+        unsigned off[4]; pf32x4 v[4];                                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                           \
+            off[m] = (unsigned)(((OFFP) + slot * XPART + (((long)g * 8 + 2 * wave + (m >> 1)) * 2 + (m & 1)) * 256) * 4 + 16 * lane); \
+        if (!gather<4>(xr, off, v, d.ctrl)) PFAIL();                                                                            \
+        *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 0) * 64 + lane) * 4) = v[0] + v[2];                                \
+        *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 1) * 64 + lane) * 4) = v[1] + v[3];                                \
+    }
+#define SUM_PARTIALS()                                                                                                          \
+    ((*reinterpret_cast<const pf32x4*>(sm + S_RED + ((0 * 2 + et) * 64 + lane) * 4) + *reinterpret_cast<const pf32x4*>(sm + S_RED + ((1 * 2 + et) * 64 + lane) * 4)) + \
+     (*reinterpret_cast<const pf32x4*>(sm + S_RED + ((2 * 2 + et) * 64 + lane) * 4) + *reinterpret_cast<const pf32x4*>(sm + S_RED + ((3 * 2 + et) * 64 + lane) * 4)))
+    __syncthreads();
+    if (PROF && tid == 0) tprev = (unsigned)wall_clock64();
+
+    for (int s = 0; s < S; ++s) {
+        const unsigned slot = (unsigned)s & 3u, rslot = (unsigned)(s + 2) & 3u, pslot = (unsigned)(s + 3) & 3u;   // pslot: the slot of step s - 1
+        // Every index below is re-derived from the thread / workgroup id behind an opaque asm once per step: left alone, the compiler
+        // hoists some ninety loop-invariant ring offsets and LDS addresses out of the step loop, keeps them in VGPRs next to the 120
+        // kernel registers, and spills into scratch inside the hand-off paths.
+        tid = tid0; g = g0; wave = wave0;
+        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+s"(g), "+s"(wave));
+        lane = tid & 63; gi = g & 7; gj = g >> 3; ab = gj; ak = tid & 15; atg = tid >> 4;
+        et = wave & 1; er = 16 * et + (lane & 15); ee = lane >> 4; eu = 4 * g + ee;
+        ew = wave < 2; elive = ew && er < B;
+        if (s == d.fail_step && g == 0 && tid == 0) {      // self-test: this workgroup leaves at its next check, the others find the abort word while they wait for its data
+            __hip_atomic_store(d.ctrl + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sflag[0] = 1;
+        }
+        // ---- cell-update operands of both cells, requested now (plain loads of loop-invariant inputs), by EVERY wave and without any
+        // condition, and consumed by every wave below (waves 2..7 repeat the update of waves 0 / 1 and drop the result): a load that
+        // is issued or consumed under a condition is still "pending" for the compiler at the loop's back edge, and the s_waitcnt
+        // vmcnt it then places at the top of the loop also waits for every write-through store of the step before (~2 us per step).
+        // (addresses: a wave-uniform 64-bit base of the step + a 32-bit lane offset, so that no per-array address pair stays in VGPRs)
+        const long sB = (long)s * B, sB1 = sB + B;
+        const bool rowok = er < B;
+        const unsigned erc = rowok ? (unsigned)er : 0u;
+        const unsigned oH = erc * PH + eu, o4H = erc * 4 * PH + eu;
+        float xwv[4];
+        uint8_t zc0v, zh0v, zc1v, zh1v;
+        {
+            const float* xw = d.xw0 + sB * 4 * PH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xwv[q] = xw[o4H + q * PH];
+            zc0v = (d.zc0 + sB * PH)[oH]; zh0v = (d.zh0 + sB * PH)[oH];
+            zc1v = (d.zc1 + sB * PH)[oH]; zh1v = (d.zh1 + sB * PH)[oH];
+        }
+        // ================= A: cell 0, context rows.  In the shadow of the ctx_{s-1} hand-off: second half of h1_{s-1} . W1[h rows]
+        if (s > 0) {
+            mfma_part<4, 8, LA, 32, 64>(w1, stg, lane, acc1);
+            __syncthreads();                                         // every wave is done with the staged h1 before ctx overwrites it
+            PSTAMP(0);
+            if (!stage_slice<6, LC>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, stg, tid, d.ctrl)) PFAIL();
+            PABORT_CHECK();
+            PSTAMP(1);
+            mfma_part<0, 6, LC, 0, 56>(w0, stg, lane, acc0);
+        }
+        PUBLISH_PARTIAL(OFF_P0, acc0)
+        PSTAMP(2);
+        // ================= B: sum of the eight partials, cell-0 update
+        GATHER_PARTIALS(OFF_P0)
+        PABORT_CHECK();
+        PSTAMP(3);
+        {
+            const pf32x4 gs = SUM_PARTIALS();
+            float add0[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) add0[q] = rowok ? xwv[q] : 0.f;
+            const CellOut o = cell_update(gs, add0, c0s, h0s, (zc0v || !rowok) ? d.keep : 0.f, (zh0v || !rowok) ? d.keep : 0.f);
+            if (ew) {
+                sm[S_TR + er * 4 + ee] = o.m;
+                sm[S_TR + 128 + er * 4 + ee] = h0s;
+            }
+            __syncthreads();
+            if (tid < 64) {         // m0 / h0' of the 4 units for one row: 16 bytes into slice gi of the consumers' rings
+                const int arr = tid >> 5, row = tid & 31;
+                const pf32x4 val = *reinterpret_cast<const pf32x4*>(sm + S_TR + arr * 128 + row * 4);
+                const int rho = (((gj & 3) * 2 + (row >> 4)) * 16) + (row & 15);
+                const long base = arr ? OFF_H0 : OFF_M0;
+                const long o2 = gi * 4096L + rho * 32 + 4 * (gj >> 2);
+                xstore(xr, (unsigned)((base + slot * XACT + o2) * 4), val);
+                xstore(xr, (unsigned)((base + rslot * XACT + o2) * 4), sentv());
+            }
+            if (elive) {            // what BPTT reads, behind the hand-off stores (ahead of them they delayed the publication by their issue time)
+                float* a = d.acts0 + sB * 4 * PH; a[o4H] = o.si; a[o4H + PH] = o.tj; a[o4H + 2 * PH] = o.sf; a[o4H + 3 * PH] = o.so;
+                (d.craw0 + sB * PH)[oH] = o.c;
+                (d.c0 + sB1 * PH)[oH] = c0s;
+                (d.in1 + sB * 2 * PH)[(unsigned)er * 2 * PH + eu] = o.m;
+                (d.in0 + sB1 * (PM + PH))[(unsigned)er * (PM + PH) + PM + eu] = h0s;
+            }
+        }
+        PSTAMP(4);
+        // ================= C: cell 1, input rows (m0_s)
+        if (!stage_slice<8, LA>(xr, OFF_M0 + slot * XACT + gi * 4096L, stg, tid, d.ctrl)) PFAIL();
+        PABORT_CHECK();
+        PSTAMP(5);
+        mfma_part<0, 8, LA, 0, 64>(w1, stg, lane, acc1);
+        PUBLISH_PARTIAL(OFF_P1, acc1)
+        PSTAMP(6);
+        // in the shadow of the partial-gates hand-off: h0_s (published together with m0_s) staged, first half of h0_s . W0[h rows] for step s+1
+        __syncthreads();                                             // m0 is consumed by every wave
+        if (!stage_slice<8, LA>(xr, OFF_H0 + slot * XACT + gi * 4096L, stg, tid, d.ctrl)) PFAIL();
+        PABORT_CHECK();
+        mfma_part<0, 4, LA, 24, 56>(w0, stg, lane, acc0);
+        PSTAMP(7);
+        // ================= D: sum of the eight partials, cell-1 update
+        GATHER_PARTIALS(OFF_P1)
+        PABORT_CHECK();
+        PSTAMP(8);
+        {
+            const pf32x4 gs = SUM_PARTIALS();
+            const CellOut o = cell_update(gs, b1v, c1s, h1s, (zc1v || !rowok) ? d.keep : 0.f, (zh1v || !rowok) ? d.keep : 0.f);
+            if (ew) {
+                sm[S_TR + er * 4 + ee] = o.m;
+                sm[S_TR + 128 + er * 4 + ee] = h1s;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int arr = tid >> 5, row = tid & 31;
+                const pf32x4 val = *reinterpret_cast<const pf32x4*>(sm + S_TR + arr * 128 + row * 4);
+                if (arr == 0) {     // m1: row-major [32][1024] for the attention workgroups of the row
+                    const long o2 = (long)row * PH + 4 * g;
+                    xstore(xr, (unsigned)((OFF_M1 + slot * XM1 + o2) * 4), val);
+                    xstore(xr, (unsigned)((OFF_M1 + rslot * XM1 + o2) * 4), sentv());
+                } else {
+                    const int rho = (((gj & 3) * 2 + (row >> 4)) * 16) + (row & 15);
+                    const long o2 = gi * 4096L + rho * 32 + 4 * (gj >> 2);
+                    xstore(xr, (unsigned)((OFF_H1 + slot * XACT + o2) * 4), val);
+                    xstore(xr, (unsigned)((OFF_H1 + rslot * XACT + o2) * 4), sentv());
+                }
+            }
+            if (elive) {
+                float* a = d.acts1 + sB * 4 * PH; a[o4H] = o.si; a[o4H + PH] = o.tj; a[o4H + 2 * PH] = o.sf; a[o4H + 3 * PH] = o.so;
+                (d.craw1 + sB * PH)[oH] = o.c;
+                (d.c1 + sB1 * PH)[oH] = c1s;
+                (d.pj + sB * (PH + PM))[(unsigned)er * (PH + PM) + eu] = o.m;
+                (d.in1 + sB1 * 2 * PH)[(unsigned)er * 2 * PH + PH + eu] = h1s;
+            }
+        }
+        PSTAMP(9);
+        // in the shadow of the m1 hand-off: second half of h0_s . W0[h rows]
+        mfma_part<4, 8, LA, 24, 56>(w0, stg, lane, acc0);
+        PSTAMP(10);
+        // ================= E: attention, query units and partial energies of row ab
+        if (arow) {
+            if (tid < 256) {
+                unsigned off[1]; pf32x4 v[1];
+                off[0] = (unsigned)((OFF_M1 + slot * XM1 + (long)ab * PH) * 4 + 16 * tid);
+                if (!gather<1>(xr, off, v, d.ctrl)) PFAIL();
+                *reinterpret_cast<pf32x4*>(sm + S_M1 + 4 * tid) = v[0];
+            }
+            PABORT_CHECK();
+            PSTAMP(11);
+            {       // thread (unit ak, hidden-unit group atg): rows 32 atg .. 32 atg + 31 of column 16 gi + ak of the query kernel
+                float qp = 0.f;
+#pragma unroll
+                for (int x4 = 0; x4 < 8; ++x4) {
+                    const pf32x4 mv = *reinterpret_cast<const pf32x4*>(sm + S_M1 + 32 * atg + 4 * x4);
+                    const pf32x4 wv = *reinterpret_cast<const pf32x4*>(sm + S_WQ + (x4 * PTH + tid) * 4);
+                    qp += wv[0] * mv[0]; qp += wv[1] * mv[1]; qp += wv[2] * mv[2]; qp += wv[3] * mv[3];
+                }
+                sm[S_Q + atg * 16 + ak] = qp;
+            }
+            __syncthreads();
+            if (tid < 16) {
+                float qv = 0.f;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) qv += sm[S_Q + u * 16 + tid];
+                sm[S_QF + tid] = qv;
+                (d.q_hist + (sB + ab) * PA + 16 * gi)[tid] = qv;
+            }
+            __syncthreads();
+            {
+                const float qk = sm[S_QF + ak] + asb;
+                float cw[36];
+#pragma unroll
+                for (int x4 = 0; x4 < 9; ++x4) {
+                    const pf32x4 cv = *reinterpret_cast<const pf32x4*>(sm + S_CUM + 4 * atg + 4 * x4);
+                    cw[4 * x4] = cv[0]; cw[4 * x4 + 1] = cv[1]; cw[4 * x4 + 2] = cv[2]; cw[4 * x4 + 3] = cv[3];
+                }
+                float pre[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk;
+#pragma unroll
+                for (int jj = 0; jj < PKS; ++jj) {
+                    const float lk = sm[S_LK + jj * 16 + ak];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) pre[m] += cw[m + jj] * lk;
+                }
+                pf32x4 e4;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float e = awk * tanhf_(pre[m]);
+                    e += dpp_mov<0xB1, 0xf>(0.f, e);
+                    e += dpp_mov<0x4E, 0xf>(0.f, e);
+                    e += dpp_mov<0x141, 0xf>(0.f, e);
+                    e += dpp_mov<0x140, 0xf>(0.f, e);
+                    e4[m] = e;
+                }
+                if (ak == 0) {
+                    const long o = ((long)ab * 8 + gi) * PT + 4 * atg;
+                    xstore(xr, (unsigned)((OFF_EN + slot * XEN + o) * 4), e4);
+                    xstore(xr, (unsigned)((OFF_EN + rslot * XEN + o) * 4), sentv());
+                }
+            }
+        } else {
+            PSTAMP(11);
+        }
+        PSTAMP(12);
+        // in the shadow of the energy hand-off: h1_s staged (it stays staged until the next step's context arrives), first half of h1_s . W1[h rows]
+        __syncthreads();                                             // h0 is consumed by every wave
+        if (!stage_slice<8, LA>(xr, OFF_H1 + slot * XACT + gi * 4096L, stg, tid, d.ctrl)) PFAIL();
+        PABORT_CHECK();
+        mfma_part<0, 4, LA, 32, 64>(w1, stg, lane, acc1);
+        PSTAMP(13);
+        // ================= F: energies of the row, softmax, cumulative alignment, context columns 96 gi ..
+        if (arow) {
+            if (tid < 256) {
+                unsigned off[1]; pf32x4 v[1];
+                off[0] = (unsigned)((OFF_EN + slot * XEN + (long)ab * 8 * PT) * 4 + 16 * tid);
+                if (!gather<1>(xr, off, v, d.ctrl)) PFAIL();
+                *reinterpret_cast<pf32x4*>(sm + S_EN + 4 * tid) = v[0];
+            }
+            PABORT_CHECK();
+            PSTAMP(14);
+            if (wave == 0) {
+                float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { e0 += sm[S_EN + i * PT + lane]; e1 += sm[S_EN + i * PT + 64 + lane]; }
+                const bool l0 = lane < alen, l1 = lane + 64 < alen;
+                e0 = l0 ? e0 : -INFINITY; e1 = l1 ? e1 : -INFINITY;
+                const float mx = wave_max(fmaxf(e0, e1));
+                const float p0 = l0 ? __expf(e0 - mx) : 0.f, p1 = l1 ? __expf(e1 - mx) : 0.f;
+                const float inv = 1.f / wave_sum(p0 + p1);
+                const float a0 = p0 * inv, a1 = p1 * inv;
+                sm[S_A + lane] = a0; sm[S_A + 64 + lane] = a1;
+                const float n0 = sm[S_CUM + 15 + lane] + a0, n1 = sm[S_CUM + 15 + 64 + lane] + a1;
+                sm[S_CUM + 15 + lane] = n0; sm[S_CUM + 15 + 64 + lane] = n1;
+                if (gi == 0) {
+                    float* ah = d.align_hist + (sB + ab) * T; float* ch = d.cum_hist + (sB1 + ab) * T;
+                    if (lane < T) { ah[lane] = a0; ch[lane] = n0; }
+                    if (lane + 64 < T) { ah[lane + 64] = a1; ch[lane + 64] = n1; }
+                }
+            }
+            __syncthreads();
+            if (tid < 384) {
+                const int c = tid % 96, th = tid / 96;
+                float acc = 0.f;
+#pragma unroll 16
+                for (int t = 0; t < 32; ++t) acc += sm[S_A + 32 * th + t] * sm[S_VAL + (32 * th + t) * 96 + c];
+                sm[S_CO + th * 96 + c] = acc;
+            }
+            __syncthreads();
+            if (tid < 24) {
+                const pf32x4 val = (*reinterpret_cast<const pf32x4*>(sm + S_CO + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + S_CO + 96 + 4 * tid)) +
+                                   (*reinterpret_cast<const pf32x4*>(sm + S_CO + 192 + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + S_CO + 288 + 4 * tid));
+                const int qq = tid / 6, k4 = tid - qq * 6;
+                const int rho = ((qq * 2 + (ab >> 4)) * 16) + (ab & 15);
+                const long o = gi * 3072L + rho * 24 + 4 * k4;
+                xstore(xr, (unsigned)((OFF_CTX + slot * XCTX + o) * 4), val);
+                xstore(xr, (unsigned)((OFF_CTX + rslot * XCTX + o) * 4), sentv());
+                reinterpret_cast<pf32x4*>(d.in0 + (sB1 + ab) * (PM + PH) + 96 * gi)[tid] = val;
+                reinterpret_cast<pf32x4*>(d.pj + (sB + ab) * (PH + PM) + PH + 96 * gi)[tid] = val;
+            }
+        } else {
+            PSTAMP(14);
+            if (tid < 24) {         // rows past the batch: zero context, so that the cells' waits complete
+                const int qq = tid / 6, k4 = tid - qq * 6;
+                const int rho = ((qq * 2 + (ab >> 4)) * 16) + (ab & 15);
+                const long o = gi * 3072L + rho * 24 + 4 * k4;
+                xstore(xr, (unsigned)((OFF_CTX + slot * XCTX + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f});
+                xstore(xr, (unsigned)((OFF_CTX + rslot * XCTX + o) * 4), sentv());
+            }
+        }
+        PSTAMP(15);
+    }
+    if (tid == 0) {
+        __hip_atomic_fetch_add(d.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (PROF && d.stamps) {
+#pragma unroll
+            for (int x = 0; x < NSTAMP; ++x) d.stamps[(long)g * NSTAMP + x] = sstamp[x];
+        }
+    }
+#undef PSTAMP
+#undef PABORT_CHECK
+#undef PFAIL
+#undef PUBLISH_PARTIAL
+#undef GATHER_PARTIALS
+#undef SUM_PARTIALS
+}
+
+// ---- packers: the kernels in the order the lanes keep them (see the header comment)
+// k-step ks of a 128-unit recurrent slice: q = lane >> 4 -> producer column slice j' = 4 (ks / 4) + q, unit 32 j' + 4 i + ks % 4
+__device__ __forceinline__ int unit_of_kstep(int gi, int ks, int q) { return 32 * (4 * (ks >> 2) + q) + 4 * gi + (ks & 3); }
+
+__global__ void persist_pack_cells_kernel(const float* __restrict__ w0f, const float* __restrict__ w1, float* __restrict__ w0pk, float* __restrict__ w1pk) {
+    const long n0 = 256L * 8 * 56 * 64, n1 = 256L * 8 * 64 * 64;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n0 + n1; p += (long)gridDim.x * blockDim.x) {
+        const bool c1 = p >= n0;
+        long r = c1 ? p - n0 : p;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int per = c1 ? 64 : 56;
+        const int ks = (int)(r % per); r /= per;
+        const int wave = (int)(r & 7), g = (int)(r >> 3);
+        const int gi = g & 7, gj = g >> 3;
+        const int q = lane >> 4, mcol = lane & 15, ue = mcol >> 2, gate = mcol & 3;
+        const int u = 32 * gj + 4 * wave + ue;
+        const long col = (long)gate * PH + u;
+        long row;
+        if (!c1) row = ks < 24 ? 96 * gi + 24 * q + ks : PM + unit_of_kstep(gi, ks - 24, q);
+        else row = ks < 32 ? unit_of_kstep(gi, ks, q) : PH + unit_of_kstep(gi, ks - 32, q);
+        if (c1) w1pk[p - n0] = w1[row * 4 * PH + col]; else w0pk[p] = w0f[row * 4 * PH + col];
+    }
+}
+// query kernel by unit slice gi: [8][8 x4][512 threads][4] - thread (unit ak = tid & 15, hidden-unit group atg = tid >> 4) finds rows
+// 32 atg + 4 x4 .. + 3 of column 16 gi + ak in its x4-th float4 (a straight copy into LDS, conflict-free b128 reads)
+__global__ void persist_pack_wq_kernel(const float* __restrict__ wq, float* __restrict__ wqpk) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= 8 * 64 * 256) return;
+    const int e = p & 3, tid = (p >> 2) & 511, x4 = (p >> 11) & 7, gi = p >> 14;
+    wqpk[p] = wq[(long)(32 * (tid >> 4) + 4 * x4 + e) * PA + 16 * gi + (tid & 15)];
+}
+
+}  // namespace mstts
+using namespace mstts;
+
+extern "C" int64_t mstts_persist_fwd_ws_bytes(void) { return XCH_FLOATS * 4; }
+extern "C" int64_t mstts_persist_pack_floats(int32_t which) { return which == 0 ? 256L * 8 * 56 * 64 : which == 1 ? 256L * 8 * 64 * 64 : 8L * 64 * 256; }
+
+/* 1 when the persistent loop can run this shape on the current device: reference widths, at most 32 rows and 128 encoder
+ * positions, 31 filter taps, and a device that takes all 256 workgroups at once (one per CU - the occupancy query must admit the
+ * kernel's LDS and registers, and the device must have at least 256 CUs) */
+extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS) {
+    if (!(B >= 1 && B <= PROWS && H == PH && M == PM && A == PA && T >= 1 && T <= PT && KS == PKS)) return 0;
+    static int cached = -1;
+    if (cached < 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        cached = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= PWG) {
+            const size_t lds = (size_t)S_FLOATS * 4;
+            if (hipFuncSetAttribute((const void*)persist_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)persist_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false>, PTH, lds) == hipSuccess && per_cu >= 1)
+                cached = 1;
+        }
+        (void)hipGetLastError();
+    }
+    return cached;
+}
+
+extern "C" int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s) {
+    MSTTS_REQUIRE(w0f && w1 && wq && w0pk && w1pk && wqpk, MSTTS_ERR_SHAPE, "persist_pack: null pointer");
+    hipLaunchKernelGGL(persist_pack_cells_kernel, dim3(4096), dim3(256), 0, (hipStream_t)s, w0f, w1, w0pk, w1pk);
+    MSTTS_CHECK_LAUNCH("persist_pack_cells");
+    hipLaunchKernelGGL(persist_pack_wq_kernel, dim3(8 * 64), dim3(256), 0, (hipStream_t)s, wq, wqpk);
+    MSTTS_CHECK_LAUNCH("persist_pack_wq");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc* d, const mstts_persist_desc* p, mstts_stream_t s) {
+    MSTTS_REQUIRE(d && p && d->xw0 && d->b1 && d->in0 && d->in1 && d->pj && d->c0 && d->c1 && d->acts0 && d->acts1 && d->craw0 && d->craw1 &&
+                  d->q_hist && d->align_hist && d->cum_hist && p->w0pk && p->w1pk && p->wqpk && p->xch && p->ctrl, MSTTS_ERR_SHAPE,
+                  "decoder_train_fwd_persistent: null pointer");
+    const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
+    MSTTS_REQUIRE(d->lsa.B == B && mstts_persist_fwd_supported(B, H, M, A, T, d->lsa.KS), MSTTS_ERR_SHAPE,
+                  "decoder_train_fwd_persistent: shape or device not supported (see mstts_persist_fwd_supported)");
+    MSTTS_REQUIRE(d->zc0 && d->zh0 && d->zc1 && d->zh1, MSTTS_ERR_SHAPE, "decoder_train_fwd_persistent: the four zoneout keep-masks are required (all ones = no zoneout)");
+    MSTTS_REQUIRE(d->lsa.keys && d->lsa.values && d->lsa.loc_k && d->lsa.loc_b && d->lsa.score_w && d->lsa.score_b, MSTTS_ERR_SHAPE,
+                  "decoder_train_fwd_persistent: attention constants missing");
+    MSTTS_REQUIRE(aligned16(p->xch) && aligned16(d->in0) && aligned16(d->pj) && (M + H) % 4 == 0, MSTTS_ERR_ALIGN, "decoder_train_fwd_persistent: 16-byte alignment");
+    hipStream_t hs = (hipStream_t)s;
+    // step-0 state (zero context / hidden / cell states / cumulative alignment), armed rings, cleared control words
+    hipError_t e = hipMemsetAsync(d->in0, 0, B * (M + H) * sizeof(float), hs);
+    if (e == hipSuccess) e = hipMemsetAsync(d->in1, 0, B * 2 * H * sizeof(float), hs);
+    if (e == hipSuccess) e = hipMemsetAsync(d->c0, 0, B * H * sizeof(float), hs);
+    if (e == hipSuccess) e = hipMemsetAsync(d->c1, 0, B * H * sizeof(float), hs);
+    if (e == hipSuccess) e = hipMemsetAsync(d->cum_hist, 0, B * T * sizeof(float), hs);
+    if (e == hipSuccess) e = hipMemsetAsync(p->xch, 0xFF, XCH_FLOATS * 4, hs);
+    if (e == hipSuccess) e = hipMemsetAsync(p->ctrl, 0, 16 * sizeof(unsigned), hs);
+    if (e != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "decoder_train_fwd_persistent: memset: %s", hipGetErrorString(e));
+    PersistFwd a;
+    a.w0pk = p->w0pk; a.w1pk = p->w1pk; a.wqpk = p->wqpk; a.xw0 = d->xw0; a.b1 = d->b1;
+    a.zc0 = d->zc0; a.zh0 = d->zh0; a.zc1 = d->zc1; a.zh1 = d->zh1; a.keep = 1.f - d->zoneout;
+    a.keys = d->lsa.keys; a.values = d->lsa.values; a.lengths = d->lsa.lengths;
+    a.loc_k = d->lsa.loc_k; a.loc_b = d->lsa.loc_b; a.score_w = d->lsa.score_w; a.score_b = d->lsa.score_b;
+    a.B = (int)B; a.S = (int)S; a.T = (int)T;
+    a.in0 = d->in0; a.in1 = d->in1; a.pj = d->pj; a.c0 = d->c0; a.c1 = d->c1; a.acts0 = d->acts0; a.acts1 = d->acts1;
+    a.craw0 = d->craw0; a.craw1 = d->craw1; a.q_hist = d->q_hist; a.align_hist = d->align_hist; a.cum_hist = d->cum_hist;
+    a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1;
+    const size_t lds = (size_t)S_FLOATS * 4;
+    if (p->stamps) hipLaunchKernelGGL(persist_fwd_kernel<true>, dim3(PWG), dim3(PTH), lds, hs, a);
+    else hipLaunchKernelGGL(persist_fwd_kernel<false>, dim3(PWG), dim3(PTH), lds, hs, a);
+    MSTTS_CHECK_LAUNCH("persist_fwd");
+    return MSTTS_OK;
+}

@@ -59,8 +59,10 @@ def average_(tensors, group=None):
 
 class GradAllReduce:
     def __init__(self, grad_slab: torch.Tensor, world: int, bucket_mb: float = 32.0, group=None, force: bool = False,
-                 comm_dtype: str = "f32"):
+                 comm_dtype: str = "f32", overlap: bool = True):
         """force: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU).
+        overlap=False: start() only notes the range; the whole slab is exchanged in finish(), behind the backward pass (the A/B
+        switch for the overlapped form, `bench.py --no-overlap`).  exposed_ms() reports how long the compute stream waited in finish().
         comm_dtype "bf16" (BASELINE config 3): the message is bf16, the accumulation fp32 - each piece is rounded to bf16, every
         rank receives its 1/world shard of every rank's piece (all-to-all), sums the shards in fp32 in rank order, rounds the sum
         once and all-gathers it: half the bytes of the fp32 all-reduce on every xGMI link, and no bf16 partial sums anywhere.
@@ -68,6 +70,8 @@ class GradAllReduce:
         if comm_dtype not in ("f32", "bf16"):
             raise ValueError("comm_dtype must be 'f32' or 'bf16'")
         self.world, self.group = world, group
+        self.overlap = bool(overlap)
+        self._exposed = []                   # (event before the waits, event after them) per finish() on a GPU
         self.active = world > 1 or force
         self.bf16 = comm_dtype == "bf16"
         n = grad_slab.numel()
@@ -122,7 +126,7 @@ class GradAllReduce:
         """Asynchronously sum grad_slab[lo:hi] over the ranks (in <= bucket-size pieces).  Call it at the point of the
         backward pass where that range is final: the collective is ordered after everything enqueued so far on the
         current stream and runs beside what is enqueued next."""
-        if not self.active or hi <= lo:
+        if not self.active or hi <= lo or (not self.overlap and not getattr(self, "_finishing", False)):
             return
         import torch.distributed as dist
         per = self.bounds[0][1] - self.bounds[0][0]
@@ -147,12 +151,28 @@ class GradAllReduce:
         if not self.active:
             return
         covered, pos = sorted(self._done), 0
+        self._finishing = True
         for a, b in covered + [(self.n, self.n)]:
             if a > pos:
                 self.start(grad_slab, pos, a)
             pos = max(pos, b)
+        self._finishing = False
+        ev = None
+        if grad_slab.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()
         if self._side is not None:
             torch.cuda.current_stream(grad_slab.device).wait_stream(self._side)
+        if ev is not None:
+            ev[1].record()
+            self._exposed = (self._exposed + [ev])[-64:]
         self._works, self._done = [], []
+
+    def exposed_ms(self):
+        """Mean time per finish() that the compute stream spent waiting for the exchange (what the overlap did not hide).  Synchronises."""
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)

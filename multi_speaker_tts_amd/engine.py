@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -99,6 +100,15 @@ class TrainEngine:
         He = d.enc_lstm
         self.enc_whp = {dr: self._f(He * 4 * He) for dr in ("fw", "bw")} if lb.mstts_cell_fwd_supported(He, He) else None
         self.wq_t = self._f(d.att * H) if d.att == 128 else None         # query kernel as [A/4, H, 4] (fused query-layer data gradient)
+        # persistent decoder loop (csrc/persist.hip): fp32, reference widths; MSTTS_PERSIST=0 keeps the launch-per-step loop
+        self.persist = (os.environ.get("MSTTS_PERSIST", "1") != "0" and (recurrent_dtype or "f32").lower() == "f32"
+                        and bool(lb.mstts_persist_fwd_supported(1, H, M, d.att, 1, d.att_k)))
+        self.persist_fallbacks = 0           # sequences that had to be re-run on the launch-per-step path
+        self.persist_selftest = 0            # tests: k > 0 makes the persistent launch abort at step k - 1
+        self.persist_stamps = None           # bench: 256 x 16 int64 tensor -> per-stage ticks of the next persistent launch
+        if self.persist:
+            self.pk = [self._f(int(lb.mstts_persist_pack_floats(i))) for i in range(3)]
+            self._side = torch.cuda.Stream(device=self.device)
         self.flip = {}
         self._derived_stale = True
         self.gemm_dtype = (gemm_dtype or "f32").lower()
@@ -166,6 +176,8 @@ class TrainEngine:
                 call("mstts_pack_cell_fwd", ptr(ke, oke + cin_e * 4 * He), 4 * He, ptr(self.enc_whp[dr]), He, He)
         if self.wq_t is not None:
             call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
+        if self.persist:
+            call("mstts_persist_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]))
         if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
             A_ = d.att
             k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
@@ -234,6 +246,12 @@ class TrainEngine:
         w.energy_ws_floats = int(lib.load().mstts_lsa_step_q_ws_bytes(B, Te)) // 4 + 2      # room for the in-launch query exchange
         w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(w.energy_ws_floats), f(int(nq.value))
         w.act_p = f(2 * int(lb.mstts_cell_act_floats(B, M + H) + lb.mstts_cell_act_floats(B, 2 * H))) if self.fused_cells else None
+        w.persist = self.persist and bool(lb.mstts_persist_fwd_supported(B, H, M, A, Te, d.att_k))
+        if w.persist:
+            w.xch = f(int(lb.mstts_persist_fwd_ws_bytes()) // 4)
+            w.pctrl = torch.zeros(16, dtype=torch.int32, device=self.device)
+            w.pctrl_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.pdesc = lib.PersistDesc()
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
         # postnet
@@ -403,7 +421,43 @@ class TrainEngine:
         dec.energy_ws_floats = w.energy_ws_floats if self.fuse_query else 0
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))
-        call("mstts_decoder_train_fwd", C.byref(dec))
+        ev = None
+        if w.persist:
+            # ONE launch for all S steps; the launch-per-step loop below is the fallback when the 256 workgroups were not co-resident
+            # or a bounded wait expired (ctrl words, checked after the rest of the forward pass is enqueued - no bubble on the device)
+            pd = w.pdesc
+            pd.w0pk, pd.w1pk, pd.wqpk, pd.xch, pd.ctrl = ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]), ptr(w.xch), ptr(w.pctrl)
+            pd.stamps = ptr(self.persist_stamps) if self.persist_stamps is not None else None
+            pd.selftest_fail_step = int(self.persist_selftest)
+            call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            call("mstts_decoder_train_fwd", C.byref(dec))
+        self._forward_tail(w)
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                w.pctrl_host.copy_(w.pctrl, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+            done.synchronize()
+            st = w.pctrl_host
+            if int(st[1]) != 0 or int(st[2]) != 256:
+                self.persist_fallbacks += 1
+                self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
+                cur.synchronize()
+                call("mstts_decoder_train_fwd", C.byref(dec))
+                self._forward_tail(w)
+        return w
+
+    def _forward_tail(self, w):
+        """Everything behind the decoder loop: projection, postnet, residual, the vocoder's statistics side effect."""
+        d = self.d
+        B, S = w.B, w.S
+        H, M = d.dec_lstm, d.mem
+        mk = w.masks
         # ---- projection (Modules.py:309-321) on all steps at once, then batch-major linear/stop
         self._gemm(w.pj, self.wp_pad, w.proj, S * B, self.proj_ld, H + M, H + M, self.proj_ld, self.proj_ld, bias=self.bp_pad)
         call("mstts_unpack_proj", ptr(w.proj), self.proj_ld, ptr(w.linear), ptr(w.stop), B, S, d.n_mel)
@@ -419,7 +473,6 @@ class TrainEngine:
         call("mstts_add", ptr(w.linear), ptr(x), ptr(w.mel_out), B * S * d.n_mel)
         if self.update_vocoder_bn:
             self._vocoder_bn_update(w)
-        return w
 
     def _vocoder_bn_update(self, w):
         """Quirk Q20: the train op also runs the vocoder conv-bank's BN update ops on the predicted mel."""

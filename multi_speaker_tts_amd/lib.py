@@ -92,6 +92,10 @@ class DecoderTrain(C.Structure):
                 ("energy_ws_floats", i64)]
 
 
+class PersistDesc(C.Structure):
+    _fields_ = [("w0pk", vp), ("w1pk", vp), ("wqpk", vp), ("xch", vp), ("ctrl", vp), ("stamps", vp), ("selftest_fail_step", i32)]
+
+
 class DecoderTrainBwd(C.Structure):
     _fields_ = [("fwd", C.POINTER(DecoderTrain)), ("d_pj", vp), ("dg0", vp), ("dg1", vp), ("dq_hist", vp),
                 ("de_hist", vp), ("d_in0", vp), ("ws", vp)]
@@ -201,6 +205,11 @@ SIGNATURES = {
     "mstts_lstm_seq_ws_floats": (i64, [i64, i64, i32]),
     "mstts_decoder_train_fwd": (i32, [P(DecoderTrain), vp]),
     "mstts_decoder_train_bwd": (i32, [P(DecoderTrainBwd), vp]),
+    "mstts_persist_fwd_supported": (i32, [i64, i64, i64, i64, i64, i64]),
+    "mstts_persist_fwd_ws_bytes": (i64, []),
+    "mstts_persist_pack_floats": (i64, [i32]),
+    "mstts_persist_pack": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+    "mstts_decoder_train_fwd_persistent": (i32, [P(DecoderTrain), P(PersistDesc), vp]),
     "mstts_decoder_train_bwd_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
     "mstts_decoder_train_bwd_parts": (i32, [i64, i64]),
     "mstts_decoder_train_ws_floats": (i32, [i64, i64, i64, i64, C.POINTER(i64), C.POINTER(i64)]),
@@ -234,7 +243,16 @@ def load():
         return _lib
     from . import build as _b
     if _b.needs_build():                 # content hashes of the sources vs the ones the library was built from (file-locked)
-        _b.build()
+        try:
+            _b.build()
+        except RuntimeError as e:
+            # a deployed library without its hash sidecars on a host without hipcc: load what is there (never a CPU fallback -
+            # without the .so this still raises)
+            if "hipcc not found" in str(e) and os.path.exists(LIB_PATH):
+                import warnings
+                warnings.warn("libmstts_hip.so could not be checked against its sources (hipcc not found); loading the existing library")
+            else:
+                raise
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch; never fall back

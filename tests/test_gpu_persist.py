@@ -1,0 +1,133 @@
+"""The persistent decoder loop (csrc/persist.hip, mstts_decoder_train_fwd_persistent: all S steps of Modules.py:397-443 in one
+launch) against the launch-per-step loop it replaces (mstts_decoder_train_fwd) on the same engine, inputs and keep-masks: every
+tensor the BPTT reads must agree.  Parity with the oracle at these widths is test_gpu_model.py::test_train_step_parity (its two
+reference-width cases take the persistent path) and test_depth_parity below."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import dims_pair, rel_err, t2n, to_dev
+from oracle import model as OM, train as OT
+from multi_speaker_tts_amd.engine import TrainEngine
+
+pytestmark = pytest.mark.gpu
+
+# reference widths where the loop sees them (decoder cells 1024, memory 768 = 2 x 256 + 256, attention 128 / 31 taps); the rest reduced
+WIDE = dict(emb=64, enc_conv_ch=64, enc_lstm=256, spk=256, prenet=64, dec_lstm=1024, n_mel=16, post_ch=32)
+HIST = ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist")
+
+
+def _engine(dev, seed=3):
+    pd, od = dims_pair(**WIDE)
+    values = OM.init_params(od, seed)
+    g = np.random.default_rng(seed + 1)
+    for k in values:
+        if k.endswith(("bias", "bias_b")):
+            values[k] = g.normal(0, 0.1, values[k].shape)
+    eng = TrainEngine(pd, device=dev, values=values)
+    if not eng.persist:
+        pytest.skip("persistent loop not available on this device (needs 256 CUs and one workgroup per CU)")
+    return eng, od
+
+
+def _snapshot(w):
+    return {k: t2n(getattr(w, k)).copy() for k in HIST + ("linear", "mel_out", "stop")}
+
+
+@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (5, 128, 3, True), (1, 7, 2, False), (32, 100, 60, True)])
+def test_persistent_equals_launch_per_step(dev, B, Te, L, ragged):
+    eng, od = _engine(dev)
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=ragged), dev)
+    seed = OT.step_seed(1234, 0)
+    w = eng.plan(B, Te, L)
+    assert w.persist
+    eng.forward(batch, w, seed=seed)
+    torch.cuda.synchronize()
+    st = w.pctrl.cpu().numpy()
+    assert eng.persist_fallbacks == 0 and st[1] == 0 and st[2] == 256, st[:3]
+    a = _snapshot(w)
+    for k in HIST:                                       # the second pass must really write them again
+        getattr(w, k).zero_()
+    w.persist = False
+    eng.forward(batch, w, seed=seed)
+    torch.cuda.synchronize()
+    b = _snapshot(w)
+    bad = {}
+    for k in a:
+        assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all(), k
+        e = rel_err(a[k], b[k])
+        if e > (2e-4 if L > 20 else 2e-5):               # same fp32 products, different summation order
+            bad[k] = e
+    assert not bad, bad
+
+
+def test_persistent_is_deterministic(dev):
+    """The launch itself, twice on identical inputs (the decoder descriptors of the plan, called directly - upstream of the loop the
+    forward pass contains reductions with atomics): bit-identical histories, i.e. no summation order depends on arrival order."""
+    import ctypes as C
+    from multi_speaker_tts_amd import lib
+    eng, od = _engine(dev)
+    batch = to_dev(OT.synthetic_batch(od, 32, 128, 7, seed=9, ragged=True), dev)
+    w = eng.plan(32, 128, 7)
+    eng.forward(batch, w, seed=77)
+    torch.cuda.synchronize()
+    a = {k: t2n(getattr(w, k)).copy() for k in HIST}
+    for _ in range(3):
+        for k in HIST:
+            getattr(w, k).zero_()
+        lib.call("mstts_decoder_train_fwd_persistent", C.byref(w.dec), C.byref(w.pdesc))
+        torch.cuda.synchronize()
+        st = w.pctrl.cpu().numpy()
+        assert st[1] == 0 and st[2] == 256, st[:3]
+        for k in HIST:
+            assert np.array_equal(a[k], t2n(getattr(w, k))), k
+    assert eng.persist_fallbacks == 0
+
+
+def test_persistent_abort_falls_back(dev):
+    """Self-test knob: workgroup 0 raises the abort word at step 3 and leaves; every other workgroup finds the word while it waits for
+    that workgroup's data, the launch ends early, and the engine re-runs the sequence on the launch-per-step path."""
+    eng, od = _engine(dev)
+    B, Te, L = 8, 40, 10
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=True), dev)
+    w = eng.plan(B, Te, L)
+    eng.persist_selftest = 4
+    eng.forward(batch, w, seed=11)
+    torch.cuda.synchronize()
+    assert eng.persist_fallbacks == 1 and eng.persist_last_status[1] == 3 and eng.persist_last_status[2] < 256
+    a = _snapshot(w)
+    eng.persist_selftest = 0
+    w.persist = False
+    eng.forward(batch, w, seed=11)
+    torch.cuda.synchronize()
+    b = _snapshot(w)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k             # the fallback IS the launch-per-step path
+    w.persist = True
+    eng.forward(batch, w, seed=11)                       # and the next launch is healthy again
+    torch.cuda.synchronize()
+    assert eng.persist_fallbacks == 1
+    c = _snapshot(w)
+    assert rel_err(c["pj"], b["pj"]) < 2e-5
+
+
+def test_persistent_train_steps(dev):
+    """Three optimizer steps through the persistent forward (kernels re-packed after every Adam update): loss scalars equal those of
+    an engine that never uses it."""
+    pd, od = dims_pair(**WIDE)
+    values = OM.init_params(od, 3)
+    batch = to_dev(OT.synthetic_batch(od, 16, 64, 20, seed=5, ragged=True), dev)
+    out = []
+    for persist in (True, False):
+        eng = TrainEngine(pd, device=dev, values=values)
+        if persist and not eng.persist:
+            pytest.skip("persistent loop not available on this device")
+        eng.persist = eng.persist and persist
+        losses = []
+        for _ in range(3):
+            w = eng.train_step(batch)
+            losses.append(eng.scalars(w)["Loss"])
+        out.append((losses, eng.persist_fallbacks))
+    assert out[0][1] == 0
+    assert np.allclose(out[0][0], out[1][0], rtol=2e-4), out
+    assert out[0][0][-1] < out[0][0][0]

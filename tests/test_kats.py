@@ -298,6 +298,52 @@ def test_corpus_walkers(tmp_path):
         PG.main([], device="cpu")
 
 
+def test_pattern_cli_per_corpus_rules(tmp_path, monkeypatch):
+    """What the reference's command line passes per corpus (Pattern_Generate.py:318-404): TIMIT pattern names carry the speaker
+    directory (its utterance names repeat from speaker to speaker - without the prefix all but one SA1 would be overwritten),
+    LibriSpeech mels are generated with spectral subtraction and the other corpora without, and the TEDLIUM generator calls
+    Mel_Generate with its defaults and stops at the first segment the length filter rejects (Pattern_Generate.py:80-113)."""
+    from multi_speaker_tts_amd import Hyper_Parameters as hp, Pattern_Generate as PG
+    ti = tmp_path / "TIMIT"
+    y = (np.arange(8000) % 200 - 100).astype(np.int16)
+    for spk in ("FCJF0", "MDAB0"):
+        _write_sphere(str(ti / "DR1" / spk / "SA1.WAV"), y)
+        (ti / "DR1" / spk / "SA1.TXT").write_text("0 46797 She had your dark suit in greasy wash water all year.\n")
+    ls = tmp_path / "LS"
+    _write_wav(str(ls / "17" / "363" / "17-363-0001.wav"))
+    (ls / "17" / "363" / "17-363.trans.txt").write_text("17-363-0001 WHO KNOWS MUCH BELIEVES THE LESS\n")
+    lj = tmp_path / "LJ"
+    _write_wav(str(lj / "wavs" / "LJ001-0001.wav"))
+    (lj / "metadata.csv").write_text("LJ001-0001|x|Printing, in the only sense\n", encoding="utf-8")
+    tl = tmp_path / "TL"
+    _write_sphere(str(tl / "sph" / "talk1.sph"), np.arange(32000, dtype=np.int16))
+    os.makedirs(tl / "stm")
+    (tl / "stm" / "talk1.stm").write_text("talk1 1 spk 0.10 0.40 <o> first one\ntalk1 1 spk 0.50 0.60 <o> too short\ntalk1 1 spk 1.00 1.50 <o> never reached\n")
+    calls = []
+
+    def fake_mel(path, spectral_Subtract=False, range_Ignore=False, device="cuda"):
+        calls.append((os.path.basename(path), bool(spectral_Subtract), bool(range_Ignore)))
+        if path.endswith(".wav") and "tmp" in os.path.basename(path).lower() and len(calls_tl) == 1:
+            calls_tl.append(1)
+            return None                                  # the second TEDLIUM segment is "out of range"
+        if "tmp" in os.path.basename(path).lower():
+            calls_tl.append(1)
+        return np.zeros((5, hp.Sound.Mel_Dim), np.float32)
+
+    calls_tl = []
+    monkeypatch.setattr(PG, "Mel_Generate", fake_mel)
+    monkeypatch.setattr(hp.Train, "Pattern_Path", str(tmp_path / "PAT"))
+    n = PG.main(["-timit", str(ti), "-ls", str(ls), "-lj", str(lj), "-tl", str(tl), "-all"], device="cpu")
+    files = sorted(f for f in os.listdir(tmp_path / "PAT") if f != hp.Train.Metadata_File.upper())
+    assert files == ["LJ.LJ001-0001.PICKLE", "LS.17-363-0001.PICKLE", "TIMIT.FCJF0.SA1.PICKLE", "TIMIT.MDAB0.SA1.PICKLE", "TL.TALK1.0.PICKLE"], files
+    assert n == 5
+    by_name = {c[0]: c for c in calls if not c[0].lower().startswith("tmp")}
+    assert by_name["17-363-0001.wav"][1:] == (True, True)            # LibriSpeech: spectral subtraction, -all forwarded
+    assert by_name["LJ001-0001.wav"][1:] == (False, True) and by_name["SA1.WAV"][1:] == (False, True)
+    tl_calls = [c for c in calls if c[0].lower().startswith("tmp")]
+    assert len(tl_calls) == 2 and all(c[1:] == (False, False) for c in tl_calls)       # defaults; third segment never generated
+
+
 def test_tf_bundle_reader_against_hand_assembled_bytes(tmp_path):
     """A checkpoint assembled BYTE BY BYTE here from the published formats (LevelDB table_format.md: prefix-compressed entries,
     restart array, 1-byte compression tag + masked CRC-32C trailer, 48-byte footer with magic 0xdb4775248b80fb57;

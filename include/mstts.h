@@ -582,6 +582,21 @@ int mstts_decoder_train_bwd(const mstts_decoder_train_bwd_desc* d, mstts_stream_
 int64_t mstts_decoder_train_bwd_ws_floats(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t CH);
 int32_t mstts_decoder_train_bwd_parts(int64_t H, int64_t M);   /* number of d_in0 slabs */
 
+/* ---- BPTT through the same S steps as ONE persistent launch (csrc/persist_bwd.hip), the counterpart of
+ * mstts_decoder_train_fwd_persistent: same geometry and support rule (mstts_persist_bwd_supported), same descriptor type with
+ *   w0pk / w1pk / wqpk = the mstts_persist_bwd_pack(w0f, w1, wq) copies (transposed kernels in the lanes' order,
+ *                        mstts_persist_bwd_pack_floats(0 / 1 / 2) floats),  xch = mstts_persist_bwd_ws_bytes() bytes,  ctrl = 16 uint32.
+ * It reads the forward history of bd->fwd and bd->d_pj and writes what mstts_decoder_train_bwd writes - dg0, dg1 [S,B,4H], dq_hist
+ * (no pre-zeroing needed), de_hist - with ONE difference: d_in0 receives, in its FIRST slab only, the complete gradient of the
+ * context rows (columns 0..M-1 of slots 1..S-1; the h0 columns are not written), so a consumer sums 1 slab instead of
+ * mstts_decoder_train_bwd_parts().  ctrl[1] == 0 and ctrl[2] == 256 after the launch <=> complete; otherwise re-run
+ * mstts_decoder_train_bwd (it overwrites everything). */
+int32_t mstts_persist_bwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
+int64_t mstts_persist_bwd_ws_bytes(void);
+int64_t mstts_persist_bwd_pack_floats(int32_t which);
+int mstts_persist_bwd_pack(const float* w0f, const float* w1, const float* wq, float* w0t, float* w1t, float* wqt, mstts_stream_t s);
+int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_desc* bd, const mstts_persist_desc* p, mstts_stream_t s);
+
 /* ---- free-running decoder steps (inference branch of Decoder_Helper.next_inputs,
  * Modules.py:212-237): enqueues steps [step0, step0+n).  frame feedback: step s reads its input
  * frame from linear rows of step s-1 (zeros for s == 0).  Buffers as in the train descriptor but

@@ -24,17 +24,10 @@
 // Every wait is bounded (wall clock); a workgroup that gives up raises an abort word that all others poll, the launch ends, and the
 // host re-runs the sequence on the launch-per-step path (mstts_decoder_train_fwd).  The same happens when the 256 workgroups do not
 // become co-resident (start rendezvous).
-#include "common.h"
+#include "persist_common.h"
 
 namespace mstts {
 
-typedef float pf32x4 __attribute__((ext_vector_type(4)));
-typedef int pi32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int PH = 1024, PM = 768, PA = 128, PT = 128, PROWS = 32, PWG = 256, PTH = 512;
-constexpr int PKS = 31;                          // location filter taps (hp.Attention.Conv.Kernel_Size)
-constexpr int PRING = 4;
-constexpr unsigned PSENT = 0xFFFFFFFFu;
 // ring sizes in floats per slot
 constexpr long XCTX = 8L * 128 * 24, XACT = 8L * 128 * 32, XPART = 256L * 8 * 2 * 256, XM1 = 32L * PH, XEN = 32L * 8 * PT;
 constexpr long OFF_CTX = 0, OFF_M0 = OFF_CTX + PRING * XCTX, OFF_H0 = OFF_M0 + PRING * XACT, OFF_H1 = OFF_H0 + PRING * XACT,
@@ -48,7 +41,6 @@ constexpr int LC = 28, LA = 36;                  // padded row strides of the st
 constexpr int S_STG = 0, S_RED = S_STG + 128 * LA, S_TR = S_RED + 4 * 2 * 256, S_M1 = S_TR + 2 * 128, S_EN = S_M1 + PH,
               S_CUM = S_EN + 8 * PT, S_A = S_CUM + 176, S_Q = S_A + PT, S_QF = S_Q + 512, S_CO = S_QF + 16, S_LK = S_CO + 4 * 96,
               S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_FLOATS = S_WQ + 8 * 512 * 4;
-constexpr unsigned long long PERSIST_TIMEOUT_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock per wait
 constexpr int NSTAMP = 16;
 
 struct PersistFwd {
@@ -65,45 +57,6 @@ struct PersistFwd {
     int fail_step;                               // self-test: workgroup 0 raises the abort word at this step (-1 = never)
 };
 
-__device__ __forceinline__ bool has_sent(const pf32x4& v) {
-    return (__float_as_uint(v[0]) == PSENT) | (__float_as_uint(v[1]) == PSENT) | (__float_as_uint(v[2]) == PSENT) | (__float_as_uint(v[3]) == PSENT);
-}
-__device__ __forceinline__ pf32x4 xload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(pf32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));       // aux 16 = sc1
-}
-__device__ __forceinline__ void xstore(__amdgpu_buffer_rsrc_t r, unsigned byte_off, pf32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pi32x4, v), r, (int)byte_off, 0, 16);
-}
-__device__ __forceinline__ pf32x4 sentv() { const float s = __uint_as_float(PSENT); return (pf32x4){s, s, s, s}; }
-
-// Polls N 16-byte pieces per lane until none holds the sentinel.  Returns false on time-out / abort (wave-uniform).
-// (The empty asm with a memory clobber is what makes this a poll: the buffer-load builtin is a plain read to the compiler, which
-//  otherwise proves the re-load redundant and deletes the whole loop.)
-template <int N>
-__device__ __forceinline__ bool gather(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N], const unsigned* ctrl) {
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int m = 0; m < N; ++m) v[m] = xload(r, off[m]);
-    unsigned spins = 0;
-    unsigned long long t0 = 0;
-    for (;;) {
-        asm volatile("" ::: "memory");
-        bool miss = false;
-#pragma unroll
-        for (int m = 0; m < N; ++m) miss |= has_sent(v[m]);
-        if (!__builtin_amdgcn_ballot_w64(miss)) return true;
-        if ((++spins & 15u) == 0) {
-            const unsigned long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            if (now - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        }
-#pragma unroll
-        for (int m = 0; m < N; ++m)
-            if (has_sent(v[m])) v[m] = xload(r, off[m]);
-    }
-}
-
-#define PMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // acc[t] += W[k-steps 4 K4A .. 4 K4B) . X[t], X read from the staged LDS slice (row stride LD); the wave's registers w[WOFF + ks]
 template <int K4A, int K4B, int LD, int WOFF, int NW>

@@ -1,0 +1,633 @@
+// Persistent BPTT of the teacher-forced decoder loop for gfx950: the backward pass through ALL S steps of
+// Decoder_Dynamic_Decode.body (Modules.py:397-443; ZoneoutLSTMCell.py:228-271; Location_Sensitive_Attention.py:43-85) in ONE
+// launch of 256 co-resident workgroups - the mirror image of csrc/persist.hip and built from the same hand-off primitives
+// (persist_common.h: write-through stores, L1-bypassing polls, the data is the flag).
+//
+// Per step (descending) the chain of mstts_decoder_train_bwd is
+//     attention backward -> cell-1 update backward -> d[g1] . W1^T -> cell-0 update backward -> d[g0] . W0f^T -> (next step)
+// and only half of each product is on it: the rows that give d[m0] / d[ctx]; the rows that give the gradients of the recurrent
+// states h1 / h0 are consumed one step later and run in the shadow of the hand-offs.
+//
+// Work cut.  Workgroup (i, j) = (id & 7, id >> 3):
+//   * products: contraction slice i (the 512 gate columns of the 128 hidden units {32 j' + 4 i + e}) x output slice j (cell 1: m0 / h1
+//     units 32 j .. 32 j + 31; cell 0: context columns 24 j .. 24 j + 23 and h0 units 32 j ..) of BOTH transposed kernels, in registers
+//     for the whole sequence (128 per lane, MFMA A operands).  Each of the 8 waves takes one eighth of the contraction and fetches
+//     exactly its own slice of the gate gradients straight into MFMA B-operand registers - no staging, no barrier in front of
+//     the product; the eight partial tiles meet in LDS and leave as one [32 k x 32 rows] tile for the 8 workgroups of column j.
+//   * cell updates: the 4 hidden units 4 id .. 4 id + 3 of both cells for all 32 rows (same owner as in the forward kernel); the
+//     carried state gradients stay in registers.
+//   * attention: row j, unit / column slice i as in the forward kernel: 96 value columns (LDS), 16 key / query units, its slice of
+//     the query kernel (LDS), and the part of G = dL/d(cumulative alignment) that its own 16 units contribute - the row's
+//     d_alignment = sum over the 8 slices of (values_i . d_ctx_i + G_i), so ONE exchange per step carries both.
+// Exact fp32, fixed summation order (deterministic).  Bounded waits / abort word / start rendezvous as in the forward kernel; on
+// abort the host re-runs mstts_decoder_train_bwd.
+#include "persist_common.h"
+
+namespace mstts {
+
+// ring sizes in floats per slot
+constexpr long BDG = 8L * 8 * 2 * 4 * 256;       // gate gradients of one cell: [slice 8][eighth 8][row tile 2][group 4][lane 64][4 units]
+constexpr long BPART = 256L * 8 * 32 * 4;        // partial product tiles: [reducer 256][source 8][row 32][4 units]
+constexpr long BPCTX = 32L * 192 * 8 * 4;        // partial d_ctx: [row 32][4-column block 192][source 8][4]
+constexpr long BDM1 = 32L * 8 * PH;              // query-layer data gradient: [row 32][slice 8][1024]
+constexpr long BDA = 32L * 8 * PT;               // partial d_alignment: [row 32][slice 8][128]
+constexpr long BO_DG1 = 0, BO_DG0 = BO_DG1 + PRING * BDG, BO_PM0 = BO_DG0 + PRING * BDG, BO_PH1 = BO_PM0 + PRING * BPART,
+               BO_PH0 = BO_PH1 + PRING * BPART, BO_PCTX = BO_PH0 + PRING * BPART, BO_DM1 = BO_PCTX + PRING * BPCTX,
+               BO_DA = BO_DM1 + PRING * BDM1, BXCH_FLOATS = BO_DA + PRING * BDA;
+// LDS layout (floats); small arrays first (DS immediate offsets reach 64 KB)
+constexpr int B_RED = 0,                         // [8 waves][4 tiles][64 lanes][4]: product partials; the attention phases use it as scratch
+              B_G = B_RED,                       //   [160 padded positions][16 units] energy gradients of this slice (attention only)
+              B_PC = B_RED + 160 * 16,           //   [192 pieces][4] partial d_ctx as fetched
+              B_DA = B_PC + 192 * 4,             //   [8 slices][128] partial d_alignment as fetched
+              B_PD = B_DA + 8 * PT,              //   [4 column quarters][128] values . d_ctx
+              B_TR = B_RED + 8 * 4 * 256,        // [3][128] transposes between the (unit, row) and (row, 4 units) thread layouts + [512] gate transpose
+              B_GP = B_TR + 3 * 128 + 512,       // [128] this slice's part of G
+              B_A = B_GP + PT, B_CUM = B_A + PT, B_DE = B_CUM + 176, B_DC = B_DE + PT, B_DPJ = B_DC + 96, B_QF = B_DPJ + 96,
+              B_DQ = B_QF + 16, B_DQF = B_DQ + 512, B_LK = B_DQF + 16, B_FLAG = B_LK + 32 * 16, B_STAMP = B_FLAG + 4,
+              B_VALT = B_STAMP + 2 * 16,         // [96 columns][128 positions] values slice, transposed
+              B_WQT = B_VALT + 96 * PT,          // [(k4 * 4 + e) * 256 + l][4]: Wq[4 l + e][16 i + 4 k4 ..]
+              B_FLOATS = B_WQT + 16 * 256 * 4;
+static_assert(B_PD + 4 * PT <= B_TR, "attention scratch must fit into the product-partial buffer");
+static_assert(B_FLOATS * 4 <= 160 * 1024, "LDS budget");
+constexpr int NBSTAMP = 16;
+
+struct PersistBwd {
+    const float* w1t; const float* w0t; const float* wqt;
+    const float* acts0; const float* acts1; const float* craw0; const float* craw1; const float* c0; const float* c1;
+    const uint8_t* zc0; const uint8_t* zh0; const uint8_t* zc1; const uint8_t* zh1; float keep;
+    const float* align_hist; const float* cum_hist; const float* q_hist;
+    const float* keys; const float* values; const int32_t* lengths;
+    const float* loc_k; const float* loc_b; const float* score_w; const float* score_b;
+    const float* d_pj;
+    int B, S, T;
+    float* dg0; float* dg1; float* dq_hist; float* de_hist; float* d_in0;
+    float* xch; unsigned* ctrl; unsigned long long* stamps; int fail_step;
+};
+
+// zoneout-LSTM cell backward for one (row, unit) (the pointwise part of mstts_lstm_point_bwd): dm = gradient of the cell output m
+// (without the zoned-state path), dhs / dcs = gradients of the zoned states h' / c'.  Returns the four gate gradients, updates the carried
+// state gradients to those of the PREVIOUS step's states (direct zoneout paths only; the product part is added by the caller).
+__device__ __forceinline__ pf32x4 cell_bwd(float dm, float& dhs, float& dcs, float si, float tj, float sf, float so, float c, float cp,
+                                           float mh, float mc) {
+    dm += mh * dhs;
+    const float tc = tanhf_(c);
+    const float dc = dm * so * (1.f - tc * tc) + mc * dcs;
+    pf32x4 dg;
+    dg[0] = dc * tj * si * (1.f - si);
+    dg[1] = dc * si * (1.f - tj * tj);
+    dg[2] = dc * cp * sf * (1.f - sf);
+    dg[3] = dm * tc * so * (1.f - so);
+    dcs = dcs * (1.f - mc) + dc * sf;
+    dhs = dhs * (1.f - mh);
+    return dg;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int g0 = blockIdx.x, tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    int g = g0, gi = g & 7, gj = g >> 3;
+    int tid = tid0, lane = tid & 63, wave = wave0;
+    const int B = d.B, S = d.S, T = d.T;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(d.xch, 0, (int)(BXCH_FLOATS * 4), 0x00020000);
+    unsigned* sflag = reinterpret_cast<unsigned*>(sm + B_FLAG);
+
+    // ---------------- start rendezvous
+    if (tid == 0) {
+        sflag[0] = 0;
+        __hip_atomic_fetch_add(d.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(d.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PWG) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(d.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(d.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sflag[0] = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (sflag[0]) return;
+
+    // ---------------- once: the transposed kernels of this workgroup / wave -> registers.  w1t[h * 32 + kt * 16 + ks]: half h (0 = the
+    // rows on the chain: m0 units, 1 = h1 units), output tile kt, contraction step ks of this wave's eighth; w0t likewise (context / h0)
+    float w1t[64], w0t[64];
+    {
+        const float* p1 = d.w1t + ((long)(g * 8 + wave) * 64) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) w1t[r] = p1[r * 64];
+        const float* p0 = d.w0t + ((long)(g * 8 + wave) * 64) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) w0t[r] = p0[r * 64];
+    }
+    int ab = gj;
+    const bool arow = ab < B;
+    const int alen = arow ? (d.lengths ? d.lengths[ab] : T) : 0;
+    int ak = tid & 15, atg = tid >> 4;
+    float kreg[4];
+    float asb = 0.f, awk = 0.f;
+    {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int t = 4 * atg + m;
+            kreg[m] = (arow && t < T) ? d.keys[((long)ab * T + t) * PA + 16 * gi + ak] : 0.f;
+        }
+        asb = d.score_b[16 * gi + ak] + d.loc_b[16 * gi + ak];
+        awk = d.score_w[16 * gi + ak];
+        for (int x = tid; x < 32 * 16; x += PTH) sm[B_LK + x] = (x < PKS * 16) ? d.loc_k[(x >> 4) * PA + 16 * gi + (x & 15)] : 0.f;
+        for (int x = tid; x < 96 * PT; x += PTH) {
+            const int c = x >> 7, t = x & 127;
+            sm[B_VALT + x] = (arow && t < alen && t < T) ? d.values[((long)ab * T + t) * PM + 96 * gi + c] : 0.f;
+        }
+        for (int x = tid; x < 176; x += PTH) sm[B_CUM + x] = 0.f;
+        for (int x = tid; x < PT; x += PTH) { sm[B_GP + x] = 0.f; sm[B_A + x] = 0.f; sm[B_DE + x] = 0.f; }
+        const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqt) + (long)gi * 16 * 256;
+        for (int x = tid; x < 16 * 256; x += PTH) reinterpret_cast<pf32x4*>(sm + B_WQT)[x] = wqs[x];
+    }
+    int et = wave & 1, er = 16 * et + (lane & 15), ee = lane >> 4, eu = 4 * g + ee;
+    bool ew = wave < 2, elive = ew && er < B;
+    float dc0s = 0.f, dh0s = 0.f, dc1s = 0.f, dh1s = 0.f;       // carried gradients of the zoned states c' / h' (direct paths)
+    unsigned long long* sstamp = reinterpret_cast<unsigned long long*>(sm + B_STAMP);
+    unsigned tprev = 0;
+    if (PROF && tid < NBSTAMP) sstamp[tid] = 0;
+#define PSTAMP(idx) do { if (PROF && tid == 0) { const unsigned n__ = (unsigned)wall_clock64(); sstamp[idx] += (unsigned)(n__ - tprev); tprev = n__; } } while (0)
+#define PABORT_CHECK() do { __syncthreads(); if (sflag[0]) return; } while (0)
+#define PFAIL() do { sflag[0] = 1; unsigned z__ = 0u; __hip_atomic_compare_exchange_strong(d.ctrl + 1, &z__, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+    __syncthreads();
+    if (PROF && tid == 0) tprev = (unsigned)wall_clock64();
+
+    for (int s = S - 1; s >= 0; --s) {
+        const bool first = s == S - 1;
+        const unsigned slot = (unsigned)s & 3u, rslot = (unsigned)(s + 2) & 3u, nslot = (unsigned)(s + 1) & 3u;     // nslot: the slot of step s + 1
+        tid = tid0; g = g0; wave = wave0;
+        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+s"(g), "+s"(wave));
+        lane = tid & 63; gi = g & 7; gj = g >> 3; ab = gj; ak = tid & 15; atg = tid >> 4;
+        et = wave & 1; er = 16 * et + (lane & 15); ee = lane >> 4; eu = 4 * g + ee;
+        ew = wave < 2; elive = ew && er < B;
+        if (s == d.fail_step && g == 0 && tid == 0) {
+            __hip_atomic_store(d.ctrl + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sflag[0] = 1;
+        }
+        const long sB = (long)s * B, sB1 = sB + B;
+        const bool rowok = er < B;
+        const unsigned erc = rowok ? (unsigned)er : 0u;
+        const unsigned oH = erc * PH + eu, o4H = erc * 4 * PH + eu;
+        // ---- operands of the cell-1 update backward, requested now by every wave (see persist.hip on why unconditionally)
+        float a1v[4], cr1, cp1, dpm1;
+        uint8_t zc1v, zh1v;
+        {
+            const float* a = d.acts1 + sB * 4 * PH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a1v[q] = a[o4H + q * PH];
+            cr1 = (d.craw1 + sB * PH)[oH]; cp1 = (d.c1 + sB * PH)[oH];
+            zc1v = (d.zc1 + sB * PH)[oH]; zh1v = (d.zh1 + sB * PH)[oH];
+            dpm1 = (d.d_pj + sB * (PH + PM))[erc * (PH + PM) + eu];
+        }
+        // ================= attention backward of row ab, slice gi
+        if (arow) {
+            {   // this step's forward rows: alignment, cumulative alignment BEFORE the step, query units, projection part of d_ctx
+                const int t = tid & 127;
+                const float av = (d.align_hist + (sB + ab) * T)[t < T ? t : 0];
+                const float cv = (d.cum_hist + (sB + ab) * T)[t < T ? t : 0];
+                const float qv = (d.q_hist + (sB + ab) * PA + 16 * gi)[tid & 15];
+                const float dv = (d.d_pj + (sB + ab) * (PH + PM) + PH + 96 * gi)[tid < 96 ? tid : 0];
+                sm[B_A + t] = t < T ? av : 0.f;
+                sm[B_CUM + 15 + t] = t < T ? cv : 0.f;
+                sm[B_QF + (tid & 15)] = qv;
+                sm[B_DPJ + (tid < 96 ? tid : 0)] = dv;
+                // zero padding of the energy-gradient window (positions -15 .. -1 and 128 .. 144): the products of the step before wrote here
+                sm[B_G + (tid < 240 ? tid : 143 * 16 + (tid - 240))] = 0.f;
+            }
+            pf32x4 pc = {0.f, 0.f, 0.f, 0.f};
+            unsigned pcoff[1];
+            pcoff[0] = (unsigned)((BO_PCTX + nslot * BPCTX + ((long)ab * 192 + 24 * gi) * 32) * 4 + 16 * (tid < 192 ? tid : 0));
+            __syncthreads();
+            // tanh terms of this slice (independent of everything that arrives): fac = w_k (1 - tanh^2(keys + q + location filter))
+            float fac[4];
+            {
+                const float qk = sm[B_QF + ak] + asb;
+                float pre[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk;
+                float w0 = sm[B_CUM + 4 * atg], w1 = sm[B_CUM + 4 * atg + 1], w2 = sm[B_CUM + 4 * atg + 2], w3 = sm[B_CUM + 4 * atg + 3];
+#pragma unroll
+                for (int jj = 0; jj < PKS; ++jj) {
+                    const float lk = sm[B_LK + jj * 16 + ak];
+                    pre[0] += w0 * lk; pre[1] += w1 * lk; pre[2] += w2 * lk; pre[3] += w3 * lk;
+                    w0 = w1; w1 = w2; w2 = w3; w3 = sm[B_CUM + 4 * atg + jj + 4];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { const float u = tanhf_(pre[m]); fac[m] = awk * (1.f - u * u); }
+            }
+            PSTAMP(0);
+            // d_ctx of this slice's 96 columns: projection part + the 8 partial tiles of the next step's cell-0 product
+            if (!first) {
+                if (tid < 192) {
+                    pf32x4 v[1];
+                    if (!gather<1>(xr, pcoff, v, d.ctrl)) PFAIL();
+                    pc = v[0];
+                }
+                *reinterpret_cast<pf32x4*>(sm + B_PC + 4 * (tid < 192 ? tid : 0)) = pc;
+            }
+            PABORT_CHECK();
+            PSTAMP(1);
+            if (tid < 24) {
+                pf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (!first) {
+#pragma unroll
+                    for (int src = 0; src < 8; ++src) acc += *reinterpret_cast<const pf32x4*>(sm + B_PC + (tid * 8 + src) * 4);
+                    reinterpret_cast<pf32x4*>(d.d_in0 + (sB1 + ab) * (PM + PH) + 96 * gi)[tid] = acc;       // gradient of ctx_s from cell 0 of step s+1 (d_values)
+                }
+                *reinterpret_cast<pf32x4*>(sm + B_DC + 4 * tid) = acc + *reinterpret_cast<const pf32x4*>(sm + B_DPJ + 4 * tid);
+            }
+            __syncthreads();
+            {   // values_i . d_ctx_i: thread (position t, column quarter cq)
+                const int t = tid & 127, cq = tid >> 7;
+                float acc = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < 6; ++c4) {
+                    const pf32x4 dcv = *reinterpret_cast<const pf32x4*>(sm + B_DC + 24 * cq + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc += sm[B_VALT + (24 * cq + 4 * c4 + e) * PT + t] * dcv[e];
+                }
+                sm[B_PD + cq * PT + t] = acc;
+            }
+            __syncthreads();
+            if (tid < 32) {         // + this slice's part of G; the row's d_alignment is the sum of the eight published vectors
+                pf32x4 pd = (*reinterpret_cast<const pf32x4*>(sm + B_PD + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + B_PD + PT + 4 * tid)) +
+                            (*reinterpret_cast<const pf32x4*>(sm + B_PD + 2 * PT + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + B_PD + 3 * PT + 4 * tid));
+                pd += *reinterpret_cast<const pf32x4*>(sm + B_GP + 4 * tid);
+                const long o = ((long)ab * 8 + gi) * PT + 4 * tid;
+                xstore(xr, (unsigned)((BO_DA + slot * BDA + o) * 4), pd);
+                xstore(xr, (unsigned)((BO_DA + rslot * BDA + o) * 4), sentv());
+            }
+            PSTAMP(2);
+            if (tid < 256) {
+                unsigned off[1]; pf32x4 v[1];
+                off[0] = (unsigned)((BO_DA + slot * BDA + (long)ab * 8 * PT) * 4 + 16 * tid);
+                if (!gather<1>(xr, off, v, d.ctrl)) PFAIL();
+                *reinterpret_cast<pf32x4*>(sm + B_DA + 4 * tid) = v[0];
+            }
+            PABORT_CHECK();
+            PSTAMP(3);
+            if (wave == 0) {        // softmax backward: d_e = a (d_a - dot(a, d_a))
+                float da0 = 0.f, da1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { da0 += sm[B_DA + i * PT + lane]; da1 += sm[B_DA + i * PT + 64 + lane]; }
+                const float a0 = sm[B_A + lane], a1 = sm[B_A + 64 + lane];
+                const float dot = wave_sum(a0 * da0 + a1 * da1);
+                const float e0 = a0 * (da0 - dot), e1 = a1 * (da1 - dot);
+                sm[B_DE + lane] = e0; sm[B_DE + 64 + lane] = e1;
+                if (gi == 0) {
+                    float* de = d.de_hist + (sB + ab) * T;
+                    if (lane < T) de[lane] = e0;
+                    if (lane + 64 < T) de[lane + 64] = e1;
+                }
+            }
+            __syncthreads();
+            {   // energy gradients g[t][k] = d_e[t] fac[t][k]; dq[k] = sum_t g
+                float dqp = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float gv = sm[B_DE + 4 * atg + m] * fac[m];
+                    sm[B_G + (15 + 4 * atg + m) * 16 + ak] = gv;
+                    dqp += gv;
+                }
+                sm[B_DQ + atg * 16 + ak] = dqp;
+            }
+            __syncthreads();
+            if (tid < 16) {
+                float qv = 0.f;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) qv += sm[B_DQ + u * 16 + tid];
+                sm[B_DQF + tid] = qv;
+                (d.dq_hist + (sB + ab) * PA + 16 * gi)[tid] = qv;
+            }
+            __syncthreads();
+            if (tid < 256) {        // query layer, data gradient of this slice's 16 units: d_m1[4 l + e] += sum_k dq[k] Wq[4 l + e][16 i + k]
+                pf32x4 out = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const pf32x4 dq4 = *reinterpret_cast<const pf32x4*>(sm + B_DQF + 4 * k4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const pf32x4 wv = *reinterpret_cast<const pf32x4*>(sm + B_WQT + ((k4 * 4 + e) * 256 + tid) * 4);
+                        out[e] += wv[0] * dq4[0] + wv[1] * dq4[1] + wv[2] * dq4[2] + wv[3] * dq4[3];
+                    }
+                }
+                const long o = ((long)ab * 8 + gi) * PH + 4 * tid;
+                xstore(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), out);
+                xstore(xr, (unsigned)((BO_DM1 + rslot * BDM1 + o) * 4), sentv());
+            }
+            PSTAMP(4);
+            {   // in the shadow of that hand-off: this slice's part of G for the step before: G[t] += sum_j sum_k g[t + 15 - j][k] loc_k[j][k]
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                float w0 = sm[B_G + (4 * atg) * 16 + ak], w1 = sm[B_G + (4 * atg + 1) * 16 + ak], w2 = sm[B_G + (4 * atg + 2) * 16 + ak],
+                      w3 = sm[B_G + (4 * atg + 3) * 16 + ak];
+#pragma unroll
+                for (int x = 0; x < PKS; ++x) {         // x = 30 - j: padded window position 4 atg + m + x
+                    const float lk = sm[B_LK + (PKS - 1 - x) * 16 + ak];
+                    acc[0] += w0 * lk; acc[1] += w1 * lk; acc[2] += w2 * lk; acc[3] += w3 * lk;
+                    w0 = w1; w1 = w2; w2 = w3; w3 = sm[B_G + (4 * atg + x + 4) * 16 + ak];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float v = acc[m];
+                    v += dpp_mov<0xB1, 0xf>(0.f, v);
+                    v += dpp_mov<0x4E, 0xf>(0.f, v);
+                    v += dpp_mov<0x141, 0xf>(0.f, v);
+                    v += dpp_mov<0x140, 0xf>(0.f, v);
+                    acc[m] = v;
+                }
+                if (ak == 0) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) sm[B_GP + 4 * atg + m] += acc[m];
+                }
+            }
+        } else {
+            PSTAMP(0); PSTAMP(1); PSTAMP(2); PSTAMP(3);
+            if (tid < 256) {        // rows past the batch: zeros, so that the cell owners' waits complete
+                const long o = ((long)ab * 8 + gi) * PH + 4 * tid;
+                xstore(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f});
+                xstore(xr, (unsigned)((BO_DM1 + rslot * BDM1 + o) * 4), sentv());
+            }
+            PSTAMP(4);
+        }
+        PSTAMP(5);
+        // ================= cell 1, update backward (units 4 g .., all rows)
+        __syncthreads();                                             // the attention phases are done with the scratch
+        {
+            pf32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (tid < 256) {        // piece (row, slice / source): 8 consecutive lanes hold the 8 partial vectors of one (row, 4 units)
+                const int row = tid >> 3, sl = tid & 7;
+                unsigned off[2];
+                off[0] = (unsigned)((BO_DM1 + slot * BDM1 + ((long)row * 8 + sl) * PH + 4 * g) * 4);
+                off[1] = first ? off[0] : (unsigned)((BO_PH1 + nslot * BPART + (((long)g * 8 + sl) * 32 + row) * 4) * 4);
+                if (!gather<2>(xr, off, v, d.ctrl)) PFAIL();
+                if (first) v[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[0][e], y = v[1][e];
+                    x += dpp_mov<0xB1, 0xf>(0.f, x); x += dpp_mov<0x4E, 0xf>(0.f, x); x += dpp_mov<0x141, 0xf>(0.f, x);
+                    y += dpp_mov<0xB1, 0xf>(0.f, y); y += dpp_mov<0x4E, 0xf>(0.f, y); y += dpp_mov<0x141, 0xf>(0.f, y);
+                    v[0][e] = x; v[1][e] = y;
+                }
+                if (sl == 0) {
+                    *reinterpret_cast<pf32x4*>(sm + B_TR + row * 4) = v[0];
+                    *reinterpret_cast<pf32x4*>(sm + B_TR + 128 + row * 4) = v[1];
+                }
+            }
+        }
+        PABORT_CHECK();
+        PSTAMP(6);
+        // operands of the cell-0 update backward: requested here, they arrive under the cell-1 product
+        float a0v[4], cr0, cp0;
+        uint8_t zc0v, zh0v;
+        {
+            const float* a = d.acts0 + sB * 4 * PH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a0v[q] = a[o4H + q * PH];
+            cr0 = (d.craw0 + sB * PH)[oH]; cp0 = (d.c0 + sB * PH)[oH];
+            zc0v = (d.zc0 + sB * PH)[oH]; zh0v = (d.zh0 + sB * PH)[oH];
+        }
+        {
+            const float dm = sm[B_TR + er * 4 + ee] + dpm1;
+            float dhs = dh1s + sm[B_TR + 128 + er * 4 + ee];
+            const float mh = zh1v ? d.keep : 0.f, mc = zc1v ? d.keep : 0.f;
+            const pf32x4 dgv = cell_bwd(dm, dhs, dc1s, a1v[0], a1v[1], a1v[2], a1v[3], cr1, cp1, mh, mc);
+            dh1s = dhs;
+            if (ew) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sm[B_TR + 384 + (q * 32 + er) * 4 + ee] = dgv[q];
+            }
+            __syncthreads();
+            if (tid < 128) {        // (gate, row): the 4 units' gradients of one gate, 16 bytes into the B-operand order of the product waves
+                const int gate = tid >> 5, row = tid & 31;
+                const pf32x4 val = *reinterpret_cast<const pf32x4*>(sm + B_TR + 384 + tid * 4);
+                const long o = ((((long)(gi * 8 + (gj >> 2)) * 2 + (row >> 4)) * 4 + (gj & 3)) * 64 + gate * 16 + (row & 15)) * 4;
+                xstore(xr, (unsigned)((BO_DG1 + slot * BDG + o) * 4), val);
+                xstore(xr, (unsigned)((BO_DG1 + rslot * BDG + o) * 4), sentv());
+            }
+            if (elive) { float* o = d.dg1 + sB * 4 * PH; o[o4H] = dgv[0]; o[o4H + PH] = dgv[1]; o[o4H + 2 * PH] = dgv[2]; o[o4H + 3 * PH] = dgv[3]; }
+        }
+        PSTAMP(7);
+        // ================= products: a wave's eighth of the gate gradients -> B-operand registers, 64 MFMAs on the chain, the 8 partial
+        // tiles meet in LDS, leave as one tile; then the 64 MFMAs of the recurrent-state rows in the shadow of that hand-off
+#define PRODUCT(OFF_DG, WT, OFF_CRIT, OFF_OFF, CRIT_IS_CTX)                                                                           \
+        {                                                                                                                            \
+            pf32x4 bq[8];                                                                                                            \
+            {                                                                                                                        \
+                unsigned off[8];                                                                                                     \
+                _Pragma("unroll") for (int x = 0; x < 8; ++x)                                                                        \
+                    off[x] = (unsigned)(((OFF_DG) + slot * BDG + ((((long)(gi * 8 + wave) * 2 + (x >> 2)) * 4 + (x & 3)) * 64 + lane) * 4) * 4); \
+                if (!gather<8>(xr, off, bq, d.ctrl)) PFAIL();                                                                        \
+            }                                                                                                                        \
+            _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                                 \
+                pf32x4 acc[2][2];                                                                                                    \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                     \
+                    _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[kt][t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                         \
+                _Pragma("unroll") for (int ks = 0; ks < 16; ++ks)                                                                    \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
+                        acc[kt][0] = PMFMA(WT[half * 32 + kt * 16 + ks], bq[ks >> 2][ks & 3], acc[kt][0]);                           \
+                        acc[kt][1] = PMFMA(WT[half * 32 + kt * 16 + ks], bq[4 + (ks >> 2)][ks & 3], acc[kt][1]);                     \
+                    }                                                                                                                \
+                if (half == 1) __syncthreads();                      /* the first tile's readers are done */                         \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                     \
+                    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
+                        *reinterpret_cast<pf32x4*>(sm + B_RED + ((wave * 4 + kt * 2 + t) * 64 + lane) * 4) = acc[kt][t];             \
+                PABORT_CHECK();                                                                                                      \
+                if (tid < 256) {                                                                                                     \
+                    const int tile = tid >> 6, l = tid & 63, kt = tile >> 1, t = tile & 1;                                           \
+                    pf32x4 r = {0.f, 0.f, 0.f, 0.f};                                                                                 \
+                    _Pragma("unroll") for (int w = 0; w < 8; ++w) r += *reinterpret_cast<const pf32x4*>(sm + B_RED + ((w * 4 + tile) * 64 + l) * 4); \
+                    const int blk = 4 * kt + (l >> 4), row = 16 * t + (l & 15);                                                      \
+                    if (half == 0 && (CRIT_IS_CTX)) {                                                                                \
+                        if (blk < 6) {                                                                                               \
+                            const long o = (((long)row * 192 + 6 * gj + blk) * 8 + gi) * 4;                                          \
+                            xstore(xr, (unsigned)((BO_PCTX + slot * BPCTX + o) * 4), r);                                             \
+                            xstore(xr, (unsigned)((BO_PCTX + rslot * BPCTX + o) * 4), sentv());                                      \
+                        }                                                                                                            \
+                    } else {                                                                                                         \
+                        const long o = (((long)(8 * gj + blk) * 8 + gi) * 32 + row) * 4;                                             \
+                        const long base = half == 0 ? (OFF_CRIT) : (OFF_OFF);                                                        \
+                        xstore(xr, (unsigned)((base + slot * BPART + o) * 4), r);                                                    \
+                        xstore(xr, (unsigned)((base + rslot * BPART + o) * 4), sentv());                                             \
+                    }                                                                                                                \
+                }                                                                                                                    \
+                if (half == 0) PSTAMP(STAMP_BASE);                                                                                   \
+            }                                                                                                                        \
+        }
+#define STAMP_BASE 8
+        PRODUCT(BO_DG1, w1t, BO_PM0, BO_PH1, false)
+#undef STAMP_BASE
+        PSTAMP(9);
+        // ================= cell 0, update backward
+        __syncthreads();
+        {
+            pf32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (tid < 256) {
+                const int row = tid >> 3, src = tid & 7;
+                unsigned off[2];
+                off[0] = (unsigned)((BO_PM0 + slot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);
+                off[1] = first ? off[0] : (unsigned)((BO_PH0 + nslot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);
+                if (!gather<2>(xr, off, v, d.ctrl)) PFAIL();
+                if (first) v[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[0][e], y = v[1][e];
+                    x += dpp_mov<0xB1, 0xf>(0.f, x); x += dpp_mov<0x4E, 0xf>(0.f, x); x += dpp_mov<0x141, 0xf>(0.f, x);
+                    y += dpp_mov<0xB1, 0xf>(0.f, y); y += dpp_mov<0x4E, 0xf>(0.f, y); y += dpp_mov<0x141, 0xf>(0.f, y);
+                    v[0][e] = x; v[1][e] = y;
+                }
+                if (src == 0) {
+                    *reinterpret_cast<pf32x4*>(sm + B_TR + row * 4) = v[0];
+                    *reinterpret_cast<pf32x4*>(sm + B_TR + 128 + row * 4) = v[1];
+                }
+            }
+        }
+        PABORT_CHECK();
+        PSTAMP(10);
+        {
+            const float dm = sm[B_TR + er * 4 + ee];
+            float dhs = dh0s + sm[B_TR + 128 + er * 4 + ee];
+            const float mh = zh0v ? d.keep : 0.f, mc = zc0v ? d.keep : 0.f;
+            const pf32x4 dgv = cell_bwd(dm, dhs, dc0s, a0v[0], a0v[1], a0v[2], a0v[3], cr0, cp0, mh, mc);
+            dh0s = dhs;
+            if (ew) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sm[B_TR + 384 + (q * 32 + er) * 4 + ee] = dgv[q];
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int gate = tid >> 5, row = tid & 31;
+                const pf32x4 val = *reinterpret_cast<const pf32x4*>(sm + B_TR + 384 + tid * 4);
+                const long o = ((((long)(gi * 8 + (gj >> 2)) * 2 + (row >> 4)) * 4 + (gj & 3)) * 64 + gate * 16 + (row & 15)) * 4;
+                xstore(xr, (unsigned)((BO_DG0 + slot * BDG + o) * 4), val);
+                xstore(xr, (unsigned)((BO_DG0 + rslot * BDG + o) * 4), sentv());
+            }
+            if (elive) { float* o = d.dg0 + sB * 4 * PH; o[o4H] = dgv[0]; o[o4H + PH] = dgv[1]; o[o4H + 2 * PH] = dgv[2]; o[o4H + 3 * PH] = dgv[3]; }
+        }
+        PSTAMP(11);
+#define STAMP_BASE 12
+        PRODUCT(BO_DG0, w0t, BO_PM0, BO_PH0, true)
+#undef STAMP_BASE
+        PSTAMP(13);
+        __syncthreads();                                             // the product's readers are done before the attention scratch is written
+    }
+    if (tid == 0) {
+        __hip_atomic_fetch_add(d.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (PROF && d.stamps) {
+#pragma unroll
+            for (int x = 0; x < NBSTAMP; ++x) d.stamps[(long)g * NBSTAMP + x] = sstamp[x];
+        }
+    }
+#undef PSTAMP
+#undef PABORT_CHECK
+#undef PFAIL
+#undef PRODUCT
+}
+
+// ---- packers.  Contraction step ks of wave w's eighth: group mm = ks >> 2 -> producer column slice j' = 4 w + mm, unit 32 j' + 4 i + (ks & 3); the
+// MFMA's inner index (lane >> 4) is the gate.  Output tile kt, row m = lane & 15 of the A operand: cell 1 half 0 = m0 unit 32 j + 16 kt + m
+// (kernel row = that), half 1 = h1 unit (row H + ...); cell 0 half 0 = context column 24 j + 16 kt + m when 16 kt + m < 24 (else a zero
+// row), half 1 = h0 unit (row M + ...).
+__global__ void persist_pack_bwd_kernel(const float* __restrict__ w0f, const float* __restrict__ w1, float* __restrict__ w0t, float* __restrict__ w1t) {
+    const long n = 256L * 8 * 64 * 64;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < 2 * n; p += (long)gridDim.x * blockDim.x) {
+        const bool c1 = p >= n;
+        long r = c1 ? p - n : p;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int reg = (int)(r & 63); r >>= 6;
+        const int wave = (int)(r & 7), g = (int)(r >> 3);
+        const int gi = g & 7, gj = g >> 3;
+        const int half = reg >> 5, kt = (reg >> 4) & 1, ks = reg & 15;
+        const int m = lane & 15, gate = lane >> 4;
+        const int unit_c = 32 * (4 * wave + (ks >> 2)) + 4 * gi + (ks & 3);
+        const long col = (long)gate * PH + unit_c;
+        const int ok = 16 * kt + m;
+        float v;
+        if (c1) {
+            const long row = (half == 0 ? 0 : PH) + 32 * gj + ok;
+            v = w1[row * 4 * PH + col];
+        } else if (half == 0) {
+            v = ok < 24 ? w0f[(long)(24 * gj + ok) * 4 * PH + col] : 0.f;
+        } else {
+            v = w0f[(long)(PM + 32 * gj + ok) * 4 * PH + col];
+        }
+        if (c1) w1t[p - n] = v; else w0t[p] = v;
+    }
+}
+// query kernel for the data gradient, by unit slice gi: float4 index (k4 * 4 + e) * 256 + l holds Wq[4 l + e][16 gi + 4 k4 .. + 3]
+__global__ void persist_pack_wqt_kernel(const float* __restrict__ wq, float* __restrict__ wqt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= 8 * 16 * 256 * 4) return;
+    const int kq = p & 3, l = (p >> 2) & 255, ke = (p >> 10) & 15, gi = p >> 14;
+    const int k4 = ke >> 2, e = ke & 3;
+    wqt[p] = wq[(long)(4 * l + e) * PA + 16 * gi + 4 * k4 + kq];
+}
+
+}  // namespace mstts
+using namespace mstts;
+
+extern "C" int64_t mstts_persist_bwd_ws_bytes(void) { return BXCH_FLOATS * 4; }
+extern "C" int64_t mstts_persist_bwd_pack_floats(int32_t which) { return which < 2 ? 256L * 8 * 64 * 64 : 8L * 16 * 256 * 4; }
+
+extern "C" int32_t mstts_persist_bwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS) {
+    if (!(B >= 1 && B <= PROWS && H == PH && M == PM && A == PA && T >= 1 && T <= PT && KS == PKS)) return 0;
+    static int cached = -1;
+    if (cached < 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        cached = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= PWG) {
+            const size_t lds = (size_t)B_FLOATS * 4;
+            if (hipFuncSetAttribute((const void*)persist_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)persist_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_bwd_kernel<false>, PTH, lds) == hipSuccess && per_cu >= 1)
+                cached = 1;
+        }
+        (void)hipGetLastError();
+    }
+    return cached;
+}
+
+extern "C" int mstts_persist_bwd_pack(const float* w0f, const float* w1, const float* wq, float* w0t, float* w1t, float* wqt, mstts_stream_t s) {
+    MSTTS_REQUIRE(w0f && w1 && wq && w0t && w1t && wqt, MSTTS_ERR_SHAPE, "persist_bwd_pack: null pointer");
+    hipLaunchKernelGGL(persist_pack_bwd_kernel, dim3(4096), dim3(256), 0, (hipStream_t)s, w0f, w1, w0t, w1t);
+    MSTTS_CHECK_LAUNCH("persist_pack_bwd");
+    hipLaunchKernelGGL(persist_pack_wqt_kernel, dim3(8 * 16 * 4), dim3(256), 0, (hipStream_t)s, wq, wqt);
+    MSTTS_CHECK_LAUNCH("persist_pack_wqt");
+    return MSTTS_OK;
+}
+
+extern "C" int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_desc* bd, const mstts_persist_desc* p, mstts_stream_t s) {
+    MSTTS_REQUIRE(bd && bd->fwd && p && bd->d_pj && bd->dg0 && bd->dg1 && bd->dq_hist && bd->de_hist && bd->d_in0 && p->w0pk && p->w1pk && p->wqpk &&
+                  p->xch && p->ctrl, MSTTS_ERR_SHAPE, "decoder_train_bwd_persistent: null pointer");
+    const mstts_decoder_train_desc* d = bd->fwd;
+    const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
+    MSTTS_REQUIRE(d->lsa.B == B && mstts_persist_bwd_supported(B, H, M, A, T, d->lsa.KS), MSTTS_ERR_SHAPE,
+                  "decoder_train_bwd_persistent: shape or device not supported (see mstts_persist_bwd_supported)");
+    MSTTS_REQUIRE(d->zc0 && d->zh0 && d->zc1 && d->zh1, MSTTS_ERR_SHAPE, "decoder_train_bwd_persistent: the four zoneout keep-masks are required");
+    MSTTS_REQUIRE(d->acts0 && d->acts1 && d->craw0 && d->craw1 && d->c0 && d->c1 && d->align_hist && d->cum_hist && d->q_hist && d->lsa.keys && d->lsa.values &&
+                  d->lsa.loc_k && d->lsa.loc_b && d->lsa.score_w && d->lsa.score_b, MSTTS_ERR_SHAPE, "decoder_train_bwd_persistent: forward state missing");
+    MSTTS_REQUIRE(aligned16(p->xch) && aligned16(bd->d_in0) && (M + H) % 4 == 0, MSTTS_ERR_ALIGN, "decoder_train_bwd_persistent: 16-byte alignment");
+    hipStream_t hs = (hipStream_t)s;
+    hipError_t e = hipMemsetAsync(p->xch, 0xFF, BXCH_FLOATS * 4, hs);
+    if (e == hipSuccess) e = hipMemsetAsync(p->ctrl, 0, 16 * sizeof(unsigned), hs);
+    if (e != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "decoder_train_bwd_persistent: memset: %s", hipGetErrorString(e));
+    PersistBwd a;
+    a.w1t = p->w1pk; a.w0t = p->w0pk; a.wqt = p->wqpk;
+    a.acts0 = d->acts0; a.acts1 = d->acts1; a.craw0 = d->craw0; a.craw1 = d->craw1; a.c0 = d->c0; a.c1 = d->c1;
+    a.zc0 = d->zc0; a.zh0 = d->zh0; a.zc1 = d->zc1; a.zh1 = d->zh1; a.keep = 1.f - d->zoneout;
+    a.align_hist = d->align_hist; a.cum_hist = d->cum_hist; a.q_hist = d->q_hist;
+    a.keys = d->lsa.keys; a.values = d->lsa.values; a.lengths = d->lsa.lengths;
+    a.loc_k = d->lsa.loc_k; a.loc_b = d->lsa.loc_b; a.score_w = d->lsa.score_w; a.score_b = d->lsa.score_b;
+    a.d_pj = bd->d_pj; a.B = (int)B; a.S = (int)S; a.T = (int)T;
+    a.dg0 = bd->dg0; a.dg1 = bd->dg1; a.dq_hist = bd->dq_hist; a.de_hist = bd->de_hist; a.d_in0 = bd->d_in0;
+    a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1;
+    const size_t lds = (size_t)B_FLOATS * 4;
+    if (p->stamps) hipLaunchKernelGGL(persist_bwd_kernel<true>, dim3(PWG), dim3(PTH), lds, hs, a);
+    else hipLaunchKernelGGL(persist_bwd_kernel<false>, dim3(PWG), dim3(PTH), lds, hs, a);
+    MSTTS_CHECK_LAUNCH("persist_bwd");
+    return MSTTS_OK;
+}

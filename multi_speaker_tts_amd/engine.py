@@ -106,9 +106,14 @@ class TrainEngine:
         self.persist_fallbacks = 0           # sequences that had to be re-run on the launch-per-step path
         self.persist_selftest = 0            # tests: k > 0 makes the persistent launch abort at step k - 1
         self.persist_stamps = None           # bench: 256 x 16 int64 tensor -> per-stage ticks of the next persistent launch
+        self.persist_bwd = self.persist and os.environ.get("MSTTS_PERSIST_BWD", "1") != "0" and bool(lb.mstts_persist_bwd_supported(1, H, M, d.att, 1, d.att_k))
+        self.persist_bwd_fallbacks = 0
+        self.persist_bwd_stamps = None
         if self.persist:
             self.pk = [self._f(int(lb.mstts_persist_pack_floats(i))) for i in range(3)]
             self._side = torch.cuda.Stream(device=self.device)
+        if self.persist_bwd:
+            self.pkb = [self._f(int(lb.mstts_persist_bwd_pack_floats(i))) for i in range(3)]
         self.flip = {}
         self._derived_stale = True
         self.gemm_dtype = (gemm_dtype or "f32").lower()
@@ -178,6 +183,8 @@ class TrainEngine:
             call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
         if self.persist:
             call("mstts_persist_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]))
+        if self.persist_bwd:
+            call("mstts_persist_bwd_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(self.pkb[0]), ptr(self.pkb[1]), ptr(self.pkb[2]))
         if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
             A_ = d.att
             k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
@@ -252,6 +259,12 @@ class TrainEngine:
             w.pctrl = torch.zeros(16, dtype=torch.int32, device=self.device)
             w.pctrl_host = torch.zeros(16, dtype=torch.int32).pin_memory()
             w.pdesc = lib.PersistDesc()
+        w.persist_bwd = w.persist and self.persist_bwd and bool(lb.mstts_persist_bwd_supported(B, H, M, A, Te, d.att_k))
+        if w.persist_bwd:
+            w.xch_b = f(int(lb.mstts_persist_bwd_ws_bytes()) // 4)
+            w.pctrl_b = torch.zeros(16, dtype=torch.int32, device=self.device)
+            w.pctrl_b_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.pdesc_b = lib.PersistDesc()
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
         # postnet
@@ -545,7 +558,33 @@ class TrainEngine:
         self.dw0f.zero_()
         w.d_keys.zero_()
         self.d_loc_k.zero_()
-        call("mstts_decoder_train_bwd", C.byref(db))
+        parts = w.d_in0_parts
+        if getattr(w, "persist_bwd", False):
+            # ONE launch for the whole BPTT; its status words are read while the hoisted weight-gradient products run (no bubble); the
+            # launch-per-step loop is the fallback
+            pb = w.pdesc_b
+            pb.w0pk, pb.w1pk, pb.wqpk, pb.xch, pb.ctrl = ptr(self.pkb[0]), ptr(self.pkb[1]), ptr(self.pkb[2]), ptr(w.xch_b), ptr(w.pctrl_b)
+            pb.stamps = ptr(self.persist_bwd_stamps) if self.persist_bwd_stamps is not None else None
+            pb.selftest_fail_step = int(self.persist_selftest)
+            call("mstts_decoder_train_bwd_persistent", C.byref(db), C.byref(pb))
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                w.pctrl_b_host.copy_(w.pctrl_b, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+            done.synchronize()
+            st = w.pctrl_b_host
+            if int(st[1]) != 0 or int(st[2]) != 256:
+                self.persist_bwd_fallbacks += 1
+                self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
+                w.dq_hist.zero_()
+                call("mstts_decoder_train_bwd", C.byref(db))
+            else:
+                parts = 1                    # d_in0 slab 0 holds the complete context gradient
+        else:
+            call("mstts_decoder_train_bwd", C.byref(db))
         # hoisted weight gradients of the loop.  (Running them chunk by chunk on a second stream under BPTT was measured: the
         # GEMMs' MFMA traffic slows every latency-bound loop kernel by 25-35 %, 105.4 vs 102.2 ms per step - not kept.)
         self._recurrent_wgrads(w, 0, S)
@@ -578,7 +617,7 @@ class TrainEngine:
         self._gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
                    strides=(Te, H + M, Te * M), b_off=H, exact=True)
         if S > 1:
-            for part in range(w.d_in0_parts):
+            for part in range(parts):
                 self._gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
                            strides=(Te, M + H, Te * M), b_off=(part * S + 1) * B * (M + H), accumulate=True, exact=True)
         # memory layer

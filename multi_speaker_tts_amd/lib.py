@@ -210,6 +210,11 @@ SIGNATURES = {
     "mstts_persist_pack_floats": (i64, [i32]),
     "mstts_persist_pack": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "mstts_decoder_train_fwd_persistent": (i32, [P(DecoderTrain), P(PersistDesc), vp]),
+    "mstts_persist_bwd_supported": (i32, [i64, i64, i64, i64, i64, i64]),
+    "mstts_persist_bwd_ws_bytes": (i64, []),
+    "mstts_persist_bwd_pack_floats": (i64, [i32]),
+    "mstts_persist_bwd_pack": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+    "mstts_decoder_train_bwd_persistent": (i32, [P(DecoderTrainBwd), P(PersistDesc), vp]),
     "mstts_decoder_train_bwd_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
     "mstts_decoder_train_bwd_parts": (i32, [i64, i64]),
     "mstts_decoder_train_ws_floats": (i32, [i64, i64, i64, i64, C.POINTER(i64), C.POINTER(i64)]),

@@ -332,6 +332,22 @@ def main():
                                "empty_bracket_us": fwd["lsa_step_fwd"]["empty_bracket_us"]}
             if fused_query:         # as launched the kernel also reads the query kernel and the cell-1 output rows
                 out["roofline"]["as_launched_bytes"] = att_bytes + H * A * 4 + B_PER_GPU * H * 4 + B_PER_GPU * A * 4
+        if bool(getattr(w, "persist_bwd", False)):
+            bnames = ["step rows + tanh terms", "wait d_ctx partials", "d_ctx, values . d_ctx, publish partial d_alignment", "wait d_alignment",
+                      "softmax backward, energy / query gradients, publish d_m1", "shadow: G of the step before", "wait d_m1 (+ d_h1)",
+                      "cell-1 update backward + publish", "d[g1] product, rows on the chain (fetch + MFMA + reduce + publish)",
+                      "shadow: d[g1] product, recurrent-state rows", "wait d_m0 (+ d_h0)", "cell-0 update backward + publish",
+                      "d[g0] product, rows on the chain", "shadow: d[g0] product, recurrent-state rows", "next step's operand requests + barrier",
+                      "loop top: window padding, d_ctx request, barrier"]
+            eng.persist_bwd_stamps = torch.zeros(256 * 16, dtype=torch.int64, device=device)
+            eng.forward(batch, w)
+            eng.loss_and_backward(w)
+            torch.cuda.synchronize()
+            bt = eng.persist_bwd_stamps.view(256, 16).double().cpu().numpy().mean(axis=0) * 0.01 / S
+            eng.persist_bwd_stamps = None
+            out["bptt_persistent"] = {"kernel": "persist_bwd_kernel", "frame_us": float(bt.sum()), "fallbacks": eng.persist_bwd_fallbacks,
+                                      "attention_backward_stage_us": float(bt[0:6].sum()),
+                                      "stage_us": {n: float(v) for n, v in zip(bnames, bt) if n != "-"}}
         bwd = probe({"lsa_step_bwd": 5, "lsa_denergy_bwd": 6, "cell0_dgemm_bwd": 7, "cell1_dgemm_bwd": 8}, True)
         wb = 2 if args.recurrent_dtype == "bf16" else 4          # the recurrent kernels stream bf16 copies in that mode
         w0 = (M + H) * 4 * H * wb

@@ -74,20 +74,24 @@ __device__ __forceinline__ void mfma_part(const float (&w)[NW], const float* sx,
     }
 }
 
-// one slice of a ring slot (128 rows x 4 K4 floats, contiguous) -> the staging buffer (row stride LD); false on time-out
-template <int K4, int LD>
-__device__ __forceinline__ bool stage_slice(__amdgpu_buffer_rsrc_t xr, long slice_float_off, float* stg, int tid, const unsigned* ctrl) {
+// one slice of a ring slot (128 rows x 4 K4 floats, contiguous) -> the staging buffer (row stride LD), in two parts: slice_issue()
+// requests the thread's two 16-byte pieces, slice_complete() polls them in and writes them to LDS; false on time-out
+template <int K4>
+__device__ __forceinline__ void slice_issue(__amdgpu_buffer_rsrc_t xr, long slice_float_off, int tid, unsigned (&off)[2], pf32x4 (&v)[2]) {
     constexpr int NPC = 128 * K4;                                    // 16-byte pieces of the slice: 768 or 1024 for 512 threads
-    unsigned off[2]; pf32x4 v[2];
-    const bool two = tid + PTH < NPC;
     off[0] = (unsigned)(slice_float_off * 4 + 16 * tid);
-    off[1] = two ? off[0] + 16 * PTH : off[0];
-    const bool ok = gather<2>(xr, off, v, ctrl);
+    off[1] = (tid + PTH < NPC) ? off[0] + 16 * PTH : off[0];
+    issue<2>(xr, off, v);
+}
+template <int K4, int LD>
+__device__ __forceinline__ bool slice_complete(__amdgpu_buffer_rsrc_t xr, float* stg, int tid, const unsigned (&off)[2], pf32x4 (&v)[2], const unsigned* ctrl) {
+    constexpr int NPC = 128 * K4;
+    const bool ok = complete<2>(xr, off, v, ctrl);
     {
         const int rho = tid / K4, k4 = tid - rho * K4;
         *reinterpret_cast<pf32x4*>(stg + rho * LD + 4 * k4) = v[0];
     }
-    if (two) {
+    if (tid + PTH < NPC) {
         const int p = tid + PTH, rho = p / K4, k4 = p - rho * K4;
         *reinterpret_cast<pf32x4*>(stg + rho * LD + 4 * k4) = v[1];
     }
@@ -195,21 +199,40 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         xstore(xr, (unsigned)(((OFFP) + rslot * XPART + piece * 256) * 4 + 16 * lane), sentv());                                \
         ACC[t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                                                                                  \
     }
-    // waves 0..3 fetch the 8 x 2 partial tiles of this workgroup's 16 gate columns (sources 2 wave, 2 wave + 1) and pre-add the pair
-#define GATHER_PARTIALS(OFFP)                                                                                                   \
+    // waves 0..3 fetch the 8 x 2 partial tiles of this workgroup's 16 gate columns (sources 2 wave, 2 wave + 1) and pre-add the pair;
+    // requested right behind the publication of this workgroup's own partials, completed where the sums are needed
+#define ISSUE_PARTIALS(OFFP)                                                                                                    \
     if (wave < 4) {                                                                                                             \
-        unsigned off[4]; pf32x4 v[4];                                                                                           \
         _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                           \
-            off[m] = (unsigned)(((OFFP) + slot * XPART + (((long)g * 8 + 2 * wave + (m >> 1)) * 2 + (m & 1)) * 256) * 4 + 16 * lane); \
-        if (!gather<4>(xr, off, v, d.ctrl)) PFAIL();                                                                            \
-        *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 0) * 64 + lane) * 4) = v[0] + v[2];                                \
-        *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 1) * 64 + lane) * 4) = v[1] + v[3];                                \
+            poff[m] = (unsigned)(((OFFP) + slot * XPART + (((long)g * 8 + 2 * wave + (m >> 1)) * 2 + (m & 1)) * 256) * 4 + 16 * lane); \
+        issue<4>(xr, poff, pv);                                                                                                 \
+    }
+#define COMPLETE_PARTIALS()                                                                                                     \
+    if (wave < 4) {                                                                                                             \
+        if (!complete<4>(xr, poff, pv, d.ctrl)) PFAIL();                                                                        \
+        *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 0) * 64 + lane) * 4) = pv[0] + pv[2];                              \
+        *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 1) * 64 + lane) * 4) = pv[1] + pv[3];                              \
     }
 #define SUM_PARTIALS()                                                                                                          \
     ((*reinterpret_cast<const pf32x4*>(sm + S_RED + ((0 * 2 + et) * 64 + lane) * 4) + *reinterpret_cast<const pf32x4*>(sm + S_RED + ((1 * 2 + et) * 64 + lane) * 4)) + \
      (*reinterpret_cast<const pf32x4*>(sm + S_RED + ((2 * 2 + et) * 64 + lane) * 4) + *reinterpret_cast<const pf32x4*>(sm + S_RED + ((3 * 2 + et) * 64 + lane) * 4)))
     __syncthreads();
     if (PROF && tid == 0) tprev = (unsigned)wall_clock64();
+
+    // ---- cell-update operands of both cells (plain loads of loop-invariant inputs: hoisted prenet product, zoneout keep-masks).  They are
+    // HBM-cold, so they are requested ONE STEP AHEAD - here for step 0, at the bottom of the loop body for step s + 1 - by EVERY wave
+    // outside any condition, and consumed by every wave (waves 2..7 repeat the update of waves 0 / 1 and drop the result): a load that is
+    // issued or consumed under a condition stays "pending" for the compiler's wait-count pass, and the s_waitcnt vmcnt it then places
+    // also waits for write-through stores that have nothing to do with it.
+    float xwv[4];
+    uint8_t zc0v, zh0v, zc1v, zh1v;
+#define LOAD_OPERANDS(ST) do { const long b__ = (long)(ST) * B; const unsigned r__ = (16 * (wave0 & 1) + (tid0 & 15)) < (unsigned)B ? 16 * (wave0 & 1) + (tid0 & 15) : 0u;  \
+        /* (waves 2..7 only repeat the update: their lanes all read ONE address, a single cache-line request instead of 16 scattered ones) */ \
+        const unsigned u__ = 4 * g0 + ((tid0 & 63) >> 4), h__ = wave0 < 2 ? r__ * PH + u__ : 0u, q__ = wave0 < 2 ? r__ * 4 * PH + u__ : 0u;                                     \
+        const float* xw__ = d.xw0 + b__ * 4 * PH;                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) xwv[q] = xw__[q__ + q * PH];                                                           \
+        zc0v = (d.zc0 + b__ * PH)[h__]; zh0v = (d.zh0 + b__ * PH)[h__]; zc1v = (d.zc1 + b__ * PH)[h__]; zh1v = (d.zh1 + b__ * PH)[h__]; } while (0)
+    LOAD_OPERANDS(0);
 
     for (int s = 0; s < S; ++s) {
         const unsigned slot = (unsigned)s & 3u, rslot = (unsigned)(s + 2) & 3u, pslot = (unsigned)(s + 3) & 3u;   // pslot: the slot of step s - 1
@@ -226,38 +249,28 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             __hip_atomic_store(d.ctrl + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sflag[0] = 1;
         }
-        // ---- cell-update operands of both cells, requested now (plain loads of loop-invariant inputs), by EVERY wave and without any
-        // condition, and consumed by every wave below (waves 2..7 repeat the update of waves 0 / 1 and drop the result): a load that
-        // is issued or consumed under a condition is still "pending" for the compiler at the loop's back edge, and the s_waitcnt
-        // vmcnt it then places at the top of the loop also waits for every write-through store of the step before (~2 us per step).
-        // (addresses: a wave-uniform 64-bit base of the step + a 32-bit lane offset, so that no per-array address pair stays in VGPRs)
         const long sB = (long)s * B, sB1 = sB + B;
         const bool rowok = er < B;
         const unsigned erc = rowok ? (unsigned)er : 0u;
         const unsigned oH = erc * PH + eu, o4H = erc * 4 * PH + eu;
-        float xwv[4];
-        uint8_t zc0v, zh0v, zc1v, zh1v;
-        {
-            const float* xw = d.xw0 + sB * 4 * PH;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xwv[q] = xw[o4H + q * PH];
-            zc0v = (d.zc0 + sB * PH)[oH]; zh0v = (d.zh0 + sB * PH)[oH];
-            zc1v = (d.zc1 + sB * PH)[oH]; zh1v = (d.zh1 + sB * PH)[oH];
-        }
+        unsigned soff[2], poff[4], roff[1];                          // requests in flight: a slice, the partial tiles, a row piece
+        pf32x4 sv[2], pv[4], rv[1];
         // ================= A: cell 0, context rows.  In the shadow of the ctx_{s-1} hand-off: second half of h1_{s-1} . W1[h rows]
         if (s > 0) {
             mfma_part<4, 8, LA, 32, 64>(w1, stg, lane, acc1);
             __syncthreads();                                         // every wave is done with the staged h1 before ctx overwrites it
             PSTAMP(0);
-            if (!stage_slice<6, LC>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, stg, tid, d.ctrl)) PFAIL();
+            slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
+            if (!slice_complete<6, LC>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
             PABORT_CHECK();
             PSTAMP(1);
-            mfma_part<0, 6, LC, 0, 56>(w0, stg, lane, acc0);
         }
+        if (s > 0) mfma_part<0, 6, LC, 0, 56>(w0, stg, lane, acc0);
         PUBLISH_PARTIAL(OFF_P0, acc0)
         PSTAMP(2);
         // ================= B: sum of the eight partials, cell-0 update
-        GATHER_PARTIALS(OFF_P0)
+        ISSUE_PARTIALS(OFF_P0)
+        COMPLETE_PARTIALS()
         PABORT_CHECK();
         PSTAMP(3);
         {
@@ -290,20 +303,23 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
         PSTAMP(4);
         // ================= C: cell 1, input rows (m0_s)
-        if (!stage_slice<8, LA>(xr, OFF_M0 + slot * XACT + gi * 4096L, stg, tid, d.ctrl)) PFAIL();
+        slice_issue<8>(xr, OFF_M0 + slot * XACT + gi * 4096L, tid, soff, sv);
+        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
         PABORT_CHECK();
         PSTAMP(5);
+        slice_issue<8>(xr, OFF_H0 + slot * XACT + gi * 4096L, tid, soff, sv);     // h0_s left its producers together with m0_s: it arrives under the product
         mfma_part<0, 8, LA, 0, 64>(w1, stg, lane, acc1);
         PUBLISH_PARTIAL(OFF_P1, acc1)
         PSTAMP(6);
-        // in the shadow of the partial-gates hand-off: h0_s (published together with m0_s) staged, first half of h0_s . W0[h rows] for step s+1
+        // in the shadow of the partial-gates hand-off: h0_s staged, first half of h0_s . W0[h rows] for step s+1
         __syncthreads();                                             // m0 is consumed by every wave
-        if (!stage_slice<8, LA>(xr, OFF_H0 + slot * XACT + gi * 4096L, stg, tid, d.ctrl)) PFAIL();
+        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
         PABORT_CHECK();
         mfma_part<0, 4, LA, 24, 56>(w0, stg, lane, acc0);
         PSTAMP(7);
         // ================= D: sum of the eight partials, cell-1 update
-        GATHER_PARTIALS(OFF_P1)
+        ISSUE_PARTIALS(OFF_P1)
+        COMPLETE_PARTIALS()
         PABORT_CHECK();
         PSTAMP(8);
         {
@@ -343,10 +359,10 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         // ================= E: attention, query units and partial energies of row ab
         if (arow) {
             if (tid < 256) {
-                unsigned off[1]; pf32x4 v[1];
-                off[0] = (unsigned)((OFF_M1 + slot * XM1 + (long)ab * PH) * 4 + 16 * tid);
-                if (!gather<1>(xr, off, v, d.ctrl)) PFAIL();
-                *reinterpret_cast<pf32x4*>(sm + S_M1 + 4 * tid) = v[0];
+                roff[0] = (unsigned)((OFF_M1 + slot * XM1 + (long)ab * PH) * 4 + 16 * tid);
+                issue<1>(xr, roff, rv);
+                if (!complete<1>(xr, roff, rv, d.ctrl)) PFAIL();
+                *reinterpret_cast<pf32x4*>(sm + S_M1 + 4 * tid) = rv[0];
             }
             PABORT_CHECK();
             PSTAMP(11);
@@ -371,20 +387,16 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             __syncthreads();
             {
                 const float qk = sm[S_QF + ak] + asb;
-                float cw[36];
-#pragma unroll
-                for (int x4 = 0; x4 < 9; ++x4) {
-                    const pf32x4 cv = *reinterpret_cast<const pf32x4*>(sm + S_CUM + 4 * atg + 4 * x4);
-                    cw[4 * x4] = cv[0]; cw[4 * x4 + 1] = cv[1]; cw[4 * x4 + 2] = cv[2]; cw[4 * x4 + 3] = cv[3];
-                }
                 float pre[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk;
-#pragma unroll
+                // location filter over the cumulative alignment: a rolling 4-position window, one new value per tap
+                float w0 = sm[S_CUM + 4 * atg], w1 = sm[S_CUM + 4 * atg + 1], w2 = sm[S_CUM + 4 * atg + 2], w3 = sm[S_CUM + 4 * atg + 3];
+#pragma unroll 8
                 for (int jj = 0; jj < PKS; ++jj) {
                     const float lk = sm[S_LK + jj * 16 + ak];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) pre[m] += cw[m + jj] * lk;
+                    pre[0] += w0 * lk; pre[1] += w1 * lk; pre[2] += w2 * lk; pre[3] += w3 * lk;
+                    w0 = w1; w1 = w2; w2 = w3; w3 = sm[S_CUM + 4 * atg + jj + 4];
                 }
                 pf32x4 e4;
 #pragma unroll
@@ -407,18 +419,19 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
         PSTAMP(12);
         // in the shadow of the energy hand-off: h1_s staged (it stays staged until the next step's context arrives), first half of h1_s . W1[h rows]
+        slice_issue<8>(xr, OFF_H1 + slot * XACT + gi * 4096L, tid, soff, sv);
         __syncthreads();                                             // h0 is consumed by every wave
-        if (!stage_slice<8, LA>(xr, OFF_H1 + slot * XACT + gi * 4096L, stg, tid, d.ctrl)) PFAIL();
+        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
         PABORT_CHECK();
         mfma_part<0, 4, LA, 32, 64>(w1, stg, lane, acc1);
         PSTAMP(13);
         // ================= F: energies of the row, softmax, cumulative alignment, context columns 96 gi ..
         if (arow) {
             if (tid < 256) {
-                unsigned off[1]; pf32x4 v[1];
-                off[0] = (unsigned)((OFF_EN + slot * XEN + (long)ab * 8 * PT) * 4 + 16 * tid);
-                if (!gather<1>(xr, off, v, d.ctrl)) PFAIL();
-                *reinterpret_cast<pf32x4*>(sm + S_EN + 4 * tid) = v[0];
+                roff[0] = (unsigned)((OFF_EN + slot * XEN + (long)ab * 8 * PT) * 4 + 16 * tid);
+                issue<1>(xr, roff, rv);
+                if (!complete<1>(xr, roff, rv, d.ctrl)) PFAIL();
+                *reinterpret_cast<pf32x4*>(sm + S_EN + 4 * tid) = rv[0];
             }
             PABORT_CHECK();
             PSTAMP(14);
@@ -472,6 +485,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             }
         }
         PSTAMP(15);
+        LOAD_OPERANDS(s + 1 < S ? s + 1 : s);
     }
     if (tid == 0) {
         __hip_atomic_fetch_add(d.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -481,10 +495,12 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
     }
 #undef PSTAMP
+#undef LOAD_OPERANDS
 #undef PABORT_CHECK
 #undef PFAIL
 #undef PUBLISH_PARTIAL
-#undef GATHER_PARTIALS
+#undef ISSUE_PARTIALS
+#undef COMPLETE_PARTIALS
 #undef SUM_PARTIALS
 }
 

@@ -153,6 +153,31 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 #define PSTAMP(idx) do { if (PROF && tid == 0) { const unsigned n__ = (unsigned)wall_clock64(); sstamp[idx] += (unsigned)(n__ - tprev); tprev = n__; } } while (0)
 #define PABORT_CHECK() do { __syncthreads(); if (sflag[0]) return; } while (0)
 #define PFAIL() do { sflag[0] = 1; unsigned z__ = 0u; __hip_atomic_compare_exchange_strong(d.ctrl + 1, &z__, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+    // the forward rows of a step that its attention backward needs (alignment, cumulative alignment BEFORE the step, this slice's
+    // query units and the projection's part of d_ctx): requested one step ahead (end of the attention phase of step s + 1), parked
+    // in LDS once the cell-1 wait of that step has drained the load queue anyway - they cost HBM latency, not bandwidth
+    float rav = 0.f, rcv = 0.f, rqv = 0.f, rdv = 0.f;
+    const int abc = arow ? ab : 0;
+#define LOAD_ROWS(ST) do { const long r__ = (long)(ST) * B + abc; const int t__ = tid0 & 127;                                   \
+        rav = (d.align_hist + r__ * T)[t__ < T ? t__ : 0]; rcv = (d.cum_hist + r__ * T)[t__ < T ? t__ : 0];                     \
+        rqv = (d.q_hist + r__ * PA + 16 * (g0 & 7))[tid0 & 15]; rdv = (d.d_pj + r__ * (PH + PM) + PH + 96 * (g0 & 7))[tid0 < 96 ? tid0 : 0]; } while (0)
+#define STORE_ROWS() do { const int t__ = tid0 & 127;                                                                           \
+        sm[B_A + t__] = t__ < T ? rav : 0.f; sm[B_CUM + 15 + t__] = t__ < T ? rcv : 0.f;                                        \
+        sm[B_QF + (tid0 & 15)] = rqv; sm[B_DPJ + (tid0 < 96 ? tid0 : 0)] = rdv; } while (0)
+    // operands of the cell-1 update backward (saved activations, cell states, keep-masks, the projection's d_m1): HBM-cold, requested ONE STEP
+    // AHEAD (here for the first step, at the bottom of the loop body for the next) by every wave outside any condition - see persist.hip
+    float a1v[4], cr1, cp1, dpm1;
+    uint8_t zc1v, zh1v;
+#define LOAD_OPERANDS1(ST) do { const long b__ = (long)(ST) * B; const unsigned r__ = (16 * (wave0 & 1) + (tid0 & 15)) < (unsigned)B ? 16 * (wave0 & 1) + (tid0 & 15) : 0u; \
+        /* (waves 2..7 only repeat the update: their lanes all read ONE address, a single cache-line request instead of 16 scattered ones) */ \
+        const unsigned u__ = 4 * g0 + ((tid0 & 63) >> 4), h__ = wave0 < 2 ? r__ * PH + u__ : 0u, q__ = wave0 < 2 ? r__ * 4 * PH + u__ : 0u;                                     \
+        const float* a__ = d.acts1 + b__ * 4 * PH;                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) a1v[q] = a__[q__ + q * PH];                                                            \
+        cr1 = (d.craw1 + b__ * PH)[h__]; cp1 = (d.c1 + b__ * PH)[h__]; zc1v = (d.zc1 + b__ * PH)[h__]; zh1v = (d.zh1 + b__ * PH)[h__];       \
+        dpm1 = (d.d_pj + b__ * (PH + PM))[wave0 < 2 ? r__ * (PH + PM) + u__ : 0u]; } while (0)
+    LOAD_OPERANDS1(S - 1);
+    LOAD_ROWS(S - 1);
+    STORE_ROWS();
     __syncthreads();
     if (PROF && tid == 0) tprev = (unsigned)wall_clock64();
 
@@ -173,45 +198,37 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         const bool rowok = er < B;
         const unsigned erc = rowok ? (unsigned)er : 0u;
         const unsigned oH = erc * PH + eu, o4H = erc * 4 * PH + eu;
-        // ---- operands of the cell-1 update backward, requested now by every wave (see persist.hip on why unconditionally)
-        float a1v[4], cr1, cp1, dpm1;
-        uint8_t zc1v, zh1v;
-        {
-            const float* a = d.acts1 + sB * 4 * PH;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a1v[q] = a[o4H + q * PH];
-            cr1 = (d.craw1 + sB * PH)[oH]; cp1 = (d.c1 + sB * PH)[oH];
-            zc1v = (d.zc1 + sB * PH)[oH]; zh1v = (d.zh1 + sB * PH)[oH];
-            dpm1 = (d.d_pj + sB * (PH + PM))[erc * (PH + PM) + eu];
-        }
+        // requests of the two cell-update waits, issued as soon as this workgroup's own contribution has left
+        unsigned uoff[2];
+        pf32x4 uv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#define ISSUE_UPDATE1() do { if (tid < 256) { const int row = tid >> 3, sl = tid & 7;                                                  \
+            uoff[0] = (unsigned)((BO_DM1 + slot * BDM1 + ((long)row * 8 + sl) * PH + 4 * g) * 4);                                     \
+            uoff[1] = first ? uoff[0] : (unsigned)((BO_PH1 + nslot * BPART + (((long)g * 8 + sl) * 32 + row) * 4) * 4);               \
+            issue<2>(xr, uoff, uv); } } while (0)
+#define ISSUE_UPDATE0() do { if (tid < 256) { const int row = tid >> 3, src = tid & 7;                                                 \
+            uoff[0] = (unsigned)((BO_PM0 + slot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);                                 \
+            uoff[1] = first ? uoff[0] : (unsigned)((BO_PH0 + nslot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);              \
+            issue<2>(xr, uoff, uv); } } while (0)
         // ================= attention backward of row ab, slice gi
+        float fac[4] = {0.f, 0.f, 0.f, 0.f};
         if (arow) {
-            {   // this step's forward rows: alignment, cumulative alignment BEFORE the step, query units, projection part of d_ctx
-                const int t = tid & 127;
-                const float av = (d.align_hist + (sB + ab) * T)[t < T ? t : 0];
-                const float cv = (d.cum_hist + (sB + ab) * T)[t < T ? t : 0];
-                const float qv = (d.q_hist + (sB + ab) * PA + 16 * gi)[tid & 15];
-                const float dv = (d.d_pj + (sB + ab) * (PH + PM) + PH + 96 * gi)[tid < 96 ? tid : 0];
-                sm[B_A + t] = t < T ? av : 0.f;
-                sm[B_CUM + 15 + t] = t < T ? cv : 0.f;
-                sm[B_QF + (tid & 15)] = qv;
-                sm[B_DPJ + (tid < 96 ? tid : 0)] = dv;
-                // zero padding of the energy-gradient window (positions -15 .. -1 and 128 .. 144): the products of the step before wrote here
-                sm[B_G + (tid < 240 ? tid : 143 * 16 + (tid - 240))] = 0.f;
-            }
-            pf32x4 pc = {0.f, 0.f, 0.f, 0.f};
+            // (this step's forward rows are in LDS already: LOAD_ROWS / STORE_ROWS)
+            // zero padding of the energy-gradient window (positions -15 .. -1 and 128 .. 144): the products of the step before wrote here
+            sm[B_G + (tid < 240 ? tid : 143 * 16 + (tid - 240))] = 0.f;
+            pf32x4 pc[1] = {{0.f, 0.f, 0.f, 0.f}};
             unsigned pcoff[1];
             pcoff[0] = (unsigned)((BO_PCTX + nslot * BPCTX + ((long)ab * 192 + 24 * gi) * 32) * 4 + 16 * (tid < 192 ? tid : 0));
+            if (!first && tid < 192) issue<1>(xr, pcoff, pc);       // requested now, it travels under the tanh terms
             __syncthreads();
+            PSTAMP(15);
             // tanh terms of this slice (independent of everything that arrives): fac = w_k (1 - tanh^2(keys + q + location filter))
-            float fac[4];
             {
                 const float qk = sm[B_QF + ak] + asb;
                 float pre[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk;
                 float w0 = sm[B_CUM + 4 * atg], w1 = sm[B_CUM + 4 * atg + 1], w2 = sm[B_CUM + 4 * atg + 2], w3 = sm[B_CUM + 4 * atg + 3];
-#pragma unroll
+#pragma unroll 4
                 for (int jj = 0; jj < PKS; ++jj) {
                     const float lk = sm[B_LK + jj * 16 + ak];
                     pre[0] += w0 * lk; pre[1] += w1 * lk; pre[2] += w2 * lk; pre[3] += w3 * lk;
@@ -224,11 +241,9 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             // d_ctx of this slice's 96 columns: projection part + the 8 partial tiles of the next step's cell-0 product
             if (!first) {
                 if (tid < 192) {
-                    pf32x4 v[1];
-                    if (!gather<1>(xr, pcoff, v, d.ctrl)) PFAIL();
-                    pc = v[0];
+                    if (!complete<1>(xr, pcoff, pc, d.ctrl)) PFAIL();
+                    *reinterpret_cast<pf32x4*>(sm + B_PC + 4 * tid) = pc[0];
                 }
-                *reinterpret_cast<pf32x4*>(sm + B_PC + 4 * (tid < 192 ? tid : 0)) = pc;
             }
             PABORT_CHECK();
             PSTAMP(1);
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             {   // values_i . d_ctx_i: thread (position t, column quarter cq)
                 const int t = tid & 127, cq = tid >> 7;
                 float acc = 0.f;
-#pragma unroll
+#pragma unroll 2
                 for (int c4 = 0; c4 < 6; ++c4) {
                     const pf32x4 dcv = *reinterpret_cast<const pf32x4*>(sm + B_DC + 24 * cq + 4 * c4);
 #pragma unroll
@@ -263,6 +278,8 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 xstore(xr, (unsigned)((BO_DA + rslot * BDA + o) * 4), sentv());
             }
             PSTAMP(2);
+        }
+        if (arow) {
             if (tid < 256) {
                 unsigned off[1]; pf32x4 v[1];
                 off[0] = (unsigned)((BO_DA + slot * BDA + (long)ab * 8 * PT) * 4 + 16 * tid);
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             __syncthreads();
             if (tid < 256) {        // query layer, data gradient of this slice's 16 units: d_m1[4 l + e] += sum_k dq[k] Wq[4 l + e][16 i + k]
                 pf32x4 out = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const pf32x4 dq4 = *reinterpret_cast<const pf32x4*>(sm + B_DQF + 4 * k4);
 #pragma unroll
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 float w0 = sm[B_G + (4 * atg) * 16 + ak], w1 = sm[B_G + (4 * atg + 1) * 16 + ak], w2 = sm[B_G + (4 * atg + 2) * 16 + ak],
                       w3 = sm[B_G + (4 * atg + 3) * 16 + ak];
-#pragma unroll
+#pragma unroll 4
                 for (int x = 0; x < PKS; ++x) {         // x = 30 - j: padded window position 4 atg + m + x
                     const float lk = sm[B_LK + (PKS - 1 - x) * 16 + ak];
                     acc[0] += w0 * lk; acc[1] += w1 * lk; acc[2] += w2 * lk; acc[3] += w3 * lk;
@@ -355,42 +372,29 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             PSTAMP(4);
         }
         PSTAMP(5);
+        LOAD_ROWS(s > 0 ? s - 1 : 0);
         // ================= cell 1, update backward (units 4 g .., all rows)
         __syncthreads();                                             // the attention phases are done with the scratch
-        {
-            pf32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if (tid < 256) {        // piece (row, slice / source): 8 consecutive lanes hold the 8 partial vectors of one (row, 4 units)
-                const int row = tid >> 3, sl = tid & 7;
-                unsigned off[2];
-                off[0] = (unsigned)((BO_DM1 + slot * BDM1 + ((long)row * 8 + sl) * PH + 4 * g) * 4);
-                off[1] = first ? off[0] : (unsigned)((BO_PH1 + nslot * BPART + (((long)g * 8 + sl) * 32 + row) * 4) * 4);
-                if (!gather<2>(xr, off, v, d.ctrl)) PFAIL();
-                if (first) v[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+        ISSUE_UPDATE1();
+        if (tid < 256) {            // piece (row, slice / source): 8 consecutive lanes hold the 8 partial vectors of one (row, 4 units)
+            const int row = tid >> 3, sl = tid & 7;
+            if (!complete<2>(xr, uoff, uv, d.ctrl)) PFAIL();
+            if (first) uv[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[0][e], y = v[1][e];
-                    x += dpp_mov<0xB1, 0xf>(0.f, x); x += dpp_mov<0x4E, 0xf>(0.f, x); x += dpp_mov<0x141, 0xf>(0.f, x);
-                    y += dpp_mov<0xB1, 0xf>(0.f, y); y += dpp_mov<0x4E, 0xf>(0.f, y); y += dpp_mov<0x141, 0xf>(0.f, y);
-                    v[0][e] = x; v[1][e] = y;
-                }
-                if (sl == 0) {
-                    *reinterpret_cast<pf32x4*>(sm + B_TR + row * 4) = v[0];
-                    *reinterpret_cast<pf32x4*>(sm + B_TR + 128 + row * 4) = v[1];
-                }
+            for (int e = 0; e < 4; ++e) {
+                float x = uv[0][e], y = uv[1][e];
+                x += dpp_mov<0xB1, 0xf>(0.f, x); x += dpp_mov<0x4E, 0xf>(0.f, x); x += dpp_mov<0x141, 0xf>(0.f, x);
+                y += dpp_mov<0xB1, 0xf>(0.f, y); y += dpp_mov<0x4E, 0xf>(0.f, y); y += dpp_mov<0x141, 0xf>(0.f, y);
+                uv[0][e] = x; uv[1][e] = y;
+            }
+            if (sl == 0) {
+                *reinterpret_cast<pf32x4*>(sm + B_TR + row * 4) = uv[0];
+                *reinterpret_cast<pf32x4*>(sm + B_TR + 128 + row * 4) = uv[1];
             }
         }
+        STORE_ROWS();                                                // (the wait above drained the queue: the rows of step s - 1 have arrived)
         PABORT_CHECK();
         PSTAMP(6);
-        // operands of the cell-0 update backward: requested here, they arrive under the cell-1 product
-        float a0v[4], cr0, cp0;
-        uint8_t zc0v, zh0v;
-        {
-            const float* a = d.acts0 + sB * 4 * PH;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a0v[q] = a[o4H + q * PH];
-            cr0 = (d.craw0 + sB * PH)[oH]; cp0 = (d.c0 + sB * PH)[oH];
-            zc0v = (d.zc0 + sB * PH)[oH]; zh0v = (d.zh0 + sB * PH)[oH];
-        }
         {
             const float dm = sm[B_TR + er * 4 + ee] + dpm1;
             float dhs = dh1s + sm[B_TR + 128 + er * 4 + ee];
@@ -414,76 +418,81 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         PSTAMP(7);
         // ================= products: a wave's eighth of the gate gradients -> B-operand registers, 64 MFMAs on the chain, the 8 partial
         // tiles meet in LDS, leave as one tile; then the 64 MFMAs of the recurrent-state rows in the shadow of that hand-off
-#define PRODUCT(OFF_DG, WT, OFF_CRIT, OFF_OFF, CRIT_IS_CTX)                                                                           \
+#define PROD_GATHER(OFF_DG)                                                                                                           \
+        pf32x4 bq[8];                                                                                                                \
         {                                                                                                                            \
-            pf32x4 bq[8];                                                                                                            \
-            {                                                                                                                        \
-                unsigned off[8];                                                                                                     \
-                _Pragma("unroll") for (int x = 0; x < 8; ++x)                                                                        \
-                    off[x] = (unsigned)(((OFF_DG) + slot * BDG + ((((long)(gi * 8 + wave) * 2 + (x >> 2)) * 4 + (x & 3)) * 64 + lane) * 4) * 4); \
-                if (!gather<8>(xr, off, bq, d.ctrl)) PFAIL();                                                                        \
-            }                                                                                                                        \
-            _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                                 \
-                pf32x4 acc[2][2];                                                                                                    \
-                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                     \
-                    _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[kt][t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                         \
-                _Pragma("unroll") for (int ks = 0; ks < 16; ++ks)                                                                    \
-                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
-                        acc[kt][0] = PMFMA(WT[half * 32 + kt * 16 + ks], bq[ks >> 2][ks & 3], acc[kt][0]);                           \
-                        acc[kt][1] = PMFMA(WT[half * 32 + kt * 16 + ks], bq[4 + (ks >> 2)][ks & 3], acc[kt][1]);                     \
-                    }                                                                                                                \
-                if (half == 1) __syncthreads();                      /* the first tile's readers are done */                         \
-                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                     \
-                    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
-                        *reinterpret_cast<pf32x4*>(sm + B_RED + ((wave * 4 + kt * 2 + t) * 64 + lane) * 4) = acc[kt][t];             \
-                PABORT_CHECK();                                                                                                      \
-                if (tid < 256) {                                                                                                     \
-                    const int tile = tid >> 6, l = tid & 63, kt = tile >> 1, t = tile & 1;                                           \
-                    pf32x4 r = {0.f, 0.f, 0.f, 0.f};                                                                                 \
-                    _Pragma("unroll") for (int w = 0; w < 8; ++w) r += *reinterpret_cast<const pf32x4*>(sm + B_RED + ((w * 4 + tile) * 64 + l) * 4); \
-                    const int blk = 4 * kt + (l >> 4), row = 16 * t + (l & 15);                                                      \
-                    if (half == 0 && (CRIT_IS_CTX)) {                                                                                \
-                        if (blk < 6) {                                                                                               \
-                            const long o = (((long)row * 192 + 6 * gj + blk) * 8 + gi) * 4;                                          \
-                            xstore(xr, (unsigned)((BO_PCTX + slot * BPCTX + o) * 4), r);                                             \
-                            xstore(xr, (unsigned)((BO_PCTX + rslot * BPCTX + o) * 4), sentv());                                      \
-                        }                                                                                                            \
-                    } else {                                                                                                         \
-                        const long o = (((long)(8 * gj + blk) * 8 + gi) * 32 + row) * 4;                                             \
-                        const long base = half == 0 ? (OFF_CRIT) : (OFF_OFF);                                                        \
-                        xstore(xr, (unsigned)((base + slot * BPART + o) * 4), r);                                                    \
-                        xstore(xr, (unsigned)((base + rslot * BPART + o) * 4), sentv());                                             \
-                    }                                                                                                                \
+            unsigned off[8];                                                                                                         \
+            _Pragma("unroll") for (int x = 0; x < 8; ++x)                                                                            \
+                off[x] = (unsigned)(((OFF_DG) + slot * BDG + ((((long)(gi * 8 + wave) * 2 + (x >> 2)) * 4 + (x & 3)) * 64 + lane) * 4) * 4); \
+            if (!gather<8>(xr, off, bq, d.ctrl)) PFAIL();                                                                            \
+        }
+#define PROD_HALF(half, WT, OFF_OUT, IS_CTX)                                                                                          \
+        {                                                                                                                            \
+            pf32x4 acc[2][2];                                                                                                        \
+            _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[kt][t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                             \
+            _Pragma("unroll") for (int ks = 0; ks < 16; ++ks)                                                                        \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                                   \
+                    acc[kt][0] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[ks >> 2][ks & 3], acc[kt][0]);                             \
+                    acc[kt][1] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[4 + (ks >> 2)][ks & 3], acc[kt][1]);                       \
                 }                                                                                                                    \
-                if (half == 0) PSTAMP(STAMP_BASE);                                                                                   \
+            if ((half) == 1) __syncthreads();                        /* the first tile's readers are done */                         \
+            _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                        \
+                    *reinterpret_cast<pf32x4*>(sm + B_RED + ((wave * 4 + kt * 2 + t) * 64 + lane) * 4) = acc[kt][t];                 \
+            PABORT_CHECK();                                                                                                          \
+            if (tid < 256) {                                                                                                         \
+                const int tile = tid >> 6, l = tid & 63, kt = tile >> 1, t = tile & 1;                                               \
+                pf32x4 r = {0.f, 0.f, 0.f, 0.f};                                                                                     \
+                _Pragma("unroll") for (int w = 0; w < 8; ++w) r += *reinterpret_cast<const pf32x4*>(sm + B_RED + ((w * 4 + tile) * 64 + l) * 4); \
+                const int blk = 4 * kt + (l >> 4), row = 16 * t + (l & 15);                                                          \
+                if (IS_CTX) {                                                                                                        \
+                    if (blk < 6) {                                                                                                   \
+                        const long o = (((long)row * 192 + 6 * gj + blk) * 8 + gi) * 4;                                              \
+                        xstore(xr, (unsigned)((BO_PCTX + slot * BPCTX + o) * 4), r);                                                 \
+                        xstore(xr, (unsigned)((BO_PCTX + rslot * BPCTX + o) * 4), sentv());                                          \
+                    }                                                                                                                \
+                } else {                                                                                                             \
+                    const long o = (((long)(8 * gj + blk) * 8 + gi) * 32 + row) * 4;                                                 \
+                    xstore(xr, (unsigned)(((OFF_OUT) + slot * BPART + o) * 4), r);                                                   \
+                    xstore(xr, (unsigned)(((OFF_OUT) + rslot * BPART + o) * 4), sentv());                                            \
+                }                                                                                                                    \
             }                                                                                                                        \
         }
-#define STAMP_BASE 8
-        PRODUCT(BO_DG1, w1t, BO_PM0, BO_PH1, false)
-#undef STAMP_BASE
+        float a0v[4], cr0, cp0;
+        uint8_t zc0v, zh0v;
+        {
+            PROD_GATHER(BO_DG1)
+            PROD_HALF(0, w1t, BO_PM0, false)
+            PSTAMP(8);
+            {   // operands of the cell-0 update backward: requested here, they arrive under the second half and the hand-off
+                const unsigned oHx = wave0 < 2 ? oH : 0u, o4Hx = wave0 < 2 ? o4H : 0u;         // (one address for the waves that only repeat the update)
+                const float* a = d.acts0 + sB * 4 * PH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a0v[q] = a[o4Hx + q * PH];
+                cr0 = (d.craw0 + sB * PH)[oHx]; cp0 = (d.c0 + sB * PH)[oHx];
+                zc0v = (d.zc0 + sB * PH)[oHx]; zh0v = (d.zh0 + sB * PH)[oHx];
+            }
+            PROD_HALF(1, w1t, BO_PH1, false)
+        }
         PSTAMP(9);
         // ================= cell 0, update backward
         __syncthreads();
-        {
-            pf32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if (tid < 256) {
-                const int row = tid >> 3, src = tid & 7;
-                unsigned off[2];
-                off[0] = (unsigned)((BO_PM0 + slot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);
-                off[1] = first ? off[0] : (unsigned)((BO_PH0 + nslot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);
-                if (!gather<2>(xr, off, v, d.ctrl)) PFAIL();
-                if (first) v[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+        ISSUE_UPDATE0();
+        if (tid < 256) {
+            const int row = tid >> 3, src = tid & 7;
+            if (!complete<2>(xr, uoff, uv, d.ctrl)) PFAIL();
+            if (first) uv[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[0][e], y = v[1][e];
-                    x += dpp_mov<0xB1, 0xf>(0.f, x); x += dpp_mov<0x4E, 0xf>(0.f, x); x += dpp_mov<0x141, 0xf>(0.f, x);
-                    y += dpp_mov<0xB1, 0xf>(0.f, y); y += dpp_mov<0x4E, 0xf>(0.f, y); y += dpp_mov<0x141, 0xf>(0.f, y);
-                    v[0][e] = x; v[1][e] = y;
-                }
-                if (src == 0) {
-                    *reinterpret_cast<pf32x4*>(sm + B_TR + row * 4) = v[0];
-                    *reinterpret_cast<pf32x4*>(sm + B_TR + 128 + row * 4) = v[1];
-                }
+            for (int e = 0; e < 4; ++e) {
+                float x = uv[0][e], y = uv[1][e];
+                x += dpp_mov<0xB1, 0xf>(0.f, x); x += dpp_mov<0x4E, 0xf>(0.f, x); x += dpp_mov<0x141, 0xf>(0.f, x);
+                y += dpp_mov<0xB1, 0xf>(0.f, y); y += dpp_mov<0x4E, 0xf>(0.f, y); y += dpp_mov<0x141, 0xf>(0.f, y);
+                uv[0][e] = x; uv[1][e] = y;
+            }
+            if (src == 0) {
+                *reinterpret_cast<pf32x4*>(sm + B_TR + row * 4) = uv[0];
+                *reinterpret_cast<pf32x4*>(sm + B_TR + 128 + row * 4) = uv[1];
             }
         }
         PABORT_CHECK();
@@ -509,11 +518,18 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             if (elive) { float* o = d.dg0 + sB * 4 * PH; o[o4H] = dgv[0]; o[o4H + PH] = dgv[1]; o[o4H + 2 * PH] = dgv[2]; o[o4H + 3 * PH] = dgv[3]; }
         }
         PSTAMP(11);
-#define STAMP_BASE 12
-        PRODUCT(BO_DG0, w0t, BO_PM0, BO_PH0, true)
-#undef STAMP_BASE
+        {
+            PROD_GATHER(BO_DG0)
+            PROD_HALF(0, w0t, BO_PM0, true)
+            PSTAMP(12);
+            PROD_HALF(1, w0t, BO_PH0, false)
+        }
         PSTAMP(13);
+#ifndef EXP_NO_OPLOAD
+        LOAD_OPERANDS1(s > 0 ? s - 1 : 0);
+#endif
         __syncthreads();                                             // the product's readers are done before the attention scratch is written
+        PSTAMP(14);
     }
     if (tid == 0) {
         __hip_atomic_fetch_add(d.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -525,7 +541,13 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 #undef PSTAMP
 #undef PABORT_CHECK
 #undef PFAIL
-#undef PRODUCT
+#undef PROD_GATHER
+#undef ISSUE_UPDATE1
+#undef ISSUE_UPDATE0
+#undef PROD_HALF
+#undef LOAD_ROWS
+#undef LOAD_OPERANDS1
+#undef STORE_ROWS
 }
 
 // ---- packers.  Contraction step ks of wave w's eighth: group mm = ks >> 2 -> producer column slice j' = 4 w + mm, unit 32 j' + 4 i + (ks & 3); the

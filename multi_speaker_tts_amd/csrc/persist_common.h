@@ -54,6 +54,37 @@ __device__ __forceinline__ bool gather(__amdgpu_buffer_rsrc_t r, const unsigned 
     }
 }
 
+// The same in two parts, so that the round trip of the first request runs under other work: issue<N>() as early as the addresses are
+// known, complete<N>() where the data is needed (it polls on as gather<N>() does).
+template <int N>
+__device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N]) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < N; ++m) v[m] = xload(r, off[m]);
+    asm volatile("" ::: "memory");                   // ... and they stay HERE: without the second fence the scheduler sinks the requests
+    __builtin_amdgcn_sched_barrier(0);               // below the work they are meant to run under
+}
+template <int N>
+__device__ __forceinline__ bool complete(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N], const unsigned* ctrl) {
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        bool miss = false;
+#pragma unroll
+        for (int m = 0; m < N; ++m) miss |= has_sent(v[m]);
+        if (!__builtin_amdgcn_ballot_w64(miss)) return true;
+        if ((++spins & 15u) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        }
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            if (has_sent(v[m])) v[m] = xload(r, off[m]);
+    }
+}
+
 #define PMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 }  // namespace mstts

@@ -75,9 +75,11 @@ def synthetic_batch(dims, B, Te, L, seed, rank, device):
 
 
 def _cpu_baseline_worker(threads, budget_s):
-    """Oracle train step (fwd + autograd bwd + TF-Adam) on `threads` host threads, bounded sample."""
+    """SURVEY 8(d) protocol: the oracle train step (fwd + autograd bwd + TF-Adam) at the FULL workload - batch 32 x (128 tokens, 800
+    mel frames) - 1 warm-up + 3 timed steps, median, on the thread count that a short sweep finds fastest (threads = the sweep's
+    candidates, comma separated).  budget_s > 0: the truncated sample of earlier rounds instead (first frames of the 800, extrapolated;
+    only for boxes where the full protocol does not fit)."""
     from oracle import model as OM, train as OT
-    torch.set_num_threads(threads)
     d = OM.Dims()
     params = OM.init_params(d, 1234)
 
@@ -88,16 +90,33 @@ def _cpu_baseline_worker(threads, budget_s):
         OT.train_step(params, None, d, batch, masks, 0, dtype=torch.float32)
         return time.perf_counter() - t0
 
-    run(4)                                              # warm the thread pool / allocator
-    L = 100                                             # fixed bounded sample: first 100 of the 800 frames
-    t = run(L)
-    if t < 0.5 * budget_s:                              # fast host: spend the budget on a longer sample
-        L = int(min(L_MEL, L * budget_s / t))
+    cands = [int(x) for x in str(threads).split(",")]
+    sweep = {}
+    for th in cands:                                        # 40-frame sample per candidate (a few seconds each), after a 4-frame warm-up
+        torch.set_num_threads(th)
+        run(4)
+        sweep[th] = B_PER_GPU * 40 / run(40)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    if budget_s > 0:
+        L = 100
         t = run(L)
-    out = {"value": B_PER_GPU * L / t, "unit": "mel-frames/s", "cores": threads, "kind": "port",
-           "sample": "1 train step (fwd+bwd+TF-Adam) of the torch-CPU fp32 oracle at batch %d x (%d tokens, first %d of %d mel frames) on %d of %d host threads, %.1f s"
-                     % (B_PER_GPU, T_ENC, L, L_MEL, threads, os.cpu_count(), t),
-           "sample_frames": L, "full_frames": L_MEL, "extrapolation_factor": L_MEL / float(L), "sample_seconds": t}
+        if t < 0.5 * budget_s:
+            L = int(min(L_MEL, L * budget_s / t))
+            t = run(L)
+        times = [t]
+        proto = "1 un-warmed step, truncated to the first %d of %d frames (time budget %.0f s)" % (L, L_MEL, budget_s)
+    else:
+        L = L_MEL
+        run(L)                                              # warm-up at full size
+        times = sorted(run(L) for _ in range(3))
+        t = times[1]
+        proto = "1 warm-up + 3 timed full steps, median"
+    out = {"value": B_PER_GPU * L / t, "unit": "mel-frames/s", "cores": best, "kind": "port",
+           "sample": "train step (fwd+bwd+TF-Adam) of the torch-CPU fp32 oracle at batch %d x (%d tokens, %d of %d mel frames) on %d of %d host threads: %s; %.1f s per step"
+                     % (B_PER_GPU, T_ENC, L, L_MEL, best, os.cpu_count(), proto, t),
+           "sample_frames": L, "full_frames": L_MEL, "extrapolation_factor": L_MEL / float(L), "sample_seconds": t, "step_seconds": times,
+           "thread_sweep_frames_per_s": {str(k): v for k, v in sweep.items()}}
     out["config1"] = _cpu_config1(d, params)
     return out
 
@@ -135,13 +154,15 @@ def _cpu_config1(d, params):
             "mel_frames_per_s_forward": frames / t_fwd, "mel_frames_per_s_end_to_end": frames / (t_fwd + t_gl)}
 
 
-def cpu_baseline(budget_s=25.0, timeout_s=300):
-    """Run the worker in a subprocess with a hard time limit (a huge host can thrash torch's
-    intra-op pool on the small per-step GEMMs; threads are capped at 32)."""
+def cpu_baseline(budget_s=0.0, timeout_s=1500):
+    """Run the worker in a subprocess with a hard time limit.  Thread candidates: 32 / 64 / 128 / all host threads (a 256-thread host
+    thrashes torch's intra-op pool on the loop's small GEMMs, so more threads are not faster - the sweep decides)."""
     import subprocess
-    threads = min(os.cpu_count() or 1, 32)
-    code = "import json,bench;print('CPUBASE'+json.dumps(bench._cpu_baseline_worker(%d,%f)))" % (threads, budget_s)
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    n = os.cpu_count() or 1
+    cands = sorted({min(n, c) for c in (32, 64, 128, n)})
+    code = "import json,bench;print('CPUBASE'+json.dumps(bench._cpu_baseline_worker('%s',%f)))" % (",".join(map(str, cands)), budget_s)
+    env = dict(os.environ)
+    env.pop("OMP_NUM_THREADS", None); env.pop("MKL_NUM_THREADS", None)
     try:
         out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s).stdout
         for line in out.splitlines():
@@ -149,7 +170,7 @@ def cpu_baseline(budget_s=25.0, timeout_s=300):
                 return json.loads(line[len("CPUBASE"):])
     except subprocess.TimeoutExpired:
         pass
-    return {"value": None, "unit": "mel-frames/s", "cores": threads, "kind": "port", "sample": "oracle did not finish within %d s" % timeout_s}
+    return {"value": None, "unit": "mel-frames/s", "cores": max(cands), "kind": "port", "sample": "oracle did not finish within %d s" % timeout_s}
 
 
 def self_launch(n):
@@ -366,7 +387,7 @@ def main():
         out["step_flops_fraction_of_fp32_mfma_peak"] = (4.047e12 * L / L_MEL) / (ms_per_step * 1e-3) / 157.3e12
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)
 
     if rank == 0:
         print(json.dumps(out))

@@ -532,7 +532,12 @@ class TrainEngine:
             self._conv_block_bwd(dy, x_in, w.post_a[i], w.post_mean[i], w.post_rstd[i], mk["post_drop_%d" % i], 1 - d.conv_drop,
                                  ACT_TANH, "decoder/conv_%d/" % i, B * S, S, cin, chans[i], d.post_k, w.post_dz[i], dx)
             dy = dx
-        if on_ready is not None:             # every postnet gradient is final: its all-reduce overlaps the decoder BPTT
+        # every postnet gradient is final: its all-reduce overlaps the decoder BPTT - unless that is the persistent launch, which needs
+        # every CU of the chip for itself: a collective kernel holding CUs at that moment and the 256 workgroups waiting for each
+        # other's CUs would sit out the launch's start window (0.2 s) and end in the fallback.  Then the range is announced BEHIND the
+        # launch (the collective is ordered after what is enqueued) and runs under the hoisted weight-gradient products instead.
+        postnet_ready_deferred = on_ready is not None and bool(getattr(w, "persist_bwd", False))
+        if on_ready is not None and not postnet_ready_deferred:
             on_ready(*self._grad_range("decoder/conv_"))
         # d_linear(total) = loss part + residual (d_post) + postnet input grad
         n = B * S * d.n_mel
@@ -585,6 +590,8 @@ class TrainEngine:
                 parts = 1                    # d_in0 slab 0 holds the complete context gradient
         else:
             call("mstts_decoder_train_bwd", C.byref(db))
+        if postnet_ready_deferred:
+            on_ready(*self._grad_range("decoder/conv_"))
         # hoisted weight gradients of the loop.  (Running them chunk by chunk on a second stream under BPTT was measured: the
         # GEMMs' MFMA traffic slows every latency-bound loop kernel by 25-35 %, 105.4 vs 102.2 ms per step - not kept.)
         self._recurrent_wgrads(w, 0, S)

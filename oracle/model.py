@@ -373,6 +373,7 @@ def run_lstm(x, lengths, kernel, bias, H, zc, zh, rate, training, reverse=False,
 
 
 KINK_BAND = 1e-4      # |pre-activation| below which two correct implementations may disagree on which side of the ReLU kink it lies
+RELU_INJECTED = {"elements": 0, "differ": 0}      # running count of injected-pattern elements and of those that differ from this evaluation's own pattern
 
 
 def relu_at(pre, active=None):
@@ -385,6 +386,8 @@ def relu_at(pre, active=None):
         return torch.relu(pre)
     active = torch.as_tensor(active).to(torch.bool).reshape(pre.shape)
     differ = active != (pre.detach() > 0)
+    RELU_INJECTED["elements"] += int(differ.numel())
+    RELU_INJECTED["differ"] += int(differ.sum())
     if bool(differ.any()):
         worst = float(pre.detach().abs()[differ].max())
         assert worst < KINK_BAND, "injected ReLU pattern differs outside the kink band: |pre| = %g" % worst

@@ -72,7 +72,7 @@ def test_train_step_through_rccl_one_rank(dev):
         dist.destroy_process_group()
 
 
-def _two_rank_worker(rank, world, port, cfg, B, Te, L, q):
+def _two_rank_worker(rank, world, port, cfg, B, Te, L, q, backend="gloo"):
     """One data-parallel rank of a 2-rank job; both ranks share the one GPU of the box, the collectives go through gloo (which
     stages device tensors through the host) - everything else is the product path: sample-keyed masks, broadcast of rank 0's
     state, gradient all-reduce overlapped with the backward pass, 1/world folded into Adam, statistics averaging."""
@@ -84,8 +84,13 @@ def _two_rank_worker(rank, world, port, cfg, B, Te, L, q):
     from multi_speaker_tts_amd.engine import TrainEngine as TE
     from tests.helpers import dims_pair as dp_, to_dev as td_
     from oracle import model as OM_, train as OT_
-    dev = torch.device("cuda:0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:%d" % (rank if backend == "nccl" else 0))     # RCCL: one GPU per rank; gloo: both ranks share the one GPU
+    if backend == "nccl":
+        os.environ["LOCAL_RANK"] = str(rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         pd, od = dp_(**cfg)
         values = OM_.init_params(od, 21 + rank)                      # ranks start DIFFERENT: the broadcast must fix that
@@ -99,16 +104,46 @@ def _two_rank_worker(rank, world, port, cfg, B, Te, L, q):
         eng.sync_statistics()
         torch.cuda.synchronize()
         sc = eng.scalars(w, average=True)
-        q.put((rank, eng.params.export(), sc["Loss"], eng.exchange_timeouts(w)))
+        extra = {}
+        if backend == "nccl":
+            # the config-3 exchange with TWO ranks on RCCL: bf16 message, fp32 sum in rank order, one rounding - checked against what the
+            # ranks' own gradients (collected with a plain fp32 all-gather) say the result must be, bit for bit
+            g = eng.params.grad
+            eng.forward(td_(mine, dev), w)
+            eng.loss_and_backward(w)
+            mine_g = g.clone()
+            parts = [torch.empty_like(mine_g) for _ in range(world)]
+            dist.all_gather(parts, mine_g)
+            want = sum(p.to(torch.bfloat16).float() for p in parts).to(torch.bfloat16).float()
+            red16 = D.GradAllReduce(g, world, bucket_mb=0.25, comm_dtype="bf16")
+            red16.start(g, g.numel() // 2, g.numel())
+            red16.finish(g)
+            torch.cuda.synchronize()
+            extra["bf16_exchange_exact"] = bool(torch.equal(g, want))
+            extra["exposed_ms"] = red.exposed_ms()
+        q.put((rank, eng.params.export(), sc["Loss"], eng.exchange_timeouts(w), extra))
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_rccl_against_oracle(dev):
+    """The same two-rank step on TWO GPUs over RCCL (one process per GPU, backend nccl) - self-skipping on a one-GPU box, so that a
+    multi-GPU box exercises the real collectives: fp32 all-reduce overlapped with the backward pass against the oracle, then the
+    bf16 exchange (all-to-all + fp32 sum + all-gather) with nr = 2, bit for bit."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL between two ranks)")
+    _run_two_ranks("nccl")
 
 
 def test_two_ranks_share_one_gpu_against_oracle(dev):
     """N = 2 data parallel end to end on the hardware at hand: two processes on the one GPU, gloo collectives.  Expected result
     from the oracle: every rank's gradient on its shard (masks keyed by global sample index, per-rank BN batch statistics), the
     mean of the two, ONE TF-Adam update from rank 0's initial state; BN moving statistics = mean of the ranks' updates."""
+    _run_two_ranks("gloo")
+
+
+def _run_two_ranks(backend):
     import torch.multiprocessing as mp
     from oracle import model as OM
     cfg = dict(dec_lstm=64, enc_lstm=32, spk=64, prenet=32)
@@ -118,13 +153,15 @@ def test_two_ranks_share_one_gpu_against_oracle(dev):
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, cfg, B, Te, L, q)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, cfg, B, Te, L, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
     for _ in range(world):
-        r, params, loss, timeouts = q.get(timeout=600)
+        r, params, loss, timeouts, extra = q.get(timeout=600)
         got[r] = (params, loss, timeouts)
+        if backend == "nccl":
+            assert extra["bf16_exchange_exact"], r
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

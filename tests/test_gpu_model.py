@@ -921,6 +921,66 @@ def test_tacotron2_surface(dev, tmp_path, monkeypatch):
         t.Inference(None, ["ünknown"], speaker_Mel_List=mels[:1])
 
 
+def test_inference_from_wav_paths(dev, tmp_path, monkeypatch):
+    """Tacotron2.Inference(path_List=[wav ...], text_List) end to end from real files (MSTTS_SV.py:295-299, Feeder.py:186-233): two
+    48 kHz wavs with silence around the signal -> load at 16 kHz, trim (top_db 15) x 0.99 -> mel on the GPU -> five 64-frame speaker
+    windows -> speaker encoder -> free-running decoder -> Taco1 -> cut at the stop token -> NPZ + Griffin-Lim WAV files."""
+    from scipy.io import wavfile
+    from multi_speaker_tts_amd import Hyper_Parameters as hp, Audio, Feeder as F
+    from multi_speaker_tts_amd.MSTTS_SV import Tacotron2
+    from multi_speaker_tts_amd.params import Dims
+    from oracle import audio as OA, feeder as OF
+    monkeypatch.setattr(hp, "Checkpoint_Path", str(tmp_path / "ckpt"))
+    monkeypatch.setattr(hp, "Inference_Path", str(tmp_path / "inf"))
+    dims = Dims(emb=32, enc_conv_ch=32, enc_lstm=16, spk=256, prenet=16, dec_lstm=32, post_ch=16, bank_ch=8, proj1_ch=16, birnn=8,
+                spk_lstm=256, max_inf=6)
+    assert dims.n_spec == hp.Sound.Spectrogram_Dim
+    g = np.random.default_rng(3)
+    paths = []
+    for i, seconds in enumerate((3.1, 1.2)):           # the second one is shorter than the 192 frames five windows need
+        n = int(48000 * seconds)
+        t = np.arange(n) / 48000.0
+        y = 0.4 * np.sin(2 * np.pi * (180 + 60 * i) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t)) + 0.02 * g.normal(size=n)
+        y = np.concatenate([1e-4 * g.normal(size=9600), y, 1e-4 * g.normal(size=14400)])          # 0.2 s / 0.3 s of near silence
+        p = str(tmp_path / ("spk%d.wav" % i))
+        wavfile.write(p, 48000, (y * 32767).astype(np.int16))
+        paths.append(p)
+    texts = ["Please call Stella.", "Who knows?"]
+    t = Tacotron2(is_Training=False, device=dev, dims=dims, allow_random_init=True)
+    # the feeder's leg, piece by piece
+    sigs = [F.load_wav(p) for p in paths]
+    assert all(s.dtype == np.float32 and 0.3 < np.abs(s).max() <= 0.99 for s in sigs)                 # [-1, 1] samples x 0.99 (Feeder.py:215)
+    assert 2.9 * 16000 < sigs[0].shape[0] < 3.3 * 16000 and 1.0 * 16000 < sigs[1].shape[0] < 1.4 * 16000     # resampled, silence trimmed
+    mels = [np.transpose(Audio.melspectrogram(y=s, num_freq=hp.Sound.Spectrogram_Dim, frame_shift_ms=hp.Sound.Frame_Shift,
+                                              frame_length_ms=hp.Sound.Frame_Length, num_mels=hp.Sound.Mel_Dim, sample_rate=hp.Sound.Sample_Rate,
+                                              max_abs_value=hp.Sound.Max_Abs_Mel, device=dev)).astype(np.float32) for s in sigs]
+    for s, m in zip(sigs, mels):
+        assert m.shape == (1 + s.shape[0] // 200, 80) and np.abs(m.T - OA.melspectrogram(s)).max() < 2e-3
+    pattern = t.feeder.Get_Inference_Pattern(paths, texts)
+    assert mels[0].shape[0] >= 192 > mels[1].shape[0]
+    assert np.array_equal(pattern["Speaker_Embedding_Mel"], OF.speaker_windows(mels))                 # [2 * 5, 64, 80], Feeder.py:62-87
+    assert np.array_equal(pattern["Token"][0, :21], [0, 29, 25, 18, 14, 32, 18, 2, 16, 14, 25, 25, 2, 32, 33, 18, 25, 25, 14, 10, 1])
+    # the whole call, from paths and from the same mels
+    od = OM.Dims(**{f: getattr(dims, f) for f in ("emb", "enc_conv_ch", "enc_lstm", "spk", "prenet", "dec_lstm", "post_ch", "bank_ch", "proj1_ch",
+                                                 "birnn", "spk_lstm", "max_inf")})
+    masks = {k: v.numpy() for k, v in OT.make_masks(od, 2, pattern["Token"].shape[1], od.max_inf + 1, False, seed=31).items()}
+    res = t.Inference(paths, texts, file_Prefix="pl", masks=masks)
+    again = t.Inference(None, texts, speaker_Mel_List=mels, masks=masks, export=False)
+    for k in ("Linear", "Mel", "Stop", "Spectrogram"):
+        assert np.array_equal(res[k], again[k]), k
+    S = res["Linear"].shape[1]
+    assert res["Spectrogram"].shape == (2, S, hp.Sound.Spectrogram_Dim) and np.isfinite(res["Spectrogram"]).all()
+    for i in range(2):
+        npz = np.load(str(tmp_path / "inf" / "NPZ" / ("pl.IDX_%d.npz" % i)))
+        assert np.array_equal(npz["Mel"], res["Cut"][i]["Mel"]) and npz["Attention_History"].shape[0] == len(texts[i]) + 2
+        wav_path = tmp_path / "inf" / "WAV" / ("pl.IDX_%d.WAV" % i)
+        if res["Cut"][i]["Spectrogram"].shape[0] > 1:          # the reference refuses one-frame spectrograms (MSTTS_SV.py:403-406)
+            rate, wav = wavfile.read(str(wav_path))
+            assert rate == hp.Sound.Sample_Rate and wav.shape[0] > 0 and np.isfinite(wav).all()
+    with pytest.raises(ValueError):
+        t.Inference(paths[:1], texts)
+
+
 def test_pattern_generate_cli_to_training(dev, tmp_path, monkeypatch):
     """SURVEY 8(f).2 end to end: `Pattern_Generate -lj <corpus>` (corpus walker -> GPU mel extraction -> pattern pickles ->
     METADATA.PICKLE), then Tacotron2.Train reads those patterns through the feeder's producer thread and takes two steps."""

@@ -136,3 +136,48 @@ def test_tacotron2_inference_waveglow_surface(dev, tmp_path, monkeypatch):
     for i in range(2):
         assert res["Cut"][i]["Wav"].shape[0] == min(res["Wav"][i].shape[0], int(res["Cut"][i]["Mel"].shape[0] * 12.5 / 1000 * 22050))
     assert (tmp_path / "inf" / "WAV" / "wg.IDX_1.WAV").exists() and last >= 1
+
+
+# the reference's own sizes (WaveGlow/Modules.py:177-208,252-327; Hyper_Parameters.py WaveGlow block): 12 flows x 8 WaveNet layers of
+# 512 channels, kernel 3, dilations 1 .. 128, transposed-conv upsampler K = 1024 / stride 256, 8 audio groups, early outputs every 4 flows
+REF_WG = dict(n_mel=80, flows=12, groups=8, early_every=4, early_size=2, up_k=1024, up_stride=256, layers=8, ch=512, k=3)
+
+
+def _ref_size_values():
+    od = OW.WGDims(**REF_WG)
+    values = OW.init_params(od, seed=3)
+    for k in values:                     # a trained network keeps the couplings' log-scales small; glorot-initialised end convolutions do not
+        if k.endswith("wavenet/conv1d/kernel"):
+            values[k] = np.asarray(values[k]) * 0.05
+    return od, values
+
+
+def test_glow_inference_reference_size(dev):
+    """The whole inference flow AT THE REFERENCE SIZE (268 M parameters) against the fp64 oracle: N = 1, T = 2 frames -> 1280 samples,
+    every coupling layer at 512 channels / 8 dilated layers, identical injected latents."""
+    od, values = _ref_size_values()
+    pd = WG.WGDims(**REF_WG)
+    N, T = 1, 2
+    g = np.random.default_rng(8)
+    mel = np.clip(g.normal(0, 1.5, (N, T, od.n_mel)), -4, 4)
+    L = (T - 1) * od.up_stride + od.up_k
+    assert L == 256 * T + 768
+    noise = OW.make_noise(od, N, L // od.groups, seed=9)
+    ref = OW.glow_inference(OW.to_torch(values), od, torch.tensor(mel), {k: torch.tensor(v) for k, v in noise.items()}, sigma=0.8)
+    eng = WG.WaveGlowEngine(pd, device=dev, values=values)
+    got = eng.infer(mel.astype(np.float32), noise=noise, sigma=0.8)
+    assert got.shape == (N, L) and bool(torch.isfinite(got).all())
+    assert rel_err(t2n(got), t2n(ref)) < 1e-3, rel_err(t2n(got), t2n(ref))
+
+
+def test_glow_inference_reference_size_properties(dev):
+    """BASELINE configs[4]'s vocoder leg at full size (batch 4 x 40-frame chunks): output length 256 T + 768 per chunk, finite,
+    reproducible per latent seed, different for a different seed."""
+    od, values = _ref_size_values()
+    eng = WG.WaveGlowEngine(WG.WGDims(**REF_WG), device=dev, values=values)
+    N, T = 4, 40
+    mel = np.clip(np.random.default_rng(3).normal(0, 1.5, (N, T, 80)), -4, 4).astype(np.float32)
+    a, b, c = eng.infer(mel, seed=5), eng.infer(mel, seed=5), eng.infer(mel, seed=6)
+    assert a.shape == (N, 256 * T + 768) and bool(torch.isfinite(a).all())
+    assert rel_err(t2n(a), t2n(b)) < 1e-5
+    assert rel_err(t2n(a), t2n(c)) > 1e-2

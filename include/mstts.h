@@ -550,7 +550,7 @@ int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s)
  * runs behind either.  Reference widths only: mstts_persist_fwd_supported(B <= 32, H == 1024, M == 768, A == 128, T <= 128, KS == 31)
  * and a device that admits all 256 workgroups at once (occupancy query, >= 256 CUs).
  *   w0pk / w1pk / wqpk: mstts_persist_pack(w0f, w1, wq) copies (mstts_persist_pack_floats(0 / 1 / 2) floats), refreshed when the
- *                       variables change;  xch: mstts_persist_fwd_ws_bytes() bytes, 16-byte aligned;  ctrl: 16 uint32.
+ *                       variables change;  xch: mstts_persist_fwd_ws_bytes() bytes, 16-byte aligned;  ctrl: 272 uint32.
  * After the launch: ctrl[1] == 0 and ctrl[2] == 256  <=>  the sequence ran to its end.  Anything else (the workgroups were not
  * co-resident within the start window, e.g. because another kernel held CUs; or a bounded wait expired) means the outputs are
  * incomplete: the caller re-runs mstts_decoder_train_fwd, which recomputes every step (abort codes: 1 = start rendezvous timed out,
@@ -560,6 +560,7 @@ typedef struct {
     const float* w0pk; const float* w1pk; const float* wqpk;
     float* xch; uint32_t* ctrl; uint64_t* stamps;
     int32_t selftest_fail_step;   /* 0 in production; k > 0: workgroup 0 raises the abort word at step k - 1 (exercises the fallback) */
+    int32_t near_xcd;             /* experimental, 0 = off: hand-offs whose producer and consumers report one XCC id stay in that XCD's L2 */
 } mstts_persist_desc;
 int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
 int64_t mstts_persist_fwd_ws_bytes(void);
@@ -585,7 +586,7 @@ int32_t mstts_decoder_train_bwd_parts(int64_t H, int64_t M);   /* number of d_in
 /* ---- BPTT through the same S steps as ONE persistent launch (csrc/persist_bwd.hip), the counterpart of
  * mstts_decoder_train_fwd_persistent: same geometry and support rule (mstts_persist_bwd_supported), same descriptor type with
  *   w0pk / w1pk / wqpk = the mstts_persist_bwd_pack(w0f, w1, wq) copies (transposed kernels in the lanes' order,
- *                        mstts_persist_bwd_pack_floats(0 / 1 / 2) floats),  xch = mstts_persist_bwd_ws_bytes() bytes,  ctrl = 16 uint32.
+ *                        mstts_persist_bwd_pack_floats(0 / 1 / 2) floats),  xch = mstts_persist_bwd_ws_bytes() bytes,  ctrl = 272 uint32.
  * It reads the forward history of bd->fwd and bd->d_pj and writes what mstts_decoder_train_bwd writes - dg0, dg1 [S,B,4H], dq_hist
  * (no pre-zeroing needed), de_hist - with ONE difference: d_in0 receives, in its FIRST slab only, the complete gradient of the
  * context rows (columns 0..M-1 of slots 1..S-1; the h0 columns are not written), so a consumer sums 1 slab instead of

@@ -9,9 +9,9 @@
 //     slice of the row's values (48 KB of LDS) stay on chip as well.
 //
 // Per step the only traffic is the recurrent data itself, handed from CU to CU through write-through (sc1) stores and L1-bypassing
-// (sc1) loads on small rings in memory, where THE DATA IS THE FLAG: every ring slot is pre-filled with the bit pattern 0xFFFFFFFF (a
-// NaN no arithmetic here produces), a consumer polls its piece until no word of it reads as that pattern, and the producer re-arms
-// the slot two steps ahead.  No barrier, no counter, no fence on the step path.  Six hand-offs per step:
+// (sc1) loads on small rings in memory, where THE DATA IS THE FLAG (persist_common.h): every exchanged word carries the generation
+// of its ring slot in its last mantissa bit, and a consumer polls its piece until every word shows the generation it expects.  No
+// barrier, no counter, no fence, no second store on the step path.  Six hand-offs per step:
 //
 //   ctx_{s-1} -> [cell-0 product, context rows]  -> partial gates -> (sum of 8, cell-0 update)  -> m0, h0
 //   m0        -> [cell-1 product, input rows]    -> partial gates -> (sum of 8, cell-1 update)  -> m1, h1
@@ -54,7 +54,7 @@ struct PersistFwd {
     float* q_hist; float* align_hist; float* cum_hist;
     float* xch; unsigned* ctrl;                  // ctrl[0] arrivals, ctrl[1] abort code, ctrl[2] workgroups that finished all S steps
     unsigned long long* stamps;                  // PROF: [256][NSTAMP] summed interval ticks
-    int fail_step;                               // self-test: workgroup 0 raises the abort word at this step (-1 = never)
+    int fail_step; int near_xcd;                               // self-test: workgroup 0 raises the abort word at this step (-1 = never)
 };
 
 
@@ -84,9 +84,10 @@ __device__ __forceinline__ void slice_issue(__amdgpu_buffer_rsrc_t xr, long slic
     issue<2>(xr, off, v);
 }
 template <int K4, int LD>
-__device__ __forceinline__ bool slice_complete(__amdgpu_buffer_rsrc_t xr, float* stg, int tid, const unsigned (&off)[2], pf32x4 (&v)[2], const unsigned* ctrl) {
+__device__ __forceinline__ bool slice_complete(__amdgpu_buffer_rsrc_t xr, float* stg, int tid, const unsigned (&off)[2], pf32x4 (&v)[2], const unsigned* ctrl, unsigned gen) {
     constexpr int NPC = 128 * K4;
-    const bool ok = complete<2>(xr, off, v, ctrl);
+    const unsigned gens[2] = {gen, gen};
+    const bool ok = complete<2>(xr, off, v, ctrl, gens);
     {
         const int rho = tid / K4, k4 = tid - rho * K4;
         *reinterpret_cast<pf32x4*>(stg + rho * LD + 4 * k4) = v[0];
@@ -123,20 +124,14 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 
     // ---------------- start rendezvous: all 256 workgroups must be resident before anyone waits for data
     if (tid == 0) {
-        sflag[0] = 0;
-        __hip_atomic_fetch_add(d.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(d.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PWG) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(d.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(d.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sflag[0] = 1;
-                break;
-            }
-        }
+        const int rz = persist_rendezvous(d.ctrl, g0);
+        sflag[0] = rz == 0 ? 1u : 0u;
+        sflag[1] = (rz == 2 && d.near_xcd) ? 1u : 0u;
+        if (rz == 2 && g0 < 8) __hip_atomic_fetch_add(d.ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (reported: groups publishing through their L2)
     }
     __syncthreads();
     if (sflag[0]) return;
+    const bool near = sflag[1] != 0;          // this workgroup's slice group shares one XCD: intra-group pieces may stay in its L2
 
     // ---------------- once: this workgroup's constants.  Cell kernels -> registers (MFMA A operands), wave v = gate-column group v of the tile:
     //   w0[ks]: k-steps 0..23 = context rows of reduction slice gi, 24..55 = its h0 rows; w1[ks]: 0..31 = m0 rows, 32..63 = h1 rows
@@ -191,12 +186,11 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 #define PABORT_CHECK() do { __syncthreads(); if (sflag[0]) return; } while (0)
     // (the first code raised stays: a workgroup that merely found the abort word while waiting does not overwrite it)
 #define PFAIL() do { sflag[0] = 1; unsigned z__ = 0u; __hip_atomic_compare_exchange_strong(d.ctrl + 1, &z__, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
-    // this wave's partial gates -> reducer (gate-column group `wave` of column slice gj), as source gi; re-arms the slot two steps ahead
+    // this wave's partial gates -> reducer (gate-column group `wave` of column slice gj), as source gi
 #define PUBLISH_PARTIAL(OFFP, ACC)                                                                                              \
     _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                             \
         const long piece = ((long)(gj * 8 + wave) * 8 + gi) * 2 + t;                                                            \
-        xstore(xr, (unsigned)(((OFFP) + slot * XPART + piece * 256) * 4 + 16 * lane), ACC[t]);                                  \
-        xstore(xr, (unsigned)(((OFFP) + rslot * XPART + piece * 256) * 4 + 16 * lane), sentv());                                \
+        xpublish(xr, (unsigned)(((OFFP) + slot * XPART + piece * 256) * 4 + 16 * lane), ACC[t], gen);                                  \
         ACC[t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                                                                                  \
     }
     // waves 0..3 fetch the 8 x 2 partial tiles of this workgroup's 16 gate columns (sources 2 wave, 2 wave + 1) and pre-add the pair;
@@ -209,7 +203,8 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     }
 #define COMPLETE_PARTIALS()                                                                                                     \
     if (wave < 4) {                                                                                                             \
-        if (!complete<4>(xr, poff, pv, d.ctrl)) PFAIL();                                                                        \
+        const unsigned gens__[4] = {gen, gen, gen, gen};                                                                        \
+        if (!complete<4>(xr, poff, pv, d.ctrl, gens__)) PFAIL();                                                                        \
         *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 0) * 64 + lane) * 4) = pv[0] + pv[2];                              \
         *reinterpret_cast<pf32x4*>(sm + S_RED + ((wave * 2 + 1) * 64 + lane) * 4) = pv[1] + pv[3];                              \
     }
@@ -235,7 +230,8 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     LOAD_OPERANDS(0);
 
     for (int s = 0; s < S; ++s) {
-        const unsigned slot = (unsigned)s & 3u, rslot = (unsigned)(s + 2) & 3u, pslot = (unsigned)(s + 3) & 3u;   // pslot: the slot of step s - 1
+        const unsigned slot = (unsigned)s & 3u, pslot = (unsigned)(s + 3) & 3u;                    // pslot: the slot of step s - 1
+        const unsigned gen = ((unsigned)s >> 2) & 1u, pgen = ((unsigned)(s - 1) >> 2) & 1u;       // ... and the generations of the two
         // Every index below is re-derived from the thread / workgroup id behind an opaque asm once per step: left alone, the compiler
         // hoists some ninety loop-invariant ring offsets and LDS addresses out of the step loop, keeps them in VGPRs next to the 120
         // kernel registers, and spills into scratch inside the hand-off paths.
@@ -261,7 +257,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             __syncthreads();                                         // every wave is done with the staged h1 before ctx overwrites it
             PSTAMP(0);
             slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
-            if (!slice_complete<6, LC>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
+            if (!slice_complete<6, LC>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
             PABORT_CHECK();
             PSTAMP(1);
         }
@@ -290,8 +286,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 const int rho = (((gj & 3) * 2 + (row >> 4)) * 16) + (row & 15);
                 const long base = arr ? OFF_H0 : OFF_M0;
                 const long o2 = gi * 4096L + rho * 32 + 4 * (gj >> 2);
-                xstore(xr, (unsigned)((base + slot * XACT + o2) * 4), val);
-                xstore(xr, (unsigned)((base + rslot * XACT + o2) * 4), sentv());
+                xpublish_near(xr, (unsigned)((base + slot * XACT + o2) * 4), val, gen, near);
             }
             if (elive) {            // what BPTT reads, behind the hand-off stores (ahead of them they delayed the publication by their issue time)
                 float* a = d.acts0 + sB * 4 * PH; a[o4H] = o.si; a[o4H + PH] = o.tj; a[o4H + 2 * PH] = o.sf; a[o4H + 3 * PH] = o.so;
@@ -304,7 +299,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         PSTAMP(4);
         // ================= C: cell 1, input rows (m0_s)
         slice_issue<8>(xr, OFF_M0 + slot * XACT + gi * 4096L, tid, soff, sv);
-        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
+        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
         PABORT_CHECK();
         PSTAMP(5);
         slice_issue<8>(xr, OFF_H0 + slot * XACT + gi * 4096L, tid, soff, sv);     // h0_s left its producers together with m0_s: it arrives under the product
@@ -313,7 +308,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         PSTAMP(6);
         // in the shadow of the partial-gates hand-off: h0_s staged, first half of h0_s . W0[h rows] for step s+1
         __syncthreads();                                             // m0 is consumed by every wave
-        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
+        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
         PABORT_CHECK();
         mfma_part<0, 4, LA, 24, 56>(w0, stg, lane, acc0);
         PSTAMP(7);
@@ -335,13 +330,11 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 const pf32x4 val = *reinterpret_cast<const pf32x4*>(sm + S_TR + arr * 128 + row * 4);
                 if (arr == 0) {     // m1: row-major [32][1024] for the attention workgroups of the row
                     const long o2 = (long)row * PH + 4 * g;
-                    xstore(xr, (unsigned)((OFF_M1 + slot * XM1 + o2) * 4), val);
-                    xstore(xr, (unsigned)((OFF_M1 + rslot * XM1 + o2) * 4), sentv());
+                    xpublish(xr, (unsigned)((OFF_M1 + slot * XM1 + o2) * 4), val, gen);
                 } else {
                     const int rho = (((gj & 3) * 2 + (row >> 4)) * 16) + (row & 15);
                     const long o2 = gi * 4096L + rho * 32 + 4 * (gj >> 2);
-                    xstore(xr, (unsigned)((OFF_H1 + slot * XACT + o2) * 4), val);
-                    xstore(xr, (unsigned)((OFF_H1 + rslot * XACT + o2) * 4), sentv());
+                    xpublish_near(xr, (unsigned)((OFF_H1 + slot * XACT + o2) * 4), val, gen, near);
                 }
             }
             if (elive) {
@@ -361,7 +354,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             if (tid < 256) {
                 roff[0] = (unsigned)((OFF_M1 + slot * XM1 + (long)ab * PH) * 4 + 16 * tid);
                 issue<1>(xr, roff, rv);
-                if (!complete<1>(xr, roff, rv, d.ctrl)) PFAIL();
+                { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }
                 *reinterpret_cast<pf32x4*>(sm + S_M1 + 4 * tid) = rv[0];
             }
             PABORT_CHECK();
@@ -410,8 +403,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 }
                 if (ak == 0) {
                     const long o = ((long)ab * 8 + gi) * PT + 4 * atg;
-                    xstore(xr, (unsigned)((OFF_EN + slot * XEN + o) * 4), e4);
-                    xstore(xr, (unsigned)((OFF_EN + rslot * XEN + o) * 4), sentv());
+                    xpublish(xr, (unsigned)((OFF_EN + slot * XEN + o) * 4), e4, gen);
                 }
             }
         } else {
@@ -421,7 +413,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         // in the shadow of the energy hand-off: h1_s staged (it stays staged until the next step's context arrives), first half of h1_s . W1[h rows]
         slice_issue<8>(xr, OFF_H1 + slot * XACT + gi * 4096L, tid, soff, sv);
         __syncthreads();                                             // h0 is consumed by every wave
-        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl)) PFAIL();
+        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
         PABORT_CHECK();
         mfma_part<0, 4, LA, 32, 64>(w1, stg, lane, acc1);
         PSTAMP(13);
@@ -430,7 +422,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             if (tid < 256) {
                 roff[0] = (unsigned)((OFF_EN + slot * XEN + (long)ab * 8 * PT) * 4 + 16 * tid);
                 issue<1>(xr, roff, rv);
-                if (!complete<1>(xr, roff, rv, d.ctrl)) PFAIL();
+                { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }
                 *reinterpret_cast<pf32x4*>(sm + S_EN + 4 * tid) = rv[0];
             }
             PABORT_CHECK();
@@ -469,8 +461,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 const int qq = tid / 6, k4 = tid - qq * 6;
                 const int rho = ((qq * 2 + (ab >> 4)) * 16) + (ab & 15);
                 const long o = gi * 3072L + rho * 24 + 4 * k4;
-                xstore(xr, (unsigned)((OFF_CTX + slot * XCTX + o) * 4), val);
-                xstore(xr, (unsigned)((OFF_CTX + rslot * XCTX + o) * 4), sentv());
+                xpublish_near(xr, (unsigned)((OFF_CTX + slot * XCTX + o) * 4), val, gen, near);
                 reinterpret_cast<pf32x4*>(d.in0 + (sB1 + ab) * (PM + PH) + 96 * gi)[tid] = val;
                 reinterpret_cast<pf32x4*>(d.pj + (sB + ab) * (PH + PM) + PH + 96 * gi)[tid] = val;
             }
@@ -480,8 +471,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 const int qq = tid / 6, k4 = tid - qq * 6;
                 const int rho = ((qq * 2 + (ab >> 4)) * 16) + (ab & 15);
                 const long o = gi * 3072L + rho * 24 + 4 * k4;
-                xstore(xr, (unsigned)((OFF_CTX + slot * XCTX + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f});
-                xstore(xr, (unsigned)((OFF_CTX + rslot * XCTX + o) * 4), sentv());
+                xpublish_near(xr, (unsigned)((OFF_CTX + slot * XCTX + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f}, gen, near);
             }
         }
         PSTAMP(15);
@@ -590,8 +580,8 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
     if (e == hipSuccess) e = hipMemsetAsync(d->c0, 0, B * H * sizeof(float), hs);
     if (e == hipSuccess) e = hipMemsetAsync(d->c1, 0, B * H * sizeof(float), hs);
     if (e == hipSuccess) e = hipMemsetAsync(d->cum_hist, 0, B * T * sizeof(float), hs);
-    if (e == hipSuccess) e = hipMemsetAsync(p->xch, 0xFF, XCH_FLOATS * 4, hs);
-    if (e == hipSuccess) e = hipMemsetAsync(p->ctrl, 0, 16 * sizeof(unsigned), hs);
+    if (e == hipSuccess) e = hipMemsetAsync(p->xch, 0xFF, XCH_FLOATS * 4, hs);                  // every word "generation 1": stale for the first pass
+    if (e == hipSuccess) e = hipMemsetAsync(p->ctrl, 0, PCTRL_WORDS * sizeof(unsigned), hs);
     if (e != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "decoder_train_fwd_persistent: memset: %s", hipGetErrorString(e));
     PersistFwd a;
     a.w0pk = p->w0pk; a.w1pk = p->w1pk; a.wqpk = p->wqpk; a.xw0 = d->xw0; a.b1 = d->b1;
@@ -601,7 +591,7 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
     a.B = (int)B; a.S = (int)S; a.T = (int)T;
     a.in0 = d->in0; a.in1 = d->in1; a.pj = d->pj; a.c0 = d->c0; a.c1 = d->c1; a.acts0 = d->acts0; a.acts1 = d->acts1;
     a.craw0 = d->craw0; a.craw1 = d->craw1; a.q_hist = d->q_hist; a.align_hist = d->align_hist; a.cum_hist = d->cum_hist;
-    a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1;
+    a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
     const size_t lds = (size_t)S_FLOATS * 4;
     if (p->stamps) hipLaunchKernelGGL(persist_fwd_kernel<true>, dim3(PWG), dim3(PTH), lds, hs, a);
     else hipLaunchKernelGGL(persist_fwd_kernel<false>, dim3(PWG), dim3(PTH), lds, hs, a);

@@ -61,7 +61,7 @@ struct PersistBwd {
     const float* d_pj;
     int B, S, T;
     float* dg0; float* dg1; float* dq_hist; float* de_hist; float* d_in0;
-    float* xch; unsigned* ctrl; unsigned long long* stamps; int fail_step;
+    float* xch; unsigned* ctrl; unsigned long long* stamps; int fail_step; int near_xcd;
 };
 
 // zoneout-LSTM cell backward for one (row, unit) (the pointwise part of mstts_lstm_point_bwd): dm = gradient of the cell output m
@@ -94,20 +94,14 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 
     // ---------------- start rendezvous
     if (tid == 0) {
-        sflag[0] = 0;
-        __hip_atomic_fetch_add(d.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(d.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PWG) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(d.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(d.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sflag[0] = 1;
-                break;
-            }
-        }
+        const int rz = persist_rendezvous(d.ctrl, g0);
+        sflag[0] = rz == 0 ? 1u : 0u;
+        sflag[1] = (rz == 2 && d.near_xcd) ? 1u : 0u;
+        if (rz == 2 && g0 < 8) __hip_atomic_fetch_add(d.ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (reported: groups publishing through their L2)
     }
     __syncthreads();
     if (sflag[0]) return;
+    const bool near = sflag[1] != 0;          // this workgroup's slice group shares one XCD: intra-group pieces may stay in its L2
 
     // ---------------- once: the transposed kernels of this workgroup / wave -> registers.  w1t[h * 32 + kt * 16 + ks]: half h (0 = the
     // rows on the chain: m0 units, 1 = h1 units), output tile kt, contraction step ks of this wave's eighth; w0t likewise (context / h0)
@@ -183,7 +177,9 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 
     for (int s = S - 1; s >= 0; --s) {
         const bool first = s == S - 1;
-        const unsigned slot = (unsigned)s & 3u, rslot = (unsigned)(s + 2) & 3u, nslot = (unsigned)(s + 1) & 3u;     // nslot: the slot of step s + 1
+        const unsigned kk = (unsigned)(S - 1 - s);                                           // steps counted from the start of the launch
+        const unsigned slot = kk & 3u, nslot = (kk + 3u) & 3u;                                 // nslot: the slot of step s + 1 (the one before in time)
+        const unsigned gen = (kk >> 2) & 1u, ngen = ((kk - 1u) >> 2) & 1u;                     // ... and their generations
         tid = tid0; g = g0; wave = wave0;
         asm volatile("" : "+v"(tid));
         asm volatile("" : "+s"(g), "+s"(wave));
@@ -241,7 +237,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             // d_ctx of this slice's 96 columns: projection part + the 8 partial tiles of the next step's cell-0 product
             if (!first) {
                 if (tid < 192) {
-                    if (!complete<1>(xr, pcoff, pc, d.ctrl)) PFAIL();
+                    { const unsigned g1[1] = {ngen}; if (!complete<1>(xr, pcoff, pc, d.ctrl, g1)) PFAIL(); }
                     *reinterpret_cast<pf32x4*>(sm + B_PC + 4 * tid) = pc[0];
                 }
             }
@@ -274,8 +270,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                             (*reinterpret_cast<const pf32x4*>(sm + B_PD + 2 * PT + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + B_PD + 3 * PT + 4 * tid));
                 pd += *reinterpret_cast<const pf32x4*>(sm + B_GP + 4 * tid);
                 const long o = ((long)ab * 8 + gi) * PT + 4 * tid;
-                xstore(xr, (unsigned)((BO_DA + slot * BDA + o) * 4), pd);
-                xstore(xr, (unsigned)((BO_DA + rslot * BDA + o) * 4), sentv());
+                xpublish(xr, (unsigned)((BO_DA + slot * BDA + o) * 4), pd, gen);
             }
             PSTAMP(2);
         }
@@ -283,7 +278,8 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             if (tid < 256) {
                 unsigned off[1]; pf32x4 v[1];
                 off[0] = (unsigned)((BO_DA + slot * BDA + (long)ab * 8 * PT) * 4 + 16 * tid);
-                if (!gather<1>(xr, off, v, d.ctrl)) PFAIL();
+                const unsigned g1[1] = {gen};
+                if (!gather<1>(xr, off, v, d.ctrl, g1)) PFAIL();
                 *reinterpret_cast<pf32x4*>(sm + B_DA + 4 * tid) = v[0];
             }
             PABORT_CHECK();
@@ -334,8 +330,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                     }
                 }
                 const long o = ((long)ab * 8 + gi) * PH + 4 * tid;
-                xstore(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), out);
-                xstore(xr, (unsigned)((BO_DM1 + rslot * BDM1 + o) * 4), sentv());
+                xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), out, gen);
             }
             PSTAMP(4);
             {   // in the shadow of that hand-off: this slice's part of G for the step before: G[t] += sum_j sum_k g[t + 15 - j][k] loc_k[j][k]
@@ -366,8 +361,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             PSTAMP(0); PSTAMP(1); PSTAMP(2); PSTAMP(3);
             if (tid < 256) {        // rows past the batch: zeros, so that the cell owners' waits complete
                 const long o = ((long)ab * 8 + gi) * PH + 4 * tid;
-                xstore(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f});
-                xstore(xr, (unsigned)((BO_DM1 + rslot * BDM1 + o) * 4), sentv());
+                xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f}, gen);
             }
             PSTAMP(4);
         }
@@ -378,7 +372,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         ISSUE_UPDATE1();
         if (tid < 256) {            // piece (row, slice / source): 8 consecutive lanes hold the 8 partial vectors of one (row, 4 units)
             const int row = tid >> 3, sl = tid & 7;
-            if (!complete<2>(xr, uoff, uv, d.ctrl)) PFAIL();
+            { const unsigned g2[2] = {gen, first ? gen : ngen}; if (!complete<2>(xr, uoff, uv, d.ctrl, g2)) PFAIL(); }
             if (first) uv[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -410,8 +404,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 const int gate = tid >> 5, row = tid & 31;
                 const pf32x4 val = *reinterpret_cast<const pf32x4*>(sm + B_TR + 384 + tid * 4);
                 const long o = ((((long)(gi * 8 + (gj >> 2)) * 2 + (row >> 4)) * 4 + (gj & 3)) * 64 + gate * 16 + (row & 15)) * 4;
-                xstore(xr, (unsigned)((BO_DG1 + slot * BDG + o) * 4), val);
-                xstore(xr, (unsigned)((BO_DG1 + rslot * BDG + o) * 4), sentv());
+                xpublish_near(xr, (unsigned)((BO_DG1 + slot * BDG + o) * 4), val, gen, near);
             }
             if (elive) { float* o = d.dg1 + sB * 4 * PH; o[o4H] = dgv[0]; o[o4H + PH] = dgv[1]; o[o4H + 2 * PH] = dgv[2]; o[o4H + 3 * PH] = dgv[3]; }
         }
@@ -424,7 +417,8 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             unsigned off[8];                                                                                                         \
             _Pragma("unroll") for (int x = 0; x < 8; ++x)                                                                            \
                 off[x] = (unsigned)(((OFF_DG) + slot * BDG + ((((long)(gi * 8 + wave) * 2 + (x >> 2)) * 4 + (x & 3)) * 64 + lane) * 4) * 4); \
-            if (!gather<8>(xr, off, bq, d.ctrl)) PFAIL();                                                                            \
+            const unsigned g8[8] = {gen, gen, gen, gen, gen, gen, gen, gen};                                                         \
+            if (!gather<8>(xr, off, bq, d.ctrl, g8)) PFAIL();                                                                            \
         }
 #define PROD_HALF(half, WT, OFF_OUT, IS_CTX)                                                                                          \
         {                                                                                                                            \
@@ -449,13 +443,11 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 if (IS_CTX) {                                                                                                        \
                     if (blk < 6) {                                                                                                   \
                         const long o = (((long)row * 192 + 6 * gj + blk) * 8 + gi) * 4;                                              \
-                        xstore(xr, (unsigned)((BO_PCTX + slot * BPCTX + o) * 4), r);                                                 \
-                        xstore(xr, (unsigned)((BO_PCTX + rslot * BPCTX + o) * 4), sentv());                                          \
+                        xpublish(xr, (unsigned)((BO_PCTX + slot * BPCTX + o) * 4), r, gen);                                                 \
                     }                                                                                                                \
                 } else {                                                                                                             \
                     const long o = (((long)(8 * gj + blk) * 8 + gi) * 32 + row) * 4;                                                 \
-                    xstore(xr, (unsigned)(((OFF_OUT) + slot * BPART + o) * 4), r);                                                   \
-                    xstore(xr, (unsigned)(((OFF_OUT) + rslot * BPART + o) * 4), sentv());                                            \
+                    xpublish(xr, (unsigned)(((OFF_OUT) + slot * BPART + o) * 4), r, gen);                                                   \
                 }                                                                                                                    \
             }                                                                                                                        \
         }
@@ -481,7 +473,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         ISSUE_UPDATE0();
         if (tid < 256) {
             const int row = tid >> 3, src = tid & 7;
-            if (!complete<2>(xr, uoff, uv, d.ctrl)) PFAIL();
+            { const unsigned g2[2] = {gen, first ? gen : ngen}; if (!complete<2>(xr, uoff, uv, d.ctrl, g2)) PFAIL(); }
             if (first) uv[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -512,8 +504,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 const int gate = tid >> 5, row = tid & 31;
                 const pf32x4 val = *reinterpret_cast<const pf32x4*>(sm + B_TR + 384 + tid * 4);
                 const long o = ((((long)(gi * 8 + (gj >> 2)) * 2 + (row >> 4)) * 4 + (gj & 3)) * 64 + gate * 16 + (row & 15)) * 4;
-                xstore(xr, (unsigned)((BO_DG0 + slot * BDG + o) * 4), val);
-                xstore(xr, (unsigned)((BO_DG0 + rslot * BDG + o) * 4), sentv());
+                xpublish_near(xr, (unsigned)((BO_DG0 + slot * BDG + o) * 4), val, gen, near);
             }
             if (elive) { float* o = d.dg0 + sB * 4 * PH; o[o4H] = dgv[0]; o[o4H + PH] = dgv[1]; o[o4H + 2 * PH] = dgv[2]; o[o4H + 3 * PH] = dgv[3]; }
         }
@@ -635,7 +626,7 @@ extern "C" int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_
     MSTTS_REQUIRE(aligned16(p->xch) && aligned16(bd->d_in0) && (M + H) % 4 == 0, MSTTS_ERR_ALIGN, "decoder_train_bwd_persistent: 16-byte alignment");
     hipStream_t hs = (hipStream_t)s;
     hipError_t e = hipMemsetAsync(p->xch, 0xFF, BXCH_FLOATS * 4, hs);
-    if (e == hipSuccess) e = hipMemsetAsync(p->ctrl, 0, 16 * sizeof(unsigned), hs);
+    if (e == hipSuccess) e = hipMemsetAsync(p->ctrl, 0, PCTRL_WORDS * sizeof(unsigned), hs);
     if (e != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "decoder_train_bwd_persistent: memset: %s", hipGetErrorString(e));
     PersistBwd a;
     a.w1t = p->w1pk; a.w0t = p->w0pk; a.wqt = p->wqpk;
@@ -646,7 +637,7 @@ extern "C" int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_
     a.loc_k = d->lsa.loc_k; a.loc_b = d->lsa.loc_b; a.score_w = d->lsa.score_w; a.score_b = d->lsa.score_b;
     a.d_pj = bd->d_pj; a.B = (int)B; a.S = (int)S; a.T = (int)T;
     a.dg0 = bd->dg0; a.dg1 = bd->dg1; a.dq_hist = bd->dq_hist; a.de_hist = bd->de_hist; a.d_in0 = bd->d_in0;
-    a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1;
+    a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
     const size_t lds = (size_t)B_FLOATS * 4;
     if (p->stamps) hipLaunchKernelGGL(persist_bwd_kernel<true>, dim3(PWG), dim3(PTH), lds, hs, a);
     else hipLaunchKernelGGL(persist_bwd_kernel<false>, dim3(PWG), dim3(PTH), lds, hs, a);

@@ -1,7 +1,11 @@
 // Shared pieces of the two persistent decoder kernels (persist.hip: forward loop, persist_bwd.hip: BPTT): the hand-off primitives.
-// THE DATA IS THE FLAG: every ring slot is pre-filled with the bit pattern 0xFFFFFFFF (a NaN no arithmetic here produces); a consumer
-// polls its piece with L1-bypassing (sc1) loads until no word reads as that pattern; producers store write-through (sc1) and re-arm a
-// slot two steps ahead of its next use.
+// THE DATA IS THE FLAG: every word that crosses a ring carries the GENERATION of its ring slot in the lowest bit of its mantissa (a ring
+// of 4 slots: step k uses slot k & 3, generation (k >> 2) & 1; the rings are pre-filled with all-ones words = "generation 1" before the
+// launch, the first pass over the ring is generation 0).  A producer stores its values write-through (sc1) with that bit forced; a
+// consumer polls its piece with L1-bypassing (sc1) loads until every word shows the generation it expects - what it last saw in that
+// slot, four steps ago, carries the opposite bit.  No flag, no counter, no fence, and no second store to re-arm a slot (the first
+// form of these kernels re-armed with a NaN pattern: half of the write-through traffic).  The price is the value's last bit: 2^-24
+// relative on exchanged copies only (what BPTT reads back is stored exactly), deterministic.
 #pragma once
 #include "common.h"
 
@@ -16,8 +20,14 @@ constexpr int PRING = 4;
 constexpr unsigned PSENT = 0xFFFFFFFFu;
 constexpr unsigned long long PERSIST_TIMEOUT_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock per wait
 
-__device__ __forceinline__ bool has_sent(const pf32x4& v) {
-    return (__float_as_uint(v[0]) == PSENT) | (__float_as_uint(v[1]) == PSENT) | (__float_as_uint(v[2]) == PSENT) | (__float_as_uint(v[3]) == PSENT);
+// true while any word of the piece still shows the other generation
+__device__ __forceinline__ bool stale(const pf32x4& v, unsigned gen) {
+    return (((__float_as_uint(v[0]) ^ gen) | (__float_as_uint(v[1]) ^ gen) | (__float_as_uint(v[2]) ^ gen) | (__float_as_uint(v[3]) ^ gen)) & 1u) != 0u;
+}
+__device__ __forceinline__ pf32x4 tagv(pf32x4 v, unsigned gen) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __uint_as_float((__float_as_uint(v[e]) & ~1u) | gen);
+    return v;
 }
 __device__ __forceinline__ pf32x4 xload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(pf32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));       // aux 16 = sc1
@@ -25,13 +35,44 @@ __device__ __forceinline__ pf32x4 xload(__amdgpu_buffer_rsrc_t r, unsigned byte_
 __device__ __forceinline__ void xstore(__amdgpu_buffer_rsrc_t r, unsigned byte_off, pf32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pi32x4, v), r, (int)byte_off, 0, 16);
 }
-__device__ __forceinline__ pf32x4 sentv() { const float s = __uint_as_float(PSENT); return (pf32x4){s, s, s, s}; }
+// publish: the value with its slot's generation in the last bit, write-through
+__device__ __forceinline__ void xpublish(__amdgpu_buffer_rsrc_t r, unsigned byte_off, pf32x4 v, unsigned gen) { xstore(r, byte_off, tagv(v, gen)); }
+// ... or, when EVERY consumer of the piece sits on the producer's XCD (`local`, established at the start rendezvous from the hardware's
+// XCC ids - never assumed from block ids), with a plain store: the line stays in that XCD's L2, where the consumers' L1-bypassing polls
+// find it without the trip to the memory side.  Correctness does not depend on the placement: a group whose members report different
+// XCC ids publishes write-through.
+__device__ __forceinline__ void xpublish_near(__amdgpu_buffer_rsrc_t r, unsigned byte_off, pf32x4 v, unsigned gen, bool local) {
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pi32x4, tagv(v, gen)), r, (int)byte_off, 0, 0);
+    else xstore(r, byte_off, tagv(v, gen));
+}
+// XCC id of the CU this wave runs on (HW_REG_XCC_ID, bits 3:0) + 1
+__device__ __forceinline__ unsigned xcc_id_plus1() { return (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) + 1u; }
+constexpr int PCTRL_WORDS = 16 + 256;            // control words: arrivals, abort code, finished count, ...; then one XCC id per workgroup
+// Start rendezvous of the 256 workgroups (thread 0 of each): records the XCC id, arrives, waits for the others (bounded).  Returns 0 on
+// time-out / abort, 1 when resident, 2 when in addition the 32 workgroups that share this workgroup's slice index (id & 7) all sit on its XCD.
+__device__ __forceinline__ int persist_rendezvous(unsigned* ctrl, int g) {
+    const unsigned me = xcc_id_plus1();
+    __hip_atomic_store(ctrl + 16 + g, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PWG) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0;
+        }
+    }
+    bool same = true;
+    for (int j = 0; j < 32; ++j) same = same && (__hip_atomic_load(ctrl + 16 + (g & 7) + 8 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == me);
+    return same ? 2 : 1;
+}
 
-// Polls N 16-byte pieces per lane until none holds the sentinel.  Returns false on time-out / abort (wave-uniform).
+// Polls N 16-byte pieces per lane until each shows its generation gen[m].  Returns false on time-out / abort (wave-uniform).
 // (The empty asm with a memory clobber is what makes this a poll: the buffer-load builtin is a plain read to the compiler, which
 //  otherwise proves the re-load redundant and deletes the whole loop.)
 template <int N>
-__device__ __forceinline__ bool gather(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N], const unsigned* ctrl) {
+__device__ __forceinline__ bool gather(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N], const unsigned* ctrl, const unsigned (&gen)[N]) {
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int m = 0; m < N; ++m) v[m] = xload(r, off[m]);
@@ -41,7 +82,7 @@ __device__ __forceinline__ bool gather(__amdgpu_buffer_rsrc_t r, const unsigned 
         asm volatile("" ::: "memory");
         bool miss = false;
 #pragma unroll
-        for (int m = 0; m < N; ++m) miss |= has_sent(v[m]);
+        for (int m = 0; m < N; ++m) miss |= stale(v[m], gen[m]);
         if (!__builtin_amdgcn_ballot_w64(miss)) return true;
         if ((++spins & 15u) == 0) {
             const unsigned long long now = wall_clock64();
@@ -50,7 +91,7 @@ __device__ __forceinline__ bool gather(__amdgpu_buffer_rsrc_t r, const unsigned 
         }
 #pragma unroll
         for (int m = 0; m < N; ++m)
-            if (has_sent(v[m])) v[m] = xload(r, off[m]);
+            if (stale(v[m], gen[m])) v[m] = xload(r, off[m]);
     }
 }
 
@@ -65,14 +106,14 @@ __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t r, const unsigned (
     __builtin_amdgcn_sched_barrier(0);               // below the work they are meant to run under
 }
 template <int N>
-__device__ __forceinline__ bool complete(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N], const unsigned* ctrl) {
+__device__ __forceinline__ bool complete(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], pf32x4 (&v)[N], const unsigned* ctrl, const unsigned (&gen)[N]) {
     unsigned spins = 0;
     unsigned long long t0 = 0;
     for (;;) {
         asm volatile("" ::: "memory");
         bool miss = false;
 #pragma unroll
-        for (int m = 0; m < N; ++m) miss |= has_sent(v[m]);
+        for (int m = 0; m < N; ++m) miss |= stale(v[m], gen[m]);
         if (!__builtin_amdgcn_ballot_w64(miss)) return true;
         if ((++spins & 15u) == 0) {
             const unsigned long long now = wall_clock64();
@@ -81,7 +122,7 @@ __device__ __forceinline__ bool complete(__amdgpu_buffer_rsrc_t r, const unsigne
         }
 #pragma unroll
         for (int m = 0; m < N; ++m)
-            if (has_sent(v[m])) v[m] = xload(r, off[m]);
+            if (stale(v[m], gen[m])) v[m] = xload(r, off[m]);
     }
 }
 

@@ -256,14 +256,14 @@ class TrainEngine:
         w.persist = self.persist and bool(lb.mstts_persist_fwd_supported(B, H, M, A, Te, d.att_k))
         if w.persist:
             w.xch = f(int(lb.mstts_persist_fwd_ws_bytes()) // 4)
-            w.pctrl = torch.zeros(16, dtype=torch.int32, device=self.device)
-            w.pctrl_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.pctrl = torch.zeros(272, dtype=torch.int32, device=self.device)
+            w.pctrl_host = torch.zeros(272, dtype=torch.int32).pin_memory()
             w.pdesc = lib.PersistDesc()
         w.persist_bwd = w.persist and self.persist_bwd and bool(lb.mstts_persist_bwd_supported(B, H, M, A, Te, d.att_k))
         if w.persist_bwd:
             w.xch_b = f(int(lb.mstts_persist_bwd_ws_bytes()) // 4)
-            w.pctrl_b = torch.zeros(16, dtype=torch.int32, device=self.device)
-            w.pctrl_b_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.pctrl_b = torch.zeros(272, dtype=torch.int32, device=self.device)
+            w.pctrl_b_host = torch.zeros(272, dtype=torch.int32).pin_memory()
             w.pdesc_b = lib.PersistDesc()
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
@@ -442,6 +442,7 @@ class TrainEngine:
             pd.w0pk, pd.w1pk, pd.wqpk, pd.xch, pd.ctrl = ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]), ptr(w.xch), ptr(w.pctrl)
             pd.stamps = ptr(self.persist_stamps) if self.persist_stamps is not None else None
             pd.selftest_fail_step = int(self.persist_selftest)
+            pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "0") == "1")
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
             ev.record()
@@ -571,6 +572,7 @@ class TrainEngine:
             pb.w0pk, pb.w1pk, pb.wqpk, pb.xch, pb.ctrl = ptr(self.pkb[0]), ptr(self.pkb[1]), ptr(self.pkb[2]), ptr(w.xch_b), ptr(w.pctrl_b)
             pb.stamps = ptr(self.persist_bwd_stamps) if self.persist_bwd_stamps is not None else None
             pb.selftest_fail_step = int(self.persist_selftest)
+            pb.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "0") == "1")
             call("mstts_decoder_train_bwd_persistent", C.byref(db), C.byref(pb))
             ev = torch.cuda.Event()
             ev.record()

@@ -7,7 +7,7 @@
 #   4. Audio.melspectrogram timing + its kernel rows
 #   5. free-running decoder (tools/infer_bench.py) timing + its kernel rows
 # Outputs land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

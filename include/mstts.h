@@ -560,7 +560,9 @@ typedef struct {
     const float* w0pk; const float* w1pk; const float* wqpk;
     float* xch; uint32_t* ctrl; uint64_t* stamps;
     int32_t selftest_fail_step;   /* 0 in production; k > 0: workgroup 0 raises the abort word at step k - 1 (exercises the fallback) */
-    int32_t near_xcd;             /* experimental, 0 = off: hand-offs whose producer and consumers report one XCC id stay in that XCD's L2 */
+    int32_t near_xcd;             /* != 0: hand-offs whose producer and all consumers report the same hardware XCC id at the start rendezvous are
+                                     published with plain stores and stay in that XCD's L2 (-3 ms per step); every launch first drops its
+                                     XCDs' copies of those rings.  0: every hand-off write-through (placement never matters for correctness) */
 } mstts_persist_desc;
 int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
 int64_t mstts_persist_fwd_ws_bytes(void);

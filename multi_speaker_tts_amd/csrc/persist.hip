@@ -123,6 +123,8 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     float* stg = sm + S_STG;
 
     // ---------------- start rendezvous: all 256 workgroups must be resident before anyone waits for data
+    if (d.near_xcd) persist_scrub(xr, OFF_CTX, OFF_M1 - OFF_CTX, g0, tid);      // context, m0, h0, h1 rings: the ones a slice group may keep in its L2
+    __syncthreads();
     if (tid == 0) {
         const int rz = persist_rendezvous(d.ctrl, g0);
         sflag[0] = rz == 0 ? 1u : 0u;

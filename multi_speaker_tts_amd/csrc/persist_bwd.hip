@@ -93,6 +93,8 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     unsigned* sflag = reinterpret_cast<unsigned*>(sm + B_FLAG);
 
     // ---------------- start rendezvous
+    if (d.near_xcd) persist_scrub(xr, BO_DG1, BO_PM0 - BO_DG1, g0, tid);        // the two gate-gradient rings: the ones a slice group may keep in its L2
+    __syncthreads();
     if (tid == 0) {
         const int rz = persist_rendezvous(d.ctrl, g0);
         sflag[0] = rz == 0 ? 1u : 0u;

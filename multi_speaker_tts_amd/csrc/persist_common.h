@@ -45,6 +45,18 @@ __device__ __forceinline__ void xpublish_near(__amdgpu_buffer_rsrc_t r, unsigned
     if (local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pi32x4, tagv(v, gen)), r, (int)byte_off, 0, 0);
     else xstore(r, byte_off, tagv(v, gen));
 }
+// Before a launch that may publish through an L2 (near_xcd): every workgroup drops its XCD's copies of the rings concerned, by storing
+// the rings' idle pattern (all ones, what the host's memset left in memory) write-through over 1/32 of them - sc1 stores do not leave
+// the line in the issuing XCD's L2.  The 32 workgroups of a slice group that shares one XCD (the only groups that publish near) cover
+// the whole region, so no line a previous launch parked in that L2 can be mistaken for fresh data, whatever the hardware does with L2
+// contents between launches.  Call before the start rendezvous.
+__device__ __forceinline__ void persist_scrub(__amdgpu_buffer_rsrc_t r, long float_off, long floats, int g, int tid) {
+    const long per = floats / 32;                                    // (region sizes are multiples of 32 * 4 floats)
+    const unsigned base = (unsigned)((float_off + (long)(g >> 3) * per) * 4);
+    const pf32x4 ones = {__uint_as_float(PSENT), __uint_as_float(PSENT), __uint_as_float(PSENT), __uint_as_float(PSENT)};
+    for (long x = tid; x < per / 4; x += PTH) xstore(r, base + (unsigned)(16 * x), ones);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // XCC id of the CU this wave runs on (HW_REG_XCC_ID, bits 3:0) + 1
 __device__ __forceinline__ unsigned xcc_id_plus1() { return (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) + 1u; }
 constexpr int PCTRL_WORDS = 16 + 256;            // control words: arrivals, abort code, finished count, ...; then one XCC id per workgroup

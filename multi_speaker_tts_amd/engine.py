@@ -442,7 +442,7 @@ class TrainEngine:
             pd.w0pk, pd.w1pk, pd.wqpk, pd.xch, pd.ctrl = ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]), ptr(w.xch), ptr(w.pctrl)
             pd.stamps = ptr(self.persist_stamps) if self.persist_stamps is not None else None
             pd.selftest_fail_step = int(self.persist_selftest)
-            pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "0") == "1")
+            pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
             ev.record()
@@ -572,7 +572,7 @@ class TrainEngine:
             pb.w0pk, pb.w1pk, pb.wqpk, pb.xch, pb.ctrl = ptr(self.pkb[0]), ptr(self.pkb[1]), ptr(self.pkb[2]), ptr(w.xch_b), ptr(w.pctrl_b)
             pb.stamps = ptr(self.persist_bwd_stamps) if self.persist_bwd_stamps is not None else None
             pb.selftest_fail_step = int(self.persist_selftest)
-            pb.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "0") == "1")
+            pb.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             call("mstts_decoder_train_bwd_persistent", C.byref(db), C.byref(pb))
             ev = torch.cuda.Event()
             ev.record()

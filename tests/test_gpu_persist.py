@@ -208,3 +208,46 @@ def test_persistent_bptt_is_deterministic_and_falls_back(dev):
     eng.persist_selftest = 0
     assert eng.persist_bwd_fallbacks == 1 and eng.persist_last_status[1] == 3
     assert rel_err(t2n(eng.params.grad), ref) < 5e-5
+
+
+def test_persistent_launches_back_to_back_on_changed_inputs(dev):
+    """Two persistent launches in direct succession on the SAME buffers with DIFFERENT data (nothing in between but one small
+    elementwise kernel): whatever the first launch left in the hand-off rings - in memory or in an XCD's L2 (the same-XCD publish path
+    keeps pieces there) - must not be taken for data of the second.  Forward: the hoisted prenet product halved in place; BPTT: the
+    projection's input gradient halved in place; each second launch against the launch-per-step loop on the same changed inputs."""
+    import ctypes as C
+    from multi_speaker_tts_amd import lib
+    eng, od = _engine(dev)
+    B, Te, L = 32, 128, 24
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=13, ragged=True), dev)
+    w = eng.plan(B, Te, L)
+    eng.forward(batch, w, seed=5)                         # launch A (inside), on the original inputs
+    w.xw0.mul_(0.5)
+    lib.call("mstts_decoder_train_fwd_persistent", C.byref(w.dec), C.byref(w.pdesc))        # launch B, directly behind
+    torch.cuda.synchronize()
+    st = w.pctrl.cpu().numpy()
+    assert st[1] == 0 and st[2] == 256, st[:4]
+    near_groups = int(st[3])
+    a = {k: t2n(getattr(w, k)).copy() for k in HIST}
+    lib.call("mstts_decoder_train_fwd", C.byref(w.dec))
+    torch.cuda.synchronize()
+    bad = {k: rel_err(a[k], t2n(getattr(w, k))) for k in HIST}
+    bad = {k: v for k, v in bad.items() if v > 1e-4}
+    assert not bad, (bad, near_groups)
+    if not getattr(w, "persist_bwd", False):
+        return
+    eng._forward_tail(w)
+    eng.loss_and_backward(w)                              # BPTT launch A
+    w.d_pj.mul_(0.5)
+    lib.call("mstts_decoder_train_bwd_persistent", C.byref(w.dec_b), C.byref(w.pdesc_b))     # launch B
+    torch.cuda.synchronize()
+    st = w.pctrl_b.cpu().numpy()
+    assert st[1] == 0 and st[2] == 256, st[:4]
+    a = {k: t2n(getattr(w, k)).copy() for k in BWD}
+    w.dq_hist.zero_()
+    lib.call("mstts_decoder_train_bwd", C.byref(w.dec_b))
+    torch.cuda.synchronize()
+    bad = {k: rel_err(a[k], t2n(getattr(w, k))) for k in BWD}
+    bad = {k: v for k, v in bad.items() if v > 5e-4}
+    assert not bad, bad
+    print("slice groups publishing through their XCD's L2: %d of 8" % near_groups)

@@ -559,6 +559,9 @@ int mstts_decoder_train_fwd(const mstts_decoder_train_desc* d, mstts_stream_t s)
 typedef struct {
     const float* w0pk; const float* w1pk; const float* wqpk;
     float* xch; uint32_t* ctrl; uint64_t* stamps;
+    float* opk;                   /* packed operands of the BPTT's cell updates, mstts_persist_opk_floats(S) floats: written by the persistent forward
+                                     INSTEAD of the row-major histories acts0/1, craw0/1, c0/1 (NULL: those are written), read by the persistent
+                                     BPTT (required there).  mstts_persist_unpack_history() converts for mstts_decoder_train_bwd. */
     int32_t selftest_fail_step;   /* 0 in production; k > 0: workgroup 0 raises the abort word at step k - 1 (exercises the fallback) */
     int32_t near_xcd;             /* != 0: hand-offs whose producer and all consumers report the same hardware XCC id at the start rendezvous are
                                      published with plain stores and stay in that XCD's L2 (-3 ms per step); every launch first drops its
@@ -569,6 +572,8 @@ int64_t mstts_persist_fwd_ws_bytes(void);
 int64_t mstts_persist_pack_floats(int32_t which);
 int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s);
 int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc* d, const mstts_persist_desc* p, mstts_stream_t s);
+int64_t mstts_persist_opk_floats(int64_t S);
+int mstts_persist_unpack_history(const float* opk, const mstts_decoder_train_desc* d, mstts_stream_t s);
 
 /* BPTT through the same S steps.  d_pj [S,B,H+M] holds the projection's input gradient on entry
  * (d_m1 | d_ctx) and is updated in place.  Outputs for the hoisted gradient GEMMs:

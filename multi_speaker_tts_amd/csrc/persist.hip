@@ -52,6 +52,7 @@ struct PersistFwd {
     int B, S, T;
     float* in0; float* in1; float* pj; float* c0; float* c1; float* acts0; float* acts1; float* craw0; float* craw1;
     float* q_hist; float* align_hist; float* cum_hist;
+    float* opk;                                  // packed BPTT operands (persist_common.h), or null: the standard histories acts / craw / c are written instead
     float* xch; unsigned* ctrl;                  // ctrl[0] arrivals, ctrl[1] abort code, ctrl[2] workgroups that finished all S steps
     unsigned long long* stamps;                  // PROF: [256][NSTAMP] summed interval ticks
     int fail_step; int near_xcd;                               // self-test: workgroup 0 raises the abort word at this step (-1 = never)
@@ -170,6 +171,10 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqpk) + (long)gi * 8 * 512;      // query kernel slice: [8][512 threads] float4
         for (int x = tid; x < 8 * 512; x += PTH) reinterpret_cast<pf32x4*>(sm + S_WQ)[x] = wqs[x];
     }
+    float lkb[8];                                                // filter slice as MFMA B operand: lk[4 ks + (lane >> 4)][unit lane & 15]; tap 31 is zero
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) lkb[ks] = sm[S_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)];
     // cell-update role (waves 0, 1): row er, hidden unit eu = 4 g + (lane >> 4); the states stay in registers for all S steps
     int et = wave & 1, er = 16 * et + (lane & 15), ee = lane >> 4, eu = 4 * g + ee;
     bool ew = wave < 2, elive = ew && er < B;
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             float add0[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) add0[q] = rowok ? xwv[q] : 0.f;
+            const float cprev0 = c0s;
             const CellOut o = cell_update(gs, add0, c0s, h0s, (zc0v || !rowok) ? d.keep : 0.f, (zh0v || !rowok) ? d.keep : 0.f);
             if (ew) {
                 sm[S_TR + er * 4 + ee] = o.m;
@@ -290,10 +296,18 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 const long o2 = gi * 4096L + rho * 32 + 4 * (gj >> 2);
                 xpublish_near(xr, (unsigned)((base + slot * XACT + o2) * 4), val, gen, near);
             }
-            if (elive) {            // what BPTT reads, behind the hand-off stores (ahead of them they delayed the publication by their issue time)
-                float* a = d.acts0 + sB * 4 * PH; a[o4H] = o.si; a[o4H + PH] = o.tj; a[o4H + 2 * PH] = o.sf; a[o4H + 3 * PH] = o.so;
-                (d.craw0 + sB * PH)[oH] = o.c;
-                (d.c0 + sB1 * PH)[oH] = c0s;
+            // what BPTT reads, behind the hand-off stores (ahead of them they delayed the publication by their issue time)
+            if (ew && d.opk) {      // the cell-update operands as ONE contiguous block per workgroup, step and cell: 2 KB instead of 6 row-strided stores
+                pf32x4* ob = reinterpret_cast<pf32x4*>(d.opk) + opk_index(s, g, 0, 0, tid);
+                ob[0] = (pf32x4){o.si, o.tj, o.sf, o.so};
+                ob[128] = (pf32x4){o.c, cprev0, __uint_as_float((zc0v ? 1u : 0u) | (zh0v ? 2u : 0u)), 0.f};
+            }
+            if (elive) {
+                if (!d.opk) {
+                    float* a = d.acts0 + sB * 4 * PH; a[o4H] = o.si; a[o4H + PH] = o.tj; a[o4H + 2 * PH] = o.sf; a[o4H + 3 * PH] = o.so;
+                    (d.craw0 + sB * PH)[oH] = o.c;
+                    (d.c0 + sB1 * PH)[oH] = c0s;
+                }
                 (d.in1 + sB * 2 * PH)[(unsigned)er * 2 * PH + eu] = o.m;
                 (d.in0 + sB1 * (PM + PH))[(unsigned)er * (PM + PH) + PM + eu] = h0s;
             }
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         PSTAMP(8);
         {
             const pf32x4 gs = SUM_PARTIALS();
+            const float cprev1 = c1s;
             const CellOut o = cell_update(gs, b1v, c1s, h1s, (zc1v || !rowok) ? d.keep : 0.f, (zh1v || !rowok) ? d.keep : 0.f);
             if (ew) {
                 sm[S_TR + er * 4 + ee] = o.m;
@@ -339,10 +354,17 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                     xpublish_near(xr, (unsigned)((OFF_H1 + slot * XACT + o2) * 4), val, gen, near);
                 }
             }
+            if (ew && d.opk) {
+                pf32x4* ob = reinterpret_cast<pf32x4*>(d.opk) + opk_index(s, g, 1, 0, tid);
+                ob[0] = (pf32x4){o.si, o.tj, o.sf, o.so};
+                ob[128] = (pf32x4){o.c, cprev1, __uint_as_float((zc1v ? 1u : 0u) | (zh1v ? 2u : 0u)), 0.f};
+            }
             if (elive) {
-                float* a = d.acts1 + sB * 4 * PH; a[o4H] = o.si; a[o4H + PH] = o.tj; a[o4H + 2 * PH] = o.sf; a[o4H + 3 * PH] = o.so;
-                (d.craw1 + sB * PH)[oH] = o.c;
-                (d.c1 + sB1 * PH)[oH] = c1s;
+                if (!d.opk) {
+                    float* a = d.acts1 + sB * 4 * PH; a[o4H] = o.si; a[o4H + PH] = o.tj; a[o4H + 2 * PH] = o.sf; a[o4H + 3 * PH] = o.so;
+                    (d.craw1 + sB * PH)[oH] = o.c;
+                    (d.c1 + sB1 * PH)[oH] = c1s;
+                }
                 (d.pj + sB * (PH + PM))[(unsigned)er * (PH + PM) + eu] = o.m;
                 (d.in1 + sB1 * 2 * PH)[(unsigned)er * 2 * PH + PH + eu] = h1s;
             }
@@ -382,17 +404,17 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             __syncthreads();
             {
                 const float qk = sm[S_QF + ak] + asb;
+                // location filter over the cumulative alignment as a Toeplitz product on the matrix core: loc[t][k] = sum_j cum[t + j - 15] lk[j][k]
+                // = A . B with A[t][j] = cum window (one LDS word per lane and k-step), B[j][k] = the filter slice (8 registers, loaded once);
+                // wave w takes positions 16 w .. 16 w + 15, and the D layout (position 4 (lane >> 4) + r, unit lane & 15) is exactly this
+                // thread's four positions - 8 MFMAs replace 62 LDS reads + 124 FMAs per thread
+                pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    loc = PMFMA(sm[S_CUM + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], loc);
                 float pre[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk;
-                // location filter over the cumulative alignment: a rolling 4-position window, one new value per tap
-                float w0 = sm[S_CUM + 4 * atg], w1 = sm[S_CUM + 4 * atg + 1], w2 = sm[S_CUM + 4 * atg + 2], w3 = sm[S_CUM + 4 * atg + 3];
-#pragma unroll 8
-                for (int jj = 0; jj < PKS; ++jj) {
-                    const float lk = sm[S_LK + jj * 16 + ak];
-                    pre[0] += w0 * lk; pre[1] += w1 * lk; pre[2] += w2 * lk; pre[3] += w3 * lk;
-                    w0 = w1; w1 = w2; w2 = w3; w3 = sm[S_CUM + 4 * atg + jj + 4];
-                }
+                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk + loc[m];
                 pf32x4 e4;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -593,7 +615,7 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
     a.B = (int)B; a.S = (int)S; a.T = (int)T;
     a.in0 = d->in0; a.in1 = d->in1; a.pj = d->pj; a.c0 = d->c0; a.c1 = d->c1; a.acts0 = d->acts0; a.acts1 = d->acts1;
     a.craw0 = d->craw0; a.craw1 = d->craw1; a.q_hist = d->q_hist; a.align_hist = d->align_hist; a.cum_hist = d->cum_hist;
-    a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
+    a.opk = p->opk; a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
     const size_t lds = (size_t)S_FLOATS * 4;
     if (p->stamps) hipLaunchKernelGGL(persist_fwd_kernel<true>, dim3(PWG), dim3(PTH), lds, hs, a);
     else hipLaunchKernelGGL(persist_fwd_kernel<false>, dim3(PWG), dim3(PTH), lds, hs, a);

@@ -59,6 +59,7 @@ struct PersistBwd {
     const float* keys; const float* values; const int32_t* lengths;
     const float* loc_k; const float* loc_b; const float* score_w; const float* score_b;
     const float* d_pj;
+    const float* opk;                            // packed cell-update operands written by the persistent forward (persist_common.h)
     int B, S, T;
     float* dg0; float* dg1; float* dq_hist; float* de_hist; float* d_in0;
     float* xch; unsigned* ctrl; unsigned long long* stamps; int fail_step; int near_xcd;
@@ -165,11 +166,12 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     float a1v[4], cr1, cp1, dpm1;
     uint8_t zc1v, zh1v;
 #define LOAD_OPERANDS1(ST) do { const long b__ = (long)(ST) * B; const unsigned r__ = (16 * (wave0 & 1) + (tid0 & 15)) < (unsigned)B ? 16 * (wave0 & 1) + (tid0 & 15) : 0u; \
-        /* (waves 2..7 only repeat the update: their lanes all read ONE address, a single cache-line request instead of 16 scattered ones) */ \
-        const unsigned u__ = 4 * g0 + ((tid0 & 63) >> 4), h__ = wave0 < 2 ? r__ * PH + u__ : 0u, q__ = wave0 < 2 ? r__ * 4 * PH + u__ : 0u;                                     \
-        const float* a__ = d.acts1 + b__ * 4 * PH;                                                                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) a1v[q] = a__[q__ + q * PH];                                                            \
-        cr1 = (d.craw1 + b__ * PH)[h__]; cp1 = (d.c1 + b__ * PH)[h__]; zc1v = (d.zc1 + b__ * PH)[h__]; zh1v = (d.zh1 + b__ * PH)[h__];       \
+        const unsigned u__ = 4 * g0 + ((tid0 & 63) >> 4);                                                                                   \
+        /* (waves 2..7 only repeat the update: they read what wave 0 / 1 read - tid0 & 127 - from the packed block) */                      \
+        const pf32x4* ob__ = reinterpret_cast<const pf32x4*>(d.opk) + opk_index((ST), g0, 1, 0, tid0 & 127);                                \
+        const pf32x4 A__ = ob__[0], B__ = ob__[128];                                                                                        \
+        a1v[0] = A__[0]; a1v[1] = A__[1]; a1v[2] = A__[2]; a1v[3] = A__[3]; cr1 = B__[0]; cp1 = B__[1];                                      \
+        zc1v = (uint8_t)(__float_as_uint(B__[2]) & 1u); zh1v = (uint8_t)((__float_as_uint(B__[2]) >> 1) & 1u);                               \
         dpm1 = (d.d_pj + b__ * (PH + PM))[wave0 < 2 ? r__ * (PH + PM) + u__ : 0u]; } while (0)
     LOAD_OPERANDS1(S - 1);
     LOAD_ROWS(S - 1);
@@ -222,16 +224,14 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             // tanh terms of this slice (independent of everything that arrives): fac = w_k (1 - tanh^2(keys + q + location filter))
             {
                 const float qk = sm[B_QF + ak] + asb;
+                // location filter as a Toeplitz product on the matrix core (see persist.hip): A = the cumulative-alignment window, B = the filter slice
+                pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    loc = PMFMA(sm[B_CUM + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], sm[B_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)], loc);
                 float pre[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk;
-                float w0 = sm[B_CUM + 4 * atg], w1 = sm[B_CUM + 4 * atg + 1], w2 = sm[B_CUM + 4 * atg + 2], w3 = sm[B_CUM + 4 * atg + 3];
-#pragma unroll 4
-                for (int jj = 0; jj < PKS; ++jj) {
-                    const float lk = sm[B_LK + jj * 16 + ak];
-                    pre[0] += w0 * lk; pre[1] += w1 * lk; pre[2] += w2 * lk; pre[3] += w3 * lk;
-                    w0 = w1; w1 = w2; w2 = w3; w3 = sm[B_CUM + 4 * atg + jj + 4];
-                }
+                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk + loc[m];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) { const float u = tanhf_(pre[m]); fac[m] = awk * (1.f - u * u); }
             }
@@ -460,12 +460,10 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             PROD_HALF(0, w1t, BO_PM0, false)
             PSTAMP(8);
             {   // operands of the cell-0 update backward: requested here, they arrive under the second half and the hand-off
-                const unsigned oHx = wave0 < 2 ? oH : 0u, o4Hx = wave0 < 2 ? o4H : 0u;         // (one address for the waves that only repeat the update)
-                const float* a = d.acts0 + sB * 4 * PH;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a0v[q] = a[o4Hx + q * PH];
-                cr0 = (d.craw0 + sB * PH)[oHx]; cp0 = (d.c0 + sB * PH)[oHx];
-                zc0v = (d.zc0 + sB * PH)[oHx]; zh0v = (d.zh0 + sB * PH)[oHx];
+                const pf32x4* ob = reinterpret_cast<const pf32x4*>(d.opk) + opk_index(s, g0, 0, 0, tid0 & 127);
+                const pf32x4 A_ = ob[0], B_ = ob[128];
+                a0v[0] = A_[0]; a0v[1] = A_[1]; a0v[2] = A_[2]; a0v[3] = A_[3]; cr0 = B_[0]; cp0 = B_[1];
+                zc0v = (uint8_t)(__float_as_uint(B_[2]) & 1u); zh0v = (uint8_t)((__float_as_uint(B_[2]) >> 1) & 1u);
             }
             PROD_HALF(1, w1t, BO_PH1, false)
         }
@@ -582,8 +580,36 @@ __global__ void persist_pack_wqt_kernel(const float* __restrict__ wq, float* __r
     wqt[p] = wq[(long)(4 * l + e) * PA + 16 * gi + 4 * k4 + kq];
 }
 
+// packed operand blocks -> the row-major histories mstts_decoder_train_bwd reads (fallback path; also what the tests compare)
+__global__ void persist_unpack_history_kernel(const float* __restrict__ opk, int S, int B, float* acts0, float* acts1, float* craw0, float* craw1,
+                                              float* c0, float* c1) {
+    const long n = (long)S * PWG * 2 * 128;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tid = (int)(i & 127), cell = (int)((i >> 7) & 1), g = (int)((i >> 8) & 255), s = (int)(i >> 16);
+        const int row = 16 * (tid >> 6) + (tid & 15), u = 4 * g + ((tid & 63) >> 4);
+        if (row >= B) continue;
+        const pf32x4* ob = reinterpret_cast<const pf32x4*>(opk) + opk_index(s, g, cell, 0, tid);
+        const pf32x4 A = ob[0], Bv = ob[128];
+        float* acts = (cell ? acts1 : acts0) + ((long)s * B + row) * 4 * PH + u;
+        acts[0] = A[0]; acts[PH] = A[1]; acts[2 * PH] = A[2]; acts[3 * PH] = A[3];
+        (cell ? craw1 : craw0)[((long)s * B + row) * PH + u] = Bv[0];
+        (cell ? c1 : c0)[((long)s * B + row) * PH + u] = Bv[1];                // the zoned state BEFORE step s = slot s of the [S + 1, B, H] history
+    }
+}
+
 }  // namespace mstts
 using namespace mstts;
+
+extern "C" int64_t mstts_persist_opk_floats(int64_t S) { return S * OPK_FLOATS_PER_STEP; }
+
+extern "C" int mstts_persist_unpack_history(const float* opk, const mstts_decoder_train_desc* d, mstts_stream_t s) {
+    MSTTS_REQUIRE(opk && d && d->acts0 && d->acts1 && d->craw0 && d->craw1 && d->c0 && d->c1 && d->H == PH && d->B >= 1 && d->B <= PROWS, MSTTS_ERR_SHAPE,
+                  "persist_unpack_history: null pointer or unsupported shape");
+    hipLaunchKernelGGL(persist_unpack_history_kernel, dim3(4096), dim3(256), 0, (hipStream_t)s, opk, (int)d->S, (int)d->B, d->acts0, d->acts1, d->craw0,
+                       d->craw1, d->c0, d->c1);
+    MSTTS_CHECK_LAUNCH("persist_unpack_history");
+    return MSTTS_OK;
+}
 
 extern "C" int64_t mstts_persist_bwd_ws_bytes(void) { return BXCH_FLOATS * 4; }
 extern "C" int64_t mstts_persist_bwd_pack_floats(int32_t which) { return which < 2 ? 256L * 8 * 64 * 64 : 8L * 16 * 256 * 4; }
@@ -623,7 +649,8 @@ extern "C" int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_
     MSTTS_REQUIRE(d->lsa.B == B && mstts_persist_bwd_supported(B, H, M, A, T, d->lsa.KS), MSTTS_ERR_SHAPE,
                   "decoder_train_bwd_persistent: shape or device not supported (see mstts_persist_bwd_supported)");
     MSTTS_REQUIRE(d->zc0 && d->zh0 && d->zc1 && d->zh1, MSTTS_ERR_SHAPE, "decoder_train_bwd_persistent: the four zoneout keep-masks are required");
-    MSTTS_REQUIRE(d->acts0 && d->acts1 && d->craw0 && d->craw1 && d->c0 && d->c1 && d->align_hist && d->cum_hist && d->q_hist && d->lsa.keys && d->lsa.values &&
+    MSTTS_REQUIRE(p->opk, MSTTS_ERR_SHAPE, "decoder_train_bwd_persistent: the packed operand blocks of the persistent forward (opk) are required");
+    MSTTS_REQUIRE(d->align_hist && d->cum_hist && d->q_hist && d->lsa.keys && d->lsa.values &&
                   d->lsa.loc_k && d->lsa.loc_b && d->lsa.score_w && d->lsa.score_b, MSTTS_ERR_SHAPE, "decoder_train_bwd_persistent: forward state missing");
     MSTTS_REQUIRE(aligned16(p->xch) && aligned16(bd->d_in0) && (M + H) % 4 == 0, MSTTS_ERR_ALIGN, "decoder_train_bwd_persistent: 16-byte alignment");
     hipStream_t hs = (hipStream_t)s;
@@ -637,7 +664,7 @@ extern "C" int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_
     a.align_hist = d->align_hist; a.cum_hist = d->cum_hist; a.q_hist = d->q_hist;
     a.keys = d->lsa.keys; a.values = d->lsa.values; a.lengths = d->lsa.lengths;
     a.loc_k = d->lsa.loc_k; a.loc_b = d->lsa.loc_b; a.score_w = d->lsa.score_w; a.score_b = d->lsa.score_b;
-    a.d_pj = bd->d_pj; a.B = (int)B; a.S = (int)S; a.T = (int)T;
+    a.d_pj = bd->d_pj; a.opk = p->opk; a.B = (int)B; a.S = (int)S; a.T = (int)T;
     a.dg0 = bd->dg0; a.dg1 = bd->dg1; a.dq_hist = bd->dq_hist; a.de_hist = bd->de_hist; a.d_in0 = bd->d_in0;
     a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
     const size_t lds = (size_t)B_FLOATS * 4;

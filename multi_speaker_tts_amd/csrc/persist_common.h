@@ -138,6 +138,14 @@ __device__ __forceinline__ bool complete(__amdgpu_buffer_rsrc_t r, const unsigne
     }
 }
 
+// Packed operands of the BPTT's cell updates, written by the forward loop's cell updates: float4 index of (step, workgroup, cell, half,
+// owner thread) - the owner thread tid < 128 is (row 16 (tid >> 6) + (tid & 15), unit 4 g + ((tid & 63) >> 4)); half 0 = the gate
+// activations (i, j, f, o), half 1 = (raw cell state, previous zoned cell state, keep-mask bits zc | zh << 1, -).  One workgroup's block
+// of a step and cell is 4 KB contiguous: the row-major histories [S, B, 4H] / [S, B, H] cost the owner of 4 units x 32 rows sixteen
+// row-strided accesses per step and direction, each touching 16 pages.
+__device__ __forceinline__ long opk_index(int s, int g, int cell, int half, int tid) { return ((((long)s * PWG + g) * 2 + cell) * 2 + half) * 128 + tid; }
+constexpr long OPK_FLOATS_PER_STEP = (long)PWG * 2 * 2 * 128 * 4;
+
 #define PMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 }  // namespace mstts

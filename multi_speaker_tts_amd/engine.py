@@ -104,7 +104,8 @@ class TrainEngine:
         self.persist = (os.environ.get("MSTTS_PERSIST", "1") != "0" and (recurrent_dtype or "f32").lower() == "f32"
                         and bool(lb.mstts_persist_fwd_supported(1, H, M, d.att, 1, d.att_k)))
         self.persist_fallbacks = 0           # sequences that had to be re-run on the launch-per-step path
-        self.persist_selftest = 0            # tests: k > 0 makes the persistent launch abort at step k - 1
+        self.persist_selftest = 0            # tests: k > 0 makes the persistent forward launch abort at step k - 1
+        self.persist_bwd_selftest = 0        # ... and the persistent BPTT launch at its k-th step
         self.persist_stamps = None           # bench: 256 x 16 int64 tensor -> per-stage ticks of the next persistent launch
         self.persist_bwd = self.persist and os.environ.get("MSTTS_PERSIST_BWD", "1") != "0" and bool(lb.mstts_persist_bwd_supported(1, H, M, d.att, 1, d.att_k))
         self.persist_bwd_fallbacks = 0
@@ -265,6 +266,8 @@ class TrainEngine:
             w.pctrl_b = torch.zeros(272, dtype=torch.int32, device=self.device)
             w.pctrl_b_host = torch.zeros(272, dtype=torch.int32).pin_memory()
             w.pdesc_b = lib.PersistDesc()
+            w.opk = f(int(lb.mstts_persist_opk_floats(S)))         # the cell updates' BPTT operands, packed by owner (instead of acts / craw / c)
+        w.opk_valid = False
         w.proj = f(S, B, self.proj_ld)
         w.linear, w.stop = f(B, S, d.n_mel), f(B, S)
         # postnet
@@ -441,12 +444,15 @@ class TrainEngine:
             pd = w.pdesc
             pd.w0pk, pd.w1pk, pd.wqpk, pd.xch, pd.ctrl = ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]), ptr(w.xch), ptr(w.pctrl)
             pd.stamps = ptr(self.persist_stamps) if self.persist_stamps is not None else None
+            pd.opk = ptr(w.opk) if getattr(w, "persist_bwd", False) else None
+            w.opk_valid = pd.opk is not None
             pd.selftest_fail_step = int(self.persist_selftest)
             pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
             ev.record()
         else:
+            w.opk_valid = False
             call("mstts_decoder_train_fwd", C.byref(dec))
         self._forward_tail(w)
         if ev is not None:
@@ -462,9 +468,16 @@ class TrainEngine:
                 self.persist_fallbacks += 1
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
                 cur.synchronize()
+                w.opk_valid = False                   # the launch-per-step loop writes the row-major histories
                 call("mstts_decoder_train_fwd", C.byref(dec))
                 self._forward_tail(w)
         return w
+
+    def unpack_history(self, w):
+        """Packed cell-update operands of the persistent forward -> the row-major histories acts0/1, craw0/1, c0/1 (what the
+        launch-per-step BPTT and the tests read)."""
+        if getattr(w, "opk_valid", False):
+            call("mstts_persist_unpack_history", ptr(w.opk), C.byref(w.dec))
 
     def _forward_tail(self, w):
         """Everything behind the decoder loop: projection, postnet, residual, the vocoder's statistics side effect."""
@@ -565,13 +578,16 @@ class TrainEngine:
         w.d_keys.zero_()
         self.d_loc_k.zero_()
         parts = w.d_in0_parts
-        if getattr(w, "persist_bwd", False):
+        if getattr(w, "opk_valid", False) and not getattr(w, "persist_bwd", False):
+            self.unpack_history(w)            # the persistent forward packed the cell operands; the launch-per-step BPTT reads the histories
+        if getattr(w, "persist_bwd", False) and getattr(w, "opk_valid", False):
             # ONE launch for the whole BPTT; its status words are read while the hoisted weight-gradient products run (no bubble); the
             # launch-per-step loop is the fallback
             pb = w.pdesc_b
             pb.w0pk, pb.w1pk, pb.wqpk, pb.xch, pb.ctrl = ptr(self.pkb[0]), ptr(self.pkb[1]), ptr(self.pkb[2]), ptr(w.xch_b), ptr(w.pctrl_b)
             pb.stamps = ptr(self.persist_bwd_stamps) if self.persist_bwd_stamps is not None else None
-            pb.selftest_fail_step = int(self.persist_selftest)
+            pb.opk = ptr(w.opk)
+            pb.selftest_fail_step = int(self.persist_bwd_selftest)
             pb.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             call("mstts_decoder_train_bwd_persistent", C.byref(db), C.byref(pb))
             ev = torch.cuda.Event()
@@ -586,6 +602,7 @@ class TrainEngine:
             if int(st[1]) != 0 or int(st[2]) != 256:
                 self.persist_bwd_fallbacks += 1
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
+                self.unpack_history(w)
                 w.dq_hist.zero_()
                 call("mstts_decoder_train_bwd", C.byref(db))
             else:

@@ -313,10 +313,11 @@ def main():
             return res
 
         persistent = bool(getattr(w, "persist", False))
-        stage_names = ["shadow: h1 half 2", "wait ctx", "cell0 ctx product + publish", "wait partials0", "cell0 update + publish",
-                       "wait m0", "cell1 m0 product + publish", "stage h0 + h0 half 1", "wait partials1", "cell1 update + publish",
-                       "shadow: h0 half 2", "wait m1 row", "query + partial energies + publish", "stage h1 + h1 half 1", "wait energies",
+        stage_names = ["loop top", "wait ctx", "cell0 ctx product + publish", "wait partials0", "cell0 update + publish",
+                       "wait m0", "cell1 m0 product + publish", "shadow: stage h0 + h0 half 1", "wait partials1", "cell1 update + publish",
+                       "shadow: h0 half 2", "wait m1 row", "query + partial energies + publish", "shadow: stage h1 + h1 product", "wait energies",
                        "softmax + context + publish"]
+        stage_order = [0, 1, 2, 13, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15]      # execution order (stamp 13 sits behind stage 2)
         if persistent:
             # in-kernel stage timing: the persistent launch stamps the 100 MHz wall clock (s_memrealtime) at 16 points of every
             # step in every workgroup and sums the intervals; one extra, untimed step with the stamping instantiation
@@ -330,7 +331,7 @@ def main():
             # the attention STAGE: from the moment the cell-1 outputs (m1) leave their producers to the moment the context has left
             # this workgroup - the m1 hand-off, the 16 query units, the partial energies, the energy hand-off, softmax, context.  It
             # contains the recurrent-half products that run in the shadow of its two hand-offs (stages 10 and 13).
-            att_us = float(per_step_us[10:16].sum())
+            att_us = float(per_step_us[10:13].sum() + per_step_us[14:16].sum())
             ach = att_bytes / (att_us * 1e-6) / 1e9
             out["roofline"] = {"kernel": "persist_fwd_kernel, attention stage of one decoder step (m1 hand-off, query units, partial energies, energy hand-off, softmax, context; B=32): keys / values stay on chip",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -339,7 +340,7 @@ def main():
                                "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT),
                                "algorithmic_bytes_per_launch": att_bytes, "avg_launch_us": att_us,
                                "timing": "s_memrealtime stamps inside the launch, mean over 256 workgroups x %d steps" % S,
-                               "stage_us": {n: float(v) for n, v in zip(stage_names, per_step_us)}, "frame_us": frame_us,
+                               "stage_us": {stage_names[i]: float(per_step_us[i]) for i in stage_order}, "frame_us": frame_us,
                                "attention_compute_only_us": float(per_step_us[12] + per_step_us[15]),
                                "persistent_fallbacks": eng.persist_fallbacks}
             # the launch-per-step loop it replaced, measured the old way for the record

@@ -260,8 +260,6 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         pf32x4 sv[2], pv[4], rv[1];
         // ================= A: cell 0, context rows.  In the shadow of the ctx_{s-1} hand-off: second half of h1_{s-1} . W1[h rows]
         if (s > 0) {
-            mfma_part<4, 8, LA, 32, 64>(w1, stg, lane, acc1);
-            __syncthreads();                                         // every wave is done with the staged h1 before ctx overwrites it
             PSTAMP(0);
             slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
             if (!slice_complete<6, LC>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
@@ -271,6 +269,15 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         if (s > 0) mfma_part<0, 6, LC, 0, 56>(w0, stg, lane, acc0);
         PUBLISH_PARTIAL(OFF_P0, acc0)
         PSTAMP(2);
+        // in the shadow of the partial-gates hand-off (the longest wait of the step, and the staging buffer is free): h1_{s-1} . W1[h rows]
+        if (s > 0) {
+            slice_issue<8>(xr, OFF_H1 + pslot * XACT + gi * 4096L, tid, soff, sv);
+            __syncthreads();                                         // the context rows are consumed by every wave
+            if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
+            PABORT_CHECK();
+            mfma_part<0, 8, LA, 32, 64>(w1, stg, lane, acc1);
+        }
+        PSTAMP(13);
         // ================= B: sum of the eight partials, cell-0 update
         ISSUE_PARTIALS(OFF_P0)
         COMPLETE_PARTIALS()
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             }
         }
         PSTAMP(4);
-        // ================= C: cell 1, input rows (m0_s)
+        // ================= C: cell 1, input rows (m0_s)   (every wave passed the barriers of B since it read the staged h1)
         slice_issue<8>(xr, OFF_M0 + slot * XACT + gi * 4096L, tid, soff, sv);
         if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
         PABORT_CHECK();
@@ -391,19 +398,19 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                     const pf32x4 wv = *reinterpret_cast<const pf32x4*>(sm + S_WQ + (x4 * PTH + tid) * 4);
                     qp += wv[0] * mv[0]; qp += wv[1] * mv[1]; qp += wv[2] * mv[2]; qp += wv[3] * mv[3];
                 }
-                sm[S_Q + atg * 16 + ak] = qp;
+                // the wave's four hidden-unit groups (lanes ak, ak + 16, ak + 32, ak + 48) meet through the LDS crossbar, the eight waves through
+                // 128 floats of LDS behind ONE barrier; every thread then sums the eight wave partials of its unit itself (fixed order)
+                qp += __shfl_xor(qp, 16);
+                qp += __shfl_xor(qp, 32);
+                if (lane < 16) sm[S_Q + wave * 16 + lane] = qp;
             }
             __syncthreads();
-            if (tid < 16) {
-                float qv = 0.f;
+            float qsum = 0.f;
 #pragma unroll
-                for (int u = 0; u < 32; ++u) qv += sm[S_Q + u * 16 + tid];
-                sm[S_QF + tid] = qv;
-                (d.q_hist + (sB + ab) * PA + 16 * gi)[tid] = qv;
-            }
-            __syncthreads();
+            for (int u = 0; u < 8; ++u) qsum += sm[S_Q + u * 16 + ak];
+            if (tid < 16) (d.q_hist + (sB + ab) * PA + 16 * gi)[tid] = qsum;
             {
-                const float qk = sm[S_QF + ak] + asb;
+                const float qk = qsum + asb;
                 // location filter over the cumulative alignment as a Toeplitz product on the matrix core: loc[t][k] = sum_j cum[t + j - 15] lk[j][k]
                 // = A . B with A[t][j] = cum window (one LDS word per lane and k-step), B[j][k] = the filter slice (8 registers, loaded once);
                 // wave w takes positions 16 w .. 16 w + 15, and the D layout (position 4 (lane >> 4) + r, unit lane & 15) is exactly this
@@ -434,13 +441,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             PSTAMP(11);
         }
         PSTAMP(12);
-        // in the shadow of the energy hand-off: h1_s staged (it stays staged until the next step's context arrives), first half of h1_s . W1[h rows]
-        slice_issue<8>(xr, OFF_H1 + slot * XACT + gi * 4096L, tid, soff, sv);
-        __syncthreads();                                             // h0 is consumed by every wave
-        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
-        PABORT_CHECK();
-        mfma_part<0, 4, LA, 32, 64>(w1, stg, lane, acc1);
-        PSTAMP(13);
+        __syncthreads();                                             // (h0 is consumed by every wave before the next step stages the context)
         // ================= F: energies of the row, softmax, cumulative alignment, context columns 96 gi ..
         if (arow) {
             if (tid < 256) {

@@ -47,12 +47,12 @@ PMC_TRAFFIC_CSV = _latest_pmc_csv()
 
 
 def pmc_traffic_bytes(kernel_prefix):
-    """2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch of the kernel whose name starts with `kernel_prefix`, or None."""
+    """2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch of the first kernel whose name contains `kernel_prefix`, or None."""
     import csv
     if not os.path.exists(PMC_TRAFFIC_CSV):
         return None
     for r in csv.DictReader(open(PMC_TRAFFIC_CSV)):
-        if r["kernel"].startswith(kernel_prefix):
+        if kernel_prefix in r["kernel"]:
             try:
                 return (float(r["avg_FETCH_SIZE_KB_x2_gfx950_correction"]) + float(r["avg_WRITE_SIZE_KB"])) * 1024.0
             except (KeyError, ValueError):
@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--frames", type=int, default=L_MEL, help=argparse.SUPPRESS)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help=argparse.SUPPRESS)       # supplementary measurements only: never the headline
     ap.add_argument("--recurrent-dtype", default="f32", choices=("f32", "bf16"), help=argparse.SUPPRESS)   # bf16 recurrent products only
+    ap.add_argument("--force-bf16-recurrent", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--config3", action="store_true", help="BASELINE config 3 arithmetic (bf16 operands everywhere, fp32 master/accumulate); never the headline")
     args = ap.parse_args()
     headline_batch = args.batch == B_PER_GPU
@@ -243,7 +244,13 @@ def main():
     dims = Dims()
     L = args.frames
     if args.config3:
-        args.recurrent_dtype = "bf16"
+        # config 3 = bf16 operands with fp32 master / accumulate.  Where the persistent decoder loops are available they run the recurrent
+        # products in exact fp32 AND faster than the bf16 launch-per-step products, so config 3 keeps them (bf16 for every hoisted
+        # contraction, fp32 inside the two loops); --recurrent-dtype bf16 forces the all-bf16 form of earlier rounds
+        lb0 = lib.load()
+        persist_ok = os.environ.get("MSTTS_PERSIST", "1") != "0" and bool(lb0.mstts_persist_fwd_supported(B_PER_GPU, dims.dec_lstm, dims.mem, dims.att, T_ENC, dims.att_k))
+        if not (persist_ok and not args.force_bf16_recurrent):
+            args.recurrent_dtype = "bf16"
     eng = TrainEngine(dims, device=device, seed=1234, rank=rank, world=world, recurrent_dtype=args.recurrent_dtype,
                       gemm_dtype="bf16" if args.config3 else "f32")
     batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
@@ -274,7 +281,8 @@ def main():
                      "mel-frames/sec (train step) at per-GPU batch %d (supplementary, not the BASELINE configuration)" % B_PER_GPU, "value": value, "unit": "mel-frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": ("f32" if args.recurrent_dtype == "f32" else
+           "dtype": ("bf16 operands in every hoisted contraction, f32 accumulate + f32 master, f32 inside the persistent decoder loops (BASELINE config 3 arithmetic, not the headline)"
+                     if args.config3 and args.recurrent_dtype == "f32" else "f32" if args.recurrent_dtype == "f32" else
                      "bf16 operands, f32 accumulate + f32 master (BASELINE config 3 arithmetic, not the headline)" if args.config3 else
                      "f32 + bf16 recurrent products (not the headline)"), "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[%d]: Tacotron2 train step (fwd+bwd+TF-Adam), per-GPU batch %d x (%d tokens, %d mel frames), random speaker embeddings, %s"
@@ -335,7 +343,7 @@ def main():
             ach = att_bytes / (att_us * 1e-6) / 1e9
             out["roofline"] = {"kernel": "persist_fwd_kernel, attention stage of one decoder step (m1 hand-off, query units, partial energies, energy hand-off, softmax, context; B=32): keys / values stay on chip",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": (pmc_traffic_bytes("void mstts::persist_fwd_kernel") or 0) / S or None,
+                               "traffic": (pmc_traffic_bytes("persist_fwd_kernel") or 0) / S or None,
                                "traffic_note": "HBM-side bytes of the WHOLE persistent launch per decoder step (committed rocprofv3 PMC pass, FETCH_SIZE x 2 + WRITE_SIZE, / %d steps): history written for BPTT, hand-off rings and operands - the attention stage's keys / values are read once per sequence" % S,
                                "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT),
                                "algorithmic_bytes_per_launch": att_bytes, "avg_launch_us": att_us,
@@ -378,6 +386,7 @@ def main():
             bt = eng.persist_bwd_stamps.view(256, 16).double().cpu().numpy().mean(axis=0) * 0.01 / S
             eng.persist_bwd_stamps = None
             out["bptt_persistent"] = {"kernel": "persist_bwd_kernel", "frame_us": float(bt.sum()), "fallbacks": eng.persist_bwd_fallbacks,
+                                      "traffic_per_step": (pmc_traffic_bytes("persist_bwd_kernel") or 0) / S or None,
                                       "attention_backward_stage_us": float(bt[0:6].sum()),
                                       "stage_us": {n: float(v) for n, v in zip(bnames, bt) if n != "-"}}
         bwd = probe({"lsa_step_bwd": 5, "lsa_denergy_bwd": 6, "cell0_dgemm_bwd": 7, "cell1_dgemm_bwd": 8}, True)

@@ -694,8 +694,9 @@ def _l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / ((b ** 2).sum() + 1e-30)))
 
 
-@pytest.mark.parametrize("B,Te,L,kw", [(5, 18, 9, MID), (32, 24, 6, dict(dec_lstm=1024, enc_lstm=256, spk=256, prenet=256, n_mel=80, emb=128, enc_conv_ch=128, post_ch=128))])
-def test_train_step_parity_bf16_full(dev, monkeypatch, B, Te, L, kw):
+@pytest.mark.parametrize("B,Te,L,kw,recurrent", [(5, 18, 9, MID, "bf16"), (32, 24, 6, dict(dec_lstm=1024, enc_lstm=256, spk=256, prenet=256, n_mel=80, emb=128, enc_conv_ch=128, post_ch=128), "bf16"),
+                                                   (32, 24, 6, dict(dec_lstm=1024, enc_lstm=256, spk=256, prenet=256, n_mel=80, emb=128, enc_conv_ch=128, post_ch=128), "f32")])
+def test_train_step_parity_bf16_full(dev, monkeypatch, B, Te, L, kw, recurrent):
     """Complete BASELINE config-3 arithmetic: every dense / conv contraction of the step (forward, data gradients, weight gradients,
     the hoisted recurrent weight gradients) AND the decoder's recurrent products multiply bf16-rounded operands with fp32
     accumulation; master weights, activations, gradients, BN, losses and Adam stay fp32.  The oracle emulates exactly that
@@ -705,7 +706,8 @@ def test_train_step_parity_bf16_full(dev, monkeypatch, B, Te, L, kw):
     flip worth 2^-8 of that operand, and five BN layers / BPTT amplify it - the oracle's OWN gradients move by 2-4 % (relative L2) under
     a 1e-6 perturbation of the variables (tests/test_cpu_oracle.py::test_bf16_emulation_sensitivity).  Hence: relative-L2 bounds at
     that noise level, a tight bound where the chain is short (the decoder outputs), and the emulation must be clearly closer to the
-    HIP path than exact arithmetic is."""
+    HIP path than exact arithmetic is.  recurrent = "f32": what `bench.py --config3` runs where the persistent decoder loops exist -
+    bf16 operands in every hoisted contraction, exact fp32 inside the two loops."""
     pd, od = dims_pair(**kw)
     values = OM.init_params(od, 13)
     g = np.random.default_rng(14)
@@ -716,7 +718,7 @@ def test_train_step_parity_bf16_full(dev, monkeypatch, B, Te, L, kw):
             values[k] = 1.0 + g.normal(0, 0.1, values[k].shape)
     batch = OT.synthetic_batch(od, B, Te, L, seed=13, ragged=True)
     masks = OT.make_masks(od, B, Te, L + 1, True, seed=OT.step_seed(1234, 0))
-    eng = TrainEngine(pd, device=dev, values=values, recurrent_dtype="bf16", gemm_dtype="bf16")
+    eng = TrainEngine(pd, device=dev, values=values, recurrent_dtype=recurrent, gemm_dtype="bf16")
     w = eng.plan(B, Te, L)
     eng.forward(to_dev(batch, dev), w, seed=OT.step_seed(1234, 0))
     eng.loss_and_backward(w)
@@ -728,7 +730,7 @@ def test_train_step_parity_bf16_full(dev, monkeypatch, B, Te, L, kw):
     ggot = eng.params.export(grads=True)
     res = {}
     for mode in ("emulated", "exact"):
-        monkeypatch.setattr(OM, "RECURRENT_BF16", mode == "emulated")
+        monkeypatch.setattr(OM, "RECURRENT_BF16", mode == "emulated" and recurrent == "bf16")
         monkeypatch.setattr(OM, "GEMM_BF16", mode == "emulated")
         _, _, sc, grads, out = OT.train_step(values, None, od, batch, omasks, 0, return_grads=True)
         gl2 = {k: _l2(ggot[k].astype(np.float64) + (1e-6 * np.asarray(values[k]) if OM.in_weight_reg(k) else 0.0), t2n(gr)) for k, gr in grads.items()}

@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help=argparse.SUPPRESS)       # supplementary measurements only: never the headline
     ap.add_argument("--recurrent-dtype", default="f32", choices=("f32", "bf16"), help=argparse.SUPPRESS)   # bf16 recurrent products only
     ap.add_argument("--force-bf16-recurrent", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-gemm-tail-split", action="store_true", help=argparse.SUPPRESS)      # A/B: every GEMM tile whole (mstts_gemm_tail_split(0))
     ap.add_argument("--config3", action="store_true", help="BASELINE config 3 arithmetic (bf16 operands everywhere, fp32 master/accumulate); never the headline")
     args = ap.parse_args()
     headline_batch = args.batch == B_PER_GPU
@@ -243,6 +244,8 @@ def main():
 
     dims = Dims()
     L = args.frames
+    if args.no_gemm_tail_split:
+        lib.call("mstts_gemm_tail_split", 0)
     if args.config3:
         # config 3 = bf16 operands with fp32 master / accumulate.  Where the persistent decoder loops are available they run the recurrent
         # products in exact fp32 AND faster than the bf16 launch-per-step products, so config 3 keeps them (bf16 for every hoisted

@@ -53,6 +53,11 @@ typedef struct {
     int32_t win_dil;
 } mstts_gemm_desc;
 int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
+/* Scheduling of mstts_gemm_f32, process-wide, default on: a tile list that ends in a small fraction of a round of the 256 CUs
+ * (25 632 x 512 outputs = 3 rounds + 36 tiles) has its last tiles cut along K into pieces that fill one short round, accumulated with
+ * atomics onto a cleared (or, with accumulate, the existing) C.  Only for act == none, batch == 1, split_k == 1.  0 switches it off
+ * (every tile whole: the summation order of every output element fixed). */
+int mstts_gemm_tail_split(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes. */
 int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t s);

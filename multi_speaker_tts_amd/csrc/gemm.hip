@@ -30,6 +30,10 @@ struct GemmArgs {
     long stride_a, stride_b, stride_c;
     float alpha;
     int k_per_split;
+    // body + tail (see mstts_gemm_f32): blocks [0, body) own one whole output tile each; the last tiles of the list are cut along K
+    // into tail_s pieces of tail_kps each, blocks body + (tile - body) * tail_s + piece, accumulated with atomics.  body = all tiles
+    // when the split is off.
+    int body, tail_s, tail_kps;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -121,11 +125,11 @@ struct LoaderKC {
     }
 };
 
-template <int R, bool VEC>
+template <int R, bool VEC, int BKT = BK>
 struct LoaderMC {
     static constexpr int C4 = R / 4;                  // float4 per k-row
     static constexpr int KR = 256 / C4;               // k-rows per pass
-    static constexpr int NV = BK / KR;
+    static constexpr int NV = BKT / KR;
     float4 reg[NV];
     // window (A only): element (m, kk) with kk=(b,t) row index, m=(tap, c):
     //   valid iff 0 <= (kk % T) + m / C - pad < T; address = base[(kk + (tap - pad) dil) * ld + c]
@@ -164,8 +168,8 @@ struct LoaderMC {
             if (wT > 0) {
                 const int t = t_k[i] + sh;
                 ok = ok && t >= 0 && t < wT;
-                t_k[i] += BK;                          // next call is for k0 + BK
-                if (wT >= BK) t_k[i] -= (t_k[i] >= wT) ? wT : 0;      // one wrap at most (every real sequence is longer than a K-tile)
+                t_k[i] += BKT;                         // next call is for k0 + BKT
+                if (wT >= BKT) t_k[i] -= (t_k[i] >= wT) ? wT : 0;     // one wrap at most (every real sequence is longer than a K-tile)
                 else while (t_k[i] >= wT) t_k[i] -= wT;
             }
             if (VEC) {
@@ -179,7 +183,7 @@ struct LoaderMC {
             }
             reg[i] = v;
         }
-        ubase += BK * ld;
+        ubase += BKT * ld;
     }
     __device__ __forceinline__ void store(float* __restrict__ s, int ldS) const {
         const int c4 = threadIdx.x % C4, kr = threadIdx.x / C4;
@@ -188,6 +192,34 @@ struct LoaderMC {
             *reinterpret_cast<float4*>(s + (kr + i * KR) * ldS + c4 * 4) = reg[i];
     }
 };
+
+// epilogue of one wave's WM x WN grid of 32 x 32 MFMA tiles: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const f32x16 (&acc)[WM][WN], float* __restrict__ C, int row0, int col0,
+                                                int lane, bool with_bias, bool atomic) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = col0 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = (g.bias != nullptr && with_bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = g.alpha * acc[i][j][r] + bv;
+                float* dst = C + (long)row * g.ldc + col;
+                if (atomic) {
+                    atomicAdd(dst, v);
+                } else {
+                    v = apply_act(v, g.act);
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
 
 template <int BM, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -203,10 +235,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int tiles_n = (g.N + BN - 1) / BN;
     // XCD-aware tile order: block b runs on XCD b % 8 and every XCD has its own L2, so give each XCD a contiguous range
     // of the (tile_m-major) tile list - a band of A rows it re-reads from its own L2 - instead of every eighth tile.
-    int tile = blockIdx.x;
-    {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = tile & 7, idx = tile >> 3;
+    int tile = blockIdx.x, piece = -1;
+    if (tile < g.body) {
+        const int nb = g.body, q = nb >> 3, r = nb & 7, xcd = tile & 7, idx = tile >> 3;
         if (nb >= 64) tile = xcd * q + (xcd < r ? xcd : r) + idx;
+    } else {
+        const int u = tile - g.body;
+        tile = g.body + u / g.tail_s;
+        piece = u % g.tail_s;
     }
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int batch = blockIdx.z / g.split_k, split = blockIdx.z % g.split_k;
@@ -214,8 +250,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const float* B = g.B + (long)batch * g.stride_b;
     float* C = g.C + (long)batch * g.stride_c;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = split * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int kbeg = piece >= 0 ? piece * g.tail_kps : split * g.k_per_split;
+    const int kend = min(g.K, kbeg + (piece >= 0 ? g.tail_kps : g.k_per_split));
 
     using LA = typename std::conditional<TA, LoaderMC<BM, VEC>, LoaderKC<BM, VEC>>::type;
     using LB = typename std::conditional<TB, LoaderKC<BN, VEC>, LoaderMC<BN, VEC>>::type;
@@ -288,30 +324,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
     }
 
-    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool first_split = (split == 0);
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + wcol + j * 32 + (lane & 31);
-            if (col >= g.N) continue;
-            const float bv = (g.bias != nullptr && first_split) ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
-                float v = g.alpha * acc[i][j][r] + bv;
-                float* dst = C + (long)row * g.ldc + col;
-                if (g.split_k > 1) {
-                    atomicAdd(dst, v);
-                } else {
-                    v = apply_act(v, g.act);
-                    if (g.accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
+    gemm_store_tile<WM, WN>(g, acc, C, m0 + wrow, n0 + wcol, lane, split == 0 && piece <= 0, g.split_k > 1 || piece >= 0);
+}
+
+__global__ void gemm_tail_act_kernel(float* __restrict__ C, long ldc, int N, long n, int act) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float* p = C + (i / N) * ldc + (i % N);
+    *p = apply_act(*p, act);
 }
 
 template <int BM, bool TA, bool TB>
@@ -323,6 +343,9 @@ static void launch_gemm(const GemmArgs& g, bool vec, dim3 grid, hipStream_t st) 
 }  // namespace mstts
 
 using namespace mstts;
+
+static int g_tail_split = 1;
+extern "C" int mstts_gemm_tail_split(int32_t on) { g_tail_split = on != 0; return MSTTS_OK; }
 
 extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm: null descriptor");
@@ -362,14 +385,48 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     // 128-row tiles unless 64-row tiles fill the 256 CUs' rounds visibly better (25 632 x 512: 804 tiles = 3.14 rounds -> 4, but
     // 1 608 half tiles = 6.28 -> 7; 4 096 x 512: 128 tiles use half the chip, 256 half tiles all of it); the half tile re-reads
     // the B operand twice as often, so it has to win by more than 5 %
-    int bm = skinny ? 32 : 128;
+    int bm = skinny ? 32 : 128, tail_s = 1, tail_rem = 0;
     if (!skinny) {
         const double t128 = (double)cdiv(d->M, 128) * cdiv(d->N, BN) * batch * split, t64 = (double)cdiv(d->M, 64) * cdiv(d->N, BN) * batch * split;
         const double e128 = t128 / (ceil(t128 / 256.0) * 256.0), e64 = t64 / (ceil(t64 / 256.0) * 256.0);
         if (e64 * 0.95 > e128) bm = 64;
+        // Body + tail: when a list of more than 256 tiles ends in a small fraction of a round (25 632 x 512: 804 tiles = 3 rounds + 36),
+        // the last round runs 36 tiles on 256 CUs.  Cut those tiles along K into floor(256 / rem) pieces each instead, so the
+        // remainder is one short round of the whole chip: 3 + 1/7 rounds instead of 4 (or 7 rounds of half tiles).  Costs in units of
+        // one round of 128-row tiles; a half tile is 0.54 (it re-reads B twice as often), a piece pays its atomics and a short K loop.
+        if (g_tail_split && batch == 1 && split == 1 && (d->act == MSTTS_ACT_NONE || !d->accumulate)) {
+            double best = (bm == 128 ? ceil(t128 / 256.0) : ceil(t64 / 256.0) * 0.54);
+            const int ktiles = cdiv(d->K, BK);
+            for (int cand = 128; cand >= 64; cand -= 64) {
+                const long t = (long)cdiv(d->M, cand) * cdiv(d->N, BN);
+                int rem = (int)(t % 256);
+                // with an activation the tail is made of whole tile rows (the activation runs over those rows once the pieces are summed)
+                if (d->act != MSTTS_ACT_NONE) rem = (int)(t - (t - rem) / cdiv(d->N, BN) * cdiv(d->N, BN));
+                if (t <= 256 || rem == 0 || rem > 128) continue;
+                int s = 256 / rem;
+                if (s > 16) s = 16;
+                if (s > ktiles / 8) s = ktiles / 8;              // a piece keeps at least 8 K-tiles: below that its prologue and atomics cost more than the round it saves
+                if (s < 2) continue;
+                const double c = ((double)(t / 256) + 1.25 / s + 0.06) * (cand == 128 ? 1.0 : 0.54);
+                if (c < best) { best = c; bm = cand; tail_s = s; tail_rem = rem; }
+            }
+        }
     }
-    dim3 grid(cdiv(d->M, bm) * cdiv(d->N, BN), 1, batch * split);
     hipStream_t st = (hipStream_t)stream;
+    const int tiles = cdiv(d->M, bm) * cdiv(d->N, BN);
+    g.body = tiles; g.tail_s = 1; g.tail_kps = kps;
+    if (tail_s > 1) {
+        // the last `rem` tiles of the list as rem x tail_s blocks behind the body (highest block ids: they start as body tiles retire)
+        const int rem = tail_rem, tiles_n = cdiv(d->N, BN);
+        g.body = tiles - rem; g.tail_s = tail_s;
+        g.tail_kps = (cdiv(g.K, BK) + tail_s - 1) / tail_s * BK;
+        if (!d->accumulate) {           // the pieces add onto zeros: clear every tile row that holds a tail tile (body tiles of a mixed row overwrite)
+            const long r0 = (long)(g.body / tiles_n) * bm;
+            if (hipMemset2DAsync(d->C + r0 * d->ldc, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)(d->M - r0), st) != hipSuccess)
+                MSTTS_REQUIRE(false, MSTTS_ERR_LAUNCH, "gemm: clearing the tail tiles failed");
+        }
+    }
+    dim3 grid(g.body + (tiles - g.body) * g.tail_s, 1, batch * split);
     const bool ta = d->trans_a != 0, tb = d->trans_b != 0;
     if (skinny) {
         if (!ta && !tb) launch_gemm<32, false, false>(g, vec, grid, st);
@@ -388,5 +445,11 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
         else launch_gemm<128, true, true>(g, vec, grid, st);
     }
     MSTTS_CHECK_LAUNCH("gemm_f32");
+    if (tail_s > 1 && d->act != MSTTS_ACT_NONE) {        // the tail's tile rows hold bias + the summed pieces: apply the activation there
+        const long r0 = (long)(g.body / cdiv(d->N, BN)) * bm;
+        const long n = (d->M - r0) * d->N;
+        hipLaunchKernelGGL(gemm_tail_act_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, d->C + r0 * d->ldc, d->ldc, (int)d->N, n, d->act);
+        MSTTS_CHECK_LAUNCH("gemm_f32 tail activation");
+    }
     return MSTTS_OK;
 }

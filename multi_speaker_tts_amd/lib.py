@@ -115,6 +115,7 @@ SIGNATURES = {
     "mstts_last_error": (C.c_char_p, []),
     "mstts_abi_version": (i32, []),
     "mstts_gemm_f32": (i32, [P(GemmDesc), vp]),
+    "mstts_gemm_tail_split": (i32, [i32]),
     "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
     "mstts_philox_keep_mask_rows": (i32, [vp, i64, i64, i64, u64, u32, u64, f32, vp]),

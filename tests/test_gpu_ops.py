@@ -48,6 +48,51 @@ def test_gemm_splitk_batch_accumulate(dev):
     assert rel_err(t2n(Cm2), ref2) < TOL
 
 
+def test_gemm_dw_shapes_full_tiles(dev):
+    """dW-shaped products (A as [K, M], B as [K, N]) large enough for the 128-row tile (the small cases above all take 64-row tiles):
+    plain with ragged M / N / K and split-K onto ones, and a conv weight gradient (window)."""
+    if True:
+        M, N, K = 4000, 1000, 333
+        A = _r(dev, K, M, seed=21); B = _r(dev, K, N, seed=22, scale=1.0 / np.sqrt(K))
+        for sk in (1, 3):
+            Cm = torch.ones(M, N, device=dev)
+            lib.gemm(A, B, Cm, M, N, K, M, N, N, trans_a=True, split_k=sk, accumulate=(sk == 1), alpha=0.5)
+            ref = 1.0 + 0.5 * (t2n(A).astype(np.float64).T @ t2n(B).astype(np.float64))
+            assert rel_err(t2n(Cm), ref) < TOL, sk
+        Bn, T, cin, cout, Kt = 3, 37, 800, 1000, 5
+        x = _r(dev, Bn, T, cin, seed=23); dy = _r(dev, Bn, T, cout, seed=24, scale=0.1)
+        dw = torch.zeros(Kt, cin, cout, device=dev)
+        pad = (Kt - 1) // 2
+        lib.gemm(x, dy, dw, Kt * cin, cout, Bn * T, cin, cout, cout, trans_a=True, win=(T, cin, pad), split_k=2)
+        xp = np.pad(t2n(x).astype(np.float64), ((0, 0), (pad, Kt - 1 - pad), (0, 0)))
+        win = np.stack([xp[:, k:k + T] for k in range(Kt)], axis=2).reshape(Bn, T, Kt * cin)
+        ref_dw = np.einsum("btk,bto->ko", win, t2n(dy).astype(np.float64)).reshape(Kt, cin, cout)
+        assert rel_err(t2n(dw), ref_dw) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,win,accumulate,act", [(8990, 512, 640, None, False, 0), (8990, 512, 330, None, True, 0), (4 * 2237, 500, 5 * 64, (2237, 64, 2), False, 0),
+                                                       (17000, 140, 2048, None, False, 0), (8990, 512, 640, None, False, 2), (4 * 2237, 500, 5 * 64, (2237, 64, 2), False, 1)])
+def test_gemm_body_tail_split(dev, M, N, K, win, accumulate, act):
+    """Tile lists that end in a small fraction of a round (here 284 / 281 / 284 / 266 tiles): the last tiles are cut along K into pieces
+    accumulated with atomics onto cleared tile rows - same product as with the split switched off, ragged edges included."""
+    A = _r(dev, M, win[1] if win else K, seed=11)
+    B = _r(dev, K, N, seed=12, scale=1.0 / np.sqrt(K))
+    bias = _r(dev, N, seed=13)
+    outs = []
+    for on in (1, 0):
+        lib.call("mstts_gemm_tail_split", on)
+        Cm = torch.full((M + 3, N), 0.5, device=dev)          # three guard rows behind the operand: the clearing must stop at M
+        lib.gemm(A, B, Cm, M, N, K, A.shape[1], N, N, bias=bias, win=win, accumulate=accumulate, act=act)
+        outs.append(t2n(Cm))
+    lib.call("mstts_gemm_tail_split", 1)
+    assert np.all(outs[0][M:] == 0.5) and np.all(outs[1][M:] == 0.5)
+    assert rel_err(outs[0][:M], outs[1][:M].astype(np.float64)) < 1e-5         # (the two schedules add the K range in different orders)
+    if win is None:
+        ref = t2n(A).astype(np.float64) @ t2n(B).astype(np.float64) + t2n(bias) + (0.5 if accumulate else 0.0)
+        ref = np.tanh(ref) if act == 2 else ref
+        assert rel_err(outs[0][:M], ref) < TOL
+
+
 @pytest.mark.parametrize("K,cin,cout,T", [(5, 32, 48, 19), (1, 8, 16, 7), (2, 8, 12, 9), (8, 8, 20, 33), (3, 64, 8, 140)])
 def test_conv1d_same_fwd_bwd(dev, K, cin, cout, T):
     """conv1d 'same' as windowed GEMM: forward, weight gradient, data gradient vs torch-free NumPy."""

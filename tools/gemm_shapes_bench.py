@@ -32,6 +32,8 @@ shapes = [  # name, M, N, K, trans_a, trans_b, win(T, C, pad) or None, split_k, 
     ("dWq = m1^T . dq", 1024, 128, SB, 1, 0, None, max(2, _split_k(1024, 128, SB)), 1),
     ("prenet_1 fwd", SB, 256, 256, 0, 0, None, 1, 1),
 ]
+if len(sys.argv) > 1:                         # python tools/gemm_shapes_bench.py 0 : body + tail scheduling off (A/B)
+    lib.call("mstts_gemm_tail_split", int(sys.argv[1]))
 tot = {"f32": 0.0, "bf16": 0.0}
 print("%-34s %7s %6s %7s sk | %9s %8s | %9s %8s" % ("contraction", "M", "N", "K", "f32 us", "TFLOP/s", "bf16 us", "TFLOP/s"))
 for name, M, N, K, ta, tb, win, sk, cnt in shapes:

@@ -296,6 +296,10 @@ def main():
         out["allreduce"] = {"overlapped_with_backward": not args.no_overlap, "exposed_ms_per_step": reducer.exposed_ms(),
                             "message": "bf16, fp32 accumulate" if args.config3 else "fp32", "bytes_per_rank": eng.params.grad.numel() * (2 if args.config3 else 4)}
 
+    out["persistent_launches"] = {"decoder_forward": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist", False)),
+                                  "decoder_bptt": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist_bwd", False)),
+                                  "encoder_bilstm": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist_enc", False)),
+                                  "fallbacks": {"decoder_forward": eng.persist_fallbacks, "decoder_bptt": eng.persist_bwd_fallbacks, "encoder_bilstm": eng.persist_enc_fallbacks}}
     if rank == 0 and not args.no_roofline:
         w = eng.plan(B_PER_GPU, T_ENC, L)
         S = L + 1

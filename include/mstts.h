@@ -497,6 +497,30 @@ int mstts_lstm_seq_bwd(const mstts_lstm_seq_bwd_desc* d, mstts_stream_t s);
 /* BPTT of the two directions together: two launches per step (pointwise pair + product pair) instead of four */
 int mstts_lstm_seq_bwd_pair(const mstts_lstm_seq_bwd_desc* a, const mstts_lstm_seq_bwd_desc* b, mstts_stream_t s);
 
+/* Both directions of a bidirectional layer, ALL T steps in ONE launch each way (csrc/persist_lstm.hip; H == 256, B <= 32, no residual
+ * input): the recurrent kernels stay in registers, the hidden state (forward) / the gate gradients (BPTT) travel between the workgroups
+ * through a small ring in `xch`.  Same descriptors, same buffers and same results (up to the order of the partial sums) as
+ * mstts_lstm_seq_fwd_pair / mstts_lstm_seq_bwd_pair (the packed-kernel / scratch fields wh, wh_p, h_p, gates_ws, ws are not used).
+ *   pk_* / pkt_*: mstts_persist_lstm_pack(wh, wh_ld, fwd_pk, bwd_pk) copies of each direction's recurrent rows,
+ *                 mstts_persist_lstm_pack_floats() floats each, refreshed when the variables change;
+ *   xch: mstts_persist_lstm_ws_bytes() bytes, 16-byte aligned;  ctrl: 16 uint32;
+ *   hist: mstts_persist_lstm_hist_floats(T) floats, 16-byte aligned: the forward call packs its per-step inputs there, the loop writes its
+ *         history there (one contiguous kilobyte per wave access instead of 16 row-strided pieces) and a streaming kernel of the same call
+ *         then fills the descriptor's row-major tensors; the BPTT call reads the SAME buffer (so it must follow a persistent forward
+ *         call on it) and packs / unpacks its own input / output through bws (mstts_persist_lstm_bwd_floats(T) floats).
+ * After the launch ctrl[1] == 0 and ctrl[2] == 64 (forward) / 32 (BPTT) <=> it ran to its end; anything else (a bounded wait expired)
+ * means the outputs are incomplete and the caller re-runs the launch-per-step entry point. */
+int32_t mstts_persist_lstm_supported(int64_t B, int64_t H);
+int64_t mstts_persist_lstm_pack_floats(void);
+int64_t mstts_persist_lstm_ws_bytes(void);
+int mstts_persist_lstm_pack(const float* wh, int64_t wh_ld, float* fwd_pk, float* bwd_pk, mstts_stream_t s);
+int64_t mstts_persist_lstm_hist_floats(int64_t T);
+int64_t mstts_persist_lstm_bwd_floats(int64_t T);
+int mstts_lstm_seq_fwd_pair_persistent(const mstts_lstm_seq_fwd_desc* a, const mstts_lstm_seq_fwd_desc* b, const float* pk_a, const float* pk_b,
+                                       float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s);
+int mstts_lstm_seq_bwd_pair_persistent(const mstts_lstm_seq_bwd_desc* a, const mstts_lstm_seq_bwd_desc* b, const float* pkt_a, const float* pkt_b,
+                                       float* xch, uint32_t* ctrl, const float* hist, float* bws, mstts_stream_t s);
+
 /* ---- Decoder_LSTM / Decoder_Dynamic_Decode in teacher-forcing mode (Modules.py:76-119,323-472
  * with the TF AttentionWrapper step).  Everything that does not depend on the
  * recurrence is hoisted by the caller: xw0 = prenet(frames).Wx0 + b0 for all S steps, and the

@@ -27,13 +27,14 @@ int set_err(int code, const char* fmt, ...);
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// (v_rcp_f32, 1 ulp, instead of the IEEE division's ten-instruction sequence: these sit on the serial tails of the recurrent kernels)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 // tanh through exp: |err| ~ 1e-7 rel, saturates correctly for large |x|
 __device__ __forceinline__ float tanhf_(float x) {
     float ax = fabsf(x);
     float e = __expf(-2.0f * ax);
-    float t = (1.0f - e) / (1.0f + e);
+    float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(t, x);
 }
 

@@ -112,6 +112,14 @@ class TrainEngine:
         self.persist_bwd_stamps = None
         if self.persist:
             self.pk = [self._f(int(lb.mstts_persist_pack_floats(i))) for i in range(3)]
+        # persistent encoder BiLSTM (csrc/persist_lstm.hip): all T steps of both directions in one launch each way; MSTTS_PERSIST_ENC=0
+        # keeps the launch-per-step pair drivers
+        self.persist_enc = os.environ.get("MSTTS_PERSIST_ENC", "1") != "0" and bool(lb.mstts_persist_lstm_supported(1, He))
+        self.persist_enc_fallbacks = 0
+        if self.persist_enc:
+            n = int(lb.mstts_persist_lstm_pack_floats())
+            self.enc_pk = {dr: (self._f(n), self._f(n)) for dr in ("fw", "bw")}          # (forward order, BPTT order)
+        if self.persist or self.persist_enc:
             self._side = torch.cuda.Stream(device=self.device)
         if self.persist_bwd:
             self.pkb = [self._f(int(lb.mstts_persist_bwd_pack_floats(i))) for i in range(3)]
@@ -180,6 +188,11 @@ class TrainEngine:
             for dr in ("fw", "bw"):
                 ke, oke = self.P(ENC_CELL % dr + "kernel")
                 call("mstts_pack_cell_fwd", ptr(ke, oke + cin_e * 4 * He), 4 * He, ptr(self.enc_whp[dr]), He, He)
+        if self.persist_enc:
+            cin_e, He = d.enc_conv_ch, d.enc_lstm
+            for dr in ("fw", "bw"):
+                ke, oke = self.P(ENC_CELL % dr + "kernel")
+                call("mstts_persist_lstm_pack", ptr(ke, oke + cin_e * 4 * He), 4 * He, ptr(self.enc_pk[dr][0]), ptr(self.enc_pk[dr][1]))
         if self.wq_t is not None:
             call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
         if self.persist:
@@ -254,6 +267,14 @@ class TrainEngine:
         w.energy_ws_floats = int(lib.load().mstts_lsa_step_q_ws_bytes(B, Te)) // 4 + 2      # room for the in-launch query exchange
         w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(w.energy_ws_floats), f(int(nq.value))
         w.act_p = f(2 * int(lb.mstts_cell_act_floats(B, M + H) + lb.mstts_cell_act_floats(B, 2 * H))) if self.fused_cells else None
+        w.persist_enc = self.persist_enc and bool(lb.mstts_persist_lstm_supported(B, He))
+        if w.persist_enc:
+            w.enc_xch = f(int(lb.mstts_persist_lstm_ws_bytes()) // 4)
+            w.enc_ctrl = torch.zeros(16, dtype=torch.int32, device=self.device)
+            w.enc_ctrl_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.enc_hist = f(int(lb.mstts_persist_lstm_hist_floats(Te)))        # packed per-step inputs + history of the persistent forward
+            w.enc_bws = f(int(lb.mstts_persist_lstm_bwd_floats(Te)))
+            w.enc_hist_valid = False
         w.persist = self.persist and bool(lb.mstts_persist_fwd_supported(B, H, M, A, Te, d.att_k))
         if w.persist:
             w.xch = f(int(lb.mstts_persist_fwd_ws_bytes()) // 4)
@@ -395,7 +416,9 @@ class TrainEngine:
             if self.enc_whp is not None:                 # fused steps: packed recurrent kernel + packed h blocks
                 q.wh_p, q.h_p = ptr(self.enc_whp[dr]), ptr(w.enc_hp[dr])
             seqs.append(q)
-        call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
+        w.enc_hist_valid = bool(getattr(w, "persist_enc", False)) and self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)
+        if not w.enc_hist_valid:
+            call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
         # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
         call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
         wm, owm = self.P("attention/memory_layer/kernel")
@@ -472,6 +495,26 @@ class TrainEngine:
                 call("mstts_decoder_train_fwd", C.byref(dec))
                 self._forward_tail(w)
         return w
+
+    def _enc_persistent(self, w, entry, seqs, which, n_wg):
+        """One persistent launch for all steps of both encoder directions (forward: which = 0, BPTT: 1).  Its control words are read
+        right behind it (a sub-millisecond launch); False = it gave up (bounded waits) and the caller runs the launch-per-step pair,
+        which rewrites every output."""
+        extra = (ptr(w.enc_hist),) if which == 0 else (ptr(w.enc_hist), ptr(w.enc_bws))
+        call(entry, C.byref(seqs[0]), C.byref(seqs[1]), ptr(self.enc_pk["fw"][which]), ptr(self.enc_pk["bw"][which]), ptr(w.enc_xch), ptr(w.enc_ctrl), *extra)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            w.enc_ctrl_host.copy_(w.enc_ctrl, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        done.synchronize()
+        st = w.enc_ctrl_host
+        if int(st[1]) != 0 or int(st[2]) != n_wg:
+            self.persist_enc_fallbacks += 1
+            return False
+        return True
 
     def unpack_history(self, w):
         """Packed cell-update operands of the persistent forward -> the row-major histories acts0/1, craw0/1, c0/1 (what the
@@ -666,7 +709,9 @@ class TrainEngine:
             q.c_hist = ptr(w.enc_c[dr]); q.acts = ptr(w.enc_acts[dr]); q.c_raw = ptr(w.enc_craw[dr])
             q.dgates_step = ptr(w.enc_dgs[dr]); q.dgates_pos = ptr(w.enc_dgp[dr]); q.ws = ptr(w.enc_bwd_ws[dr])
             bseqs.append(q)
-        call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
+        # (the persistent BPTT reads the packed history of a persistent forward)
+        if not (getattr(w, "enc_hist_valid", False) and self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)):
+            call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(ENC_CELL % dr + "kernel")
             gk, ogk = self.G(ENC_CELL % dr + "kernel"); gb, ogb = self.G(ENC_CELL % dr + "bias")

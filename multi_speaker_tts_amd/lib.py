@@ -201,6 +201,14 @@ SIGNATURES = {
     "mstts_lstm_seq_bwd": (i32, [P(LstmSeqBwd), vp]),
     "mstts_lstm_seq_fwd_pair": (i32, [P(LstmSeqFwd), P(LstmSeqFwd), vp]),
     "mstts_lstm_seq_bwd_pair": (i32, [P(LstmSeqBwd), P(LstmSeqBwd), vp]),
+    "mstts_persist_lstm_supported": (i32, [i64, i64]),
+    "mstts_persist_lstm_pack_floats": (i64, []),
+    "mstts_persist_lstm_ws_bytes": (i64, []),
+    "mstts_persist_lstm_pack": (i32, [vp, i64, vp, vp, vp]),
+    "mstts_persist_lstm_hist_floats": (i64, [i64]),
+    "mstts_persist_lstm_bwd_floats": (i64, [i64]),
+    "mstts_lstm_seq_fwd_pair_persistent": (i32, [P(LstmSeqFwd), P(LstmSeqFwd), vp, vp, vp, vp, vp, vp]),
+    "mstts_lstm_seq_bwd_pair_persistent": (i32, [P(LstmSeqBwd), P(LstmSeqBwd), vp, vp, vp, vp, vp, vp, vp]),
     "mstts_lstm_point_bwd_pair": (i32, [P(LstmPointBwd), P(LstmPointBwd), vp]),
     "mstts_skinny_bwd_pair": (i32, [vp, vp, i64, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_lstm_seq_ws_floats": (i64, [i64, i64, i32]),

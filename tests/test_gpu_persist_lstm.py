@@ -1,0 +1,159 @@
+"""Persistent BiLSTM launches (csrc/persist_lstm.hip): all T steps of both directions in one launch, forward and BPTT, against the
+launch-per-step pair drivers (mstts_lstm_seq_fwd_pair / mstts_lstm_seq_bwd_pair, themselves checked against the oracle in
+test_gpu_ops.py / test_gpu_model.py) on the same buffers: ragged lengths, reversed direction, zoneout masks, fewer than 32 rows."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from multi_speaker_tts_amd import lib
+from tests.helpers import rel_err, t2n
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+def _setup(dev, B, T, seed, zoneout=0.1):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)
+    lens = torch.randint(max(1, T // 3), T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = T
+    if B > 1:
+        lens[1] = 1
+    st = {"B": B, "T": T, "lens": lens.to(dev), "zoneout": zoneout}
+    for dr in ("fw", "bw"):
+        st["wh_" + dr] = r(H, 4 * H, scale=0.06)
+        st["xw_" + dr] = r(B, T, 4 * H, scale=0.8)
+        st["zc_" + dr] = (torch.rand(T, B, H, generator=g) > zoneout).to(torch.uint8).to(dev)
+        st["zh_" + dr] = (torch.rand(T, B, H, generator=g) > zoneout).to(torch.uint8).to(dev)
+        st["dout_" + dr] = r(B, T, H, scale=0.5)
+    return st
+
+
+def _fwd_bufs(dev, B, T):
+    z = lambda *s: torch.full(s, float("nan"), device=dev)
+    o = {"out": torch.zeros(B, T, 2 * H, device=dev)}
+    for dr in ("fw", "bw"):
+        o["c_" + dr], o["h_" + dr] = z(T + 1, B, H), z(T + 1, B, H)
+        o["acts_" + dr], o["craw_" + dr] = z(T, B, 4 * H), z(T, B, H)
+    return o
+
+
+def _fwd_descs(st, o, extra):
+    B, T = st["B"], st["T"]
+    qs = []
+    for di, dr in enumerate(("fw", "bw")):
+        q = lib.LstmSeqFwd()
+        q.B, q.T, q.H = B, T, H
+        q.xw = lib.ptr(st["xw_" + dr]); q.wh = lib.ptr(st["wh_" + dr]); q.wh_ld = 4 * H
+        q.lengths = lib.ptr(st["lens"]); q.reverse = di; q.zoneout = st["zoneout"]
+        q.zc = lib.ptr(st["zc_" + dr]); q.zh = lib.ptr(st["zh_" + dr])
+        q.out = lib.ptr(o["out"], di * H); q.out_sb = T * 2 * H; q.out_st = 2 * H
+        q.c_hist = lib.ptr(o["c_" + dr]); q.h_hist = lib.ptr(o["h_" + dr]); q.acts = lib.ptr(o["acts_" + dr]); q.c_raw = lib.ptr(o["craw_" + dr])
+        if extra is not None:
+            q.gates_ws = lib.ptr(extra["gates_" + dr])
+        qs.append(q)
+    return qs
+
+
+def _run_fwd(dev, st, persistent):
+    B, T = st["B"], st["T"]
+    L = lib.load()
+    o = _fwd_bufs(dev, B, T)
+    if persistent:
+        assert L.mstts_persist_lstm_supported(B, H)
+        n = L.mstts_persist_lstm_pack_floats()
+        pk = {}
+        for dr in ("fw", "bw"):
+            pk[dr], pk["t" + dr] = torch.empty(n, device=dev), torch.empty(n, device=dev)
+            lib.call("mstts_persist_lstm_pack", lib.ptr(st["wh_" + dr]), 4 * H, lib.ptr(pk[dr]), lib.ptr(pk["t" + dr]))
+        xch = torch.empty(L.mstts_persist_lstm_ws_bytes() // 4, device=dev)
+        ctrl = torch.zeros(16, dtype=torch.int32, device=dev)
+        hist = torch.empty(L.mstts_persist_lstm_hist_floats(T), device=dev)
+        qs = _fwd_descs(st, o, None)
+        lib.call("mstts_lstm_seq_fwd_pair_persistent", C.byref(qs[0]), C.byref(qs[1]), lib.ptr(pk["fw"]), lib.ptr(pk["bw"]), lib.ptr(xch), lib.ptr(ctrl), lib.ptr(hist))
+        torch.cuda.synchronize()
+        c = ctrl.cpu().numpy()
+        assert c[1] == 0 and c[2] == 64, c[:4]
+        o["pk"], o["xch"], o["ctrl"], o["hist"] = pk, xch, ctrl, hist
+    else:
+        extra = {"gates_" + dr: torch.empty(L.mstts_lstm_seq_ws_floats(B, H, 0), device=dev) for dr in ("fw", "bw")}
+        qs = _fwd_descs(st, o, extra)
+        lib.call("mstts_lstm_seq_fwd_pair", C.byref(qs[0]), C.byref(qs[1]))
+        torch.cuda.synchronize()
+    return o
+
+
+def _run_bwd(dev, st, o, persistent):
+    B, T = st["B"], st["T"]
+    L = lib.load()
+    r = {}
+    qs = []
+    for di, dr in enumerate(("fw", "bw")):
+        r["dgs_" + dr] = torch.full((T, B, 4 * H), float("nan"), device=dev)
+        r["dgp_" + dr] = torch.full((B, T, 4 * H), float("nan"), device=dev)
+        q = lib.LstmSeqBwd()
+        q.B, q.T, q.H = B, T, H
+        q.wh = lib.ptr(st["wh_" + dr]); q.wh_ld = 4 * H
+        q.lengths = lib.ptr(st["lens"]); q.reverse = di; q.zoneout = st["zoneout"]
+        q.zc = lib.ptr(st["zc_" + dr]); q.zh = lib.ptr(st["zh_" + dr])
+        q.d_out = lib.ptr(st["dout_" + dr]); q.dout_sb = T * H; q.dout_st = H
+        q.c_hist = lib.ptr(o["c_" + dr]); q.acts = lib.ptr(o["acts_" + dr]); q.c_raw = lib.ptr(o["craw_" + dr])
+        q.dgates_step = lib.ptr(r["dgs_" + dr]); q.dgates_pos = lib.ptr(r["dgp_" + dr])
+        r["ws_" + dr] = torch.empty(L.mstts_lstm_seq_ws_floats(B, H, 1), device=dev)
+        q.ws = lib.ptr(r["ws_" + dr])
+        qs.append(q)
+    if persistent:
+        pk, xch, ctrl = o["pk"], o["xch"], o["ctrl"]
+        r["bws"] = torch.empty(L.mstts_persist_lstm_bwd_floats(T), device=dev)
+        lib.call("mstts_lstm_seq_bwd_pair_persistent", C.byref(qs[0]), C.byref(qs[1]), lib.ptr(pk["tfw"]), lib.ptr(pk["tbw"]), lib.ptr(xch), lib.ptr(ctrl),
+                 lib.ptr(o["hist"]), lib.ptr(r["bws"]))
+        torch.cuda.synchronize()
+        c = ctrl.cpu().numpy()
+        assert c[1] == 0 and c[2] == 32, c[:4]
+    else:
+        lib.call("mstts_lstm_seq_bwd_pair", C.byref(qs[0]), C.byref(qs[1]))
+        torch.cuda.synchronize()
+    return r
+
+
+@pytest.mark.parametrize("B,T", [(32, 128), (5, 9), (17, 40), (1, 1)])
+def test_persistent_bilstm_equals_launch_per_step(dev, B, T):
+    st = _setup(dev, B, T, seed=100 + B)
+    ref = _run_fwd(dev, st, False)
+    got = _run_fwd(dev, st, True)
+    for k in ("out", "c_fw", "h_fw", "acts_fw", "craw_fw", "c_bw", "h_bw", "acts_bw", "craw_bw"):
+        a, b = t2n(got[k]), t2n(ref[k])
+        assert np.isfinite(a).all(), k
+        assert rel_err(a, b) < 2e-5, (k, rel_err(a, b))
+    # BPTT: the launch-per-step pair on its own forward's row-major histories, the persistent launch on the packed history of its forward
+    rb = _run_bwd(dev, st, ref, False)
+    gb = _run_bwd(dev, st, got, True)
+    for k in ("dgs_fw", "dgp_fw", "dgs_bw", "dgp_bw"):
+        a, b = t2n(gb[k]), t2n(rb[k])
+        if k.startswith("dgp"):                 # positions past a row's length are written by neither path in the reversed direction
+            m = np.isfinite(b)
+            assert np.array_equal(m, np.isfinite(a)), k
+            a, b = np.where(m, a, 0.0), np.where(m, b, 0.0)
+        assert np.isfinite(a).all(), k
+        assert rel_err(a, b) < 5e-5, (k, rel_err(a, b))
+
+
+def test_persistent_bilstm_is_deterministic_and_reusable(dev):
+    """Two runs give identical bits; a second sequence through the same ring / control buffers (stale generations) is right as well."""
+    st = _setup(dev, 32, 64, seed=7)
+    a = _run_fwd(dev, st, True)
+    b = _run_fwd(dev, st, True)
+    assert np.array_equal(t2n(a["out"]), t2n(b["out"])) and np.array_equal(t2n(a["c_bw"]), t2n(b["c_bw"]))
+    st2 = _setup(dev, 32, 64, seed=8)
+    ref2 = _run_fwd(dev, st2, False)
+    L = lib.load()
+    o = _fwd_bufs(dev, 32, 64)
+    qs = _fwd_descs(st2, o, None)
+    for dr in ("fw", "bw"):
+        lib.call("mstts_persist_lstm_pack", lib.ptr(st2["wh_" + dr]), 4 * H, lib.ptr(a["pk"][dr]), lib.ptr(a["pk"]["t" + dr]))
+    lib.call("mstts_lstm_seq_fwd_pair_persistent", C.byref(qs[0]), C.byref(qs[1]), lib.ptr(a["pk"]["fw"]), lib.ptr(a["pk"]["bw"]), lib.ptr(a["xch"]), lib.ptr(a["ctrl"]),
+             lib.ptr(a["hist"]))
+    torch.cuda.synchronize()
+    assert rel_err(t2n(o["out"]), t2n(ref2["out"])) < 2e-5

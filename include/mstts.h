@@ -595,11 +595,17 @@ typedef struct {
     int32_t near_xcd;             /* != 0: hand-offs whose producer and all consumers report the same hardware XCC id at the start rendezvous are
                                      published with plain stores and stay in that XCD's L2 (-3 ms per step); every launch first drops its
                                      XCDs' copies of those rings.  0: every hand-off write-through (placement never matters for correctness) */
+    const float* pre; const float* b0;
+                                  /* forward only, optional: the prenet output [S, B, 256] (step-major, 16-byte aligned) and the cell-0 bias [4H].
+                                     When given, the launch forms the prenet rows' share of the cell-0 gates itself (8 more k-steps per wave,
+                                     kernel rows from the wx0 argument of mstts_persist_pack) and ignores mstts_decoder_train_desc.xw0: the
+                                     caller skips that [S B, 256] x [256, 4H] product and its 16 KB-per-row tensor.  NULL: xw0 is read. */
 } mstts_persist_desc;
 int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
 int64_t mstts_persist_fwd_ws_bytes(void);
 int64_t mstts_persist_pack_floats(int32_t which);
-int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s);
+/* wx0: the prenet rows [256, 4H] of the cell-0 kernel (row stride 4H), or NULL (zeros are packed: the launch then needs xw0) */
+int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, const float* wx0, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s);
 int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc* d, const mstts_persist_desc* p, mstts_stream_t s);
 int64_t mstts_persist_opk_floats(int64_t S);
 int mstts_persist_unpack_history(const float* opk, const mstts_decoder_train_desc* d, mstts_stream_t s);

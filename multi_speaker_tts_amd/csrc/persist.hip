@@ -46,6 +46,7 @@ constexpr int NSTAMP = 16;
 struct PersistFwd {
     const float* w0pk; const float* w1pk; const float* wqpk;
     const float* xw0; const float* b1;
+    const float* pre; const float* b0;           // FOLD: prenet output [S, B, 256] and the cell-0 bias - the hoisted product xw0 is then formed inside the loop
     const uint8_t* zc0; const uint8_t* zh0; const uint8_t* zc1; const uint8_t* zh1; float keep;
     const float* keys; const float* values; const int32_t* lengths;
     const float* loc_k; const float* loc_b; const float* score_w; const float* score_b;
@@ -112,7 +113,9 @@ __device__ __forceinline__ CellOut cell_update(const pf32x4& gs, const float (&a
     return o;
 }
 
-template <bool PROF>
+// FOLD: the prenet rows of the cell-0 kernel ride along with the context rows (8 more k-steps per wave on the matrix cores) instead of
+// arriving as a hoisted [S B, 4096] product: no 420 MB tensor written by a GEMM and read back by row-strided loads in every step.
+template <bool PROF, bool FOLD>
 __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g0 = blockIdx.x, tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -137,12 +140,12 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     const bool near = sflag[1] != 0;          // this workgroup's slice group shares one XCD: intra-group pieces may stay in its L2
 
     // ---------------- once: this workgroup's constants.  Cell kernels -> registers (MFMA A operands), wave v = gate-column group v of the tile:
-    //   w0[ks]: k-steps 0..23 = context rows of reduction slice gi, 24..55 = its h0 rows; w1[ks]: 0..31 = m0 rows, 32..63 = h1 rows
-    float w0[56], w1[64];
+    //   w0[ks]: k-steps 0..23 = context rows of reduction slice gi, 24..31 = its prenet rows (FOLD), 32..63 = its h0 rows; w1[ks]: 0..31 = m0 rows, 32..63 = h1 rows
+    float w0[64], w1[64];
     {
-        const float* p0 = d.w0pk + ((long)(g * 8 + wave) * 56) * 64 + lane;
+        const float* p0 = d.w0pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 56; ++r) w0[r] = p0[r * 64];
+        for (int r = 0; r < 64; ++r) w0[r] = (FOLD || r < 24 || r >= 32) ? p0[r * 64] : 0.f;
         const float* p1 = d.w1pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 64; ++r) w1[r] = p1[r * 64];
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     int et = wave & 1, er = 16 * et + (lane & 15), ee = lane >> 4, eu = 4 * g + ee;
     bool ew = wave < 2, elive = ew && er < B;
     float c0s = 0.f, h0s = 0.f, c1s = 0.f, h1s = 0.f;
-    float b1v[4];
+    float b1v[4], b0v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b1v[q] = d.b1[q * PH + eu];
+    for (int q = 0; q < 4; ++q) { b1v[q] = d.b1[q * PH + eu]; b0v[q] = FOLD ? d.b0[q * PH + eu] : 0.f; }
     pf32x4 acc0[2], acc1[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) { acc0[b] = (pf32x4){0.f, 0.f, 0.f, 0.f}; acc1[b] = acc0[b]; }
@@ -226,13 +229,20 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     // outside any condition, and consumed by every wave (waves 2..7 repeat the update of waves 0 / 1 and drop the result): a load that is
     // issued or consumed under a condition stays "pending" for the compiler's wait-count pass, and the s_waitcnt vmcnt it then places
     // also waits for write-through stores that have nothing to do with it.
-    float xwv[4];
+    float xwv[4] = {0.f, 0.f, 0.f, 0.f};
+    pf32x4 prv = {0.f, 0.f, 0.f, 0.f};           // FOLD: this thread's 16 bytes of the step's prenet slice (staging row rho = (tid & 255) >> 1, half tid & 1)
     uint8_t zc0v, zh0v, zc1v, zh1v;
 #define LOAD_OPERANDS(ST) do { const long b__ = (long)(ST) * B; const unsigned r__ = (16 * (wave0 & 1) + (tid0 & 15)) < (unsigned)B ? 16 * (wave0 & 1) + (tid0 & 15) : 0u;  \
         /* (waves 2..7 only repeat the update: their lanes all read ONE address, a single cache-line request instead of 16 scattered ones) */ \
         const unsigned u__ = 4 * g0 + ((tid0 & 63) >> 4), h__ = wave0 < 2 ? r__ * PH + u__ : 0u, q__ = wave0 < 2 ? r__ * 4 * PH + u__ : 0u;                                     \
-        const float* xw__ = d.xw0 + b__ * 4 * PH;                                                                                           \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) xwv[q] = xw__[q__ + q * PH];                                                           \
+        if (FOLD) {                                                                                                                         \
+            const unsigned rho__ = ((unsigned)tid0 & 255u) >> 1, pb__ = 16 * ((rho__ >> 4) & 1u) + (rho__ & 15u);                                     \
+            const pf32x4 v__ = *reinterpret_cast<const pf32x4*>(d.pre + (b__ + (pb__ < (unsigned)B ? pb__ : 0u)) * 256 + 32 * (g0 & 7) + 8 * (rho__ >> 5) + 4 * ((unsigned)tid0 & 1u)); \
+            prv = pb__ < (unsigned)B ? v__ : (pf32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+        } else {                                                                                                                            \
+            const float* xw__ = d.xw0 + b__ * 4 * PH;                                                                                       \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) xwv[q] = xw__[q__ + q * PH];                                                       \
+        }                                                                                                                                   \
         zc0v = (d.zc0 + b__ * PH)[h__]; zh0v = (d.zh0 + b__ * PH)[h__]; zc1v = (d.zc1 + b__ * PH)[h__]; zh1v = (d.zh1 + b__ * PH)[h__]; } while (0)
     LOAD_OPERANDS(0);
 
@@ -259,14 +269,31 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         unsigned soff[2], poff[4], roff[1];                          // requests in flight: a slice, the partial tiles, a row piece
         pf32x4 sv[2], pv[4], rv[1];
         // ================= A: cell 0, context rows.  In the shadow of the ctx_{s-1} hand-off: second half of h1_{s-1} . W1[h rows]
-        if (s > 0) {
+        if (FOLD) {
+            // context slice (ring, columns 0..23 of the staging rows; zeros at step 0) + prenet slice (requested one step ahead, columns 24..31)
             PSTAMP(0);
-            slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
-            if (!slice_complete<6, LC>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
+            if (s > 0) {
+                slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
+                if (!slice_complete<6, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
+            } else {
+                const pf32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                { const int rho = tid / 6, k4 = tid - rho * 6; *reinterpret_cast<pf32x4*>(stg + rho * LA + 4 * k4) = z4; }
+                if (tid + PTH < 768) { const int pp = tid + PTH, rho = pp / 6, k4 = pp - rho * 6; *reinterpret_cast<pf32x4*>(stg + rho * LA + 4 * k4) = z4; }
+            }
+            if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
             PABORT_CHECK();
             PSTAMP(1);
+            mfma_part<0, 8, LA, 0, 64>(w0, stg, lane, acc0);
+        } else {
+            if (s > 0) {
+                PSTAMP(0);
+                slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
+                if (!slice_complete<6, LC>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
+                PABORT_CHECK();
+                PSTAMP(1);
+            }
+            if (s > 0) mfma_part<0, 6, LC, 0, 64>(w0, stg, lane, acc0);
         }
-        if (s > 0) mfma_part<0, 6, LC, 0, 56>(w0, stg, lane, acc0);
         PUBLISH_PARTIAL(OFF_P0, acc0)
         PSTAMP(2);
         // in the shadow of the partial-gates hand-off (the longest wait of the step, and the staging buffer is free): h1_{s-1} . W1[h rows]
@@ -287,7 +314,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             const pf32x4 gs = SUM_PARTIALS();
             float add0[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) add0[q] = rowok ? xwv[q] : 0.f;
+            for (int q = 0; q < 4; ++q) add0[q] = FOLD ? b0v[q] : (rowok ? xwv[q] : 0.f);
             const float cprev0 = c0s;
             const CellOut o = cell_update(gs, add0, c0s, h0s, (zc0v || !rowok) ? d.keep : 0.f, (zh0v || !rowok) ? d.keep : 0.f);
             if (ew) {
@@ -333,7 +360,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         __syncthreads();                                             // m0 is consumed by every wave
         if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
         PABORT_CHECK();
-        mfma_part<0, 4, LA, 24, 56>(w0, stg, lane, acc0);
+        mfma_part<0, 4, LA, 32, 64>(w0, stg, lane, acc0);
         PSTAMP(7);
         // ================= D: sum of the eight partials, cell-1 update
         ISSUE_PARTIALS(OFF_P1)
@@ -378,7 +405,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
         PSTAMP(9);
         // in the shadow of the m1 hand-off: second half of h0_s . W0[h rows]
-        mfma_part<4, 8, LA, 24, 56>(w0, stg, lane, acc0);
+        mfma_part<4, 8, LA, 32, 64>(w0, stg, lane, acc0);
         PSTAMP(10);
         // ================= E: attention, query units and partial energies of row ab
         if (arow) {
@@ -523,23 +550,24 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 // k-step ks of a 128-unit recurrent slice: q = lane >> 4 -> producer column slice j' = 4 (ks / 4) + q, unit 32 j' + 4 i + ks % 4
 __device__ __forceinline__ int unit_of_kstep(int gi, int ks, int q) { return 32 * (4 * (ks >> 2) + q) + 4 * gi + (ks & 3); }
 
-__global__ void persist_pack_cells_kernel(const float* __restrict__ w0f, const float* __restrict__ w1, float* __restrict__ w0pk, float* __restrict__ w1pk) {
-    const long n0 = 256L * 8 * 56 * 64, n1 = 256L * 8 * 64 * 64;
+__global__ void persist_pack_cells_kernel(const float* __restrict__ w0f, const float* __restrict__ w1, const float* __restrict__ wx0, float* __restrict__ w0pk, float* __restrict__ w1pk) {
+    const long n0 = 256L * 8 * 64 * 64, n1 = 256L * 8 * 64 * 64;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n0 + n1; p += (long)gridDim.x * blockDim.x) {
         const bool c1 = p >= n0;
         long r = c1 ? p - n0 : p;
         const int lane = (int)(r & 63); r >>= 6;
-        const int per = c1 ? 64 : 56;
-        const int ks = (int)(r % per); r /= per;
+        const int ks = (int)(r & 63); r >>= 6;
         const int wave = (int)(r & 7), g = (int)(r >> 3);
         const int gi = g & 7, gj = g >> 3;
         const int q = lane >> 4, mcol = lane & 15, ue = mcol >> 2, gate = mcol & 3;
         const int u = 32 * gj + 4 * wave + ue;
         const long col = (long)gate * PH + u;
         long row;
-        if (!c1) row = ks < 24 ? 96 * gi + 24 * q + ks : PM + unit_of_kstep(gi, ks - 24, q);
+        // cell 0: k-steps 0..23 context rows 96 gi + 24 q + ks, 24..31 prenet rows 32 gi + 8 q + (ks - 24) of wx0 (zeros without it), 32..63 h0 rows
+        if (!c1) row = ks < 24 ? 96 * gi + 24 * q + ks : ks < 32 ? 32 * gi + 8 * q + (ks - 24) : PM + unit_of_kstep(gi, ks - 32, q);
         else row = ks < 32 ? unit_of_kstep(gi, ks, q) : PH + unit_of_kstep(gi, ks - 32, q);
-        if (c1) w1pk[p - n0] = w1[row * 4 * PH + col]; else w0pk[p] = w0f[row * 4 * PH + col];
+        if (c1) w1pk[p - n0] = w1[row * 4 * PH + col];
+        else w0pk[p] = (ks >= 24 && ks < 32) ? (wx0 ? wx0[row * 4 * PH + col] : 0.f) : w0f[row * 4 * PH + col];
     }
 }
 // query kernel by unit slice gi: [8][8 x4][512 threads][4] - thread (unit ak = tid & 15, hidden-unit group atg = tid >> 4) finds rows
@@ -555,7 +583,7 @@ __global__ void persist_pack_wq_kernel(const float* __restrict__ wq, float* __re
 using namespace mstts;
 
 extern "C" int64_t mstts_persist_fwd_ws_bytes(void) { return XCH_FLOATS * 4; }
-extern "C" int64_t mstts_persist_pack_floats(int32_t which) { return which == 0 ? 256L * 8 * 56 * 64 : which == 1 ? 256L * 8 * 64 * 64 : 8L * 64 * 256; }
+extern "C" int64_t mstts_persist_pack_floats(int32_t which) { return which == 0 ? 256L * 8 * 64 * 64 : which == 1 ? 256L * 8 * 64 * 64 : 8L * 64 * 256; }
 
 /* 1 when the persistent loop can run this shape on the current device: reference widths, at most 32 rows and 128 encoder
  * positions, 31 filter taps, and a device that takes all 256 workgroups at once (one per CU - the occupancy query must admit the
@@ -568,9 +596,12 @@ extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, 
         cached = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= PWG) {
             const size_t lds = (size_t)S_FLOATS * 4;
-            if (hipFuncSetAttribute((const void*)persist_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipFuncSetAttribute((const void*)persist_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false>, PTH, lds) == hipSuccess && per_cu >= 1)
+            if (hipFuncSetAttribute((const void*)persist_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)persist_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)persist_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipFuncSetAttribute((const void*)persist_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, true>, PTH, lds) == hipSuccess && per_cu >= 1 &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, false>, PTH, lds) == hipSuccess && per_cu >= 1)
                 cached = 1;
         }
         (void)hipGetLastError();
@@ -578,9 +609,9 @@ extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, 
     return cached;
 }
 
-extern "C" int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s) {
+extern "C" int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, const float* wx0, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s) {
     MSTTS_REQUIRE(w0f && w1 && wq && w0pk && w1pk && wqpk, MSTTS_ERR_SHAPE, "persist_pack: null pointer");
-    hipLaunchKernelGGL(persist_pack_cells_kernel, dim3(4096), dim3(256), 0, (hipStream_t)s, w0f, w1, w0pk, w1pk);
+    hipLaunchKernelGGL(persist_pack_cells_kernel, dim3(4096), dim3(256), 0, (hipStream_t)s, w0f, w1, wx0, w0pk, w1pk);
     MSTTS_CHECK_LAUNCH("persist_pack_cells");
     hipLaunchKernelGGL(persist_pack_wq_kernel, dim3(8 * 64), dim3(256), 0, (hipStream_t)s, wq, wqpk);
     MSTTS_CHECK_LAUNCH("persist_pack_wq");
@@ -588,7 +619,8 @@ extern "C" int mstts_persist_pack(const float* w0f, const float* w1, const float
 }
 
 extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc* d, const mstts_persist_desc* p, mstts_stream_t s) {
-    MSTTS_REQUIRE(d && p && d->xw0 && d->b1 && d->in0 && d->in1 && d->pj && d->c0 && d->c1 && d->acts0 && d->acts1 && d->craw0 && d->craw1 &&
+    const bool fold = p && p->pre != nullptr;
+    MSTTS_REQUIRE(d && p && (fold ? p->b0 != nullptr : d->xw0 != nullptr) && d->b1 && d->in0 && d->in1 && d->pj && d->c0 && d->c1 && d->acts0 && d->acts1 && d->craw0 && d->craw1 &&
                   d->q_hist && d->align_hist && d->cum_hist && p->w0pk && p->w1pk && p->wqpk && p->xch && p->ctrl, MSTTS_ERR_SHAPE,
                   "decoder_train_fwd_persistent: null pointer");
     const long B = d->B, S = d->S, H = d->H, M = d->lsa.M, A = d->lsa.A, T = d->lsa.T;
@@ -609,7 +641,8 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
     if (e == hipSuccess) e = hipMemsetAsync(p->ctrl, 0, PCTRL_WORDS * sizeof(unsigned), hs);
     if (e != hipSuccess) return set_err(MSTTS_ERR_LAUNCH, "decoder_train_fwd_persistent: memset: %s", hipGetErrorString(e));
     PersistFwd a;
-    a.w0pk = p->w0pk; a.w1pk = p->w1pk; a.wqpk = p->wqpk; a.xw0 = d->xw0; a.b1 = d->b1;
+    MSTTS_REQUIRE(!fold || (d->P == 256 && aligned16(p->pre)), MSTTS_ERR_SHAPE, "decoder_train_fwd_persistent: the folded prenet product needs a 256-wide prenet, 16-byte aligned");
+    a.w0pk = p->w0pk; a.w1pk = p->w1pk; a.wqpk = p->wqpk; a.xw0 = d->xw0; a.b1 = d->b1; a.pre = p->pre; a.b0 = p->b0;
     a.zc0 = d->zc0; a.zh0 = d->zh0; a.zc1 = d->zc1; a.zh1 = d->zh1; a.keep = 1.f - d->zoneout;
     a.keys = d->lsa.keys; a.values = d->lsa.values; a.lengths = d->lsa.lengths;
     a.loc_k = d->lsa.loc_k; a.loc_b = d->lsa.loc_b; a.score_w = d->lsa.score_w; a.score_b = d->lsa.score_b;
@@ -618,8 +651,13 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
     a.craw0 = d->craw0; a.craw1 = d->craw1; a.q_hist = d->q_hist; a.align_hist = d->align_hist; a.cum_hist = d->cum_hist;
     a.opk = p->opk; a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
     const size_t lds = (size_t)S_FLOATS * 4;
-    if (p->stamps) hipLaunchKernelGGL(persist_fwd_kernel<true>, dim3(PWG), dim3(PTH), lds, hs, a);
-    else hipLaunchKernelGGL(persist_fwd_kernel<false>, dim3(PWG), dim3(PTH), lds, hs, a);
+    if (fold) {
+        if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, true>), dim3(PWG), dim3(PTH), lds, hs, a);
+        else hipLaunchKernelGGL((persist_fwd_kernel<false, true>), dim3(PWG), dim3(PTH), lds, hs, a);
+    } else {
+        if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, false>), dim3(PWG), dim3(PTH), lds, hs, a);
+        else hipLaunchKernelGGL((persist_fwd_kernel<false, false>), dim3(PWG), dim3(PTH), lds, hs, a);
+    }
     MSTTS_CHECK_LAUNCH("persist_fwd");
     return MSTTS_OK;
 }

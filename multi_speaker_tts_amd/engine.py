@@ -196,7 +196,7 @@ class TrainEngine:
         if self.wq_t is not None:
             call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
         if self.persist:
-            call("mstts_persist_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]))
+            call("mstts_persist_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(k0, o0), ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]))
         if self.persist_bwd:
             call("mstts_persist_bwd_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(self.pkb[0]), ptr(self.pkb[1]), ptr(self.pkb[2]))
         if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
@@ -432,7 +432,11 @@ class TrainEngine:
             call("mstts_dropout", ptr(w.pre_a[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(w.pre_d[i]), S * B * Pn)
             x, cin = w.pre_d[i], Pn
         k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
-        self._gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
+        # cell-0 input product xw0 = prenet . W0[:P] + b0: inside the persistent launch (fp32 mode, 256-wide prenet), else hoisted here
+        w.fold_prenet = bool(w.persist) and self.gemm_dtype == "f32" and Pn == 256 and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"
+        xw0_product = lambda: self._gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
+        if not w.fold_prenet:
+            xw0_product()
         # ---- decoder loop
         dec = w.dec
         dec.B, dec.S, dec.H, dec.P = B, S, H, Pn
@@ -471,6 +475,7 @@ class TrainEngine:
             w.opk_valid = pd.opk is not None
             pd.selftest_fail_step = int(self.persist_selftest)
             pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
+            pd.pre, pd.b0 = (ptr(x), ptr(b0, ob0)) if w.fold_prenet else (None, None)
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
             ev.record()
@@ -492,6 +497,8 @@ class TrainEngine:
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
                 cur.synchronize()
                 w.opk_valid = False                   # the launch-per-step loop writes the row-major histories
+                if w.fold_prenet:
+                    xw0_product()                     # ... and reads the hoisted cell-0 input product
                 call("mstts_decoder_train_fwd", C.byref(dec))
                 self._forward_tail(w)
         return w

@@ -93,7 +93,7 @@ class DecoderTrain(C.Structure):
 
 
 class PersistDesc(C.Structure):
-    _fields_ = [("w0pk", vp), ("w1pk", vp), ("wqpk", vp), ("xch", vp), ("ctrl", vp), ("stamps", vp), ("opk", vp), ("selftest_fail_step", i32), ("near_xcd", i32)]
+    _fields_ = [("w0pk", vp), ("w1pk", vp), ("wqpk", vp), ("xch", vp), ("ctrl", vp), ("stamps", vp), ("opk", vp), ("selftest_fail_step", i32), ("near_xcd", i32), ("pre", vp), ("b0", vp)]
 
 
 class DecoderTrainBwd(C.Structure):
@@ -217,7 +217,7 @@ SIGNATURES = {
     "mstts_persist_fwd_supported": (i32, [i64, i64, i64, i64, i64, i64]),
     "mstts_persist_fwd_ws_bytes": (i64, []),
     "mstts_persist_pack_floats": (i64, [i32]),
-    "mstts_persist_pack": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+    "mstts_persist_pack": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "mstts_decoder_train_fwd_persistent": (i32, [P(DecoderTrain), P(PersistDesc), vp]),
     "mstts_persist_opk_floats": (i64, [i64]),
     "mstts_persist_unpack_history": (i32, [vp, P(DecoderTrain), vp]),

@@ -226,7 +226,11 @@ def test_persistent_launches_back_to_back_on_changed_inputs(dev):
     batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=13, ragged=True), dev)
     w = eng.plan(B, Te, L)
     eng.forward(batch, w, seed=5)                         # launch A (inside), on the original inputs
-    w.xw0.mul_(0.5)
+    w.pre_d[-1].mul_(0.5)                                 # changed input of launch B (the folded form reads the prenet output, the
+    od_ = eng.d                                           # launch-per-step loop below its hoisted product xw0 = pre . W0[:P] + b0)
+    k0, o0 = eng.P("decoder/decoder/attention_wrapper/multi_rnn_cell/cell_0/zoneout_lstm_cell/kernel")
+    b0, ob0 = eng.P("decoder/decoder/attention_wrapper/multi_rnn_cell/cell_0/zoneout_lstm_cell/bias")
+    lib.gemm(w.pre_d[-1], k0, w.xw0, w.S * B, 4 * od_.dec_lstm, od_.prenet, od_.prenet, 4 * od_.dec_lstm, 4 * od_.dec_lstm, bias=b0, b_off=o0, bias_off=ob0)
     lib.call("mstts_decoder_train_fwd_persistent", C.byref(w.dec), C.byref(w.pdesc))        # launch B, directly behind
     torch.cuda.synchronize()
     st = w.pctrl.cpu().numpy()

@@ -328,7 +328,7 @@ def main():
             return res
 
         persistent = bool(getattr(w, "persist", False))
-        stage_names = ["loop top", "wait ctx", "cell0 ctx product + publish", "wait partials0", "cell0 update + publish",
+        stage_names = ["loop top + prenet rows of cell 0 (in the shadow of the context hand-off)", "wait ctx", "cell0 ctx product + publish", "wait partials0", "cell0 update + publish",
                        "wait m0", "cell1 m0 product + publish", "shadow: stage h0 + h0 half 1", "wait partials1", "cell1 update + publish",
                        "shadow: h0 half 2", "wait m1 row", "query + partial energies + publish", "shadow: stage h1 + h1 product", "wait energies",
                        "softmax + context + publish"]

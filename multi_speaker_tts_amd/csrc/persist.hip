@@ -270,20 +270,19 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         pf32x4 sv[2], pv[4], rv[1];
         // ================= A: cell 0, context rows.  In the shadow of the ctx_{s-1} hand-off: second half of h1_{s-1} . W1[h rows]
         if (FOLD) {
-            // context slice (ring, columns 0..23 of the staging rows; zeros at step 0) + prenet slice (requested one step ahead, columns 24..31)
-            PSTAMP(0);
+            // prenet slice of this step (requested one step ahead) -> columns 24..31 of the staging rows, multiplied at once: this runs in the
+            // shadow of the context hand-off, which has nothing else to hide behind; then the context slice (columns 0..23) when it arrives
+            if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
+            __syncthreads();
+            mfma_part<6, 8, LA, 0, 64>(w0, stg, lane, acc0);
             if (s > 0) {
+                PSTAMP(0);
                 slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
                 if (!slice_complete<6, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
-            } else {
-                const pf32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                { const int rho = tid / 6, k4 = tid - rho * 6; *reinterpret_cast<pf32x4*>(stg + rho * LA + 4 * k4) = z4; }
-                if (tid + PTH < 768) { const int pp = tid + PTH, rho = pp / 6, k4 = pp - rho * 6; *reinterpret_cast<pf32x4*>(stg + rho * LA + 4 * k4) = z4; }
+                PABORT_CHECK();
+                PSTAMP(1);
+                mfma_part<0, 6, LA, 0, 64>(w0, stg, lane, acc0);
             }
-            if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
-            PABORT_CHECK();
-            PSTAMP(1);
-            mfma_part<0, 8, LA, 0, 64>(w0, stg, lane, acc0);
         } else {
             if (s > 0) {
                 PSTAMP(0);

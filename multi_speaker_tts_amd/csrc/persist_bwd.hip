@@ -29,7 +29,7 @@ namespace mstts {
 constexpr long BDG = 8L * 8 * 2 * 4 * 256;       // gate gradients of one cell: [slice 8][eighth 8][row tile 2][group 4][lane 64][4 units]
 constexpr long BPART = 256L * 8 * 32 * 4;        // partial product tiles: [reducer 256][source 8][row 32][4 units]
 constexpr long BPCTX = 32L * 192 * 8 * 4;        // partial d_ctx: [row 32][4-column block 192][source 8][4]
-constexpr long BDM1 = 32L * 8 * PH;              // query-layer data gradient: [row 32][slice 8][1024]
+constexpr long BDM1 = 32L * 8 * PH;              // query-layer data gradient: [owner 256][slice 8][row 32][4 units]
 constexpr long BDA = 32L * 8 * PT;               // partial d_alignment: [row 32][slice 8][128]
 constexpr long BO_DG1 = 0, BO_DG0 = BO_DG1 + PRING * BDG, BO_PM0 = BO_DG0 + PRING * BDG, BO_PH1 = BO_PM0 + PRING * BPART,
                BO_PH0 = BO_PH1 + PRING * BPART, BO_PCTX = BO_PH0 + PRING * BPART, BO_DM1 = BO_PCTX + PRING * BPCTX,
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         unsigned uoff[2];
         pf32x4 uv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #define ISSUE_UPDATE1() do { if (tid < 256) { const int row = tid >> 3, sl = tid & 7;                                                  \
-            uoff[0] = (unsigned)((BO_DM1 + slot * BDM1 + ((long)row * 8 + sl) * PH + 4 * g) * 4);                                     \
+            uoff[0] = (unsigned)((BO_DM1 + slot * BDM1 + (((long)g * 8 + sl) * 32 + row) * 4) * 4);                                   \
             uoff[1] = first ? uoff[0] : (unsigned)((BO_PH1 + nslot * BPART + (((long)g * 8 + sl) * 32 + row) * 4) * 4);               \
             issue<2>(xr, uoff, uv); } } while (0)
 #define ISSUE_UPDATE0() do { if (tid < 256) { const int row = tid >> 3, src = tid & 7;                                                 \
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                         out[e] += wv[0] * dq4[0] + wv[1] * dq4[1] + wv[2] * dq4[2] + wv[3] * dq4[3];
                     }
                 }
-                const long o = ((long)ab * 8 + gi) * PH + 4 * tid;
+                const long o = (((long)tid * 8 + gi) * 32 + ab) * 4;           // owner-major: the owner of units 4 tid .. polls ONE contiguous 4 KB block (row-major, its 256 pieces were 4 KB apart: 0.24 us of address processing per poll instruction)
                 xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), out, gen);
             }
             PSTAMP(4);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         } else {
             PSTAMP(0); PSTAMP(1); PSTAMP(2); PSTAMP(3);
             if (tid < 256) {        // rows past the batch: zeros, so that the cell owners' waits complete
-                const long o = ((long)ab * 8 + gi) * PH + 4 * tid;
+                const long o = (((long)tid * 8 + gi) * 32 + ab) * 4;
                 xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f}, gen);
             }
             PSTAMP(4);

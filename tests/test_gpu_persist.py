@@ -60,7 +60,7 @@ def test_persistent_equals_launch_per_step(dev, B, Te, L, ragged):
     for k in a:
         assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all(), k
         e = rel_err(a[k], b[k])
-        if e > (2e-4 if L > 20 else 2e-5):               # same fp32 products, different summation order
+        if e > (5e-4 if L > 20 else 5e-5):               # same fp32 products, different summation order (and atomics upstream of the loop: not bit-reproducible run to run)
             bad[k] = e
     assert not bad, bad
 

@@ -38,10 +38,20 @@ def learning_rate(step):
 
 def _split_k(M, N, K, n_cu=256, max_split=16):
     """Reduction split of a weight-gradient GEMM (atomic accumulation into the gradient slab).  128x128 output tiles are
-    spread round-robin over the CUs, so a CU runs ceil(tiles * sk / n_cu) workgroups of K / sk each: pick the sk with the
+    spread round-robin over the CUs, so a CU runs c = ceil(tiles * sk / n_cu) workgroups of K / sk each: pick the sk with the
     least work on the busiest CU (448 tiles: sk = 4 -> 7 per CU exactly, 127 TFLOP/s, where sk = 2 leaves 3.5 -> 4 per CU,
-    107 TFLOP/s; tools/gemm_split_probe.py), with a small per-split charge for the atomics."""
+    107 TFLOP/s; tools/gemm_split_probe.py), with a small per-split charge for the atomics.  Long reductions (the 25 632-row
+    products) also weigh HOW MANY workgroups share a CU: one per CU is one wave per SIMD, nothing hides its load / store phases
+    (2 560 x 512 x 25 632: sk = 3 -> 240 tiles, 91 TFLOP/s; sk = 9 -> 720 tiles = 3 per CU, 117 TFLOP/s)."""
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
+    if K >= 16384:
+        ktiles, best, best_cost = K / 32.0, 1, None
+        for sk in range(1, max_split + 1):
+            c = math.ceil(tiles * sk / n_cu)
+            cost = c * (ktiles / sk + 6.0) / (0.75 if c == 1 else 0.92 if c == 2 else 1.0) * (1.0 + 0.004 * sk)
+            if best_cost is None or cost < best_cost * (1.0 - 1e-9):
+                best, best_cost = sk, cost
+        return best
     best, best_cost = 1, None
     for sk in range(1, max_split + 1):
         if sk > 1 and K // sk < 512:

@@ -94,3 +94,17 @@ def test_top_level_drop_in_names():
     for name in ("Restore", "Train", "Inference"):
         assert callable(getattr(Tacotron2, name))
     assert list(inspect.signature(Tacotron2.Inference).parameters)[:4] == ["self", "path_List", "text_List", "file_Prefix"]
+
+
+def test_split_k_choices_of_the_train_step():
+    """Host logic: the reduction split of the weight-gradient products (engine._split_k).  The cases are the shapes of one config-2
+    step with the split that was measured best on the GPU (tools/gemm_step_profile.py): long reductions want three workgroups per CU,
+    shapes that already fill the chip whole rounds."""
+    from multi_speaker_tts_amd.engine import _split_k
+    assert _split_k(2560, 512, 25632) == 9          # postnet convolution gradients: 80 tiles -> 720 = 3 per CU (sk 3: 91, sk 9: 117 TFLOP/s)
+    assert _split_k(1792, 4096, 25632) == 4         # dw0f: 448 tiles -> 7 per CU exactly
+    assert _split_k(2048, 4096, 25632) in (1, 2)    # dW1: 512 tiles = 2 per CU either way
+    assert _split_k(2560, 512, 4096) == 3           # encoder convolution gradients (short reduction: the round model)
+    for M, N, K in ((256, 4096, 25632), (1024, 128, 25632), (80, 256, 25632), (512, 1024, 4096)):
+        sk = _split_k(M, N, K)
+        assert 1 <= sk <= 16 and (K < 16384 or K // sk >= 1024)

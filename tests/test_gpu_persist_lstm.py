@@ -157,3 +157,37 @@ def test_persistent_bilstm_is_deterministic_and_reusable(dev):
              lib.ptr(a["hist"]))
     torch.cuda.synchronize()
     assert rel_err(t2n(o["out"]), t2n(ref2["out"])) < 2e-5
+
+
+def test_train_step_with_and_without_the_persistent_encoder(dev, monkeypatch):
+    """A whole train step at the loop's reference widths three ways: encoder recurrence persistent both ways, persistent forward with the
+    BPTT falling back to the launch-per-step pair (which then reads the row-major history the unpack kernel wrote), and launch per step both
+    ways: every gradient agrees."""
+    from tests.test_gpu_persist import _engine
+    from tests.helpers import to_dev
+    from oracle import train as OT
+    eng, od = _engine(dev)
+    if not eng.persist_enc:
+        pytest.skip("persistent BiLSTM launches not available on this device")
+    B, Te, L = 8, 40, 6
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=21, ragged=True), dev)
+    seed = OT.step_seed(1234, 0)
+    w = eng.plan(B, Te, L)
+    assert w.persist_enc
+
+    def grads():
+        eng.forward(batch, w, seed=seed)
+        eng.loss_and_backward(w)
+        torch.cuda.synchronize()
+        return t2n(eng.params.grad).copy()
+
+    a = grads()
+    assert w.enc_hist_valid and eng.persist_enc_fallbacks == 0
+    real = eng._enc_persistent
+    monkeypatch.setattr(eng, "_enc_persistent", lambda w_, entry, seqs, which, n: False if which == 1 else real(w_, entry, seqs, which, n))
+    b = grads()                                           # persistent forward, launch-per-step BPTT
+    monkeypatch.setattr(eng, "_enc_persistent", lambda *a_, **k_: False)
+    c = grads()                                           # launch per step both ways
+    scale = np.abs(c).max()
+    assert np.abs(a - c).max() < 2e-4 * scale, np.abs(a - c).max() / scale
+    assert np.abs(b - c).max() < 2e-4 * scale, np.abs(b - c).max() / scale

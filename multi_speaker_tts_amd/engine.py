@@ -171,22 +171,21 @@ class TrainEngine:
     def G(self, name):
         return self.params.g(name)
 
-    def refresh_derived(self):
-        """Folded cell-0 kernel (context rows appear twice, SURVEY Q1) and the 4-column padded
-        projection kernel.  Must run after the variables change."""
-        d, ps = self.d, self.params
-        H, M, Pn = d.dec_lstm, d.mem, d.prenet
-        k0, o0 = self.P(CELL % 0 + "kernel")
-        call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(self.w0f), 2 * M + H, 4 * H, 0, M)
+    def _ensure_fallback_packs(self):
+        """Packed kernels of the launch-per-step loops (decoder cells forward / data-gradient products backward, encoder cells, the
+        transposed query kernel of the fused query gradient), refreshed at most once per optimizer step."""
+        if not getattr(self, "_fallback_packs_stale", True):
+            return
+        self._fallback_packs_stale = False
+        d = self.d
+        H, M = d.dec_lstm, d.mem
+        k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
         if self.fused_cells and self.bf is None:
-            k1, o1 = self.P(CELL % 1 + "kernel")
             call("mstts_pack_cell_fwd", ptr(self.w0f), 4 * H, ptr(self.w0p), M + H, H)
             call("mstts_pack_cell_fwd", ptr(k1, o1), 4 * H, ptr(self.w1p), 2 * H, H)
         if self.w0p16 is not None:
-            k1, o1 = self.P(CELL % 1 + "kernel")
             call("mstts_pack_cell_fwd_bf16", ptr(self.w0f), 4 * H, ptr(self.w0p16), M + H, H)
             call("mstts_pack_cell_fwd_bf16", ptr(k1, o1), 4 * H, ptr(self.w1p16), 2 * H, H)
-        k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
         if self.w0f_bp is not None:
             call("mstts_pack_skinny_bwd", ptr(self.w0f), 4 * H, ptr(self.w0f_bp), M + H, 4 * H, self.bwd_splits[0])
         if self.w1_bp is not None:
@@ -198,13 +197,27 @@ class TrainEngine:
             for dr in ("fw", "bw"):
                 ke, oke = self.P(ENC_CELL % dr + "kernel")
                 call("mstts_pack_cell_fwd", ptr(ke, oke + cin_e * 4 * He), 4 * He, ptr(self.enc_whp[dr]), He, He)
+        if self.wq_t is not None:
+            call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
+
+    def refresh_derived(self):
+        """Folded cell-0 kernel (context rows appear twice, SURVEY Q1) and the 4-column padded
+        projection kernel.  Must run after the variables change."""
+        d, ps = self.d, self.params
+        H, M, Pn = d.dec_lstm, d.mem, d.prenet
+        k0, o0 = self.P(CELL % 0 + "kernel")
+        call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(self.w0f), 2 * M + H, 4 * H, 0, M)
+        # the launch-per-step kernels' packed copies (cells, data-gradient products, encoder cells, transposed query kernel): every step where
+        # those loops run, on demand where the persistent launches do the work (_ensure_fallback_packs: ~0.1 ms of packing per step otherwise)
+        self._fallback_packs_stale = True
+        if not (self.persist and self.persist_bwd and self.persist_enc):
+            self._ensure_fallback_packs()
+        k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
         if self.persist_enc:
             cin_e, He = d.enc_conv_ch, d.enc_lstm
             for dr in ("fw", "bw"):
                 ke, oke = self.P(ENC_CELL % dr + "kernel")
                 call("mstts_persist_lstm_pack", ptr(ke, oke + cin_e * 4 * He), 4 * He, ptr(self.enc_pk[dr][0]), ptr(self.enc_pk[dr][1]))
-        if self.wq_t is not None:
-            call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
         if self.persist:
             call("mstts_persist_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(k0, o0), ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]))
         if self.persist_bwd:
@@ -428,6 +441,7 @@ class TrainEngine:
             seqs.append(q)
         w.enc_hist_valid = bool(getattr(w, "persist_enc", False)) and self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)
         if not w.enc_hist_valid:
+            self._ensure_fallback_packs()
             call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
         # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
         call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
@@ -491,6 +505,7 @@ class TrainEngine:
             ev.record()
         else:
             w.opk_valid = False
+            self._ensure_fallback_packs()
             call("mstts_decoder_train_fwd", C.byref(dec))
         self._forward_tail(w)
         if ev is not None:
@@ -509,6 +524,7 @@ class TrainEngine:
                 w.opk_valid = False                   # the launch-per-step loop writes the row-major histories
                 if w.fold_prenet:
                     xw0_product()                     # ... and reads the hoisted cell-0 input product
+                self._ensure_fallback_packs()
                 call("mstts_decoder_train_fwd", C.byref(dec))
                 self._forward_tail(w)
         return w
@@ -664,10 +680,12 @@ class TrainEngine:
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
                 self.unpack_history(w)
                 w.dq_hist.zero_()
+                self._ensure_fallback_packs()
                 call("mstts_decoder_train_bwd", C.byref(db))
             else:
                 parts = 1                    # d_in0 slab 0 holds the complete context gradient
         else:
+            self._ensure_fallback_packs()
             call("mstts_decoder_train_bwd", C.byref(db))
         if postnet_ready_deferred:
             on_ready(*self._grad_range("decoder/conv_"))
@@ -728,6 +746,7 @@ class TrainEngine:
             bseqs.append(q)
         # (the persistent BPTT reads the packed history of a persistent forward)
         if not (getattr(w, "enc_hist_valid", False) and self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)):
+            self._ensure_fallback_packs()
             call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(ENC_CELL % dr + "kernel")

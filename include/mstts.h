@@ -520,6 +520,17 @@ int mstts_lstm_seq_fwd_pair_persistent(const mstts_lstm_seq_fwd_desc* a, const m
                                        float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s);
 int mstts_lstm_seq_bwd_pair_persistent(const mstts_lstm_seq_bwd_desc* a, const mstts_lstm_seq_bwd_desc* b, const float* pkt_a, const float* pkt_b,
                                        float* xch, uint32_t* ctrl, const float* hist, float* bws, mstts_stream_t s);
+/* The same launches for MORE THAN 32 ROWS and for a single (unidirectional) sequence: rows are independent recurrences, so B rows run as
+ * ceil(B / 32) row groups, each with its own workgroups and ring (ndir x groups <= 16: up to 512 rows of one sequence, 256 of a pair; the
+ * speaker-encoder trainer's 320 utterances are 10 groups).  Buffer sizes for ndir sequences (1, or 2 = a bidirectional pair) of B rows:
+ * mstts_persist_lstm_ws_bytes_n / _hist_floats_n / _bwd_floats_n; ctrl: 16 uint32, ctrl[2] == 32 x groups (forward) / 16 x groups (BPTT)
+ * after a complete run.  The pair entry points above accept any B that mstts_persist_lstm_supported_n(B, H, 2) admits. */
+int32_t mstts_persist_lstm_supported_n(int64_t B, int64_t H, int32_t ndir);
+int64_t mstts_persist_lstm_ws_bytes_n(int64_t B, int32_t ndir);
+int64_t mstts_persist_lstm_hist_floats_n(int64_t T, int64_t B, int32_t ndir);
+int64_t mstts_persist_lstm_bwd_floats_n(int64_t T, int64_t B, int32_t ndir);
+int mstts_lstm_seq_fwd_persistent(const mstts_lstm_seq_fwd_desc* a, const float* pk, float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s);
+int mstts_lstm_seq_bwd_persistent(const mstts_lstm_seq_bwd_desc* a, const float* pkt, float* xch, uint32_t* ctrl, const float* hist, float* bws, mstts_stream_t s);
 
 /* ---- Decoder_LSTM / Decoder_Dynamic_Decode in teacher-forcing mode (Modules.py:76-119,323-472
  * with the TF AttentionWrapper step).  Everything that does not depend on the

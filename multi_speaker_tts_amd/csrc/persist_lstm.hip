@@ -24,10 +24,12 @@ constexpr long EB_SLOT = 2L * 64 * 64 * 4;        // backward ring slot: gate gr
 // in front of / behind the two loops convert: forward inputs ipx (float4: hoisted gate inputs) + ipm (keep-mask bits), forward
 // history epk (2 float4 per owner lane and step: gate activations | output, h, c, bits zc | zh << 1 | live << 2), BPTT input dop
 // (upstream gradient), BPTT output dpk (float4 gate gradients).  Owner-lane index of the forward kernel: ((t * 64 + g) * 4 + wave) *
-// 64 + lane with g = dir * 32 + gl; of the BPTT kernel: ((k * 32 + g) * 8 + wave) * 64 + lane with g = dir * 16 + gl, k = T - 1 - t.
-constexpr long EP_STEP = 64L * 4 * 64;            // owner lanes per step (both directions): 16 384, forward and backward alike
-// float4 index into epk: [t][forward workgroup 64][owner wave 4][half 2][lane 64]
-__host__ __device__ __forceinline__ long epk_index(int t, int g, int ow, int half, int lane) { return ((((long)t * 64 + g) * 4 + ow) * 2 + half) * 64 + lane; }
+// 64 + lane with g = group * 32 + gl; of the BPTT kernel: ((k * G2 + g) * 8 + wave) * 64 + lane with g = group * 16 + gl, k = T - 1 - t.
+// ROW GROUPS: rows are independent recurrences, so a sequence of more than 32 rows (the speaker-encoder trainer: 320) is cut into groups of 32
+// rows, each with its own 32 (forward) / 16 (BPTT) workgroups and its own ring; group index = direction * groups_per_direction + row block.
+constexpr long EP_GROUP = 32L * 4 * 64;           // owner lanes per step and row group: 8 192, forward and backward alike
+// float4 index into epk: [t][forward workgroup G][owner wave 4][half 2][lane 64]
+__host__ __device__ __forceinline__ long epk_index(int t, int G, int g, int ow, int half, int lane) { return ((((long)t * G + g) * 4 + ow) * 2 + half) * 64 + lane; }
 
 struct EncFwdDir {
     const float* xw; const float* wpk; const int32_t* lengths; const uint8_t* zc; const uint8_t* zh;
@@ -35,7 +37,7 @@ struct EncFwdDir {
     float* c_hist; float* h_hist; float* acts; float* c_raw;
     int reverse;
 };
-struct EncFwd { EncFwdDir d[2]; int ndir, B, T; float keep; float* xch; unsigned* ctrl; const pf32x4* ipx; const unsigned* ipm; pf32x4* epk; };
+struct EncFwd { EncFwdDir d[2]; int ndir, gpd, B, T; float keep; float* xch; unsigned* ctrl; const pf32x4* ipx; const unsigned* ipm; pf32x4* epk; };     // gpd: row groups per direction
 struct EncBwdDir {
     const float* wtpk; const int32_t* lengths; const uint8_t* zc; const uint8_t* zh;
     const float* d_out; long dout_sb, dout_st;
@@ -43,7 +45,7 @@ struct EncBwdDir {
     float* dgates_step; float* dgates_pos;
     int reverse;
 };
-struct EncBwd { EncBwdDir d[2]; int ndir, B, T; float keep; float* xch; unsigned* ctrl; const pf32x4* epk; const float* dop; pf32x4* dpk; };
+struct EncBwd { EncBwdDir d[2]; int ndir, gpd, B, T; float keep; float* xch; unsigned* ctrl; const pf32x4* epk; const float* dop; pf32x4* dpk; };
 
 // start rendezvous of n workgroups (thread 0 of each); false on time-out / abort
 __device__ __forceinline__ bool lstm_rendezvous(unsigned* ctrl, unsigned n) {
@@ -63,13 +65,15 @@ __device__ __forceinline__ bool lstm_rendezvous(unsigned* ctrl, unsigned n) {
 __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
     __shared__ __attribute__((aligned(16))) float red[2 * 4 * 2 * 2 * 64 * 4];      // [buffer][quarter][row tile][unit tile][lane][4]
     __shared__ unsigned sflag[2];
-    const int g = blockIdx.x, dir = g / EFWG, gl = g % EFWG;
+    const int g = blockIdx.x, grp = g / EFWG, gl = g % EFWG, dir = grp / p.gpd, row0 = 32 * (grp % p.gpd);
+    const int G = p.ndir * p.gpd * EFWG;
+    const long ep = (long)p.ndir * p.gpd * EP_GROUP;
     const EncFwdDir& d = p.d[dir];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = wave & 1, kq4 = wave >> 1, n = lane & 15, q = lane >> 4;
     const int B = p.B, T = p.T;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xch + (long)dir * PRING * EF_SLOT, 0, (int)(PRING * EF_SLOT * 4), 0x00020000);
-    if (tid == 0) { sflag[0] = lstm_rendezvous(p.ctrl, (unsigned)(p.ndir * EFWG)) ? 0u : 1u; }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xch + (long)grp * PRING * EF_SLOT, 0, (int)(PRING * EF_SLOT * 4), 0x00020000);
+    if (tid == 0) { sflag[0] = lstm_rendezvous(p.ctrl, (unsigned)G) ? 0u : 1u; }
     __syncthreads();
     if (sflag[0]) return;
     // this wave's slice of the recurrent kernel: 2 unit tiles x 16 k-steps (its quarter of the 256 hidden units)
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
     // cell-update role (waves 0..3): row tile o_rt, unit tile o_ut; lane = (unit within the tile q, row n)
     const bool owner = wave < 4;
     const int o_rt = wave & 1, o_ut = (wave >> 1) & 1;
-    const int b = 16 * o_rt + n, u = 8 * gl + 4 * o_ut + q;
+    const int b = row0 + 16 * o_rt + n, u = 8 * gl + 4 * o_ut + q;
     const bool brow = owner && b < B;
     const int len = brow ? (d.lengths ? d.lengths[b] : T) : 0;
     float cs = 0.f, hs = 0.f;
@@ -90,12 +94,12 @@ __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
     // has come in itself.
     pf32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
     unsigned zca = 3, zcb = 3;
-    const long own = (long)g * 256 + (wave & 3) * 64 + lane;     // + t * EP_STEP
+    const long own = (long)g * 256 + (wave & 3) * 64 + lane;     // + t * ep
     // (unconditional, in every wave, clamped at the last step: a conditional request leaves the compiler's wait-count pass with a "maybe
     //  pending" load at the loop's back edge, and the s_waitcnt vmcnt(0) it then places there also waits for the write-through
     //  publication to be acknowledged - 0.5 us per step)
 #define LSTM_FWD_OPERANDS(TT, XV, ZM)                                                                                              \
-    { const long t__ = (TT) < T ? (TT) : T - 1; XV = p.ipx[t__ * EP_STEP + own]; ZM = p.ipm[t__ * EP_STEP + own]; }
+    { const long t__ = (TT) < T ? (TT) : T - 1; XV = p.ipx[t__ * ep + own]; ZM = p.ipm[t__ * ep + own]; }
     LSTM_FWD_OPERANDS(0, xa, zca)
 #ifdef LSTM_PROF
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
                 xpublish(xr, (unsigned)((slot * EF_SLOT + ((o_rt * 16 + (gl >> 1)) * 64 + ((2 * (gl & 1) + o_ut) * 16 + n)) * 4) * 4), pv, gen);
             LSTAMP(4);
             // history of this (row, unit) for the BPTT and for the row-major tensors (persist_lstm_unpack_fwd_kernel): two contiguous KB per wave
-            pf32x4* eo = p.epk + epk_index(t, g, wave, 0, lane);
+            pf32x4* eo = p.epk + epk_index(t, G, g, wave, 0, lane);
             eo[0] = (pf32x4){si, tj, sf, so};
             eo[64] = (pf32x4){m, hn, cn, __uint_as_float((zcv ? 1u : 0u) | (zhv ? 2u : 0u) | (live ? 4u : 0u))};
             LSTAMP(5);
@@ -178,13 +182,15 @@ __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
 __global__ __launch_bounds__(ETH) void persist_lstm_bwd_kernel(EncBwd p) {
     __shared__ __attribute__((aligned(16))) float red[2 * 4 * 2 * 64 * 4];          // [buffer][quarter][row tile][lane][4]
     __shared__ unsigned sflag[2];
-    const int g = blockIdx.x, dir = g / EBWG, gl = g % EBWG;
+    const int g = blockIdx.x, grp = g / EBWG, gl = g % EBWG, dir = grp / p.gpd, row0 = 32 * (grp % p.gpd);
+    const int G = p.ndir * p.gpd * EFWG;              // forward workgroups (the packed history's geometry)
+    const long ep = (long)p.ndir * p.gpd * EP_GROUP;
     const EncBwdDir& d = p.d[dir];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = wave & 1, kq4 = wave >> 1, n = lane & 15, q = lane >> 4;
     const int B = p.B, T = p.T;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xch + (long)dir * PRING * EB_SLOT, 0, (int)(PRING * EB_SLOT * 4), 0x00020000);
-    if (tid == 0) { sflag[0] = lstm_rendezvous(p.ctrl, (unsigned)(p.ndir * EBWG)) ? 0u : 1u; }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xch + (long)grp * PRING * EB_SLOT, 0, (int)(PRING * EB_SLOT * 4), 0x00020000);
+    if (tid == 0) { sflag[0] = lstm_rendezvous(p.ctrl, (unsigned)(p.ndir * p.gpd * EBWG)) ? 0u : 1u; }
     __syncthreads();
     if (sflag[0]) return;
     // rows 16 gl .. + 15 of the recurrent kernel (the hidden units this workgroup owns), this wave's quarter of the 1024 gate columns
@@ -193,14 +199,14 @@ __global__ __launch_bounds__(ETH) void persist_lstm_bwd_kernel(EncBwd p) {
     for (int ks = 0; ks < 64; ++ks) wt[ks] = d.wtpk[(((long)gl * 4 + kq4) * 64 + ks) * 64 + lane];
     // cell-backward role (all 8 waves): row tile o_rt = rt, accumulator component r = kq4: unit 4 q + r of the tile, row n
     const int r = kq4;
-    const int b = 16 * rt + n, u = 16 * gl + 4 * q + r;
+    const int b = row0 + 16 * rt + n, u = 16 * gl + 4 * q + r;
     const bool brow = b < B;
     const int len = brow ? (d.lengths ? d.lengths[b] : T) : 0;
     float dcs = 0.f, dhc = 0.f;                       // gradients of the carried cell / hidden state (from the later steps)
     // operands of the cell backward two steps ahead, requested behind a completed gather (see the forward kernel)
     // this lane's element (unit u, row b) in the forward kernel's owner order: workgroup u >> 3, owner wave rt + 2 ((u >> 2) & 1), lane 16 (u & 3) + n
-    const int fg = dir * EFWG + (u >> 3), fw = rt + 2 * ((u >> 2) & 1), fl = 16 * (u & 3) + n;
-    const long bown = (long)g * 512 + wave * 64 + lane;      // + k * EP_STEP
+    const int fg = grp * EFWG + (u >> 3), fw = rt + 2 * ((u >> 2) & 1), fl = 16 * (u & 3) + n;
+    const long bown = (long)g * 512 + wave * 64 + lane;      // + k * ep
     struct BwdOps { pf32x4 act, st, prev; float dout; };
     BwdOps oa, ob;
     oa.act = oa.st = oa.prev = (pf32x4){0.f, 0.f, 0.f, 0.f}; oa.dout = 0.f;
@@ -208,10 +214,10 @@ __global__ __launch_bounds__(ETH) void persist_lstm_bwd_kernel(EncBwd p) {
 #define LSTM_BWD_OPERANDS(KK, O)                                                                                                   \
     {                                                                                                                              \
         const int kk__ = (KK) < T ? (KK) : T - 1, tt__ = T - 1 - kk__;                                                             \
-        O.act = p.epk[epk_index(tt__, fg, fw, 0, fl)];                                                                             \
-        O.st = p.epk[epk_index(tt__, fg, fw, 1, fl)];                                                                              \
-        O.prev = p.epk[epk_index(tt__ > 0 ? tt__ - 1 : 0, fg, fw, 1, fl)];                                                         \
-        O.dout = p.dop[(long)kk__ * EP_STEP + bown];                                                                               \
+        O.act = p.epk[epk_index(tt__, G, fg, fw, 0, fl)];                                                                             \
+        O.st = p.epk[epk_index(tt__, G, fg, fw, 1, fl)];                                                                             \
+        O.prev = p.epk[epk_index(tt__ > 0 ? tt__ - 1 : 0, G, fg, fw, 1, fl)];                                                         \
+        O.dout = p.dop[(long)kk__ * ep + bown];                                                                                    \
     }
     LSTM_BWD_OPERANDS(0, oa)
     for (int k = 0; k < T; ++k) {
@@ -276,30 +282,41 @@ __global__ __launch_bounds__(ETH) void persist_lstm_bwd_kernel(EncBwd p) {
         // the piece of (row b, unit u) = its four gate gradients: ring column 4 u + gate
         const int uu = 16 * gl + 4 * q + r;
         xpublish(xr, (unsigned)((slot * EB_SLOT + ((rt * 64 + (uu >> 2)) * 64 + ((uu & 3) * 16 + n)) * 4) * 4), dg, gen);
-        p.dpk[(long)k * EP_STEP + bown] = dg;               // -> dgates_step / dgates_pos by persist_lstm_unpack_bwd_kernel
+        p.dpk[(long)k * ep + bown] = dg;               // -> dgates_step / dgates_pos by persist_lstm_unpack_bwd_kernel
     }
     if (tid == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the streaming kernels around the two loops (one thread per owner lane and step)
-__device__ __forceinline__ void fwd_owner_of(long idx, int& t, int& g, int& ow, int& lane, int& b, int& u) {
-    lane = (int)(idx & 63); ow = (int)((idx >> 6) & 3); g = (int)((idx >> 8) & 63); t = (int)(idx >> 14);
-    b = 16 * (ow & 1) + (lane & 15);
-    u = 8 * (g & 31) + 4 * (ow >> 1) + (lane >> 4);
+// (ngr = row groups in all, gpd = per direction; a group is 32 forward / 16 BPTT workgroups)
+__device__ __forceinline__ void fwd_owner_of(long idx, int ngr, int gpd, int& t, int& g, int& ow, int& lane, int& dir, int& b, int& u) {
+    const int G = ngr * EFWG;
+    lane = (int)(idx & 63); ow = (int)((idx >> 6) & 3);
+    const long wg = idx >> 8;
+    g = (int)(wg % G); t = (int)(wg / G);
+    const int grp = g / EFWG;
+    dir = grp / gpd;
+    b = 32 * (grp % gpd) + 16 * (ow & 1) + (lane & 15);
+    u = 8 * (g % EFWG) + 4 * (ow >> 1) + (lane >> 4);
 }
-__device__ __forceinline__ void bwd_owner_of(long idx, int& k, int& g, int& b, int& u) {
+__device__ __forceinline__ void bwd_owner_of(long idx, int ngr, int gpd, int& k, int& dir, int& b, int& u) {
+    const int G2 = ngr * EBWG;
     const int lane = (int)(idx & 63), wave = (int)((idx >> 6) & 7);
-    g = (int)((idx >> 9) & 31); k = (int)(idx >> 14);
-    b = 16 * (wave & 1) + (lane & 15);
-    u = 16 * (g & 15) + 4 * (lane >> 4) + (wave >> 1);
+    const long wg = idx >> 9;
+    const int g = (int)(wg % G2), grp = g / EBWG;
+    k = (int)(wg / G2);
+    dir = grp / gpd;
+    b = 32 * (grp % gpd) + 16 * (wave & 1) + (lane & 15);
+    u = 16 * (g % EBWG) + 4 * (lane >> 4) + (wave >> 1);
 }
 // hoisted gate inputs xw [B, T, 4H] (at the row's position of step t) and the keep-mask bytes -> ipx / ipm
 __global__ void persist_lstm_pack_in_kernel(EncFwd p, pf32x4* __restrict__ ipx, unsigned* __restrict__ ipm) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)p.T * EP_STEP) return;
-    int t, g, ow, lane, b, u;
-    fwd_owner_of(idx, t, g, ow, lane, b, u);
-    const EncFwdDir& d = p.d[g >> 5];
+    const int ngr = p.ndir * p.gpd;
+    if (idx >= (long)p.T * ngr * EP_GROUP) return;
+    int t, g, ow, lane, dir, b, u;
+    fwd_owner_of(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
+    const EncFwdDir& d = p.d[dir];
     pf32x4 x = {0.f, 0.f, 0.f, 0.f};
     unsigned m = 3u;
     if (b < p.B) {
@@ -316,13 +333,14 @@ __global__ void persist_lstm_pack_in_kernel(EncFwd p, pf32x4* __restrict__ ipx, 
 // epk -> the row-major tensors of mstts_lstm_seq_fwd_desc: out (at the row's position), h_hist / c_hist [T + 1, B, H], acts, c_raw
 __global__ void persist_lstm_unpack_fwd_kernel(EncFwd p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)p.T * EP_STEP) return;
-    int t, g, ow, lane, b, u;
-    fwd_owner_of(idx, t, g, ow, lane, b, u);
+    const int ngr = p.ndir * p.gpd, G = ngr * EFWG;
+    if (idx >= (long)p.T * ngr * EP_GROUP) return;
+    int t, g, ow, lane, dir, b, u;
+    fwd_owner_of(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
     if (b >= p.B) return;
-    const EncFwdDir& d = p.d[g >> 5];
-    const pf32x4 a = p.epk[epk_index(t, g, ow, 0, lane)], s = p.epk[epk_index(t, g, ow, 1, lane)];
-    const float cp = t > 0 ? p.epk[epk_index(t - 1, g, ow, 1, lane)][2] : 0.f;
+    const EncFwdDir& d = p.d[dir];
+    const pf32x4 a = p.epk[epk_index(t, G, g, ow, 0, lane)], s = p.epk[epk_index(t, G, g, ow, 1, lane)];
+    const float cp = t > 0 ? p.epk[epk_index(t - 1, G, g, ow, 1, lane)][2] : 0.f;
     const bool live = (__float_as_uint(s[3]) & 4u) != 0u;
     const int len = d.lengths ? d.lengths[b] : p.T;
     const int pos = (d.reverse && live) ? len - 1 - t : t;
@@ -336,10 +354,11 @@ __global__ void persist_lstm_unpack_fwd_kernel(EncFwd p) {
 // upstream gradient d_out (at the row's position of step t = T - 1 - k, 0 for rows past their length) -> dop
 __global__ void persist_lstm_pack_dout_kernel(EncBwd p, float* __restrict__ dop) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)p.T * EP_STEP) return;
-    int k, g, b, u;
-    bwd_owner_of(idx, k, g, b, u);
-    const EncBwdDir& d = p.d[g >> 4];
+    const int ngr = p.ndir * p.gpd;
+    if (idx >= (long)p.T * ngr * EP_GROUP) return;
+    int k, dir, b, u;
+    bwd_owner_of(idx, ngr, p.gpd, k, dir, b, u);
+    const EncBwdDir& d = p.d[dir];
     const int t = p.T - 1 - k;
     float v = 0.f;
     if (b < p.B) {
@@ -351,11 +370,12 @@ __global__ void persist_lstm_pack_dout_kernel(EncBwd p, float* __restrict__ dop)
 // dpk -> dgates_step [T, B, 4H] (processing order) and dgates_pos [B, T, 4H] (position order)
 __global__ void persist_lstm_unpack_bwd_kernel(EncBwd p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)p.T * EP_STEP) return;
-    int k, g, b, u;
-    bwd_owner_of(idx, k, g, b, u);
+    const int ngr = p.ndir * p.gpd;
+    if (idx >= (long)p.T * ngr * EP_GROUP) return;
+    int k, dir, b, u;
+    bwd_owner_of(idx, ngr, p.gpd, k, dir, b, u);
     if (b >= p.B) return;
-    const EncBwdDir& d = p.d[g >> 4];
+    const EncBwdDir& d = p.d[dir];
     const int t = p.T - 1 - k;
     const pf32x4 dg = p.dpk[idx];
     const int len = d.lengths ? d.lengths[b] : p.T;
@@ -391,23 +411,30 @@ __global__ void persist_lstm_pack_bwd_kernel(const float* __restrict__ wh, long 
 }  // namespace mstts
 using namespace mstts;
 
-/* 1 when the persistent BiLSTM launches cover this shape on the current device */
-extern "C" int32_t mstts_persist_lstm_supported(int64_t B, int64_t H) {
-    if (!(B >= 1 && B <= 32 && H == EH)) return 0;
+static int lstm_groups(long B) { return (int)((B + 31) / 32); }
+/* 1 when the persistent LSTM launches cover `ndir` sequences (1, or the 2 directions of a bidirectional layer) of B rows and H units each on
+ * the current device: H == 256, at most 16 row groups of 32 rows in all (their workgroups must be co-resident) */
+extern "C" int32_t mstts_persist_lstm_supported_n(int64_t B, int64_t H, int32_t ndir) {
+    if (!(B >= 1 && H == EH && (ndir == 1 || ndir == 2) && ndir * lstm_groups(B) <= 16)) return 0;
     static int cached = -1;
     if (cached < 0) {
         int dev = 0, cus = 0;
-        cached = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 2 * EFWG) ? 1 : 0;
+        cached = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256) ? 1 : 0;
         (void)hipGetLastError();
     }
     return cached;
 }
+extern "C" int32_t mstts_persist_lstm_supported(int64_t B, int64_t H) { return B <= 32 ? mstts_persist_lstm_supported_n(B, H, 2) : 0; }
 extern "C" int64_t mstts_persist_lstm_pack_floats(void) { return (int64_t)EH * 4 * EH; }
-extern "C" int64_t mstts_persist_lstm_ws_bytes(void) { return 2 * PRING * (EB_SLOT > EF_SLOT ? EB_SLOT : EF_SLOT) * 4; }
-/* packed forward inputs + history of a T-step sequence (float4 ipx | uint32 ipm | 2 float4 epk per owner lane and step), in floats */
-extern "C" int64_t mstts_persist_lstm_hist_floats(int64_t T) { return T * EP_STEP * (4 + 1 + 8); }
-/* packed BPTT input / output (float dop | float4 dpk per owner lane and step), in floats */
-extern "C" int64_t mstts_persist_lstm_bwd_floats(int64_t T) { return T * EP_STEP * (1 + 4); }
+/* ring bytes, packed forward inputs + history floats (float4 ipx | uint32 ipm | 2 float4 epk per owner lane and step) and packed BPTT input /
+ * output floats (float dop | float4 dpk) for ndir sequences of B rows and T steps */
+extern "C" int64_t mstts_persist_lstm_ws_bytes_n(int64_t B, int32_t ndir) { return (int64_t)ndir * lstm_groups(B) * PRING * (EB_SLOT > EF_SLOT ? EB_SLOT : EF_SLOT) * 4; }
+extern "C" int64_t mstts_persist_lstm_hist_floats_n(int64_t T, int64_t B, int32_t ndir) { return T * ndir * lstm_groups(B) * EP_GROUP * (4 + 1 + 8); }
+extern "C" int64_t mstts_persist_lstm_bwd_floats_n(int64_t T, int64_t B, int32_t ndir) { return T * ndir * lstm_groups(B) * EP_GROUP * (1 + 4); }
+/* the bidirectional pair of at most 32 rows (the encoder) */
+extern "C" int64_t mstts_persist_lstm_ws_bytes(void) { return mstts_persist_lstm_ws_bytes_n(32, 2); }
+extern "C" int64_t mstts_persist_lstm_hist_floats(int64_t T) { return mstts_persist_lstm_hist_floats_n(T, 32, 2); }
+extern "C" int64_t mstts_persist_lstm_bwd_floats(int64_t T) { return mstts_persist_lstm_bwd_floats_n(T, 32, 2); }
 
 extern "C" int mstts_persist_lstm_pack(const float* wh, int64_t wh_ld, float* fwd_pk, float* bwd_pk, mstts_stream_t s) {
     MSTTS_REQUIRE(wh && fwd_pk && bwd_pk && wh_ld >= 4 * EH, MSTTS_ERR_SHAPE, "persist_lstm_pack: null pointer or row stride below 4 H");
@@ -418,75 +445,106 @@ extern "C" int mstts_persist_lstm_pack(const float* wh, int64_t wh_ld, float* fw
     return MSTTS_OK;
 }
 
-extern "C" int mstts_lstm_seq_fwd_pair_persistent(const mstts_lstm_seq_fwd_desc* a, const mstts_lstm_seq_fwd_desc* b, const float* pk_a, const float* pk_b,
-                                                  float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s) {
-    MSTTS_REQUIRE(a && b && pk_a && pk_b && xch && ctrl && hist, MSTTS_ERR_SHAPE, "lstm_seq_fwd_pair_persistent: null pointer");
-    MSTTS_REQUIRE(aligned16(hist) && aligned16(xch), MSTTS_ERR_ALIGN, "lstm_seq_fwd_pair_persistent: hist / xch must be 16-byte aligned");
-    MSTTS_REQUIRE(a->B == b->B && a->T == b->T && a->H == b->H && mstts_persist_lstm_supported(a->B, a->H) && a->T >= 1, MSTTS_ERR_SHAPE,
-                  "lstm_seq_fwd_pair_persistent: shape or device not supported (see mstts_persist_lstm_supported)");
-    const mstts_lstm_seq_fwd_desc* dd[2] = {a, b};
-    const float* pk[2] = {pk_a, pk_b};
+static int lstm_fwd_launch(const mstts_lstm_seq_fwd_desc* const* dd, const float* const* pk, int ndir, float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s) {
+    const mstts_lstm_seq_fwd_desc* a = dd[0];
+    MSTTS_REQUIRE(xch && ctrl && hist, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null pointer");
+    MSTTS_REQUIRE(aligned16(hist) && aligned16(xch), MSTTS_ERR_ALIGN, "lstm_seq_fwd_persistent: hist / xch must be 16-byte aligned");
+    MSTTS_REQUIRE(mstts_persist_lstm_supported_n(a->B, a->H, ndir) && a->T >= 1, MSTTS_ERR_SHAPE,
+                  "lstm_seq_fwd_persistent: shape or device not supported (see mstts_persist_lstm_supported_n)");
     EncFwd p;
+    memset(&p, 0, sizeof(p));
     hipStream_t hs = (hipStream_t)s;
     const long BH = a->B * a->H;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < ndir; ++k) {
         const mstts_lstm_seq_fwd_desc* d = dd[k];
-        MSTTS_REQUIRE(d->xw && d->c_hist && d->h_hist && d->out && !d->residual, MSTTS_ERR_SHAPE, "lstm_seq_fwd_pair_persistent: null pointer / residual input not covered");
-        MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_fwd_pair_persistent: reverse needs a lengths array (pass T for every row)");
-        MSTTS_REQUIRE(d->zoneout == a->zoneout, MSTTS_ERR_SHAPE, "lstm_seq_fwd_pair_persistent: one zoneout rate for both directions");
+        MSTTS_REQUIRE(d && pk[k] && d->B == a->B && d->T == a->T && d->H == a->H, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null descriptor / the sequences must have one shape");
+        MSTTS_REQUIRE(d->xw && d->c_hist && d->h_hist && d->out && !d->residual, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null pointer / residual input not covered");
+        MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: reverse needs a lengths array (pass T for every row)");
+        MSTTS_REQUIRE(d->zoneout == a->zoneout, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: one zoneout rate for both directions");
         if (hipMemsetAsync(d->c_hist, 0, BH * sizeof(float), hs) != hipSuccess || hipMemsetAsync(d->h_hist, 0, BH * sizeof(float), hs) != hipSuccess)
-            return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_fwd_pair_persistent: memset failed");
+            return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_fwd_persistent: memset failed");
         EncFwdDir& e = p.d[k];
         e.xw = d->xw; e.wpk = pk[k]; e.lengths = d->lengths; e.zc = d->zc; e.zh = d->zh; e.out = d->out; e.out_sb = d->out_sb; e.out_st = d->out_st;
         e.c_hist = d->c_hist; e.h_hist = d->h_hist; e.acts = d->acts; e.c_raw = d->c_raw; e.reverse = d->reverse;
     }
-    p.ndir = 2; p.B = (int)a->B; p.T = (int)a->T; p.keep = 1.f - a->zoneout; p.xch = xch; p.ctrl = ctrl;
-    if (hipMemsetAsync(xch, 0xFF, 2 * PRING * EF_SLOT * 4, hs) != hipSuccess || hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), hs) != hipSuccess)
-        return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_fwd_pair_persistent: memset failed");
-    const long nl = (long)p.T * EP_STEP;
+    p.ndir = ndir; p.gpd = lstm_groups(a->B); p.B = (int)a->B; p.T = (int)a->T; p.keep = 1.f - a->zoneout; p.xch = xch; p.ctrl = ctrl;
+    const int ngr = ndir * p.gpd;
+    if (hipMemsetAsync(xch, 0xFF, (size_t)ngr * PRING * EF_SLOT * 4, hs) != hipSuccess || hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), hs) != hipSuccess)
+        return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_fwd_persistent: memset failed");
+    const long nl = (long)p.T * ngr * EP_GROUP;
     pf32x4* ipx = reinterpret_cast<pf32x4*>(hist);
     unsigned* ipm = reinterpret_cast<unsigned*>(hist + nl * 4);
     p.ipx = ipx; p.ipm = ipm; p.epk = reinterpret_cast<pf32x4*>(hist + nl * 5);
-    static_assert(EP_STEP % 4 == 0, "epk stays 16-byte aligned behind ipx | ipm");
+    static_assert(EP_GROUP % 4 == 0, "epk stays 16-byte aligned behind ipx | ipm");
     hipLaunchKernelGGL(persist_lstm_pack_in_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p, ipx, ipm);
     MSTTS_CHECK_LAUNCH("persist_lstm_pack_in");
-    hipLaunchKernelGGL(persist_lstm_fwd_kernel, dim3(2 * EFWG), dim3(ETH), 0, hs, p);
+    hipLaunchKernelGGL(persist_lstm_fwd_kernel, dim3(ngr * EFWG), dim3(ETH), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_fwd");
     hipLaunchKernelGGL(persist_lstm_unpack_fwd_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_unpack_fwd");
     return MSTTS_OK;
 }
 
-extern "C" int mstts_lstm_seq_bwd_pair_persistent(const mstts_lstm_seq_bwd_desc* a, const mstts_lstm_seq_bwd_desc* b, const float* pkt_a, const float* pkt_b,
-                                                  float* xch, uint32_t* ctrl, const float* hist, float* bws, mstts_stream_t s) {
-    MSTTS_REQUIRE(a && b && pkt_a && pkt_b && xch && ctrl && hist && bws, MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair_persistent: null pointer");
-    MSTTS_REQUIRE(aligned16(hist) && aligned16(xch) && aligned16(bws), MSTTS_ERR_ALIGN, "lstm_seq_bwd_pair_persistent: hist / xch / bws must be 16-byte aligned");
-    MSTTS_REQUIRE(a->B == b->B && a->T == b->T && a->H == b->H && mstts_persist_lstm_supported(a->B, a->H) && a->T >= 1, MSTTS_ERR_SHAPE,
-                  "lstm_seq_bwd_pair_persistent: shape or device not supported (see mstts_persist_lstm_supported)");
-    const mstts_lstm_seq_bwd_desc* dd[2] = {a, b};
-    const float* pk[2] = {pkt_a, pkt_b};
+static int lstm_bwd_launch(const mstts_lstm_seq_bwd_desc* const* dd, const float* const* pk, int ndir, float* xch, uint32_t* ctrl, const float* hist, float* bws,
+                           mstts_stream_t s) {
+    const mstts_lstm_seq_bwd_desc* a = dd[0];
+    MSTTS_REQUIRE(xch && ctrl && hist && bws, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: null pointer");
+    MSTTS_REQUIRE(aligned16(hist) && aligned16(xch) && aligned16(bws), MSTTS_ERR_ALIGN, "lstm_seq_bwd_persistent: hist / xch / bws must be 16-byte aligned");
+    MSTTS_REQUIRE(mstts_persist_lstm_supported_n(a->B, a->H, ndir) && a->T >= 1, MSTTS_ERR_SHAPE,
+                  "lstm_seq_bwd_persistent: shape or device not supported (see mstts_persist_lstm_supported_n)");
     EncBwd p;
+    memset(&p, 0, sizeof(p));
     hipStream_t hs = (hipStream_t)s;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < ndir; ++k) {
         const mstts_lstm_seq_bwd_desc* d = dd[k];
-        MSTTS_REQUIRE(d->d_out && d->dgates_step && d->dgates_pos, MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair_persistent: null pointer");
-        MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair_persistent: reverse needs a lengths array");
-        MSTTS_REQUIRE(d->zoneout == a->zoneout, MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair_persistent: one zoneout rate for both directions");
+        MSTTS_REQUIRE(d && pk[k] && d->B == a->B && d->T == a->T && d->H == a->H, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: null descriptor / the sequences must have one shape");
+        MSTTS_REQUIRE(d->d_out && d->dgates_step && d->dgates_pos, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: null pointer");
+        MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: reverse needs a lengths array");
+        MSTTS_REQUIRE(d->zoneout == a->zoneout, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: one zoneout rate for both directions");
         EncBwdDir& e = p.d[k];
         e.wtpk = pk[k]; e.lengths = d->lengths; e.zc = d->zc; e.zh = d->zh; e.d_out = d->d_out; e.dout_sb = d->dout_sb; e.dout_st = d->dout_st;
         e.c_hist = d->c_hist; e.acts = d->acts; e.c_raw = d->c_raw; e.dgates_step = d->dgates_step; e.dgates_pos = d->dgates_pos; e.reverse = d->reverse;
     }
-    p.ndir = 2; p.B = (int)a->B; p.T = (int)a->T; p.keep = 1.f - a->zoneout; p.xch = xch; p.ctrl = ctrl;
-    if (hipMemsetAsync(xch, 0xFF, 2 * PRING * EB_SLOT * 4, hs) != hipSuccess || hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), hs) != hipSuccess)
-        return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_bwd_pair_persistent: memset failed");
-    const long nl = (long)p.T * EP_STEP;
+    p.ndir = ndir; p.gpd = lstm_groups(a->B); p.B = (int)a->B; p.T = (int)a->T; p.keep = 1.f - a->zoneout; p.xch = xch; p.ctrl = ctrl;
+    const int ngr = ndir * p.gpd;
+    if (hipMemsetAsync(xch, 0xFF, (size_t)ngr * PRING * EB_SLOT * 4, hs) != hipSuccess || hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), hs) != hipSuccess)
+        return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_bwd_persistent: memset failed");
+    const long nl = (long)p.T * ngr * EP_GROUP;
     p.epk = reinterpret_cast<const pf32x4*>(hist + nl * 5);
     p.dop = bws; p.dpk = reinterpret_cast<pf32x4*>(bws + nl);
     hipLaunchKernelGGL(persist_lstm_pack_dout_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p, bws);
     MSTTS_CHECK_LAUNCH("persist_lstm_pack_dout");
-    hipLaunchKernelGGL(persist_lstm_bwd_kernel, dim3(2 * EBWG), dim3(ETH), 0, hs, p);
+    hipLaunchKernelGGL(persist_lstm_bwd_kernel, dim3(ngr * EBWG), dim3(ETH), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_bwd");
     hipLaunchKernelGGL(persist_lstm_unpack_bwd_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_unpack_bwd");
     return MSTTS_OK;
+}
+
+extern "C" int mstts_lstm_seq_fwd_pair_persistent(const mstts_lstm_seq_fwd_desc* a, const mstts_lstm_seq_fwd_desc* b, const float* pk_a, const float* pk_b,
+                                                  float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && b && pk_a && pk_b, MSTTS_ERR_SHAPE, "lstm_seq_fwd_pair_persistent: null pointer");
+    const mstts_lstm_seq_fwd_desc* dd[2] = {a, b};
+    const float* pk[2] = {pk_a, pk_b};
+    return lstm_fwd_launch(dd, pk, 2, xch, ctrl, hist, s);
+}
+extern "C" int mstts_lstm_seq_bwd_pair_persistent(const mstts_lstm_seq_bwd_desc* a, const mstts_lstm_seq_bwd_desc* b, const float* pkt_a, const float* pkt_b,
+                                                  float* xch, uint32_t* ctrl, const float* hist, float* bws, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && b && pkt_a && pkt_b, MSTTS_ERR_SHAPE, "lstm_seq_bwd_pair_persistent: null pointer");
+    const mstts_lstm_seq_bwd_desc* dd[2] = {a, b};
+    const float* pk[2] = {pkt_a, pkt_b};
+    return lstm_bwd_launch(dd, pk, 2, xch, ctrl, hist, bws, s);
+}
+/* one sequence (a unidirectional layer) of up to 512 rows */
+extern "C" int mstts_lstm_seq_fwd_persistent(const mstts_lstm_seq_fwd_desc* a, const float* pk, float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && pk, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null pointer");
+    const mstts_lstm_seq_fwd_desc* dd[1] = {a};
+    const float* pks[1] = {pk};
+    return lstm_fwd_launch(dd, pks, 1, xch, ctrl, hist, s);
+}
+extern "C" int mstts_lstm_seq_bwd_persistent(const mstts_lstm_seq_bwd_desc* a, const float* pkt, float* xch, uint32_t* ctrl, const float* hist, float* bws, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && pkt, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: null pointer");
+    const mstts_lstm_seq_bwd_desc* dd[1] = {a};
+    const float* pks[1] = {pkt};
+    return lstm_bwd_launch(dd, pks, 1, xch, ctrl, hist, bws, s);
 }

@@ -205,6 +205,12 @@ SIGNATURES = {
     "mstts_persist_lstm_pack_floats": (i64, []),
     "mstts_persist_lstm_ws_bytes": (i64, []),
     "mstts_persist_lstm_pack": (i32, [vp, i64, vp, vp, vp]),
+    "mstts_persist_lstm_supported_n": (i32, [i64, i64, i32]),
+    "mstts_persist_lstm_ws_bytes_n": (i64, [i64, i32]),
+    "mstts_persist_lstm_hist_floats_n": (i64, [i64, i64, i32]),
+    "mstts_persist_lstm_bwd_floats_n": (i64, [i64, i64, i32]),
+    "mstts_lstm_seq_fwd_persistent": (i32, [P(LstmSeqFwd), vp, vp, vp, vp, vp]),
+    "mstts_lstm_seq_bwd_persistent": (i32, [P(LstmSeqBwd), vp, vp, vp, vp, vp, vp]),
     "mstts_persist_lstm_hist_floats": (i64, [i64]),
     "mstts_persist_lstm_bwd_floats": (i64, [i64]),
     "mstts_lstm_seq_fwd_pair_persistent": (i32, [P(LstmSeqFwd), P(LstmSeqFwd), vp, vp, vp, vp, vp, vp]),

@@ -191,3 +191,64 @@ def test_train_step_with_and_without_the_persistent_encoder(dev, monkeypatch):
     scale = np.abs(c).max()
     assert np.abs(a - c).max() < 2e-4 * scale, np.abs(a - c).max() / scale
     assert np.abs(b - c).max() < 2e-4 * scale, np.abs(b - c).max() / scale
+
+
+@pytest.mark.parametrize("B,T", [(70, 21), (320, 12), (33, 5)])
+def test_persistent_single_sequence_row_groups(dev, B, T):
+    """More than 32 rows of ONE unidirectional sequence (the speaker-encoder trainer's layers): ceil(B / 32) independent row groups in one
+    launch, forward and BPTT, against mstts_lstm_seq_fwd / mstts_lstm_seq_bwd."""
+    L = lib.load()
+    if not L.mstts_persist_lstm_supported_n(B, H, 1):
+        pytest.skip("not supported on this device")
+    st = _setup(dev, B, T, seed=300 + B)
+    out = {}
+    for persistent in (False, True):
+        o = {"out": torch.zeros(B, T, H, device=dev)}
+        z = lambda *s: torch.full(s, float("nan"), device=dev)
+        o["c"], o["h"], o["acts"], o["craw"] = z(T + 1, B, H), z(T + 1, B, H), z(T, B, 4 * H), z(T, B, H)
+        q = lib.LstmSeqFwd()
+        q.B, q.T, q.H = B, T, H
+        q.xw = lib.ptr(st["xw_fw"]); q.wh = lib.ptr(st["wh_fw"]); q.wh_ld = 4 * H
+        q.lengths = lib.ptr(st["lens"]); q.reverse = 0; q.zoneout = st["zoneout"]
+        q.zc = lib.ptr(st["zc_fw"]); q.zh = lib.ptr(st["zh_fw"])
+        q.out = lib.ptr(o["out"]); q.out_sb = T * H; q.out_st = H
+        q.c_hist = lib.ptr(o["c"]); q.h_hist = lib.ptr(o["h"]); q.acts = lib.ptr(o["acts"]); q.c_raw = lib.ptr(o["craw"])
+        o["dgs"], o["dgp"] = z(T, B, 4 * H), z(B, T, 4 * H)
+        qb = lib.LstmSeqBwd()
+        qb.B, qb.T, qb.H = B, T, H
+        qb.wh = lib.ptr(st["wh_fw"]); qb.wh_ld = 4 * H
+        qb.lengths = lib.ptr(st["lens"]); qb.reverse = 0; qb.zoneout = st["zoneout"]
+        qb.zc = lib.ptr(st["zc_fw"]); qb.zh = lib.ptr(st["zh_fw"])
+        qb.d_out = lib.ptr(st["dout_fw"]); qb.dout_sb = T * H; qb.dout_st = H
+        qb.c_hist = lib.ptr(o["c"]); qb.acts = lib.ptr(o["acts"]); qb.c_raw = lib.ptr(o["craw"])
+        qb.dgates_step = lib.ptr(o["dgs"]); qb.dgates_pos = lib.ptr(o["dgp"])
+        if persistent:
+            n = L.mstts_persist_lstm_pack_floats()
+            pk, pkt = torch.empty(n, device=dev), torch.empty(n, device=dev)
+            lib.call("mstts_persist_lstm_pack", lib.ptr(st["wh_fw"]), 4 * H, lib.ptr(pk), lib.ptr(pkt))
+            xch = torch.empty(L.mstts_persist_lstm_ws_bytes_n(B, 1) // 4, device=dev)
+            ctrl = torch.zeros(16, dtype=torch.int32, device=dev)
+            hist = torch.empty(L.mstts_persist_lstm_hist_floats_n(T, B, 1), device=dev)
+            bws = torch.empty(L.mstts_persist_lstm_bwd_floats_n(T, B, 1), device=dev)
+            lib.call("mstts_lstm_seq_fwd_persistent", C.byref(q), lib.ptr(pk), lib.ptr(xch), lib.ptr(ctrl), lib.ptr(hist))
+            torch.cuda.synchronize()
+            groups = (B + 31) // 32
+            c = ctrl.cpu().numpy()
+            assert c[1] == 0 and c[2] == 32 * groups, c[:4]
+            lib.call("mstts_lstm_seq_bwd_persistent", C.byref(qb), lib.ptr(pkt), lib.ptr(xch), lib.ptr(ctrl), lib.ptr(hist), lib.ptr(bws))
+            torch.cuda.synchronize()
+            c = ctrl.cpu().numpy()
+            assert c[1] == 0 and c[2] == 16 * groups, c[:4]
+            o["keep"] = (pk, pkt, xch, ctrl, hist, bws)
+        else:
+            o["gates"] = torch.empty(L.mstts_lstm_seq_ws_floats(B, H, 0), device=dev)
+            o["ws"] = torch.empty(L.mstts_lstm_seq_ws_floats(B, H, 1), device=dev)
+            q.gates_ws = lib.ptr(o["gates"]); qb.ws = lib.ptr(o["ws"])
+            lib.call("mstts_lstm_seq_fwd", C.byref(q))
+            lib.call("mstts_lstm_seq_bwd", C.byref(qb))
+            torch.cuda.synchronize()
+        out[persistent] = o
+    for k in ("out", "c", "h", "acts", "craw", "dgs", "dgp"):
+        a, b = t2n(out[True][k]), t2n(out[False][k])
+        assert np.isfinite(a).all(), k
+        assert rel_err(a, b) < 5e-5, (k, rel_err(a, b))

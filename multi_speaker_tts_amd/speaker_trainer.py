@@ -8,6 +8,7 @@ learning rate max(exponential_decay, Min).  Python owns buffers and the schedule
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -50,6 +51,10 @@ class SpeakerTrainEngine:
         self.wb_mask = torch.zeros(4, dtype=torch.uint8, device=self.device)
         self.global_step = 0
         self._plans = {}          # workspace sets keyed by batch shape, least recently used first (at most MAX_PLANS kept)
+        # persistent LSTM launches (csrc/persist_lstm.hip): all T steps of a layer in one launch each way; MSTTS_PERSIST_ENC=0 keeps the
+        # launch-per-step loops, which are also the fallback
+        self.persist_lstm = os.environ.get("MSTTS_PERSIST_ENC", "1") != "0"
+        self.persist_lstm_fallbacks = 0
 
     def _f(self, *shape):
         n = int(np.prod(shape))
@@ -88,6 +93,17 @@ class SpeakerTrainEngine:
         if w.fused:
             w.whp, w.hp, w.y = f(H * 4 * H), f(2 * int(lb.mstts_cell_act_floats(N, H))), f(N, T, H)
         w.lengths = torch.full((N,), T, dtype=torch.int32, device=self.device)
+        w.persist = self.persist_lstm and d.spk == H and bool(lb.mstts_persist_lstm_supported_n(N, H, 1))
+        if w.persist:
+            n = int(lb.mstts_persist_lstm_pack_floats())
+            w.pk = [(f(n), f(n)) for _ in range(L)]                                   # (forward order, BPTT order) per layer, refreshed per step
+            w.pxch = f(int(lb.mstts_persist_lstm_ws_bytes_n(N, 1)) // 4)
+            w.pctrl = torch.zeros(16, dtype=torch.int32, device=self.device)
+            w.pctrl_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.phist = [f(int(lb.mstts_persist_lstm_hist_floats_n(T, N, 1))) for _ in range(L)]   # packed history per layer (the BPTT reads it)
+            w.pbws = f(int(lb.mstts_persist_lstm_bwd_floats_n(T, N, 1)))
+            w.phist_valid = [False] * L
+            w.groups = (N + 31) // 32
         w.loss_ws = f(int(lb.mstts_ge2e_ws_floats(N, d.spk, 256)))
         w.out3 = f(4)
         w.d_out = f(N, T, d.spk)                                # gradient of a cell's output sequence
@@ -124,13 +140,28 @@ class SpeakerTrainEngine:
             q.out = ptr(w.y if (res and w.fused) else w.x[i + 1]); q.out_sb = T * H; q.out_st = H
             q.c_hist, q.h_hist, q.acts, q.c_raw = ptr(w.c[i]), ptr(w.h[i]), ptr(w.acts[i]), ptr(w.craw[i])
             q.gates_ws = ptr(w.gates)
-            if w.fused:
-                call("mstts_pack_cell_fwd", ptr(k, ok + d.spk * 4 * H), 4 * H, ptr(w.whp), H, H)
-                q.wh_p, q.h_p = ptr(w.whp), ptr(w.hp)
-            call("mstts_lstm_seq_fwd", C.byref(q))
+            done = False
+            if getattr(w, "persist", False):
+                call("mstts_persist_lstm_pack", ptr(k, ok + d.spk * 4 * H), 4 * H, ptr(w.pk[i][0]), ptr(w.pk[i][1]))
+                call("mstts_lstm_seq_fwd_persistent", C.byref(q), ptr(w.pk[i][0]), ptr(w.pxch), ptr(w.pctrl), ptr(w.phist[i]))
+                done = w.phist_valid[i] = self._persist_ok(w, 32 * w.groups)
+            if not done:
+                if w.fused:
+                    call("mstts_pack_cell_fwd", ptr(k, ok + d.spk * 4 * H), 4 * H, ptr(w.whp), H, H)
+                    q.wh_p, q.h_p = ptr(w.whp), ptr(w.hp)
+                call("mstts_lstm_seq_fwd", C.byref(q))
             if res and w.fused:
                 call("mstts_add", ptr(w.y), ptr(w.x[i]), ptr(w.x[i + 1]), N * T * H)
         return w.x[-1]
+
+    def _persist_ok(self, w, n_wg):
+        """Control words of the persistent launch just enqueued: True when it ran to its end (else the caller runs the launch-per-step loop)."""
+        w.pctrl_host.copy_(w.pctrl, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        ok = int(w.pctrl_host[1]) == 0 and int(w.pctrl_host[2]) == n_wg
+        if not ok:
+            self.persist_lstm_fallbacks += 1
+        return ok
 
     def loss_and_backward(self, w, batch_per_speaker):
         d = self.d
@@ -154,7 +185,12 @@ class SpeakerTrainEngine:
             q.d_out = ptr(d_out); q.dout_sb = T * H; q.dout_st = H
             q.c_hist, q.acts, q.c_raw = ptr(w.c[i]), ptr(w.acts[i]), ptr(w.craw[i])
             q.dgates_step, q.dgates_pos, q.ws = ptr(w.dgs), ptr(w.dgp), ptr(w.bwd_ws)
-            call("mstts_lstm_seq_bwd", C.byref(q))
+            done = False
+            if getattr(w, "persist", False) and w.phist_valid[i]:       # (the persistent BPTT reads the packed history of a persistent forward)
+                call("mstts_lstm_seq_bwd_persistent", C.byref(q), ptr(w.pk[i][1]), ptr(w.pxch), ptr(w.pctrl), ptr(w.phist[i]), ptr(w.pbws))
+                done = self._persist_ok(w, 16 * w.groups)
+            if not done:
+                call("mstts_lstm_seq_bwd", C.byref(q))
             gk, ogk = self.G(SPK_CELL % (i, i) + "kernel"); gb, ogb = self.G(SPK_CELL % (i, i) + "bias")
             gemm(w.x[i], w.dgp, gk, Dm, 4 * H, N * T, Dm, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(Dm, 4 * H, N * T)), c_off=ogk)
             gemm(w.h[i], w.dgs, gk, H, 4 * H, N * T, H, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(H, 4 * H, N * T)), c_off=ogk + Dm * 4 * H)

@@ -35,7 +35,8 @@ def test_ge2e_loss_kernel(dev, S, P, D):
     assert float(dx[:, D:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("S,P,T,kw", [(3, 2, 7, {}), (4, 3, 12, dict(spk=64, spk_lstm=64, n_mel=80))])
+@pytest.mark.parametrize("S,P,T,kw", [(3, 2, 7, {}), (4, 3, 12, dict(spk=64, spk_lstm=64, n_mel=80)),
+                                      (12, 3, 9, dict(spk=256, spk_lstm=256, n_mel=80))])       # reference widths, 36 rows: the persistent launches, 2 row groups
 def test_speaker_train_step_parity(dev, S, P, T, kw):
     """Loss, every gradient (incl. the loss's weight / bias) and the parameters after TF-Adam over two trainer steps."""
     pd, od = dims_pair(**kw)
@@ -63,6 +64,8 @@ def test_speaker_train_step_parity(dev, S, P, T, kw):
         bad = [(k, rel_err(gexp[k], t2n(grads[k]))) for k in gexp if k.startswith(OM.P_S) and rel_err(gexp[k], t2n(grads[k])) > 5e-3]
         assert not bad, bad
         assert abs(float(w.out3[1]) - float(grads["loss/weight"])) < 5e-3 * abs(float(grads["loss/weight"])) + 1e-7
+        if od.spk_lstm == 256 and eng.persist_lstm:
+            assert w.persist and all(w.phist_valid) and eng.persist_lstm_fallbacks == 0      # this case really ran on the persistent launches
         eng.adam_step(w)
         now = eng.params.export()
         bad = [(k, rel_err(now[k], t2n(params[k]))) for k in now if k.startswith(OM.P_S) and rel_err(now[k], t2n(params[k])) > 2e-3]

@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help=argparse.SUPPRESS)       # supplementary measurements only: never the headline
     ap.add_argument("--recurrent-dtype", default="f32", choices=("f32", "bf16"), help=argparse.SUPPRESS)   # bf16 recurrent products only
     ap.add_argument("--force-bf16-recurrent", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-allreduce", action="store_true", help=argparse.SUPPRESS)          # 1 GPU: a one-rank RCCL group, every collective really issued (mechanics check, never a headline)
     ap.add_argument("--no-gemm-tail-split", action="store_true", help=argparse.SUPPRESS)      # A/B: every GEMM tile whole (mstts_gemm_tail_split(0))
     ap.add_argument("--config3", action="store_true", help="BASELINE config 3 arithmetic (bf16 operands everywhere, fp32 master/accumulate); never the headline")
     args = ap.parse_args()
@@ -231,8 +232,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_allreduce:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -258,7 +261,8 @@ def main():
                       gemm_dtype="bf16" if args.config3 else "f32")
     batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
     # config 3: bf16 gradient message with fp32 accumulation on receipt; the fp32 headline keeps the fp32 all-reduce
-    reducer = GradAllReduce(eng.params.grad, world, comm_dtype="bf16" if args.config3 else "f32", overlap=not args.no_overlap) if world > 1 else None
+    reducer = GradAllReduce(eng.params.grad, world, comm_dtype="bf16" if args.config3 else "f32", overlap=not args.no_overlap,
+                            **({"force": True} if args.force_allreduce else {})) if (world > 1 or args.force_allreduce) else None
 
     def sync():
         if dist is not None:

@@ -46,6 +46,8 @@ def _split_k(M, N, K, n_cu=256, max_split=16):
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     if K >= 16384:
         ktiles, best, best_cost = K / 32.0, 1, None
+        if tiles * max_split < n_cu:             # a handful of tiles (the Taco1 convolution bank: 1..8): split until the chip is covered once
+            max_split = min(64, max(max_split, n_cu // tiles))
         for sk in range(1, max_split + 1):
             c = math.ceil(tiles * sk / n_cu)
             cost = c * (ktiles / sk + 6.0) / (0.75 if c == 1 else 0.92 if c == 2 else 1.0) * (1.0 + 0.004 * sk)

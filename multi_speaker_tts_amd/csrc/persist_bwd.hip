@@ -453,17 +453,16 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 }                                                                                                                    \
             }                                                                                                                        \
         }
-        float a0v[4], cr0, cp0;
-        uint8_t zc0v, zh0v;
+        pf32x4 A0_, B0_;                      // cell-0 operands as loaded: split into activations / states / mask bits only where the update uses them
         {
             PROD_GATHER(BO_DG1)
             PROD_HALF(0, w1t, BO_PM0, false)
             PSTAMP(8);
             {   // operands of the cell-0 update backward: requested here, they arrive under the second half and the hand-off
                 const pf32x4* ob = reinterpret_cast<const pf32x4*>(d.opk) + opk_index(s, g0, 0, 0, tid0 & 127);
-                const pf32x4 A_ = ob[0], B_ = ob[128];
-                a0v[0] = A_[0]; a0v[1] = A_[1]; a0v[2] = A_[2]; a0v[3] = A_[3]; cr0 = B_[0]; cp0 = B_[1];
-                zc0v = (uint8_t)(__float_as_uint(B_[2]) & 1u); zh0v = (uint8_t)((__float_as_uint(B_[2]) >> 1) & 1u);
+                A0_ = ob[0]; B0_ = ob[128];
+                // (no arithmetic on them here: the first use makes the compiler wait for the loads, and its vmcnt(0) - the publication just
+                //  above sits in a conditional block - also waits for that write-through store to be acknowledged: 0.5 us in this stage)
             }
             PROD_HALF(1, w1t, BO_PH1, false)
         }
@@ -492,8 +491,9 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         {
             const float dm = sm[B_TR + er * 4 + ee];
             float dhs = dh0s + sm[B_TR + 128 + er * 4 + ee];
-            const float mh = zh0v ? d.keep : 0.f, mc = zc0v ? d.keep : 0.f;
-            const pf32x4 dgv = cell_bwd(dm, dhs, dc0s, a0v[0], a0v[1], a0v[2], a0v[3], cr0, cp0, mh, mc);
+            const unsigned bits0 = __float_as_uint(B0_[2]);
+            const float mh = (bits0 & 2u) ? d.keep : 0.f, mc = (bits0 & 1u) ? d.keep : 0.f;
+            const pf32x4 dgv = cell_bwd(dm, dhs, dc0s, A0_[0], A0_[1], A0_[2], A0_[3], B0_[0], B0_[1], mh, mc);
             dh0s = dhs;
             if (ew) {
 #pragma unroll

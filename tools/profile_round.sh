@@ -6,6 +6,8 @@
 #      SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE (matrix-core busy) - all at the FULL config-2 size
 #   4. Audio.melspectrogram timing + its kernel rows
 #   5. free-running decoder (tools/infer_bench.py) timing + its kernel rows
+#   6. device idle time inside a step, every GEMM call of a step replayed on its own, the BiLSTM recurrence bench, the auxiliary trainers,
+#      per-workgroup stage stamps of the persistent decoder launches
 # Outputs land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -32,5 +34,10 @@ python $ROOT/tools/rocpd_stats.py $OUT/kt_stft/kt_results.db $OUT/stft_mel_kerne
 python $ROOT/tools/infer_bench.py > $OUT/infer_line.txt 2> $OUT/infer.err
 rocprofv3 --kernel-trace -d $OUT/kt_inf -o kt -- python $ROOT/tools/infer_bench.py > $OUT/kt_inf.log 2>&1
 python $ROOT/tools/rocpd_stats.py $OUT/kt_inf/kt_results.db $OUT/infer_kernel_stats.csv
+python $ROOT/tools/rocpd_gaps.py $OUT/kt/kt_results.db $OUT/train_step_gaps.txt
+python $ROOT/tools/gemm_step_profile.py > $OUT/gemm_step_profile.txt 2> /dev/null
+python $ROOT/tools/lstm_bench.py > $OUT/lstm_bench.txt 2> /dev/null
+python $ROOT/tools/aux_trainers_bench.py > $OUT/aux_trainers.txt 2> /dev/null
+python $ROOT/tools/persist_stamps.py > $OUT/persist_stamps_per_workgroup.txt 2> /dev/null
 rm -rf $OUT/kt $OUT/kt3 $OUT/kt_stft $OUT/kt_inf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcm_*
 ls -la $OUT

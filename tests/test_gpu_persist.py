@@ -13,7 +13,7 @@ from multi_speaker_tts_amd.engine import TrainEngine
 pytestmark = pytest.mark.gpu
 
 # reference widths where the loop sees them (decoder cells 1024, memory 768 = 2 x 256 + 256, attention 128 / 31 taps); the rest reduced
-WIDE = dict(emb=64, enc_conv_ch=64, enc_lstm=256, spk=256, prenet=64, dec_lstm=1024, n_mel=16, post_ch=32)
+WIDE = dict(emb=64, enc_conv_ch=64, enc_lstm=256, spk=256, prenet=256, dec_lstm=1024, n_mel=16, post_ch=32)      # (prenet 256: the launch forms the prenet rows' product itself)
 HIST = ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist")
 
 

@@ -30,7 +30,12 @@ enum { MSTTS_OK = 0, MSTTS_ERR_SHAPE = -1, MSTTS_ERR_DTYPE = -2, MSTTS_ERR_ALIGN
 enum { MSTTS_ACT_NONE = 0, MSTTS_ACT_RELU = 1, MSTTS_ACT_TANH = 2, MSTTS_ACT_SIGMOID = 3 };
 
 const char* mstts_last_error(void);
+/* Bumped whenever a descriptor struct or an entry point's signature changes (2: round 4); the Python binding checks it at load. */
 int mstts_abi_version(void);
+/* Diagnostic (tests of the persistent launches' co-residency handling; no reference counterpart - MSTTS_SV.py:24 is a single session on one
+ * device): n_workgroups workgroups that each hold 96 KB of LDS - a whole CU as far as a persistent workgroup is concerned - for
+ * `microseconds`, then add 1 to *done_count (may be null). */
+int mstts_debug_park_cus(int32_t n_workgroups, int64_t microseconds, uint32_t* done_count, mstts_stream_t s);
 
 /* ---- dense contraction (tf.matmul / tf.layers.dense / tf.layers.conv1d and their gradients) ---
  * C[M,N] = act(alpha * op(A) . op(B) + bias)   (accumulate: C += ...; split_k > 1: atomic add)
@@ -55,8 +60,11 @@ typedef struct {
 int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
 /* Scheduling of mstts_gemm_f32, process-wide, default on: a tile list that ends in a small fraction of a round of the 256 CUs
  * (25 632 x 512 outputs = 3 rounds + 36 tiles) has its last tiles cut along K into pieces that fill one short round, accumulated with
- * atomics onto a cleared (or, with accumulate, the existing) C.  Only for act == none, batch == 1, split_k == 1.  0 switches it off
- * (every tile whole: the summation order of every output element fixed). */
+ * atomics onto a cleared (or, with accumulate, the existing) C; bias from piece 0; an activation (relu / tanh) is applied to the cut
+ * tiles' rows by a second small kernel once the pieces have landed.  Only for batch == 1, split_k == 1.  The fp32 atomicAdd order of
+ * the pieces is not fixed, so the cut tiles of a FORWARD product (e.g. the last rows of a postnet convolution) are reproducible run to
+ * run only to the last bit or two; 0 switches the schedule off (every tile whole: the summation order of every output element fixed -
+ * what the bit-reproducibility tests select). */
 int mstts_gemm_tail_split(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes. */

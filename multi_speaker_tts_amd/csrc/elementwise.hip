@@ -802,13 +802,39 @@ __global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ 
     }
 }
 
+// Diagnostic: `n` workgroups that each claim a whole CU's worth of LDS (96 KB: no persistent workgroup fits beside one) and sit on it for
+// `ticks` of the 100 MHz wall clock - a stand-in for another tenant of the chip (a collective that outlives its slot, a second process)
+// in the tests of the persistent launches' co-residency rendezvous.
+__global__ __launch_bounds__(64) void park_cus_kernel(unsigned long long ticks, unsigned* out) {
+    extern __shared__ float park_lds[];
+    park_lds[threadIdx.x] = 1.f;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (out && threadIdx.x == 0 && park_lds[0] > 0.f) atomicAdd(out, 1u);
+}
+
 }  // namespace mstts
 
 using namespace mstts;
 #define ST(s) ((hipStream_t)(s))
 
 extern "C" const char* mstts_last_error(void) { return err_buf(); }
-extern "C" int mstts_abi_version(void) { return 1; }
+extern "C" int mstts_abi_version(void) { return 2; }
+
+extern "C" int mstts_debug_park_cus(int32_t n_workgroups, int64_t microseconds, uint32_t* done_count, mstts_stream_t s) {
+    MSTTS_REQUIRE(n_workgroups >= 1 && n_workgroups <= 1024 && microseconds >= 0 && microseconds <= 1000000, MSTTS_ERR_SHAPE, "debug_park_cus: 1..1024 workgroups, at most 1 s");
+    const size_t lds = 96 * 1024;
+    static int memo[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !memo[dev]) {
+        if (hipFuncSetAttribute((const void*)park_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return set_err(MSTTS_ERR_LAUNCH, "debug_park_cus: the device does not take a 96 KB workgroup");
+        memo[dev] = 1;
+    }
+    hipLaunchKernelGGL(park_cus_kernel, dim3((unsigned)n_workgroups), dim3(64), lds, ST(s), (unsigned long long)microseconds * 100ull, done_count);
+    MSTTS_CHECK_LAUNCH("park_cus");
+    return MSTTS_OK;
+}
 
 extern "C" int mstts_philox_keep_mask(uint8_t* out, int64_t n, uint64_t seed, uint32_t stream_id, float keep_prob, mstts_stream_t s) {
     MSTTS_REQUIRE(n >= 0 && (n == 0 || out), MSTTS_ERR_SHAPE, "philox: bad args");

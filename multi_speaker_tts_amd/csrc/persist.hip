@@ -589,23 +589,18 @@ extern "C" int64_t mstts_persist_pack_floats(int32_t which) { return which == 0 
  * kernel's LDS and registers, and the device must have at least 256 CUs) */
 extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS) {
     if (!(B >= 1 && B <= PROWS && H == PH && M == PM && A == PA && T >= 1 && T <= PT && KS == PKS)) return 0;
-    static int cached = -1;
-    if (cached < 0) {
-        int dev = 0, cus = 0, per_cu = 0;
-        cached = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= PWG) {
-            const size_t lds = (size_t)S_FLOATS * 4;
-            if (hipFuncSetAttribute((const void*)persist_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipFuncSetAttribute((const void*)persist_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipFuncSetAttribute((const void*)persist_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipFuncSetAttribute((const void*)persist_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, true>, PTH, lds) == hipSuccess && per_cu >= 1 &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, false>, PTH, lds) == hipSuccess && per_cu >= 1)
-                cached = 1;
-        }
-        (void)hipGetLastError();
-    }
-    return cached;
+    static int memo[PERSIST_MAX_DEVICES];
+    return persist_device_memo(memo, [](int dev) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < PWG) return false;
+        const size_t lds = (size_t)S_FLOATS * 4;
+        return hipFuncSetAttribute((const void*)persist_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipFuncSetAttribute((const void*)persist_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipFuncSetAttribute((const void*)persist_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipFuncSetAttribute((const void*)persist_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, true>, PTH, lds) == hipSuccess && per_cu >= 1 &&
+               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, false>, PTH, lds) == hipSuccess && per_cu >= 1;
+    });
 }
 
 extern "C" int mstts_persist_pack(const float* w0f, const float* w1, const float* wq, const float* wx0, float* w0pk, float* w1pk, float* wqpk, mstts_stream_t s) {

@@ -18,7 +18,11 @@ constexpr int PH = 1024, PM = 768, PA = 128, PT = 128, PROWS = 32, PWG = 256, PT
 constexpr int PKS = 31;                          // location filter taps (hp.Attention.Conv.Kernel_Size)
 constexpr int PRING = 4;
 constexpr unsigned PSENT = 0xFFFFFFFFu;
-constexpr unsigned long long PERSIST_TIMEOUT_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock per wait
+constexpr unsigned long long PERSIST_TIMEOUT_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock per wait inside the loop
+// The start rendezvous has its own, much shorter bound: the workgroups of one launch are dispatched together, so either all of them find a
+// CU within microseconds or some of them are waiting for CUs that another stream's kernel holds - and then the launch-per-step loop is
+// the better use of the next 0.2 s.  2 ms covers a collective's kernel draining off the CUs it took.
+constexpr unsigned long long PERSIST_RENDEZVOUS_TICKS = 200000ull;
 
 // true while any word of the piece still shows the other generation
 __device__ __forceinline__ bool stale(const pf32x4& v, unsigned gen) {
@@ -70,7 +74,7 @@ __device__ __forceinline__ int persist_rendezvous(unsigned* ctrl, int g) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PWG) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (wall_clock64() - t0 > PERSIST_RENDEZVOUS_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
             __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return 0;
         }
@@ -145,6 +149,17 @@ __device__ __forceinline__ bool complete(__amdgpu_buffer_rsrc_t r, const unsigne
 // row-strided accesses per step and direction, each touching 16 pages.
 __device__ __forceinline__ long opk_index(int s, int g, int cell, int half, int tid) { return ((((long)s * PWG + g) * 2 + cell) * 2 + half) * 128 + tid; }
 constexpr long OPK_FLOATS_PER_STEP = (long)PWG * 2 * 2 * 128 * 4;
+
+// Per-device memo of a "can this device take the launch" probe (CU count, occupancy, the kernels' dynamic-LDS attribute): the probe runs
+// once for EVERY device a process drives - hipFuncSetAttribute applies to the current device only - not once per process.
+constexpr int PERSIST_MAX_DEVICES = 64;
+template <typename Probe>
+static inline int persist_device_memo(int* memo, Probe probe) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PERSIST_MAX_DEVICES) { (void)hipGetLastError(); return 0; }
+    if (memo[dev] == 0) { memo[dev] = probe(dev) ? 2 : 1; (void)hipGetLastError(); }
+    return memo[dev] == 2 ? 1 : 0;
+}
 
 #define PMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 

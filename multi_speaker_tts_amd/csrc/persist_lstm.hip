@@ -53,7 +53,7 @@ __device__ __forceinline__ bool lstm_rendezvous(unsigned* ctrl, unsigned n) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (wall_clock64() - t0 > PERSIST_RENDEZVOUS_TICKS || __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
             __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -416,13 +416,11 @@ static int lstm_groups(long B) { return (int)((B + 31) / 32); }
  * the current device: H == 256, at most 16 row groups of 32 rows in all (their workgroups must be co-resident) */
 extern "C" int32_t mstts_persist_lstm_supported_n(int64_t B, int64_t H, int32_t ndir) {
     if (!(B >= 1 && H == EH && (ndir == 1 || ndir == 2) && ndir * lstm_groups(B) <= 16)) return 0;
-    static int cached = -1;
-    if (cached < 0) {
-        int dev = 0, cus = 0;
-        cached = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256) ? 1 : 0;
-        (void)hipGetLastError();
-    }
-    return cached;
+    static int memo[PERSIST_MAX_DEVICES];
+    return persist_device_memo(memo, [](int dev) {
+        int cus = 0;
+        return hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256;
+    });
 }
 extern "C" int32_t mstts_persist_lstm_supported(int64_t B, int64_t H) { return B <= 32 ? mstts_persist_lstm_supported_n(B, H, 2) : 0; }
 extern "C" int64_t mstts_persist_lstm_pack_floats(void) { return (int64_t)EH * 4 * EH; }

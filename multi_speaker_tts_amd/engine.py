@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -62,6 +63,10 @@ def _split_k(M, N, K, n_cu=256, max_split=16):
         if best_cost is None or cost < best_cost - 1e-9:
             best, best_cost = sk, cost
     return best
+
+
+PERSIST_STRIKES = 2          # consecutive steps with a fallback before the persistent plans are switched off ...
+PERSIST_COOLDOWN = 200       # ... for this many steps
 
 
 class _WS:
@@ -116,6 +121,18 @@ class TrainEngine:
         self.persist = (os.environ.get("MSTTS_PERSIST", "1") != "0" and (recurrent_dtype or "f32").lower() == "f32"
                         and bool(lb.mstts_persist_fwd_supported(1, H, M, d.att, 1, d.att_k)))
         self.persist_fallbacks = 0           # sequences that had to be re-run on the launch-per-step path
+        # Adaptive policy: a persistent launch that gives up costs its rendezvous bound plus the slow loop, and something that holds CUs
+        # (another process, a profiler, a collective that outlives its slot) will do so again next step.  After PERSIST_STRIKES
+        # consecutive steps with a fallback the persistent plans are switched off for PERSIST_COOLDOWN steps (warned once), then probed
+        # again.  persist_disabled_steps counts the steps run that way; non_persistent_plans the shapes planned without them although
+        # the widths are the reference's (the T_enc / batch cliff of the persistent kernels).
+        self._moving_snapshot = None
+        self._persist_strikes = 0
+        self._persist_off = 0                # steps left of the cool-down
+        self._persist_warned = False
+        self.persist_disabled_steps = 0
+        self.non_persistent_plans = 0
+        self._warned_shapes = set()
         self.persist_selftest = 0            # tests: k > 0 makes the persistent forward launch abort at step k - 1
         self.persist_bwd_selftest = 0        # ... and the persistent BPTT launch at its k-th step
         self.persist_stamps = None           # bench: 256 x 16 int64 tensor -> per-stage ticks of the next persistent launch
@@ -301,6 +318,13 @@ class TrainEngine:
             w.enc_bws = f(int(lb.mstts_persist_lstm_bwd_floats(Te)))
             w.enc_hist_valid = False
         w.persist = self.persist and bool(lb.mstts_persist_fwd_supported(B, H, M, A, Te, d.att_k))
+        if self.persist and not w.persist:
+            # the device and the widths admit the persistent launches, this batch shape does not: ~1.7x slower loop - say so, once per shape
+            self.non_persistent_plans += 1
+            if (B, Te) not in self._warned_shapes:
+                self._warned_shapes.add((B, Te))
+                warnings.warn("multi_speaker_tts_amd: batch %d x %d tokens is outside the persistent decoder kernels' range "
+                              "(mstts_persist_fwd_supported); this shape runs the launch-per-step loops" % (B, Te), RuntimeWarning, stacklevel=3)
         if w.persist:
             w.xch = f(int(lb.mstts_persist_fwd_ws_bytes()) // 4)
             w.pctrl = torch.zeros(272, dtype=torch.int32, device=self.device)
@@ -407,6 +431,9 @@ class TrainEngine:
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
         if self._derived_stale:
             self.refresh_derived()
+        allowed = self._persist_begin_step()
+        w.persist_now = bool(w.persist) and allowed
+        w.persist_bwd_now = bool(getattr(w, "persist_bwd", False)) and allowed
         if masks is not None:
             w.masks.load(masks)
         else:
@@ -441,7 +468,7 @@ class TrainEngine:
             if self.enc_whp is not None:                 # fused steps: packed recurrent kernel + packed h blocks
                 q.wh_p, q.h_p = ptr(self.enc_whp[dr]), ptr(w.enc_hp[dr])
             seqs.append(q)
-        w.enc_hist_valid = bool(getattr(w, "persist_enc", False)) and self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)
+        w.enc_hist_valid = bool(getattr(w, "persist_enc", False)) and allowed and self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)
         if not w.enc_hist_valid:
             self._ensure_fallback_packs()
             call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
@@ -459,7 +486,7 @@ class TrainEngine:
             x, cin = w.pre_d[i], Pn
         k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
         # cell-0 input product xw0 = prenet . W0[:P] + b0: inside the persistent launch (fp32 mode, 256-wide prenet), else hoisted here
-        w.fold_prenet = bool(w.persist) and self.gemm_dtype == "f32" and Pn == 256 and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"
+        w.fold_prenet = w.persist_now and self.gemm_dtype == "f32" and Pn == 256 and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"
         xw0_product = lambda: self._gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
         if not w.fold_prenet:
             xw0_product()
@@ -491,13 +518,13 @@ class TrainEngine:
         for nm in ("in0", "in1", "pj", "c0", "c1", "acts0", "acts1", "craw0", "craw1", "q_hist", "align_hist", "cum_hist", "gates_ws", "energy_ws", "q_ws"):
             setattr(dec, nm, ptr(getattr(w, nm)))
         ev = None
-        if w.persist:
+        if w.persist_now:
             # ONE launch for all S steps; the launch-per-step loop below is the fallback when the 256 workgroups were not co-resident
             # or a bounded wait expired (ctrl words, checked after the rest of the forward pass is enqueued - no bubble on the device)
             pd = w.pdesc
             pd.w0pk, pd.w1pk, pd.wqpk, pd.xch, pd.ctrl = ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]), ptr(w.xch), ptr(w.pctrl)
             pd.stamps = ptr(self.persist_stamps) if self.persist_stamps is not None else None
-            pd.opk = ptr(w.opk) if getattr(w, "persist_bwd", False) else None
+            pd.opk = ptr(w.opk) if w.persist_bwd_now else None
             w.opk_valid = pd.opk is not None
             pd.selftest_fail_step = int(self.persist_selftest)
             pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
@@ -509,6 +536,14 @@ class TrainEngine:
             w.opk_valid = False
             self._ensure_fallback_packs()
             call("mstts_decoder_train_fwd", C.byref(dec))
+        if ev is not None:
+            # the tail below runs on the persistent launch's outputs before its status words are known; a launch that gave up leaves junk
+            # there, and the tail's BN layers (postnet, the vocoder's conv bank) would fold that junk into their MOVING statistics - one
+            # update per train step is the reference's behaviour (Modules.py:37-40 update ops), so they are put back before the re-run
+            n_mov = self.params.n_moving
+            if self._moving_snapshot is None or self._moving_snapshot.numel() != n_mov:
+                self._moving_snapshot = torch.empty(n_mov, dtype=torch.float32, device=self.device)
+            self._moving_snapshot.copy_(self.params.frozen[:n_mov])
         self._forward_tail(w)
         if ev is not None:
             cur = torch.cuda.current_stream()
@@ -521,8 +556,10 @@ class TrainEngine:
             st = w.pctrl_host
             if int(st[1]) != 0 or int(st[2]) != 256:
                 self.persist_fallbacks += 1
+                self._step_fell_back = True
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
                 cur.synchronize()
+                self.params.frozen[:self.params.n_moving].copy_(self._moving_snapshot)
                 w.opk_valid = False                   # the launch-per-step loop writes the row-major histories
                 if w.fold_prenet:
                     xw0_product()                     # ... and reads the hoisted cell-0 input product
@@ -548,7 +585,33 @@ class TrainEngine:
         st = w.enc_ctrl_host
         if int(st[1]) != 0 or int(st[2]) != n_wg:
             self.persist_enc_fallbacks += 1
+            self._step_fell_back = True
             return False
+        return True
+
+    def _persist_begin_step(self):
+        """Adaptive fallback policy, called once per forward pass: closes the books on the previous step (a step in which any persistent
+        launch gave up is a strike; PERSIST_STRIKES in a row start a cool-down) and says whether this step may use the persistent
+        launches."""
+        if getattr(self, "_step_fell_back", False):
+            self._persist_strikes += 1
+            if self._persist_strikes >= PERSIST_STRIKES:
+                self._persist_off = PERSIST_COOLDOWN
+                self._persist_strikes = 0
+                if not self._persist_warned:
+                    self._persist_warned = True
+                    warnings.warn("multi_speaker_tts_amd: %d consecutive steps fell back from the persistent launches (status %r: something "
+                                  "else holds compute units); running the launch-per-step loops for %d steps before probing again"
+                                  % (PERSIST_STRIKES, getattr(self, "persist_last_status", None), PERSIST_COOLDOWN), RuntimeWarning, stacklevel=4)
+        elif getattr(self, "_step_was_persistent", False):
+            self._persist_strikes = 0
+        self._step_fell_back = False
+        if self._persist_off > 0:
+            self._persist_off -= 1
+            self.persist_disabled_steps += 1
+            self._step_was_persistent = False
+            return False
+        self._step_was_persistent = True
         return True
 
     def unpack_history(self, w):
@@ -628,7 +691,7 @@ class TrainEngine:
         # every CU of the chip for itself: a collective kernel holding CUs at that moment and the 256 workgroups waiting for each
         # other's CUs would sit out the launch's start window (0.2 s) and end in the fallback.  Then the range is announced BEHIND the
         # launch (the collective is ordered after what is enqueued) and runs under the hoisted weight-gradient products instead.
-        postnet_ready_deferred = on_ready is not None and bool(getattr(w, "persist_bwd", False))
+        postnet_ready_deferred = on_ready is not None and bool(getattr(w, "persist_bwd_now", False))
         if on_ready is not None and not postnet_ready_deferred:
             on_ready(*self._grad_range("decoder/conv_"))
         # d_linear(total) = loss part + residual (d_post) + postnet input grad
@@ -656,9 +719,9 @@ class TrainEngine:
         w.d_keys.zero_()
         self.d_loc_k.zero_()
         parts = w.d_in0_parts
-        if getattr(w, "opk_valid", False) and not getattr(w, "persist_bwd", False):
+        if getattr(w, "opk_valid", False) and not getattr(w, "persist_bwd_now", False):
             self.unpack_history(w)            # the persistent forward packed the cell operands; the launch-per-step BPTT reads the histories
-        if getattr(w, "persist_bwd", False) and getattr(w, "opk_valid", False):
+        if getattr(w, "persist_bwd_now", False) and getattr(w, "opk_valid", False):
             # ONE launch for the whole BPTT; its status words are read while the hoisted weight-gradient products run (no bubble); the
             # launch-per-step loop is the fallback
             pb = w.pdesc_b
@@ -679,6 +742,7 @@ class TrainEngine:
             st = w.pctrl_b_host
             if int(st[1]) != 0 or int(st[2]) != 256:
                 self.persist_bwd_fallbacks += 1
+                self._step_fell_back = True
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
                 self.unpack_history(w)
                 w.dq_hist.zero_()

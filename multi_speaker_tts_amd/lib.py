@@ -114,6 +114,7 @@ P = C.POINTER
 SIGNATURES = {
     "mstts_last_error": (C.c_char_p, []),
     "mstts_abi_version": (i32, []),
+    "mstts_debug_park_cus": (i32, [i32, i64, vp, vp]),
     "mstts_gemm_f32": (i32, [P(GemmDesc), vp]),
     "mstts_gemm_tail_split": (i32, [i32]),
     "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
@@ -254,6 +255,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 2          # = mstts_abi_version() of the library this binding's ctypes structs describe (bump both on a descriptor change)
+
+
 class MsttsError(RuntimeError):
     pass
 
@@ -268,9 +272,10 @@ def load():
         try:
             _b.build()
         except RuntimeError as e:
-            # a deployed library without its hash sidecars on a host without hipcc: load what is there (never a CPU fallback -
-            # without the .so this still raises)
-            if "hipcc not found" in str(e) and os.path.exists(LIB_PATH):
+            # a deployed library WITHOUT its hash sidecar on a host without hipcc: load what is there (never a CPU fallback - without
+            # the .so this still raises).  A sidecar that exists and disagrees with the sources means the library really is stale: its
+            # descriptor structs may differ from the ctypes ones (symbols would still resolve), so that stays an error.
+            if "hipcc not found" in str(e) and os.path.exists(LIB_PATH) and not os.path.exists(LIB_PATH + ".hash"):
                 import warnings
                 warnings.warn("libmstts_hip.so could not be checked against its sources (hipcc not found); loading the existing library")
             else:
@@ -280,6 +285,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch; never fall back
         fn.restype = res
         fn.argtypes = args
+    if lib.mstts_abi_version() != ABI_VERSION:     # descriptor layouts are not visible to the symbol check above
+        raise MsttsError("libmstts_hip.so reports ABI version %d, this binding is written for %d: rebuild the library (python -m multi_speaker_tts_amd.build --force)"
+                         % (lib.mstts_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

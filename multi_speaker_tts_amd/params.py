@@ -203,17 +203,25 @@ class ParamStore:
         weight_reg_fn = weight_reg_fn or in_weight_reg
         self.offset, self.shape, self.trainable = {}, {}, {}
         n_t = n_f = 0
-        for name, shape, _ in self.table:
-            n = int(np.prod(shape))
-            tr = bool(trainable_fn(name))
-            self.trainable[name] = tr
-            self.shape[name] = tuple(shape)
-            if tr:
-                self.offset[name] = n_t
-                n_t += (n + 3) // 4 * 4
-            else:
-                self.offset[name] = n_f
-                n_f += (n + 3) // 4 * 4
+        # the non-trainable slab starts with every BN moving statistic (one contiguous range `frozen[:n_moving]`: the train engine
+        # snapshots it with one small copy before a speculative forward tail), the frozen sub-models' variables follow
+        is_moving = lambda name: name.endswith(("moving_mean", "moving_variance"))
+        for moving_pass in (True, False):
+            for name, shape, _ in self.table:
+                n = int(np.prod(shape))
+                tr = bool(trainable_fn(name))
+                if moving_pass != (not tr and is_moving(name)):
+                    continue
+                self.trainable[name] = tr
+                self.shape[name] = tuple(shape)
+                if tr:
+                    self.offset[name] = n_t
+                    n_t += (n + 3) // 4 * 4
+                else:
+                    self.offset[name] = n_f
+                    n_f += (n + 3) // 4 * 4
+            if moving_pass:
+                self.n_moving = n_f
         self.n_train, self.n_frozen = n_t, n_f
         self.train = torch.zeros(n_t, dtype=torch.float32, device=device)
         self.frozen = torch.zeros(max(n_f, 4), dtype=torch.float32, device=device)

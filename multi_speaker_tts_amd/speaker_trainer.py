@@ -93,7 +93,8 @@ class SpeakerTrainEngine:
         if w.fused:
             w.whp, w.hp, w.y = f(H * 4 * H), f(2 * int(lb.mstts_cell_act_floats(N, H))), f(N, T, H)
         w.lengths = torch.full((N,), T, dtype=torch.int32, device=self.device)
-        w.persist = self.persist_lstm and d.spk == H and bool(lb.mstts_persist_lstm_supported_n(N, H, 1))
+        # (the persistent launches take no residual input: they need the fused form's "one add per sequence afterwards")
+        w.persist = self.persist_lstm and w.fused and bool(lb.mstts_persist_lstm_supported_n(N, H, 1))
         if w.persist:
             n = int(lb.mstts_persist_lstm_pack_floats())
             w.pk = [(f(n), f(n)) for _ in range(L)]                                   # (forward order, BPTT order) per layer, refreshed per step

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), "library does not export %s" % name
     assert sorted(lib.SIGNATURES) == declared, set(lib.SIGNATURES) ^ set(declared)
     cdll.mstts_abi_version.restype = ctypes.c_int
-    assert cdll.mstts_abi_version() == 1
+    from multi_speaker_tts_amd.lib import ABI_VERSION
+    assert cdll.mstts_abi_version() == ABI_VERSION == 2
     # host-only helpers are callable without a GPU
     cdll.mstts_skinny_fwd_splits.restype = ctypes.c_int32
     cdll.mstts_skinny_fwd_splits.argtypes = [ctypes.c_int64, ctypes.c_int64]

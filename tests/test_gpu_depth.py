@@ -1,6 +1,7 @@
 """Parity at the DEPTH the headline metric is quoted on (Modules.py:212-237: the teacher-forced loop runs max(Mel_Length) + 1 = 801
 steps; Hyper_Parameters.py:53 allows 1000 free-running steps): the HIP path against the fp64 oracle at the reference's decoder widths
-over 51 / 201 / 801 decoder steps, and 200 free-running steps with rows that stop at different steps.  Everything recurrent in the
+over 51 / 201 / 801 decoder steps (B = 4 x 64 tokens) and once at the full headline shape (B = 32 x 128 tokens x 801 steps), and up to 200
+free-running steps with rows that stop at different steps.  Everything recurrent in the
 HIP path is fp32 with hardware exp-based gates; these tests are where its error growth over the sequence is measured."""
 import json
 import os
@@ -24,14 +25,11 @@ def _record(tag, payload):
             f.write(json.dumps(dict(tag=tag, **payload)) + "\n")
 
 
-@pytest.mark.parametrize("L", [50, 200, 800])
-def test_depth_parity_train(dev, L):
-    """One train step at B = 4 x 64 tokens x L frames, reference widths, fp32 HIP vs fp64 oracle (forward tensors, loss scalars, every
-    gradient).  north_star's bound - mel within 1e-3 relative - must hold at every depth, including the 801 steps of BASELINE configs[1]."""
+def _train_depth_case(dev, B, Te, L, tag):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     OM.RELU_INJECTED.update(elements=0, differ=0)
-    eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, 4, 64, L, True, seed=17, **REF)
-    assert not w.persist or (eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0)
+    eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, True, seed=17, **REF)
+    assert not w.persist or (eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0 and eng.persist_enc_fallbacks == 0)
     errs = {"linear": rel_err(t2n(w.linear), t2n(out["Linear"])), "mel": rel_err(t2n(w.mel_out), t2n(out["Mel"])),
             "stop": rel_err(t2n(w.stop), t2n(out["Stop_Logit"])),
             "align": rel_err(t2n(w.align_hist).transpose(1, 2, 0), t2n(out["Attention_History"]))}
@@ -46,16 +44,37 @@ def test_depth_parity_train(dev, L):
         worst[k] = float(np.abs(mine - ref).max() / (np.abs(ref).max() + 1e-9))
     gmax = max(worst.values())
     got = eng.scalars(w)
-    _record("train", dict(L=L, steps=L + 1, persistent=bool(w.persist), forward=errs, mel_err_up_to_step=curve, worst_gradient=gmax,
-                          relu_injected=dict(OM.RELU_INJECTED)))
-    print("depth %d: forward %s, mel error up to step %s, worst gradient %.2e, injected ReLU pattern: %d of %d elements differ (all inside the kink band)"
-          % (L, errs, curve, gmax, OM.RELU_INJECTED["differ"], OM.RELU_INJECTED["elements"]))
+    _record(tag, dict(B=B, tokens=Te, L=L, steps=L + 1, persistent=bool(w.persist), forward=errs, mel_err_up_to_step=curve, worst_gradient=gmax,
+                      relu_injected=dict(OM.RELU_INJECTED)))
+    print("%s B %d x %d tokens, depth %d: forward %s, mel error up to step %s, worst gradient %.2e, injected ReLU pattern: %d of %d elements differ "
+          "(all inside the kink band)" % (tag, B, Te, L, errs, curve, gmax, OM.RELU_INJECTED["differ"], OM.RELU_INJECTED["elements"]))
     for k, e in errs.items():
         assert e < 1e-3, (k, e, L)
     for k in ("Linear_Loss", "Postnet_Loss", "Stop_Loss", "Loss"):
         assert abs(got[k] - sc[k]) <= 1e-4 * max(1.0, abs(sc[k])), (k, got[k], sc[k])
     bad = {k: v for k, v in worst.items() if v > 5e-3}
     assert not bad, bad
+    return w
+
+
+@pytest.mark.parametrize("L", [50, 200, 800])
+def test_depth_parity_train(dev, L):
+    """One train step at B = 4 x 64 tokens x L frames, reference widths, fp32 HIP vs fp64 oracle (forward tensors, loss scalars, every
+    gradient).  north_star's bound - mel within 1e-3 relative - must hold at every depth, including the 801 steps of BASELINE configs[1]."""
+    _train_depth_case(dev, 4, 64, L, "train")
+
+
+def test_headline_shape_parity(dev):
+    """The exact shape the headline metric is quoted on (BASELINE configs[1]; MSTTS_SV.py:129-161, Hyper_Parameters.py:69, Modules.py:215):
+    ONE train step at B = 32 x 128 tokens x 800 frames (801 decoder steps), reference widths, every attention row and every key position of
+    the persistent kernels busy, fp32 HIP against the **fp64** oracle: forward <= 1e-3, losses <= 1e-4, every gradient <= 5e-3 of its
+    maximum, zero fallbacks.  The oracle's autograd tape at this size needs tens of GB of host memory: skipped on a host without it."""
+    import psutil
+    need = 96 << 30
+    if psutil.virtual_memory().available < need:
+        pytest.skip("fp64 oracle tape of the full shape needs ~%d GB of host memory" % (need >> 30))
+    w = _train_depth_case(dev, 32, 128, 800, "headline_shape")
+    assert w.persist and w.persist_bwd and w.persist_enc
 
 
 def test_depth_parity_free_running(dev):

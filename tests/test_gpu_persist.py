@@ -97,15 +97,24 @@ def test_persistent_abort_falls_back(dev):
     batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=True), dev)
     w = eng.plan(B, Te, L)
     eng.persist_selftest = 4
+    mov0 = eng.params.frozen[:eng.params.n_moving].clone()
+    assert eng.params.n_moving > 0
     eng.forward(batch, w, seed=11)
     torch.cuda.synchronize()
     assert eng.persist_fallbacks == 1 and eng.persist_last_status[1] == 3 and eng.persist_last_status[2] < 256
     a = _snapshot(w, eng)
+    mov_a = eng.params.frozen[:eng.params.n_moving].clone()
     eng.persist_selftest = 0
     w.persist = False
+    eng.params.frozen[:eng.params.n_moving].copy_(mov0)
     eng.forward(batch, w, seed=11)
     torch.cuda.synchronize()
     b = _snapshot(w, eng)
+    # the BN moving statistics took ONE update (Modules.py:37-40: one update op per train step), not one from the aborted launch's junk
+    # outputs and a second from the re-run (postnet layers and the vocoder conv bank sit behind the decoder loop)
+    mov_b = eng.params.frozen[:eng.params.n_moving]
+    assert not torch.equal(mov_b, mov0)
+    assert torch.allclose(mov_a, mov_b, rtol=1e-5, atol=1e-7), float((mov_a - mov_b).abs().max())
     for k in a:                                          # the fallback IS the launch-per-step path (what is upstream of the loop
         assert rel_err(a[k], b[k]) < 5e-5, k             # holds atomic reductions, so equal to rounding, not to the bit)
     w.persist = True
@@ -114,6 +123,86 @@ def test_persistent_abort_falls_back(dev):
     assert eng.persist_fallbacks == 1
     c = _snapshot(w, eng)
     assert rel_err(c["pj"], b["pj"]) < 2e-5
+
+
+def test_adaptive_fallback_cooldown(dev, monkeypatch):
+    """Policy (engine._persist_begin_step): two consecutive steps whose persistent launch gave up switch the persistent plans off for a
+    cool-down (one warning), the steps in between run the launch-per-step loops without paying a rendezvous, then the launches are
+    probed again."""
+    import warnings
+    from multi_speaker_tts_amd import engine as E
+    monkeypatch.setattr(E, "PERSIST_COOLDOWN", 3)
+    eng, od = _engine(dev)
+    B, Te, L = 8, 40, 6
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=True), dev)
+    w = eng.plan(B, Te, L)
+    eng.forward(batch, w, seed=11)
+    ref = _snapshot(w, eng)
+    eng.persist_selftest = 2
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        eng.forward(batch, w, seed=11)                   # strike 1
+        eng.forward(batch, w, seed=11)                   # strike 2
+        assert eng.persist_fallbacks == 2 and eng.persist_disabled_steps == 0
+        for i in range(3):                               # cool-down: not even attempted (the self-test knob would fail them)
+            eng.forward(batch, w, seed=11)
+            assert not w.persist_now and eng.persist_fallbacks == 2 and eng.persist_disabled_steps == i + 1
+        assert rel_err(_snapshot(w, eng)["pj"], ref["pj"]) < 5e-5
+        eng.persist_selftest = 0
+        eng.forward(batch, w, seed=11)                   # probe: healthy again
+        torch.cuda.synchronize()
+        assert w.persist_now and eng.persist_fallbacks == 2 and eng.persist_disabled_steps == 3
+        assert rel_err(_snapshot(w, eng)["pj"], ref["pj"]) < 5e-5
+    assert sum("consecutive steps fell back" in str(r.message) for r in rec) == 1
+
+
+@pytest.mark.parametrize("park_us", [400, 6000])
+def test_intruder_on_the_compute_units(dev, park_us):
+    """Another tenant holds 16 CUs (mstts_debug_park_cus on a side stream: 96 KB of LDS per workgroup, nothing of the persistent
+    launches fits beside it) while a train step's persistent launches want all 256.  Short stay (0.4 ms, inside the 2 ms rendezvous
+    bound): the launch waits and runs.  Long stay (6 ms): the rendezvous gives up, the step runs the launch-per-step loop.  Either way
+    the step finishes with the result of the undisturbed step; wall times are recorded."""
+    import json, os, time
+    from multi_speaker_tts_amd import lib
+    eng, od = _engine(dev)
+    B, Te, L = 16, 64, 30
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=True), dev)
+    w = eng.plan(B, Te, L)
+    eng.forward(batch, w, seed=11); eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    ref = _snapshot(w, eng)
+    gref = eng.params.grad.clone()
+    t0 = time.perf_counter()
+    eng.forward(batch, w, seed=11); eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    quiet_ms = (time.perf_counter() - t0) * 1e3
+    assert eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0
+    side = torch.cuda.Stream(device=dev)
+    done = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(side):
+        lib.call("mstts_debug_park_cus", 16, park_us, lib.ptr(done))
+    eng.forward(batch, w, seed=11)
+    fwd_fb = eng.persist_fallbacks
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    assert int(done.item()) == 16
+    got = _snapshot(w, eng)
+    for k in ("pj", "align_hist", "linear", "mel_out"):
+        assert rel_err(got[k], ref[k]) < 5e-5, k
+    assert rel_err(t2n(eng.params.grad), t2n(gref)) < 2e-4
+    if park_us >= 2500:
+        assert fwd_fb == 1, "a tenant that outstays the rendezvous bound must end in the launch-per-step loop"
+    else:
+        assert fwd_fb == 0, "a tenant that leaves inside the rendezvous bound must only delay the launch"
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(root):
+        with open(os.path.join(root, "intruder.jsonl"), "a") as f:
+            f.write(json.dumps(dict(park_us=park_us, quiet_step_ms=quiet_ms, disturbed_step_ms=ms, forward_fallbacks=fwd_fb,
+                                    bptt_fallbacks=eng.persist_bwd_fallbacks, enc_fallbacks=eng.persist_enc_fallbacks)) + "\n")
+    print("intruder %d us on 16 CUs: quiet step %.2f ms, disturbed %.2f ms, forward fallbacks %d" % (park_us, quiet_ms, ms, fwd_fb))
 
 
 def test_persistent_train_steps(dev):

@@ -692,6 +692,38 @@ int32_t mstts_decoder_infer_fast(int64_t B, int64_t H, int64_t P, int64_t M, int
 int mstts_decoder_infer_steps(const mstts_decoder_infer_desc* d, int64_t step0, int64_t n, mstts_stream_t s);
 int64_t mstts_decoder_infer_ws_floats(int64_t B, int64_t H, int64_t P, int64_t T, int64_t A, int64_t n_mel);
 
+/* ---- the same free-running loop as ONE persistent launch (csrc/persist_infer.hip): every step of Decoder_Dynamic_Decode.body in
+ * inference mode (Modules.py:397-443; Decoder_Helper.next_inputs :212-237: the step's own frame -> prenet with dropout always on
+ * :239-255 -> next input; stop gating :216-219, finished OR-accumulated :409, loop condition :395; projection :309-321) on 256 co-resident
+ * workgroups, cell kernels in registers, keys / values / prenet operands on chip, at most Smax = Hyper_Parameters.py:53 + 1 steps.
+ * Reads from mstts_decoder_infer_desc: B, H, P, n_mel, Smax, lsa (keys, values, lengths, loc_k, loc_b, score_w, score_b), b0, b1, pw1, pb1 (second prenet
+ * layer), pm0 / pm1 (keep-masks [Smax, B, P]: row s = the prenet that FEEDS step s), prenet_keep, zoneout; writes linear [Smax, B, n_mel],
+ * stop [Smax, B], align_hist [Smax, B, T] for the steps it ran.
+ * Loop invariants the caller prepares once per batch (plain mstts_gemm_f32 products; W1p / b1p = first prenet layer, Wp = [Wp_m ; Wp_c] the
+ * projection kernel padded to 84 columns, bp its padded bias):
+ *   vp  [B T, 84]  = values . Wp_c                 u   [B T, 256] = vp[:, :80] . W1p
+ *   wfm [H, 256]   = Wp_m[:, :80] . W1p            bf  [256]      = bp[:80] . W1p + b1p
+ *   pre0 [B, 256]  = prenet of the all-zero start frame with the masks of step 0 (Modules.py:178-185)
+ *   w0pk / w1pk    = mstts_persist_pack(w0f, w1, wq, wx0) copies of the cell kernels (prenet rows folded in),
+ *   wqppk          = mstts_persist_infer_pack(wq, wp_pad, 84, wfm): mstts_persist_infer_pack_floats() floats.
+ * xch: mstts_persist_infer_ws_bytes() bytes; ctrl: 272 uint32, afterwards [1] = abort code (0 = none: 1 start rendezvous, 2 a bounded wait
+ * expired, 3 self-test), [2] = workgroups that left in order (256), [5] = number of valid steps (n + 1 where n is the step at which the last row
+ * finished; the launch runs one more step than that before every workgroup has seen the word - its rows are to be ignored).  Non-zero [1] or
+ * [2] != 256: run mstts_decoder_infer_steps instead (it rewrites every output). */
+typedef struct {
+    const float* w0pk; const float* w1pk; const float* wqppk;
+    const float* pre0; const float* bf; const float* u; const float* vp; const float* bp_pad;
+    float* xch; uint32_t* ctrl;
+    void* stamps;                    /* NULL, or 256 x 24 uint64: per-workgroup stage ticks (100 MHz) of the profiling instantiation */
+    int32_t selftest_fail_step;      /* k > 0: workgroup 0 raises the abort word at step k - 1 (tests) */
+    int32_t near_xcd;
+} mstts_persist_infer_desc;
+int32_t mstts_persist_infer_supported(int64_t B, int64_t H, int64_t P, int64_t M, int64_t A, int64_t T, int64_t KS, int64_t n_mel);
+int64_t mstts_persist_infer_ws_bytes(void);
+int64_t mstts_persist_infer_pack_floats(void);
+int mstts_persist_infer_pack(const float* wq, const float* wp_pad, int64_t wp_ld, const float* wfm, float* wqppk, mstts_stream_t s);
+int mstts_decoder_infer_persistent(const mstts_decoder_infer_desc* d, const mstts_persist_infer_desc* p, mstts_stream_t s);
+
 /* ---- bf16 gradient exchange (BASELINE config 3, dist.GradAllReduce(comm_dtype="bf16")): the message is bf16, the sum is fp32.
  * f32_to_bf16 rounds to nearest even; bf16_chunks_sum: out[i] = bf16(sum_r float(chunks[r*stride + i])), r = 0..nchunks-1 in order. */
 int mstts_f32_to_bf16(const float* x, void* y_bf16, int64_t n, mstts_stream_t s);

@@ -24,7 +24,7 @@
 // Every wait is bounded (wall clock); a workgroup that gives up raises an abort word that all others poll, the launch ends, and the
 // host re-runs the sequence on the launch-per-step path (mstts_decoder_train_fwd).  The same happens when the 256 workgroups do not
 // become co-resident (start rendezvous).
-#include "persist_common.h"
+#include "persist_fwd_parts.h"
 
 namespace mstts {
 
@@ -34,7 +34,6 @@ constexpr long OFF_CTX = 0, OFF_M0 = OFF_CTX + PRING * XCTX, OFF_H0 = OFF_M0 + P
                OFF_M1 = OFF_H1 + PRING * XACT, OFF_EN = OFF_M1 + PRING * XM1, OFF_P0 = OFF_EN + PRING * XEN, OFF_P1 = OFF_P0 + PRING * XPART,
                XCH_FLOATS = OFF_P1 + PRING * XPART;
 // LDS layout (floats)
-constexpr int LC = 28, LA = 36;                  // padded row strides of the staged activation slices (conflict-free b128 reads)
 // ONE staging buffer serves the four slices a step consumes, in turn: ctx_{s-1} -> m0_s -> h0_s -> h1_s (each is dead before the next arrives)
 // (small arrays first: a DS instruction's immediate offset reaches 64 KB, and every access beyond that needs an address register of its
 //  own, which the compiler hoists out of the step loop - with the two big flat arrays in front the kernel spilled 119 registers)
@@ -59,59 +58,6 @@ struct PersistFwd {
     int fail_step; int near_xcd;                               // self-test: workgroup 0 raises the abort word at this step (-1 = never)
 };
 
-
-// acc[t] += W[k-steps 4 K4A .. 4 K4B) . X[t], X read from the staged LDS slice (row stride LD); the wave's registers w[WOFF + ks]
-template <int K4A, int K4B, int LD, int WOFF, int NW>
-__device__ __forceinline__ void mfma_part(const float (&w)[NW], const float* sx, int lane, pf32x4 (&acc)[2]) {
-    const int row0 = ((lane >> 4) * 2) * 16 + (lane & 15);          // rho of row tile 0; tile 1 is 16 rows further
-#pragma unroll
-    for (int k4 = K4A; k4 < K4B; ++k4) {
-        const pf32x4 x0 = *reinterpret_cast<const pf32x4*>(sx + row0 * LD + 4 * k4);
-        const pf32x4 x1 = *reinterpret_cast<const pf32x4*>(sx + (row0 + 16) * LD + 4 * k4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0] = PMFMA(w[WOFF + 4 * k4 + e], x0[e], acc[0]);
-            acc[1] = PMFMA(w[WOFF + 4 * k4 + e], x1[e], acc[1]);
-        }
-    }
-}
-
-// one slice of a ring slot (128 rows x 4 K4 floats, contiguous) -> the staging buffer (row stride LD), in two parts: slice_issue()
-// requests the thread's two 16-byte pieces, slice_complete() polls them in and writes them to LDS; false on time-out
-template <int K4>
-__device__ __forceinline__ void slice_issue(__amdgpu_buffer_rsrc_t xr, long slice_float_off, int tid, unsigned (&off)[2], pf32x4 (&v)[2]) {
-    constexpr int NPC = 128 * K4;                                    // 16-byte pieces of the slice: 768 or 1024 for 512 threads
-    off[0] = (unsigned)(slice_float_off * 4 + 16 * tid);
-    off[1] = (tid + PTH < NPC) ? off[0] + 16 * PTH : off[0];
-    issue<2>(xr, off, v);
-}
-template <int K4, int LD>
-__device__ __forceinline__ bool slice_complete(__amdgpu_buffer_rsrc_t xr, float* stg, int tid, const unsigned (&off)[2], pf32x4 (&v)[2], const unsigned* ctrl, unsigned gen) {
-    constexpr int NPC = 128 * K4;
-    const unsigned gens[2] = {gen, gen};
-    const bool ok = complete<2>(xr, off, v, ctrl, gens);
-    {
-        const int rho = tid / K4, k4 = tid - rho * K4;
-        *reinterpret_cast<pf32x4*>(stg + rho * LD + 4 * k4) = v[0];
-    }
-    if (tid + PTH < NPC) {
-        const int p = tid + PTH, rho = p / K4, k4 = p - rho * K4;
-        *reinterpret_cast<pf32x4*>(stg + rho * LD + 4 * k4) = v[1];
-    }
-    return ok;
-}
-
-struct CellOut { float si, tj, sf, so, c, m; };
-// ZoneoutLSTMCell.py:228-271 for one (row, unit): gates i, j, f, o (forget bias 1.0 added here), training-mode zoneout with keep masks
-__device__ __forceinline__ CellOut cell_update(const pf32x4& gs, const float (&add)[4], float& cs, float& hs, float kc, float kh) {
-    CellOut o;
-    o.si = sigmoidf_(gs[0] + add[0]); o.tj = tanhf_(gs[1] + add[1]); o.sf = sigmoidf_(gs[2] + add[2] + 1.0f); o.so = sigmoidf_(gs[3] + add[3]);
-    o.c = o.sf * cs + o.si * o.tj;
-    o.m = o.so * tanhf_(o.c);
-    hs = kh * (o.m - hs) + hs;
-    cs = kc * (o.c - cs) + cs;
-    return o;
-}
 
 // FOLD: the prenet rows of the cell-0 kernel ride along with the context rows (8 more k-steps per wave on the matrix cores) instead of
 // arriving as a hoisted [S B, 4096] product: no 420 MB tensor written by a GEMM and read back by row-strided loads in every step.
@@ -546,8 +492,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 }
 
 // ---- packers: the kernels in the order the lanes keep them (see the header comment)
-// k-step ks of a 128-unit recurrent slice: q = lane >> 4 -> producer column slice j' = 4 (ks / 4) + q, unit 32 j' + 4 i + ks % 4
-__device__ __forceinline__ int unit_of_kstep(int gi, int ks, int q) { return 32 * (4 * (ks >> 2) + q) + 4 * gi + (ks & 3); }
+// (unit_of_kstep: persist_fwd_parts.h)
 
 __global__ void persist_pack_cells_kernel(const float* __restrict__ w0f, const float* __restrict__ w1, const float* __restrict__ wx0, float* __restrict__ w0pk, float* __restrict__ w1pk) {
     const long n0 = 256L * 8 * 64 * 64, n1 = 256L * 8 * 64 * 64;

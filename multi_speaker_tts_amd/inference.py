@@ -11,6 +11,8 @@ Prenet dropout stays active (quirk Q9): its keep-masks are Philox streams, or in
 from __future__ import annotations
 
 import ctypes as C
+import os
+import warnings
 
 import numpy as np
 import torch
@@ -32,6 +34,18 @@ class InferEngine:
         self.params = params if params is not None else ParamStore(self.d, self.device, seed=seed, values=values)
         self.chunk = chunk
         self._keep = []          # keeps temporaries alive until the stream is synchronised
+        # persistent launches (csrc/persist_infer.hip, persist_lstm.hip): MSTTS_PERSIST_INFER=0 keeps the launch-per-step drivers
+        self.persist_infer = os.environ.get("MSTTS_PERSIST_INFER", "1") != "0"
+        self.persist_infer_launches = 0      # decoder loops that ran as one launch
+        self.persist_infer_fallbacks = 0     # ... that gave up (bounded waits / no co-residency) and were re-run launch by launch
+        self.persist_infer_selftest = 0      # tests: k > 0 makes the launch abort at step k - 1
+        self.persist_infer_stamps = None     # bench: 256 x 24 int64 tensor -> per-stage ticks of the next launch
+        self.persist_infer_status = None
+        self._persist_strikes = 0
+        self._persist_off = 0                # decodes left of the cool-down after PERSIST_STRIKES consecutive fallbacks
+        self.persist_disabled_decodes = 0
+        self.non_persistent_decodes = 0      # decodes at the reference widths whose shape the persistent loop does not cover
+        self._warned_shapes = set()
 
     # ------------------------------------------------------------------ helpers
     def _f(self, *shape):
@@ -219,6 +233,9 @@ class InferEngine:
         q.pre_ws = ptr(self._f(int(lib.load().mstts_decoder_infer_ws_floats(B, H, Pn, T, A, NM))))
         linear, stop, align = self._f(Smax, B, NM), self._f(Smax, B), self._f(Smax, B, T)
         q.linear, q.stop, q.align_hist = ptr(linear), ptr(stop), ptr(align)
+        S = self._decode_persistent(q, values, w0f, mk, B, T, Smax)
+        if S is not None:
+            return linear[:S], stop[:S], align[:S], S
         # Decoder_Dynamic_Decode stops after the first step at which every row has raised its stop flag
         # (stop_logit >= 0 OR time >= Max_Inference_Length, OR-accumulated; Modules.py:216-219,395,409).
         finished = np.zeros(B, bool)
@@ -236,6 +253,79 @@ class InferEngine:
                     break
             done += n
         return linear[:S], stop[:S], align[:S], S
+
+    def _decode_persistent(self, q, values, w0f, mk, B, T, Smax):
+        """The whole free-running loop as ONE launch (mstts_decoder_infer_persistent).  Returns the number of steps, or None when the
+        shape / device is not covered, the persistent plans are cooling down, or the launch gave up - the caller then runs the
+        launch-per-step loop, which rewrites every output."""
+        d, L_ = self.d, lib.load()
+        H, A, Pn, NM, M = d.dec_lstm, d.att, d.prenet, d.n_mel, d.mem
+        if not self.persist_infer:
+            return None
+        if not L_.mstts_persist_infer_supported(B, H, Pn, M, A, T, d.att_k, NM):
+            if L_.mstts_persist_infer_supported(1, H, Pn, M, A, 1, d.att_k, NM):      # widths and device fit, this batch shape does not
+                self.non_persistent_decodes += 1
+                if (B, T) not in self._warned_shapes:
+                    self._warned_shapes.add((B, T))
+                    warnings.warn("multi_speaker_tts_amd: batch %d x %d tokens is outside the persistent free-running decoder's range "
+                                  "(mstts_persist_infer_supported); decoding launch by launch" % (B, T), RuntimeWarning, stacklevel=4)
+            return None
+        if self._persist_off > 0:
+            self._persist_off -= 1
+            self.persist_disabled_decodes += 1
+            return None
+        NP = 84
+        k0, o0 = self.P(CELL % 0 + "kernel"); k1, o1 = self.P(CELL % 1 + "kernel"); wq, oq = self.P(LSA + "query_layer/kernel")
+        wpj, owpj = self.P("decoder/decoder/linear_projection/dense/kernel"); bpj, obpj = self.P("decoder/decoder/linear_projection/dense/bias")
+        pw0, opw0 = self.P("decoder/decoder/prenet_0/dense/kernel"); pb0, opb0 = self.P("decoder/decoder/prenet_0/dense/bias")
+        pw1, opw1 = self.P("decoder/decoder/prenet_1/dense/kernel"); pb1, opb1 = self.P("decoder/decoder/prenet_1/dense/bias")
+        # loop invariants (see include/mstts.h): padded projection, projected values, the first prenet layer folded onto both
+        wp_pad, bp_pad = self._f(H + M, NP), self._f(NP)
+        call("mstts_copy2d", ptr(wpj, owpj), NM + 1, ptr(wp_pad), NP, H + M, NM + 1, 0)
+        call("mstts_copy2d", ptr(bpj, obpj), NM + 1, ptr(bp_pad), NP, 1, NM + 1, 0)
+        vp, u, wfm, bf = self._f(B * T, NP), self._f(B * T, Pn), self._f(H, Pn), self._f(4, Pn)
+        gemm(values, wp_pad, vp, B * T, NP, M, M, NP, NP, b_off=H * NP)
+        gemm(vp, pw0, u, B * T, Pn, NM, NP, Pn, Pn, b_off=opw0)
+        gemm(wp_pad, pw0, wfm, H, Pn, NM, NP, Pn, Pn, b_off=opw0)
+        bp4 = self._f(4, NP)                          # (a 4-row product: row 0 is bp, the other rows are zero)
+        bp4[0].copy_(bp_pad)
+        gemm(bp4, pw0, bf, 4, Pn, NM, NP, Pn, Pn, bias=pb0, b_off=opw0, bias_off=opb0)
+        # prenet of the all-zero start frame with the masks of step 0 (Modules.py:178-185)
+        zf, pa, pb = self._f(B, NM), self._f(B, Pn), self._f(B, Pn)
+        gemm(zf, pw0, pa, B, Pn, NM, NM, Pn, Pn, bias=pb0, act=ACT_RELU, b_off=opw0, bias_off=opb0)
+        call("mstts_dropout", ptr(pa), ptr(mk["prenet_drop_0"]), 1 - d.prenet_drop, ptr(pb), B * Pn)
+        gemm(pb, pw1, pa, B, Pn, Pn, Pn, Pn, Pn, bias=pb1, act=ACT_RELU, b_off=opw1, bias_off=opb1)
+        pre0 = self._f(B, Pn)
+        call("mstts_dropout", ptr(pa), ptr(mk["prenet_drop_1"]), 1 - d.prenet_drop, ptr(pre0), B * Pn)
+        # kernels in the lanes' order
+        pk = [self._f(int(L_.mstts_persist_pack_floats(i))) for i in range(3)]
+        call("mstts_persist_pack", ptr(w0f), ptr(k1, o1), ptr(wq, oq), ptr(k0, o0), ptr(pk[0]), ptr(pk[1]), ptr(pk[2]))
+        wqppk = self._f(int(L_.mstts_persist_infer_pack_floats()))
+        call("mstts_persist_infer_pack", ptr(wq, oq), ptr(wp_pad), NP, ptr(wfm), ptr(wqppk))
+        xch = self._f(int(L_.mstts_persist_infer_ws_bytes()) // 4)
+        ctrl = torch.zeros(272, dtype=torch.int32, device=self.device)
+        self._keep.append(ctrl)
+        pd = lib.PersistInferDesc()
+        pd.w0pk, pd.w1pk, pd.wqppk = ptr(pk[0]), ptr(pk[1]), ptr(wqppk)
+        pd.pre0, pd.bf, pd.u, pd.vp, pd.bp_pad = ptr(pre0), ptr(bf), ptr(u), ptr(vp), ptr(bp_pad)
+        pd.xch, pd.ctrl = ptr(xch), ptr(ctrl)
+        pd.stamps = ptr(self.persist_infer_stamps) if self.persist_infer_stamps is not None else None
+        pd.selftest_fail_step = int(self.persist_infer_selftest)
+        pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
+        call("mstts_decoder_infer_persistent", C.byref(q), C.byref(pd))
+        st = ctrl.cpu().numpy()                       # synchronises the stream
+        self.persist_infer_status = (int(st[0]), int(st[1]), int(st[2]), int(st[4]), int(st[5]))
+        if int(st[1]) != 0 or int(st[2]) != 256:
+            self.persist_infer_fallbacks += 1
+            self._persist_strikes += 1
+            if self._persist_strikes >= 2:
+                self._persist_strikes, self._persist_off = 0, 200
+                warnings.warn("multi_speaker_tts_amd: two consecutive persistent decoder launches gave up (status %r); decoding launch by "
+                              "launch for the next 200 batches" % (self.persist_infer_status,), RuntimeWarning, stacklevel=4)
+            return None
+        self._persist_strikes = 0
+        self.persist_infer_launches += 1
+        return int(st[5]) if int(st[5]) > 0 else Smax
 
     def postnet(self, linear_bsc, B, S):
         d = self.d

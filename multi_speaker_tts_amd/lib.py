@@ -96,6 +96,11 @@ class PersistDesc(C.Structure):
     _fields_ = [("w0pk", vp), ("w1pk", vp), ("wqpk", vp), ("xch", vp), ("ctrl", vp), ("stamps", vp), ("opk", vp), ("selftest_fail_step", i32), ("near_xcd", i32), ("pre", vp), ("b0", vp)]
 
 
+class PersistInferDesc(C.Structure):
+    _fields_ = [("w0pk", vp), ("w1pk", vp), ("wqppk", vp), ("pre0", vp), ("bf", vp), ("u", vp), ("vp", vp), ("bp_pad", vp),
+                ("xch", vp), ("ctrl", vp), ("stamps", vp), ("selftest_fail_step", i32), ("near_xcd", i32)]
+
+
 class DecoderTrainBwd(C.Structure):
     _fields_ = [("fwd", C.POINTER(DecoderTrain)), ("d_pj", vp), ("dg0", vp), ("dg1", vp), ("dq_hist", vp),
                 ("de_hist", vp), ("d_in0", vp), ("ws", vp)]
@@ -244,6 +249,11 @@ SIGNATURES = {
     "mstts_skinny_bwd_packed": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mstts_decoder_infer_fast": (i32, [i64, i64, i64, i64, i64, i64]),
     "mstts_decoder_infer_steps": (i32, [P(DecoderInfer), i64, i64, vp]),
+    "mstts_persist_infer_supported": (i32, [i64, i64, i64, i64, i64, i64, i64, i64]),
+    "mstts_persist_infer_ws_bytes": (i64, []),
+    "mstts_persist_infer_pack_floats": (i64, []),
+    "mstts_persist_infer_pack": (i32, [vp, vp, i64, vp, vp, vp]),
+    "mstts_decoder_infer_persistent": (i32, [P(DecoderInfer), P(PersistInferDesc), vp]),
     "mstts_decoder_infer_ws_floats": (i64, [i64, i64, i64, i64, i64, i64]),
     "mstts_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "mstts_bf16_to_f32": (i32, [vp, vp, i64, vp]),

@@ -124,8 +124,11 @@ def test_depth_parity_free_running(dev):
     eng = InferEngine(pd, device=dev, values=values)
     got = eng.forward({"Token": batch["Token"].numpy(), "Token_Length": batch["Token_Length"].numpy(), "Speaker_Embedding": spk.astype(np.float32)},
                       masks={k: v.numpy() for k, v in masks.items()}, with_vocoder=False)
+    from multi_speaker_tts_amd import lib as _lib
+    if _lib.load().mstts_persist_infer_supported(B, pd.dec_lstm, pd.prenet, pd.mem, pd.att, Te, pd.att_k, pd.n_mel):
+        assert eng.persist_infer_launches == 1 and eng.persist_infer_fallbacks == 0, eng.persist_infer_status      # the whole loop was ONE launch
     errs = {k: rel_err(got[k], t2n(ref[k])) for k in ("Linear", "Mel", "Stop", "Attention_History")}
-    _record("free_running", dict(steps=S, first_stop_step=first.tolist(), threshold_margin=margin, errors=errs))
+    _record("free_running", dict(persistent_launches=eng.persist_infer_launches, steps=S, first_stop_step=first.tolist(), threshold_margin=margin, errors=errs))
     print("free running: %d steps, rows stop at %s (margin %.3g), errors %s" % (S, first.tolist(), margin, errs))
     assert got["Linear"].shape == (B, S, od.n_mel), (got["Linear"].shape, S)
     for k, e in errs.items():

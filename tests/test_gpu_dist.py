@@ -67,7 +67,7 @@ def test_train_step_through_rccl_one_rank(dev):
         assert np.isfinite(dp.scalars(wc)["Loss"]) and bool(torch.isfinite(dp.params.train).all())
         before = dp.params.frozen.clone()
         dp.sync_statistics()                                              # BN moving statistics averaged over (one) rank
-        assert len(dp.moving_stat_ranges()) >= 2 and torch.allclose(before, dp.params.frozen)
+        assert len(dp.moving_stat_ranges()) >= 1 and torch.allclose(before, dp.params.frozen)
     finally:
         dist.destroy_process_group()
 

@@ -534,6 +534,11 @@ int mstts_lstm_seq_bwd_pair_persistent(const mstts_lstm_seq_bwd_desc* a, const m
  * mstts_persist_lstm_ws_bytes_n / _hist_floats_n / _bwd_floats_n; ctrl: 16 uint32, ctrl[2] == 32 x groups (forward) / 16 x groups (BPTT)
  * after a complete run.  The pair entry points above accept any B that mstts_persist_lstm_supported_n(B, H, 2) admits. */
 int32_t mstts_persist_lstm_supported_n(int64_t B, int64_t H, int32_t ndir);
+/* The FORWARD launches (mstts_lstm_seq_fwd_persistent / _pair_persistent) also cover H == 128 - the Taco1 vocoder's BiRNN at inference
+ * (Taco1_Mel_to_Spect/Modules.py:75-99): H / 8 workgroups per row group; pack that kernel with mstts_persist_lstm_pack_fwd (H = 256 or 128,
+ * H * 4H floats).  Buffers sized by the same *_n functions (they are sized for H = 256).  After a complete run ctrl[2] == (H / 8) x row groups. */
+int32_t mstts_persist_lstm_fwd_supported_n(int64_t B, int64_t H, int32_t ndir);
+int mstts_persist_lstm_pack_fwd(const float* wh, int64_t wh_ld, int64_t H, float* fwd_pk, mstts_stream_t s);
 int64_t mstts_persist_lstm_ws_bytes_n(int64_t B, int32_t ndir);
 int64_t mstts_persist_lstm_hist_floats_n(int64_t T, int64_t B, int32_t ndir);
 int64_t mstts_persist_lstm_bwd_floats_n(int64_t T, int64_t B, int32_t ndir);

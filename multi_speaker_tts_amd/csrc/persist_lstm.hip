@@ -28,6 +28,16 @@ constexpr long EB_SLOT = 2L * 64 * 64 * 4;        // backward ring slot: gate gr
 // ROW GROUPS: rows are independent recurrences, so a sequence of more than 32 rows (the speaker-encoder trainer: 320) is cut into groups of 32
 // rows, each with its own 32 (forward) / 16 (BPTT) workgroups and its own ring; group index = direction * groups_per_direction + row block.
 constexpr long EP_GROUP = 32L * 4 * 64;           // owner lanes per step and row group: 8 192, forward and backward alike
+// The FORWARD loop also exists for H = 128 (the Taco1 vocoder's BiRNN, Taco1_Mel_to_Spect/Modules.py:75-99; inference only - the BPTT kernel
+// stays at 256): same scheme, 8 hidden units per workgroup, so H / 8 workgroups per row group, H / 16 k-steps per wave quarter.
+template <int HH> struct LF {
+    static constexpr int WG = HH / 8;                    // workgroups per row group
+    static constexpr int KS = HH / 16;                   // k-steps of one wave's quarter of the contraction
+    static constexpr int NJ = HH / 16;                   // 16-unit pieces per row tile of a ring slot
+    static constexpr long SLOT = 2L * NJ * 64 * 4;       // ring slot in floats
+    static constexpr long PGROUP = (long)WG * 4 * 64;    // owner lanes per step and row group
+};
+static_assert(LF<256>::WG == EFWG && LF<256>::SLOT == EF_SLOT && LF<256>::PGROUP == EP_GROUP, "H = 256 geometry");
 // float4 index into epk: [t][forward workgroup G][owner wave 4][half 2][lane 64]
 __host__ __device__ __forceinline__ long epk_index(int t, int G, int g, int ow, int half, int lane) { return ((((long)t * G + g) * 4 + ow) * 2 + half) * 64 + lane; }
 
@@ -62,26 +72,29 @@ __device__ __forceinline__ bool lstm_rendezvous(unsigned* ctrl, unsigned n) {
 }
 #define LFAIL(ctrl) do { sflag[0] = 1; unsigned z__ = 0u; __hip_atomic_compare_exchange_strong((ctrl) + 1, &z__, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 
+template <int HH>
 __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
+    typedef LF<HH> L;
+    constexpr int KS = L::KS, NPC = L::KS / 4;
     __shared__ __attribute__((aligned(16))) float red[2 * 4 * 2 * 2 * 64 * 4];      // [buffer][quarter][row tile][unit tile][lane][4]
     __shared__ unsigned sflag[2];
-    const int g = blockIdx.x, grp = g / EFWG, gl = g % EFWG, dir = grp / p.gpd, row0 = 32 * (grp % p.gpd);
-    const int G = p.ndir * p.gpd * EFWG;
-    const long ep = (long)p.ndir * p.gpd * EP_GROUP;
+    const int g = blockIdx.x, grp = g / L::WG, gl = g % L::WG, dir = grp / p.gpd, row0 = 32 * (grp % p.gpd);
+    const int G = p.ndir * p.gpd * L::WG;
+    const long ep = (long)p.ndir * p.gpd * L::PGROUP;
     const EncFwdDir& d = p.d[dir];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = wave & 1, kq4 = wave >> 1, n = lane & 15, q = lane >> 4;
     const int B = p.B, T = p.T;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xch + (long)grp * PRING * EF_SLOT, 0, (int)(PRING * EF_SLOT * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xch + (long)grp * PRING * L::SLOT, 0, (int)(PRING * L::SLOT * 4), 0x00020000);
     if (tid == 0) { sflag[0] = lstm_rendezvous(p.ctrl, (unsigned)G) ? 0u : 1u; }
     __syncthreads();
     if (sflag[0]) return;
-    // this wave's slice of the recurrent kernel: 2 unit tiles x 16 k-steps (its quarter of the 256 hidden units)
-    float wa[2][16];
+    // this wave's slice of the recurrent kernel: 2 unit tiles x KS k-steps (its quarter of the H hidden units)
+    float wa[2][KS];
 #pragma unroll
     for (int ut = 0; ut < 2; ++ut)
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) wa[ut][ks] = d.wpk[((((long)gl * 4 + kq4) * 2 + ut) * 16 + ks) * 64 + lane];
+        for (int ks = 0; ks < KS; ++ks) wa[ut][ks] = d.wpk[((((long)gl * 4 + kq4) * 2 + ut) * KS + ks) * 64 + lane];
     // cell-update role (waves 0..3): row tile o_rt, unit tile o_ut; lane = (unit within the tile q, row n)
     const bool owner = wave < 4;
     const int o_rt = wave & 1, o_ut = (wave >> 1) & 1;
@@ -117,16 +130,15 @@ __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
         const unsigned zcv = zca & 1u, zhv = zca & 2u;
         pf32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (t > 0) {
-            unsigned off[4];
-            pf32x4 hv[4];
+            unsigned off[NPC], gens[NPC];
+            pf32x4 hv[NPC];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) off[jj] = (unsigned)((pslot * EF_SLOT + ((rt * 16 + 4 * kq4 + jj) * 64 + lane) * 4) * 4);
-            const unsigned gens[4] = {pgen, pgen, pgen, pgen};
-            if (!gather<4>(xr, off, hv, p.ctrl, gens)) LFAIL(p.ctrl);
+            for (int jj = 0; jj < NPC; ++jj) { off[jj] = (unsigned)((pslot * L::SLOT + ((rt * L::NJ + NPC * kq4 + jj) * 64 + lane) * 4) * 4); gens[jj] = pgen; }
+            if (!gather<NPC>(xr, off, hv, p.ctrl, gens)) LFAIL(p.ctrl);
             LSTAMP(1);
             LSTM_FWD_OPERANDS(t + 1, xb, zcb)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < NPC; ++jj)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[0] = PMFMA(wa[0][4 * jj + e], hv[jj][e], acc[0]);
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) pv[e] = __shfl(hn, 16 * e + n, 64);
             if (q == 0)
-                xpublish(xr, (unsigned)((slot * EF_SLOT + ((o_rt * 16 + (gl >> 1)) * 64 + ((2 * (gl & 1) + o_ut) * 16 + n)) * 4) * 4), pv, gen);
+                xpublish(xr, (unsigned)((slot * L::SLOT + ((o_rt * L::NJ + (gl >> 1)) * 64 + ((2 * (gl & 1) + o_ut) * 16 + n)) * 4) * 4), pv, gen);
             LSTAMP(4);
             // history of this (row, unit) for the BPTT and for the row-major tensors (persist_lstm_unpack_fwd_kernel): two contiguous KB per wave
             pf32x4* eo = p.epk + epk_index(t, G, g, wave, 0, lane);
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(ETH) void persist_lstm_fwd_kernel(EncFwd p) {
         }
     }
 #ifdef LSTM_PROF
-    if (tid == 0 && g == 0) for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long*>(p.xch + 2 * PRING * EF_SLOT)[i] = st_[i];
+    if (tid == 0 && g == 0) for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long*>(p.xch + 2 * PRING * L::SLOT)[i] = st_[i];
 #endif
     if (tid == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -289,15 +301,17 @@ __global__ __launch_bounds__(ETH) void persist_lstm_bwd_kernel(EncBwd p) {
 
 // ---- the streaming kernels around the two loops (one thread per owner lane and step)
 // (ngr = row groups in all, gpd = per direction; a group is 32 forward / 16 BPTT workgroups)
+template <int HH>
 __device__ __forceinline__ void fwd_owner_of(long idx, int ngr, int gpd, int& t, int& g, int& ow, int& lane, int& dir, int& b, int& u) {
-    const int G = ngr * EFWG;
+    constexpr int WG = LF<HH>::WG;
+    const int G = ngr * WG;
     lane = (int)(idx & 63); ow = (int)((idx >> 6) & 3);
     const long wg = idx >> 8;
     g = (int)(wg % G); t = (int)(wg / G);
-    const int grp = g / EFWG;
+    const int grp = g / WG;
     dir = grp / gpd;
     b = 32 * (grp % gpd) + 16 * (ow & 1) + (lane & 15);
-    u = 8 * (g % EFWG) + 4 * (ow >> 1) + (lane >> 4);
+    u = 8 * (g % WG) + 4 * (ow >> 1) + (lane >> 4);
 }
 __device__ __forceinline__ void bwd_owner_of(long idx, int ngr, int gpd, int& k, int& dir, int& b, int& u) {
     const int G2 = ngr * EBWG;
@@ -310,12 +324,14 @@ __device__ __forceinline__ void bwd_owner_of(long idx, int ngr, int gpd, int& k,
     u = 16 * (g % EBWG) + 4 * (lane >> 4) + (wave >> 1);
 }
 // hoisted gate inputs xw [B, T, 4H] (at the row's position of step t) and the keep-mask bytes -> ipx / ipm
+template <int HH>
 __global__ void persist_lstm_pack_in_kernel(EncFwd p, pf32x4* __restrict__ ipx, unsigned* __restrict__ ipm) {
+    constexpr int EH = HH;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int ngr = p.ndir * p.gpd;
-    if (idx >= (long)p.T * ngr * EP_GROUP) return;
+    if (idx >= (long)p.T * ngr * LF<HH>::PGROUP) return;
     int t, g, ow, lane, dir, b, u;
-    fwd_owner_of(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
+    fwd_owner_of<HH>(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
     const EncFwdDir& d = p.d[dir];
     pf32x4 x = {0.f, 0.f, 0.f, 0.f};
     unsigned m = 3u;
@@ -331,12 +347,14 @@ __global__ void persist_lstm_pack_in_kernel(EncFwd p, pf32x4* __restrict__ ipx, 
     ipm[idx] = m;
 }
 // epk -> the row-major tensors of mstts_lstm_seq_fwd_desc: out (at the row's position), h_hist / c_hist [T + 1, B, H], acts, c_raw
+template <int HH>
 __global__ void persist_lstm_unpack_fwd_kernel(EncFwd p) {
+    constexpr int EH = HH;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ngr = p.ndir * p.gpd, G = ngr * EFWG;
-    if (idx >= (long)p.T * ngr * EP_GROUP) return;
+    const int ngr = p.ndir * p.gpd, G = ngr * LF<HH>::WG;
+    if (idx >= (long)p.T * ngr * LF<HH>::PGROUP) return;
     int t, g, ow, lane, dir, b, u;
-    fwd_owner_of(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
+    fwd_owner_of<HH>(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
     if (b >= p.B) return;
     const EncFwdDir& d = p.d[dir];
     const pf32x4 a = p.epk[epk_index(t, G, g, ow, 0, lane)], s = p.epk[epk_index(t, G, g, ow, 1, lane)];
@@ -389,12 +407,14 @@ __global__ void persist_lstm_unpack_bwd_kernel(EncBwd p) {
 // recurrent kernel Wh [256, 1024] (row stride ld, gate-major columns i | j | f | o) -> the forward kernel's register order
 // [workgroup 32][quarter 4][unit tile 2][k-step 16][lane 64]: A operand of k-step ks = 4 jj + e, lane (kq, m): row k = 64 quarter + 16 jj +
 // 4 kq + e, column = gate (m & 3) of unit 8 gl + 4 ut + (m >> 2)
+template <int HH>
 __global__ void persist_lstm_pack_fwd_kernel(const float* __restrict__ wh, long ld, float* __restrict__ pk) {
+    constexpr int EH = HH, KS = LF<HH>::KS;
     const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (pidx >= EH * 4 * EH) return;
-    const int lane = pidx & 63, ks = (pidx >> 6) & 15, ut = (pidx >> 10) & 1, kq4 = (pidx >> 11) & 3, gl = pidx >> 13;
+    const int lane = pidx & 63, ks = (pidx >> 6) % KS, ut = (pidx / (64 * KS)) & 1, kq4 = (pidx / (128 * KS)) & 3, gl = pidx / (512 * KS);
     const int m = lane & 15, kq = lane >> 4, jj = ks >> 2, e = ks & 3;
-    const int k = 64 * kq4 + 16 * jj + 4 * kq + e, col = (m & 3) * EH + 8 * gl + 4 * ut + (m >> 2);
+    const int k = (EH / 4) * kq4 + 16 * jj + 4 * kq + e, col = (m & 3) * EH + 8 * gl + 4 * ut + (m >> 2);
     pk[pidx] = wh[(long)k * ld + col];
 }
 // ... -> the BPTT kernel's order [workgroup 16][quarter 4][k-step 64][lane 64]: lane (kq, m) of k-step ks = 4 jj + e holds Wh[unit 16 gl + m]
@@ -423,6 +443,18 @@ extern "C" int32_t mstts_persist_lstm_supported_n(int64_t B, int64_t H, int32_t 
     });
 }
 extern "C" int32_t mstts_persist_lstm_supported(int64_t B, int64_t H) { return B <= 32 ? mstts_persist_lstm_supported_n(B, H, 2) : 0; }
+/* the FORWARD launches alone also take H == 128 (inference: the Taco1 vocoder's BiRNN) */
+extern "C" int32_t mstts_persist_lstm_fwd_supported_n(int64_t B, int64_t H, int32_t ndir) {
+    if (H == EH) return mstts_persist_lstm_supported_n(B, H, ndir);
+    return H == 128 ? mstts_persist_lstm_supported_n(B, EH, ndir) : 0;
+}
+extern "C" int mstts_persist_lstm_pack_fwd(const float* wh, int64_t wh_ld, int64_t H, float* fwd_pk, mstts_stream_t s) {
+    MSTTS_REQUIRE(wh && fwd_pk && (H == 256 || H == 128) && wh_ld >= 4 * H, MSTTS_ERR_SHAPE, "persist_lstm_pack_fwd: null pointer, H not 256 / 128, or row stride below 4 H");
+    if (H == 256) hipLaunchKernelGGL(persist_lstm_pack_fwd_kernel<256>, dim3(256 * 4 * 256 / 256), dim3(256), 0, (hipStream_t)s, wh, (long)wh_ld, fwd_pk);
+    else hipLaunchKernelGGL(persist_lstm_pack_fwd_kernel<128>, dim3(128 * 4 * 128 / 256), dim3(256), 0, (hipStream_t)s, wh, (long)wh_ld, fwd_pk);
+    MSTTS_CHECK_LAUNCH("persist_lstm_pack_fwd");
+    return MSTTS_OK;
+}
 extern "C" int64_t mstts_persist_lstm_pack_floats(void) { return (int64_t)EH * 4 * EH; }
 /* ring bytes, packed forward inputs + history floats (float4 ipx | uint32 ipm | 2 float4 epk per owner lane and step) and packed BPTT input /
  * output floats (float dop | float4 dpk) for ndir sequences of B rows and T steps */
@@ -436,19 +468,21 @@ extern "C" int64_t mstts_persist_lstm_bwd_floats(int64_t T) { return mstts_persi
 
 extern "C" int mstts_persist_lstm_pack(const float* wh, int64_t wh_ld, float* fwd_pk, float* bwd_pk, mstts_stream_t s) {
     MSTTS_REQUIRE(wh && fwd_pk && bwd_pk && wh_ld >= 4 * EH, MSTTS_ERR_SHAPE, "persist_lstm_pack: null pointer or row stride below 4 H");
-    hipLaunchKernelGGL(persist_lstm_pack_fwd_kernel, dim3(EH * 4 * EH / 256), dim3(256), 0, (hipStream_t)s, wh, (long)wh_ld, fwd_pk);
+    hipLaunchKernelGGL(persist_lstm_pack_fwd_kernel<EH>, dim3(EH * 4 * EH / 256), dim3(256), 0, (hipStream_t)s, wh, (long)wh_ld, fwd_pk);
     MSTTS_CHECK_LAUNCH("persist_lstm_pack_fwd");
     hipLaunchKernelGGL(persist_lstm_pack_bwd_kernel, dim3(EH * 4 * EH / 256), dim3(256), 0, (hipStream_t)s, wh, (long)wh_ld, bwd_pk);
     MSTTS_CHECK_LAUNCH("persist_lstm_pack_bwd");
     return MSTTS_OK;
 }
 
-static int lstm_fwd_launch(const mstts_lstm_seq_fwd_desc* const* dd, const float* const* pk, int ndir, float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s) {
+template <int HH>
+static int lstm_fwd_launch_h(const mstts_lstm_seq_fwd_desc* const* dd, const float* const* pk, int ndir, float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s) {
+    typedef LF<HH> L;
     const mstts_lstm_seq_fwd_desc* a = dd[0];
     MSTTS_REQUIRE(xch && ctrl && hist, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null pointer");
     MSTTS_REQUIRE(aligned16(hist) && aligned16(xch), MSTTS_ERR_ALIGN, "lstm_seq_fwd_persistent: hist / xch must be 16-byte aligned");
-    MSTTS_REQUIRE(mstts_persist_lstm_supported_n(a->B, a->H, ndir) && a->T >= 1, MSTTS_ERR_SHAPE,
-                  "lstm_seq_fwd_persistent: shape or device not supported (see mstts_persist_lstm_supported_n)");
+    MSTTS_REQUIRE(a->H == HH && mstts_persist_lstm_fwd_supported_n(a->B, a->H, ndir) && a->T >= 1, MSTTS_ERR_SHAPE,
+                  "lstm_seq_fwd_persistent: shape or device not supported (see mstts_persist_lstm_fwd_supported_n)");
     EncFwd p;
     memset(&p, 0, sizeof(p));
     hipStream_t hs = (hipStream_t)s;
@@ -467,20 +501,24 @@ static int lstm_fwd_launch(const mstts_lstm_seq_fwd_desc* const* dd, const float
     }
     p.ndir = ndir; p.gpd = lstm_groups(a->B); p.B = (int)a->B; p.T = (int)a->T; p.keep = 1.f - a->zoneout; p.xch = xch; p.ctrl = ctrl;
     const int ngr = ndir * p.gpd;
-    if (hipMemsetAsync(xch, 0xFF, (size_t)ngr * PRING * EF_SLOT * 4, hs) != hipSuccess || hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), hs) != hipSuccess)
+    if (hipMemsetAsync(xch, 0xFF, (size_t)ngr * PRING * L::SLOT * 4, hs) != hipSuccess || hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), hs) != hipSuccess)
         return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_fwd_persistent: memset failed");
-    const long nl = (long)p.T * ngr * EP_GROUP;
+    const long nl = (long)p.T * ngr * L::PGROUP;
     pf32x4* ipx = reinterpret_cast<pf32x4*>(hist);
     unsigned* ipm = reinterpret_cast<unsigned*>(hist + nl * 4);
     p.ipx = ipx; p.ipm = ipm; p.epk = reinterpret_cast<pf32x4*>(hist + nl * 5);
-    static_assert(EP_GROUP % 4 == 0, "epk stays 16-byte aligned behind ipx | ipm");
-    hipLaunchKernelGGL(persist_lstm_pack_in_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p, ipx, ipm);
+    static_assert(L::PGROUP % 4 == 0, "epk stays 16-byte aligned behind ipx | ipm");
+    hipLaunchKernelGGL(persist_lstm_pack_in_kernel<HH>, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p, ipx, ipm);
     MSTTS_CHECK_LAUNCH("persist_lstm_pack_in");
-    hipLaunchKernelGGL(persist_lstm_fwd_kernel, dim3(ngr * EFWG), dim3(ETH), 0, hs, p);
+    hipLaunchKernelGGL(persist_lstm_fwd_kernel<HH>, dim3(ngr * L::WG), dim3(ETH), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_fwd");
-    hipLaunchKernelGGL(persist_lstm_unpack_fwd_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p);
+    hipLaunchKernelGGL(persist_lstm_unpack_fwd_kernel<HH>, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_unpack_fwd");
     return MSTTS_OK;
+}
+static int lstm_fwd_launch(const mstts_lstm_seq_fwd_desc* const* dd, const float* const* pk, int ndir, float* xch, uint32_t* ctrl, float* hist, mstts_stream_t s) {
+    MSTTS_REQUIRE(dd[0], MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null descriptor");
+    return dd[0]->H == 128 ? lstm_fwd_launch_h<128>(dd, pk, ndir, xch, ctrl, hist, s) : lstm_fwd_launch_h<256>(dd, pk, ndir, xch, ctrl, hist, s);
 }
 
 static int lstm_bwd_launch(const mstts_lstm_seq_bwd_desc* const* dd, const float* const* pk, int ndir, float* xch, uint32_t* ctrl, const float* hist, float* bws,

@@ -884,6 +884,7 @@ class TrainEngine:
         call("mstts_adam_tf", ptr(ps.train), ptr(ps.grad), ptr(ps.adam_m), ptr(ps.adam_v), ptr(ps.wd_mask), float(self.wr_rate),
              float(grad_scale), float(lr_t), b1, b2, eps, ps.n_train)
         self.global_step += 1
+        ps.version += 1
         self._derived_stale = True
         self.refresh_derived()
         return lr

@@ -25,6 +25,10 @@ from .params import CELL, ENC_CELL, LSA, SPK, SPK_CELL, VOC, VOC_CELL, Dims, Par
 BN_EPS = 1e-3
 
 
+class _PersistRetry(RuntimeError):
+    pass
+
+
 class InferEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, params: ParamStore = None, values=None, chunk=50):
         lib.load()
@@ -46,6 +50,19 @@ class InferEngine:
         self.persist_disabled_decodes = 0
         self.non_persistent_decodes = 0      # decodes at the reference widths whose shape the persistent loop does not cover
         self._warned_shapes = set()
+        # recurrent layers around the decoder (encoder BiLSTM, speaker-encoder stack: H = 256; Taco1 BiRNN: H = 128) as ONE persistent launch per
+        # layer (csrc/persist_lstm.hip) instead of a launch per step; their control words are read at the forward pass's existing sync points
+        self.persist_lstm = os.environ.get("MSTTS_PERSIST_LSTM", "1") != "0"
+        self.persist_lstm_launches = 0
+        self.persist_lstm_fallbacks = 0      # forward passes re-run without them because a launch gave up
+        self._lstm_retry = False
+        self._lstm_pending = []              # (slot, workgroups expected to have left in order)
+        self._lstm_ctrl = None
+        self._lstm_ctrl_host = None
+        self._lstm_copied = 0
+        self._lcache = {}                    # packed recurrent kernels by cell, keyed on ParamStore.version
+        self._dcache = {}                    # ... and those both decoder drivers share
+        self._pcache = {}                    # variable-derived operands of the persistent decoder, keyed on ParamStore.version
 
     # ------------------------------------------------------------------ helpers
     def _f(self, *shape):
@@ -77,7 +94,7 @@ class InferEngine:
         call("mstts_bn_infer_fwd", ptr(a), ptr(g, og), ptr(be, obe), ptr(mm, omm), ptr(mv, omv), ptr(y), BN_EPS, rows, cout)
         return y
 
-    def _lstm_seq_desc(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, lengths=None, reverse=0, residual=None, zc=None, zh=None):
+    def _lstm_seq_desc(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, lengths=None, reverse=0, residual=None, zc=None, zh=None, fused=True):
         """Descriptor of one ZoneoutLSTMCell over a sequence: inference mode without masks (0.9*new + 0.1*old), training-mode zoneout
         with keep-masks zc / zh [T, B, H] (ZoneoutLSTMCell.py:259-271).  Where the fused cell step covers the shape (no residual) the
         packed recurrent kernel and packed h blocks are attached, so every step is one launch."""
@@ -98,11 +115,54 @@ class InferEngine:
         q.c_hist, q.h_hist = ptr(ch), ptr(hh)
         L_ = lib.load()
         q.gates_ws = ptr(self._f(int(L_.mstts_lstm_seq_ws_floats(B, H, 0))))
-        if residual is None and L_.mstts_cell_fwd_supported(H, H):
+        if fused and residual is None and L_.mstts_cell_fwd_supported(H, H):
             whp = self._f(H * 4 * H)             # (packed per call: the parameters may have been reloaded in between; 1 small launch)
             call("mstts_pack_cell_fwd", ptr(k, ok + cin * 4 * H), 4 * H, ptr(whp), H, H)
             q.wh_p, q.h_p = ptr(whp), ptr(self._f(2 * int(L_.mstts_cell_act_floats(B, H))))
         return q
+
+    # ---- persistent recurrent layers
+    def _lstm_persist_args(self, descs, cell_prefixes, cins, B, T, H):
+        """Packed kernels (cached), ring, history scratch and a fresh control-word slot for one persistent LSTM launch over `descs`; None when
+        the shape / device is not covered or this forward pass is a retry without them."""
+        L_, ndir = lib.load(), len(descs)
+        if not self.persist_lstm or self._lstm_retry or not L_.mstts_persist_lstm_fwd_supported_n(B, H, ndir):
+            return None
+        if self._lstm_ctrl is None:
+            self._lstm_ctrl = torch.zeros(64, 16, dtype=torch.int32, device=self.device)
+            self._lstm_ctrl_host = torch.zeros(64, 16, dtype=torch.int32).pin_memory()
+        if len(self._lstm_pending) >= 64:
+            return None
+        pks = []
+        for prefix, cin in zip(cell_prefixes, cins):
+            ent = self._lcache.get(prefix)
+            if ent is None or ent[0] != self.params.version:
+                k, ok = self.P(prefix + "kernel")
+                pk = ent[1] if ent is not None else torch.empty(H * 4 * H, dtype=torch.float32, device=self.device)
+                call("mstts_persist_lstm_pack_fwd", ptr(k, ok + cin * 4 * H), 4 * H, H, ptr(pk))
+                self._lcache[prefix] = ent = (self.params.version, pk)
+            pks.append(ent[1])
+        empty = lambda n: torch.empty((int(n) + 3) // 4 * 4, dtype=torch.float32, device=self.device)
+        xch, hist = empty(L_.mstts_persist_lstm_ws_bytes_n(B, ndir) // 4), empty(L_.mstts_persist_lstm_hist_floats_n(T, B, ndir))
+        self._keep.extend((xch, hist))
+        slot = len(self._lstm_pending)
+        self._lstm_pending.append((slot, ndir * ((B + 31) // 32) * (H // 8)))
+        self.persist_lstm_launches += 1
+        return pks, ptr(xch), ptr(self._lstm_ctrl, slot * 16), ptr(hist)
+
+    def _lstm_ctrl_copy(self):
+        """Enqueue the read-back of the control words of the persistent LSTM launches so far (call in front of a host sync)."""
+        if len(self._lstm_pending) > self._lstm_copied:
+            self._lstm_ctrl_host.copy_(self._lstm_ctrl, non_blocking=True)
+            self._lstm_copied = len(self._lstm_pending)
+
+    def _lstm_verify(self):
+        """After a host sync: did every persistent LSTM launch read back so far run to its end?  Raises _PersistRetry otherwise (the
+        forward pass is then re-run with the launch-per-step drivers)."""
+        for slot, n_wg in self._lstm_pending[:self._lstm_copied]:
+            st = self._lstm_ctrl_host[slot]
+            if int(st[1]) != 0 or int(st[2]) != n_wg:
+                raise _PersistRetry("persistent LSTM launch %d: control words %r" % (slot, st[:3].tolist()))
 
     def _lstm_seq(self, x, B, T, cin, H, cell_prefix, out, out_sb, out_st, out_off=0, residual=None, **kw):
         # residual wrapper (output = cell output + input, state untouched): with a dense [B, T, H] output the fused steps run without it
@@ -110,20 +170,59 @@ class InferEngine:
         post_add = (residual is not None and out_off == 0 and out_st == H and out_sb == T * H and
                     bool(lib.load().mstts_cell_fwd_supported(H, H)))
         dst = self._f(B, T, H) if post_add else out
-        q = self._lstm_seq_desc(x, B, T, cin, H, cell_prefix, dst, out_sb, out_st, out_off=out_off, residual=None if post_add else residual, **kw)
-        call("mstts_lstm_seq_fwd", C.byref(q))
+        pa = self._lstm_persist_args([None], [cell_prefix], [cin], B, T, H) if (residual is None or post_add) else None
+        q = self._lstm_seq_desc(x, B, T, cin, H, cell_prefix, dst, out_sb, out_st, out_off=out_off, residual=None if post_add else residual,
+                                fused=pa is None, **kw)
+        if pa is not None:
+            call("mstts_lstm_seq_fwd_persistent", C.byref(q), ptr(pa[0][0]), pa[1], pa[2], pa[3])
+        else:
+            call("mstts_lstm_seq_fwd", C.byref(q))
         if post_add:
             call("mstts_add", ptr(dst), ptr(residual), ptr(out), B * T * H)
 
     def _bilstm_seq(self, x, B, T, cin, H, cell_fmt, out, out_sb, out_st, lengths=None):
         """Forward and backward direction of a bidirectional layer advancing together: one launch per step where the fused form applies
         (mstts_lstm_seq_fwd_pair falls back to two sequential loops otherwise)."""
-        qs = [self._lstm_seq_desc(x, B, T, cin, H, cell_fmt % dr, out, out_sb, out_st, out_off=di * H, lengths=lengths, reverse=di)
+        pa = self._lstm_persist_args([None, None], [cell_fmt % "fw", cell_fmt % "bw"], [cin, cin], B, T, H)
+        qs = [self._lstm_seq_desc(x, B, T, cin, H, cell_fmt % dr, out, out_sb, out_st, out_off=di * H, lengths=lengths, reverse=di, fused=pa is None)
               for di, dr in enumerate(("fw", "bw"))]
-        call("mstts_lstm_seq_fwd_pair", C.byref(qs[0]), C.byref(qs[1]))
+        if pa is not None:
+            call("mstts_lstm_seq_fwd_pair_persistent", C.byref(qs[0]), C.byref(qs[1]), ptr(pa[0][0]), ptr(pa[0][1]), pa[1], pa[2], pa[3])
+        else:
+            call("mstts_lstm_seq_fwd_pair", C.byref(qs[0]), C.byref(qs[1]))
 
     # ------------------------------------------------------------------ sub-graphs
+    def _guarded(self, fn, *a, **k):
+        """A sub-graph called on its own (outside forward): the control words of its persistent LSTM launches are checked before its
+        result is handed out (one stream sync), and the sub-graph is re-run launch by launch if one of them gave up."""
+        self._lstm_pending, self._lstm_copied = [], 0
+        try:
+            out = fn(*a, **k)
+            if self._lstm_pending:
+                self._lstm_ctrl_copy()
+                torch.cuda.current_stream().synchronize()
+                self._lstm_verify()
+            return out
+        except _PersistRetry as e:
+            self.persist_lstm_fallbacks += 1
+            warnings.warn("multi_speaker_tts_amd: %s; re-running launch by launch" % (e,), RuntimeWarning, stacklevel=3)
+            self._lstm_retry = True
+            try:
+                return fn(*a, **k)
+            finally:
+                self._lstm_retry = False
+                self._lstm_pending, self._lstm_copied = [], 0
+
     def speaker_embedding(self, spk_mel, masks=None):
+        return self._guarded(self._speaker_embedding, spk_mel, masks=masks)
+
+    def encoder(self, token, token_length, spk):
+        return self._guarded(self._encoder, token, token_length, spk)
+
+    def mel_to_spectrogram(self, mel, B, S):
+        return self._guarded(self._mel_to_spectrogram, mel, B, S)
+
+    def _speaker_embedding(self, spk_mel, masks=None):
         """[5B,64,80] float32 device tensor -> [B, spk] (MSTTS_SV.py:49-56).  masks: optional {'s_zc_<i>', 's_zh_<i>'} uint8
         keep-masks [64, 5B, cell] - the reference feeds Is_Training into this (frozen) stack too, so a Tacotron2 TRAIN step sees
         stochastic zoneout in the speaker encoder (MSTTS_SV.py:49-56, ZoneoutLSTMCell.py:259-260)."""
@@ -142,7 +241,7 @@ class InferEngine:
         call("mstts_speaker_finalize", ptr(x), ptr(e), B, d.spk_samples, T, d.spk)
         return e
 
-    def encoder(self, token, token_length, spk):
+    def _encoder(self, token, token_length, spk):
         """-> values [B,T,M] (memory masked past Token_Length), keys [B,T,A]."""
         d = self.d
         B, T = token.shape
@@ -174,9 +273,28 @@ class InferEngine:
         else:
             mk.draw(seed if seed is not None else step_seed(self.seed, 0))
         self._keep.append(mk)
-        w0f = self._f(M + H, 4 * H)
+        # variable-derived operands shared by both drivers, kept until the variables change: cell-0 kernel with its two context row blocks
+        # folded, the folded location filter
+        c = self._dcache
+        if c.get("version") != self.params.version:
+            k0, o0 = self.P(CELL % 0 + "kernel")
+            if "w0f" not in c:
+                c.update(w0f=torch.zeros((M + H) * 4 * H, dtype=torch.float32, device=self.device).view(M + H, 4 * H),
+                         loc_k=torch.zeros(d.att_k * A, dtype=torch.float32, device=self.device).view(d.att_k, A),
+                         loc_b=torch.zeros(A, dtype=torch.float32, device=self.device),
+                         loc_kt=torch.zeros(A * 36, dtype=torch.float32, device=self.device).view(A, 36) if d.att_k <= 31 else None)
+            call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(c["w0f"]), 2 * M + H, 4 * H, 0, M)
+            cp = {}
+            for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
+                                ("dense_k", "attention_convolution_dense_layer/dense/kernel")):
+                t, o = self.P(LSA + name)
+                cp[field] = ptr(t, o)
+            call("mstts_lsa_fold_location", cp["conv_k"], cp["conv_b"], cp["dense_k"], ptr(c["loc_k"]), ptr(c["loc_b"]), d.att_k, d.att_ch, A)
+            if c["loc_kt"] is not None:
+                call("mstts_lsa_filter_by_unit", ptr(c["loc_k"]), ptr(c["loc_kt"]), d.att_k, A)
+            c["version"] = self.params.version
+        w0f = c["w0f"]
         k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
-        call("mstts_fold_rows", ptr(k0, o0 + Pn * 4 * H), ptr(w0f), 2 * M + H, 4 * H, 0, M)
         q = lib.DecoderInfer()
         q.B, q.H, q.P, q.n_mel, q.Smax = B, H, Pn, NM, Smax
         ls = q.lsa
@@ -186,13 +304,9 @@ class InferEngine:
                             ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
             t, o = self.P(LSA + name)
             setattr(ls, field, ptr(t, o))
-        loc_k, loc_b = self._f(d.att_k, A), self._f(A)
-        call("mstts_lsa_fold_location", ls.conv_k, ls.conv_b, ls.dense_k, ptr(loc_k), ptr(loc_b), d.att_k, d.att_ch, A)
-        ls.loc_k, ls.loc_b = ptr(loc_k), ptr(loc_b)
-        if d.att_k <= 31:
-            loc_kt = self._f(A, 36)
-            call("mstts_lsa_filter_by_unit", ptr(loc_k), ptr(loc_kt), d.att_k, A)
-            ls.loc_kt = ptr(loc_kt)
+        ls.loc_k, ls.loc_b = ptr(c["loc_k"]), ptr(c["loc_b"])
+        if c["loc_kt"] is not None:
+            ls.loc_kt = ptr(c["loc_kt"])
         for field, name in (("pw0", "decoder/decoder/prenet_0/dense/kernel"), ("pb0", "decoder/decoder/prenet_0/dense/bias"),
                             ("pw1", "decoder/decoder/prenet_1/dense/kernel"), ("pb1", "decoder/decoder/prenet_1/dense/bias"),
                             ("w1", CELL % 1 + "kernel"), ("b1", CELL % 1 + "bias"), ("wq", LSA + "query_layer/kernel"),
@@ -202,6 +316,16 @@ class InferEngine:
         q.pm0, q.pm1, q.prenet_keep = ptr(mk["prenet_drop_0"]), ptr(mk["prenet_drop_1"]), 1 - d.prenet_drop
         q.wx0, q.b0, q.w0f = ptr(k0, o0), ptr(b0, ob0), ptr(w0f)
         q.zoneout = d.zoneout
+        # (outputs: every row of the steps that ran is written by whichever driver runs; no clearing pass)
+        empty = lambda *shape: torch.empty(int(np.prod(shape)), dtype=torch.float32, device=self.device).view(shape)
+        linear, stop, align = empty(Smax, B, NM), empty(Smax, B), empty(Smax, B, T)
+        self._keep.extend((linear, stop, align))
+        q.linear, q.stop, q.align_hist = ptr(linear), ptr(stop), ptr(align)
+        # ONE launch for the whole loop where the shape and the device allow it ...
+        S = self._decode_persistent(q, values, w0f, mk, B, T, Smax)
+        if S is not None:
+            return linear[:S], stop[:S], align[:S], S
+        # ... else a launch chain per step
         q.in0, q.in1, q.pj = ptr(self._f(2, B, Pn + M + H)), ptr(self._f(2, B, 2 * H)), ptr(self._f(B, H + M))
         if lib.load().mstts_decoder_infer_fast(B, H, Pn, M, A, NM):
             # weight-streaming path: cell-0 kernel with the prenet rows stacked on the folded [ctx ; h] rows, padded projection
@@ -231,13 +355,9 @@ class InferEngine:
                     q.wp_own, q.vp = ptr(wp_own), ptr(vp)
         q.c0, q.c1, q.cum = ptr(self._f(2, B, H)), ptr(self._f(2, B, H)), ptr(self._f(2, B, T))
         q.pre_ws = ptr(self._f(int(lib.load().mstts_decoder_infer_ws_floats(B, H, Pn, T, A, NM))))
-        linear, stop, align = self._f(Smax, B, NM), self._f(Smax, B), self._f(Smax, B, T)
-        q.linear, q.stop, q.align_hist = ptr(linear), ptr(stop), ptr(align)
-        S = self._decode_persistent(q, values, w0f, mk, B, T, Smax)
-        if S is not None:
-            return linear[:S], stop[:S], align[:S], S
         # Decoder_Dynamic_Decode stops after the first step at which every row has raised its stop flag
         # (stop_logit >= 0 OR time >= Max_Inference_Length, OR-accumulated; Modules.py:216-219,395,409).
+        self._lstm_ctrl_copy()
         finished = np.zeros(B, bool)
         done, S = 0, None
         limit = Smax - 1                         # time index at which the forced stop fires
@@ -275,21 +395,35 @@ class InferEngine:
             self.persist_disabled_decodes += 1
             return None
         NP = 84
-        k0, o0 = self.P(CELL % 0 + "kernel"); k1, o1 = self.P(CELL % 1 + "kernel"); wq, oq = self.P(LSA + "query_layer/kernel")
-        wpj, owpj = self.P("decoder/decoder/linear_projection/dense/kernel"); bpj, obpj = self.P("decoder/decoder/linear_projection/dense/bias")
         pw0, opw0 = self.P("decoder/decoder/prenet_0/dense/kernel"); pb0, opb0 = self.P("decoder/decoder/prenet_0/dense/bias")
         pw1, opw1 = self.P("decoder/decoder/prenet_1/dense/kernel"); pb1, opb1 = self.P("decoder/decoder/prenet_1/dense/bias")
-        # loop invariants (see include/mstts.h): padded projection, projected values, the first prenet layer folded onto both
-        wp_pad, bp_pad = self._f(H + M, NP), self._f(NP)
-        call("mstts_copy2d", ptr(wpj, owpj), NM + 1, ptr(wp_pad), NP, H + M, NM + 1, 0)
-        call("mstts_copy2d", ptr(bpj, obpj), NM + 1, ptr(bp_pad), NP, 1, NM + 1, 0)
-        vp, u, wfm, bf = self._f(B * T, NP), self._f(B * T, Pn), self._f(H, Pn), self._f(4, Pn)
+        # what depends on the variables only (padded projection, first prenet layer folded onto its m1 half, kernels in the lanes' order):
+        # kept until the variables change (ParamStore.version)
+        c = self._pcache
+        if c.get("version") != self.params.version:
+            alloc = lambda *shape: torch.zeros(int(np.prod(shape)), dtype=torch.float32, device=self.device).view(shape)
+            k0, o0 = self.P(CELL % 0 + "kernel"); k1, o1 = self.P(CELL % 1 + "kernel"); wq, oq = self.P(LSA + "query_layer/kernel")
+            wpj, owpj = self.P("decoder/decoder/linear_projection/dense/kernel"); bpj, obpj = self.P("decoder/decoder/linear_projection/dense/bias")
+            if "wp_pad" not in c:
+                c.update(wp_pad=alloc(H + M, NP), bp_pad=alloc(NP), wfm=alloc(H, Pn), bf=alloc(4, Pn), bp4=alloc(4, NP),
+                         pk=[torch.empty(int(L_.mstts_persist_pack_floats(i)), dtype=torch.float32, device=self.device) for i in range(3)],
+                         wqppk=torch.empty(int(L_.mstts_persist_infer_pack_floats()), dtype=torch.float32, device=self.device),
+                         xch=torch.empty(int(L_.mstts_persist_infer_ws_bytes()) // 4, dtype=torch.float32, device=self.device),
+                         ctrl=torch.zeros(272, dtype=torch.int32, device=self.device), ctrl_host=torch.zeros(272, dtype=torch.int32).pin_memory())
+            call("mstts_copy2d", ptr(wpj, owpj), NM + 1, ptr(c["wp_pad"]), NP, H + M, NM + 1, 0)
+            call("mstts_copy2d", ptr(bpj, obpj), NM + 1, ptr(c["bp_pad"]), NP, 1, NM + 1, 0)
+            gemm(c["wp_pad"], pw0, c["wfm"], H, Pn, NM, NP, Pn, Pn, b_off=opw0)
+            c["bp4"][0].copy_(c["bp_pad"])                # (a 4-row product: row 0 is bp, the other rows are zero)
+            gemm(c["bp4"], pw0, c["bf"], 4, Pn, NM, NP, Pn, Pn, bias=pb0, b_off=opw0, bias_off=opb0)
+            # (w0f: the caller's folded cell-0 kernel - its values depend on the variables only)
+            call("mstts_persist_pack", ptr(w0f), ptr(k1, o1), ptr(wq, oq), ptr(k0, o0), ptr(c["pk"][0]), ptr(c["pk"][1]), ptr(c["pk"][2]))
+            call("mstts_persist_infer_pack", ptr(wq, oq), ptr(c["wp_pad"]), NP, ptr(c["wfm"]), ptr(c["wqppk"]))
+            c["version"] = self.params.version
+        wp_pad, bp_pad, wfm, bf, pk, wqppk, xch, ctrl = (c[k] for k in ("wp_pad", "bp_pad", "wfm", "bf", "pk", "wqppk", "xch", "ctrl"))
+        # loop invariants of this batch (see include/mstts.h): projected values, and the first prenet layer applied to them
+        vp, u = self._f(B * T, NP), self._f(B * T, Pn)
         gemm(values, wp_pad, vp, B * T, NP, M, M, NP, NP, b_off=H * NP)
         gemm(vp, pw0, u, B * T, Pn, NM, NP, Pn, Pn, b_off=opw0)
-        gemm(wp_pad, pw0, wfm, H, Pn, NM, NP, Pn, Pn, b_off=opw0)
-        bp4 = self._f(4, NP)                          # (a 4-row product: row 0 is bp, the other rows are zero)
-        bp4[0].copy_(bp_pad)
-        gemm(bp4, pw0, bf, 4, Pn, NM, NP, Pn, Pn, bias=pb0, b_off=opw0, bias_off=opb0)
         # prenet of the all-zero start frame with the masks of step 0 (Modules.py:178-185)
         zf, pa, pb = self._f(B, NM), self._f(B, Pn), self._f(B, Pn)
         gemm(zf, pw0, pa, B, Pn, NM, NM, Pn, Pn, bias=pb0, act=ACT_RELU, b_off=opw0, bias_off=opb0)
@@ -297,14 +431,6 @@ class InferEngine:
         gemm(pb, pw1, pa, B, Pn, Pn, Pn, Pn, Pn, bias=pb1, act=ACT_RELU, b_off=opw1, bias_off=opb1)
         pre0 = self._f(B, Pn)
         call("mstts_dropout", ptr(pa), ptr(mk["prenet_drop_1"]), 1 - d.prenet_drop, ptr(pre0), B * Pn)
-        # kernels in the lanes' order
-        pk = [self._f(int(L_.mstts_persist_pack_floats(i))) for i in range(3)]
-        call("mstts_persist_pack", ptr(w0f), ptr(k1, o1), ptr(wq, oq), ptr(k0, o0), ptr(pk[0]), ptr(pk[1]), ptr(pk[2]))
-        wqppk = self._f(int(L_.mstts_persist_infer_pack_floats()))
-        call("mstts_persist_infer_pack", ptr(wq, oq), ptr(wp_pad), NP, ptr(wfm), ptr(wqppk))
-        xch = self._f(int(L_.mstts_persist_infer_ws_bytes()) // 4)
-        ctrl = torch.zeros(272, dtype=torch.int32, device=self.device)
-        self._keep.append(ctrl)
         pd = lib.PersistInferDesc()
         pd.w0pk, pd.w1pk, pd.wqppk = ptr(pk[0]), ptr(pk[1]), ptr(wqppk)
         pd.pre0, pd.bf, pd.u, pd.vp, pd.bp_pad = ptr(pre0), ptr(bf), ptr(u), ptr(vp), ptr(bp_pad)
@@ -313,7 +439,10 @@ class InferEngine:
         pd.selftest_fail_step = int(self.persist_infer_selftest)
         pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
         call("mstts_decoder_infer_persistent", C.byref(q), C.byref(pd))
-        st = ctrl.cpu().numpy()                       # synchronises the stream
+        self._lstm_ctrl_copy()
+        c["ctrl_host"].copy_(ctrl, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        st = c["ctrl_host"].numpy()
         self.persist_infer_status = (int(st[0]), int(st[1]), int(st[2]), int(st[4]), int(st[5]))
         if int(st[1]) != 0 or int(st[2]) != 256:
             self.persist_infer_fallbacks += 1
@@ -338,7 +467,7 @@ class InferEngine:
         call("mstts_add", ptr(linear_bsc), ptr(x), ptr(mel), B * S * d.n_mel)
         return mel
 
-    def mel_to_spectrogram(self, mel, B, S):
+    def _mel_to_spectrogram(self, mel, B, S):
         """ConvBank -> Highway -> BiRNN -> Projection (MSTTS_SV.py:100-115), inference mode."""
         d = self.d
         rows, C1 = B * S, d.bank_k * d.bank_ch
@@ -371,10 +500,25 @@ class InferEngine:
 
     # ------------------------------------------------------------------ whole forward
     def forward(self, pattern, masks=None, seed=None, max_steps=None, with_vocoder=True):
+        """See _forward.  A persistent LSTM launch that gave up (bounded waits, no co-residency) invalidates what was computed from its output:
+        the pass is run again with the launch-per-step drivers."""
+        try:
+            return self._forward(pattern, masks, seed, max_steps, with_vocoder)
+        except _PersistRetry as e:
+            self.persist_lstm_fallbacks += 1
+            warnings.warn("multi_speaker_tts_amd: %s; re-running the forward pass launch by launch" % (e,), RuntimeWarning, stacklevel=2)
+            self._lstm_retry = True
+            try:
+                return self._forward(pattern, masks, seed, max_steps, with_vocoder)
+            finally:
+                self._lstm_retry = False
+
+    def _forward(self, pattern, masks=None, seed=None, max_steps=None, with_vocoder=True):
         """pattern: dict with Token [B,T] int32, Token_Length [B] int32 and either Speaker_Embedding_Mel
         [5B,64,80] or Speaker_Embedding [B,spk] (numpy or tensors).  Returns the reference's
         inference_Tensor_Dict as numpy arrays: Linear, Mel, Stop (sigmoid), Attention_History [B,T,S], Spectrogram."""
         self._keep = []
+        self._lstm_pending, self._lstm_copied = [], 0
         dev = self.device
         t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev, dt).contiguous()
         token, tlen = t(pattern["Token"], torch.int32), t(pattern["Token_Length"], torch.int32)
@@ -382,9 +526,10 @@ class InferEngine:
         if "Speaker_Embedding" in pattern:
             spk = t(pattern["Speaker_Embedding"], torch.float32)
         else:
-            spk = self.speaker_embedding(t(pattern["Speaker_Embedding_Mel"], torch.float32))
-        values, keys = self.encoder(token, tlen, spk)
+            spk = self._speaker_embedding(t(pattern["Speaker_Embedding_Mel"], torch.float32))
+        values, keys = self._encoder(token, tlen, spk)
         lin_s, stop_s, align_s, S = self.decode(values, keys, tlen, masks=masks, seed=seed, max_steps=max_steps)
+        self._lstm_verify()                  # (decode synchronised the stream behind the read-back of their control words)
         d = self.d
         linear = self._f(B, S, d.n_mel)
         call("mstts_transpose01", ptr(lin_s), ptr(linear), S, B, d.n_mel)
@@ -392,8 +537,10 @@ class InferEngine:
         out = {"Linear": linear, "Mel": mel, "Stop_Logit": stop_s.t().contiguous(), "Attention_History": align_s.permute(1, 2, 0).contiguous(),
                "Speaker_Embedding": spk}
         if with_vocoder:
-            out["Spectrogram"] = self.mel_to_spectrogram(mel, B, S)
+            out["Spectrogram"] = self._mel_to_spectrogram(mel, B, S)
+        self._lstm_ctrl_copy()
         torch.cuda.synchronize()
+        self._lstm_verify()
         res = {k: v.detach().cpu().numpy() for k, v in out.items()}
         res["Stop"] = 1.0 / (1.0 + np.exp(-res["Stop_Logit"]))
         self._keep = []

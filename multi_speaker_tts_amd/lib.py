@@ -212,6 +212,8 @@ SIGNATURES = {
     "mstts_persist_lstm_ws_bytes": (i64, []),
     "mstts_persist_lstm_pack": (i32, [vp, i64, vp, vp, vp]),
     "mstts_persist_lstm_supported_n": (i32, [i64, i64, i32]),
+    "mstts_persist_lstm_fwd_supported_n": (i32, [i64, i64, i32]),
+    "mstts_persist_lstm_pack_fwd": (i32, [vp, i64, i64, vp, vp]),
     "mstts_persist_lstm_ws_bytes_n": (i64, [i64, i32]),
     "mstts_persist_lstm_hist_floats_n": (i64, [i64, i64, i32]),
     "mstts_persist_lstm_bwd_floats_n": (i64, [i64, i64, i32]),

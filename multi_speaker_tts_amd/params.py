@@ -234,6 +234,7 @@ class ParamStore:
                 o = self.offset[name]
                 wd[o:o + int(np.prod(shape))] = 1
         self.wd_mask = torch.from_numpy(wd).to(device)
+        self.version = 0          # bumped whenever the variables change (load, optimizer step): engines key their packed / folded copies on it
         self.load(values if values is not None else initial_values(d, seed))
 
     def _slab(self, name, grad=False):
@@ -253,6 +254,7 @@ class ParamStore:
         return self.grad, self.offset[name]
 
     def load(self, values):
+        self.version += 1
         for name, shape, _ in self.table:
             if name in values:
                 v = values[name]

@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 REFW = dict(dec_lstm=1024, prenet=256, enc_lstm=256, spk=256, n_mel=80)
 
 
-def _setup(dev, B, Te, max_inf, seed, stop_bias=-8.0, stop_scale=1.0):
+def _setup(dev, B, Te, max_inf, seed, stop_bias=-8.0, stop_scale=1.0, **more):
     from multi_speaker_tts_amd.inference import InferEngine
-    pd, od = dims_pair(max_inf=max_inf, **REFW)
+    pd, od = dims_pair(max_inf=max_inf, **REFW, **more)
     values = OM.init_params(od, seed)
     g = np.random.default_rng(seed + 1)
     for k in values:
@@ -76,16 +76,17 @@ def test_rows_stop_at_different_steps(dev):
     raw = eng.forward(pat, masks=masks, with_vocoder=False)["Stop_Logit"] + 100.0          # [B, S] bias-free logits (the trajectory does not depend on the bias)
     assert raw.shape == (B, max_inf + 1)
     best = None
-    for beta in -np.sort(raw.max(axis=1))[0] + np.linspace(0.0005, 0.05, 100):
+    lo = -np.sort(raw.max(axis=1))[0]                                                       # from here on every row crosses 0 somewhere
+    for beta in lo + np.concatenate([np.linspace(0.0005, 0.05, 100), np.linspace(0.05, 3.0, 600)]):
         z = raw + beta
         first = np.array([int(np.argmax(z[b] >= 0)) if (z[b] >= 0).any() else -1 for b in range(B)])
         if (first < 0).any() or len(set(first.tolist())) < 3:
             continue
         S = int(first.max()) + 1
         margin = float(np.abs(z[:, :S]).min())
-        if S >= 12 and S < max_inf and (best is None or margin > best[0]):
+        if S >= 8 and S < max_inf and margin > 1e-4 and (best is None or margin > best[0]):
             best = (margin, float(beta), first, S)
-    assert best is not None, "no stop bias makes the rows stop at three or more different steps"
+    assert best is not None, ("no stop bias makes the rows stop at three or more different steps", raw.max(axis=1), raw.argmax(axis=1))
     margin, beta, first, S = best
     values["decoder/decoder/linear_projection/dense/bias"][-1] = beta
     eng.params.load(values)
@@ -122,7 +123,7 @@ def test_abort_falls_back_and_recovers(dev):
     c = eng.forward(pat, masks=masks, with_vocoder=False)
     assert eng.persist_infer_launches == 2 and eng.persist_infer_fallbacks == 1
     for k in KEYS:
-        assert np.array_equal(c[k], ref[k]), k                              # the launch is deterministic: bit-equal to the first healthy one
+        assert rel_err(c[k], ref[k]) < 5e-6, k                              # (the launch itself is deterministic; the encoder's tail-split products upstream of it are not, to the last bit)
     eng.persist_infer_selftest = 2
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
@@ -149,3 +150,29 @@ def test_against_oracle_reference_widths(dev):
     assert got["Linear"].shape == tuple(ref["Linear"].shape)
     for k in ("Linear", "Mel", "Stop", "Attention_History"):
         assert rel_err(got[k], t2n(ref[k])) < 1e-3, (k, rel_err(got[k], t2n(ref[k])))
+
+
+def test_whole_forward_takes_the_persistent_recurrences(dev):
+    """BASELINE configs[3] end to end (speaker encoder on 5 x 64-frame windows, text encoder, free-running decoder, postnet, Taco1 mel ->
+    spectrogram): every recurrence is ONE launch - speaker stack 3, encoder BiLSTM 1, decoder 1, vocoder BiRNN (H = 128) 1 - with no
+    fallback, and the result equals the launch-per-step forward."""
+    from multi_speaker_tts_amd import lib
+    B, Te, max_inf = 4, 40, 30
+    eng, od, values, pat, masks = _setup(dev, B, Te, max_inf, seed=13, birnn=128, spk_lstm=256)      # the recurrent widths of the reference
+    _skip_unless_supported(eng, B, Te)
+    d = eng.d
+    assert lib.load().mstts_persist_lstm_fwd_supported_n(B, d.birnn, 2) and lib.load().mstts_persist_lstm_fwd_supported_n(d.spk_samples * B, d.spk_lstm, 1)
+    g = np.random.default_rng(3)
+    pat = dict(pat)
+    del pat["Speaker_Embedding"]
+    pat["Speaker_Embedding_Mel"] = g.normal(0, 1, (d.spk_samples * B, d.spk_frames, d.n_mel)).astype(np.float32)
+    a = eng.forward(pat, masks=masks, with_vocoder=True)
+    L = lib.load()
+    expect = (d.spk_lstm_n if L.mstts_persist_lstm_fwd_supported_n(d.spk_samples * B, d.spk_lstm, 1) and d.spk == d.spk_lstm else 0) + \
+             (1 if L.mstts_persist_lstm_fwd_supported_n(B, d.enc_lstm, 2) else 0) + (1 if L.mstts_persist_lstm_fwd_supported_n(B, d.birnn, 2) else 0)
+    assert eng.persist_lstm_launches == expect and eng.persist_lstm_fallbacks == 0 and eng.persist_infer_launches == 1, (eng.persist_lstm_launches, expect)
+    eng.persist_lstm = eng.persist_infer = False
+    b = eng.forward(pat, masks=masks, with_vocoder=True)
+    assert eng.persist_lstm_launches == expect
+    for k in KEYS + ("Spectrogram", "Speaker_Embedding"):
+        assert np.isfinite(a[k]).all() and rel_err(a[k], b[k]) < 1e-4, (k, rel_err(a[k], b[k]))

@@ -252,3 +252,64 @@ def test_persistent_single_sequence_row_groups(dev, B, T):
         a, b = t2n(out[True][k]), t2n(out[False][k])
         assert np.isfinite(a).all(), k
         assert rel_err(a, b) < 5e-5, (k, rel_err(a, b))
+
+
+@pytest.mark.parametrize("B,T,HH,ndir", [(16, 50, 128, 2), (5, 9, 128, 2), (1, 1, 128, 2), (16, 401, 128, 2), (40, 12, 128, 1), (80, 64, 256, 1)])
+def test_forward_only_launch_h128_and_single_direction(dev, B, T, HH, ndir):
+    """The forward launch at H = 128 (the Taco1 vocoder's BiRNN, Taco1_Mel_to_Spect/Modules.py:75-99) and as a single direction over row groups
+    (the speaker-encoder stack, Speaker_Embedding/Modules.py:15-37), inference arithmetic (no keep-masks: state' = 0.9 new + 0.1 old),
+    against the launch-per-step drivers on the same inputs."""
+    L = lib.load()
+    if not L.mstts_persist_lstm_fwd_supported_n(B, HH, ndir):
+        pytest.skip("persistent LSTM launches not available on this device")
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)
+    lens = torch.randint(max(1, T // 3), T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = T
+    lens = lens.to(dev)
+    wh = [r(HH, 4 * HH, scale=0.08) for _ in range(ndir)]
+    xw = [r(B, T, 4 * HH, scale=0.8) for _ in range(ndir)]
+
+    def run(persistent):
+        out = torch.zeros(B, T, ndir * HH, device=dev)
+        keep, qs = [], []
+        for di in range(ndir):
+            q = lib.LstmSeqFwd()
+            q.B, q.T, q.H = B, T, HH
+            q.xw = lib.ptr(xw[di]); q.wh = lib.ptr(wh[di]); q.wh_ld = 4 * HH
+            q.lengths = lib.ptr(lens); q.reverse = di; q.zoneout = 0.1
+            q.out = lib.ptr(out, di * HH); q.out_sb = T * ndir * HH; q.out_st = ndir * HH
+            ch, hh = torch.full((T + 1, B, HH), float("nan"), device=dev), torch.full((T + 1, B, HH), float("nan"), device=dev)
+            q.c_hist, q.h_hist = lib.ptr(ch), lib.ptr(hh)
+            gw = torch.empty(L.mstts_lstm_seq_ws_floats(B, HH, 0), device=dev)
+            q.gates_ws = lib.ptr(gw)
+            keep += [ch, hh, gw]
+            qs.append(q)
+        if persistent:
+            pk = [torch.empty(HH * 4 * HH, device=dev) for _ in range(ndir)]
+            for di in range(ndir):
+                lib.call("mstts_persist_lstm_pack_fwd", lib.ptr(wh[di]), 4 * HH, HH, lib.ptr(pk[di]))
+            xch = torch.empty(L.mstts_persist_lstm_ws_bytes_n(B, ndir) // 4, device=dev)
+            ctrl = torch.zeros(16, dtype=torch.int32, device=dev)
+            hist = torch.empty(L.mstts_persist_lstm_hist_floats_n(T, B, ndir), device=dev)
+            if ndir == 2:
+                lib.call("mstts_lstm_seq_fwd_pair_persistent", C.byref(qs[0]), C.byref(qs[1]), lib.ptr(pk[0]), lib.ptr(pk[1]), lib.ptr(xch), lib.ptr(ctrl), lib.ptr(hist))
+            else:
+                lib.call("mstts_lstm_seq_fwd_persistent", C.byref(qs[0]), lib.ptr(pk[0]), lib.ptr(xch), lib.ptr(ctrl), lib.ptr(hist))
+            torch.cuda.synchronize()
+            c = ctrl.cpu().numpy()
+            assert c[1] == 0 and c[2] == ndir * ((B + 31) // 32) * (HH // 8), c[:4]
+        else:
+            if ndir == 2:
+                lib.call("mstts_lstm_seq_fwd_pair", C.byref(qs[0]), C.byref(qs[1]))
+            else:
+                lib.call("mstts_lstm_seq_fwd", C.byref(qs[0]))
+            torch.cuda.synchronize()
+        return t2n(out), [t2n(keep[3 * di]) for di in range(ndir)], [t2n(keep[3 * di + 1]) for di in range(ndir)]
+
+    oa, ca, ha = run(True)
+    ob, cb, hb = run(False)
+    tol = 2e-4 if T > 100 else 2e-5
+    assert np.isfinite(oa).all() and rel_err(oa, ob) < tol, rel_err(oa, ob)
+    for di in range(ndir):
+        assert rel_err(ca[di][1:], cb[di][1:]) < tol and rel_err(ha[di][1:], hb[di][1:]) < tol, di

@@ -5,10 +5,17 @@ per-GPU batch 32 x (128 tokens, 800 mel frames), fp32, synthetic data (BASELINE.
   python bench.py --gpus N --steps K --warmup W          (N > 1: spawns one rank per GPU itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is the location-sensitive-attention step (the kernel
-north_star names), measured in situ with HIP events around every launch inside the native
-decoder loop of one extra, untimed step; `cpu_baseline` is the oracle (torch-CPU restatement of the
-same graph) timed on this host on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.
+  `roofline`: the location-sensitive-attention step (the kernel north_star names).  In the persistent decoder launch it is a STAGE of
+      every step, not a launch, so it is timed with device timestamps inside the kernel (s_memrealtime, 100 MHz) by the launch's
+      profiling instantiation - a separate binary of the same source, run for one extra untimed step; mean over 256 workgroups x 801
+      steps.  `frac` ends the stage where the context store is issued; `frac_incl_outbound_handoff` adds the consumer-side wait for that
+      context (the flight time of the outbound hand-off), the stricter reading.  The launch-per-step attention kernel is measured beside
+      it with HIP events around every launch (`roofline.launch_per_step`).  `traffic` comes from the committed rocprofv3 PMC pass named
+      in `traffic_source`; `traffic_stale` says whether the kernel sources have changed since that pass was taken.
+  `cpu_baseline`: the oracle (torch-CPU fp32 restatement of the same graph) timed on this host at the FULL workload: thread sweep on a
+      short prefix, then 1 warm-up + 3 timed full train steps at the best thread count, median (falls back to a truncated sample only
+      when a full step would not fit the time limit, and says so).
 """
 import argparse
 import ctypes
@@ -44,6 +51,30 @@ def _latest_pmc_csv():
 
 
 PMC_TRAFFIC_CSV = _latest_pmc_csv()
+
+
+def _sha16(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for f in paths:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def persist_source_sha16():
+    """Hash of the sources the persistent decoder kernels are compiled from: a PMC pass is only as good as the kernel it measured."""
+    c = os.path.join(ROOT, "multi_speaker_tts_amd", "csrc")
+    return _sha16([os.path.join(c, f) for f in ("persist.hip", "persist_bwd.hip", "persist_common.h", "persist_fwd_parts.h", "common.h")])
+
+
+def pmc_collected_for():
+    """The kernel-source hash recorded next to the committed PMC pass when it was taken (tools/profile_round.sh), or None."""
+    f = PMC_TRAFFIC_CSV.replace("_pmc_fetch_write_per_kernel.csv", "_pmc_kernel_source_sha16.txt")
+    try:
+        return open(f).read().strip()
+    except OSError:
+        return None
 
 
 def pmc_traffic_bytes(kernel_prefix):
@@ -303,7 +334,8 @@ def main():
     out["persistent_launches"] = {"decoder_forward": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist", False)),
                                   "decoder_bptt": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist_bwd", False)),
                                   "encoder_bilstm": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist_enc", False)),
-                                  "fallbacks": {"decoder_forward": eng.persist_fallbacks, "decoder_bptt": eng.persist_bwd_fallbacks, "encoder_bilstm": eng.persist_enc_fallbacks}}
+                                  "fallbacks": {"decoder_forward": eng.persist_fallbacks, "decoder_bptt": eng.persist_bwd_fallbacks, "encoder_bilstm": eng.persist_enc_fallbacks},
+                                  "non_persistent_plans": eng.non_persistent_plans, "persist_disabled_steps": eng.persist_disabled_steps}
     if rank == 0 and not args.no_roofline:
         w = eng.plan(B_PER_GPU, T_ENC, L)
         S = L + 1
@@ -347,18 +379,24 @@ def main():
             eng.persist_stamps = None
             per_step_us = ticks.mean(axis=0) * 0.01 / S                 # 10 ns per tick
             frame_us = float(per_step_us.sum())
-            # the attention STAGE: from the moment the cell-1 outputs (m1) leave their producers to the moment the context has left
-            # this workgroup - the m1 hand-off, the 16 query units, the partial energies, the energy hand-off, softmax, context.  It
-            # contains the recurrent-half products that run in the shadow of its two hand-offs (stages 10 and 13).
+            # the attention STAGE: from the moment the cell-1 outputs (m1) leave their producers to the moment the context store has been
+            # issued - the m1 hand-off, the 16 query units, the partial energies, the energy hand-off, softmax, context (stamps 11, 12,
+            # 14, 15) and the half-product that runs in the shadow of the m1 hand-off (stamp 10).  The stricter reading also charges the
+            # outbound hand-off: the time the consumers of that context wait for it at the top of the next step (stamp 1, "wait ctx").
             att_us = float(per_step_us[10:13].sum() + per_step_us[14:16].sum())
+            strict_us = att_us + float(per_step_us[1])
             ach = att_bytes / (att_us * 1e-6) / 1e9
             out["roofline"] = {"kernel": "persist_fwd_kernel, attention stage of one decoder step (m1 hand-off, query units, partial energies, energy hand-off, softmax, context; B=32): keys / values stay on chip",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "frac_incl_outbound_handoff": att_bytes / (strict_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us_incl_outbound_handoff": strict_us,
                                "traffic": (pmc_traffic_bytes("persist_fwd_kernel") or 0) / S or None,
                                "traffic_note": "HBM-side bytes of the WHOLE persistent launch per decoder step (committed rocprofv3 PMC pass, FETCH_SIZE x 2 + WRITE_SIZE, / %d steps): history written for BPTT, hand-off rings and operands - the attention stage's keys / values are read once per sequence" % S,
-                               "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT),
+                               "traffic_source": os.path.relpath(PMC_TRAFFIC_CSV, ROOT), "traffic_source_sha16": _sha16([PMC_TRAFFIC_CSV]) if os.path.exists(PMC_TRAFFIC_CSV) else None,
+                               "traffic_collected_for_kernel_sources": pmc_collected_for(), "kernel_sources_now": persist_source_sha16(),
+                               "traffic_stale": pmc_collected_for() != persist_source_sha16(),
                                "algorithmic_bytes_per_launch": att_bytes, "avg_launch_us": att_us,
-                               "timing": "s_memrealtime stamps inside the launch, mean over 256 workgroups x %d steps" % S,
+                               "timing": "s_memrealtime stamps inside the launch (its PROF template instantiation: a different binary from the timed one, same source, "
+                                         "stamping overhead < 1 %% of the frame), one extra untimed step, mean over 256 workgroups x %d steps" % S,
                                "stage_us": {stage_names[i]: float(per_step_us[i]) for i in stage_order}, "frame_us": frame_us,
                                "attention_compute_only_us": float(per_step_us[12] + per_step_us[15]),
                                "persistent_fallbacks": eng.persist_fallbacks}

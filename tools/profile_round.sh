@@ -24,6 +24,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$c.log 2>&1
 done
 python $ROOT/tools/pmc_summary.py $OUT/pmc_fetch_write_per_kernel.csv $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+(cd $ROOT && python -c "import bench; print(bench.persist_source_sha16())") > $OUT/pmc_kernel_source_sha16.txt     # what the pass measured: bench.py reports traffic_stale against it
 for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmcm_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmcm_$c.log 2>&1
 done

@@ -29,7 +29,7 @@
 namespace mstts {
 
 // ring sizes in floats per slot
-constexpr long XCTX = 8L * 128 * 24, XACT = 8L * 128 * 32, XPART = 256L * 8 * 2 * 256, XM1 = 32L * PH, XEN = 32L * 8 * PT;
+constexpr long XCTX = 8L * 128 * 24, XACT = 8L * 128 * 32, XPART = 256L * 8 * 2 * 256, XM1 = 32L * PH, XEN = 32L * 8 * PTMAX;
 constexpr long OFF_CTX = 0, OFF_M0 = OFF_CTX + PRING * XCTX, OFF_H0 = OFF_M0 + PRING * XACT, OFF_H1 = OFF_H0 + PRING * XACT,
                OFF_M1 = OFF_H1 + PRING * XACT, OFF_EN = OFF_M1 + PRING * XM1, OFF_P0 = OFF_EN + PRING * XEN, OFF_P1 = OFF_P0 + PRING * XPART,
                XCH_FLOATS = OFF_P1 + PRING * XPART;
@@ -37,9 +37,16 @@ constexpr long OFF_CTX = 0, OFF_M0 = OFF_CTX + PRING * XCTX, OFF_H0 = OFF_M0 + P
 // ONE staging buffer serves the four slices a step consumes, in turn: ctx_{s-1} -> m0_s -> h0_s -> h1_s (each is dead before the next arrives)
 // (small arrays first: a DS instruction's immediate offset reaches 64 KB, and every access beyond that needs an address register of its
 //  own, which the compiler hoists out of the step loop - with the two big flat arrays in front the kernel spilled 119 registers)
-constexpr int S_STG = 0, S_RED = S_STG + 128 * LA, S_TR = S_RED + 4 * 2 * 256, S_M1 = S_TR + 2 * 128, S_EN = S_M1 + PH,
-              S_CUM = S_EN + 8 * PT, S_A = S_CUM + 176, S_Q = S_A + PT, S_QF = S_Q + 512, S_CO = S_QF + 16, S_LK = S_CO + 4 * 96,
-              S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_FLOATS = S_WQ + 8 * 512 * 4;
+// TT = 128 or 256 encoder positions (the kernel's instantiations).  The value slice in LDS always covers positions 0 .. 127; with TT = 256 the
+// positions from 128 on are read from memory (an XCD's 32 attention workgroups read 1.5 MB of them per step: they stay in its L2), the
+// energies of a row (8 x 256) share the staging buffer, which is idle between the last product of a step and the first of the next.
+template <int TT> struct FL {
+    static constexpr int S_STG = 0, S_RED = S_STG + 128 * LA, S_TR = S_RED + 4 * 2 * 256, S_M1 = S_TR + 2 * 128,
+                         S_EN = TT > 128 ? S_STG : S_M1 + PH, S_CUM = TT > 128 ? S_M1 + PH : S_EN + 8 * PT,
+                         S_A = S_CUM + TT + 48, S_Q = S_A + TT, S_QF = S_Q + 512, S_CO = S_QF + 16, S_LK = S_CO + 4 * 96,
+                         S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_FLOATS = S_WQ + 8 * 512 * 4;
+    static_assert(8 * TT <= 128 * LA && S_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
 constexpr int NSTAMP = 16;
 
 struct PersistFwd {
@@ -61,8 +68,12 @@ struct PersistFwd {
 
 // FOLD: the prenet rows of the cell-0 kernel ride along with the context rows (8 more k-steps per wave on the matrix cores) instead of
 // arriving as a hoisted [S B, 4096] product: no 420 MB tensor written by a GEMM and read back by row-strided loads in every step.
-template <bool PROF, bool FOLD>
+template <bool PROF, bool FOLD, int TT>
 __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
+    typedef FL<TT> Y;
+    constexpr int S_STG = Y::S_STG, S_RED = Y::S_RED, S_TR = Y::S_TR, S_M1 = Y::S_M1, S_EN = Y::S_EN, S_CUM = Y::S_CUM, S_A = Y::S_A, S_Q = Y::S_Q,
+                  S_CO = Y::S_CO, S_LK = Y::S_LK, S_FLAG = Y::S_FLAG, S_STAMP = Y::S_STAMP, S_VAL = Y::S_VAL, S_WQ = Y::S_WQ;
+    constexpr int NH = TT / 128;                  // halves of 128 encoder positions
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g0 = blockIdx.x, tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     int g = g0, gi = g & 7, gj = g >> 3;
@@ -101,12 +112,12 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     const bool arow = ab < B;
     const int alen = arow ? (d.lengths ? d.lengths[ab] : T) : 0;
     int ak = tid & 15, atg = tid >> 4;                           // energy phase: attention unit 16 gi + ak, positions 4 atg .. 4 atg + 3
-    float kreg[4];
+    float kreg[4 * NH];
     float asb = 0.f, awk = 0.f;
     {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int t = 4 * atg + m;
+        for (int m = 0; m < 4 * NH; ++m) {
+            const int t = 128 * (m >> 2) + 4 * atg + (m & 3);
             kreg[m] = (arow && t < T) ? d.keys[((long)ab * T + t) * PA + 16 * gi + ak] : 0.f;
         }
         asb = d.score_b[16 * gi + ak] + d.loc_b[16 * gi + ak];
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             const int t = x / 96, c = x - t * 96;
             sm[S_VAL + x] = (arow && t < alen && t < T) ? d.values[((long)ab * T + t) * PM + 96 * gi + c] : 0.f;
         }
-        for (int x = tid; x < 176; x += PTH) sm[S_CUM + x] = 0.f;
+        for (int x = tid; x < TT + 48; x += PTH) sm[S_CUM + x] = 0.f;
         const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqpk) + (long)gi * 8 * 512;      // query kernel slice: [8][512 threads] float4
         for (int x = tid; x < 8 * 512; x += PTH) reinterpret_cast<pf32x4*>(sm + S_WQ)[x] = wqs[x];
     }
@@ -387,26 +398,29 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 // = A . B with A[t][j] = cum window (one LDS word per lane and k-step), B[j][k] = the filter slice (8 registers, loaded once);
                 // wave w takes positions 16 w .. 16 w + 15, and the D layout (position 4 (lane >> 4) + r, unit lane & 15) is exactly this
                 // thread's four positions - 8 MFMAs replace 62 LDS reads + 124 FMAs per thread
-                pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    loc = PMFMA(sm[S_CUM + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], loc);
-                float pre[4];
+                for (int hh = 0; hh < NH; ++hh) {                    // (TT = 256: the same for positions 128 + ...)
+                    pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk + loc[m];
-                pf32x4 e4;
+                    for (int ks = 0; ks < 8; ++ks)
+                        loc = PMFMA(sm[S_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], loc);
+                    float pre[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    float e = awk * tanhf_(pre[m]);
-                    e += dpp_mov<0xB1, 0xf>(0.f, e);
-                    e += dpp_mov<0x4E, 0xf>(0.f, e);
-                    e += dpp_mov<0x141, 0xf>(0.f, e);
-                    e += dpp_mov<0x140, 0xf>(0.f, e);
-                    e4[m] = e;
-                }
-                if (ak == 0) {
-                    const long o = ((long)ab * 8 + gi) * PT + 4 * atg;
-                    xpublish(xr, (unsigned)((OFF_EN + slot * XEN + o) * 4), e4, gen);
+                    for (int m = 0; m < 4; ++m) pre[m] = kreg[4 * hh + m] + qk + loc[m];
+                    pf32x4 e4;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        float e = awk * tanhf_(pre[m]);
+                        e += dpp_mov<0xB1, 0xf>(0.f, e);
+                        e += dpp_mov<0x4E, 0xf>(0.f, e);
+                        e += dpp_mov<0x141, 0xf>(0.f, e);
+                        e += dpp_mov<0x140, 0xf>(0.f, e);
+                        e4[m] = e;
+                    }
+                    if (ak == 0) {
+                        const long o = ((long)ab * 8 + gi) * TT + 128 * hh + 4 * atg;
+                        xpublish(xr, (unsigned)((OFF_EN + slot * XEN + o) * 4), e4, gen);
+                    }
                 }
             }
         } else {
@@ -416,31 +430,37 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         __syncthreads();                                             // (h0 is consumed by every wave before the next step stages the context)
         // ================= F: energies of the row, softmax, cumulative alignment, context columns 96 gi ..
         if (arow) {
-            if (tid < 256) {
-                roff[0] = (unsigned)((OFF_EN + slot * XEN + (long)ab * 8 * PT) * 4 + 16 * tid);
+            if (tid < 256 * NH) {                                    // 8 slices x TT energies = 256 NH pieces
+                roff[0] = (unsigned)((OFF_EN + slot * XEN + (long)ab * 8 * TT) * 4 + 16 * tid);
                 issue<1>(xr, roff, rv);
                 { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }
                 *reinterpret_cast<pf32x4*>(sm + S_EN + 4 * tid) = rv[0];
             }
             PABORT_CHECK();
             PSTAMP(14);
-            if (wave == 0) {
-                float e0 = 0.f, e1 = 0.f;
+            if (wave == 0) {        // masked softmax over the row's TT positions: lane holds positions lane + 64 i
+                float ev[2 * NH];
+                float mx = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { e0 += sm[S_EN + i * PT + lane]; e1 += sm[S_EN + i * PT + 64 + lane]; }
-                const bool l0 = lane < alen, l1 = lane + 64 < alen;
-                e0 = l0 ? e0 : -INFINITY; e1 = l1 ? e1 : -INFINITY;
-                const float mx = wave_max(fmaxf(e0, e1));
-                const float p0 = l0 ? __expf(e0 - mx) : 0.f, p1 = l1 ? __expf(e1 - mx) : 0.f;
-                const float inv = 1.f / wave_sum(p0 + p1);
-                const float a0 = p0 * inv, a1 = p1 * inv;
-                sm[S_A + lane] = a0; sm[S_A + 64 + lane] = a1;
-                const float n0 = sm[S_CUM + 15 + lane] + a0, n1 = sm[S_CUM + 15 + 64 + lane] + a1;
-                sm[S_CUM + 15 + lane] = n0; sm[S_CUM + 15 + 64 + lane] = n1;
-                if (gi == 0) {
-                    float* ah = d.align_hist + (sB + ab) * T; float* ch = d.cum_hist + (sB1 + ab) * T;
-                    if (lane < T) { ah[lane] = a0; ch[lane] = n0; }
-                    if (lane + 64 < T) { ah[lane + 64] = a1; ch[lane + 64] = n1; }
+                for (int i = 0; i < 2 * NH; ++i) {
+                    float e = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e += sm[S_EN + k * TT + 64 * i + lane];
+                    ev[i] = (lane + 64 * i < alen) ? e : -INFINITY;
+                    mx = fmaxf(mx, ev[i]);
+                }
+                mx = wave_max(mx);
+                float ps = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2 * NH; ++i) { ev[i] = (lane + 64 * i < alen) ? __expf(ev[i] - mx) : 0.f; ps += ev[i]; }
+                const float inv = 1.f / wave_sum(ps);
+                float* ah = d.align_hist + (sB + ab) * T; float* ch = d.cum_hist + (sB1 + ab) * T;
+#pragma unroll
+                for (int i = 0; i < 2 * NH; ++i) {
+                    const float a = ev[i] * inv, n = sm[S_CUM + 15 + 64 * i + lane] + a;
+                    sm[S_A + 64 * i + lane] = a;
+                    sm[S_CUM + 15 + 64 * i + lane] = n;
+                    if (gi == 0 && lane + 64 * i < T) { ah[lane + 64 * i] = a; ch[lane + 64 * i] = n; }
                 }
             }
             __syncthreads();
@@ -449,6 +469,12 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 float acc = 0.f;
 #pragma unroll 16
                 for (int t = 0; t < 32; ++t) acc += sm[S_A + 32 * th + t] * sm[S_VAL + (32 * th + t) * 96 + c];
+                if (NH > 1) {       // positions 128 + 32 th ..: the values from memory (zero past the row's length there, Modules.py:87-93), L2 hits after the first step
+                    const float* vg = d.values + ((long)ab * T + 128 + 32 * th) * PM + 96 * gi + c;
+                    const int nt = T - (128 + 32 * th) < 32 ? (T - (128 + 32 * th) > 0 ? T - (128 + 32 * th) : 0) : 32;
+#pragma unroll 16
+                    for (int t = 0; t < 32; ++t) acc += sm[S_A + 128 + 32 * th + t] * (t < nt ? vg[(long)t * PM] : 0.f);
+                }
                 sm[S_CO + th * 96 + c] = acc;
             }
             __syncthreads();
@@ -529,22 +555,26 @@ using namespace mstts;
 extern "C" int64_t mstts_persist_fwd_ws_bytes(void) { return XCH_FLOATS * 4; }
 extern "C" int64_t mstts_persist_pack_floats(int32_t which) { return which == 0 ? 256L * 8 * 64 * 64 : which == 1 ? 256L * 8 * 64 * 64 : 8L * 64 * 256; }
 
-/* 1 when the persistent loop can run this shape on the current device: reference widths, at most 32 rows and 128 encoder
- * positions, 31 filter taps, and a device that takes all 256 workgroups at once (one per CU - the occupancy query must admit the
+/* 1 when the persistent loop can run this shape on the current device: reference widths, at most 32 rows and 256 encoder
+ * positions (two instantiations: up to 128 positions everything of the attention stage is on chip, beyond that the value rows from 128 on are
+ * re-read from the L2 every step), 31 filter taps, and a device that takes all 256 workgroups at once (one per CU - the occupancy query must admit the
  * kernel's LDS and registers, and the device must have at least 256 CUs) */
 extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS) {
-    if (!(B >= 1 && B <= PROWS && H == PH && M == PM && A == PA && T >= 1 && T <= PT && KS == PKS)) return 0;
+    if (!(B >= 1 && B <= PROWS && H == PH && M == PM && A == PA && T >= 1 && T <= PTMAX && KS == PKS)) return 0;
     static int memo[PERSIST_MAX_DEVICES];
     return persist_device_memo(memo, [](int dev) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < PWG) return false;
-        const size_t lds = (size_t)S_FLOATS * 4;
-        return hipFuncSetAttribute((const void*)persist_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)persist_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)persist_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)persist_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, true>, PTH, lds) == hipSuccess && per_cu >= 1 &&
-               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_fwd_kernel<false, false>, PTH, lds) == hipSuccess && per_cu >= 1;
+        bool ok = true;
+        int per = 0;
+#define PFW_SETUP(P_, F_, T_)                                                                                                                          \
+        ok = ok && hipFuncSetAttribute((const void*)persist_fwd_kernel<P_, F_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FL<T_>::S_FLOATS * 4)) == hipSuccess && \
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_fwd_kernel<P_, F_, T_>, PTH, (size_t)FL<T_>::S_FLOATS * 4) == hipSuccess && per >= 1;
+        PFW_SETUP(false, false, 128) PFW_SETUP(true, false, 128) PFW_SETUP(false, true, 128) PFW_SETUP(true, true, 128)
+        PFW_SETUP(false, false, 256) PFW_SETUP(true, false, 256) PFW_SETUP(false, true, 256) PFW_SETUP(true, true, 256)
+#undef PFW_SETUP
+        (void)per_cu;
+        return ok;
     });
 }
 
@@ -589,14 +619,19 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
     a.in0 = d->in0; a.in1 = d->in1; a.pj = d->pj; a.c0 = d->c0; a.c1 = d->c1; a.acts0 = d->acts0; a.acts1 = d->acts1;
     a.craw0 = d->craw0; a.craw1 = d->craw1; a.q_hist = d->q_hist; a.align_hist = d->align_hist; a.cum_hist = d->cum_hist;
     a.opk = p->opk; a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
-    const size_t lds = (size_t)S_FLOATS * 4;
-    if (fold) {
-        if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, true>), dim3(PWG), dim3(PTH), lds, hs, a);
-        else hipLaunchKernelGGL((persist_fwd_kernel<false, true>), dim3(PWG), dim3(PTH), lds, hs, a);
-    } else {
-        if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, false>), dim3(PWG), dim3(PTH), lds, hs, a);
-        else hipLaunchKernelGGL((persist_fwd_kernel<false, false>), dim3(PWG), dim3(PTH), lds, hs, a);
+#define PFW_LAUNCH(T_)                                                                                                                  \
+    {                                                                                                                                   \
+        const size_t lds = (size_t)FL<T_>::S_FLOATS * 4;                                                                                \
+        if (fold) {                                                                                                                     \
+            if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, true, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                  \
+            else hipLaunchKernelGGL((persist_fwd_kernel<false, true, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                           \
+        } else {                                                                                                                        \
+            if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, false, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                 \
+            else hipLaunchKernelGGL((persist_fwd_kernel<false, false, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                          \
+        }                                                                                                                               \
     }
+    if (T <= 128) PFW_LAUNCH(128) else PFW_LAUNCH(256)          // (the 128-position instantiation keeps the whole value slice in LDS)
+#undef PFW_LAUNCH
     MSTTS_CHECK_LAUNCH("persist_fwd");
     return MSTTS_OK;
 }

@@ -30,25 +30,28 @@ constexpr long BDG = 8L * 8 * 2 * 4 * 256;       // gate gradients of one cell: 
 constexpr long BPART = 256L * 8 * 32 * 4;        // partial product tiles: [reducer 256][source 8][row 32][4 units]
 constexpr long BPCTX = 32L * 192 * 8 * 4;        // partial d_ctx: [row 32][4-column block 192][source 8][4]
 constexpr long BDM1 = 32L * 8 * PH;              // query-layer data gradient: [owner 256][slice 8][row 32][4 units]
-constexpr long BDA = 32L * 8 * PT;               // partial d_alignment: [row 32][slice 8][128]
+constexpr long BDA = 32L * 8 * PTMAX;            // partial d_alignment: [row 32][slice 8][TT]
 constexpr long BO_DG1 = 0, BO_DG0 = BO_DG1 + PRING * BDG, BO_PM0 = BO_DG0 + PRING * BDG, BO_PH1 = BO_PM0 + PRING * BPART,
                BO_PH0 = BO_PH1 + PRING * BPART, BO_PCTX = BO_PH0 + PRING * BPART, BO_DM1 = BO_PCTX + PRING * BPCTX,
                BO_DA = BO_DM1 + PRING * BDM1, BXCH_FLOATS = BO_DA + PRING * BDA;
-// LDS layout (floats); small arrays first (DS immediate offsets reach 64 KB)
-constexpr int B_RED = 0,                         // [8 waves][4 tiles][64 lanes][4]: product partials; the attention phases use it as scratch
-              B_G = B_RED,                       //   [160 padded positions][16 units] energy gradients of this slice (attention only)
-              B_PC = B_RED + 160 * 16,           //   [192 pieces][4] partial d_ctx as fetched
-              B_DA = B_PC + 192 * 4,             //   [8 slices][128] partial d_alignment as fetched
-              B_PD = B_DA + 8 * PT,              //   [4 column quarters][128] values . d_ctx
-              B_TR = B_RED + 8 * 4 * 256,        // [3][128] transposes between the (unit, row) and (row, 4 units) thread layouts + [512] gate transpose
-              B_GP = B_TR + 3 * 128 + 512,       // [128] this slice's part of G
-              B_A = B_GP + PT, B_CUM = B_A + PT, B_DE = B_CUM + 176, B_DC = B_DE + PT, B_DPJ = B_DC + 96, B_QF = B_DPJ + 96,
+// LDS layout (floats); small arrays first (DS immediate offsets reach 64 KB).  TT = 128 or 256 encoder positions (the kernel's instantiations);
+// the transposed value slice in LDS always covers positions 0 .. 127, with TT = 256 the positions from 128 on are read from memory (L2 hits).
+template <int TT> struct BL {
+    static constexpr int B_RED = 0,                  // [8 waves][4 tiles][64 lanes][4]: product partials; the attention phases use it as scratch
+              B_G = B_RED,                           //   [TT + 32 padded positions][16 units] energy gradients of this slice (attention only)
+              B_PC = B_G + (TT + 32) * 16,           //   [192 pieces][4] partial d_ctx as fetched
+              B_DA = B_PC + 192 * 4,                 //   [8 slices][TT] partial d_alignment as fetched
+              B_PD = B_DA + 8 * TT,                  //   [4 column quarters][TT] values . d_ctx
+              B_SCR_END = B_PD + 4 * TT,
+              B_TR = B_SCR_END > B_RED + 8 * 4 * 256 ? B_SCR_END : B_RED + 8 * 4 * 256,   // [3][128] transposes between the (unit, row) and (row, 4 units) thread layouts + [512] gate transpose
+              B_GP = B_TR + 3 * 128 + 512,           // [TT] this slice's part of G
+              B_A = B_GP + TT, B_CUM = B_A + TT, B_DE = B_CUM + TT + 48, B_DC = B_DE + TT, B_DPJ = B_DC + 96, B_QF = B_DPJ + 96,
               B_DQ = B_QF + 16, B_DQF = B_DQ + 512, B_LK = B_DQF + 16, B_FLAG = B_LK + 32 * 16, B_STAMP = B_FLAG + 4,
-              B_VALT = B_STAMP + 2 * 16,         // [96 columns][128 positions] values slice, transposed
-              B_WQT = B_VALT + 96 * PT,          // [(k4 * 4 + e) * 256 + l][4]: Wq[4 l + e][16 i + 4 k4 ..]
+              B_VALT = B_STAMP + 2 * 16,             // [96 columns][128 positions] values slice, transposed
+              B_WQT = B_VALT + 96 * PT,              // [(k4 * 4 + e) * 256 + l][4]: Wq[4 l + e][16 i + 4 k4 ..]
               B_FLOATS = B_WQT + 16 * 256 * 4;
-static_assert(B_PD + 4 * PT <= B_TR, "attention scratch must fit into the product-partial buffer");
-static_assert(B_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(B_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
 constexpr int NBSTAMP = 16;
 
 struct PersistBwd {
@@ -83,8 +86,13 @@ __device__ __forceinline__ pf32x4 cell_bwd(float dm, float& dhs, float& dcs, flo
     return dg;
 }
 
-template <bool PROF>
+template <bool PROF, int TT>
 __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
+    typedef BL<TT> Y;
+    constexpr int B_RED = Y::B_RED, B_G = Y::B_G, B_PC = Y::B_PC, B_DA = Y::B_DA, B_PD = Y::B_PD, B_TR = Y::B_TR, B_GP = Y::B_GP, B_A = Y::B_A, B_CUM = Y::B_CUM,
+                  B_DE = Y::B_DE, B_DC = Y::B_DC, B_DPJ = Y::B_DPJ, B_QF = Y::B_QF, B_DQ = Y::B_DQ, B_DQF = Y::B_DQF, B_LK = Y::B_LK, B_FLAG = Y::B_FLAG,
+                  B_STAMP = Y::B_STAMP, B_VALT = Y::B_VALT, B_WQT = Y::B_WQT;
+    constexpr int NH = TT / 128;                  // halves of 128 encoder positions
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g0 = blockIdx.x, tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     int g = g0, gi = g & 7, gj = g >> 3;
@@ -121,12 +129,12 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     const bool arow = ab < B;
     const int alen = arow ? (d.lengths ? d.lengths[ab] : T) : 0;
     int ak = tid & 15, atg = tid >> 4;
-    float kreg[4];
+    float kreg[4 * NH];
     float asb = 0.f, awk = 0.f;
     {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int t = 4 * atg + m;
+        for (int m = 0; m < 4 * NH; ++m) {
+            const int t = 128 * (m >> 2) + 4 * atg + (m & 3);
             kreg[m] = (arow && t < T) ? d.keys[((long)ab * T + t) * PA + 16 * gi + ak] : 0.f;
         }
         asb = d.score_b[16 * gi + ak] + d.loc_b[16 * gi + ak];
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             const int c = x >> 7, t = x & 127;
             sm[B_VALT + x] = (arow && t < alen && t < T) ? d.values[((long)ab * T + t) * PM + 96 * gi + c] : 0.f;
         }
-        for (int x = tid; x < 176; x += PTH) sm[B_CUM + x] = 0.f;
-        for (int x = tid; x < PT; x += PTH) { sm[B_GP + x] = 0.f; sm[B_A + x] = 0.f; sm[B_DE + x] = 0.f; }
+        for (int x = tid; x < TT + 48; x += PTH) sm[B_CUM + x] = 0.f;
+        for (int x = tid; x < TT; x += PTH) { sm[B_GP + x] = 0.f; sm[B_A + x] = 0.f; sm[B_DE + x] = 0.f; }
         const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqt) + (long)gi * 16 * 256;
         for (int x = tid; x < 16 * 256; x += PTH) reinterpret_cast<pf32x4*>(sm + B_WQT)[x] = wqs[x];
     }
@@ -155,10 +163,10 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     // in LDS once the cell-1 wait of that step has drained the load queue anyway - they cost HBM latency, not bandwidth
     float rav = 0.f, rcv = 0.f, rqv = 0.f, rdv = 0.f;
     const int abc = arow ? ab : 0;
-#define LOAD_ROWS(ST) do { const long r__ = (long)(ST) * B + abc; const int t__ = tid0 & 127;                                   \
+#define LOAD_ROWS(ST) do { const long r__ = (long)(ST) * B + abc; const int t__ = tid0 & (TT - 1);                                   \
         rav = (d.align_hist + r__ * T)[t__ < T ? t__ : 0]; rcv = (d.cum_hist + r__ * T)[t__ < T ? t__ : 0];                     \
         rqv = (d.q_hist + r__ * PA + 16 * (g0 & 7))[tid0 & 15]; rdv = (d.d_pj + r__ * (PH + PM) + PH + 96 * (g0 & 7))[tid0 < 96 ? tid0 : 0]; } while (0)
-#define STORE_ROWS() do { const int t__ = tid0 & 127;                                                                           \
+#define STORE_ROWS() do { const int t__ = tid0 & (TT - 1);                                                                           \
         sm[B_A + t__] = t__ < T ? rav : 0.f; sm[B_CUM + 15 + t__] = t__ < T ? rcv : 0.f;                                        \
         sm[B_QF + (tid0 & 15)] = rqv; sm[B_DPJ + (tid0 < 96 ? tid0 : 0)] = rdv; } while (0)
     // operands of the cell-1 update backward (saved activations, cell states, keep-masks, the projection's d_m1): HBM-cold, requested ONE STEP
@@ -210,11 +218,13 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             uoff[1] = first ? uoff[0] : (unsigned)((BO_PH0 + nslot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);              \
             issue<2>(xr, uoff, uv); } } while (0)
         // ================= attention backward of row ab, slice gi
-        float fac[4] = {0.f, 0.f, 0.f, 0.f};
+        float fac[4 * NH];
+#pragma unroll
+        for (int m = 0; m < 4 * NH; ++m) fac[m] = 0.f;
         if (arow) {
             // (this step's forward rows are in LDS already: LOAD_ROWS / STORE_ROWS)
-            // zero padding of the energy-gradient window (positions -15 .. -1 and 128 .. 144): the products of the step before wrote here
-            sm[B_G + (tid < 240 ? tid : 143 * 16 + (tid - 240))] = 0.f;
+            // zero padding of the energy-gradient window (positions -15 .. -1 and TT .. TT + 16): the products of the step before wrote here
+            sm[B_G + (tid < 240 ? tid : (15 + TT) * 16 + (tid - 240))] = 0.f;
             pf32x4 pc[1] = {{0.f, 0.f, 0.f, 0.f}};
             unsigned pcoff[1];
             pcoff[0] = (unsigned)((BO_PCTX + nslot * BPCTX + ((long)ab * 192 + 24 * gi) * 32) * 4 + 16 * (tid < 192 ? tid : 0));
@@ -225,15 +235,15 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             {
                 const float qk = sm[B_QF + ak] + asb;
                 // location filter as a Toeplitz product on the matrix core (see persist.hip): A = the cumulative-alignment window, B = the filter slice
-                pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    loc = PMFMA(sm[B_CUM + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], sm[B_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)], loc);
-                float pre[4];
+                for (int hh = 0; hh < NH; ++hh) {
+                    pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < 4; ++m) pre[m] = kreg[m] + qk + loc[m];
+                    for (int ks = 0; ks < 8; ++ks)
+                        loc = PMFMA(sm[B_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], sm[B_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)], loc);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { const float u = tanhf_(pre[m]); fac[m] = awk * (1.f - u * u); }
+                    for (int m = 0; m < 4; ++m) { const float u = tanhf_(kreg[4 * hh + m] + qk + loc[m]); fac[4 * hh + m] = awk * (1.f - u * u); }
+                }
             }
             PSTAMP(0);
             // d_ctx of this slice's 96 columns: projection part + the 8 partial tiles of the next step's cell-0 product
@@ -257,56 +267,83 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             __syncthreads();
             {   // values_i . d_ctx_i: thread (position t, column quarter cq)
                 const int t = tid & 127, cq = tid >> 7;
-                float acc = 0.f;
+                pf32x4 vg[6];
+                if (NH > 1) {       // position 128 + t: this thread's 24 value columns from memory (zero past the row's length there; L2 hits after the first step)
+                    const int tt = 128 + t < T ? 128 + t : 0;
+                    const pf32x4* vp4 = reinterpret_cast<const pf32x4*>(d.values + ((long)ab * T + tt) * PM + 96 * gi + 24 * cq);
+#pragma unroll
+                    for (int c4 = 0; c4 < 6; ++c4) vg[c4] = vp4[c4];
+                }
+                float acc = 0.f, acc2 = 0.f;
 #pragma unroll 2
                 for (int c4 = 0; c4 < 6; ++c4) {
                     const pf32x4 dcv = *reinterpret_cast<const pf32x4*>(sm + B_DC + 24 * cq + 4 * c4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc += sm[B_VALT + (24 * cq + 4 * c4 + e) * PT + t] * dcv[e];
                 }
-                sm[B_PD + cq * PT + t] = acc;
+                sm[B_PD + cq * TT + t] = acc;
+                if (NH > 1) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 6; ++c4) {
+                        const pf32x4 dcv = *reinterpret_cast<const pf32x4*>(sm + B_DC + 24 * cq + 4 * c4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc2 += vg[c4][e] * dcv[e];
+                    }
+                    sm[B_PD + cq * TT + 128 + t] = 128 + t < T ? acc2 : 0.f;
+                }
             }
             __syncthreads();
-            if (tid < 32) {         // + this slice's part of G; the row's d_alignment is the sum of the eight published vectors
-                pf32x4 pd = (*reinterpret_cast<const pf32x4*>(sm + B_PD + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + B_PD + PT + 4 * tid)) +
-                            (*reinterpret_cast<const pf32x4*>(sm + B_PD + 2 * PT + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + B_PD + 3 * PT + 4 * tid));
+            if (tid < 32 * NH) {    // + this slice's part of G; the row's d_alignment is the sum of the eight published vectors
+                pf32x4 pd = (*reinterpret_cast<const pf32x4*>(sm + B_PD + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + B_PD + TT + 4 * tid)) +
+                            (*reinterpret_cast<const pf32x4*>(sm + B_PD + 2 * TT + 4 * tid) + *reinterpret_cast<const pf32x4*>(sm + B_PD + 3 * TT + 4 * tid));
                 pd += *reinterpret_cast<const pf32x4*>(sm + B_GP + 4 * tid);
-                const long o = ((long)ab * 8 + gi) * PT + 4 * tid;
+                const long o = ((long)ab * 8 + gi) * TT + 4 * tid;
                 xpublish(xr, (unsigned)((BO_DA + slot * BDA + o) * 4), pd, gen);
             }
             PSTAMP(2);
         }
         if (arow) {
-            if (tid < 256) {
+            if (tid < 256 * NH) {
                 unsigned off[1]; pf32x4 v[1];
-                off[0] = (unsigned)((BO_DA + slot * BDA + (long)ab * 8 * PT) * 4 + 16 * tid);
+                off[0] = (unsigned)((BO_DA + slot * BDA + (long)ab * 8 * TT) * 4 + 16 * tid);
                 const unsigned g1[1] = {gen};
                 if (!gather<1>(xr, off, v, d.ctrl, g1)) PFAIL();
                 *reinterpret_cast<pf32x4*>(sm + B_DA + 4 * tid) = v[0];
             }
             PABORT_CHECK();
             PSTAMP(3);
-            if (wave == 0) {        // softmax backward: d_e = a (d_a - dot(a, d_a))
-                float da0 = 0.f, da1 = 0.f;
+            if (wave == 0) {        // softmax backward: d_e = a (d_a - dot(a, d_a)); lane holds positions lane + 64 i
+                float da[2 * NH], av[2 * NH];
+                float dp = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { da0 += sm[B_DA + i * PT + lane]; da1 += sm[B_DA + i * PT + 64 + lane]; }
-                const float a0 = sm[B_A + lane], a1 = sm[B_A + 64 + lane];
-                const float dot = wave_sum(a0 * da0 + a1 * da1);
-                const float e0 = a0 * (da0 - dot), e1 = a1 * (da1 - dot);
-                sm[B_DE + lane] = e0; sm[B_DE + 64 + lane] = e1;
-                if (gi == 0) {
-                    float* de = d.de_hist + (sB + ab) * T;
-                    if (lane < T) de[lane] = e0;
-                    if (lane + 64 < T) de[lane + 64] = e1;
+                for (int i = 0; i < 2 * NH; ++i) {
+                    float x = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x += sm[B_DA + k * TT + 64 * i + lane];
+                    da[i] = x; av[i] = sm[B_A + 64 * i + lane];
+                }
+                if (NH == 1) dp = av[0] * da[0] + av[1] * da[1];
+                else {
+#pragma unroll
+                    for (int i = 0; i < 2 * NH; ++i) dp += av[i] * da[i];
+                }
+                const float dot = wave_sum(dp);
+                float* de = d.de_hist + (sB + ab) * T;
+#pragma unroll
+                for (int i = 0; i < 2 * NH; ++i) {
+                    const float e = av[i] * (da[i] - dot);
+                    sm[B_DE + 64 * i + lane] = e;
+                    if (gi == 0 && lane + 64 * i < T) de[lane + 64 * i] = e;
                 }
             }
             __syncthreads();
             {   // energy gradients g[t][k] = d_e[t] fac[t][k]; dq[k] = sum_t g
                 float dqp = 0.f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float gv = sm[B_DE + 4 * atg + m] * fac[m];
-                    sm[B_G + (15 + 4 * atg + m) * 16 + ak] = gv;
+                for (int m = 0; m < 4 * NH; ++m) {
+                    const int t = 128 * (m >> 2) + 4 * atg + (m & 3);
+                    const float gv = sm[B_DE + t] * fac[m];
+                    sm[B_G + (15 + t) * 16 + ak] = gv;
                     dqp += gv;
                 }
                 sm[B_DQ + atg * 16 + ak] = dqp;
@@ -335,15 +372,17 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), out, gen);
             }
             PSTAMP(4);
-            {   // in the shadow of that hand-off: this slice's part of G for the step before: G[t] += sum_j sum_k g[t + 15 - j][k] loc_k[j][k]
+#pragma unroll 1
+            for (int hh = 0; hh < NH; ++hh) {   // in the shadow of that hand-off: this slice's part of G for the step before: G[t] += sum_j sum_k g[t + 15 - j][k] loc_k[j][k]
+                const int p0 = 128 * hh + 4 * atg;
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                float w0 = sm[B_G + (4 * atg) * 16 + ak], w1 = sm[B_G + (4 * atg + 1) * 16 + ak], w2 = sm[B_G + (4 * atg + 2) * 16 + ak],
-                      w3 = sm[B_G + (4 * atg + 3) * 16 + ak];
+                float w0 = sm[B_G + p0 * 16 + ak], w1 = sm[B_G + (p0 + 1) * 16 + ak], w2 = sm[B_G + (p0 + 2) * 16 + ak],
+                      w3 = sm[B_G + (p0 + 3) * 16 + ak];
 #pragma unroll 4
-                for (int x = 0; x < PKS; ++x) {         // x = 30 - j: padded window position 4 atg + m + x
+                for (int x = 0; x < PKS; ++x) {         // x = 30 - j: padded window position p0 + m + x
                     const float lk = sm[B_LK + (PKS - 1 - x) * 16 + ak];
                     acc[0] += w0 * lk; acc[1] += w1 * lk; acc[2] += w2 * lk; acc[3] += w3 * lk;
-                    w0 = w1; w1 = w2; w2 = w3; w3 = sm[B_G + (4 * atg + x + 4) * 16 + ak];
+                    w0 = w1; w1 = w2; w2 = w3; w3 = sm[B_G + (p0 + x + 4) * 16 + ak];
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -356,7 +395,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 }
                 if (ak == 0) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) sm[B_GP + 4 * atg + m] += acc[m];
+                    for (int m = 0; m < 4; ++m) sm[B_GP + p0 + m] += acc[m];
                 }
             }
         } else {
@@ -615,15 +654,20 @@ extern "C" int64_t mstts_persist_bwd_ws_bytes(void) { return BXCH_FLOATS * 4; }
 extern "C" int64_t mstts_persist_bwd_pack_floats(int32_t which) { return which < 2 ? 256L * 8 * 64 * 64 : 8L * 16 * 256 * 4; }
 
 extern "C" int32_t mstts_persist_bwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS) {
-    if (!(B >= 1 && B <= PROWS && H == PH && M == PM && A == PA && T >= 1 && T <= PT && KS == PKS)) return 0;
+    if (!(B >= 1 && B <= PROWS && H == PH && M == PM && A == PA && T >= 1 && T <= PTMAX && KS == PKS)) return 0;
     static int memo[PERSIST_MAX_DEVICES];
     return persist_device_memo(memo, [](int dev) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < PWG) return false;
-        const size_t lds = (size_t)B_FLOATS * 4;
-        return hipFuncSetAttribute((const void*)persist_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)persist_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_bwd_kernel<false>, PTH, lds) == hipSuccess && per_cu >= 1;
+        bool ok = true;
+        int per = 0;
+#define PBW_SETUP(P_, T_)                                                                                                                              \
+        ok = ok && hipFuncSetAttribute((const void*)persist_bwd_kernel<P_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BL<T_>::B_FLOATS * 4)) == hipSuccess && \
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_bwd_kernel<P_, T_>, PTH, (size_t)BL<T_>::B_FLOATS * 4) == hipSuccess && per >= 1;
+        PBW_SETUP(false, 128) PBW_SETUP(true, 128) PBW_SETUP(false, 256) PBW_SETUP(true, 256)
+#undef PBW_SETUP
+        (void)per_cu;
+        return ok;
     });
 }
 
@@ -662,9 +706,15 @@ extern "C" int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_
     a.d_pj = bd->d_pj; a.opk = p->opk; a.B = (int)B; a.S = (int)S; a.T = (int)T;
     a.dg0 = bd->dg0; a.dg1 = bd->dg1; a.dq_hist = bd->dq_hist; a.de_hist = bd->de_hist; a.d_in0 = bd->d_in0;
     a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
-    const size_t lds = (size_t)B_FLOATS * 4;
-    if (p->stamps) hipLaunchKernelGGL(persist_bwd_kernel<true>, dim3(PWG), dim3(PTH), lds, hs, a);
-    else hipLaunchKernelGGL(persist_bwd_kernel<false>, dim3(PWG), dim3(PTH), lds, hs, a);
+    if (a.T <= 128) {       // (the 128-position instantiation; beyond that the positions from 128 on are read from memory)
+        const size_t lds = (size_t)BL<128>::B_FLOATS * 4;
+        if (p->stamps) hipLaunchKernelGGL((persist_bwd_kernel<true, 128>), dim3(PWG), dim3(PTH), lds, hs, a);
+        else hipLaunchKernelGGL((persist_bwd_kernel<false, 128>), dim3(PWG), dim3(PTH), lds, hs, a);
+    } else {
+        const size_t lds = (size_t)BL<256>::B_FLOATS * 4;
+        if (p->stamps) hipLaunchKernelGGL((persist_bwd_kernel<true, 256>), dim3(PWG), dim3(PTH), lds, hs, a);
+        else hipLaunchKernelGGL((persist_bwd_kernel<false, 256>), dim3(PWG), dim3(PTH), lds, hs, a);
+    }
     MSTTS_CHECK_LAUNCH("persist_bwd");
     return MSTTS_OK;
 }

@@ -15,6 +15,7 @@ typedef float pf32x4 __attribute__((ext_vector_type(4)));
 typedef int pi32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PH = 1024, PM = 768, PA = 128, PT = 128, PROWS = 32, PWG = 256, PTH = 512;
+constexpr int PTMAX = 256;                       // encoder positions the persistent decoder kernels admit (instantiations for 128 and 256)
 constexpr int PKS = 31;                          // location filter taps (hp.Attention.Conv.Kernel_Size)
 constexpr int PRING = 4;
 constexpr unsigned PSENT = 0xFFFFFFFFu;

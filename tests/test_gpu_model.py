@@ -449,9 +449,12 @@ REF = dict(emb=512, enc_conv_ch=512, enc_lstm=256, spk=256, prenet=256, dec_lstm
 
 @pytest.mark.parametrize("B,Te,L,ragged,kw", [(3, 9, 6, False, {}), (4, 21, 13, True, {}), (5, 18, 9, True, MID), (16, 12, 7, True, MID),
                                                 (1, 2, 1, False, {}), (2, 140, 3, True, MID),       # smallest batch/lengths; more tokens than one attention pass
-                                                (32, 128, 4, False, REF), (8, 40, 12, True, REF)])  # fp32 at the reference widths (config-2 geometry / ragged)
+                                                (32, 128, 4, False, REF), (8, 40, 12, True, REF),   # fp32 at the reference widths (config-2 geometry / ragged)
+                                                (6, 160, 10, True, REF)])                           # ... and a batch padded to 160 tokens (256-position persistent kernels)
 def test_train_step_parity(dev, B, Te, L, ragged, kw):
     eng, w, od, values, batch, sc, grads, out, new_p = _engine_vs_oracle(dev, B, Te, L, ragged, seed=11, **kw)
+    if kw is REF and eng.persist:     # the reference-width cases run the persistent launches (<= 128 tokens and the 256-position instantiation)
+        assert w.persist and w.persist_bwd and eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0 and eng.non_persistent_plans == 0
     tol = 1e-3    # north_star: within 1e-3 relative on fp32 mels
     assert rel_err(t2n(w.linear), t2n(out["Linear"])) < tol
     assert rel_err(t2n(w.mel_out), t2n(out["Mel"])) < tol

@@ -38,7 +38,8 @@ def _snapshot(w, eng=None):
     return out
 
 
-@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (5, 128, 3, True), (1, 7, 2, False), (32, 100, 60, True)])
+@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (5, 128, 3, True), (1, 7, 2, False), (32, 100, 60, True),
+                                                (32, 129, 5, True), (8, 160, 12, True), (32, 200, 9, False), (32, 256, 6, True), (3, 131, 40, True)])       # > 128 tokens: the 256-position instantiation (Feeder.py:148-152 pads a batch to its longest text)
 def test_persistent_equals_launch_per_step(dev, B, Te, L, ragged):
     eng, od = _engine(dev)
     batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=ragged), dev)
@@ -238,7 +239,8 @@ def _bwd_snapshot(eng, w):
     return out
 
 
-@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (5, 128, 3, True), (1, 7, 2, False), (32, 100, 60, True)])
+@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (5, 128, 3, True), (1, 7, 2, False), (32, 100, 60, True),
+                                                (32, 129, 5, True), (8, 160, 12, True), (32, 200, 9, False), (32, 256, 6, True), (3, 131, 40, True)])       # > 128 tokens: the 256-position instantiation (Feeder.py:148-152 pads a batch to its longest text)
 def test_persistent_bptt_equals_launch_per_step(dev, B, Te, L, ragged):
     """mstts_decoder_train_bwd_persistent (the whole BPTT in one launch) against mstts_decoder_train_bwd on the same forward state:
     gate gradients, query / energy gradients, the context gradient and every parameter gradient of the step."""

@@ -624,6 +624,9 @@ typedef struct {
                                      When given, the launch forms the prenet rows' share of the cell-0 gates itself (8 more k-steps per wave,
                                      kernel rows from the wx0 argument of mstts_persist_pack) and ignores mstts_decoder_train_desc.xw0: the
                                      caller skips that [S B, 256] x [256, 4H] product and its 16 KB-per-row tensor.  NULL: xw0 is read. */
+    int32_t pipeline;                /* forward launch only: 1 = the software-pipelined schedule (rows 0..15 and 16..31 as two chains half a step apart, each
+                                      * hiding the other's hand-offs; same arithmetic, bit-identical results) where it exists (folded prenet product, <= 128
+                                      * encoder positions); 0 = every stage on all 32 rows at once */
 } mstts_persist_desc;
 int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
 int64_t mstts_persist_fwd_ws_bytes(void);

@@ -44,7 +44,7 @@ template <int TT> struct FL {
     static constexpr int S_STG = 0, S_RED = S_STG + 128 * LA, S_TR = S_RED + 4 * 2 * 256, S_M1 = S_TR + 2 * 128,
                          S_EN = TT > 128 ? S_STG : S_M1 + PH, S_CUM = TT > 128 ? S_M1 + PH : S_EN + 8 * PT,
                          S_A = S_CUM + TT + 48, S_Q = S_A + TT, S_QF = S_Q + 512, S_CO = S_QF + 16, S_LK = S_CO + 4 * 96,
-                         S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_FLOATS = S_WQ + 8 * 512 * 4;
+                         S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_BV = S_WQ + 8 * 512 * 4, S_FLOATS = S_BV + 32;      // (S_BV: the owner's 2 x 16 bias values, pipelined kernel)
     static_assert(8 * TT <= 128 * LA && S_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 constexpr int NSTAMP = 16;
@@ -517,6 +517,8 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 #undef SUM_PARTIALS
 }
 
+#include "persist_pipe.inc"
+
 // ---- packers: the kernels in the order the lanes keep them (see the header comment)
 // (unit_of_kstep: persist_fwd_parts.h)
 
@@ -573,6 +575,9 @@ extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, 
         PFW_SETUP(false, false, 128) PFW_SETUP(true, false, 128) PFW_SETUP(false, true, 128) PFW_SETUP(true, true, 128)
         PFW_SETUP(false, false, 256) PFW_SETUP(true, false, 256) PFW_SETUP(false, true, 256) PFW_SETUP(true, true, 256)
 #undef PFW_SETUP
+        ok = ok && hipFuncSetAttribute((const void*)persist_fwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FL<128>::S_FLOATS * 4)) == hipSuccess &&
+             hipFuncSetAttribute((const void*)persist_fwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FL<128>::S_FLOATS * 4)) == hipSuccess &&
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_fwd_pipe_kernel<false>, PTH, (size_t)FL<128>::S_FLOATS * 4) == hipSuccess && per >= 1;
         (void)per_cu;
         return ok;
     });
@@ -630,7 +635,11 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
             else hipLaunchKernelGGL((persist_fwd_kernel<false, false, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                          \
         }                                                                                                                               \
     }
-    if (T <= 128) PFW_LAUNCH(128) else PFW_LAUNCH(256)          // (the 128-position instantiation keeps the whole value slice in LDS)
+    if (p->pipeline && fold && T <= 128) {      // the two half-batch chains half a step apart (persist_pipe.inc); bit-identical results
+        const size_t lds = (size_t)FL<128>::S_FLOATS * 4;
+        if (p->stamps) hipLaunchKernelGGL((persist_fwd_pipe_kernel<true>), dim3(PWG), dim3(PTH), lds, hs, a);
+        else hipLaunchKernelGGL((persist_fwd_pipe_kernel<false>), dim3(PWG), dim3(PTH), lds, hs, a);
+    } else if (T <= 128) PFW_LAUNCH(128) else PFW_LAUNCH(256)   // (the 128-position instantiation keeps the whole value slice in LDS)
 #undef PFW_LAUNCH
     MSTTS_CHECK_LAUNCH("persist_fwd");
     return MSTTS_OK;

@@ -529,6 +529,7 @@ class TrainEngine:
             pd.selftest_fail_step = int(self.persist_selftest)
             pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             pd.pre, pd.b0 = (ptr(x), ptr(b0, ob0)) if w.fold_prenet else (None, None)
+            pd.pipeline = int(os.environ.get("MSTTS_PERSIST_PIPE", "1") != "0")
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
             ev.record()

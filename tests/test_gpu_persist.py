@@ -66,6 +66,34 @@ def test_persistent_equals_launch_per_step(dev, B, Te, L, ragged):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (20, 100, 33, True), (1, 7, 2, False), (17, 64, 1, False)])
+def test_pipelined_schedule_is_bit_identical(dev, B, Te, L, ragged, monkeypatch):
+    """persist_fwd_pipe_kernel (rows 0..15 and 16..31 as two chains half a step apart) visits the same work in another order: every
+    history, packed operand block and output equals persist_fwd_kernel's TO THE BIT, for batches that fill both chains, one chain, part of a
+    chain, and for one-step sequences (chain 1 finishes in the extra iteration)."""
+    import ctypes as C
+    from multi_speaker_tts_amd import lib
+    eng, od = _engine(dev)
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=ragged), dev)
+    w = eng.plan(B, Te, L)
+    monkeypatch.setenv("MSTTS_PERSIST_PIPE", "1")
+    eng.forward(batch, w, seed=77)
+    torch.cuda.synchronize()
+    assert w.pdesc.pipeline == 1 and eng.persist_fallbacks == 0
+    keys = HIST + (("opk",) if w.opk_valid else ())
+    a = {k: t2n(getattr(w, k)).copy() for k in keys}
+    for want in (0, 1):
+        for k in keys:
+            getattr(w, k).zero_()
+        w.pdesc.pipeline = want
+        lib.call("mstts_decoder_train_fwd_persistent", C.byref(w.dec), C.byref(w.pdesc))
+        torch.cuda.synchronize()
+        st = w.pctrl.cpu().numpy()
+        assert st[1] == 0 and st[2] == 256, st[:3]
+        for k in keys:
+            assert np.array_equal(a[k], t2n(getattr(w, k))), (k, want)
+
+
 def test_persistent_is_deterministic(dev):
     """The launch itself, twice on identical inputs (the decoder descriptors of the plan, called directly - upstream of the loop the
     forward pass contains reductions with atomics): bit-identical histories, i.e. no summation order depends on arrival order."""

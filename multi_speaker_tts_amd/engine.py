@@ -529,7 +529,9 @@ class TrainEngine:
             pd.selftest_fail_step = int(self.persist_selftest)
             pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             pd.pre, pd.b0 = (ptr(x), ptr(b0, ob0)) if w.fold_prenet else (None, None)
-            pd.pipeline = int(os.environ.get("MSTTS_PERSIST_PIPE", "1") != "0")
+            # (the two-chain schedule of persist_pipe.inc: measured SLOWER, 24.6 vs 17.0 us per frame - a chain's step is bound by its six
+            #  hand-off flights, not by the workgroups' work, so a second chain in the gaps only adds its own instructions; opt-in for A/B)
+            pd.pipeline = int(os.environ.get("MSTTS_PERSIST_PIPE", "0") != "0")
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
             ev.record()

@@ -79,7 +79,7 @@ def test_pipelined_schedule_is_bit_identical(dev, B, Te, L, ragged, monkeypatch)
     monkeypatch.setenv("MSTTS_PERSIST_PIPE", "1")
     eng.forward(batch, w, seed=77)
     torch.cuda.synchronize()
-    assert w.pdesc.pipeline == 1 and eng.persist_fallbacks == 0
+    assert w.pdesc.pipeline == 1 and eng.persist_fallbacks == 0 and w.fold_prenet
     keys = HIST + (("opk",) if w.opk_valid else ())
     a = {k: t2n(getattr(w, k)).copy() for k in keys}
     for want in (0, 1):

@@ -8,17 +8,23 @@ namespace mstts {
 constexpr int LC = 28, LA = 36;                  // padded row strides of the staged activation slices (conflict-free b128 reads)
 
 // acc[t] += W[k-steps 4 K4A .. 4 K4B) . X[t], X read from the staged LDS slice (row stride LD); the wave's registers w[WOFF + ks]
-template <int K4A, int K4B, int LD, int WOFF, int NW>
+// NT = 1: row tile 0 only (a batch of at most 16 rows: the second tile's rows do not exist)
+template <int K4A, int K4B, int LD, int WOFF, int NW, int NT = 2>
 __device__ __forceinline__ void mfma_part(const float (&w)[NW], const float* sx, int lane, pf32x4 (&acc)[2]) {
     const int row0 = ((lane >> 4) * 2) * 16 + (lane & 15);          // rho of row tile 0; tile 1 is 16 rows further
 #pragma unroll
     for (int k4 = K4A; k4 < K4B; ++k4) {
         const pf32x4 x0 = *reinterpret_cast<const pf32x4*>(sx + row0 * LD + 4 * k4);
-        const pf32x4 x1 = *reinterpret_cast<const pf32x4*>(sx + (row0 + 16) * LD + 4 * k4);
+        if (NT == 2) {
+            const pf32x4 x1 = *reinterpret_cast<const pf32x4*>(sx + (row0 + 16) * LD + 4 * k4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0] = PMFMA(w[WOFF + 4 * k4 + e], x0[e], acc[0]);
-            acc[1] = PMFMA(w[WOFF + 4 * k4 + e], x1[e], acc[1]);
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = PMFMA(w[WOFF + 4 * k4 + e], x0[e], acc[0]);
+                acc[1] = PMFMA(w[WOFF + 4 * k4 + e], x1[e], acc[1]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0] = PMFMA(w[WOFF + 4 * k4 + e], x0[e], acc[0]);
         }
     }
 }

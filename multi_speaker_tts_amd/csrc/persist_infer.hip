@@ -31,7 +31,7 @@
 namespace mstts {
 
 // ring sizes in floats per slot.  Near rings (an XCD's slice group may keep them in its L2) first.
-constexpr long IXCTX = 8L * 128 * 24, IXACT = 8L * 128 * 32, IXPRE = 8L * 128 * 8, IXPART = 256L * 8 * 2 * 256, IXQP = 32L * 8 * 512, IXEN = 32L * 8 * PT,
+constexpr long IXCTX = 8L * 128 * 24, IXACT = 8L * 128 * 32, IXPRE = 8L * 128 * 8, IXPART = 256L * 8 * 2 * 256, IXQP = 32L * 8 * 512, IXEN = 32L * 8 * PTMAX,
                IXL1 = 32L * 256;
 constexpr long IOFF_CTX = 0, IOFF_M0 = IOFF_CTX + PRING * IXCTX, IOFF_H0 = IOFF_M0 + PRING * IXACT, IOFF_H1 = IOFF_H0 + PRING * IXACT,
                IOFF_MQ = IOFF_H1 + PRING * IXACT, IOFF_PRE = IOFF_MQ + PRING * IXACT, IOFF_NEAR_END = IOFF_PRE + PRING * IXPRE,
@@ -39,11 +39,15 @@ constexpr long IOFF_CTX = 0, IOFF_M0 = IOFF_CTX + PRING * IXCTX, IOFF_H0 = IOFF_
                IOFF_P1 = IOFF_P0 + PRING * IXPART, IXCH_FLOATS = IOFF_P1 + PRING * IXPART;
 constexpr int INP = 84;                          // projection outputs padded to a multiple of 4 (n_mel + 1 = 81)
 constexpr int IPC = 12;                          // projection outputs per attention slice (8 x 12 = 96 >= 84)
-// LDS layout (floats); small hot arrays first (DS immediate offsets reach 64 KB)
-constexpr int I_STG = 0, I_RED = I_STG + 128 * LA, I_TR = I_RED + 4 * 2 * 256, I_QP = I_TR + 2 * 128, I_QS = I_QP + 512, I_EN = I_QS + 64,
-              I_CUM = I_EN + 8 * PT, I_A = I_CUM + 176, I_CO = I_A + PT, I_CO2 = I_CO + 4 * 96, I_L1 = I_CO2 + 4 * 32, I_PR = I_L1 + 256,
+// LDS layout (floats); small hot arrays first (DS immediate offsets reach 64 KB).  TT = 128 or 256 encoder positions: the value / projected-value /
+// prenet-1 slices in LDS always cover positions 0 .. 127; with TT = 256 the rows from 128 on are read from memory every step (L2 hits)
+template <int TT> struct IL {
+    static constexpr int I_STG = 0, I_RED = I_STG + 128 * LA, I_TR = I_RED + 4 * 2 * 256, I_QP = I_TR + 2 * 128, I_QS = I_QP + 512, I_EN = I_QS + 64,
+              I_CUM = I_EN + 8 * TT, I_A = I_CUM + TT + 48, I_CO = I_A + TT, I_CO2 = I_CO + 4 * 96, I_L1 = I_CO2 + 4 * 32, I_PR = I_L1 + 256,
               I_FR = I_PR + 8 * 32, I_BS = I_FR + 64, I_LK = I_BS + 80, I_FLAG = I_LK + 32 * 16, I_STAMP = I_FLAG + 8, I_VAL = I_STAMP + 2 * 24,
               I_VP = I_VAL + PT * 96, I_U = I_VP + PT * IPC, I_W2 = I_U + PT * 32, I_FLOATS = I_W2 + 256 * 32;
+    static_assert(I_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
 constexpr int INSTAMP = 24;
 
 struct PersistInfer {
@@ -66,8 +70,15 @@ struct PersistInfer {
     int fail_step; int near_xcd;
 };
 
-template <bool PROF>
+// NT = row tiles of 16 in the batch: a batch of at most 16 rows (BASELINE configs[3]) runs every product, partial-sum exchange and stage-Q
+// product on ONE tile - half the matrix-core work and half the bytes of the two partial-sum exchanges, the largest transfers of a step
+template <bool PROF, int NT, int TT>
 __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
+    typedef IL<TT> Y;
+    constexpr int I_STG = Y::I_STG, I_RED = Y::I_RED, I_TR = Y::I_TR, I_QP = Y::I_QP, I_QS = Y::I_QS, I_EN = Y::I_EN, I_CUM = Y::I_CUM, I_A = Y::I_A, I_CO = Y::I_CO,
+                  I_CO2 = Y::I_CO2, I_L1 = Y::I_L1, I_PR = Y::I_PR, I_FR = Y::I_FR, I_BS = Y::I_BS, I_LK = Y::I_LK, I_FLAG = Y::I_FLAG, I_STAMP = Y::I_STAMP,
+                  I_VAL = Y::I_VAL, I_VP = Y::I_VP, I_U = Y::I_U, I_W2 = Y::I_W2;
+    constexpr int NH = TT / 128;                  // halves of 128 encoder positions
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g0 = blockIdx.x, tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     int g = g0, gi = g & 7, gj = g >> 3;
@@ -111,12 +122,12 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
     const bool arow = ab < B;
     const int alen = arow ? (d.lengths ? d.lengths[ab] : T) : 0;
     int ak = tid & 15, atg = tid >> 4;
-    float kreg[4];
+    float kreg[4 * NH];
     float asb = 0.f, awk = 0.f;
     {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int t = 4 * atg + m;
+        for (int m = 0; m < 4 * NH; ++m) {
+            const int t = 128 * (m >> 2) + 4 * atg + (m & 3);
             kreg[m] = (arow && t < T) ? d.keys[((long)ab * T + t) * PA + 16 * gi + ak] : 0.f;
         }
         asb = d.score_b[16 * gi + ak] + d.loc_b[16 * gi + ak];
@@ -135,7 +146,8 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
             sm[I_U + x] = (arow && t < alen && t < T) ? d.u[((long)ab * T + t) * 256 + 32 * gi + c] : 0.f;
         }
         for (int x = tid; x < 256 * 32; x += PTH) sm[I_W2 + x] = d.w2[(long)(x >> 5) * 256 + 32 * gi + (x & 31)];
-        for (int x = tid; x < 176; x += PTH) sm[I_CUM + x] = 0.f;
+        for (int x = tid; x < TT + 48; x += PTH) sm[I_CUM + x] = 0.f;
+        for (int x = tid; x < 4 * 2 * 256; x += PTH) sm[I_RED + x] = 0.f;      // (NT = 1: the tile-1 gate sums are never written; zeros keep those rows' states finite)
         // bias slices of this attention slice: folded prenet-1 bias (32), prenet-2 bias (32), projection bias (12)
         if (tid < 32) { sm[I_BS + tid] = d.bf[32 * gi + tid]; sm[I_BS + 32 + tid] = d.b2[32 * gi + tid]; }
         if (tid < 16) sm[I_BS + 64 + tid] = (tid < IPC && IPC * gi + tid < INP) ? d.bp[IPC * gi + tid] : 0.f;
@@ -161,15 +173,16 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
 #define PABORT_CHECK() do { __syncthreads(); if (sflag[0]) return; } while (0)
 #define PFAIL() do { sflag[0] = 1; unsigned z__ = 0u; __hip_atomic_compare_exchange_strong(d.ctrl + 1, &z__, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #define PUBLISH_PARTIAL(OFFP, ACC)                                                                                              \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                             \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                             \
         const long piece = ((long)(gj * 8 + wave) * 8 + gi) * 2 + t;                                                            \
         xpublish(xr, (unsigned)(((OFFP) + slot * IXPART + piece * 256) * 4 + 16 * lane), ACC[t], gen);                          \
         ACC[t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                                                                                  \
     }
+    // (NT = 1: the tile-1 pieces do not exist - both requests of a source point at its tile-0 piece, the tile-1 sums stay at their initial zero)
 #define ISSUE_PARTIALS(OFFP)                                                                                                    \
     if (wave < 4) {                                                                                                             \
         _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                           \
-            poff[m] = (unsigned)(((OFFP) + slot * IXPART + (((long)g * 8 + 2 * wave + (m >> 1)) * 2 + (m & 1)) * 256) * 4 + 16 * lane); \
+            poff[m] = (unsigned)(((OFFP) + slot * IXPART + (((long)g * 8 + 2 * wave + (m >> 1)) * 2 + (NT == 2 ? (m & 1) : 0)) * 256) * 4 + 16 * lane); \
         issue<4>(xr, poff, pv);                                                                                                 \
     }
 #define COMPLETE_PARTIALS()                                                                                                     \
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
         const unsigned gens__[4] = {gen, gen, gen, gen};                                                                        \
         if (!complete<4>(xr, poff, pv, d.ctrl, gens__)) PFAIL();                                                                \
         *reinterpret_cast<pf32x4*>(sm + I_RED + ((wave * 2 + 0) * 64 + lane) * 4) = pv[0] + pv[2];                              \
-        *reinterpret_cast<pf32x4*>(sm + I_RED + ((wave * 2 + 1) * 64 + lane) * 4) = pv[1] + pv[3];                              \
+        if (NT == 2) *reinterpret_cast<pf32x4*>(sm + I_RED + ((wave * 2 + 1) * 64 + lane) * 4) = pv[1] + pv[3];                 \
     }
 #define SUM_PARTIALS()                                                                                                          \
     ((*reinterpret_cast<const pf32x4*>(sm + I_RED + ((0 * 2 + et) * 64 + lane) * 4) + *reinterpret_cast<const pf32x4*>(sm + I_RED + ((1 * 2 + et) * 64 + lane) * 4)) + \
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
             if (!slice_complete<6, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
             PABORT_CHECK();
             PSTAMP(1);
-            mfma_part<0, 6, LA, 0, 64>(w0, stg, lane, acc0);
+            mfma_part<0, 6, LA, 0, 64, NT>(w0, stg, lane, acc0);
             PSTAMP(2);
             if (tid < 256) {
                 roff[0] = (unsigned)((IOFF_PRE + pslot * IXPRE + gi * 1024L) * 4 + 16 * tid);
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
             if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
             PABORT_CHECK();
         }
-        mfma_part<6, 8, LA, 0, 64>(w0, stg, lane, acc0);
+        mfma_part<6, 8, LA, 0, 64, NT>(w0, stg, lane, acc0);
         PUBLISH_PARTIAL(IOFF_P0, acc0)
         PSTAMP(4);
         // in the shadow of the partial-gates hand-off: h1_{s-1} . W1[h rows]
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
             __syncthreads();                                         // the context / prenet rows are consumed by every wave
             if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
             PABORT_CHECK();
-            mfma_part<0, 8, LA, 32, 64>(w1, stg, lane, acc1);
+            mfma_part<0, 8, LA, 32, 64, NT>(w1, stg, lane, acc1);
         }
         PSTAMP(5);
         // ================= B: sum of the eight partials, cell-0 update
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
         PABORT_CHECK();
         PSTAMP(8);
         slice_issue<8>(xr, IOFF_H0 + slot * IXACT + gi * 4096L, tid, soff, sv);     // h0_s left its producers together with m0_s: it arrives under the product
-        mfma_part<0, 8, LA, 0, 64>(w1, stg, lane, acc1);
+        mfma_part<0, 8, LA, 0, 64, NT>(w1, stg, lane, acc1);
         PUBLISH_PARTIAL(IOFF_P1, acc1)
         PSTAMP(9);
         // in the shadow of the partial-gates hand-off: h0_s staged, the whole of h0_s . W0[h rows] for step s + 1 (the staging buffer has to
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
         __syncthreads();                                             // m0 is consumed by every wave
         if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
         PABORT_CHECK();
-        mfma_part<0, 8, LA, 32, 64>(w0, stg, lane, acc0);
+        mfma_part<0, 8, LA, 32, 64, NT>(w0, stg, lane, acc0);
         PSTAMP(10);
         // ================= D: sum of the eight partials, cell-1 update
         ISSUE_PARTIALS(IOFF_P1)
@@ -336,15 +349,17 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
         {
             pf32x4 qa = {0.f, 0.f, 0.f, 0.f};
             const int row = ((lane >> 4) * 2 + (wave & 1)) * 16 + (lane & 15), kq = wave >> 1;
+            if (NT == 2 || (wave & 1) == 0) {
 #pragma unroll
-            for (int k4 = 0; k4 < 2; ++k4) {
-                const pf32x4 x = *reinterpret_cast<const pf32x4*>(stg + row * LA + 4 * (2 * kq + k4));
+                for (int k4 = 0; k4 < 2; ++k4) {
+                    const pf32x4 x = *reinterpret_cast<const pf32x4*>(stg + row * LA + 4 * (2 * kq + k4));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qa = PMFMA(wq[4 * k4 + e], x[e], qa);
+                    for (int e = 0; e < 4; ++e) qa = PMFMA(wq[4 * k4 + e], x[e], qa);
+                }
             }
             *reinterpret_cast<pf32x4*>(sm + I_RED + (wave * 64 + lane) * 4) = qa;
             __syncthreads();
-            if (tid < 128) {        // (row tile t, lane l): columns 4 (l >> 4) .. + 3 of row 16 t + (l & 15), summed over the four k-quarters
+            if (tid < 64 * NT) {        // (row tile t, lane l): columns 4 (l >> 4) .. + 3 of row 16 t + (l & 15), summed over the four k-quarters
                 const int t = tid >> 6, l = tid & 63;
                 const pf32x4 v = (*reinterpret_cast<const pf32x4*>(sm + I_RED + ((0 * 2 + t) * 64 + l) * 4) + *reinterpret_cast<const pf32x4*>(sm + I_RED + ((1 * 2 + t) * 64 + l) * 4)) +
                                  (*reinterpret_cast<const pf32x4*>(sm + I_RED + ((2 * 2 + t) * 64 + l) * 4) + *reinterpret_cast<const pf32x4*>(sm + I_RED + ((3 * 2 + t) * 64 + l) * 4));
@@ -374,23 +389,26 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
             __syncthreads();
             {
                 const float qk = sm[I_QS + (ak >> 2) * 16 + (ak & 3)] + asb;
-                pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    loc = PMFMA(sm[I_CUM + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], loc);
-                pf32x4 e4;
+                for (int hh = 0; hh < NH; ++hh) {
+                    pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    float e = awk * tanhf_(kreg[m] + qk + loc[m]);
-                    e += dpp_mov<0xB1, 0xf>(0.f, e);
-                    e += dpp_mov<0x4E, 0xf>(0.f, e);
-                    e += dpp_mov<0x141, 0xf>(0.f, e);
-                    e += dpp_mov<0x140, 0xf>(0.f, e);
-                    e4[m] = e;
-                }
-                if (ak == 0) {
-                    const long o = ((long)ab * 8 + gi) * PT + 4 * atg;
-                    xpublish(xr, (unsigned)((IOFF_EN + slot * IXEN + o) * 4), e4, gen);
+                    for (int ks = 0; ks < 8; ++ks)
+                        loc = PMFMA(sm[I_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], loc);
+                    pf32x4 e4;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        float e = awk * tanhf_(kreg[4 * hh + m] + qk + loc[m]);
+                        e += dpp_mov<0xB1, 0xf>(0.f, e);
+                        e += dpp_mov<0x4E, 0xf>(0.f, e);
+                        e += dpp_mov<0x141, 0xf>(0.f, e);
+                        e += dpp_mov<0x140, 0xf>(0.f, e);
+                        e4[m] = e;
+                    }
+                    if (ak == 0) {
+                        const long o = ((long)ab * 8 + gi) * TT + 128 * hh + 4 * atg;
+                        xpublish(xr, (unsigned)((IOFF_EN + slot * IXEN + o) * 4), e4, gen);
+                    }
                 }
             }
         } else {
@@ -400,30 +418,37 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
         __syncthreads();
         // ================= F: energies of the row, softmax, cumulative alignment; context slice, prenet-1 slice, frame outputs
         if (arow) {
-            if (tid < 256) {
-                roff[0] = (unsigned)((IOFF_EN + slot * IXEN + (long)ab * 8 * PT) * 4 + 16 * tid);
+            if (tid < 256 * NH) {
+                roff[0] = (unsigned)((IOFF_EN + slot * IXEN + (long)ab * 8 * TT) * 4 + 16 * tid);
                 issue<1>(xr, roff, rv);
                 { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }
                 *reinterpret_cast<pf32x4*>(sm + I_EN + 4 * tid) = rv[0];
             }
             PABORT_CHECK();
             PSTAMP(17);
-            if (wave == 0) {
-                float e0 = 0.f, e1 = 0.f;
+            if (wave == 0) {        // masked softmax over the row's TT positions: lane holds positions lane + 64 i
+                float ev[2 * NH];
+                float mx = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { e0 += sm[I_EN + i * PT + lane]; e1 += sm[I_EN + i * PT + 64 + lane]; }
-                const bool l0 = lane < alen, l1 = lane + 64 < alen;
-                e0 = l0 ? e0 : -INFINITY; e1 = l1 ? e1 : -INFINITY;
-                const float mx = wave_max(fmaxf(e0, e1));
-                const float p0 = l0 ? __expf(e0 - mx) : 0.f, p1 = l1 ? __expf(e1 - mx) : 0.f;
-                const float inv = 1.f / wave_sum(p0 + p1);
-                const float a0 = p0 * inv, a1 = p1 * inv;
-                sm[I_A + lane] = a0; sm[I_A + 64 + lane] = a1;
-                sm[I_CUM + 15 + lane] += a0; sm[I_CUM + 15 + 64 + lane] += a1;
-                if (gi == 0) {
-                    float* ah = d.align_hist + ((long)s * B + ab) * T;
-                    if (lane < T) ah[lane] = a0;
-                    if (lane + 64 < T) ah[lane + 64] = a1;
+                for (int i = 0; i < 2 * NH; ++i) {
+                    float e = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e += sm[I_EN + k * TT + 64 * i + lane];
+                    ev[i] = (lane + 64 * i < alen) ? e : -INFINITY;
+                    mx = fmaxf(mx, ev[i]);
+                }
+                mx = wave_max(mx);
+                float ps = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2 * NH; ++i) { ev[i] = (lane + 64 * i < alen) ? __expf(ev[i] - mx) : 0.f; ps += ev[i]; }
+                const float inv = 1.f / wave_sum(ps);
+                float* ah = d.align_hist + ((long)s * B + ab) * T;
+#pragma unroll
+                for (int i = 0; i < 2 * NH; ++i) {
+                    const float a = ev[i] * inv;
+                    sm[I_A + 64 * i + lane] = a;
+                    sm[I_CUM + 15 + 64 * i + lane] += a;
+                    if (gi == 0 && lane + 64 * i < T) ah[lane + 64 * i] = a;
                 }
             }
             __syncthreads();
@@ -432,12 +457,24 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
                 float acc = 0.f;
 #pragma unroll 16
                 for (int t = 0; t < 32; ++t) acc += sm[I_A + 32 * th + t] * sm[I_VAL + (32 * th + t) * 96 + c];
+                if (NH > 1) {       // positions 128 + 32 th ..: from memory (zero past the row's length there)
+                    const float* vg = d.values + ((long)ab * T + 128 + 32 * th) * PM + 96 * gi + c;
+                    const int nt = T - (128 + 32 * th) < 32 ? (T - (128 + 32 * th) > 0 ? T - (128 + 32 * th) : 0) : 32;
+#pragma unroll 16
+                    for (int t = 0; t < 32; ++t) acc += sm[I_A + 128 + 32 * th + t] * (t < nt ? vg[(long)t * PM] : 0.f);
+                }
                 sm[I_CO + th * 96 + c] = acc;
             } else {                // the alignment's share of the prenet's first layer: 32 units x 4 position quarters
                 const int x = tid - 384, c = x & 31, th = x >> 5;
                 float acc = 0.f;
 #pragma unroll 16
                 for (int t = 0; t < 32; ++t) acc += sm[I_A + 32 * th + t] * sm[I_U + (32 * th + t) * 32 + c];
+                if (NH > 1) {
+                    const float* ug = d.u + ((long)ab * T + 128 + 32 * th) * 256 + 32 * gi + c;
+                    const int nt = T - (128 + 32 * th) < 32 ? (T - (128 + 32 * th) > 0 ? T - (128 + 32 * th) : 0) : 32;
+#pragma unroll 16
+                    for (int t = 0; t < 32; ++t) acc += sm[I_A + 128 + 32 * th + t] * (t < nt ? ug[(long)t * 256] : 0.f);
+                }
                 sm[I_CO2 + th * 32 + c] = acc;
             }
             __syncthreads();
@@ -464,6 +501,12 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
                 float acc = 0.f;
 #pragma unroll 8
                 for (int t = 0; t < 32; ++t) acc += sm[I_A + 32 * th + t] * sm[I_VP + (32 * th + t) * IPC + o];
+                if (NH > 1 && IPC * gi + o < INP) {
+                    const float* pg = d.vp + ((long)ab * T + 128 + 32 * th) * INP + IPC * gi + o;
+                    const int nt = T - (128 + 32 * th) < 32 ? (T - (128 + 32 * th) > 0 ? T - (128 + 32 * th) : 0) : 32;
+#pragma unroll 8
+                    for (int t = 0; t < 32; ++t) acc += sm[I_A + 128 + 32 * th + t] * (t < nt ? pg[(long)t * INP] : 0.f);
+                }
                 sm[I_FR + th * IPC + o] = acc;
             }
             PSTAMP(18);
@@ -573,17 +616,23 @@ extern "C" int64_t mstts_persist_infer_ws_bytes(void) { return IXCH_FLOATS * 4; 
 extern "C" int64_t mstts_persist_infer_pack_floats(void) { return 256L * 8 * 8 * 64; }
 
 /* 1 when the persistent free-running loop covers this shape on the current device: the reference's widths (cells 1024, prenet 256,
- * memory 768, attention 128 with 31 taps, 80 mel bins), at most 32 rows and 128 encoder positions, 256 CUs that each take one workgroup */
+ * memory 768, attention 128 with 31 taps, 80 mel bins), at most 32 rows and 256 encoder positions (beyond 128 the value / projected-value rows from 128 on are re-read from the L2 every step), 256 CUs that each take one workgroup */
 extern "C" int32_t mstts_persist_infer_supported(int64_t B, int64_t H, int64_t P, int64_t M, int64_t A, int64_t T, int64_t KS, int64_t n_mel) {
-    if (!(B >= 1 && B <= PROWS && H == PH && P == 256 && M == PM && A == PA && T >= 1 && T <= PT && KS == PKS && n_mel == 80)) return 0;
+    if (!(B >= 1 && B <= PROWS && H == PH && P == 256 && M == PM && A == PA && T >= 1 && T <= PTMAX && KS == PKS && n_mel == 80)) return 0;
     static int memo[PERSIST_MAX_DEVICES];
     return persist_device_memo(memo, [](int dev) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < PWG) return false;
-        const size_t lds = (size_t)I_FLOATS * 4;
-        return hipFuncSetAttribute((const void*)persist_infer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)persist_infer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)persist_infer_kernel<false>, PTH, lds) == hipSuccess && per_cu >= 1;
+        bool ok = true;
+        int per = 0;
+#define PI_SETUP(P_, N_, T_)                                                                                                                            \
+        ok = ok && hipFuncSetAttribute((const void*)persist_infer_kernel<P_, N_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(IL<T_>::I_FLOATS * 4)) == hipSuccess && \
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_infer_kernel<P_, N_, T_>, PTH, (size_t)IL<T_>::I_FLOATS * 4) == hipSuccess && per >= 1;
+        PI_SETUP(false, 1, 128) PI_SETUP(true, 1, 128) PI_SETUP(false, 2, 128) PI_SETUP(true, 2, 128)
+        PI_SETUP(false, 1, 256) PI_SETUP(true, 1, 256) PI_SETUP(false, 2, 256) PI_SETUP(true, 2, 256)
+#undef PI_SETUP
+        (void)per_cu;
+        return ok;
     });
 }
 
@@ -620,9 +669,16 @@ extern "C" int mstts_decoder_infer_persistent(const mstts_decoder_infer_desc* d,
     a.linear = d->linear; a.stop = d->stop; a.align_hist = d->align_hist;
     a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps;
     a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
-    const size_t lds = (size_t)I_FLOATS * 4;
-    if (p->stamps) hipLaunchKernelGGL((persist_infer_kernel<true>), dim3(PWG), dim3(PTH), lds, hs, a);
-    else hipLaunchKernelGGL((persist_infer_kernel<false>), dim3(PWG), dim3(PTH), lds, hs, a);
+#define PI_LAUNCH(N_, T_)                                                                                                               \
+    {                                                                                                                                   \
+        const size_t lds = (size_t)IL<T_>::I_FLOATS * 4;                                                                                \
+        if (p->stamps) hipLaunchKernelGGL((persist_infer_kernel<true, N_, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                      \
+        else hipLaunchKernelGGL((persist_infer_kernel<false, N_, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                               \
+    }
+    // one row tile for batches of at most 16 rows (half the matrix-core work and partial-sum bytes); 128 or 256 encoder positions
+    if (B <= 16) { if (T <= 128) PI_LAUNCH(1, 128) else PI_LAUNCH(1, 256) }
+    else { if (T <= 128) PI_LAUNCH(2, 128) else PI_LAUNCH(2, 256) }
+#undef PI_LAUNCH
     MSTTS_CHECK_LAUNCH("persist_infer");
     return MSTTS_OK;
 }

@@ -46,7 +46,8 @@ def _skip_unless_supported(eng, B, Te):
 KEYS = ("Linear", "Mel", "Stop_Logit", "Attention_History")
 
 
-@pytest.mark.parametrize("B,Te,max_inf", [(16, 128, 39), (32, 128, 24), (5, 23, 11), (1, 7, 5), (16, 100, 150)])
+@pytest.mark.parametrize("B,Te,max_inf", [(16, 128, 39), (32, 128, 24), (5, 23, 11), (1, 7, 5), (16, 100, 150),
+                                            (16, 160, 20), (32, 256, 12), (4, 131, 30), (17, 129, 9)])      # > 128 tokens: the 256-position instantiations (one and two row tiles)
 def test_persistent_equals_launch_per_step(dev, B, Te, max_inf):
     """Nobody stops early (stop bias -8): both drivers run max_inf + 1 steps; every output agrees to fp32 rounding (the persistent loop
     forms the first prenet layer from (m1, alignment) instead of from the frame, and sums its products in another order)."""

@@ -368,6 +368,20 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             if (tid < 256) {
                 roff[0] = (unsigned)((OFF_M1 + slot * XM1 + (long)ab * PH) * 4 + 16 * tid);
                 issue<1>(xr, roff, rv);
+            }
+            // while the m1 row is in flight: the location filter over the cumulative alignment (known since the last step's softmax) as a
+            // Toeplitz product on the matrix core: loc[t][k] = sum_j cum[t + j - 15] lk[j][k] = A . B with A[t][j] = cum window (one LDS word per
+            // lane and k-step), B[j][k] = the filter slice (8 registers, loaded once); wave w takes positions 16 w .. 16 w + 15, and the D layout
+            // (position 4 (lane >> 4) + r, unit lane & 15) is exactly this thread's four positions - 8 MFMAs replace 62 LDS reads + 124 FMAs
+            pf32x4 locv[NH];
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {                        // (TT = 256: the same for positions 128 + ...)
+                locv[hh] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    locv[hh] = PMFMA(sm[S_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], locv[hh]);
+            }
+            if (tid < 256) {
                 { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }
                 *reinterpret_cast<pf32x4*>(sm + S_M1 + 4 * tid) = rv[0];
             }
@@ -394,16 +408,9 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             if (tid < 16) (d.q_hist + (sB + ab) * PA + 16 * gi)[tid] = qsum;
             {
                 const float qk = qsum + asb;
-                // location filter over the cumulative alignment as a Toeplitz product on the matrix core: loc[t][k] = sum_j cum[t + j - 15] lk[j][k]
-                // = A . B with A[t][j] = cum window (one LDS word per lane and k-step), B[j][k] = the filter slice (8 registers, loaded once);
-                // wave w takes positions 16 w .. 16 w + 15, and the D layout (position 4 (lane >> 4) + r, unit lane & 15) is exactly this
-                // thread's four positions - 8 MFMAs replace 62 LDS reads + 124 FMAs per thread
 #pragma unroll
-                for (int hh = 0; hh < NH; ++hh) {                    // (TT = 256: the same for positions 128 + ...)
-                    pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks)
-                        loc = PMFMA(sm[S_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], loc);
+                for (int hh = 0; hh < NH; ++hh) {
+                    const pf32x4 loc = locv[hh];
                     float pre[4];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) pre[m] = kreg[4 * hh + m] + qk + loc[m];

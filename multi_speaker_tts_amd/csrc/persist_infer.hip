@@ -375,6 +375,16 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
             if (tid < 128) {
                 roff[0] = (unsigned)((IOFF_QP + slot * IXQP + ((long)ab * 8 + gi) * 512) * 4 + 16 * tid);
                 issue<1>(xr, roff, rv);
+            }
+            pf32x4 locv[NH];                                         // while the granules are in flight: the location filter over the cumulative alignment (persist.hip)
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                locv[hh] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    locv[hh] = PMFMA(sm[I_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], locv[hh]);
+            }
+            if (tid < 128) {
                 { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }
                 *reinterpret_cast<pf32x4*>(sm + I_QP + 4 * tid) = rv[0];
             }
@@ -391,10 +401,7 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
                 const float qk = sm[I_QS + (ak >> 2) * 16 + (ak & 3)] + asb;
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
-                    pf32x4 loc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks)
-                        loc = PMFMA(sm[I_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], loc);
+                    const pf32x4 loc = locv[hh];
                     pf32x4 e4;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {

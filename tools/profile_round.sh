@@ -9,7 +9,7 @@
 #   6. device idle time inside a step, every GEMM call of a step replayed on its own, the BiLSTM recurrence bench, the auxiliary trainers,
 #      per-workgroup stage stamps of the persistent decoder launches
 # Outputs land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

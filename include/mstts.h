@@ -30,7 +30,7 @@ enum { MSTTS_OK = 0, MSTTS_ERR_SHAPE = -1, MSTTS_ERR_DTYPE = -2, MSTTS_ERR_ALIGN
 enum { MSTTS_ACT_NONE = 0, MSTTS_ACT_RELU = 1, MSTTS_ACT_TANH = 2, MSTTS_ACT_SIGMOID = 3 };
 
 const char* mstts_last_error(void);
-/* Bumped whenever a descriptor struct or an entry point's signature changes (2: round 4); the Python binding checks it at load. */
+/* Bumped whenever a descriptor struct or an entry point's signature changes (4: round 4); the Python binding checks it at load. */
 int mstts_abi_version(void);
 /* Diagnostic (tests of the persistent launches' co-residency handling; no reference counterpart - MSTTS_SV.py:24 is a single session on one
  * device): n_workgroups workgroups that each hold 96 KB of LDS - a whole CU as far as a persistent workgroup is concerned - for
@@ -326,10 +326,15 @@ int mstts_lsa_step_fwd_selftest(const mstts_lsa_const* c, const float* q, int32_
                                 uint32_t epoch, int32_t skip_slice, mstts_stream_t s);
 
 /* post-loop parameter gradients over all S steps (recomputes tanh tiles from the saved d_e):
- * hist pointers are [S,B,*]; outputs accumulate (atomic): d_keys[B,T,A], d_loc_k[KS,A], d_score_w[A], d_score_b[A]
- * (d_loc_b equals d_score_b); unfold d_loc_k with mstts_lsa_unfold_location_grad. */
+ * hist pointers are [S,B,*]; outputs accumulate: d_keys[B,T,A] (atomic, at most a few adds per element), d_loc_k[KS,A], d_score_w[A], d_score_b[A]
+ * (d_loc_b equals d_score_b); unfold d_loc_k with mstts_lsa_unfold_location_grad.
+ * ws: mstts_lsa_param_bwd_ws_floats(B, T, S) floats, 8-byte aligned: every workgroup writes its partial block of the filter / score-layer
+ * gradients there and two small kernels add the blocks in fp64 in a fixed order - these gradients are sums over every (row, step, position) of
+ * the batch with heavy cancellation (with fp32 atomics: 5e-3 of the gradient's maximum off at batch 32 x 801 steps, and different run to run).
+ * NULL: fp32 atomics. */
+int64_t mstts_lsa_param_bwd_ws_floats(int64_t B, int64_t T, int64_t S);
 int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
-                        float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, mstts_stream_t s);
+                        float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, float* ws, mstts_stream_t s);
 
 /* ---- losses (MSTTS_SV.py:127-144) forward + gradient in one pass -------------------------------
  * linear/post [B,S,n_mel] with S = L+1, mel [B,L,n_mel], stop_logit [B,S], mel_length [B].

@@ -1182,12 +1182,13 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
 // (lane half h: row (r&3) + 8(r>>2) + 4h) - g never leaves its registers.  Wave w owns attention units 32w .. 32w+31; a workgroup
 // walks a chunk of steps for one (row, tile); accumulators (d_keys tile, d_loc_k, d_score_w/b) stay in registers over the chunk.
 constexpr int PT = 32;                      // encoder positions per workgroup
+constexpr int LP_ROWS = 34, LP_GROUPS = 16; // partial block rows (32 filter taps incl. padding | score w | score b); block groups of the fp64 reduction
 typedef float lp_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, int S, int steps_per_block,
                                                             const float* __restrict__ q_hist, const float* __restrict__ cum_hist,
                                                             const float* __restrict__ de_hist, float* __restrict__ d_keys,
                                                             float* __restrict__ d_loc_k, float* __restrict__ d_score_w,
-                                                            float* __restrict__ d_score_b) {
+                                                            float* __restrict__ d_score_b, float* __restrict__ part) {
     __shared__ float s_win[2][PT + 32];     // cum[t0 - pad + i], i < PT + KS - 1 (zero outside the sequence and past the window)
     __shared__ float s_de[2][PT];
     const int b = blockIdx.x, t0 = blockIdx.y * PT, T = (int)c.T, B = (int)c.B, KS = (int)c.KS, pad = (KS - 1) / 2;
@@ -1253,14 +1254,52 @@ __global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, i
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (t0 + row < T) atomicAdd(d_keys + ((long)b * T + t0 + row) * A_ + a, acc_keys[r]);
-        if (row < KS) atomicAdd(d_loc_k + row * A_ + a, acc_lk[r]);                 // row = tap j here
     }
     acc_w += __shfl_xor(acc_w, 32);            // (once per workgroup, off any per-step path)
     acc_b += __shfl_xor(acc_b, 32);
+    if (part) {
+        // The filter / score-layer gradients are sums over EVERY (row, step, position) of the batch: thousands of workgroup partials per element
+        // with heavy cancellation.  Summed with fp32 atomics they come out 5e-3 off (of the gradient's maximum) at batch 32 x 801 steps and
+        // differ run to run; each workgroup therefore writes its partial block [34][128] (31 taps | - | score w | score b) and
+        // lsa_param_reduce_kernel adds the blocks in fp64 in a fixed order.
+        float* pb = part + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (LP_ROWS * A_);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pb[((r & 3) + 8 * (r >> 2) + 4 * kh) * A_ + a] = acc_lk[r];
+        if (kh == 0) { pb[32 * A_ + a] = acc_w; pb[33 * A_ + a] = acc_b; }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < KS) atomicAdd(d_loc_k + row * A_ + a, acc_lk[r]);                 // row = tap j here
+    }
     if (kh == 0) {
         atomicAdd(d_score_w + a, acc_w);
         atomicAdd(d_score_b + a, acc_b);
     }
+}
+// stage 1: block group gz sums its share of the partial blocks for 64 elements in fp64 (fixed order); stage 2 adds the LP_GROUPS group sums in order
+__global__ __launch_bounds__(256) void lsa_param_reduce1_kernel(const float* __restrict__ part, int nblk, double* __restrict__ gsum) {
+    __shared__ double red[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, gz = blockIdx.y;
+    const int per = (nblk + LP_GROUPS - 1) / LP_GROUPS, b0 = gz * per, b1 = min(nblk, b0 + per);
+    double acc = 0.0;
+#pragma unroll 8
+    for (int bl = b0 + sub; bl < b1; bl += 4) acc += (double)part[(long)bl * (LP_ROWS * A_) + e];
+    red[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0) gsum[(long)gz * (LP_ROWS * A_) + e] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void lsa_param_reduce2_kernel(const double* __restrict__ gsum, int KS, float* __restrict__ d_loc_k, float* __restrict__ d_score_w, float* __restrict__ d_score_b) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= LP_ROWS * A_) return;
+    double v = 0.0;
+#pragma unroll
+    for (int gz = 0; gz < LP_GROUPS; ++gz) v += gsum[(long)gz * (LP_ROWS * A_) + e];
+    const int row = e / A_, a = e - row * A_;
+    if (row < KS) d_loc_k[row * A_ + a] += (float)v;
+    else if (row == 32) d_score_w[a] += (float)v;
+    else if (row == 33) d_score_b[a] += (float)v;
 }
 
 static int check_const(const mstts_lsa_const* c) {
@@ -1474,19 +1513,40 @@ extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, 
     MSTTS_CHECK_LAUNCH("lsa_step_bwd");
     return MSTTS_OK;
 }
+static void lsa_param_geometry(long B, long T, long S, int* nt, int* chunks, int* spb) {
+    *nt = cdiv(T, PT);
+    int ch = (int)(2048 / (B * *nt));
+    if (ch < 1) ch = 1;
+    if (ch > S) ch = (int)S;
+    *spb = cdiv(S, ch);
+    *chunks = cdiv(S, *spb);
+}
+extern "C" int64_t mstts_lsa_param_bwd_ws_floats(int64_t B, int64_t T, int64_t S) {
+    if (B < 1 || T < 1 || S < 1) return 0;
+    int nt, chunks, spb;
+    lsa_param_geometry(B, T, S, &nt, &chunks, &spb);
+    return (int64_t)B * nt * chunks * (LP_ROWS * A_) + 2 * (int64_t)LP_GROUPS * (LP_ROWS * A_);      // partial blocks, then LP_GROUPS blocks of doubles
+}
 extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
-                                   float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, mstts_stream_t s) {
+                                   float* d_keys, float* d_loc_k, float* d_score_w, float* d_score_b, float* ws, mstts_stream_t s) {
     int rc = check_const(c); if (rc) return rc;
     if (S <= 0) return MSTTS_OK;
-    const int nt = cdiv(c->T, PT);
-    int chunks = (int)(2048 / (c->B * nt));
-    if (chunks < 1) chunks = 1;
-    if (chunks > S) chunks = (int)S;
-    const int spb = cdiv(S, chunks);
-    chunks = cdiv(S, spb);
+    MSTTS_REQUIRE(!ws || (reinterpret_cast<uintptr_t>(ws) & 7u) == 0, MSTTS_ERR_ALIGN, "lsa_param_bwd: the workspace must be 8-byte aligned");
+    int nt, chunks, spb;
+    lsa_param_geometry(c->B, c->T, S, &nt, &chunks, &spb);
     hipLaunchKernelGGL(lsa_param_bwd_kernel, dim3((unsigned)c->B, nt, chunks), dim3(256), 0, ST(s), *c, (int)S, spb, q_hist, cum_hist,
-                       de_hist, d_keys, d_loc_k, d_score_w, d_score_b);
+                       de_hist, d_keys, d_loc_k, d_score_w, d_score_b, ws);
     MSTTS_CHECK_LAUNCH("lsa_param_bwd");
+    if (ws) {
+        const int nblk = (int)c->B * nt * chunks;
+        long nb = (long)nblk * (LP_ROWS * A_);
+        nb += nb & 1;                                                    // (doubles behind the blocks: keep them 8-byte aligned)
+        double* gsum = reinterpret_cast<double*>(ws + nb);
+        hipLaunchKernelGGL(lsa_param_reduce1_kernel, dim3(LP_ROWS * A_ / 64, LP_GROUPS), dim3(256), 0, ST(s), ws, nblk, gsum);
+        MSTTS_CHECK_LAUNCH("lsa_param_reduce1");
+        hipLaunchKernelGGL(lsa_param_reduce2_kernel, dim3(cdiv(LP_ROWS * A_, 256)), dim3(256), 0, ST(s), gsum, (int)c->KS, d_loc_k, d_score_w, d_score_b);
+        MSTTS_CHECK_LAUNCH("lsa_param_reduce2");
+    }
     return MSTTS_OK;
 }
 

@@ -373,6 +373,7 @@ class TrainEngine:
         w.d_in0_parts = int(lb.mstts_decoder_train_bwd_parts(H, M))
         w.d_in0 = f(w.d_in0_parts, S, B, M + H)
         w.dec_bwd_ws = f(int(lb.mstts_decoder_train_bwd_ws_floats(B, H, M, A, Te, d.att_ch)))
+        w.lsa_param_ws = torch.empty((int(lb.mstts_lsa_param_bwd_ws_floats(B, Te, S)) + 3) // 4 * 4, dtype=torch.float32, device=self.device)   # partial blocks of the attention parameter gradients
         w.d_pre = f(S * B, Pn)
         w.d_pre2 = f(S * B, Pn)
         w.d_keys = f(B, Te, A)
@@ -866,7 +867,7 @@ class TrainEngine:
         self._gemm(w.pj, w.dq_hist, gq, H, A, n, H + M, A, A, trans_a=True, split_k=max(2, _split_k(H, A, n)), a_off=r * (H + M), b_off=r * A, c_off=ogq)
         gsw, ogsw = self.G(LSA + "score_layer/weight_w"); gsb, ogsb = self.G(LSA + "score_layer/bias_b")
         call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), hi - lo, ptr(w.q_hist, r * A), ptr(w.cum_hist, r * Te), ptr(w.de_hist, r * Te), ptr(w.d_keys),
-             ptr(self.d_loc_k), ptr(gsw, ogsw), ptr(gsb, ogsb))
+             ptr(self.d_loc_k), ptr(gsw, ogsw), ptr(gsb, ogsb), ptr(w.lsa_param_ws))
 
     def _grad_range(self, *prefixes):
         """[lo, hi) of the gradient slab covered by the trainable variables whose names start with one of `prefixes` (the

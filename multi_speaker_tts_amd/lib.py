@@ -170,7 +170,8 @@ SIGNATURES = {
     "mstts_lsa_step_fwd_selftest": (i32, [P(LsaConst), vp, i32, i64, vp, vp, vp, vp, vp, i64, vp, C.c_uint32, i32, vp]),
     "mstts_lsa_dalign_bwd": (i32, [P(LsaConst), vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "mstts_lsa_denergy_bwd": (i32, [P(LsaConst), vp, vp, vp, vp, vp, vp, vp, vp]),
-    "mstts_lsa_param_bwd": (i32, [P(LsaConst), i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mstts_lsa_param_bwd": (i32, [P(LsaConst), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mstts_lsa_param_bwd_ws_floats": (i64, [i64, i64, i64]),
     "mstts_lsa_fold_location": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "mstts_lsa_filter_by_unit": (i32, [vp, vp, i64, i64, vp]),
     "mstts_lsa_unfold_location_grad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
@@ -267,7 +268,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3          # = mstts_abi_version() of the library this binding's ctypes structs describe (bump both on a descriptor change)
+ABI_VERSION = 4          # = mstts_abi_version() of the library this binding's ctypes structs describe (bump both on a descriptor change)
 
 
 class MsttsError(RuntimeError):

@@ -158,7 +158,8 @@ def test_lsa_step_fwd_bwd(dev, B, T, M, KS):
     # parameter gradients + d_keys through the post-loop kernel with S = 1, then unfolded to the reference variables
     dkeys = torch.zeros(B, T, A, device=dev)
     dlk, gw, gsb = torch.zeros(KS, A, device=dev), torch.zeros(A, device=dev), torch.zeros(A, device=dev)
-    lib.call("mstts_lsa_param_bwd", C.byref(c), 1, lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dkeys), lib.ptr(dlk), lib.ptr(gw), lib.ptr(gsb))
+    ws = torch.empty(int(lib.load().mstts_lsa_param_bwd_ws_floats(B, T, 1)) + 2, device=dev) if B % 2 else None      # both accumulation forms: fp64 block reduction / fp32 atomics
+    lib.call("mstts_lsa_param_bwd", C.byref(c), 1, lib.ptr(q), lib.ptr(dcum), lib.ptr(de), lib.ptr(dkeys), lib.ptr(dlk), lib.ptr(gw), lib.ptr(gsb), lib.ptr(ws))
     gk, gb, gd = torch.zeros(KS, CH, device=dev), torch.zeros(CH, device=dev), torch.zeros(CH, A, device=dev)
     lib.call("mstts_lsa_unfold_location_grad", c.conv_k, c.conv_b, c.dense_k, lib.ptr(dlk), lib.ptr(gsb), lib.ptr(gk), lib.ptr(gb), lib.ptr(gd), KS, CH, A)
     assert rel_err(t2n(dkeys), t2n(kt.grad)) < 5e-5

@@ -462,8 +462,12 @@ __global__ __launch_bounds__(PTH) void persist_infer_kernel(PersistInfer d) {
             if (tid < 384) {        // context: 96 columns x 4 position quarters
                 const int c = tid % 96, th = tid / 96;
                 float acc = 0.f;
-#pragma unroll 16
-                for (int t = 0; t < 32; ++t) acc += sm[I_A + 32 * th + t] * sm[I_VAL + (32 * th + t) * 96 + c];
+#pragma unroll
+                for (int t4 = 0; t4 < 8; ++t4) {                     // (the four alignment weights of a group in one 16-byte LDS read)
+                    const pf32x4 a4 = *reinterpret_cast<const pf32x4*>(sm + I_A + 32 * th + 4 * t4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc += a4[e] * sm[I_VAL + (32 * th + 4 * t4 + e) * 96 + c];
+                }
                 if (NH > 1) {       // positions 128 + 32 th ..: from memory (zero past the row's length there)
                     const float* vg = d.values + ((long)ab * T + 128 + 32 * th) * PM + 96 * gi + c;
                     const int nt = T - (128 + 32 * th) < 32 ? (T - (128 + 32 * th) > 0 ? T - (128 + 32 * th) : 0) : 32;

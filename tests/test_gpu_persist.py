@@ -206,7 +206,7 @@ def test_intruder_on_the_compute_units(dev, park_us):
     torch.cuda.synchronize()
     quiet_ms = (time.perf_counter() - t0) * 1e3
     assert eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0
-    side = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev, priority=-1)            # (a high-priority stream gets a hardware queue of its own where the runtime has one left)
     done = torch.zeros(1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -314,6 +314,7 @@ class TrainEngine:
             w.enc_xch = f(int(lb.mstts_persist_lstm_ws_bytes()) // 4)
             w.enc_ctrl = torch.zeros(16, dtype=torch.int32, device=self.device)
             w.enc_ctrl_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.enc_ctrl_host_b = torch.zeros(16, dtype=torch.int32).pin_memory()
             w.enc_hist = f(int(lb.mstts_persist_lstm_hist_floats(Te)))        # packed per-step inputs + history of the persistent forward
             w.enc_bws = f(int(lb.mstts_persist_lstm_bwd_floats(Te)))
             w.enc_hist_valid = False
@@ -426,15 +427,27 @@ class TrainEngine:
             self._gemm(dz, wt, dx, rows, cin, K * cout, cout, cin, cin, win=(T, cout, K - 1 - pad))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch, w, seed=None, masks=None):
+    def forward(self, batch, w, seed=None, masks=None, _redo=False):
+        """Forward pass.  The persistent launches (encoder BiLSTM, decoder loop) are enqueued WITHOUT waiting for their control words; the
+        words of both are read once, behind the rest of the pass (one host sync per pass).  If either launch gave up, the BN moving statistics
+        are put back to their state at the start of the pass and the whole pass is run again with the launch-per-step loops (_redo)."""
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
         if self._derived_stale:
             self.refresh_derived()
-        allowed = self._persist_begin_step()
+        allowed = False if _redo else self._persist_begin_step()
         w.persist_now = bool(w.persist) and allowed
         w.persist_bwd_now = bool(getattr(w, "persist_bwd", False)) and allowed
+        speculative = allowed and (w.persist_now or bool(getattr(w, "persist_enc", False)))
+        if speculative:
+            # the pass runs on the persistent launches' outputs before their status words are known; a launch that gave up leaves junk there,
+            # and the BN layers would fold that junk into their MOVING statistics - one update per train step is the reference's behaviour
+            # (Modules.py:37-40 update ops), so the whole range (one contiguous slice of the non-trainable slab) is put back before the re-run
+            n_mov = self.params.n_moving
+            if self._moving_snapshot is None or self._moving_snapshot.numel() != n_mov:
+                self._moving_snapshot = torch.empty(n_mov, dtype=torch.float32, device=self.device)
+            self._moving_snapshot.copy_(self.params.frozen[:n_mov])
         if masks is not None:
             w.masks.load(masks)
         else:
@@ -469,7 +482,10 @@ class TrainEngine:
             if self.enc_whp is not None:                 # fused steps: packed recurrent kernel + packed h blocks
                 q.wh_p, q.h_p = ptr(self.enc_whp[dr]), ptr(w.enc_hp[dr])
             seqs.append(q)
-        w.enc_hist_valid = bool(getattr(w, "persist_enc", False)) and allowed and self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)
+        enc_ticket = None
+        w.enc_hist_valid = bool(getattr(w, "persist_enc", False)) and allowed
+        if w.enc_hist_valid:
+            enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)       # (status read at the end of the pass)
         if not w.enc_hist_valid:
             self._ensure_fallback_packs()
             call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
@@ -540,54 +556,53 @@ class TrainEngine:
             w.opk_valid = False
             self._ensure_fallback_packs()
             call("mstts_decoder_train_fwd", C.byref(dec))
-        if ev is not None:
-            # the tail below runs on the persistent launch's outputs before its status words are known; a launch that gave up leaves junk
-            # there, and the tail's BN layers (postnet, the vocoder's conv bank) would fold that junk into their MOVING statistics - one
-            # update per train step is the reference's behaviour (Modules.py:37-40 update ops), so they are put back before the re-run
-            n_mov = self.params.n_moving
-            if self._moving_snapshot is None or self._moving_snapshot.numel() != n_mov:
-                self._moving_snapshot = torch.empty(n_mov, dtype=torch.float32, device=self.device)
-            self._moving_snapshot.copy_(self.params.frozen[:n_mov])
         self._forward_tail(w)
+        dec_ok = enc_ok = True
         if ev is not None:
-            cur = torch.cuda.current_stream()
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
                 w.pctrl_host.copy_(w.pctrl, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record()
-            done.synchronize()
+            done.synchronize()               # (the side stream runs in order: the encoder launch's words, copied earlier, have landed too)
             st = w.pctrl_host
-            if int(st[1]) != 0 or int(st[2]) != 256:
+            dec_ok = int(st[1]) == 0 and int(st[2]) == 256
+            if not dec_ok:
                 self.persist_fallbacks += 1
-                self._step_fell_back = True
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
-                cur.synchronize()
-                self.params.frozen[:self.params.n_moving].copy_(self._moving_snapshot)
-                w.opk_valid = False                   # the launch-per-step loop writes the row-major histories
-                if w.fold_prenet:
-                    xw0_product()                     # ... and reads the hoisted cell-0 input product
-                self._ensure_fallback_packs()
-                call("mstts_decoder_train_fwd", C.byref(dec))
-                self._forward_tail(w)
+        if enc_ticket is not None:
+            enc_ok = self._enc_check(w, enc_ticket)
+        if not (dec_ok and enc_ok):
+            self._step_fell_back = True
+            torch.cuda.current_stream().synchronize()
+            self.params.frozen[:self.params.n_moving].copy_(self._moving_snapshot)
+            return self.forward(batch, w, seed=seed, masks=masks, _redo=True)
         return w
 
     def _enc_persistent(self, w, entry, seqs, which, n_wg):
-        """One persistent launch for all steps of both encoder directions (forward: which = 0, BPTT: 1).  Its control words are read
-        right behind it (a sub-millisecond launch); False = it gave up (bounded waits) and the caller runs the launch-per-step pair,
-        which rewrites every output."""
+        """One persistent launch for all steps of both encoder directions (forward: which = 0, BPTT: 1).  Nothing waits here: the launch's
+        control words are copied to pinned host memory on the side stream behind it; the returned ticket is redeemed with _enc_check at the
+        end of the pass."""
         extra = (ptr(w.enc_hist),) if which == 0 else (ptr(w.enc_hist), ptr(w.enc_bws))
         call(entry, C.byref(seqs[0]), C.byref(seqs[1]), ptr(self.enc_pk["fw"][which]), ptr(self.enc_pk["bw"][which]), ptr(w.enc_xch), ptr(w.enc_ctrl), *extra)
         ev = torch.cuda.Event()
         ev.record()
+        host = w.enc_ctrl_host if which == 0 else w.enc_ctrl_host_b
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
-            w.enc_ctrl_host.copy_(w.enc_ctrl, non_blocking=True)
+            host.copy_(w.enc_ctrl, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
+        return done, host, n_wg
+
+    def _enc_check(self, w, ticket):
+        """True when the encoder launch of the ticket ran to its end (False: the caller re-runs the pass with the launch-per-step pair)."""
+        done, host, n_wg = ticket
         done.synchronize()
-        st = w.enc_ctrl_host
-        if int(st[1]) != 0 or int(st[2]) != n_wg:
+        if getattr(self, "persist_enc_selftest", 0):              # tests: pretend the next encoder launch gave up
+            self.persist_enc_selftest -= 1
+            host[1] = 3
+        if int(host[1]) != 0 or int(host[2]) != n_wg:
             self.persist_enc_fallbacks += 1
             self._step_fell_back = True
             return False
@@ -670,7 +685,11 @@ class TrainEngine:
         self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.bn_ws)
 
     # ------------------------------------------------------------------ loss + backward
-    def loss_and_backward(self, w, grad_scale=1.0, on_ready=None):
+    def loss_and_backward(self, w, grad_scale=1.0, on_ready=None, on_abort=None, _redo=False):
+        """Loss and backward pass.  Like forward(): the persistent launches (decoder BPTT, encoder BPTT) are enqueued without waiting for their
+        control words, which are read once at the end of the pass; if either gave up the whole pass is run again with the launch-per-step
+        loops (it starts by clearing the gradient slab).  on_abort: called before that re-run (train_step: wait for the collectives that the
+        abandoned pass has already started on the slab)."""
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
@@ -695,7 +714,7 @@ class TrainEngine:
         # every CU of the chip for itself: a collective kernel holding CUs at that moment and the 256 workgroups waiting for each
         # other's CUs would sit out the launch's start window (0.2 s) and end in the fallback.  Then the range is announced BEHIND the
         # launch (the collective is ordered after what is enqueued) and runs under the hoisted weight-gradient products instead.
-        postnet_ready_deferred = on_ready is not None and bool(getattr(w, "persist_bwd_now", False))
+        postnet_ready_deferred = on_ready is not None and bool(getattr(w, "persist_bwd_now", False)) and bool(getattr(w, "persist_bwd", False)) and not _redo
         if on_ready is not None and not postnet_ready_deferred:
             on_ready(*self._grad_range("decoder/conv_"))
         # d_linear(total) = loss part + residual (d_post) + postnet input grad
@@ -723,9 +742,12 @@ class TrainEngine:
         w.d_keys.zero_()
         self.d_loc_k.zero_()
         parts = w.d_in0_parts
-        if getattr(w, "opk_valid", False) and not getattr(w, "persist_bwd_now", False):
+        # (persist_bwd_now: this step's policy decision, taken in forward(); persist_bwd: the plan's flag, which tests clear between two backward passes)
+        use_pbwd = bool(getattr(w, "persist_bwd_now", False)) and bool(getattr(w, "persist_bwd", False)) and bool(getattr(w, "opk_valid", False)) and not _redo
+        bwd_done = None
+        if getattr(w, "opk_valid", False) and not use_pbwd:
             self.unpack_history(w)            # the persistent forward packed the cell operands; the launch-per-step BPTT reads the histories
-        if getattr(w, "persist_bwd_now", False) and getattr(w, "opk_valid", False):
+        if use_pbwd:
             # ONE launch for the whole BPTT; its status words are read while the hoisted weight-gradient products run (no bubble); the
             # launch-per-step loop is the fallback
             pb = w.pdesc_b
@@ -740,20 +762,9 @@ class TrainEngine:
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
                 w.pctrl_b_host.copy_(w.pctrl_b, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-            done.synchronize()
-            st = w.pctrl_b_host
-            if int(st[1]) != 0 or int(st[2]) != 256:
-                self.persist_bwd_fallbacks += 1
-                self._step_fell_back = True
-                self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
-                self.unpack_history(w)
-                w.dq_hist.zero_()
-                self._ensure_fallback_packs()
-                call("mstts_decoder_train_bwd", C.byref(db))
-            else:
-                parts = 1                    # d_in0 slab 0 holds the complete context gradient
+                bwd_done = torch.cuda.Event()
+                bwd_done.record()
+            parts = 1                        # (on success d_in0 slab 0 holds the complete context gradient; a failed launch re-runs the pass)
         else:
             self._ensure_fallback_packs()
             call("mstts_decoder_train_bwd", C.byref(db))
@@ -815,7 +826,10 @@ class TrainEngine:
             q.dgates_step = ptr(w.enc_dgs[dr]); q.dgates_pos = ptr(w.enc_dgp[dr]); q.ws = ptr(w.enc_bwd_ws[dr])
             bseqs.append(q)
         # (the persistent BPTT reads the packed history of a persistent forward)
-        if not (getattr(w, "enc_hist_valid", False) and self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)):
+        enc_ticket = None
+        if getattr(w, "enc_hist_valid", False) and not _redo:
+            enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)
+        else:
             self._ensure_fallback_packs()
             call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
         for di, dr in enumerate(("fw", "bw")):
@@ -841,6 +855,24 @@ class TrainEngine:
         call("mstts_embedding_bwd", ptr(tok), ptr(dy), ptr(ge, oge), B * Te, d.n_tok, d.emb)
         if on_ready is not None:
             on_ready(*self._grad_range("encoder/"))
+        # ---- the status words of this pass's persistent launches: ONE host sync (the side stream runs in order)
+        passed = True
+        if enc_ticket is not None:
+            passed = self._enc_check(w, enc_ticket)
+        elif bwd_done is not None:
+            bwd_done.synchronize()
+        if bwd_done is not None:
+            st = w.pctrl_b_host
+            if int(st[1]) != 0 or int(st[2]) != 256:
+                self.persist_bwd_fallbacks += 1
+                self._step_fell_back = True
+                self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
+                passed = False
+        if not passed:
+            if on_abort is not None:
+                on_abort()
+            torch.cuda.current_stream().synchronize()
+            return self.loss_and_backward(w, grad_scale=grad_scale, on_ready=on_ready, on_abort=on_abort, _redo=True)
 
     def _recurrent_wgrads(self, w, lo, hi):
         """Weight gradients of the decoder loop summed over the steps [lo, hi) (accumulating into the gradient slab):
@@ -949,7 +981,7 @@ class TrainEngine:
         self.forward(batch, w, masks=masks)
         if all_reduce is not None:           # bucketed in the order gradients become final (postnet -> decoder/attention -> encoder),
             g = self.params.grad             # each bucket's all-reduce running under the rest of the backward pass
-            self.loss_and_backward(w, on_ready=lambda lo, hi: all_reduce.start(g, lo, hi))
+            self.loss_and_backward(w, on_ready=lambda lo, hi: all_reduce.start(g, lo, hi), on_abort=lambda: all_reduce.finish(g))
             all_reduce.finish(g)
         else:
             self.loss_and_backward(w)

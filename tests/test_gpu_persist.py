@@ -154,6 +154,43 @@ def test_persistent_abort_falls_back(dev):
     assert rel_err(c["pj"], b["pj"]) < 2e-5
 
 
+def test_encoder_launch_failure_reruns_the_pass(dev):
+    """The encoder's persistent launches are checked together with the decoder's at the END of a pass (one host sync per pass).  A failed encoder
+    launch (test knob: the next check reads a give-up code) therefore means the whole pass ran on junk: it is run again launch by launch - same
+    results as an undisturbed pass, the BN moving statistics updated once, one fallback counted; the same for the backward pass."""
+    eng, od = _engine(dev)
+    if not eng.persist_enc:
+        pytest.skip("persistent encoder launches not available on this device")
+    B, Te, L = 8, 40, 6
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=True), dev)
+    w = eng.plan(B, Te, L)
+    mov0 = eng.params.frozen[:eng.params.n_moving].clone()
+    eng.forward(batch, w, seed=11); eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    ref, gref, mov_ref = _snapshot(w, eng), eng.params.grad.clone(), eng.params.frozen[:eng.params.n_moving].clone()
+    assert eng.persist_enc_fallbacks == 0 and w.enc_hist_valid
+    # forward
+    eng.params.frozen[:eng.params.n_moving].copy_(mov0)
+    eng.persist_enc_selftest = 1
+    eng.forward(batch, w, seed=11)
+    assert eng.persist_enc_fallbacks == 1 and not w.enc_hist_valid and not w.persist_now        # re-run without the persistent launches
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    got = _snapshot(w, eng)
+    for k in ("pj", "align_hist", "linear", "mel_out"):
+        assert rel_err(got[k], ref[k]) < 5e-5, k
+    assert rel_err(t2n(eng.params.grad), t2n(gref)) < 2e-4
+    assert torch.allclose(eng.params.frozen[:eng.params.n_moving], mov_ref, rtol=1e-5, atol=1e-7)
+    # backward: a healthy forward, then the encoder BPTT launch "fails"
+    eng.forward(batch, w, seed=11)
+    assert w.enc_hist_valid and w.persist_now
+    eng.persist_enc_selftest = 1
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    assert eng.persist_enc_fallbacks == 2 and eng.persist_bwd_fallbacks == 0
+    assert rel_err(t2n(eng.params.grad), t2n(gref)) < 2e-4
+
+
 def test_adaptive_fallback_cooldown(dev, monkeypatch):
     """Policy (engine._persist_begin_step): two consecutive steps whose persistent launch gave up switch the persistent plans off for a
     cool-down (one warning), the steps in between run the launch-per-step loops without paying a rendezvous, then the launches are

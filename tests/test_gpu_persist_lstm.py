@@ -175,19 +175,21 @@ def test_train_step_with_and_without_the_persistent_encoder(dev, monkeypatch):
     w = eng.plan(B, Te, L)
     assert w.persist_enc
 
-    def grads():
+    def grads(fail_bptt=False):
         eng.forward(batch, w, seed=seed)
+        if fail_bptt:
+            eng.persist_enc_selftest = 1                  # the encoder BPTT launch's status reads "gave up": the backward pass re-runs launch by launch
         eng.loss_and_backward(w)
         torch.cuda.synchronize()
         return t2n(eng.params.grad).copy()
 
     a = grads()
     assert w.enc_hist_valid and eng.persist_enc_fallbacks == 0
-    real = eng._enc_persistent
-    monkeypatch.setattr(eng, "_enc_persistent", lambda w_, entry, seqs, which, n: False if which == 1 else real(w_, entry, seqs, which, n))
-    b = grads()                                           # persistent forward, launch-per-step BPTT
-    monkeypatch.setattr(eng, "_enc_persistent", lambda *a_, **k_: False)
+    b = grads(fail_bptt=True)                             # persistent forward, launch-per-step BPTT (reads the row-major history the unpack kernel wrote)
+    assert eng.persist_enc_fallbacks == 1
+    w.persist_enc = False
     c = grads()                                           # launch per step both ways
+    assert not w.enc_hist_valid
     scale = np.abs(c).max()
     assert np.abs(a - c).max() < 2e-4 * scale, np.abs(a - c).max() / scale
     assert np.abs(b - c).max() < 2e-4 * scale, np.abs(b - c).max() / scale

@@ -66,6 +66,10 @@ int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
  * run only to the last bit or two; 0 switches the schedule off (every tile whole: the summation order of every output element fixed -
  * what the bit-reproducibility tests select). */
 int mstts_gemm_tail_split(int32_t on);
+/* 1 (default): contractions with more than 32 rows run on the bf16 matrix cores as an EXACT three-way split of every fp32 operand element and
+ * six bf16 products per fp32 product (csrc/gemm_split.inc: dropped terms <= 2^-26 relative, fp32 accumulate - fp32 accuracy, 6/16 of the
+ * f32-input MFMA time); 0: v_mfma_f32_32x32x2_f32 for everything (bitwise an fmaf chain).  Process-wide switch for tests and A/B runs. */
+int mstts_gemm_split3(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes. */
 int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t s);

@@ -34,6 +34,7 @@ struct GemmArgs {
     // into tail_s pieces of tail_kps each, blocks body + (tile - body) * tail_s + piece, accumulated with atomics.  body = all tiles
     // when the split is off.
     int body, tail_s, tail_kps;
+    int band;                     // gemm_split_kernel: tile list in column bands of this many tiles (0: row-major)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -50,6 +51,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // Out-of-range elements are read from this zero block instead of being skipped: the loads stay unconditional (no exec-mask
 // branches in the K loop, the scheduler can hide them behind the MFMAs) and the padding is zero without a select on the data.
 __device__ __attribute__((aligned(16))) const float gemm_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+// ... and they go through an explicit GLOBAL-address-space pointer: the select between the operand and the zero block otherwise degrades to
+// a flat pointer, flat loads count in lgkmcnt as well as vmcnt, and every s_waitcnt lgkmcnt(0) in front of an MFMA group (placed for the
+// LDS fragment reads) would then also wait for the K-tile prefetch issued just before - the whole global latency exposed once per K-tile.
+typedef float gemm_f32x4 __attribute__((ext_vector_type(4)));
+typedef const gemm_f32x4 __attribute__((address_space(1)))* gemm_gptr4;
+__device__ __forceinline__ float4 gemm_ld4(const float* p) {
+    const gemm_f32x4 v = *(gemm_gptr4)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 // Addressing: every load is  uniform base (SGPRs, advanced once per K-tile)  +  a 32-bit per-thread offset fixed at prepare()  -
 // no 64-bit address arithmetic and no bounds arithmetic beyond one compare in the K loop (it cost 9 % of the matrix-core time).
@@ -98,7 +108,7 @@ struct LoaderKC {
                 ok = ok && t >= 0 && t < wT;
             }
             if (VEC) {
-                v = *reinterpret_cast<const float4*>(ok ? ubase + (voff[i] + wadd) : gemm_zero16);
+                v = gemm_ld4(ok ? ubase + (voff[i] + wadd) : gemm_zero16);
             } else if (ok) {
                 const float* p = ubase + (voff[i] + wadd);
                 v.x = p[0];
@@ -173,7 +183,7 @@ struct LoaderMC {
                 else while (t_k[i] >= wT) t_k[i] -= wT;
             }
             if (VEC) {
-                v = *reinterpret_cast<const float4*>(ok ? ubase + voff[i] : gemm_zero16);
+                v = gemm_ld4(ok ? ubase + voff[i] : gemm_zero16);
             } else if (ok) {
                 const float* p = ubase + voff[i];
                 v.x = p[0];
@@ -340,12 +350,18 @@ static void launch_gemm(const GemmArgs& g, bool vec, dim3 grid, hipStream_t st) 
     else     hipLaunchKernelGGL((gemm_kernel<BM, TA, TB, false>), grid, dim3(256), 0, st, g);
 }
 
+#include "gemm_split.inc"
+
 }  // namespace mstts
 
 using namespace mstts;
 
 static int g_tail_split = 1;
 extern "C" int mstts_gemm_tail_split(int32_t on) { g_tail_split = on != 0; return MSTTS_OK; }
+// 1 (default): every contraction with more than 32 rows runs as the six-product bf16 split (gemm_split.inc: fp32 accuracy at 6/16 of
+// the f32-input MFMA time); 0: all of them on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain).  Tests and the bench's A/B leg switch it.
+static int g_split3 = 1;
+extern "C" int mstts_gemm_split3(int32_t on) { g_split3 = on != 0; return MSTTS_OK; }
 
 extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm: null descriptor");
@@ -386,10 +402,11 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     // 1 608 half tiles = 6.28 -> 7; 4 096 x 512: 128 tiles use half the chip, 256 half tiles all of it); the half tile re-reads
     // the B operand twice as often, so it has to win by more than 5 %
     int bm = skinny ? 32 : 128, tail_s = 1, tail_rem = 0;
+    const bool split3 = g_split3 && !skinny && (d->win_T <= 0 || (d->win_T >= BK && d->win_C >= BK)) && gemm_split_lds_ready();          // (128-row tiles only; two workgroups per CU, so half-filled rounds cost half as much)
     if (!skinny) {
         const double t128 = (double)cdiv(d->M, 128) * cdiv(d->N, BN) * batch * split, t64 = (double)cdiv(d->M, 64) * cdiv(d->N, BN) * batch * split;
         const double e128 = t128 / (ceil(t128 / 256.0) * 256.0), e64 = t64 / (ceil(t64 / 256.0) * 256.0);
-        if (e64 * 0.95 > e128) bm = 64;
+        if (e64 * 0.95 > e128 && !split3) bm = 64;
         // Body + tail: when a list of more than 256 tiles ends in a small fraction of a round (25 632 x 512: 804 tiles = 3 rounds + 36),
         // the last round runs 36 tiles on 256 CUs.  Cut those tiles along K into floor(256 / rem) pieces each instead, so the
         // remainder is one short round of the whole chip: 3 + 1/7 rounds instead of 4 (or 7 rounds of half tiles).  Costs in units of
@@ -397,7 +414,7 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
         if (g_tail_split && batch == 1 && split == 1 && (d->act == MSTTS_ACT_NONE || !d->accumulate)) {
             double best = (bm == 128 ? ceil(t128 / 256.0) : ceil(t64 / 256.0) * 0.54);
             const int ktiles = cdiv(d->K, BK);
-            for (int cand = 128; cand >= 64; cand -= 64) {
+            for (int cand = 128; cand >= (split3 ? 128 : 64); cand -= 64) {
                 const long t = (long)cdiv(d->M, cand) * cdiv(d->N, BN);
                 int rem = (int)(t % 256);
                 // with an activation the tail is made of whole tile rows (the activation runs over those rows once the pieces are summed)
@@ -415,6 +432,7 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tiles = cdiv(d->M, bm) * cdiv(d->N, BN);
     g.body = tiles; g.tail_s = 1; g.tail_kps = kps;
+    g.band = (split3 && tail_s == 1 && cdiv(d->N, BN) > 8) ? 8 : 0;
     if (tail_s > 1) {
         // the last `rem` tiles of the list as rem x tail_s blocks behind the body (highest block ids: they start as body tiles retire)
         const int rem = tail_rem, tiles_n = cdiv(d->N, BN);
@@ -428,7 +446,12 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     }
     dim3 grid(g.body + (tiles - g.body) * g.tail_s, 1, batch * split);
     const bool ta = d->trans_a != 0, tb = d->trans_b != 0;
-    if (skinny) {
+    if (split3) {
+        if (!ta && !tb) launch_gemm_split<false, false>(g, vec, grid, st);
+        else if (!ta && tb) launch_gemm_split<false, true>(g, vec, grid, st);
+        else if (ta && !tb) launch_gemm_split<true, false>(g, vec, grid, st);
+        else launch_gemm_split<true, true>(g, vec, grid, st);
+    } else if (skinny) {
         if (!ta && !tb) launch_gemm<32, false, false>(g, vec, grid, st);
         else if (!ta && tb) launch_gemm<32, false, true>(g, vec, grid, st);
         else if (ta && !tb) launch_gemm<32, true, false>(g, vec, grid, st);

@@ -122,6 +122,7 @@ SIGNATURES = {
     "mstts_debug_park_cus": (i32, [i32, i64, vp, vp]),
     "mstts_gemm_f32": (i32, [P(GemmDesc), vp]),
     "mstts_gemm_tail_split": (i32, [i32]),
+    "mstts_gemm_split3": (i32, [i32]),
     "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
     "mstts_philox_keep_mask_rows": (i32, [vp, i64, i64, i64, u64, u32, u64, f32, vp]),

@@ -55,6 +55,20 @@ def _train_depth_case(dev, B, Te, L, tag, grad_tol=5e-3):
         assert abs(got[k] - sc[k]) <= 1e-4 * max(1.0, abs(sc[k])), (k, got[k], sc[k])
     print("worst gradients:", top)
     bad = {k: v for k, v in worst.items() if v > grad_tol}
+    if bad:
+        # tell a transient error from a systematic one before failing: the same backward pass again on the same forward state, then the whole step
+        first = {k: ggot[k].astype(np.float64) for k in bad}
+        keep = {n: getattr(w, n).clone() for n in ("d_post", "d_linear", "d_pj")}
+        keep.update({"post_dz[%d]" % i: t.clone() for i, t in enumerate(w.post_dz)})
+        eng.loss_and_backward(w)
+        torch.cuda.synchronize()
+        again = eng.params.export(grads=True)
+        moved = {n: float((getattr(w, n.split("[")[0])[int(n[-2])] if "[" in n else getattr(w, n)).double().sub(t.double()).abs().max() / (t.abs().max() + 1e-30))
+                 for n, t in keep.items()}
+        print("RECHECK second backward pass on the same forward state: gradient moved by",
+              {k: float(np.abs(again[k] - first[k]).max() / (np.abs(first[k]).max() + 1e-30)) for k in bad}, "intermediates moved by", moved,
+              "fallbacks", eng.persist_fallbacks, eng.persist_bwd_fallbacks, eng.persist_enc_fallbacks)
+        _record(tag + "_recheck", dict(bad=bad, moved=moved))
     assert not bad, bad
     return w
 

@@ -22,9 +22,53 @@ def _r(dev, *shape, seed=0, scale=1.0):
     return torch.tensor(g.normal(0, scale, size=shape), dtype=torch.float32, device=dev)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 36), (32, 512, 260), (17, 81, 100), (300, 84, 64), (1, 1, 52)])
+@pytest.fixture(params=["split3", "f32_mfma"])
+def gemm_mode(request):
+    """The fp32 contractions' two inner products: the six-product bf16 split (default, csrc/gemm_split.inc) and v_mfma_f32_32x32x2_f32."""
+    lib.call("mstts_gemm_split3", 1 if request.param == "split3" else 0)
+    yield request.param
+    lib.call("mstts_gemm_split3", 1)
+
+
+@pytest.mark.parametrize("M,N,K,ta,win,sk", [(1792, 4096, 25632, 1, None, 4), (4096, 512, 2560, 0, (128, 512, 2), 1), (2560, 512, 6408, 1, (801, 512, 2), 3),
+                                              (25632, 256, 4096, 0, None, 1)])
+def test_gemm_split_is_fp32_accurate(dev, M, N, K, ta, win, sk):
+    """The six-product bf16 split against fp64 on the step's own big shapes (weight gradients over 25 632 rows, the 512-channel convolutions,
+    the prenet data gradient): its error must not exceed the error of the exact-fp32 matrix-core kernel on the same operands (both are fp32
+    accumulations of - to 2^-26 - the same products; measured: equal to within the run-to-run spread of the split-K atomics), and both sit at
+    the fp32 level (1e-6 of the result's scale), three orders of magnitude below one-term bf16 (test_gemm_bf16_layouts: 1e-2)."""
+    g = np.random.default_rng(5)
+    if win:
+        T, cin, pad = win
+        rows = M if not ta else K
+        x = torch.tensor(g.normal(0, 1, (rows, cin)), dtype=torch.float32, device=dev)
+        Kt = (K if not ta else M) // cin
+        xp = t2n(x).astype(np.float64).reshape(rows // T, T, cin)
+        xp = np.pad(xp, ((0, 0), (pad, Kt - 1 - pad), (0, 0)))
+        wins = np.stack([xp[:, k:k + T] for k in range(Kt)], axis=2).reshape(rows, Kt * cin)
+        a64 = wins.T if ta else wins
+        A = x
+    else:
+        A = torch.tensor(g.normal(0, 1, (K, M) if ta else (M, K)), dtype=torch.float32, device=dev)
+        a64 = t2n(A).astype(np.float64)
+        a64 = a64.T if ta else a64
+    B = torch.tensor(g.normal(0, 1, (K, N)), dtype=torch.float32, device=dev)
+    ref = a64 @ t2n(B).astype(np.float64)
+    errs = {}
+    for mode in (1, 0):
+        lib.call("mstts_gemm_split3", mode)
+        Cm = torch.zeros(M, N, device=dev)
+        lib.gemm(A, B, Cm, M, N, K, A.shape[1], N, N, trans_a=bool(ta), win=win, split_k=sk)
+        errs[mode] = rel_err(t2n(Cm), ref)
+    lib.call("mstts_gemm_split3", 1)
+    print("max error / max |ref|: split %.3e, f32 MFMA %.3e" % (errs[1], errs[0]))
+    assert errs[0] < 5e-6 and errs[1] < 5e-6
+    assert errs[1] <= 1.25 * errs[0] + 1e-8, errs
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 36), (32, 512, 260), (17, 81, 100), (300, 84, 64), (1, 1, 52), (260, 1100, 72)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_gemm_layouts(dev, M, N, K, ta, tb):
+def test_gemm_layouts(dev, gemm_mode, M, N, K, ta, tb):
     A = _r(dev, K, M, seed=1) if ta else _r(dev, M, K, seed=1)
     B = _r(dev, N, K, seed=2) if tb else _r(dev, K, N, seed=2)
     bias = _r(dev, N, seed=3)
@@ -35,7 +79,7 @@ def test_gemm_layouts(dev, M, N, K, ta, tb):
     assert rel_err(t2n(Cm), ref) < TOL
 
 
-def test_gemm_splitk_batch_accumulate(dev):
+def test_gemm_splitk_batch_accumulate(dev, gemm_mode):
     M, N, K, nb = 96, 160, 1000, 3
     A = _r(dev, nb, K, M, seed=4); B = _r(dev, nb, K, N, seed=5)
     Cm = torch.ones(nb, M, N, device=dev)
@@ -48,7 +92,7 @@ def test_gemm_splitk_batch_accumulate(dev):
     assert rel_err(t2n(Cm2), ref2) < TOL
 
 
-def test_gemm_dw_shapes_full_tiles(dev):
+def test_gemm_dw_shapes_full_tiles(dev, gemm_mode):
     """dW-shaped products (A as [K, M], B as [K, N]) large enough for the 128-row tile (the small cases above all take 64-row tiles):
     plain with ragged M / N / K and split-K onto ones, and a conv weight gradient (window)."""
     if True:
@@ -72,7 +116,7 @@ def test_gemm_dw_shapes_full_tiles(dev):
 
 @pytest.mark.parametrize("M,N,K,win,accumulate,act", [(8990, 512, 640, None, False, 0), (8990, 512, 330, None, True, 0), (4 * 2237, 500, 5 * 64, (2237, 64, 2), False, 0),
                                                        (17000, 140, 2048, None, False, 0), (8990, 512, 640, None, False, 2), (4 * 2237, 500, 5 * 64, (2237, 64, 2), False, 1)])
-def test_gemm_body_tail_split(dev, M, N, K, win, accumulate, act):
+def test_gemm_body_tail_split(dev, gemm_mode, M, N, K, win, accumulate, act):
     """Tile lists that end in a small fraction of a round (here 284 / 281 / 284 / 266 tiles): the last tiles are cut along K into pieces
     accumulated with atomics onto cleared tile rows - same product as with the split switched off, ragged edges included."""
     A = _r(dev, M, win[1] if win else K, seed=11)
@@ -94,7 +138,7 @@ def test_gemm_body_tail_split(dev, M, N, K, win, accumulate, act):
 
 
 @pytest.mark.parametrize("K,cin,cout,T", [(5, 32, 48, 19), (1, 8, 16, 7), (2, 8, 12, 9), (8, 8, 20, 33), (3, 64, 8, 140)])
-def test_conv1d_same_fwd_bwd(dev, K, cin, cout, T):
+def test_conv1d_same_fwd_bwd(dev, gemm_mode, K, cin, cout, T):
     """conv1d 'same' as windowed GEMM: forward, weight gradient, data gradient vs torch-free NumPy."""
     Bn = 3
     x = _r(dev, Bn, T, cin, seed=6); w = _r(dev, K, cin, cout, seed=7, scale=0.3); bias = _r(dev, cout, seed=8)

@@ -328,6 +328,25 @@ def main():
            "config": {"workload": "BASELINE.json configs[%d]: Tacotron2 train step (fwd+bwd+TF-Adam), per-GPU batch %d x (%d tokens, %d mel frames), random speaker embeddings, %s"
                                   % (2 if args.config3 else 1, B_PER_GPU, T_ENC, L, "bf16 operands with fp32 master / accumulate" if args.config3 else "fp32"),
                       "global_batch": world * B_PER_GPU, "parallelism": "dp%d" % world}}
+    if not args.config3:
+        # How the fp32 contractions are evaluated (csrc/gemm_split.inc), and the same steps with every contraction on the f32-input MFMA
+        # (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) for comparison - a short untimed-warmup + 5-step leg on rank 0 at N = 1.
+        out["config"]["fp32_contractions"] = ("fp32 operands and accumulators; every operand element split EXACTLY into three bf16 terms, six bf16 x bf16 "
+                                              "products per fp32 product on v_mfma_f32_32x32x16_bf16 (dropped terms <= 2^-26 relative, below fp32 unit roundoff; "
+                                              "error vs fp64 equal to the f32-input MFMA kernel's: tests/test_gpu_ops.py::test_gemm_split_is_fp32_accurate); "
+                                              "MSTTS_GEMM_SPLIT3=0 or mstts_gemm_split3(0) selects v_mfma_f32_32x32x2_f32 everywhere")
+        if world == 1 and not args.no_roofline:
+            lib.call("mstts_gemm_split3", 0)
+            for _ in range(2):
+                eng.train_step(batch, all_reduce=reducer)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                eng.train_step(batch, all_reduce=reducer)
+            sync()
+            out["f32_input_mfma_everywhere"] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / 5, "steps": 5}
+            out["f32_input_mfma_everywhere"]["value"] = B_PER_GPU * L / (out["f32_input_mfma_everywhere"]["ms_per_step"] * 1e-3)
+            lib.call("mstts_gemm_split3", 1)
     if dist is not None:
         out["rccl_ranks"] = dist.get_world_size()
         out["allreduce"] = {"overlapped_with_backward": not args.no_overlap, "exposed_ms_per_step": reducer.exposed_ms(),

@@ -402,7 +402,7 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     // 1 608 half tiles = 6.28 -> 7; 4 096 x 512: 128 tiles use half the chip, 256 half tiles all of it); the half tile re-reads
     // the B operand twice as often, so it has to win by more than 5 %
     int bm = skinny ? 32 : 128, tail_s = 1, tail_rem = 0;
-    const bool split3 = g_split3 && !skinny && (d->win_T <= 0 || (d->win_T >= BK && d->win_C >= BK)) && gemm_split_lds_ready();          // (128-row tiles only; two workgroups per CU, so half-filled rounds cost half as much)
+    const bool split3 = g_split3 && !skinny && d->K >= 160 && (d->win_T <= 0 || (d->win_T >= BK && d->win_C >= BK)) && gemm_split_lds_ready();   // (K < 160: the pipeline's prologue and padding tile outweigh the matrix-core time saved)          // (128-row tiles only; two workgroups per CU, so half-filled rounds cost half as much)
     if (!skinny) {
         const double t128 = (double)cdiv(d->M, 128) * cdiv(d->N, BN) * batch * split, t64 = (double)cdiv(d->M, 64) * cdiv(d->N, BN) * batch * split;
         const double e128 = t128 / (ceil(t128 / 256.0) * 256.0), e64 = t64 / (ceil(t64 / 256.0) * 256.0);
@@ -419,7 +419,10 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
                 int rem = (int)(t % 256);
                 // with an activation the tail is made of whole tile rows (the activation runs over those rows once the pieces are summed)
                 if (d->act != MSTTS_ACT_NONE) rem = (int)(t - (t - rem) / cdiv(d->N, BN) * cdiv(d->N, BN));
-                if (t <= 256 || rem == 0 || rem > 128) continue;
+                // (the split kernel has one workgroup per CU and only 128-row tiles: a list of at most 128 tiles - the encoder's 4 096-row
+                //  convolutions - leaves half the chip idle, so there EVERY tile is cut along K)
+                if (split3 && t <= 128) rem = (int)t;
+                else if (t <= 256 || rem == 0 || rem > 128) continue;
                 int s = 256 / rem;
                 if (s > 16) s = 16;
                 if (s > ktiles / 8) s = ktiles / 8;              // a piece keeps at least 8 K-tiles: below that its prologue and atomics cost more than the round it saves

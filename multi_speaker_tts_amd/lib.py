@@ -302,6 +302,8 @@ def load():
     if lib.mstts_abi_version() != ABI_VERSION:     # descriptor layouts are not visible to the symbol check above
         raise MsttsError("libmstts_hip.so reports ABI version %d, this binding is written for %d: rebuild the library (python -m multi_speaker_tts_amd.build --force)"
                          % (lib.mstts_abi_version(), ABI_VERSION))
+    if os.environ.get("MSTTS_GEMM_SPLIT3", "1") == "0":      # A/B switch: every fp32 contraction on the f32-input MFMA (see mstts_gemm_split3)
+        lib.mstts_gemm_split3(0)
     _lib = lib
     return lib
 

@@ -115,7 +115,8 @@ def test_gemm_dw_shapes_full_tiles(dev, gemm_mode):
 
 
 @pytest.mark.parametrize("M,N,K,win,accumulate,act", [(8990, 512, 640, None, False, 0), (8990, 512, 330, None, True, 0), (4 * 2237, 500, 5 * 64, (2237, 64, 2), False, 0),
-                                                       (17000, 140, 2048, None, False, 0), (8990, 512, 640, None, False, 2), (4 * 2237, 500, 5 * 64, (2237, 64, 2), False, 1)])
+                                                       (17000, 140, 2048, None, False, 0), (8990, 512, 640, None, False, 2), (4 * 2237, 500, 5 * 64, (2237, 64, 2), False, 1),
+                                                       (3000, 500, 2048, None, False, 2), (3000, 500, 2048, None, True, 0), (8 * 128, 512, 5 * 512, (128, 512, 2), False, 1)])   # at most 128 tiles: the split kernel cuts every tile
 def test_gemm_body_tail_split(dev, gemm_mode, M, N, K, win, accumulate, act):
     """Tile lists that end in a small fraction of a round (here 284 / 281 / 284 / 266 tiles): the last tiles are cut along K into pieces
     accumulated with atomics onto cleared tile rows - same product as with the split switched off, ragged edges included."""

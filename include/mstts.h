@@ -70,6 +70,10 @@ int mstts_gemm_tail_split(int32_t on);
  * six bf16 products per fp32 product (csrc/gemm_split.inc: dropped terms <= 2^-26 relative, fp32 accumulate - fp32 accuracy, 6/16 of the
  * f32-input MFMA time); 0: v_mfma_f32_32x32x2_f32 for everything (bitwise an fmaf chain).  Process-wide switch for tests and A/B runs. */
 int mstts_gemm_split3(int32_t on);
+/* Per calling thread.  1: mstts_gemm_f32 makes no K-cut the caller did not ask for with split_k (body + tail schedule and the full cut of
+ * short tile lists off): every output element is one fixed-order sum, bit-reproducible run to run.  0 (default): the schedules of DESIGN 4.7,
+ * whose cut tiles are summed with atomics (reproducible to the last bit or two).  The inference engines set it around their forward passes. */
+int mstts_gemm_deterministic(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes. */
 int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t s);

@@ -362,6 +362,11 @@ extern "C" int mstts_gemm_tail_split(int32_t on) { g_tail_split = on != 0; retur
 // the f32-input MFMA time); 0: all of them on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain).  Tests and the bench's A/B leg switch it.
 static int g_split3 = 1;
 extern "C" int mstts_gemm_split3(int32_t on) { g_split3 = on != 0; return MSTTS_OK; }
+// Per calling thread: 1 = no K-cuts that the caller did not ask for (neither the tail of a long tile list nor a short list cut entirely), so a
+// contraction without split_k adds its K range in one fixed order and its result is bit-reproducible from run to run.  The inference engines
+// set it around their forward passes (a vocoder is a long chain of contractions; at random weights it amplifies last-bit differences).
+static thread_local int t_deterministic = 0;
+extern "C" int mstts_gemm_deterministic(int32_t on) { t_deterministic = on != 0; return MSTTS_OK; }
 
 extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm: null descriptor");
@@ -411,7 +416,7 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
         // the last round runs 36 tiles on 256 CUs.  Cut those tiles along K into floor(256 / rem) pieces each instead, so the
         // remainder is one short round of the whole chip: 3 + 1/7 rounds instead of 4 (or 7 rounds of half tiles).  Costs in units of
         // one round of 128-row tiles; a half tile is 0.54 (it re-reads B twice as often), a piece pays its atomics and a short K loop.
-        if (g_tail_split && batch == 1 && split == 1 && (d->act == MSTTS_ACT_NONE || !d->accumulate)) {
+        if (g_tail_split && !t_deterministic && batch == 1 && split == 1 && (d->act == MSTTS_ACT_NONE || !d->accumulate)) {
             double best = (bm == 128 ? ceil(t128 / 256.0) : ceil(t64 / 256.0) * 0.54);
             const int ktiles = cdiv(d->K, BK);
             for (int cand = 128; cand >= (split3 ? 128 : 64); cand -= 64) {

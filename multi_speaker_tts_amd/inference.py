@@ -192,6 +192,7 @@ class InferEngine:
             call("mstts_lstm_seq_fwd_pair", C.byref(qs[0]), C.byref(qs[1]))
 
     # ------------------------------------------------------------------ sub-graphs
+    @lib.deterministic_gemm()
     def _guarded(self, fn, *a, **k):
         """A sub-graph called on its own (outside forward): the control words of its persistent LSTM launches are checked before its
         result is handed out (one stream sync), and the sub-graph is re-run launch by launch if one of them gave up."""
@@ -261,6 +262,7 @@ class InferEngine:
         gemm(values, wm, keys, B * T, d.att, M, M, d.att, d.att, b_off=owm)
         return values, keys
 
+    @lib.deterministic_gemm()
     def decode(self, values, keys, token_length, masks=None, seed=None, max_steps=None):
         """Free-running decoder.  Returns step-major linear [S,B,n_mel], stop logits [S,B], align [S,B,T]."""
         d = self.d
@@ -499,6 +501,7 @@ class InferEngine:
         return spec.view(B, S, d.n_spec)
 
     # ------------------------------------------------------------------ whole forward
+    @lib.deterministic_gemm()
     def forward(self, pattern, masks=None, seed=None, max_steps=None, with_vocoder=True):
         """See _forward.  A persistent LSTM launch that gave up (bounded waits, no co-residency) invalidates what was computed from its output:
         the pass is run again with the launch-per-step drivers."""

@@ -123,6 +123,7 @@ SIGNATURES = {
     "mstts_gemm_f32": (i32, [P(GemmDesc), vp]),
     "mstts_gemm_tail_split": (i32, [i32]),
     "mstts_gemm_split3": (i32, [i32]),
+    "mstts_gemm_deterministic": (i32, [i32]),
     "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
     "mstts_philox_keep_mask_rows": (i32, [vp, i64, i64, i64, u64, u32, u64, f32, vp]),
@@ -306,6 +307,34 @@ def load():
         lib.mstts_gemm_split3(0)
     _lib = lib
     return lib
+
+
+class deterministic_gemm:
+    """Context manager / decorator: inside it (on this thread) mstts_gemm_f32 makes no K-cut of its own - one fixed summation order per output
+    element, bit-reproducible run to run (mstts_gemm_deterministic).  Nests."""
+    _depth = __import__("threading").local()
+
+    def __enter__(self):
+        n = getattr(self._depth, "n", 0)
+        if n == 0:
+            load().mstts_gemm_deterministic(1)
+        self._depth.n = n + 1
+        return self
+
+    def __exit__(self, *exc):
+        self._depth.n -= 1
+        if self._depth.n == 0:
+            load().mstts_gemm_deterministic(0)
+        return False
+
+    def __call__(self, fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            with deterministic_gemm():
+                return fn(*a, **k)
+        return wrapped
 
 
 def stream():

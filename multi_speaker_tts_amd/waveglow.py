@@ -155,6 +155,7 @@ class WaveGlowEngine:
         return t
 
     # ------------------------------------------------------------------ Glow_Inference
+    @lib.deterministic_gemm()          # bit-reproducible per latent seed: no K-cuts with atomics inside the flow's contractions
     def infer(self, mel, noise=None, seed=None, sigma=1.0):
         """mel [N, T, n_mel] (tensor or array) -> wav tensor [N, (T-1)*stride + kernel].  noise: {"z": [N,L/G,z_channels],
         "early_<flow>": [N,L/G,early_size]} to inject the latents, else Philox normals of `seed`."""

@@ -138,6 +138,25 @@ def test_gemm_body_tail_split(dev, gemm_mode, M, N, K, win, accumulate, act):
         assert rel_err(outs[0][:M], ref) < TOL
 
 
+def test_gemm_deterministic_switch(dev):
+    """mstts_gemm_deterministic (per thread): with it a short tile list (96 tiles - cut along K otherwise) and a list with a tail are bit-equal
+    from run to run; the context manager nests and restores."""
+    for M, N, K in ((3000, 500, 4096), (8990, 512, 640)):
+        A = _r(dev, M, K, seed=31); B = _r(dev, K, N, seed=32)
+        outs = []
+        with lib.deterministic_gemm():
+            with lib.deterministic_gemm():
+                pass
+            for _ in range(3):
+                Cm = torch.zeros(M, N, device=dev)
+                lib.gemm(A, B, Cm, M, N, K, K, N, N)
+                outs.append(t2n(Cm))
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        Cm = torch.zeros(M, N, device=dev)
+        lib.gemm(A, B, Cm, M, N, K, K, N, N)                 # outside: the K-cut schedules, same product to fp32 rounding
+        assert rel_err(t2n(Cm), outs[0].astype(np.float64)) < 1e-5
+
+
 @pytest.mark.parametrize("K,cin,cout,T", [(5, 32, 48, 19), (1, 8, 16, 7), (2, 8, 12, 9), (8, 8, 20, 33), (3, 64, 8, 140)])
 def test_conv1d_same_fwd_bwd(dev, gemm_mode, K, cin, cout, T):
     """conv1d 'same' as windowed GEMM: forward, weight gradient, data gradient vs torch-free NumPy."""

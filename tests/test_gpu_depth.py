@@ -54,6 +54,15 @@ def _train_depth_case(dev, B, Te, L, tag, grad_tol=5e-3):
     for k in ("Linear_Loss", "Postnet_Loss", "Stop_Loss", "Loss"):
         assert abs(got[k] - sc[k]) <= 1e-4 * max(1.0, abs(sc[k])), (k, got[k], sc[k])
     print("worst gradients:", top)
+    # the same backward pass a second time on the same forward state: the two gradient slabs differ only by the order of the split-K atomics
+    # (recorded: a transient error in one pass would show here whether or not it crosses the parity bound)
+    g_first = eng.params.grad.clone()
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    repeat_diff = float((eng.params.grad - g_first).abs().max() / g_first.abs().max())
+    _record(tag + "_backward_twice", dict(B=B, tokens=Te, L=L, max_abs_diff_over_max_abs=repeat_diff))
+    print("backward pass twice on the same forward state: max |difference| / max |gradient| = %.2e" % repeat_diff)
+    assert repeat_diff < 1e-4, repeat_diff
     bad = {k: v for k, v in worst.items() if v > grad_tol}
     if bad:
         # tell a transient error from a systematic one before failing: the same backward pass again on the same forward state, then the whole step

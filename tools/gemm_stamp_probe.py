@@ -1,5 +1,7 @@
+"""Barrier-time stamps of the split GEMM's consumer waves (build with MSTTS_EXTRA_HIPCC_FLAGS=-DGS_STAMP): per K-tile, cycles a consumer wave of
+workgroup 0 spends inside the barrier and outside it (1 536 = the MFMA issue time of a tile).  usage: python tools/gemm_stamp_probe.py"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multi_speaker_tts_amd import lib
 dev = torch.device("cuda:0")
@@ -10,5 +12,4 @@ for (M, N, K, ta) in ((8192, 8192, 8192, 0), (2048, 4096, 12816, 1)):
         lib.gemm(A, B, Cm, M, N, K, A.shape[1], N, N, trans_a=bool(ta), bias=st.view(torch.float32))
     torch.cuda.synchronize()
     v = st.cpu().tolist()
-    print(M, N, K, "consumer: wait %d of %d cycles over %d tiles (%.0f + %.0f per tile) | producer: wait %d of %d (%.0f + %.0f per tile), of which waiting for the older register set on every second tile %.0f" % (
-        v[0], v[1], v[2], v[0] / v[2], (v[1] - v[0]) / v[2], v[4], v[5], v[4] / v[6], (v[5] - v[4]) / v[6], v[7] / (v[6] / 2)))
+    print(M, N, K, "consumer: waits %.0f + busy %.0f cycles per K-tile over %d tiles" % (v[0] / max(v[2], 1), (v[1] - v[0]) / max(v[2], 1), v[2]))

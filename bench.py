@@ -13,6 +13,9 @@ Prints ONE JSON line on rank 0.
       context (the flight time of the outbound hand-off), the stricter reading.  The launch-per-step attention kernel is measured beside
       it with HIP events around every launch (`roofline.launch_per_step`).  `traffic` comes from the committed rocprofv3 PMC pass named
       in `traffic_source`; `traffic_stale` says whether the kernel sources have changed since that pass was taken.
+  `config.fp32_contractions` / `f32_input_mfma_everywhere`: how the hoisted fp32 contractions are evaluated (exact three-way bf16 split, six
+      products per fp32 product on the bf16 matrix cores, fp32 accuracy - csrc/gemm_split.inc), and the same train step timed for 5 more
+      steps with every contraction on the f32-input MFMA instead (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), N = 1 only.
   `cpu_baseline`: the oracle (torch-CPU fp32 restatement of the same graph) timed on this host at the FULL workload: thread sweep on a
       short prefix, then 1 warm-up + 3 timed full train steps at the best thread count, median (falls back to a truncated sample only
       when a full step would not fit the time limit, and says so).

@@ -67,6 +67,7 @@ def _split_k(M, N, K, n_cu=256, max_split=16):
 
 PERSIST_STRIKES = 2          # consecutive steps with a fallback before the persistent plans are switched off ...
 PERSIST_COOLDOWN = 200       # ... for this many steps
+ENC_OVERLAP = os.environ.get("MSTTS_ENC_OVERLAP", "1") != "0"    # the encoder's persistent launches on their own stream, under decoder-side products that do not depend on them
 
 
 class _WS:
@@ -150,6 +151,7 @@ class TrainEngine:
             self.enc_pk = {dr: (self._f(n), self._f(n)) for dr in ("fw", "bw")}          # (forward order, BPTT order)
         if self.persist or self.persist_enc:
             self._side = torch.cuda.Stream(device=self.device)
+            self._enc_stream = torch.cuda.Stream(device=self.device)          # the encoder's persistent BPTT (loss_and_backward)
         if self.persist_bwd:
             self.pkb = [self._f(int(lb.mstts_persist_bwd_pack_floats(i))) for i in range(3)]
         self.flip = {}
@@ -482,17 +484,22 @@ class TrainEngine:
             if self.enc_whp is not None:                 # fused steps: packed recurrent kernel + packed h blocks
                 q.wh_p, q.h_p = ptr(self.enc_whp[dr]), ptr(w.enc_hp[dr])
             seqs.append(q)
-        enc_ticket = None
+        enc_ticket, enc_done = None, None
         w.enc_hist_valid = bool(getattr(w, "persist_enc", False)) and allowed
-        if w.enc_hist_valid:
-            enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)       # (status read at the end of the pass)
+        if w.enc_hist_valid and ENC_OVERLAP:
+            # (the persistent launch occupies 64 of the 256 CUs for 0.34 ms: on its own stream, under the decoder's hoisted prenet, which does not depend on it)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._enc_stream):
+                self._enc_stream.wait_event(ready)
+                enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)   # (status read at the end of the pass)
+                enc_done = torch.cuda.Event()
+                enc_done.record()
+        elif w.enc_hist_valid:
+            enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_fwd_pair_persistent", seqs, 0, 64)
         if not w.enc_hist_valid:
             self._ensure_fallback_packs()
             call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
-        # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
-        call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
-        wm, owm = self.P("attention/memory_layer/kernel")
-        self._gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)
         # ---- hoisted prenet over all S frames (Modules.py:239-255) and cell-0 input product
         call("mstts_shift_frames", ptr(mel), ptr(w.frames), B, L, d.n_mel)
         x, cin = w.frames, d.n_mel
@@ -501,6 +508,12 @@ class TrainEngine:
             self._gemm(x, k, w.pre_a[i], S * B, Pn, cin, cin, Pn, Pn, bias=b, act=ACT_RELU, b_off=ok, bias_off=ob)
             call("mstts_dropout", ptr(w.pre_a[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(w.pre_d[i]), S * B * Pn)
             x, cin = w.pre_d[i], Pn
+        if enc_done is not None:
+            torch.cuda.current_stream().wait_event(enc_done)
+        # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
+        call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
+        wm, owm = self.P("attention/memory_layer/kernel")
+        self._gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)
         k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
         # cell-0 input product xw0 = prenet . W0[:P] + b0: inside the persistent launch (fp32 mode, 256-wide prenet), else hoisted here
         w.fold_prenet = w.persist_now and self.gemm_dtype == "f32" and Pn == 256 and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"
@@ -770,48 +783,50 @@ class TrainEngine:
             call("mstts_decoder_train_bwd", C.byref(db))
         if postnet_ready_deferred:
             on_ready(*self._grad_range("decoder/conv_"))
-        # hoisted weight gradients of the loop.  (Running them chunk by chunk on a second stream under BPTT was measured: the
-        # GEMMs' MFMA traffic slows every latency-bound loop kernel by 25-35 %, 105.4 vs 102.2 ms per step - not kept.)
-        self._recurrent_wgrads(w, 0, S)
-        g0, og0 = self.G(CELL % 0 + "kernel")
-        call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + Pn * 4 * H), 4 * H, M, 4 * H, 1)
-        call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + (Pn + M) * 4 * H), 4 * H, M, 4 * H, 1)
-        call("mstts_copy2d", ptr(self.dw0f, M * 4 * H), 4 * H, ptr(g0, og0 + (Pn + 2 * M) * 4 * H), 4 * H, H, 4 * H, 1)
-        # prenet backward (d_pre = dg0 . W0[:P]^T was produced per chunk above)
-        dcur, dnxt = w.d_pre, w.d_pre2
-        for i in range(d.prenet_n - 1, -1, -1):
-            cin = d.n_mel if i == 0 else Pn
-            x_in = w.frames if i == 0 else w.pre_d[i - 1]
-            call("mstts_relu_dropout_bwd", ptr(dcur), ptr(w.pre_d[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(dcur), SB * Pn)
-            gk, ogk = self.G("decoder/decoder/prenet_%d/dense/kernel" % i); gb, ogb = self.G("decoder/decoder/prenet_%d/dense/bias" % i)
-            self._gemm(x_in, dcur, gk, cin, Pn, SB, cin, Pn, Pn, trans_a=True, split_k=max(2, _split_k(cin, Pn, SB)), c_off=ogk)
-            call("mstts_colsum", ptr(dcur), SB, Pn, Pn, ptr(gb, ogb), 1)
-            if i > 0:
-                k, ok = self.P("decoder/decoder/prenet_%d/dense/kernel" % i)
-                self._gemm(dcur, k, dnxt, SB, cin, Pn, Pn, Pn, cin, trans_b=True, b_off=ok)
-                dcur, dnxt = dnxt, dcur
-        gs = {}
-        for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
-                            ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
-            t, o = self.G(LSA + name)
-            gs[field] = ptr(t, o)
-        ls = w.dec.lsa
-        call("mstts_lsa_unfold_location_grad", ls.conv_k, ls.conv_b, ls.dense_k, ptr(self.d_loc_k), gs["score_b"],
-             gs["conv_k"], gs["conv_b"], gs["dense_k"], d.att_k, d.att_ch, d.att)
-        # d_values[b] = sum_s align[s,b,:]^T (d_ctx from projection + d_ctx from next step's cell 0)
-        self._gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
-                   strides=(Te, H + M, Te * M), b_off=H, exact=True)
-        if S > 1:
-            for part in range(parts):
-                self._gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
-                           strides=(Te, M + H, Te * M), b_off=(part * S + 1) * B * (M + H), accumulate=True, exact=True)
-        # memory layer
-        wm, owm = self.P("attention/memory_layer/kernel"); gwm, ogwm = self.G("attention/memory_layer/kernel")
-        self._gemm(w.values, w.d_keys, gwm, M, A, B * Te, M, A, A, trans_a=True, split_k=max(2, _split_k(M, A, B * Te)), c_off=ogwm)
-        self._gemm(w.d_keys, wm, w.d_values, B * Te, M, A, A, A, M, trans_b=True, accumulate=True, b_off=owm)
-        if on_ready is not None:             # decoder + attention gradients are final: overlaps the encoder backward
-            on_ready(*self._grad_range("attention/", "decoder/decoder"))
-        # ---- encoder BiLSTM backward
+        def decoder_products():
+            # hoisted weight gradients of the loop.  (Running them chunk by chunk on a second stream under BPTT was measured: the
+            # GEMMs' MFMA traffic slows every latency-bound loop kernel by 25-35 %, 105.4 vs 102.2 ms per step - not kept.)
+            self._recurrent_wgrads(w, 0, S, part="products")
+            g0, og0 = self.G(CELL % 0 + "kernel")
+            call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + Pn * 4 * H), 4 * H, M, 4 * H, 1)
+            call("mstts_copy2d", ptr(self.dw0f), 4 * H, ptr(g0, og0 + (Pn + M) * 4 * H), 4 * H, M, 4 * H, 1)
+            call("mstts_copy2d", ptr(self.dw0f, M * 4 * H), 4 * H, ptr(g0, og0 + (Pn + 2 * M) * 4 * H), 4 * H, H, 4 * H, 1)
+            # prenet backward (d_pre = dg0 . W0[:P]^T was produced per chunk above)
+            dcur, dnxt = w.d_pre, w.d_pre2
+            for i in range(d.prenet_n - 1, -1, -1):
+                cin = d.n_mel if i == 0 else Pn
+                x_in = w.frames if i == 0 else w.pre_d[i - 1]
+                call("mstts_relu_dropout_bwd", ptr(dcur), ptr(w.pre_d[i]), ptr(mk["prenet_drop_%d" % i]), 1 - d.prenet_drop, ptr(dcur), SB * Pn)
+                gk, ogk = self.G("decoder/decoder/prenet_%d/dense/kernel" % i); gb, ogb = self.G("decoder/decoder/prenet_%d/dense/bias" % i)
+                self._gemm(x_in, dcur, gk, cin, Pn, SB, cin, Pn, Pn, trans_a=True, split_k=max(2, _split_k(cin, Pn, SB)), c_off=ogk)
+                call("mstts_colsum", ptr(dcur), SB, Pn, Pn, ptr(gb, ogb), 1)
+                if i > 0:
+                    k, ok = self.P("decoder/decoder/prenet_%d/dense/kernel" % i)
+                    self._gemm(dcur, k, dnxt, SB, cin, Pn, Pn, Pn, cin, trans_b=True, b_off=ok)
+                    dcur, dnxt = dnxt, dcur
+            gs = {}
+            for field, name in (("conv_k", "attention_convolution_dense_layer/conv1d/kernel"), ("conv_b", "attention_convolution_dense_layer/conv1d/bias"),
+                                ("dense_k", "attention_convolution_dense_layer/dense/kernel"), ("score_w", "score_layer/weight_w"), ("score_b", "score_layer/bias_b")):
+                t, o = self.G(LSA + name)
+                gs[field] = ptr(t, o)
+            ls = w.dec.lsa
+            call("mstts_lsa_unfold_location_grad", ls.conv_k, ls.conv_b, ls.dense_k, ptr(self.d_loc_k), gs["score_b"],
+                 gs["conv_k"], gs["conv_b"], gs["dense_k"], d.att_k, d.att_ch, d.att)
+
+        def memory_gradient():
+            # d_values[b] = sum_s align[s,b,:]^T (d_ctx from projection + d_ctx from next step's cell 0)
+            self._gemm(w.align_hist, w.d_pj, w.d_values, Te, M, S, B * Te, B * (H + M), M, trans_a=True, batch=B,
+                       strides=(Te, H + M, Te * M), b_off=H, exact=True)
+            if S > 1:
+                for part in range(parts):
+                    self._gemm(w.align_hist, w.d_in0, w.d_values, Te, M, S - 1, B * Te, B * (M + H), M, trans_a=True, batch=B,
+                               strides=(Te, M + H, Te * M), b_off=(part * S + 1) * B * (M + H), accumulate=True, exact=True)
+            # memory layer
+            wm, owm = self.P("attention/memory_layer/kernel"); gwm, ogwm = self.G("attention/memory_layer/kernel")
+            self._gemm(w.values, w.d_keys, gwm, M, A, B * Te, M, A, A, trans_a=True, split_k=max(2, _split_k(M, A, B * Te)), c_off=ogwm)
+            self._gemm(w.d_keys, wm, w.d_values, B * Te, M, A, A, A, M, trans_b=True, accumulate=True, b_off=owm)
+
+        # ---- encoder BiLSTM backward: descriptors
         x_in, cin = w.enc_y[-1], d.enc_conv_ch
         bseqs = []
         for di, dr in enumerate(("fw", "bw")):
@@ -827,11 +842,35 @@ class TrainEngine:
             bseqs.append(q)
         # (the persistent BPTT reads the packed history of a persistent forward)
         enc_ticket = None
-        if getattr(w, "enc_hist_valid", False) and not _redo:
-            enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)
+        enc_persistent = bool(getattr(w, "enc_hist_valid", False)) and not _redo
+        if enc_persistent and ENC_OVERLAP:
+            # The encoder's persistent BPTT occupies 32 of the 256 CUs for 0.65 ms: it runs on its own stream UNDER the decoder's hoisted weight-gradient
+            # products instead of in front of the encoder's.  What it waits for - the attention parameter gradients' d_keys, the memory gradient -
+            # is computed first; its launch is enqueued before the products, so its 32 workgroups are resident when the products' tiles arrive.
+            self._recurrent_wgrads(w, 0, S, part="attention")
+            memory_gradient()
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._enc_stream):
+                self._enc_stream.wait_event(ready)
+                enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)
+                enc_done = torch.cuda.Event()
+                enc_done.record()
+            decoder_products()
+            if on_ready is not None:         # decoder + attention gradients are final: overlaps the encoder backward
+                on_ready(*self._grad_range("attention/", "decoder/decoder"))
+            torch.cuda.current_stream().wait_event(enc_done)
         else:
-            self._ensure_fallback_packs()
-            call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
+            self._recurrent_wgrads(w, 0, S, part="attention")
+            decoder_products()
+            memory_gradient()
+            if on_ready is not None:
+                on_ready(*self._grad_range("attention/", "decoder/decoder"))
+            if enc_persistent:
+                enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)
+            else:
+                self._ensure_fallback_packs()
+                call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
         for di, dr in enumerate(("fw", "bw")):
             k, ok = self.P(ENC_CELL % dr + "kernel")
             gk, ogk = self.G(ENC_CELL % dr + "kernel"); gb, ogb = self.G(ENC_CELL % dr + "bias")
@@ -874,15 +913,22 @@ class TrainEngine:
             torch.cuda.current_stream().synchronize()
             return self.loss_and_backward(w, grad_scale=grad_scale, on_ready=on_ready, on_abort=on_abort, _redo=True)
 
-    def _recurrent_wgrads(self, w, lo, hi):
+    def _recurrent_wgrads(self, w, lo, hi, part="all"):
         """Weight gradients of the decoder loop summed over the steps [lo, hi) (accumulating into the gradient slab):
         dW1, db1, dw0f (folded cell-0 rows), cell-0 prenet rows, db0, dWq, the attention parameter gradients and d_keys; also
-        that range of d_pre = dg0 . W0[:P]^T for the prenet backward."""
+        that range of d_pre = dg0 . W0[:P]^T for the prenet backward.  part: "attention" = the attention parameter gradients and d_keys only
+        (what the encoder's gradient path waits for), "products" = everything else, "all"."""
         d = self.d
         B, Te = w.B, w.Te
         H, M, A, Pn = d.dec_lstm, d.mem, d.att, d.prenet
         n = (hi - lo) * B
         r = lo * B                                           # first row of the range in the step-major histories
+        if part in ("all", "attention"):
+            gsw, ogsw = self.G(LSA + "score_layer/weight_w"); gsb, ogsb = self.G(LSA + "score_layer/bias_b")
+            call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), hi - lo, ptr(w.q_hist, r * A), ptr(w.cum_hist, r * Te), ptr(w.de_hist, r * Te), ptr(w.d_keys),
+                 ptr(self.d_loc_k), ptr(gsw, ogsw), ptr(gsb, ogsb), ptr(w.lsa_param_ws))
+        if part == "attention":
+            return
         g1, og1 = self.G(CELL % 1 + "kernel"); gb1, ogb1 = self.G(CELL % 1 + "bias")
         self._gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, n, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, n), accumulate=True,
              a_off=r * 2 * H, b_off=r * 4 * H, c_off=og1)
@@ -897,9 +943,6 @@ class TrainEngine:
         self._gemm(w.dg0, k0, w.d_pre, n, Pn, 4 * H, 4 * H, 4 * H, Pn, trans_b=True, a_off=r * 4 * H, b_off=o0, c_off=r * Pn)
         gq, ogq = self.G(LSA + "query_layer/kernel")
         self._gemm(w.pj, w.dq_hist, gq, H, A, n, H + M, A, A, trans_a=True, split_k=max(2, _split_k(H, A, n)), a_off=r * (H + M), b_off=r * A, c_off=ogq)
-        gsw, ogsw = self.G(LSA + "score_layer/weight_w"); gsb, ogsb = self.G(LSA + "score_layer/bias_b")
-        call("mstts_lsa_param_bwd", C.byref(w.dec.lsa), hi - lo, ptr(w.q_hist, r * A), ptr(w.cum_hist, r * Te), ptr(w.de_hist, r * Te), ptr(w.d_keys),
-             ptr(self.d_loc_k), ptr(gsw, ogsw), ptr(gsb, ogsb), ptr(w.lsa_param_ws))
 
     def _grad_range(self, *prefixes):
         """[lo, hi) of the gradient slab covered by the trainable variables whose names start with one of `prefixes` (the

@@ -450,10 +450,13 @@ class TrainEngine:
             if self._moving_snapshot is None or self._moving_snapshot.numel() != n_mov:
                 self._moving_snapshot = torch.empty(n_mov, dtype=torch.float32, device=self.device)
             self._moving_snapshot.copy_(self.params.frozen[:n_mov])
+        # (the decoder-side masks are drawn under the encoder's persistent launch when that runs on its own stream)
+        late_masks = masks is None and bool(getattr(w, "persist_enc", False)) and allowed and ENC_OVERLAP
+        mask_seed = seed if seed is not None else step_seed(self.seed, self.global_step)
         if masks is not None:
             w.masks.load(masks)
         else:
-            w.masks.draw(seed if seed is not None else step_seed(self.seed, self.global_step))
+            w.masks.draw(mask_seed, only=(lambda n: n.startswith("enc_")) if late_masks else None)
         mk = w.masks
         self._bnws = w.bn_ws
         tok, tlen = batch["Token"], batch["Token_Length"]
@@ -500,6 +503,8 @@ class TrainEngine:
         if not w.enc_hist_valid:
             self._ensure_fallback_packs()
             call("mstts_lstm_seq_fwd_pair", C.byref(seqs[0]), C.byref(seqs[1]))     # both directions advance together: one launch per step
+        if late_masks:
+            w.masks.draw(mask_seed, only=lambda n: not n.startswith("enc_"))
         # ---- hoisted prenet over all S frames (Modules.py:239-255) and cell-0 input product
         call("mstts_shift_frames", ptr(mel), ptr(w.frames), B, L, d.n_mel)
         x, cin = w.frames, d.n_mel

@@ -64,10 +64,13 @@ class MaskSet:
             n = int(np.prod(shape))
             self.buf[name] = torch.empty((n + 3) // 4 * 4, dtype=torch.uint8, device=device)[:n].view(shape)
 
-    def draw(self, seed):
+    def draw(self, seed, only=None):
         """Masks are keyed by (seed, stream, GLOBAL sample index, position in the sample): rank r holds the samples
-        r * B .. r * B + B - 1 of the global batch, so 1/2/4/8-rank runs draw the same mask for the same sample."""
+        r * B .. r * B + B - 1 of the global batch, so 1/2/4/8-rank runs draw the same mask for the same sample.
+        only: a predicate on the mask name (draw a subset now, the rest later)."""
         for name, stream, shape, keep in self.spec:
+            if only is not None and not only(name):
+                continue
             ax = batch_axis(name)
             outer, nb = (1, shape[0]) if ax == 0 else (shape[0], shape[1])
             inner = int(np.prod(shape[ax + 1:]))

@@ -193,6 +193,14 @@ def test_train_step_with_and_without_the_persistent_encoder(dev, monkeypatch):
     scale = np.abs(c).max()
     assert np.abs(a - c).max() < 2e-4 * scale, np.abs(a - c).max() / scale
     assert np.abs(b - c).max() < 2e-4 * scale, np.abs(b - c).max() / scale
+    # the persistent launches in the serial order (not on their own stream under the decoder-side products): the same gradients
+    import multi_speaker_tts_amd.engine as E
+    assert E.ENC_OVERLAP
+    w.persist_enc = True
+    monkeypatch.setattr(E, "ENC_OVERLAP", False)
+    e = grads()
+    assert w.enc_hist_valid and eng.persist_enc_fallbacks == 1
+    assert np.abs(e - a).max() < 2e-5 * scale, np.abs(e - a).max() / scale
 
 
 @pytest.mark.parametrize("B,T", [(70, 21), (320, 12), (33, 5)])

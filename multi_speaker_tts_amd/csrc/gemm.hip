@@ -337,17 +337,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     gemm_store_tile<WM, WN>(g, acc, C, m0 + wrow, n0 + wcol, lane, split == 0 && piece <= 0, g.split_k > 1 || piece >= 0);
 }
 
-// rows r0 .. M of C (N columns, row stride ldc) := 0, four elements per thread
-__global__ void gemm_clear_rows_kernel(float* __restrict__ C, long ldc, int N, long n) {
-    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= n) return;
-    if (ldc == N && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && i0 + 4 <= n) {
-        *reinterpret_cast<float4*>(C + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    for (long i = i0; i < i0 + 4 && i < n; ++i) C[(i / N) * ldc + (i % N)] = 0.f;
-}
-
 __global__ void gemm_tail_act_kernel(float* __restrict__ C, long ldc, int N, long n, int act) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -459,9 +448,8 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
         g.tail_kps = (cdiv(g.K, BK) + tail_s - 1) / tail_s * BK;
         if (!d->accumulate) {           // the pieces add onto zeros: clear every tile row that holds a tail tile (body tiles of a mixed row overwrite)
             const long r0 = (long)(g.body / tiles_n) * bm;
-            // (a kernel of our own: hipMemset2DAsync takes 37 us per call whatever the size - 17 calls, 0.63 ms per train step)
-            const long n_clear = (d->M - r0) * d->N;
-            hipLaunchKernelGGL(gemm_clear_rows_kernel, dim3((unsigned)cdiv(n_clear, 1024)), dim3(256), 0, st, d->C + r0 * d->ldc, d->ldc, (int)d->N, n_clear);
+            if (hipMemset2DAsync(d->C + r0 * d->ldc, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)(d->M - r0), st) != hipSuccess)
+                MSTTS_REQUIRE(false, MSTTS_ERR_LAUNCH, "gemm: clearing the tail tiles failed");
         }
     }
     dim3 grid(g.body + (tiles - g.body) * g.tail_s, 1, batch * split);

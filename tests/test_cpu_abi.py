@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -109,3 +111,37 @@ def test_split_k_choices_of_the_train_step():
     for M, N, K in ((256, 4096, 25632), (1024, 128, 25632), (80, 256, 25632), (512, 1024, 4096)):
         sk = _split_k(M, N, K)
         assert 1 <= sk <= 64 and (K < 16384 or K // sk >= 400)          # (a handful of tiles may be split up to 64 ways: one workgroup per CU)
+
+
+def test_deterministic_gemm_context_nests(monkeypatch):
+    """Host logic of lib.deterministic_gemm: the per-thread switch goes on at the outermost entry and off at the outermost exit, also through
+    the decorator form and across an exception; another thread starts from its own depth 0."""
+    import threading
+    from multi_speaker_tts_amd import lib
+    L = lib.load()
+    calls = []
+    real = L.mstts_gemm_deterministic
+    monkeypatch.setattr(L, "mstts_gemm_deterministic", lambda on: calls.append((threading.get_ident(), on)) or real(on))
+    me = threading.get_ident()
+    with lib.deterministic_gemm():
+        with lib.deterministic_gemm():
+            pass
+
+        @lib.deterministic_gemm()
+        def f():
+            return 7
+        assert f() == 7
+        assert calls == [(me, 1)]
+    assert calls == [(me, 1), (me, 0)]
+    with pytest.raises(ValueError):
+        with lib.deterministic_gemm():
+            raise ValueError("x")
+    assert calls[-2:] == [(me, 1), (me, 0)]
+    seen = []
+
+    def other():
+        with lib.deterministic_gemm():
+            seen.append([c for c in calls if c[0] == threading.get_ident()])
+    with lib.deterministic_gemm():
+        t = threading.Thread(target=other); t.start(); t.join()
+    assert seen and seen[0] == [(seen[0][0][0], 1)]

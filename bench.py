@@ -297,8 +297,9 @@ def main():
                       gemm_dtype="bf16" if args.config3 else "f32")
     batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
     # config 3: bf16 gradient message with fp32 accumulation on receipt; the fp32 headline keeps the fp32 all-reduce
-    reducer = GradAllReduce(eng.params.grad, world, comm_dtype="bf16" if args.config3 else "f32", overlap=not args.no_overlap,
+    reducer = GradAllReduce(eng.params.grad, world, comm_dtype="bf16" if args.config3 else "f32", overlap=not args.no_overlap, trace=True,
                             **({"force": True} if args.force_allreduce else {})) if (world > 1 or args.force_allreduce) else None
+    eng.trace_events = reducer is not None
 
     def sync():
         if dist is not None:
@@ -350,16 +351,42 @@ def main():
             out["f32_input_mfma_everywhere"] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / 5, "steps": 5}
             out["f32_input_mfma_everywhere"]["value"] = B_PER_GPU * L / (out["f32_input_mfma_everywhere"]["ms_per_step"] * 1e-3)
             lib.call("mstts_gemm_split3", 1)
+    # health counters of the persistent launches: in a multi-rank job every rank's, not rank 0's (a rank that falls back every step drags
+    # the whole job - the step time is the slowest rank's - and must not hide behind a healthy rank 0): sum and maximum over the ranks
+    counters = {"decoder_forward": eng.persist_fallbacks, "decoder_bptt": eng.persist_bwd_fallbacks, "encoder_bilstm": eng.persist_enc_fallbacks,
+                "non_persistent_plans": eng.non_persistent_plans, "persist_disabled_steps": eng.persist_disabled_steps, "collective_redos": eng.collective_redos}
+    per_rank_max = dict(counters)
     if dist is not None:
+        exposed = reducer.exposed_ms()
+        trace = reducer.first_piece_trace(eng.bptt_end_event) if eng.bptt_end_event is not None else None
+        vec = torch.tensor([float(v) for v in counters.values()] + [exposed] + (list(trace[:2]) if trace else [0.0, 0.0]), dtype=torch.float64, device=device)
+        vmax, vsum = vec.clone(), vec.clone()
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+        n = len(counters)
+        per_rank_max = {k: int(vmax[i].item()) for i, k in enumerate(counters)}
+        counters = {k: int(vsum[i].item()) for i, k in enumerate(counters)}
         out["rccl_ranks"] = dist.get_world_size()
-        out["allreduce"] = {"overlapped_with_backward": not args.no_overlap, "exposed_ms_per_step": reducer.exposed_ms(),
+        out["allreduce"] = {"overlapped_with_backward": not args.no_overlap, "exposed_ms_per_step": float(vmax[n].item()),
+                            "exposed_ms_per_step_mean_over_ranks": float(vsum[n].item()) / dist.get_world_size(),
                             "message": "bf16, fp32 accumulate" if args.config3 else "fp32", "bytes_per_rank": eng.params.grad.numel() * (2 if args.config3 else 4)}
+        if trace:
+            # last timed step, maximum over the ranks: the first range (postnet, announced right behind the persistent BPTT launch on the compute
+            # stream) and the end of its first piece, both relative to the END of persist_bwd_kernel.  A piece that ends about
+            # bytes / link rate after its announcement ran under the hoisted weight-gradient products; one that ends near the end of the
+            # backward pass queued behind them.
+            out["allreduce"]["first_collective_start_vs_bptt_end_ms"] = float(vmax[n + 1].item())
+            out["allreduce"]["first_piece_end_vs_bptt_end_ms"] = float(vmax[n + 2].item())
+            out["allreduce"]["first_piece_bytes"] = int(trace[2]) * (2 if args.config3 else 4)
 
-    out["persistent_launches"] = {"decoder_forward": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist", False)),
-                                  "decoder_bptt": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist_bwd", False)),
-                                  "encoder_bilstm": bool(getattr(eng.plan(B_PER_GPU, T_ENC, L), "persist_enc", False)),
-                                  "fallbacks": {"decoder_forward": eng.persist_fallbacks, "decoder_bptt": eng.persist_bwd_fallbacks, "encoder_bilstm": eng.persist_enc_fallbacks},
-                                  "non_persistent_plans": eng.non_persistent_plans, "persist_disabled_steps": eng.persist_disabled_steps}
+    plan0 = eng.plan(B_PER_GPU, T_ENC, L)
+    out["persistent_launches"] = {"decoder_forward": bool(getattr(plan0, "persist", False)),
+                                  "decoder_bptt": bool(getattr(plan0, "persist_bwd", False)),
+                                  "encoder_bilstm": bool(getattr(plan0, "persist_enc", False)),
+                                  "fallbacks": {k: counters[k] for k in ("decoder_forward", "decoder_bptt", "encoder_bilstm")},
+                                  "non_persistent_plans": counters["non_persistent_plans"], "persist_disabled_steps": counters["persist_disabled_steps"],
+                                  "collective_redos": counters["collective_redos"],
+                                  "scope": "sum over all %d ranks" % world, "max_over_ranks": per_rank_max}
     if rank == 0 and not args.no_roofline:
         w = eng.plan(B_PER_GPU, T_ENC, L)
         S = L + 1

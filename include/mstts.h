@@ -68,7 +68,15 @@ int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t s);
 int mstts_gemm_tail_split(int32_t on);
 /* 1 (default): contractions with more than 32 rows run on the bf16 matrix cores as an EXACT three-way split of every fp32 operand element and
  * six bf16 products per fp32 product (csrc/gemm_split.inc: dropped terms <= 2^-26 relative, fp32 accumulate - fp32 accuracy, 6/16 of the
- * f32-input MFMA time); 0: v_mfma_f32_32x32x2_f32 for everything (bitwise an fmaf chain).  Process-wide switch for tests and A/B runs. */
+ * f32-input MFMA time); 0: v_mfma_f32_32x32x2_f32 for everything (bitwise an fmaf chain).  Process-wide switch for tests and A/B runs.
+ * Edge semantics of the split form (tests/test_gpu_ops.py::test_gemm_split_edge_semantics), where it differs from an IEEE fp32 contraction:
+ *   - finite operands of any magnitude mix: none (same error against fp64 as the f32-input MFMA);
+ *   - an operand element that is +-inf or NaN, or finite with |x| >= 3.3961e38 (it rounds to bf16 infinity; FLT_MAX is 3.4028e38): hi = +-inf,
+ *     x - hi = NaN, so every output element of that row of A / column of B is NaN, where IEEE gives +-inf (or NaN).  The SET of non-finite
+ *     outputs is the same; only "which non-finite value" differs.  A training step that reaches it has diverged either way;
+ *   - fp32 denormal operands, and the mid / lo planes of operands below ~1e-33, may be flushed to zero by the bf16 matrix cores: an absolute
+ *     error of at most 2^-8 |a| |b| per such product - visible only in an output made of such products alone.
+ * Callers that need IEEE behaviour at those edges select 0. */
 int mstts_gemm_split3(int32_t on);
 /* Per calling thread.  1: mstts_gemm_f32 makes no K-cut the caller did not ask for with split_k (body + tail schedule and the full cut of
  * short tile lists off): every output element is one fixed-order sum, bit-reproducible run to run.  0 (default): the schedules of DESIGN 4.7,
@@ -637,9 +645,8 @@ typedef struct {
                                      When given, the launch forms the prenet rows' share of the cell-0 gates itself (8 more k-steps per wave,
                                      kernel rows from the wx0 argument of mstts_persist_pack) and ignores mstts_decoder_train_desc.xw0: the
                                      caller skips that [S B, 256] x [256, 4H] product and its 16 KB-per-row tensor.  NULL: xw0 is read. */
-    int32_t pipeline;                /* forward launch only: 1 = the software-pipelined schedule (rows 0..15 and 16..31 as two chains half a step apart, each
-                                      * hiding the other's hand-offs; same arithmetic, bit-identical results) where it exists (folded prenet product, <= 128
-                                      * encoder positions); 0 = every stage on all 32 rows at once */
+    int32_t reserved0;            /* (round 4: selected a two-chain software-pipelined forward schedule; measured 45 % slower, removed from the library in
+                                     round 5 - source kept in tools/persist_pipe.inc, numbers in profiles/r04_pipelined_forward.txt.  Ignored.) */
 } mstts_persist_desc;
 int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
 int64_t mstts_persist_fwd_ws_bytes(void);

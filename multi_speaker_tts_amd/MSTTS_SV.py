@@ -208,7 +208,11 @@ class Tacotron2:
                 self._spk_masks = MaskSet(self.train_engine.d, 1, 1, 1, True, dev, rank=self.rank, speaker_windows=nb)
                 self._spk_masks_nb = nb
             self._spk_masks.draw(step_seed(self.train_engine.seed, self.global_step))
-            batch["Speaker_Embedding"] = self.infer_engine.speaker_embedding(mel, masks=self._spk_masks).clone()
+            # (no host sync here: the stack's persistent launches are checked at the train step's own sync point, engine.forward)
+            emb, ticket = self.infer_engine.speaker_embedding(mel, masks=self._spk_masks, defer=True)
+            batch["Speaker_Embedding"] = emb.clone()
+            if ticket is not None:
+                batch["_speaker_ticket"] = ticket
         return batch
 
     def Train_Step(self, pattern=None, is_Pre_Train=False):

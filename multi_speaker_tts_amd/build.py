@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmstts_hip.so")
 SOURCES = ["gemm.hip", "gemm_bf16.hip", "skinny.hip", "cell.hip", "elementwise.hip", "lsa.hip", "decoder.hip", "audio.hip", "waveglow.hip", "ge2e.hip", "skinny_bf16.hip", "persist.hip", "persist_bwd.hip", "persist_lstm.hip", "persist_infer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MSTTS_EXTRA_HIPCC_FLAGS", "").split()     # (extra flags: kernel experiments only)
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "prenet_body.h"), os.path.join(CSRC, "persist_common.h"), os.path.join(CSRC, "persist_fwd_parts.h"), os.path.join(CSRC, "persist_pipe.inc"), os.path.join(CSRC, "gemm_split.inc"), os.path.join(HERE, "..", "include", "mstts.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "prenet_body.h"), os.path.join(CSRC, "persist_common.h"), os.path.join(CSRC, "persist_fwd_parts.h"), os.path.join(CSRC, "gemm_split.inc"), os.path.join(HERE, "..", "include", "mstts.h")]
 
 
 def _hipcc():

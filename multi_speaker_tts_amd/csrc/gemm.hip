@@ -407,7 +407,8 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     // 1 608 half tiles = 6.28 -> 7; 4 096 x 512: 128 tiles use half the chip, 256 half tiles all of it); the half tile re-reads
     // the B operand twice as often, so it has to win by more than 5 %
     int bm = skinny ? 32 : 128, tail_s = 1, tail_rem = 0;
-    const bool split3 = g_split3 && !skinny && d->K >= 160 && (d->win_T <= 0 || (d->win_T >= BK && d->win_C >= BK)) && gemm_split_lds_ready();   // (K < 160: the pipeline's prologue and padding tile outweigh the matrix-core time saved)          // (128-row tiles only; two workgroups per CU, so half-filled rounds cost half as much)
+    // (K < 160: the pipeline's prologue and padding tile outweigh the matrix-core time saved; the split kernel has 128-row tiles only)
+    const bool split3 = g_split3 && !skinny && d->K >= 160 && (d->win_T <= 0 || (d->win_T >= BK && d->win_C >= BK)) && gemm_split_lds_ready();
     if (!skinny) {
         const double t128 = (double)cdiv(d->M, 128) * cdiv(d->N, BN) * batch * split, t64 = (double)cdiv(d->M, 64) * cdiv(d->N, BN) * batch * split;
         const double e128 = t128 / (ceil(t128 / 256.0) * 256.0), e64 = t64 / (ceil(t64 / 256.0) * 256.0);

@@ -528,8 +528,6 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 #undef SUM_PARTIALS
 }
 
-#include "persist_pipe.inc"
-
 // ---- packers: the kernels in the order the lanes keep them (see the header comment)
 // (unit_of_kstep: persist_fwd_parts.h)
 
@@ -586,9 +584,6 @@ extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, 
         PFW_SETUP(false, false, 128) PFW_SETUP(true, false, 128) PFW_SETUP(false, true, 128) PFW_SETUP(true, true, 128)
         PFW_SETUP(false, false, 256) PFW_SETUP(true, false, 256) PFW_SETUP(false, true, 256) PFW_SETUP(true, true, 256)
 #undef PFW_SETUP
-        ok = ok && hipFuncSetAttribute((const void*)persist_fwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FL<128>::S_FLOATS * 4)) == hipSuccess &&
-             hipFuncSetAttribute((const void*)persist_fwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FL<128>::S_FLOATS * 4)) == hipSuccess &&
-             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_fwd_pipe_kernel<false>, PTH, (size_t)FL<128>::S_FLOATS * 4) == hipSuccess && per >= 1;
         (void)per_cu;
         return ok;
     });
@@ -646,11 +641,7 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
             else hipLaunchKernelGGL((persist_fwd_kernel<false, false, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                          \
         }                                                                                                                               \
     }
-    if (p->pipeline && fold && T <= 128) {      // the two half-batch chains half a step apart (persist_pipe.inc); bit-identical results
-        const size_t lds = (size_t)FL<128>::S_FLOATS * 4;
-        if (p->stamps) hipLaunchKernelGGL((persist_fwd_pipe_kernel<true>), dim3(PWG), dim3(PTH), lds, hs, a);
-        else hipLaunchKernelGGL((persist_fwd_pipe_kernel<false>), dim3(PWG), dim3(PTH), lds, hs, a);
-    } else if (T <= 128) PFW_LAUNCH(128) else PFW_LAUNCH(256)   // (the 128-position instantiation keeps the whole value slice in LDS)
+    if (T <= 128) PFW_LAUNCH(128) else PFW_LAUNCH(256)   // (the 128-position instantiation keeps the whole value slice in LDS)
 #undef PFW_LAUNCH
     MSTTS_CHECK_LAUNCH("persist_fwd");
     return MSTTS_OK;

@@ -59,14 +59,17 @@ def average_(tensors, group=None):
 
 class GradAllReduce:
     def __init__(self, grad_slab: torch.Tensor, world: int, bucket_mb: float = 32.0, group=None, force: bool = False,
-                 comm_dtype: str = "f32", overlap: bool = True):
+                 comm_dtype: str = "f32", overlap: bool = True, trace: bool = False):
         """force: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU).
         overlap=False: start() only notes the range; the whole slab is exchanged in finish(), behind the backward pass (the A/B
         switch for the overlapped form, `bench.py --no-overlap`).  exposed_ms() reports how long the compute stream waited in finish().
         comm_dtype "bf16" (BASELINE config 3): the message is bf16, the accumulation fp32 - each piece is rounded to bf16, every
         rank receives its 1/world shard of every rank's piece (all-to-all), sums the shards in fp32 in rank order, rounds the sum
         once and all-gathers it: half the bytes of the fp32 all-reduce on every xGMI link, and no bf16 partial sums anywhere.
-        The exchange runs on its own stream (ordered after the producing kernels, joined in finish())."""
+        The exchange runs on its own stream (ordered after the producing kernels, joined in finish()).
+        trace: bench.py - per step, a timing event where the FIRST range is announced (compute stream) and one when its first piece has
+        been exchanged (a probe stream that waits for that piece only): together with the engine's event behind the persistent BPTT launch
+        they show whether the first collective ran under the backward pass or queued behind it (first_piece_trace())."""
         if comm_dtype not in ("f32", "bf16"):
             raise ValueError("comm_dtype must be 'f32' or 'bf16'")
         self.world, self.group = world, group
@@ -79,7 +82,10 @@ class GradAllReduce:
         self.bounds = [(s, min(n, s + per)) for s in range(0, n, per)]
 
         self.n = n
+        self._device = grad_slab.device
         self._works, self._done = [], []
+        self._trace_on = bool(trace) and grad_slab.is_cuda
+        self._trace, self._probe = None, None
         self._side = None
         if self.bf16 and self.active:
             import torch.distributed as dist
@@ -130,12 +136,18 @@ class GradAllReduce:
             return
         import torch.distributed as dist
         per = self.bounds[0][1] - self.bounds[0][0]
+        first = self._trace_on and not self._done and not self._works
+        if first:
+            self._trace = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), min(hi, lo + per) - lo]
+            self._trace[0].record()
         if self.bf16:
             if self._side is not None:
                 self._side.wait_stream(torch.cuda.current_stream(grad_slab.device))
                 with torch.cuda.stream(self._side):
                     for a in range(lo, hi, per):
                         self._exchange_bf16(grad_slab[a:min(hi, a + per)])
+                        if first and a == lo:
+                            self._trace[1].record()
             else:
                 for a in range(lo, hi, per):
                     self._exchange_bf16(grad_slab[a:min(hi, a + per)])
@@ -145,6 +157,12 @@ class GradAllReduce:
             b = min(hi, a + per)
             self._works.append(dist.all_reduce(grad_slab[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self._done.append((a, b))
+            if first and a == lo:
+                if self._probe is None:
+                    self._probe = torch.cuda.Stream(device=grad_slab.device)
+                with torch.cuda.stream(self._probe):
+                    self._works[-1].wait()               # (the probe stream waits for this piece only)
+                    self._trace[1].record()
 
     def finish(self, grad_slab: torch.Tensor):
         """Wait for every started piece; ranges that were never started are reduced now (so the slab is always complete)."""
@@ -169,6 +187,25 @@ class GradAllReduce:
             ev[1].record()
             self._exposed = (self._exposed + [ev])[-64:]
         self._works, self._done = [], []
+
+    def agree(self, ok: bool) -> bool:
+        """True only if `ok` is true on EVERY rank (one MIN all-reduce of a single word, ordered behind the gradient collectives started so
+        far; identity in a one-process job).  engine.loss_and_backward asks this before it keeps or re-runs a backward pass whose
+        collectives are already in flight: the decision has to be the same on every rank or the ranks' collective sequences diverge."""
+        if not self.active or self.world <= 1:
+            return bool(ok)
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def first_piece_trace(self, reference_event):
+        """(ms from `reference_event` to the announcement of the step's first range, ms from `reference_event` to the end of that range's
+        first piece, elements of the piece) of the last traced step, or None.  Synchronises."""
+        if not self._trace:
+            return None
+        torch.cuda.synchronize()
+        return reference_event.elapsed_time(self._trace[0]), reference_event.elapsed_time(self._trace[1]), self._trace[2]
 
     def exposed_ms(self):
         """Mean time per finish() that the compute stream spent waiting for the exchange (what the overlap did not hide).  Synchronises."""

@@ -139,6 +139,9 @@ class TrainEngine:
         self.persist_stamps = None           # bench: 256 x 16 int64 tensor -> per-stage ticks of the next persistent launch
         self.persist_bwd = self.persist and os.environ.get("MSTTS_PERSIST_BWD", "1") != "0" and bool(lb.mstts_persist_bwd_supported(1, H, M, d.att, 1, d.att_k))
         self.persist_bwd_fallbacks = 0
+        self.speaker_ticket_redos = 0        # forward passes re-run because a persistent launch of the speaker stack in front of them gave up
+        self.trace_events, self.bptt_end_event = False, None
+        self.collective_redos = 0            # data parallel: backward passes re-run because ANOTHER rank's persistent launch gave up
         self.persist_bwd_stamps = None
         if self.persist:
             self.pk = [self._f(int(lb.mstts_persist_pack_floats(i))) for i in range(3)]
@@ -429,16 +432,18 @@ class TrainEngine:
             self._gemm(dz, wt, dx, rows, cin, K * cout, cout, cin, cin, win=(T, cout, K - 1 - pad))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch, w, seed=None, masks=None, _redo=False):
+    def forward(self, batch, w, seed=None, masks=None, _redo=False, allowed=None):
         """Forward pass.  The persistent launches (encoder BiLSTM, decoder loop) are enqueued WITHOUT waiting for their control words; the
         words of both are read once, behind the rest of the pass (one host sync per pass).  If either launch gave up, the BN moving statistics
-        are put back to their state at the start of the pass and the whole pass is run again with the launch-per-step loops (_redo)."""
+        are put back to their state at the start of the pass and the whole pass is run again with the launch-per-step loops (_redo).
+        allowed: the fallback policy's decision for this optimizer step (train_step takes it ONCE per step with _persist_begin_step and
+        hands it down); None = a forward pass driven on its own (tests, tools) advances the policy itself."""
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
         if self._derived_stale:
             self.refresh_derived()
-        allowed = False if _redo else self._persist_begin_step()
+        allowed = False if _redo else (self._persist_begin_step() if allowed is None else bool(allowed))
         w.persist_now = bool(w.persist) and allowed
         w.persist_bwd_now = bool(getattr(w, "persist_bwd", False)) and allowed
         speculative = allowed and (w.persist_now or bool(getattr(w, "persist_enc", False)))
@@ -564,9 +569,6 @@ class TrainEngine:
             pd.selftest_fail_step = int(self.persist_selftest)
             pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             pd.pre, pd.b0 = (ptr(x), ptr(b0, ob0)) if w.fold_prenet else (None, None)
-            # (the two-chain schedule of persist_pipe.inc: measured SLOWER, 24.6 vs 17.0 us per frame - a chain's step is bound by its six
-            #  hand-off flights, not by the workgroups' work, so a second chain in the gaps only adds its own instructions; opt-in for A/B)
-            pd.pipeline = int(os.environ.get("MSTTS_PERSIST_PIPE", "0") != "0")
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
             ev.record()
@@ -590,6 +592,13 @@ class TrainEngine:
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
         if enc_ticket is not None:
             enc_ok = self._enc_check(w, enc_ticket)
+        spk_ticket = None if _redo else batch.pop("_speaker_ticket", None)
+        if spk_ticket is not None and not spk_ticket.ok():
+            # the frozen speaker stack in front of this pass (MSTTS_SV.py:49-56) ran as persistent launches whose words are read only now:
+            # one of them gave up, the embedding this pass consumed is junk - recompute it launch by launch, then run the pass again
+            batch["Speaker_Embedding"].copy_(spk_ticket.redo())
+            self.speaker_ticket_redos += 1
+            enc_ok = False
         if not (dec_ok and enc_ok):
             self._step_fell_back = True
             torch.cuda.current_stream().synchronize()
@@ -627,7 +636,7 @@ class TrainEngine:
         return True
 
     def _persist_begin_step(self):
-        """Adaptive fallback policy, called once per forward pass: closes the books on the previous step (a step in which any persistent
+        """Adaptive fallback policy, called once per OPTIMIZER STEP (train_step; a forward pass driven on its own calls it itself): closes the books on the previous step (a step in which any persistent
         launch gave up is a strike; PERSIST_STRIKES in a row start a cool-down) and says whether this step may use the persistent
         launches."""
         if getattr(self, "_step_fell_back", False):
@@ -703,11 +712,16 @@ class TrainEngine:
         self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.bn_ws)
 
     # ------------------------------------------------------------------ loss + backward
-    def loss_and_backward(self, w, grad_scale=1.0, on_ready=None, on_abort=None, _redo=False):
+    def loss_and_backward(self, w, grad_scale=1.0, on_ready=None, on_abort=None, agree=None, _redo=False):
         """Loss and backward pass.  Like forward(): the persistent launches (decoder BPTT, encoder BPTT) are enqueued without waiting for their
         control words, which are read once at the end of the pass; if either gave up the whole pass is run again with the launch-per-step
         loops (it starts by clearing the gradient slab).  on_abort: called before that re-run (train_step: wait for the collectives that the
-        abandoned pass has already started on the slab)."""
+        abandoned pass has already started on the slab).
+        agree: data-parallel runs - callable(passed) -> bool, the MINIMUM of `passed` over the ranks (GradAllReduce.agree).  The collectives
+        on_ready started have already mixed this pass's gradients into every rank's slab, so keeping or re-running the pass must be ONE
+        decision of the whole job: either every rank keeps its pass, or every rank drains (on_abort) and runs the pass again - each rank
+        then issues the same sequence of collectives, and a rank whose own launches were healthy throws away the junk a peer contributed
+        (`collective_redos` counts the passes re-run because a PEER's launch gave up)."""
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
@@ -775,8 +789,9 @@ class TrainEngine:
             pb.selftest_fail_step = int(self.persist_bwd_selftest)
             pb.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
             call("mstts_decoder_train_bwd_persistent", C.byref(db), C.byref(pb))
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.trace_events)
             ev.record()
+            self.bptt_end_event = ev             # (bench.py --gpus N: where the first gradient collective starts relative to this)
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
                 w.pctrl_b_host.copy_(w.pctrl_b, non_blocking=True)
@@ -912,11 +927,22 @@ class TrainEngine:
                 self._step_fell_back = True
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
                 passed = False
+        passed = self._pass_verdict(passed, agree, _redo)
         if not passed:
             if on_abort is not None:
                 on_abort()
             torch.cuda.current_stream().synchronize()
-            return self.loss_and_backward(w, grad_scale=grad_scale, on_ready=on_ready, on_abort=on_abort, _redo=True)
+            return self.loss_and_backward(w, grad_scale=grad_scale, on_ready=on_ready, on_abort=on_abort, agree=agree, _redo=True)
+
+    def _pass_verdict(self, passed, agree, redo):
+        """Keep this backward pass or run it again?  With `agree` (data parallel) the answer is the job's, not the rank's: the minimum of
+        `passed` over the ranks.  A re-run takes no persistent launch, so it has nothing left to disagree about and asks nobody."""
+        if agree is not None and not redo:
+            mine = passed
+            passed = bool(agree(passed))
+            if mine and not passed:
+                self.collective_redos += 1
+        return passed
 
     def _recurrent_wgrads(self, w, lo, hi, part="all"):
         """Weight gradients of the decoder loop summed over the steps [lo, hi) (accumulating into the gradient slab):
@@ -968,7 +994,7 @@ class TrainEngine:
         call("mstts_adam_tf", ptr(ps.train), ptr(ps.grad), ptr(ps.adam_m), ptr(ps.adam_v), ptr(ps.wd_mask), float(self.wr_rate),
              float(grad_scale), float(lr_t), b1, b2, eps, ps.n_train)
         self.global_step += 1
-        ps.version += 1
+        ps.touch()
         self._derived_stale = True
         self.refresh_derived()
         return lr
@@ -1019,6 +1045,7 @@ class TrainEngine:
         step = torch.tensor([self.global_step], dtype=torch.int64, device=self.device)
         broadcast_([ps.train, ps.frozen, ps.adam_m, ps.adam_v, step], src=src, group=group)
         self.global_step = int(step.item())
+        ps.touch()
         self._derived_stale = True
 
     def train_step(self, batch, masks=None, all_reduce=None):
@@ -1026,10 +1053,11 @@ class TrainEngine:
         B, Te = batch["Token"].shape
         L = batch["Mel"].shape[1]
         w = self.plan(B, Te, L)
-        self.forward(batch, w, masks=masks)
+        self.forward(batch, w, masks=masks, allowed=self._persist_begin_step())      # the fallback policy advances once per optimizer step
         if all_reduce is not None:           # bucketed in the order gradients become final (postnet -> decoder/attention -> encoder),
             g = self.params.grad             # each bucket's all-reduce running under the rest of the backward pass
-            self.loss_and_backward(w, on_ready=lambda lo, hi: all_reduce.start(g, lo, hi), on_abort=lambda: all_reduce.finish(g))
+            self.loss_and_backward(w, on_ready=lambda lo, hi: all_reduce.start(g, lo, hi), on_abort=lambda: all_reduce.finish(g),
+                                   agree=all_reduce.agree)
             all_reduce.finish(g)
         else:
             self.loss_and_backward(w)

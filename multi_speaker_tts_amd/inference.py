@@ -29,6 +29,35 @@ class _PersistRetry(RuntimeError):
     pass
 
 
+class _DeferredCheck:
+    """Ticket of a sub-graph whose persistent LSTM launches have not been checked yet (InferEngine.speaker_embedding(defer=True))."""
+
+    def __init__(self, eng, fn, a, k, pending, event):
+        self.eng, self.fn, self.a, self.k, self.pending, self.event = eng, fn, a, k, pending, event
+
+    def ok(self):
+        """After (or as) the caller's host sync: did every launch of the sub-graph run to its end?"""
+        self.event.synchronize()
+        eng = self.eng
+        if eng.persist_lstm_selftest > 0:
+            eng.persist_lstm_selftest -= 1
+            return False
+        host = eng._lstm_ctrl_host_deferred
+        return all(int(host[slot][1]) == 0 and int(host[slot][2]) == n_wg for slot, n_wg in self.pending)
+
+    def redo(self):
+        """The sub-graph again, launch by launch (same stream); returns its output."""
+        eng = self.eng
+        eng.persist_lstm_fallbacks += 1
+        eng._lstm_retry = True
+        try:
+            with lib.deterministic_gemm():
+                return self.fn(*self.a, **self.k)
+        finally:
+            eng._lstm_retry = False
+            eng._lstm_pending, eng._lstm_copied = [], 0
+
+
 class InferEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, params: ParamStore = None, values=None, chunk=50):
         lib.load()
@@ -55,6 +84,7 @@ class InferEngine:
         self.persist_lstm = os.environ.get("MSTTS_PERSIST_LSTM", "1") != "0"
         self.persist_lstm_launches = 0
         self.persist_lstm_fallbacks = 0      # forward passes re-run without them because a launch gave up
+        self.persist_lstm_selftest = 0       # tests: k > 0 makes the next k control-word checks report a launch that gave up
         self._lstm_retry = False
         self._lstm_pending = []              # (slot, workgroups expected to have left in order)
         self._lstm_ctrl = None
@@ -159,6 +189,9 @@ class InferEngine:
     def _lstm_verify(self):
         """After a host sync: did every persistent LSTM launch read back so far run to its end?  Raises _PersistRetry otherwise (the
         forward pass is then re-run with the launch-per-step drivers)."""
+        if self.persist_lstm_selftest > 0 and self._lstm_copied:
+            self.persist_lstm_selftest -= 1
+            raise _PersistRetry("persistent LSTM launch 0: self-test")
         for slot, n_wg in self._lstm_pending[:self._lstm_copied]:
             st = self._lstm_ctrl_host[slot]
             if int(st[1]) != 0 or int(st[2]) != n_wg:
@@ -214,8 +247,27 @@ class InferEngine:
                 self._lstm_retry = False
                 self._lstm_pending, self._lstm_copied = [], 0
 
-    def speaker_embedding(self, spk_mel, masks=None):
-        return self._guarded(self._speaker_embedding, spk_mel, masks=masks)
+    def speaker_embedding(self, spk_mel, masks=None, defer=False):
+        """defer=True (the TRAIN step's frozen speaker stack, MSTTS_SV.py:49-56,211): no host sync here.  Returns (embedding, ticket);
+        the caller hands the ticket to TrainEngine.forward (batch["_speaker_ticket"]), which redeems it at its one existing sync point and
+        re-runs the sub-graph launch by launch - and its own pass - if a persistent launch of the stack gave up."""
+        if not defer:
+            return self._guarded(self._speaker_embedding, spk_mel, masks=masks)
+        return self._deferred(self._speaker_embedding, spk_mel, masks=masks)
+
+    @lib.deterministic_gemm()
+    def _deferred(self, fn, *a, **k):
+        self._lstm_pending, self._lstm_copied = [], 0
+        out = fn(*a, **k)
+        pending = list(self._lstm_pending)
+        if not pending:
+            return out, None
+        if getattr(self, "_lstm_ctrl_host_deferred", None) is None:
+            self._lstm_ctrl_host_deferred = torch.zeros(64, 16, dtype=torch.int32).pin_memory()
+        self._lstm_ctrl_host_deferred.copy_(self._lstm_ctrl, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return out, _DeferredCheck(self, fn, a, k, pending, ev)
 
     def encoder(self, token, token_length, spk):
         return self._guarded(self._encoder, token, token_length, spk)

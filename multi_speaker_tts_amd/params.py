@@ -253,8 +253,13 @@ class ParamStore:
     def g(self, name):
         return self.grad, self.offset[name]
 
-    def load(self, values):
+    def touch(self):
+        """The variables were written (optimizer step, broadcast, load): every cache keyed on `version` (packed / folded kernels of the
+        inference engines, the train engine's derived copies) is stale from here on.  Every code path that writes `train` / `frozen` calls this."""
         self.version += 1
+
+    def load(self, values):
+        self.touch()
         for name, shape, _ in self.table:
             if name in values:
                 v = values[name]

@@ -215,6 +215,7 @@ class SpeakerTrainEngine:
         # the loss's (weight, bias): gradients sit in out3[1:3]
         call("mstts_adam_tf", ptr(self.wb), ptr(w.out3, 1), ptr(self.wb_m), ptr(self.wb_v), ptr(self.wb_mask), 0.0, 1.0, float(lr_t), b1, b2, eps, 2)
         self.global_step += 1
+        ps.touch()                           # (an InferEngine sharing this store keys its packed recurrent kernels on the version)
         return lr
 
     def train_step(self, mel, batch_per_speaker, masks=None, seed=None):

@@ -276,6 +276,7 @@ class Taco1TrainEngine:
         call("mstts_adam_tf", ptr(ps.train), ptr(ps.grad), ptr(ps.adam_m), ptr(ps.adam_v), ptr(ps.wd_mask), float(self.wr_rate),
              1.0, float(lr_t), b1, b2, eps, ps.n_train)
         self.global_step += 1
+        ps.touch()                           # (an InferEngine sharing this store keys its packed / folded kernels on the version)
         return lr
 
     def scalars(self, w):

@@ -75,8 +75,33 @@ def learning_rate(step, initial=1e-3, minimum=1e-5, decay_start=0, decay_step=10
     return min(max(lr, minimum), initial)
 
 
-def losses(p, out, batch, wr_rate=1e-6, use_l1=True):
-    """MSTTS_SV.py:127-161 (quirks Q7, Q8, Q19)."""
+L1_KINK_BAND = 2e-3   # |prediction - target| below which two correct implementations may disagree on the sign of the L1 term's gradient
+L1_INJECTED = {"elements": 0, "differ": 0}
+
+
+def abs_at(x, sign=None):
+    """|x| of the L1 losses (MSTTS_SV.py:138-142: tf.losses.absolute_difference).  `sign` (optional tensor of x's shape, +-1 / 0) fixes
+    which side of the kink every element counts on - the L1 counterpart of model.relu_at: the gradient of |x| is sign(x) / n, at the
+    headline shape 2 x 2 M elements feed the two L1 terms, the targets are continuous, so a few dozen |prediction - target| land within
+    the fp32 forward error of 0, where an fp32 and an fp64 evaluation put the element on different sides and its gradient flips by 2 / n -
+    one such element moves every weight gradient upstream by about one row's contribution (measured, profiles/r05_depth_parity.jsonl:
+    4-5e-3 of the maximum at 25 632 rows; 1e-4 with the pattern injected).  The injected pattern may differ from this evaluation's own only
+    inside +-L1_KINK_BAND (asserted), so it cannot hide a wrong loss gradient."""
+    if sign is None:
+        return x.abs()
+    sign = torch.as_tensor(sign).to(x.dtype).reshape(x.shape)
+    own = torch.sign(x.detach())
+    differ = sign != own
+    L1_INJECTED["elements"] += int(differ.numel())
+    L1_INJECTED["differ"] += int(differ.sum())
+    if bool(differ.any()):
+        worst = float(x.detach().abs()[differ].max())
+        assert worst < L1_KINK_BAND, "injected L1 sign pattern differs outside the kink band: |x| = %g" % worst
+    return x * sign
+
+
+def losses(p, out, batch, wr_rate=1e-6, use_l1=True, l1_signs=None):
+    """MSTTS_SV.py:127-161 (quirks Q7, Q8, Q19).  l1_signs: optional {"linear", "post"} sign patterns for abs_at."""
     mel = batch["Mel"]
     L = batch["Mel_Length"].long()
     S = int(L.max()) + 1
@@ -85,8 +110,8 @@ def losses(p, out, batch, wr_rate=1e-6, use_l1=True):
     linear_loss = ((lin - mel) ** 2).mean()
     postnet_loss = ((post - mel) ** 2).mean()
     if use_l1:
-        linear_loss = linear_loss + (lin - mel).abs().mean()
-        postnet_loss = postnet_loss + (post - mel).abs().mean()
+        linear_loss = linear_loss + abs_at(lin - mel, l1_signs.get("linear") if l1_signs else None).mean()
+        postnet_loss = postnet_loss + abs_at(post - mel, l1_signs.get("post") if l1_signs else None).mean()
     z = out["Stop_Logit"]
     stop_loss = (torch.clamp(z, min=0) - z * stop_target + torch.log1p(torch.exp(-z.abs()))).mean()
     wr = wr_rate * sum((p[k] ** 2).sum() / 2 for k in p if M.in_weight_reg(k))
@@ -117,7 +142,8 @@ def train_step(params, opt_state, d, batch, masks, global_step, dtype=torch.floa
     if update_vocoder_bn:      # quirk Q20: the vocoder conv-bank's BN update ops ride along
         with torch.no_grad():
             M.taco1_convbank(p, d, out["Mel"].detach(), True, stats)
-    ls = losses(p, out, bt)
+    l1 = {k[len("l1_sign_"):]: v for k, v in masks.items() if k.startswith("l1_sign_")} if masks else None
+    ls = losses(p, out, bt, l1_signs=l1 or None)
     grads = torch.autograd.grad(ls["Loss"], [p[k] for k in names], allow_unused=True)
     grads = {k: (g if g is not None else torch.zeros_like(p[k])) for k, g in zip(names, grads)}
     lr = learning_rate(global_step)

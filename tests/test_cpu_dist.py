@@ -123,3 +123,66 @@ def test_dp_helpers_and_feeder_sharding_two_ranks(tmp_path):
         assert [[t - 2 for t in row] for row in toks] == want            # each rank got exactly its interleaved share, in order
         seen += [i for row in want for i in row]
     assert sorted(seen) == list(range(12))                             # disjoint and complete
+
+
+def _worker_agree(rank, world, port, q):
+    """The protocol of engine.loss_and_backward's last lines on two gloo ranks: ranges announced while the pass runs (async all-reduces in
+    flight), then the verdict; rank 1's pass 'gave up' in step 1, so BOTH ranks drain and run the pass again."""
+    import types
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multi_speaker_tts_amd.dist import GradAllReduce
+    from multi_speaker_tts_amd.engine import TrainEngine
+    eng = types.SimpleNamespace(collective_redos=0)
+    verdict = types.MethodType(TrainEngine._pass_verdict, eng)
+    n = 3000
+    g = torch.zeros(n)
+    red = GradAllReduce(g, world, bucket_mb=0.002)
+    assert red.agree(True) is True and red.agree(rank == 0) is False and red.agree(False) is False
+    log = []
+
+    def backward(step, redo=False):
+        junk = (step == 1 and rank == 1 and not redo)           # this rank's persistent launch left junk gradients behind
+        g.zero_()
+        g.add_(float("nan") if junk else float(rank + 1) * (step + 1))
+        for lo, hi in ((2000, 3000), (500, 2000), (0, 500)):     # postnet -> decoder/attention -> encoder
+            red.start(g, lo, hi)
+            log.append(("start", step, redo))
+        if not verdict(not junk, red.agree, redo):
+            red.finish(g)                                        # on_abort
+            log.append(("drain", step))
+            return backward(step, redo=True)
+
+    out = []
+    for step in range(3):
+        backward(step)
+        red.finish(g)
+        out.append(g.clone())
+    q.put((rank, [o.numpy().copy() for o in out], eng.collective_redos, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_redo_decision_is_collective():
+    """one rank's launch gives up after the pass's collectives have started.  Every rank must take the same decision, or
+    the ranks' collective sequences fall out of step.  Here: three steps, the middle one re-run by both ranks; every step ends with the
+    plain sum on both ranks (no NaN of the abandoned pass survives), rank 0 counts one peer-induced redo, rank 1 none."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_agree, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, out, redos, log = q.get(timeout=120)
+        res[r] = (out, redos, log)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        for step, o in enumerate(res[r][0]):
+            assert np.array_equal(o, np.full(3000, 3.0 * (step + 1), np.float32)), (r, step, o[:4])
+    assert res[0][1] == 1 and res[1][1] == 0
+    assert res[0][2] == res[1][2] and res[0][2].count(("drain", 1)) == 1 and len([e for e in res[0][2] if e[0] == "start"]) == 12

@@ -200,3 +200,106 @@ def _run_two_ranks(backend):
     # both ranks end with the same variables, bit for bit
     for k in got[0][0]:
         assert np.array_equal(got[0][0][k], got[1][0][k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------- one rank's launch gives up
+REFW = dict(emb=64, enc_conv_ch=64, enc_lstm=256, spk=256, prenet=256, dec_lstm=1024, n_mel=16, post_ch=32)
+
+
+def _abort_worker(rank, world, port, B, Te, L, q, ev, fail):
+    """One rank of a 2-rank job at the reference's recurrent widths (persistent launches on).  Both ranks share the one GPU, and a persistent
+    launch wants all of its CUs, so the ranks take turns on the device (events): forward 0, forward 1, backward 0 up to its `agree`, backward 1.
+    `fail`: rank 1's persistent BPTT (or encoder BPTT) launch gives up through the self-test knob - rank 0's own launches are healthy."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from multi_speaker_tts_amd import dist as D
+    from multi_speaker_tts_amd.engine import TrainEngine as TE
+    from tests.helpers import dims_pair as dp_, to_dev as td_
+    from oracle import model as OM_, train as OT_
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pd, od = dp_(**REFW)
+        eng = TE(pd, device=dev, values=OM_.init_params(od, 21), seed=1234, rank=rank, world=world)
+        full = OT_.synthetic_batch(od, world * B, Te, L, seed=9, ragged=True)
+        mine = td_({k: v[rank * B:(rank + 1) * B] for k, v in full.items()}, dev)
+        red = D.GradAllReduce(eng.params.grad, world, bucket_mb=4.0)
+        fwd0, fwd1, agree0 = ev
+        orig_fwd, orig_bwd, orig_agree = eng.forward, eng.loss_and_backward, red.agree
+
+        def fwd(*a, **k):
+            if rank == 1:
+                fwd0.wait(300)
+            out = orig_fwd(*a, **k)
+            torch.cuda.synchronize()
+            (fwd0 if rank == 0 else fwd1).set()
+            return out
+
+        def bwd(*a, **k):
+            (fwd1 if rank == 0 else agree0).wait(300)
+            if rank == 1 and fail == "encoder" and not k.get("_redo"):
+                eng.persist_enc_selftest = 1                 # (set here: the forward pass's own encoder check would consume it)
+            return orig_bwd(*a, **k)
+
+        def agree(ok):
+            if rank == 0:
+                torch.cuda.synchronize()
+                agree0.set()
+            return orig_agree(ok)
+        eng.forward, eng.loss_and_backward, red.agree = fwd, bwd, agree
+        if rank == 1 and fail == "bptt":
+            eng.persist_bwd_selftest = 3
+        w = eng.train_step(mine, all_reduce=red)
+        torch.cuda.synchronize()
+        info = dict(persist=bool(w.persist and w.persist_bwd and w.persist_enc), fwd_fallbacks=eng.persist_fallbacks, bwd_fallbacks=eng.persist_bwd_fallbacks,
+                    enc_fallbacks=eng.persist_enc_fallbacks, collective_redos=eng.collective_redos)
+        q.put((rank, eng.params.train.cpu().numpy(), eng.params.grad.cpu().numpy(), eng.scalars(w, average=True)["Loss"], info))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_launch_gives_up(dev):
+    """engine.loss_and_backward's re-run decision is collective (GradAllReduce.agree): when ONE rank's persistent BPTT launch gives up after
+    the gradient all-reduces of the pass have started, BOTH ranks drain them and run the pass again - the ranks issue the same sequence of
+    collectives (no hang, no pairing with the peer's next step), nobody applies the junk partial gradients, and the job ends where the
+    undisturbed job ends: every variable after Adam equal on both ranks bit for bit, and equal to the healthy run's to fp32 rounding."""
+    import torch.multiprocessing as mp
+    eng_probe = TrainEngine(dims_pair(**REFW)[0], device=dev)
+    if not (eng_probe.persist and eng_probe.persist_bwd and eng_probe.persist_enc):
+        pytest.skip("persistent launches not available on this device")
+    del eng_probe
+    torch.cuda.empty_cache()
+    B, Te, L, world = 3, 11, 7, 2
+    results = {}
+    for mode in ("none", "bptt", "encoder"):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ev = tuple(ctx.Event() for _ in range(3))
+        procs = [ctx.Process(target=_abort_worker, args=(r, world, port, B, Te, L, q, ev, mode)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = {}
+        for _ in range(world):
+            r, params, grad, loss, info = q.get(timeout=600)
+            got[r] = (params, loss, info, grad)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        results[mode] = got
+        assert np.array_equal(got[0][0], got[1][0]), mode                 # both ranks end with the same variables, bit for bit
+        assert got[0][2]["persist"] and got[1][2]["persist"]
+    assert results["none"][0][2]["collective_redos"] == 0 and results["none"][1][2]["collective_redos"] == 0
+    assert all(results["none"][r][2][k] == 0 for r in (0, 1) for k in ("fwd_fallbacks", "bwd_fallbacks", "enc_fallbacks"))
+    for fail in ("bptt", "encoder"):
+        i0, i1 = results[fail][0][2], results[fail][1][2]
+        assert (i1["bwd_fallbacks"] if fail == "bptt" else i1["enc_fallbacks"]) == 1 and i1["collective_redos"] == 0, (fail, i1)
+        assert i0["bwd_fallbacks"] == 0 and i0["enc_fallbacks"] == 0 and i0["collective_redos"] == 1, (fail, i0)      # rank 0 re-ran because its PEER asked
+        a, b = results["none"][0][3], results[fail][0][3]                  # the summed gradient both ranks applied
+        assert float(np.abs(a - b).max()) <= 2e-4 * float(np.abs(a).max()), (fail, float(np.abs(a - b).max()), float(np.abs(a).max()))
+        assert abs(results["none"][0][1] - results[fail][0][1]) < 1e-4 * max(1.0, abs(results["none"][0][1]))

@@ -66,6 +66,66 @@ def test_gemm_split_is_fp32_accurate(dev, M, N, K, ta, win, sk):
     assert errs[1] <= 1.25 * errs[0] + 1e-8, errs
 
 
+def _gemm_both(dev, A, B, M, N, K):
+    out = {}
+    for mode in (1, 0):
+        lib.call("mstts_gemm_split3", mode)
+        Cm = torch.zeros(M, N, device=dev)
+        lib.gemm(A, B, Cm, M, N, K, K, N, N)
+        out[mode] = t2n(Cm).astype(np.float64)
+    lib.call("mstts_gemm_split3", 1)
+    return out[1], out[0]
+
+
+def test_gemm_split_edge_semantics(dev):
+    """What the six-product split (mstts_gemm_split3(1), the default) does at the edges of fp32, next to v_mfma_f32_32x32x2_f32 (Modules.py:29-35:
+    tf.layers.conv1d is an IEEE fp32 contraction).  The statements here are the ones include/mstts.h makes next to mstts_gemm_split3:
+      (1) finite operands of any magnitude mix (1e-30 ... 1e30 inside one reduction): same error against fp64 as the f32-input MFMA kernel;
+      (2) an operand that is +-inf / NaN - or finite but rounding to bf16 infinity, |x| >= 3.3961e38 - makes every output element of its row
+          (A) / column (B) NaN, where the f32-input MFMA gives +-inf or NaN: the SET of non-finite outputs is the same, everything else untouched;
+      (3) fp32 denormals and the lower planes of operands below ~1e-33 may be flushed by the bf16 matrix cores: absolute error at most
+          2^-8 |x| |b| per such product, i.e. invisible unless an output is made of such products only."""
+    g = np.random.default_rng(11)
+    M, N, K = 256, 256, 512
+    # (1) 60 decades of operand magnitude inside every dot product, products O(1)
+    e = g.uniform(-30, 30, K)
+    A = torch.tensor(g.normal(0, 1, (M, K)) * 10.0 ** e[None, :], dtype=torch.float32, device=dev)
+    B = torch.tensor(g.normal(0, 1, (K, N)) * 10.0 ** -e[:, None], dtype=torch.float32, device=dev)
+    ref = t2n(A).astype(np.float64) @ t2n(B).astype(np.float64)
+    sp, f3 = _gemm_both(dev, A, B, M, N, K)
+    e_sp, e_f3 = rel_err(sp, ref), rel_err(f3, ref)
+    print("wide range: split %.3e, f32 MFMA %.3e" % (e_sp, e_f3))
+    assert np.isfinite(sp).all() and e_f3 < 5e-6 and e_sp <= 1.25 * e_f3 + 1e-7, (e_sp, e_f3)
+    # (2) non-finite operands
+    A = torch.tensor(g.normal(0, 1, (M, K)), dtype=torch.float32, device=dev)
+    B = torch.tensor(g.normal(0, 1, (K, N)), dtype=torch.float32, device=dev)
+    ref = t2n(A).astype(np.float64) @ t2n(B).astype(np.float64)
+    A[3, 7] = float("inf"); A[5, 9] = float("nan"); A[200, 500] = 3.4e38                 # finite, rounds to bf16 infinity
+    B[11, 2] = float("-inf"); B[300, 130] = float("nan")
+    B[500] = B[500].clamp(-0.9, 0.9)                                                     # (3.4e38 x 0.9 stays finite in fp32)
+    sp, f3 = _gemm_both(dev, A, B, M, N, K)
+    bad = np.zeros((M, N), bool)
+    bad[[3, 5], :] = True; bad[:, [2, 130]] = True
+    assert not np.isfinite(f3[bad]).any() and np.isfinite(f3[200][~bad[200]]).all()     # the f32-input MFMA: inf / NaN where IEEE says so; the 3.4e38 row is finite
+    assert np.isnan(sp[bad]).all() and np.isnan(sp[200]).all()                          # the split: NaN on all of them, and on the bf16-overflow row
+    ok = ~bad; ok[200] = False
+    assert np.isfinite(sp[ok]).all() and rel_err(sp[ok], ref[ok]) < 5e-6 and rel_err(f3[ok], ref[ok]) < 5e-6
+    # (3) denormal operands inside ordinary rows, and rows made of tiny operands only
+    A = torch.tensor(g.normal(0, 1, (M, K)), dtype=torch.float32, device=dev)
+    A[:, ::7] *= 1e-40                                                                   # fp32 denormals
+    A[64:128] *= 1e-36                                                                   # rows of tiny normals (and denormals): every product tiny
+    B = torch.tensor(g.normal(0, 1, (K, N)), dtype=torch.float32, device=dev)
+    a64, b64 = t2n(A).astype(np.float64), t2n(B).astype(np.float64)
+    ref = a64 @ b64
+    sp, f3 = _gemm_both(dev, A, B, M, N, K)
+    big = np.ones(M, bool); big[64:128] = False
+    e_sp, e_f3 = rel_err(sp[big], ref[big]), rel_err(f3[big], ref[big])
+    t_sp, t_f3 = rel_err(sp[~big], ref[~big]), rel_err(f3[~big], ref[~big])
+    print("denormals inside ordinary rows: split %.3e, f32 MFMA %.3e; rows of tiny operands only: split %.3e, f32 MFMA %.3e" % (e_sp, e_f3, t_sp, t_f3))
+    assert e_sp < 5e-6 and e_f3 < 5e-6
+    assert t_sp <= 2.0 ** -8, t_sp
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 36), (32, 512, 260), (17, 81, 100), (300, 84, 64), (1, 1, 52), (260, 1100, 72)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_layouts(dev, gemm_mode, M, N, K, ta, tb):

@@ -1,7 +1,7 @@
 """The persistent decoder loop (csrc/persist.hip, mstts_decoder_train_fwd_persistent: all S steps of Modules.py:397-443 in one
 launch) against the launch-per-step loop it replaces (mstts_decoder_train_fwd) on the same engine, inputs and keep-masks: every
 tensor the BPTT reads must agree.  Parity with the oracle at these widths is test_gpu_model.py::test_train_step_parity (its two
-reference-width cases take the persistent path) and test_depth_parity below."""
+reference-width cases take the persistent path) and tests/test_gpu_depth.py::test_depth_parity_train."""
 import numpy as np
 import pytest
 import torch
@@ -64,34 +64,6 @@ def test_persistent_equals_launch_per_step(dev, B, Te, L, ragged):
         if e > (5e-4 if L > 20 else 5e-5):               # same fp32 products, different summation order (and atomics upstream of the loop: not bit-reproducible run to run)
             bad[k] = e
     assert not bad, bad
-
-
-@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (20, 100, 33, True), (1, 7, 2, False), (17, 64, 1, False)])
-def test_pipelined_schedule_is_bit_identical(dev, B, Te, L, ragged, monkeypatch):
-    """persist_fwd_pipe_kernel (rows 0..15 and 16..31 as two chains half a step apart) visits the same work in another order: every
-    history, packed operand block and output equals persist_fwd_kernel's TO THE BIT, for batches that fill both chains, one chain, part of a
-    chain, and for one-step sequences (chain 1 finishes in the extra iteration)."""
-    import ctypes as C
-    from multi_speaker_tts_amd import lib
-    eng, od = _engine(dev)
-    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=ragged), dev)
-    w = eng.plan(B, Te, L)
-    monkeypatch.setenv("MSTTS_PERSIST_PIPE", "1")
-    eng.forward(batch, w, seed=77)
-    torch.cuda.synchronize()
-    assert w.pdesc.pipeline == 1 and eng.persist_fallbacks == 0 and w.fold_prenet
-    keys = HIST + (("opk",) if w.opk_valid else ())
-    a = {k: t2n(getattr(w, k)).copy() for k in keys}
-    for want in (0, 1):
-        for k in keys:
-            getattr(w, k).zero_()
-        w.pdesc.pipeline = want
-        lib.call("mstts_decoder_train_fwd_persistent", C.byref(w.dec), C.byref(w.pdesc))
-        torch.cuda.synchronize()
-        st = w.pctrl.cpu().numpy()
-        assert st[1] == 0 and st[2] == 256, st[:3]
-        for k in keys:
-            assert np.array_equal(a[k], t2n(getattr(w, k))), (k, want)
 
 
 def test_persistent_is_deterministic(dev):

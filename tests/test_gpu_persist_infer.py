@@ -1,7 +1,8 @@
 """The persistent FREE-RUNNING decoder loop (csrc/persist_infer.hip, mstts_decoder_infer_persistent: every step of Modules.py:397-443 in
 inference mode - own frame -> prenet -> next input, stop gating Modules.py:212-237 - in one launch) against the launch-per-step driver it
 replaces (mstts_decoder_infer_steps) on the same engine, weights, inputs and prenet keep-masks, and against the fp64 oracle.  Oracle parity
-of the same path over 122 steps with rows stopping at different steps: tests/test_gpu_depth.py::test_depth_parity_free_running."""
+of the same path at depth, rows stopping at different steps, is tests/test_gpu_depth.py::test_depth_parity_free_running (B = 4, >= 100 steps)
+and ::test_depth_parity_free_running_config4 (BASELINE configs[3]'s shape: B = 16, up to 128 tokens, >= 400 steps)."""
 import numpy as np
 import pytest
 import torch

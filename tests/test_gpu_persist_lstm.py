@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from multi_speaker_tts_amd import lib
-from tests.helpers import rel_err, t2n
+from oracle import model as OM, train as OT
+from tests.helpers import dims_pair, rel_err, t2n, to_dev
 
 pytestmark = pytest.mark.gpu
 H = 256
@@ -323,3 +324,102 @@ def test_forward_only_launch_h128_and_single_direction(dev, B, T, HH, ndir):
     assert np.isfinite(oa).all() and rel_err(oa, ob) < tol, rel_err(oa, ob)
     for di in range(ndir):
         assert rel_err(ca[di][1:], cb[di][1:]) < tol and rel_err(ha[di][1:], hb[di][1:]) < tol, di
+
+
+# ---------------------------------------------------------------------------------------------------------------- host-side contracts (round 5)
+REFW_SPK = dict(spk=256, spk_lstm=256, n_mel=80)
+
+
+def _spk_setup(dev, B=3, seed=3):
+    from multi_speaker_tts_amd.inference import InferEngine
+    from multi_speaker_tts_amd import lib
+    pd, od = dims_pair(**REFW_SPK)
+    values = OM.init_params(od, seed)
+    g = np.random.default_rng(seed + 1)
+    NB = B * od.spk_samples
+    mel = torch.tensor(np.clip(g.normal(0, 1.5, (NB, od.spk_frames, od.n_mel)), -4, 4).astype(np.float32), device=dev)
+    eng = InferEngine(pd, device=dev, values=values)
+    if not lib.load().mstts_persist_lstm_fwd_supported_n(NB, pd.spk_lstm, 1):
+        pytest.skip("persistent LSTM launches not available on this device")
+    return eng, pd, od, values, mel
+
+
+def test_guarded_subgraph_retries_launch_by_launch(dev):
+    """InferEngine._guarded: a persistent LSTM launch of a sub-graph called on its own that gave up (self-test knob) is re-run launch by
+    launch, with one warning, and gives the launch-per-step result; the next call is healthy again."""
+    import warnings
+    eng, pd, od, values, mel = _spk_setup(dev)
+    ref = t2n(eng.speaker_embedding(mel)).copy()
+    n0 = eng.persist_lstm_launches
+    assert n0 == pd.spk_lstm_n and eng.persist_lstm_fallbacks == 0
+    eng.persist_lstm = False
+    plain = t2n(eng.speaker_embedding(mel)).copy()
+    eng.persist_lstm = True
+    assert rel_err(ref, plain) < 1e-4
+    eng.persist_lstm_selftest = 1
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = t2n(eng.speaker_embedding(mel)).copy()
+    assert eng.persist_lstm_fallbacks == 1 and sum("re-running launch by launch" in str(r.message) for r in rec) == 1
+    assert np.array_equal(got, plain)                                 # the retry IS the launch-per-step path
+    again = t2n(eng.speaker_embedding(mel)).copy()
+    assert eng.persist_lstm_fallbacks == 1 and np.array_equal(again, ref)
+
+
+def test_deferred_speaker_ticket_is_redeemed_by_the_train_forward(dev):
+    """MSTTS_SV.py:49-56,211: the frozen speaker stack runs in front of every train step.  With defer=True its persistent launches are not
+    waited for; TrainEngine.forward redeems the ticket at its own sync point.  A failed launch (self-test knob) makes the forward recompute
+    the embedding launch by launch and run its pass again: same outputs as the healthy step, one redo counted, BN moving statistics updated once."""
+    from multi_speaker_tts_amd.engine import TrainEngine
+    eng, pd, od, values, mel = _spk_setup(dev, B=4)
+    tr = TrainEngine(pd, device=dev, values=values)
+    B, Te, L = 4, 9, 6
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=True), dev)
+    w = tr.plan(B, Te, L)
+
+    def step(fail):
+        tr.params.load(values)
+        tr._derived_stale = True
+        emb, ticket = eng.speaker_embedding(mel, defer=True)
+        assert ticket is not None
+        b = dict(batch)
+        b["Speaker_Embedding"] = emb.clone()
+        b["_speaker_ticket"] = ticket
+        if fail:
+            eng.persist_lstm_selftest = 1
+            b["Speaker_Embedding"].fill_(7.0)                          # what a launch that gave up leaves behind: junk
+        tr.forward(b, w, seed=11)
+        torch.cuda.synchronize()
+        assert "_speaker_ticket" not in b
+        return t2n(w.mel_out).copy(), t2n(tr.params.frozen[:tr.params.n_moving]).copy(), t2n(b["Speaker_Embedding"]).copy()
+
+    mel0, mov0, e0 = step(False)
+    assert tr.speaker_ticket_redos == 0
+    mel1, mov1, e1 = step(True)
+    assert tr.speaker_ticket_redos == 1 and eng.persist_lstm_fallbacks == 1 and eng.persist_lstm_selftest == 0
+    assert rel_err(e1, e0) < 1e-4 and rel_err(mel1, mel0) < 1e-4
+    assert rel_err(mov1, mov0) < 1e-5                                  # one moving-statistics update per step, not two
+
+
+def test_inference_after_a_trainer_step_sees_the_new_kernels(dev):
+    """Speaker_Embedding.Inference() keeps one InferEngine on the trainer's ParamStore; its packed recurrent kernels are cached per
+    ParamStore.version, so EVERY writer of the variables has to bump it (ParamStore.touch): inference -> trainer step -> inference must
+    equal the launch-per-step forward on the updated variables."""
+    from multi_speaker_tts_amd.speaker_trainer import SpeakerTrainEngine
+    from multi_speaker_tts_amd.inference import InferEngine
+    eng, pd, od, values, mel = _spk_setup(dev)
+    tr = SpeakerTrainEngine(pd, device=dev, values=values)
+    inf = InferEngine(pd, device=dev, params=tr.params)
+    before = t2n(inf.speaker_embedding(mel)).copy()
+    g = np.random.default_rng(1)
+    N, T = 12, 9
+    x = torch.tensor(np.clip(g.normal(0, 1.5, (N, T, od.n_mel)), -4, 4).astype(np.float32), device=dev)
+    v0 = tr.params.version
+    for _ in range(3):
+        tr.train_step(x, 3)
+    assert tr.params.version == v0 + 3
+    after = t2n(inf.speaker_embedding(mel)).copy()
+    inf.persist_lstm = False
+    plain = t2n(inf.speaker_embedding(mel)).copy()
+    assert rel_err(after, plain) < 1e-4, rel_err(after, plain)
+    assert rel_err(after, before) > 1e-4                               # the step really moved the variables

@@ -446,7 +446,7 @@ class TrainEngine:
         allowed = False if _redo else (self._persist_begin_step() if allowed is None else bool(allowed))
         w.persist_now = bool(w.persist) and allowed
         w.persist_bwd_now = bool(getattr(w, "persist_bwd", False)) and allowed
-        speculative = allowed and (w.persist_now or bool(getattr(w, "persist_enc", False)))
+        speculative = (allowed and (w.persist_now or bool(getattr(w, "persist_enc", False)))) or (not _redo and "_speaker_ticket" in batch)
         if speculative:
             # the pass runs on the persistent launches' outputs before their status words are known; a launch that gave up leaves junk there,
             # and the BN layers would fold that junk into their MOVING statistics - one update per train step is the reference's behaviour

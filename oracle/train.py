@@ -84,8 +84,9 @@ def abs_at(x, sign=None):
     which side of the kink every element counts on - the L1 counterpart of model.relu_at: the gradient of |x| is sign(x) / n, at the
     headline shape 2 x 2 M elements feed the two L1 terms, the targets are continuous, so a few dozen |prediction - target| land within
     the fp32 forward error of 0, where an fp32 and an fp64 evaluation put the element on different sides and its gradient flips by 2 / n -
-    one such element moves every weight gradient upstream by about one row's contribution (measured, profiles/r05_depth_parity.jsonl:
-    4-5e-3 of the maximum at 25 632 rows; 1e-4 with the pattern injected).  The injected pattern may differ from this evaluation's own only
+    one such element moves every weight gradient upstream by about one row's contribution (measured at B = 32 x 800 frames,
+    profiles/r05_depth_parity.jsonl: 3 of 4 096 000 elements differ; HIP vs fp64 4.8e-3 of the maximum plain, 3.7e-4 with the pattern
+    injected; this oracle's own fp32 autograd vs its fp64 one 3.2e-3 plain, 1.1e-4 with its own pattern).  The injected pattern may differ from this evaluation's own only
     inside +-L1_KINK_BAND (asserted), so it cannot hide a wrong loss gradient."""
     if sign is None:
         return x.abs()

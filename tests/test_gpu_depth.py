@@ -135,17 +135,21 @@ def test_depth_parity_train(dev, L):
 def test_headline_shape_parity(dev):
     """The exact shape the headline metric is quoted on (BASELINE configs[1]; MSTTS_SV.py:129-161, Hyper_Parameters.py:69, Modules.py:215):
     ONE train step at B = 32 x 128 tokens x 800 frames (801 decoder steps), reference widths, every attention row and every key position of
-    the persistent kernels busy, fp32 HIP against the **fp64** oracle: forward <= 1e-3, losses <= 1e-4, zero fallbacks, every gradient <= 1e-2 of
-    its maximum.  (The 5e-3 bound of the smaller cases does not carry over: at this size every weight gradient is an fp32 sum over 25 632 rows
-    with heavy cancellation - measured over three runs of this test: location-layer dense kernel 4.6e-3 / 5.5e-3 / 4.8e-3, the postnet convolution
-    kernels 4.1-4.2e-3, everything else below 2e-3, against 1.7e-4 worst at B = 4; run to run the atomics of the split-K products move them by
-    ~1e-3.  A wrong gradient is off by tens of percent.)  The oracle's autograd tape at this size needs tens of GB of host memory: skipped on
-    a host without it."""
+    the persistent kernels busy, fp32 HIP against the **fp64** oracle: forward <= 1e-3, losses <= 1e-4, zero fallbacks, every gradient <= 1e-3 of
+    its maximum (measured 3.7e-4).  Round 4 had to loosen this bound to 1e-2 (4.6-5.5e-3 on the location-layer dense kernel and the postnet
+    convolution kernels) without knowing why; the three-way table this test records (profiles/r05_depth_parity.jsonl,
+    `headline_shape_gradient_error_three_way`) settles it: the L1 terms' gradient is sign(prediction - target) / n, and of the 4 096 000 elements
+    that feed them THREE lie within the fp32 forward error of 0, where fp32 and fp64 evaluations take different signs.  One flipped element
+    moves every weight gradient upstream by about one row's contribution of 25 632.  With the HIP path's sign pattern handed to the oracle
+    (oracle.train.abs_at, the L1 counterpart of the ReLU pattern; it may differ from the oracle's own only inside +-2e-3, asserted) the worst
+    gradient error is 3.7e-4; without it 4.8e-3; the oracle's OWN fp32 autograd against its fp64 one: 3.2e-3 plain, 1.1e-4 with its own
+    pattern.  Not cancellation in any sum, not the split-K atomics.  The oracle's autograd tapes at this size (one fp64 + two fp64 / one fp32
+    for the table, in sequence) need tens of GB of host memory: skipped on a host without it."""
     import psutil
     need = 96 << 30
     if psutil.virtual_memory().available < need:
         pytest.skip("fp64 oracle tape of the full shape needs ~%d GB of host memory" % (need >> 30))
-    w = _train_depth_case(dev, 32, 128, 800, "headline_shape", grad_tol=5e-3, three_way=True)
+    w = _train_depth_case(dev, 32, 128, 800, "headline_shape", grad_tol=1e-3, three_way=True)
     assert w.persist and w.persist_bwd and w.persist_enc
 
 

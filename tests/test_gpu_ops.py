@@ -99,10 +99,10 @@ def test_gemm_split_edge_semantics(dev):
     # (2) non-finite operands
     A = torch.tensor(g.normal(0, 1, (M, K)), dtype=torch.float32, device=dev)
     B = torch.tensor(g.normal(0, 1, (K, N)), dtype=torch.float32, device=dev)
-    ref = t2n(A).astype(np.float64) @ t2n(B).astype(np.float64)
+    B[500] = B[500].clamp(-0.9, 0.9)                                                     # (3.4e38 x 0.9 stays finite in fp32)
+    ref = t2n(A).astype(np.float64) @ t2n(B).astype(np.float64)                          # (only the rows / columns NOT touched below are compared with it)
     A[3, 7] = float("inf"); A[5, 9] = float("nan"); A[200, 500] = 3.4e38                 # finite, rounds to bf16 infinity
     B[11, 2] = float("-inf"); B[300, 130] = float("nan")
-    B[500] = B[500].clamp(-0.9, 0.9)                                                     # (3.4e38 x 0.9 stays finite in fp32)
     sp, f3 = _gemm_both(dev, A, B, M, N, K)
     bad = np.zeros((M, N), bool)
     bad[[3, 5], :] = True; bad[:, [2, 130]] = True

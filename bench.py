@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=T_ENC, help=argparse.SUPPRESS)          # ... e.g. a batch padded to 160 tokens (the 256-position persistent kernels)
     ap.add_argument("--recurrent-dtype", default="f32", choices=("f32", "bf16"), help=argparse.SUPPRESS)   # bf16 recurrent products only
     ap.add_argument("--force-bf16-recurrent", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--config3-f32-loops", action="store_true", help=argparse.SUPPRESS)          # A/B: config 3 with exact fp32 inside the persistent loops (round 4's form)
     ap.add_argument("--force-allreduce", action="store_true", help=argparse.SUPPRESS)          # 1 GPU: a one-rank RCCL group, every collective really issued (mechanics check, never a headline)
     ap.add_argument("--no-gemm-tail-split", action="store_true", help=argparse.SUPPRESS)      # A/B: every GEMM tile whole (mstts_gemm_tail_split(0))
     ap.add_argument("--config3", action="store_true", help="BASELINE config 3 arithmetic (bf16 operands everywhere, fp32 master/accumulate); never the headline")
@@ -286,13 +287,11 @@ def main():
     if args.no_gemm_tail_split:
         lib.call("mstts_gemm_tail_split", 0)
     if args.config3:
-        # config 3 = bf16 operands with fp32 master / accumulate.  Where the persistent decoder loops are available they run the recurrent
-        # products in exact fp32 AND faster than the bf16 launch-per-step products, so config 3 keeps them (bf16 for every hoisted
-        # contraction, fp32 inside the two loops); --recurrent-dtype bf16 forces the all-bf16 form of earlier rounds
-        lb0 = lib.load()
-        persist_ok = os.environ.get("MSTTS_PERSIST", "1") != "0" and bool(lb0.mstts_persist_fwd_supported(B_PER_GPU, dims.dec_lstm, dims.mem, dims.att, T_ENC, dims.att_k))
-        if not (persist_ok and not args.force_bf16_recurrent):
-            args.recurrent_dtype = "bf16"
+        # config 3 = bf16 operands with fp32 master / accumulate, in EVERY product of the step: the hoisted contractions (gemm_bf16) and - round 5 -
+        # the recurrent products inside the two persistent decoder loops (their bf16 instantiations, v_mfma_f32_16x16x32_bf16).
+        # --config3-f32-loops: round 4's form (bf16 hoisted contractions, exact fp32 inside the loops) for the A/B;
+        # --force-bf16-recurrent together with MSTTS_PERSIST_BF16=0: the bf16 launch-per-step loops of rounds 1-2
+        args.recurrent_dtype = "f32" if (args.config3_f32_loops and not args.force_bf16_recurrent) else "bf16"
     eng = TrainEngine(dims, device=device, seed=1234, rank=rank, world=world, recurrent_dtype=args.recurrent_dtype,
                       gemm_dtype="bf16" if args.config3 else "f32")
     batch = synthetic_batch(dims, B_PER_GPU, T_ENC, L, 1234, rank, device)
@@ -327,7 +326,8 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": ("bf16 operands in every hoisted contraction, f32 accumulate + f32 master, f32 inside the persistent decoder loops (BASELINE config 3 arithmetic, not the headline)"
                      if args.config3 and args.recurrent_dtype == "f32" else "f32" if args.recurrent_dtype == "f32" else
-                     "bf16 operands, f32 accumulate + f32 master (BASELINE config 3 arithmetic, not the headline)" if args.config3 else
+                     ("bf16 operands in every product of the step incl. the recurrent ones (%s), f32 accumulate + f32 master (BASELINE config 3 arithmetic, not the headline)"
+                      % ("persistent decoder loops on v_mfma_f32_16x16x32_bf16" if getattr(eng, "persist_bf16", False) and eng.persist else "launch-per-step bf16 loops")) if args.config3 else
                      "f32 + bf16 recurrent products (not the headline)"), "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[%d]: Tacotron2 train step (fwd+bwd+TF-Adam), per-GPU batch %d x (%d tokens, %d mel frames), random speaker embeddings, %s"
                                   % (2 if args.config3 else 1, B_PER_GPU, T_ENC, L, "bf16 operands with fp32 master / accumulate" if args.config3 else "fp32"),

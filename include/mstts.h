@@ -30,7 +30,7 @@ enum { MSTTS_OK = 0, MSTTS_ERR_SHAPE = -1, MSTTS_ERR_DTYPE = -2, MSTTS_ERR_ALIGN
 enum { MSTTS_ACT_NONE = 0, MSTTS_ACT_RELU = 1, MSTTS_ACT_TANH = 2, MSTTS_ACT_SIGMOID = 3 };
 
 const char* mstts_last_error(void);
-/* Bumped whenever a descriptor struct or an entry point's signature changes (4: round 4); the Python binding checks it at load. */
+/* Bumped whenever a descriptor struct or an entry point's signature changes (4: round 4; 5: round 5 - mstts_persist_desc.recurrent_bf16 in the slot of round 4's schedule selector); the Python binding checks it at load. */
 int mstts_abi_version(void);
 /* Diagnostic (tests of the persistent launches' co-residency handling; no reference counterpart - MSTTS_SV.py:24 is a single session on one
  * device): n_workgroups workgroups that each hold 96 KB of LDS - a whole CU as far as a persistent workgroup is concerned - for
@@ -645,8 +645,11 @@ typedef struct {
                                      When given, the launch forms the prenet rows' share of the cell-0 gates itself (8 more k-steps per wave,
                                      kernel rows from the wx0 argument of mstts_persist_pack) and ignores mstts_decoder_train_desc.xw0: the
                                      caller skips that [S B, 256] x [256, 4H] product and its 16 KB-per-row tensor.  NULL: xw0 is read. */
-    int32_t reserved0;            /* (round 4: selected a two-chain software-pipelined forward schedule; measured 45 % slower, removed from the library in
-                                     round 5 - source kept in tools/persist_pipe.inc, numbers in profiles/r04_pipelined_forward.txt.  Ignored.) */
+    int32_t recurrent_bf16;       /* != 0 (BASELINE config 3, "bf16 with fp32 master"): both cell products, the query product and - in the BPTT launch - the
+                                     data-gradient products take their operands rounded to bf16 (round to nearest even; the kernels when they are loaded into
+                                     registers, the activations / gate gradients when they are staged) and run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators;
+                                     states, gates, softmax, histories and everything exchanged stay fp32.  The forward launch needs pre / b0 in this mode.
+                                     (Round 4 had a software-pipelined schedule selector in this slot: removed, tools/persist_pipe.inc.) */
 } mstts_persist_desc;
 int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, int64_t A, int64_t T, int64_t KS);
 int64_t mstts_persist_fwd_ws_bytes(void);

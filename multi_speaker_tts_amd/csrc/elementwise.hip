@@ -819,7 +819,7 @@ using namespace mstts;
 #define ST(s) ((hipStream_t)(s))
 
 extern "C" const char* mstts_last_error(void) { return err_buf(); }
-extern "C" int mstts_abi_version(void) { return 4; }
+extern "C" int mstts_abi_version(void) { return 5; }
 
 extern "C" int mstts_debug_park_cus(int32_t n_workgroups, int64_t microseconds, uint32_t* done_count, mstts_stream_t s) {
     MSTTS_REQUIRE(n_workgroups >= 1 && n_workgroups <= 1024 && microseconds >= 0 && microseconds <= 1000000, MSTTS_ERR_SHAPE, "debug_park_cus: 1..1024 workgroups, at most 1 s");

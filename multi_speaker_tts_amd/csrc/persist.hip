@@ -68,8 +68,13 @@ struct PersistFwd {
 
 // FOLD: the prenet rows of the cell-0 kernel ride along with the context rows (8 more k-steps per wave on the matrix cores) instead of
 // arriving as a hoisted [S B, 4096] product: no 420 MB tensor written by a GEMM and read back by row-strided loads in every step.
-template <bool PROF, bool FOLD, int TT>
+// BF16 (BASELINE config 3, "bf16 with fp32 master"; FOLD only): both cell products and the query product take their operands rounded to
+// bf16 - the kernels once, when they are loaded into registers, the activations when they are staged - and run on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulators (persist_fwd_parts.h); cell states, gates, softmax, cumulative alignments, the history
+// written for BPTT and everything exchanged between workgroups stay fp32.  Same geometry, same hand-offs, half the kernel registers.
+template <bool PROF, bool FOLD, int TT, bool BF16 = false>
 __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
+    static_assert(!BF16 || FOLD, "the bf16 instantiation forms the prenet rows' product itself");
     typedef FL<TT> Y;
     constexpr int S_STG = Y::S_STG, S_RED = Y::S_RED, S_TR = Y::S_TR, S_M1 = Y::S_M1, S_EN = Y::S_EN, S_CUM = Y::S_CUM, S_A = Y::S_A, S_Q = Y::S_Q,
                   S_CO = Y::S_CO, S_LK = Y::S_LK, S_FLAG = Y::S_FLAG, S_STAMP = Y::S_STAMP, S_VAL = Y::S_VAL, S_WQ = Y::S_WQ;
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(d.xch, 0, (int)(XCH_FLOATS * 4), 0x00020000);
     unsigned* sflag = reinterpret_cast<unsigned*>(sm + S_FLAG);
     float* stg = sm + S_STG;
+    __bf16* stg16 = reinterpret_cast<__bf16*>(sm + S_STG);       // BF16: the staged slices as bf16, row stride LB16
 
     // ---------------- start rendezvous: all 256 workgroups must be resident before anyone waits for data
     if (d.near_xcd) persist_scrub(xr, OFF_CTX, OFF_M1 - OFF_CTX, g0, tid);      // context, m0, h0, h1 rings: the ones a slice group may keep in its L2
@@ -98,14 +104,20 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 
     // ---------------- once: this workgroup's constants.  Cell kernels -> registers (MFMA A operands), wave v = gate-column group v of the tile:
     //   w0[ks]: k-steps 0..23 = context rows of reduction slice gi, 24..31 = its prenet rows (FOLD), 32..63 = its h0 rows; w1[ks]: 0..31 = m0 rows, 32..63 = h1 rows
-    float w0[64], w1[64];
+    float w0[BF16 ? 1 : 64], w1[BF16 ? 1 : 64];
+    pbf16x8 wb0[BF16 ? 8 : 1], wb1[BF16 ? 8 : 1];                // BF16: the same 64 + 64 values as 8 + 8 packed octets (k-steps 8 j .. 8 j + 7)
     {
         const float* p0 = d.w0pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) w0[r] = (FOLD || r < 24 || r >= 32) ? p0[r * 64] : 0.f;
         const float* p1 = d.w1pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
+        if constexpr (BF16) {
 #pragma unroll
-        for (int r = 0; r < 64; ++r) w1[r] = p1[r * 64];
+            for (int r = 0; r < 64; ++r) { wb0[r >> 3][r & 7] = (__bf16)p0[r * 64]; wb1[r >> 3][r & 7] = (__bf16)p1[r * 64]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) w0[r] = (FOLD || r < 24 || r >= 32) ? p0[r * 64] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) w1[r] = p1[r * 64];
+        }
     }
     // attention role: row ab = gj, unit slice gi (query units / key columns 16 gi ..), value columns 96 gi ..
     int ab = gj;
@@ -129,7 +141,11 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
         for (int x = tid; x < TT + 48; x += PTH) sm[S_CUM + x] = 0.f;
         const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqpk) + (long)gi * 8 * 512;      // query kernel slice: [8][512 threads] float4
-        for (int x = tid; x < 8 * 512; x += PTH) reinterpret_cast<pf32x4*>(sm + S_WQ)[x] = wqs[x];
+        for (int x = tid; x < 8 * 512; x += PTH) {
+            pf32x4 v = wqs[x];
+            if constexpr (BF16) { v[0] = bf16_round(v[0]); v[1] = bf16_round(v[1]); v[2] = bf16_round(v[2]); v[3] = bf16_round(v[3]); }
+            reinterpret_cast<pf32x4*>(sm + S_WQ)[x] = v;
+        }
     }
     float lkb[8];                                                // filter slice as MFMA B operand: lk[4 ks + (lane >> 4)][unit lane & 15]; tap 31 is zero
     __syncthreads();
@@ -229,16 +245,24 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         if (FOLD) {
             // prenet slice of this step (requested one step ahead) -> columns 24..31 of the staging rows, multiplied at once: this runs in the
             // shadow of the context hand-off, which has nothing else to hide behind; then the context slice (columns 0..23) when it arrives
-            if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
-            __syncthreads();
-            mfma_part<6, 8, LA, 0, 64>(w0, stg, lane, acc0);
+            if constexpr (BF16) {
+                if (tid < 256) *reinterpret_cast<pbf16x4*>(stg16 + (tid >> 1) * LB16 + 24 + 4 * (tid & 1)) = to_bf16x4(prv);
+                __syncthreads();
+                mfma_part_bf16<3, 4, 0>(wb0, stg16, lane, acc0);
+            } else {
+                if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
+                __syncthreads();
+                mfma_part<6, 8, LA, 0, 64>(w0, stg, lane, acc0);
+            }
             if (s > 0) {
                 PSTAMP(0);
                 slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
-                if (!slice_complete<6, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
+                if constexpr (BF16) { if (!slice_complete_bf16<6>(xr, stg16, tid, soff, sv, d.ctrl, pgen)) PFAIL(); }
+                else { if (!slice_complete<6, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL(); }
                 PABORT_CHECK();
                 PSTAMP(1);
-                mfma_part<0, 6, LA, 0, 64>(w0, stg, lane, acc0);
+                if constexpr (BF16) mfma_part_bf16<0, 3, 0>(wb0, stg16, lane, acc0);
+                else mfma_part<0, 6, LA, 0, 64>(w0, stg, lane, acc0);
             }
         } else {
             if (s > 0) {
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 PABORT_CHECK();
                 PSTAMP(1);
             }
-            if (s > 0) mfma_part<0, 6, LC, 0, 64>(w0, stg, lane, acc0);
+            if constexpr (!BF16) { if (s > 0) mfma_part<0, 6, LC, 0, 64>(w0, stg, lane, acc0); }
         }
         PUBLISH_PARTIAL(OFF_P0, acc0)
         PSTAMP(2);
@@ -256,9 +280,11 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         if (s > 0) {
             slice_issue<8>(xr, OFF_H1 + pslot * XACT + gi * 4096L, tid, soff, sv);
             __syncthreads();                                         // the context rows are consumed by every wave
-            if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL();
+            if constexpr (BF16) { if (!slice_complete_bf16<8>(xr, stg16, tid, soff, sv, d.ctrl, pgen)) PFAIL(); }
+            else { if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL(); }
             PABORT_CHECK();
-            mfma_part<0, 8, LA, 32, 64>(w1, stg, lane, acc1);
+            if constexpr (BF16) mfma_part_bf16<0, 4, 4>(wb1, stg16, lane, acc1);
+            else mfma_part<0, 8, LA, 32, 64>(w1, stg, lane, acc1);
         }
         PSTAMP(13);
         // ================= B: sum of the eight partials, cell-0 update
@@ -305,18 +331,22 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         PSTAMP(4);
         // ================= C: cell 1, input rows (m0_s)   (every wave passed the barriers of B since it read the staged h1)
         slice_issue<8>(xr, OFF_M0 + slot * XACT + gi * 4096L, tid, soff, sv);
-        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
+        if constexpr (BF16) { if (!slice_complete_bf16<8>(xr, stg16, tid, soff, sv, d.ctrl, gen)) PFAIL(); }
+        else { if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL(); }
         PABORT_CHECK();
         PSTAMP(5);
         slice_issue<8>(xr, OFF_H0 + slot * XACT + gi * 4096L, tid, soff, sv);     // h0_s left its producers together with m0_s: it arrives under the product
-        mfma_part<0, 8, LA, 0, 64>(w1, stg, lane, acc1);
+        if constexpr (BF16) mfma_part_bf16<0, 4, 0>(wb1, stg16, lane, acc1);
+        else mfma_part<0, 8, LA, 0, 64>(w1, stg, lane, acc1);
         PUBLISH_PARTIAL(OFF_P1, acc1)
         PSTAMP(6);
         // in the shadow of the partial-gates hand-off: h0_s staged, first half of h0_s . W0[h rows] for step s+1
         __syncthreads();                                             // m0 is consumed by every wave
-        if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL();
+        if constexpr (BF16) { if (!slice_complete_bf16<8>(xr, stg16, tid, soff, sv, d.ctrl, gen)) PFAIL(); }
+        else { if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL(); }
         PABORT_CHECK();
-        mfma_part<0, 4, LA, 32, 64>(w0, stg, lane, acc0);
+        if constexpr (BF16) mfma_part_bf16<0, 2, 4>(wb0, stg16, lane, acc0);
+        else mfma_part<0, 4, LA, 32, 64>(w0, stg, lane, acc0);
         PSTAMP(7);
         // ================= D: sum of the eight partials, cell-1 update
         ISSUE_PARTIALS(OFF_P1)
@@ -361,7 +391,8 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
         PSTAMP(9);
         // in the shadow of the m1 hand-off: second half of h0_s . W0[h rows]
-        mfma_part<4, 8, LA, 32, 64>(w0, stg, lane, acc0);
+        if constexpr (BF16) mfma_part_bf16<2, 4, 4>(wb0, stg16, lane, acc0);
+        else mfma_part<4, 8, LA, 32, 64>(w0, stg, lane, acc0);
         PSTAMP(10);
         // ================= E: attention, query units and partial energies of row ab
         if (arow) {
@@ -383,7 +414,8 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             }
             if (tid < 256) {
                 { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }
-                *reinterpret_cast<pf32x4*>(sm + S_M1 + 4 * tid) = rv[0];
+                if constexpr (BF16) { rv[0][0] = bf16_round(rv[0][0]); rv[0][1] = bf16_round(rv[0][1]); rv[0][2] = bf16_round(rv[0][2]); rv[0][3] = bf16_round(rv[0][3]); }
+                *reinterpret_cast<pf32x4*>(sm + S_M1 + 4 * tid) = rv[0];       // (BF16: the query product's operands are bf16 values; their products are exact in fp32)
             }
             PABORT_CHECK();
             PSTAMP(11);
@@ -584,6 +616,11 @@ extern "C" int32_t mstts_persist_fwd_supported(int64_t B, int64_t H, int64_t M, 
         PFW_SETUP(false, false, 128) PFW_SETUP(true, false, 128) PFW_SETUP(false, true, 128) PFW_SETUP(true, true, 128)
         PFW_SETUP(false, false, 256) PFW_SETUP(true, false, 256) PFW_SETUP(false, true, 256) PFW_SETUP(true, true, 256)
 #undef PFW_SETUP
+#define PFW_SETUP16(P_, T_)                                                                                                                            \
+        ok = ok && hipFuncSetAttribute((const void*)persist_fwd_kernel<P_, true, T_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FL<T_>::S_FLOATS * 4)) == hipSuccess && \
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_fwd_kernel<P_, true, T_, true>, PTH, (size_t)FL<T_>::S_FLOATS * 4) == hipSuccess && per >= 1;
+        PFW_SETUP16(false, 128) PFW_SETUP16(true, 128) PFW_SETUP16(false, 256) PFW_SETUP16(true, 256)
+#undef PFW_SETUP16
         (void)per_cu;
         return ok;
     });
@@ -630,10 +667,14 @@ extern "C" int mstts_decoder_train_fwd_persistent(const mstts_decoder_train_desc
     a.in0 = d->in0; a.in1 = d->in1; a.pj = d->pj; a.c0 = d->c0; a.c1 = d->c1; a.acts0 = d->acts0; a.acts1 = d->acts1;
     a.craw0 = d->craw0; a.craw1 = d->craw1; a.q_hist = d->q_hist; a.align_hist = d->align_hist; a.cum_hist = d->cum_hist;
     a.opk = p->opk; a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
+    MSTTS_REQUIRE(!p->recurrent_bf16 || fold, MSTTS_ERR_SHAPE, "decoder_train_fwd_persistent: the bf16 form needs the folded prenet product (pre / b0)");
 #define PFW_LAUNCH(T_)                                                                                                                  \
     {                                                                                                                                   \
         const size_t lds = (size_t)FL<T_>::S_FLOATS * 4;                                                                                \
-        if (fold) {                                                                                                                     \
+        if (p->recurrent_bf16) {                                                                                                        \
+            if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, true, T_, true>), dim3(PWG), dim3(PTH), lds, hs, a);            \
+            else hipLaunchKernelGGL((persist_fwd_kernel<false, true, T_, true>), dim3(PWG), dim3(PTH), lds, hs, a);                     \
+        } else if (fold) {                                                                                                              \
             if (p->stamps) hipLaunchKernelGGL((persist_fwd_kernel<true, true, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                  \
             else hipLaunchKernelGGL((persist_fwd_kernel<false, true, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                           \
         } else {                                                                                                                        \

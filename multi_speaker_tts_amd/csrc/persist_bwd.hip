@@ -21,7 +21,7 @@
 //     d_alignment = sum over the 8 slices of (values_i . d_ctx_i + G_i), so ONE exchange per step carries both.
 // Exact fp32, fixed summation order (deterministic).  Bounded waits / abort word / start rendezvous as in the forward kernel; on
 // abort the host re-runs mstts_decoder_train_bwd.
-#include "persist_common.h"
+#include "persist_fwd_parts.h"        // (the bf16 operand types and the 16x16x32 bf16 MFMA macro; persist_common.h through it)
 
 namespace mstts {
 
@@ -86,7 +86,11 @@ __device__ __forceinline__ pf32x4 cell_bwd(float dm, float& dhs, float& dcs, flo
     return dg;
 }
 
-template <bool PROF, int TT>
+// BF16 (BASELINE config 3): the data-gradient products d[g] . W^T of both cells and of the query layer take their operands rounded to bf16
+// (the transposed kernels once, when they are loaded into registers; the gate / query gradients when they are fetched) and run on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulators; the cell-update backward, the attention backward and everything exchanged stay fp32, and
+// the gate gradients written for the hoisted weight-gradient products are the unrounded ones (those products round for themselves).
+template <bool PROF, int TT, bool BF16 = false>
 __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     typedef BL<TT> Y;
     constexpr int B_RED = Y::B_RED, B_G = Y::B_G, B_PC = Y::B_PC, B_DA = Y::B_DA, B_PD = Y::B_PD, B_TR = Y::B_TR, B_GP = Y::B_GP, B_A = Y::B_A, B_CUM = Y::B_CUM,
@@ -116,14 +120,20 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 
     // ---------------- once: the transposed kernels of this workgroup / wave -> registers.  w1t[h * 32 + kt * 16 + ks]: half h (0 = the
     // rows on the chain: m0 units, 1 = h1 units), output tile kt, contraction step ks of this wave's eighth; w0t likewise (context / h0)
-    float w1t[64], w0t[64];
+    float w1t[BF16 ? 1 : 64], w0t[BF16 ? 1 : 64];
+    pbf16x8 wb1t[BF16 ? 8 : 1], wb0t[BF16 ? 8 : 1];              // BF16: the same values as packed octets (contraction steps 8 j .. 8 j + 7 of a (half, tile))
     {
         const float* p1 = d.w1t + ((long)(g * 8 + wave) * 64) * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) w1t[r] = p1[r * 64];
         const float* p0 = d.w0t + ((long)(g * 8 + wave) * 64) * 64 + lane;
+        if constexpr (BF16) {
 #pragma unroll
-        for (int r = 0; r < 64; ++r) w0t[r] = p0[r * 64];
+            for (int r = 0; r < 64; ++r) { wb1t[r >> 3][r & 7] = (__bf16)p1[r * 64]; wb0t[r >> 3][r & 7] = (__bf16)p0[r * 64]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) w1t[r] = p1[r * 64];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) w0t[r] = p0[r * 64];
+        }
     }
     int ab = gj;
     const bool arow = ab < B;
@@ -147,7 +157,11 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         for (int x = tid; x < TT + 48; x += PTH) sm[B_CUM + x] = 0.f;
         for (int x = tid; x < TT; x += PTH) { sm[B_GP + x] = 0.f; sm[B_A + x] = 0.f; sm[B_DE + x] = 0.f; }
         const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqt) + (long)gi * 16 * 256;
-        for (int x = tid; x < 16 * 256; x += PTH) reinterpret_cast<pf32x4*>(sm + B_WQT)[x] = wqs[x];
+        for (int x = tid; x < 16 * 256; x += PTH) {
+            pf32x4 v = wqs[x];
+            if constexpr (BF16) { v[0] = bf16_round(v[0]); v[1] = bf16_round(v[1]); v[2] = bf16_round(v[2]); v[3] = bf16_round(v[3]); }
+            reinterpret_cast<pf32x4*>(sm + B_WQT)[x] = v;
+        }
     }
     int et = wave & 1, er = 16 * et + (lane & 15), ee = lane >> 4, eu = 4 * g + ee;
     bool ew = wave < 2, elive = ew && er < B;
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 float qv = 0.f;
 #pragma unroll
                 for (int u = 0; u < 32; ++u) qv += sm[B_DQ + u * 16 + tid];
-                sm[B_DQF + tid] = qv;
+                sm[B_DQF + tid] = BF16 ? bf16_round(qv) : qv;       // (BF16: the data-gradient product's operand; the history keeps the unrounded value)
                 (d.dq_hist + (sB + ab) * PA + 16 * gi)[tid] = qv;
             }
             __syncthreads();
@@ -460,17 +474,30 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 off[x] = (unsigned)(((OFF_DG) + slot * BDG + ((((long)(gi * 8 + wave) * 2 + (x >> 2)) * 4 + (x & 3)) * 64 + lane) * 4) * 4); \
             const unsigned g8[8] = {gen, gen, gen, gen, gen, gen, gen, gen};                                                         \
             if (!gather<8>(xr, off, bq, d.ctrl, g8)) PFAIL();                                                                            \
+        }                                                                                                                            \
+        pbf16x8 bqh[BF16 ? 4 : 1];            /* BF16: [row tile t][octet j] = contraction steps 8 j .. 8 j + 7 of tile t, rounded */  \
+        if constexpr (BF16) {                                                                                                        \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                            \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) bqh[x][e] = (__bf16)bq[(x >> 1) * 4 + 2 * (x & 1) + (e >> 2)][e & 3];  \
         }
-#define PROD_HALF(half, WT, OFF_OUT, IS_CTX)                                                                                          \
+#define PROD_HALF(half, WT, WB, OFF_OUT, IS_CTX)                                                                                      \
         {                                                                                                                            \
             pf32x4 acc[2][2];                                                                                                        \
             _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
                 _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[kt][t] = (pf32x4){0.f, 0.f, 0.f, 0.f};                             \
-            _Pragma("unroll") for (int ks = 0; ks < 16; ++ks)                                                                        \
-                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                                   \
-                    acc[kt][0] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[ks >> 2][ks & 3], acc[kt][0]);                             \
-                    acc[kt][1] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[4 + (ks >> 2)][ks & 3], acc[kt][1]);                       \
-                }                                                                                                                    \
+            if constexpr (BF16) {                                                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
+                        acc[kt][0] = PMFMA_BF16(WB[(half) * 4 + kt * 2 + j], bqh[j], acc[kt][0]);                                     \
+                        acc[kt][1] = PMFMA_BF16(WB[(half) * 4 + kt * 2 + j], bqh[2 + j], acc[kt][1]);                                 \
+                    }                                                                                                                \
+            } else {                                                                                                                 \
+                _Pragma("unroll") for (int ks = 0; ks < 16; ++ks)                                                                    \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
+                        acc[kt][0] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[ks >> 2][ks & 3], acc[kt][0]);                         \
+                        acc[kt][1] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[4 + (ks >> 2)][ks & 3], acc[kt][1]);                   \
+                    }                                                                                                                \
+            }                                                                                                                        \
             if ((half) == 1) __syncthreads();                        /* the first tile's readers are done */                         \
             _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
                 _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                        \
@@ -495,7 +522,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         pf32x4 A0_, B0_;                      // cell-0 operands as loaded: split into activations / states / mask bits only where the update uses them
         {
             PROD_GATHER(BO_DG1)
-            PROD_HALF(0, w1t, BO_PM0, false)
+            PROD_HALF(0, w1t, wb1t, BO_PM0, false)
             PSTAMP(8);
             {   // operands of the cell-0 update backward: requested here, they arrive under the second half and the hand-off
                 const pf32x4* ob = reinterpret_cast<const pf32x4*>(d.opk) + opk_index(s, g0, 0, 0, tid0 & 127);
@@ -503,7 +530,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 // (no arithmetic on them here: the first use makes the compiler wait for the loads, and its vmcnt(0) - the publication just
                 //  above sits in a conditional block - also waits for that write-through store to be acknowledged: 0.5 us in this stage)
             }
-            PROD_HALF(1, w1t, BO_PH1, false)
+            PROD_HALF(1, w1t, wb1t, BO_PH1, false)
         }
         PSTAMP(9);
         // ================= cell 0, update backward
@@ -550,9 +577,9 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         PSTAMP(11);
         {
             PROD_GATHER(BO_DG0)
-            PROD_HALF(0, w0t, BO_PM0, true)
+            PROD_HALF(0, w0t, wb0t, BO_PM0, true)
             PSTAMP(12);
-            PROD_HALF(1, w0t, BO_PH0, false)
+            PROD_HALF(1, w0t, wb0t, BO_PH0, false)
         }
         PSTAMP(13);
 #ifndef EXP_NO_OPLOAD
@@ -666,6 +693,11 @@ extern "C" int32_t mstts_persist_bwd_supported(int64_t B, int64_t H, int64_t M, 
              hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_bwd_kernel<P_, T_>, PTH, (size_t)BL<T_>::B_FLOATS * 4) == hipSuccess && per >= 1;
         PBW_SETUP(false, 128) PBW_SETUP(true, 128) PBW_SETUP(false, 256) PBW_SETUP(true, 256)
 #undef PBW_SETUP
+#define PBW_SETUP16(P_, T_)                                                                                                                            \
+        ok = ok && hipFuncSetAttribute((const void*)persist_bwd_kernel<P_, T_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BL<T_>::B_FLOATS * 4)) == hipSuccess && \
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)persist_bwd_kernel<P_, T_, true>, PTH, (size_t)BL<T_>::B_FLOATS * 4) == hipSuccess && per >= 1;
+        PBW_SETUP16(false, 128) PBW_SETUP16(true, 128) PBW_SETUP16(false, 256) PBW_SETUP16(true, 256)
+#undef PBW_SETUP16
         (void)per_cu;
         return ok;
     });
@@ -706,15 +738,19 @@ extern "C" int mstts_decoder_train_bwd_persistent(const mstts_decoder_train_bwd_
     a.d_pj = bd->d_pj; a.opk = p->opk; a.B = (int)B; a.S = (int)S; a.T = (int)T;
     a.dg0 = bd->dg0; a.dg1 = bd->dg1; a.dq_hist = bd->dq_hist; a.de_hist = bd->de_hist; a.d_in0 = bd->d_in0;
     a.xch = p->xch; a.ctrl = p->ctrl; a.stamps = (unsigned long long*)p->stamps; a.fail_step = p->selftest_fail_step > 0 ? p->selftest_fail_step - 1 : -1; a.near_xcd = p->near_xcd;
-    if (a.T <= 128) {       // (the 128-position instantiation; beyond that the positions from 128 on are read from memory)
-        const size_t lds = (size_t)BL<128>::B_FLOATS * 4;
-        if (p->stamps) hipLaunchKernelGGL((persist_bwd_kernel<true, 128>), dim3(PWG), dim3(PTH), lds, hs, a);
-        else hipLaunchKernelGGL((persist_bwd_kernel<false, 128>), dim3(PWG), dim3(PTH), lds, hs, a);
-    } else {
-        const size_t lds = (size_t)BL<256>::B_FLOATS * 4;
-        if (p->stamps) hipLaunchKernelGGL((persist_bwd_kernel<true, 256>), dim3(PWG), dim3(PTH), lds, hs, a);
-        else hipLaunchKernelGGL((persist_bwd_kernel<false, 256>), dim3(PWG), dim3(PTH), lds, hs, a);
+#define PBW_LAUNCH(T_)                                                                                                                  \
+    {                                                                                                                                   \
+        const size_t lds = (size_t)BL<T_>::B_FLOATS * 4;                                                                                \
+        if (p->recurrent_bf16) {                                                                                                        \
+            if (p->stamps) hipLaunchKernelGGL((persist_bwd_kernel<true, T_, true>), dim3(PWG), dim3(PTH), lds, hs, a);                  \
+            else hipLaunchKernelGGL((persist_bwd_kernel<false, T_, true>), dim3(PWG), dim3(PTH), lds, hs, a);                           \
+        } else {                                                                                                                        \
+            if (p->stamps) hipLaunchKernelGGL((persist_bwd_kernel<true, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                        \
+            else hipLaunchKernelGGL((persist_bwd_kernel<false, T_>), dim3(PWG), dim3(PTH), lds, hs, a);                                 \
+        }                                                                                                                               \
     }
+    if (a.T <= 128) PBW_LAUNCH(128) else PBW_LAUNCH(256)      // (the 128-position instantiation; beyond that the positions from 128 on are read from memory)
+#undef PBW_LAUNCH
     MSTTS_CHECK_LAUNCH("persist_bwd");
     return MSTTS_OK;
 }

@@ -54,6 +54,54 @@ __device__ __forceinline__ bool slice_complete(__amdgpu_buffer_rsrc_t xr, float*
     return ok;
 }
 
+// ---- BASELINE config 3 ("bf16 with fp32 master"): the same products with both operands rounded to bf16 (round to nearest even) and fp32
+// accumulation on v_mfma_f32_16x16x32_bf16 - 16 times the f32-input MFMA's rate.  One instruction covers EIGHT k-steps of the fp32 form: lane
+// (q = lane >> 4, m) holds, as A operand, the 8 kernel values of k-steps 8 j .. 8 j + 7 it would have used one at a time (same registers,
+// packed in pairs), and as B operand 8 consecutive activations of ITS staging row (the staging rows are per q already) - the sum over the
+// instruction's inner index 8 q + e is the sum over (q, k-step), i.e. the same contraction.  The staged slices are kept as bf16 (converted
+// once, by the thread that fetched the piece, instead of once per consuming wave): row stride 80 B, conflict-free 16-byte reads.
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LB16 = 40;
+#define PMFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ pbf16x4 to_bf16x4(const pf32x4& v) {
+    pbf16x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (__bf16)v[e];
+    return r;
+}
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+// acc[t] += W[k-steps 8 K8A .. 8 K8B) . X[t]; kernel registers wb[WOFF8 + j] = k-steps 8 j .. 8 j + 7
+template <int K8A, int K8B, int WOFF8, int NW, int NT = 2>
+__device__ __forceinline__ void mfma_part_bf16(const pbf16x8 (&wb)[NW], const __bf16* sx, int lane, pf32x4 (&acc)[2]) {
+    const int row0 = ((lane >> 4) * 2) * 16 + (lane & 15);
+#pragma unroll
+    for (int j = K8A; j < K8B; ++j) {
+        const pbf16x8 x0 = *reinterpret_cast<const pbf16x8*>(sx + row0 * LB16 + 8 * j);
+        acc[0] = PMFMA_BF16(wb[WOFF8 + j], x0, acc[0]);
+        if (NT == 2) {
+            const pbf16x8 x1 = *reinterpret_cast<const pbf16x8*>(sx + (row0 + 16) * LB16 + 8 * j);
+            acc[1] = PMFMA_BF16(wb[WOFF8 + j], x1, acc[1]);
+        }
+    }
+}
+// slice_complete with the pieces rounded to bf16 on their way into the staging buffer
+template <int K4>
+__device__ __forceinline__ bool slice_complete_bf16(__amdgpu_buffer_rsrc_t xr, __bf16* stg, int tid, const unsigned (&off)[2], pf32x4 (&v)[2], const unsigned* ctrl, unsigned gen) {
+    constexpr int NPC = 128 * K4;
+    const unsigned gens[2] = {gen, gen};
+    const bool ok = complete<2>(xr, off, v, ctrl, gens);
+    {
+        const int rho = tid / K4, k4 = tid - rho * K4;
+        *reinterpret_cast<pbf16x4*>(stg + rho * LB16 + 4 * k4) = to_bf16x4(v[0]);
+    }
+    if (tid + PTH < NPC) {
+        const int p = tid + PTH, rho = p / K4, k4 = p - rho * K4;
+        *reinterpret_cast<pbf16x4*>(stg + rho * LB16 + 4 * k4) = to_bf16x4(v[1]);
+    }
+    return ok;
+}
+
 struct CellOut { float si, tj, sf, so, c, m; };
 // ZoneoutLSTMCell.py:228-271 for one (row, unit): gates i, j, f, o (forget bias 1.0 added here); zoneout as state' = k (new - old) + old with
 // k = (1 - z) * keep-mask in training (:266-271) and k = 1 - z at inference (:259-264)

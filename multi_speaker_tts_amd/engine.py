@@ -118,8 +118,13 @@ class TrainEngine:
         He = d.enc_lstm
         self.enc_whp = {dr: self._f(He * 4 * He) for dr in ("fw", "bw")} if lb.mstts_cell_fwd_supported(He, He) else None
         self.wq_t = self._f(d.att * H) if d.att == 128 else None         # query kernel as [A/4, H, 4] (fused query-layer data gradient)
-        # persistent decoder loop (csrc/persist.hip): fp32, reference widths; MSTTS_PERSIST=0 keeps the launch-per-step loop
-        self.persist = (os.environ.get("MSTTS_PERSIST", "1") != "0" and (recurrent_dtype or "f32").lower() == "f32"
+        # persistent decoder loop (csrc/persist.hip): reference widths; MSTTS_PERSIST=0 keeps the launch-per-step loop.  fp32 recurrent products
+        # (BASELINE config 2), or - round 5 - bf16 ones when the whole step runs config-3 arithmetic (recurrent_dtype AND gemm_dtype "bf16":
+        # the bf16 instantiation forms the prenet rows' product itself, as a bf16 product like the hoisted one it replaces; with fp32
+        # contractions around bf16 loops that product would have to stay fp32, and that combination keeps the launch-per-step loops)
+        rdt, gdt = (recurrent_dtype or "f32").lower(), (gemm_dtype or "f32").lower()
+        self.persist_bf16 = rdt == "bf16" and gdt == "bf16" and d.prenet == 256 and os.environ.get("MSTTS_PERSIST_BF16", "1") != "0"
+        self.persist = (os.environ.get("MSTTS_PERSIST", "1") != "0" and (rdt == "f32" or self.persist_bf16)
                         and bool(lb.mstts_persist_fwd_supported(1, H, M, d.att, 1, d.att_k)))
         self.persist_fallbacks = 0           # sequences that had to be re-run on the launch-per-step path
         # Adaptive policy: a persistent launch that gives up costs its rendezvous bound plus the slow loop, and something that holds CUs
@@ -223,6 +228,15 @@ class TrainEngine:
                 call("mstts_pack_cell_fwd", ptr(ke, oke + cin_e * 4 * He), 4 * He, ptr(self.enc_whp[dr]), He, He)
         if self.wq_t is not None:
             call("mstts_transpose01", ptr(wq_, oq_), ptr(self.wq_t), H, d.att // 4, 4)      # [H, A/4, 4] -> [A/4, H, 4]
+        if self.bf is not None:              # bf16 copies of the master weights for the launch-per-step bf16 loops, in the lanes' consumption order
+            A_ = d.att
+            f0, f1, fq, b0, b1, bq = self.bf["splits"]
+            call("mstts_pack_bf16_fwd", ptr(self.w0f), 4 * H, ptr(self.bf["w0f_f"]), M + H, 4 * H, f0)
+            call("mstts_pack_bf16_fwd", ptr(k1, o1), 4 * H, ptr(self.bf["w1_f"]), 2 * H, 4 * H, f1)
+            call("mstts_pack_bf16_fwd", ptr(wq_, oq_), A_, ptr(self.bf["wq_f"]), H, A_, fq)
+            call("mstts_pack_bf16_bwd", ptr(self.w0f), 4 * H, ptr(self.bf["w0f_b"]), M + H, 4 * H, b0)
+            call("mstts_pack_bf16_bwd", ptr(k1, o1), 4 * H, ptr(self.bf["w1_b"]), 2 * H, 4 * H, b1)
+            call("mstts_pack_bf16_bwd", ptr(wq_, oq_), A_, ptr(self.bf["wq_b"]), H, A_, bq)
 
     def refresh_derived(self):
         """Folded cell-0 kernel (context rows appear twice) and the 4-column padded
@@ -246,16 +260,6 @@ class TrainEngine:
             call("mstts_persist_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(k0, o0), ptr(self.pk[0]), ptr(self.pk[1]), ptr(self.pk[2]))
         if self.persist_bwd:
             call("mstts_persist_bwd_pack", ptr(self.w0f), ptr(k1, o1), ptr(wq_, oq_), ptr(self.pkb[0]), ptr(self.pkb[1]), ptr(self.pkb[2]))
-        if self.bf is not None:              # bf16 copies of the master weights, in the lanes' consumption order
-            A_ = d.att
-            k1, o1 = self.P(CELL % 1 + "kernel"); wq_, oq_ = self.P(LSA + "query_layer/kernel")
-            f0, f1, fq, b0, b1, bq = self.bf["splits"]
-            call("mstts_pack_bf16_fwd", ptr(self.w0f), 4 * H, ptr(self.bf["w0f_f"]), M + H, 4 * H, f0)
-            call("mstts_pack_bf16_fwd", ptr(k1, o1), 4 * H, ptr(self.bf["w1_f"]), 2 * H, 4 * H, f1)
-            call("mstts_pack_bf16_fwd", ptr(wq_, oq_), A_, ptr(self.bf["wq_f"]), H, A_, fq)
-            call("mstts_pack_bf16_bwd", ptr(self.w0f), 4 * H, ptr(self.bf["w0f_b"]), M + H, 4 * H, b0)
-            call("mstts_pack_bf16_bwd", ptr(k1, o1), 4 * H, ptr(self.bf["w1_b"]), 2 * H, 4 * H, b1)
-            call("mstts_pack_bf16_bwd", ptr(wq_, oq_), A_, ptr(self.bf["wq_b"]), H, A_, bq)
         wp, owp = self.P("decoder/decoder/linear_projection/dense/kernel")
         bp, obp = self.P("decoder/decoder/linear_projection/dense/bias")
         nm1 = d.n_mel + 1
@@ -526,7 +530,7 @@ class TrainEngine:
         self._gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)
         k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
         # cell-0 input product xw0 = prenet . W0[:P] + b0: inside the persistent launch (fp32 mode, 256-wide prenet), else hoisted here
-        w.fold_prenet = w.persist_now and self.gemm_dtype == "f32" and Pn == 256 and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"
+        w.fold_prenet = w.persist_now and Pn == 256 and (self.persist_bf16 or (self.gemm_dtype == "f32" and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"))
         xw0_product = lambda: self._gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
         if not w.fold_prenet:
             xw0_product()
@@ -568,6 +572,7 @@ class TrainEngine:
             w.opk_valid = pd.opk is not None
             pd.selftest_fail_step = int(self.persist_selftest)
             pd.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
+            pd.recurrent_bf16 = int(self.persist_bf16)
             pd.pre, pd.b0 = (ptr(x), ptr(b0, ob0)) if w.fold_prenet else (None, None)
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
             ev = torch.cuda.Event()
@@ -788,6 +793,7 @@ class TrainEngine:
             pb.opk = ptr(w.opk)
             pb.selftest_fail_step = int(self.persist_bwd_selftest)
             pb.near_xcd = int(os.environ.get("MSTTS_PERSIST_NEAR", "1") != "0")
+            pb.recurrent_bf16 = int(self.persist_bf16)
             call("mstts_decoder_train_bwd_persistent", C.byref(db), C.byref(pb))
             ev = torch.cuda.Event(enable_timing=self.trace_events)
             ev.record()

@@ -93,7 +93,7 @@ class DecoderTrain(C.Structure):
 
 
 class PersistDesc(C.Structure):
-    _fields_ = [("w0pk", vp), ("w1pk", vp), ("wqpk", vp), ("xch", vp), ("ctrl", vp), ("stamps", vp), ("opk", vp), ("selftest_fail_step", i32), ("near_xcd", i32), ("pre", vp), ("b0", vp), ("reserved0", i32)]
+    _fields_ = [("w0pk", vp), ("w1pk", vp), ("wqpk", vp), ("xch", vp), ("ctrl", vp), ("stamps", vp), ("opk", vp), ("selftest_fail_step", i32), ("near_xcd", i32), ("pre", vp), ("b0", vp), ("recurrent_bf16", i32)]
 
 
 class PersistInferDesc(C.Structure):
@@ -270,7 +270,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4          # = mstts_abi_version() of the library this binding's ctypes structs describe (bump both on a descriptor change)
+ABI_VERSION = 5          # = mstts_abi_version() of the library this binding's ctypes structs describe (bump both on a descriptor change)
 
 
 class MsttsError(RuntimeError):

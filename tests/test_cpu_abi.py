@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(lib.SIGNATURES) == declared, set(lib.SIGNATURES) ^ set(declared)
     cdll.mstts_abi_version.restype = ctypes.c_int
     from multi_speaker_tts_amd.lib import ABI_VERSION
-    assert cdll.mstts_abi_version() == ABI_VERSION == 4
+    assert cdll.mstts_abi_version() == ABI_VERSION == 5
     # host-only helpers are callable without a GPU
     cdll.mstts_skinny_fwd_splits.restype = ctypes.c_int32
     cdll.mstts_skinny_fwd_splits.argtypes = [ctypes.c_int64, ctypes.c_int64]

@@ -132,6 +132,58 @@ def test_depth_parity_train(dev, L):
     _train_depth_case(dev, 4, 64, L, "train", three_way=(L == 200))
 
 
+@pytest.mark.parametrize("L", [200])
+def test_depth_parity_train_bf16(dev, monkeypatch, L):
+    """BASELINE config 3 arithmetic at depth, on the persistent bf16 launches: B = 4 x 64 tokens x L frames at the reference widths against the
+    bf16-EMULATING oracle (oracle.model.GEMM_BF16 + RECURRENT_BF16) with the bounds of test_gpu_model.py::test_train_step_parity_bf16_full, whose
+    docstring says why a whole step in this mode is compared in relative L2: the emulation must be clearly closer to the HIP path than exact
+    arithmetic is, forward tensors <= 2e-3 / 2e-2, gradients at the oracle's own noise level."""
+    from test_gpu_model import _l2
+    from helpers import to_dev
+    from multi_speaker_tts_amd.engine import TrainEngine
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    pd, od = dims_pair(**REF)
+    values = OM.init_params(od, 17)
+    g = np.random.default_rng(18)
+    for k in values:
+        if k.endswith(("bias", "beta", "bias_b")):
+            values[k] = g.normal(0, 0.1, values[k].shape)
+        if k.endswith("gamma"):
+            values[k] = 1.0 + g.normal(0, 0.1, values[k].shape)
+    B, Te = 4, 64
+    batch = OT.synthetic_batch(od, B, Te, L, seed=17, ragged=True)
+    masks = OT.make_masks(od, B, Te, L + 1, True, seed=OT.step_seed(1234, 0))
+    eng = TrainEngine(pd, device=dev, values=values, recurrent_dtype="bf16", gemm_dtype="bf16")
+    if not (eng.persist and eng.persist_bf16):
+        pytest.skip("persistent bf16 loops not available on this device")
+    w = eng.plan(B, Te, L)
+    eng.forward(to_dev(batch, dev), w, seed=OT.step_seed(1234, 0))
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    assert w.persist and w.persist_bwd and w.pdesc.recurrent_bf16 == 1 and eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0
+    omasks = dict(masks)
+    for i in range(od.enc_conv_n):
+        omasks["relu_enc_%d" % i] = (w.enc_a[i] > 0).reshape(B, Te, od.enc_conv_ch).cpu()
+    monkeypatch.setattr(OM, "KINK_BAND", 5e-2)
+    ggot = eng.params.export(grads=True)
+    res = {}
+    for mode in ("emulated", "exact"):
+        monkeypatch.setattr(OM, "RECURRENT_BF16", mode == "emulated")
+        monkeypatch.setattr(OM, "GEMM_BF16", mode == "emulated")
+        _, _, sc, grads, out = OT.train_step(values, None, od, batch, omasks, 0, return_grads=True)
+        gl2 = {k: _l2(ggot[k].astype(np.float64) + (1e-6 * np.asarray(values[k]) if OM.in_weight_reg(k) else 0.0), t2n(gr)) for k, gr in grads.items()}
+        res[mode] = dict(linear=_l2(t2n(w.linear), t2n(out["Linear"])), mel=_l2(t2n(w.mel_out), t2n(out["Mel"])),
+                         align=_l2(t2n(w.align_hist).transpose(1, 2, 0), t2n(out["Attention_History"])), loss=sc["Loss"],
+                         grads_median=float(np.median(list(gl2.values()))), grads_worst=max(gl2.items(), key=lambda kv: kv[1]))
+    em, ex = res["emulated"], res["exact"]
+    _record("train_bf16", dict(B=B, tokens=Te, L=L, steps=L + 1, persistent_bf16=True, vs_emulating_oracle=em, vs_exact_oracle=ex))
+    print("bf16 depth %d: vs emulating oracle %s; vs exact oracle %s" % (L, em, ex))
+    assert em["linear"] < 2e-3 and em["align"] < 2e-3 and em["mel"] < 2e-2, em
+    assert em["linear"] < ex["linear"] / 3 and em["mel"] < ex["mel"], (em, ex)
+    assert abs(eng.scalars(w)["Loss"] - em["loss"]) <= 1e-3 * max(1.0, abs(em["loss"]))
+    assert em["grads_worst"][1] < 0.15 and em["grads_median"] < 6e-2, em
+
+
 def test_headline_shape_parity(dev):
     """The exact shape the headline metric is quoted on (BASELINE configs[1]; MSTTS_SV.py:129-161, Hyper_Parameters.py:69, Modules.py:215):
     ONE train step at B = 32 x 128 tokens x 800 frames (801 decoder steps), reference widths, every attention row and every key position of

@@ -735,6 +735,10 @@ def test_train_step_parity_bf16_full(dev, monkeypatch, B, Te, L, kw, recurrent):
     eng.forward(to_dev(batch, dev), w, seed=OT.step_seed(1234, 0))
     eng.loss_and_backward(w)
     torch.cuda.synchronize()
+    if recurrent == "bf16" and od.dec_lstm == 1024 and eng.persist:
+        # round 5: at the reference widths the all-bf16 step runs the BF16 instantiations of the persistent decoder launches
+        assert eng.persist_bf16 and w.persist and w.persist_bwd and w.pdesc.recurrent_bf16 == 1 and w.pdesc_b.recurrent_bf16 == 1
+        assert eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0
     omasks = dict(masks)
     for i in range(od.enc_conv_n):
         omasks["relu_enc_%d" % i] = (w.enc_a[i] > 0).reshape(B, Te, od.enc_conv_ch).cpu()

@@ -399,3 +399,58 @@ def test_persistent_launches_back_to_back_on_changed_inputs(dev):
     bad = {k: v for k, v in bad.items() if v > 5e-4}
     assert not bad, bad
     print("slice groups publishing through their XCD's L2: %d of 8" % near_groups)
+
+
+# ---------------------------------------------------------------------------------------------------------------- config 3: bf16 recurrent products
+def _bf16_engines(dev, seed=3):
+    pd, od = dims_pair(**WIDE)
+    values = OM.init_params(od, seed)
+    g = np.random.default_rng(seed + 1)
+    for k in values:
+        if k.endswith(("bias", "bias_b")):
+            values[k] = g.normal(0, 0.1, values[k].shape)
+    eng = TrainEngine(pd, device=dev, values=values, recurrent_dtype="bf16", gemm_dtype="bf16")
+    if not (eng.persist and eng.persist_bf16 and eng.persist_bwd):
+        pytest.skip("persistent bf16 loops not available on this device")
+    return eng, od
+
+
+@pytest.mark.parametrize("B,Te,L,ragged", [(32, 128, 9, False), (8, 40, 12, True), (5, 160, 6, True), (1, 7, 2, False)])
+def test_persistent_bf16_equals_launch_per_step_bf16(dev, B, Te, L, ragged):
+    """BASELINE config 3 arithmetic inside the persistent launches (round 5: the BF16 instantiations of persist_fwd_kernel / persist_bwd_kernel,
+    v_mfma_f32_16x16x32_bf16) against the launch-per-step bf16 loops (csrc/skinny_bf16.hip, cell_fwd_bf16_kernel) on the same engine, inputs and
+    masks: both form bf(X) . bf(W) with fp32 accumulation from the same fp32 operands, in different summation orders.  Rounding to 8 mantissa bits
+    is discontinuous - an operand that differs in the last fp32 bit between the two paths may round to a different bf16 value, 2^-9 of that
+    operand - so the bound is that of one bf16 flip spread over a row, not fp32 rounding: every history tensor <= 2e-3 of its scale, the
+    gradient slab <= 2 % in relative L2.  Zero fallbacks, and the persistent launches really ran in bf16 mode."""
+    eng, od = _bf16_engines(dev)
+    batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=5, ragged=ragged), dev)
+    seed = OT.step_seed(1234, 0)
+    w = eng.plan(B, Te, L)
+    assert w.persist and w.persist_bwd
+    eng.forward(batch, w, seed=seed)
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    assert w.fold_prenet and w.pdesc.recurrent_bf16 == 1 and w.pdesc_b.recurrent_bf16 == 1
+    assert eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0
+    a = _snapshot(w, eng)
+    ga = t2n(eng.params.grad).astype(np.float64)
+    w.persist = w.persist_bwd = False
+    eng.forward(batch, w, seed=seed)
+    eng.loss_and_backward(w)
+    torch.cuda.synchronize()
+    b = _snapshot(w, eng)
+    gb = t2n(eng.params.grad).astype(np.float64)
+    errs = {k: rel_err(a[k], b[k]) for k in a}
+    gl2 = float(np.sqrt(((ga - gb) ** 2).sum() / (gb ** 2).sum()))
+    print("persistent bf16 vs launch-per-step bf16: worst history %s, gradient slab relative L2 %.2e" % (max(errs.items(), key=lambda kv: kv[1]), gl2))
+    assert all(np.isfinite(v).all() for v in a.values())
+    bad = {k: e for k, e in errs.items() if e > 2e-3}
+    assert not bad, bad
+    assert gl2 < 2e-2, gl2
+    # ... and the mode really is bf16: against the fp32 persistent loops the same tensors are off by more than fp32 rounding
+    e32 = TrainEngine(eng.d, device=dev, values=eng.params.export(), gemm_dtype="bf16")
+    w32 = e32.plan(B, Te, L)
+    e32.forward(batch, w32, seed=seed)
+    torch.cuda.synchronize()
+    assert rel_err(_snapshot(w32, e32)["pj"], a["pj"]) > 1e-4

@@ -12,4 +12,5 @@ for (M, N, K, ta) in ((8192, 8192, 8192, 0), (2048, 4096, 12816, 1)):
         lib.gemm(A, B, Cm, M, N, K, A.shape[1], N, N, trans_a=bool(ta), bias=st.view(torch.float32))
     torch.cuda.synchronize()
     v = st.cpu().tolist()
-    print(M, N, K, "consumer: waits %.0f + busy %.0f cycles per K-tile over %d tiles" % (v[0] / max(v[2], 1), (v[1] - v[0]) / max(v[2], 1), v[2]))
+    print(M, N, K, "consumer: waits %.0f + busy %.0f cycles per K-tile over %d tiles; shader clock while it ran: %.0f MHz (cycle counter / 100 MHz wall clock)"
+          % (v[0] / max(v[2], 1), (v[1] - v[0]) / max(v[2], 1), v[2], v[1] / max(v[3], 1) * 100.0))

@@ -108,6 +108,57 @@ def synthetic_batch(dims, B, Te, L, seed, rank, device):
             "Mel_Length": t(np.full(B, L, np.int32)), "Speaker_Embedding": t(spk)}
 
 
+def contraction_replay(eng, batch, w, config3):
+    """Every GEMM-entry-point call of one train step, recorded at the ctypes boundary and replayed on its own (HIP events, 5 repeats per distinct
+    call, as tools/gemm_step_profile.py): their summed time per step and rate.  The fp32 contractions run as six bf16 products per fp32 product,
+    so their ceiling is the bf16 matrix-core peak / 6 (417 TFLOP/s-equivalent at the 2.5 PF spec; the chip runs them power-limited - ~1 375 W, shader
+    clock ~1.95 GHz, profiles/r05_gemm_stamps_and_clock.txt - which puts the attainable ceiling nearer 340); config 3's single-product bf16 contractions
+    are priced against the bf16 peak itself."""
+    import ctypes as C
+    from collections import OrderedDict
+    from multi_speaker_tts_amd import lib
+    import multi_speaker_tts_amd.engine as E
+    calls, real = [], lib.call
+
+    def spy(name, *a):
+        if name in ("mstts_gemm_f32", "mstts_gemm_bf16"):
+            cp = lib.GemmDesc()
+            C.memmove(C.byref(cp), C.byref(a[0]._obj), C.sizeof(lib.GemmDesc))
+            calls.append((name, cp))
+        return real(name, *a)
+    lib.call = E.call = spy
+    try:
+        eng.forward(batch, w)
+        eng.loss_and_backward(w)
+        torch.cuda.synchronize()
+    finally:
+        lib.call = E.call = real
+    groups = OrderedDict()
+    for name, d in calls:
+        groups.setdefault((name, d.M, d.N, d.K, d.trans_a, d.trans_b, d.win_T, d.win_C, d.split_k, d.batch, d.accumulate, d.act), []).append(d)
+    total_us, total_flop = 0.0, 0.0
+    for key, ds in groups.items():
+        d = ds[0]
+        real(key[0], C.byref(d))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            real(key[0], C.byref(d))
+        e1.record()
+        torch.cuda.synchronize()
+        total_us += e0.elapsed_time(e1) * 1e3 / 5 * len(ds)
+        total_flop += 2.0 * d.M * d.N * d.K * max(1, d.batch) * len(ds)
+    tf = total_flop / total_us * 1e-6
+    out = {"calls_per_step": len(calls), "ms_per_step": total_us * 1e-3, "tflops_equivalent": tf,
+           "note": "replayed call by call outside the step (HIP events); accumulating calls re-add onto live gradients - results of this pass are not used"}
+    if config3:
+        out["fraction_of_bf16_mfma_peak"] = tf / 2500.0
+    else:
+        out["contractions_fraction_of_six_product_ceiling"] = tf / (2500.0 / 6.0)
+        out["contractions_fraction_of_fp32_mfma_peak"] = tf / 157.3
+    return out
+
+
 def _cpu_baseline_worker(threads, budget_s):
     """SURVEY 8(d) protocol: the oracle train step (fwd + autograd bwd + TF-Adam) at the FULL workload - batch 32 x (128 tokens, 800
     mel frames) - 1 warm-up + 3 timed steps, median, on the thread count that a short sweep finds fastest (threads = the sweep's
@@ -505,6 +556,7 @@ def main():
         out["roofline_other"] = extra
         out["kernel_avg_us"] = {k: v["avg_us"] for k, v in allk.items()}
         out["step_flops_fraction_of_fp32_mfma_peak"] = (4.047e12 * L / L_MEL) / (ms_per_step * 1e-3) / 157.3e12
+        out["hoisted_contractions"] = contraction_replay(eng, batch, w, args.config3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)

@@ -85,6 +85,10 @@ int mstts_gemm_deterministic(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes. */
 int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t s);
+/* 1 (default): contractions large enough to fill the chip with 256 x 256 tiles run on the big-tile kernel (csrc/gemm_bf16.hip: half the operand
+ * bytes per flop of the 128 x 128 kernel); 0: the 128 x 128 kernel for everything (A/B runs, tests).  Process-wide; MSTTS_GEMM_BF16_BIG=0 in
+ * the environment sets the initial state. */
+int mstts_gemm_bf16_big(int32_t on);
 
 /* ---- randomness: Philox4x32-10 keep-masks (replaces tf.random_uniform inside
  * tf.layers.dropout, Modules.py:41-45,137-141,248-253, and ZoneoutLSTMCell.py:266-271) ---- */

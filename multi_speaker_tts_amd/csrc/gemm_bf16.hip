@@ -11,6 +11,7 @@
 // writes four 8-byte k-runs.  The next K-tile is prefetched into registers while the current one is multiplied.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace mstts {
 
@@ -255,11 +256,293 @@ static void launch_gemm_bf16(const GemmBfArgs& g, bool vec, dim3 grid, hipStream
     else     hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, false>), grid, dim3(256), 0, st, g);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Big-tile form (round 5): 256 x 256 x 32 per 512-thread workgroup, one workgroup per CU.  The 128 x 128 kernel above moves 32 KB of fp32
+// operands per 1.05 MFLOP through the CU's vector-memory path; with one bf16 product per element (not six, as in the fp32 split kernel) the
+// matrix cores need 512 cycles for what the loads need ~1 000 for, and the kernel sat at 11-16 % of the bf16 peak.  A 256 x 256 tile
+// halves the bytes per flop (64 KB per 4.2 MFLOP).  Eight waves as 2 x 4, each 128 x 64 = 4 x 2 MFMA tiles (128 accumulator registers); every
+// wave loads, converts, stages and multiplies; two LDS buffers (2 x 40 KB), ONE raw barrier per K-tile:
+//     k-step 0 of tile t   |  registers of tile t + 1 -> bf16 -> buffer (t + 1) & 1  |  loads of tile t + 2 issued  |  k-step 1 of tile t  |  barrier
+// (buffer (t + 1) & 1 was last read as tile t - 1, i.e. before the previous barrier).  Loaders as in gemm_split.inc: uniform base + 32-bit
+// per-thread offsets fixed at prepare(), unconditional loads (out-of-range lanes read a zero block), branch-free conv-window bookkeeping
+// (template flag; needs win_C >= 32 and win_T >= 32 - anything smaller stays on the kernel above).
+constexpr int GX_BM = 256, GX_BN = 256, GX_BK = 32, GX_LD = 40, GX_THREADS = 512;     // LDS row stride 80 B: conflict-free b128 fragment reads
+constexpr int GX_PLANE = 256 * GX_LD;                                                   // bf16 elements of one operand's tile
+constexpr size_t GX_LDS_BYTES = 2 * 2 * GX_PLANE * sizeof(__bf16);
+__device__ __attribute__((aligned(16))) const float gx_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+typedef float gx_f32x4 __attribute__((ext_vector_type(4)));
+typedef const gx_f32x4 __attribute__((address_space(1)))* gx_gptr4;
+__device__ __forceinline__ float4 gx_ld4(const float* p) {       // explicit global address space: a flat load would count in lgkmcnt too
+    const gx_f32x4 v = *(gx_gptr4)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void gx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // (not __syncthreads(): its fence drains the loads in flight)
+
+// operand contiguous along k: thread (k4 = tid & 7, r = tid >> 3 in 0..63) takes the float4 k-run k4 of rows r, r + 64, r + 128, r + 192
+template <bool VEC, bool WIN>
+struct GxLoaderKC {
+    const float* ubase;
+    unsigned voff[4], rmask;
+    int t_row[4], tap, kc, ld_;
+    __device__ __forceinline__ void prepare(int tid, const float* __restrict__ base, long ld, int row0, int k0, int rows, int wT, int wC, int wpad, int wdil) {
+        const int k4 = tid & 7, r = tid >> 3;
+        rmask = 0; ld_ = (int)ld;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + r + i * 64;
+            if (row < rows) rmask |= 1u << i;
+            voff[i] = (unsigned)((r + i * 64) * (int)ld) + (WIN ? 0u : (unsigned)(k4 * 4));
+            if (WIN) t_row[i] = row % wT;
+        }
+        if (WIN) {
+            const int k = k0 + k4 * 4;
+            tap = k / wC; kc = k - tap * wC;
+            ubase = base + ((long)row0 - (long)wpad * wdil) * ld;
+        } else {
+            ubase = base + (long)row0 * ld + k0;
+        }
+    }
+    __device__ __forceinline__ void load(int tid, float4 (&reg)[4], int k0, int kmax, int wT, int wC, int wpad, int wdil) {
+        const int k4 = tid & 7;
+        const int k = k0 + k4 * 4;
+        const bool kok = k < kmax;
+        const int sh = WIN ? (tap - wpad) * wdil : 0;
+        const unsigned wadd = WIN ? (unsigned)(tap * wdil * ld_ + kc) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = kok && ((rmask >> i) & 1u);
+            if (WIN) {
+                const int t = t_row[i] + sh;
+                ok = ok && t >= 0 && t < wT;
+            }
+            if (VEC) {
+                v = gx_ld4(ok ? ubase + (voff[i] + wadd) : gx_zero16);
+            } else if (ok) {
+                const float* p = ubase + (voff[i] + wadd);
+                v.x = p[0];
+                if (k + 1 < kmax) v.y = p[1];
+                if (k + 2 < kmax) v.z = p[2];
+                if (k + 3 < kmax) v.w = p[3];
+            }
+            reg[i] = v;
+        }
+        if (WIN) {
+            kc += GX_BK;
+            const bool wrap = kc >= wC;
+            kc -= wrap ? wC : 0; tap += wrap ? 1 : 0;
+        } else {
+            ubase += GX_BK;
+        }
+    }
+    __device__ __forceinline__ void store(int tid, const float4 (&reg)[4], __bf16* __restrict__ s) const {
+        const int k4 = tid & 7, r = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<gb_bf16x4*>(s + (r + i * 64) * GX_LD + k4 * 4) = gb_round4(reg[i].x, reg[i].y, reg[i].z, reg[i].w);
+    }
+};
+
+// operand contiguous along its M/N index: thread (kq = tid & 7, c4 = tid >> 3 in 0..63) takes the 4 x 4 block of k rows 4 kq .. + 3 x columns
+// 4 c4 .. + 3 as four float4 and writes it transposed (four 8-byte k-runs); kq in the low lane bits (see gemm_split.inc: bank conflicts)
+template <bool VEC, bool WIN>
+struct GxLoaderMC {
+    const float* ubase;
+    unsigned voff[4];
+    int sh, t_k[4], cols_left;
+    __device__ __forceinline__ void prepare(int tid, const float* __restrict__ base, long ld, int col0, int k0, int cols, int wT, int wC, int wpad, int wdil) {
+        const int kq = tid & 7, c4 = tid >> 3;
+        const int col = col0 + c4 * 4;
+        cols_left = cols - col;
+        if (WIN) {
+            const int tp = col / wC, cm = col - tp * wC;
+            sh = (tp - wpad) * wdil;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                t_k[i] = (k0 + kq * 4 + i) % wT;
+                voff[i] = (unsigned)((kq * 4 + i + tp * wdil) * (int)ld + cm);
+            }
+            ubase = base + ((long)k0 - (long)wpad * wdil) * ld;
+        } else {
+            sh = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) voff[i] = (unsigned)((kq * 4 + i) * (int)ld + c4 * 4);
+            ubase = base + (long)k0 * ld + col0;
+        }
+    }
+    __device__ __forceinline__ void load(int tid, float4 (&reg)[4], int k0, int kmax, long ld, int wT) {
+        const int kq = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + kq * 4 + i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = k < kmax && cols_left > 0;
+            if (WIN) {
+                const int t = t_k[i] + sh;
+                ok = ok && t >= 0 && t < wT;
+                t_k[i] += GX_BK;
+                t_k[i] -= (t_k[i] >= wT) ? wT : 0;
+            }
+            if (VEC) {
+                v = gx_ld4(ok ? ubase + voff[i] : gx_zero16);
+            } else if (ok) {
+                const float* p = ubase + voff[i];
+                v.x = p[0];
+                if (cols_left > 1) v.y = p[1];
+                if (cols_left > 2) v.z = p[2];
+                if (cols_left > 3) v.w = p[3];
+            }
+            reg[i] = v;
+        }
+        ubase += GX_BK * ld;
+    }
+    __device__ __forceinline__ void store(int tid, const float4 (&reg)[4], __bf16* __restrict__ s) const {
+        const int kq = tid & 7, c4 = tid >> 3;
+        __bf16* p = s + (c4 * 4) * GX_LD + kq * 4;
+        *reinterpret_cast<gb_bf16x4*>(p) = gb_round4(reg[0].x, reg[1].x, reg[2].x, reg[3].x);
+        *reinterpret_cast<gb_bf16x4*>(p + GX_LD) = gb_round4(reg[0].y, reg[1].y, reg[2].y, reg[3].y);
+        *reinterpret_cast<gb_bf16x4*>(p + 2 * GX_LD) = gb_round4(reg[0].z, reg[1].z, reg[2].z, reg[3].z);
+        *reinterpret_cast<gb_bf16x4*>(p + 3 * GX_LD) = gb_round4(reg[0].w, reg[1].w, reg[2].w, reg[3].w);
+    }
+};
+
+template <bool TA, bool TB, bool VEC, bool WIN>
+__global__ __launch_bounds__(GX_THREADS) void gemm_bf16_big_kernel(GemmBfArgs g) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 gx_lds[];           // [buffer 2][A | B][256 rows][GX_LD]
+    const int tiles_n = (g.N + GX_BN - 1) / GX_BN;
+    int tile = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = tile & 7, idx = tile >> 3;
+        if (nb >= 64) tile = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int batch = blockIdx.z / g.split_k, split = blockIdx.z % g.split_k;
+    float* C = g.C + (long)batch * g.stride_c;
+    const int m0 = tile_m * GX_BM, n0 = tile_n * GX_BN;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nt = kend > kbeg ? (kend - kbeg + GX_BK - 1) / GX_BK : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = (wave >> 2) * 128, wcol = (wave & 3) * 64;
+    const int l31 = lane & 31, kg = lane >> 5;
+
+    using LA = typename std::conditional<TA, GxLoaderMC<VEC, WIN>, GxLoaderKC<VEC, WIN>>::type;
+    using LB = typename std::conditional<TB, GxLoaderKC<VEC, false>, GxLoaderMC<VEC, false>>::type;
+    LA la; LB lb;
+    la.prepare(tid, g.A + (long)batch * g.stride_a, g.lda, m0, kbeg, g.M, g.win_T, g.win_C, g.win_pad, g.win_dil);
+    lb.prepare(tid, g.B + (long)batch * g.stride_b, g.ldb, n0, kbeg, g.N, 0, 1, 0, 1);
+    float4 ra[4], rb[4];
+    auto load = [&](int k) {
+        if constexpr (TA) la.load(tid, ra, k, kend, g.lda, g.win_T);
+        else la.load(tid, ra, k, kend, g.win_T, g.win_C, g.win_pad, g.win_dil);
+        if constexpr (TB) lb.load(tid, rb, k, kend, 0, 1, 0, 1);
+        else lb.load(tid, rb, k, kend, g.ldb, 0);
+    };
+    auto store = [&](int buf) {
+        la.store(tid, ra, gx_lds + buf * 2 * GX_PLANE);
+        lb.store(tid, rb, gx_lds + buf * 2 * GX_PLANE + GX_PLANE);
+    };
+
+    gb_f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int aoff = (wrow + l31) * GX_LD + kg * 8, boff = GX_PLANE + (wcol + l31) * GX_LD + kg * 8;
+    auto kstep = [&](const __bf16* buf, int ks) {
+        gb_bf16x8 a[4], b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const gb_bf16x8*>(buf + aoff + i * 32 * GX_LD + ks * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const gb_bf16x8*>(buf + boff + j * 32 * GX_LD + ks * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    // (Measured and not kept: two fragment register sets with the barrier between a tile's two k-steps, as in gemm_split.inc - 554 instead of
+    //  714 TFLOP/s on 8192^3, 416 instead of 500 on the 25 632-row weight gradient; and two operand register sets, i.e. loads issued two
+    //  iterations ahead - no change.  With two waves per SIMD the hardware interleaves one wave's fragment reads / staging with the other's MFMAs.)
+    if (nt > 0) {
+        load(kbeg);
+        store(0);
+        load(kbeg + GX_BK);                 // (past the end: the loaders read the zero block)
+        gx_barrier();
+        for (int t = 0; t < nt; ++t) {
+            const __bf16* buf = gx_lds + (t & 1) * 2 * GX_PLANE;
+            kstep(buf, 0);
+            store((t + 1) & 1);             // tile t + 1 (loaded one iteration ago) -> the buffer tile t - 1 was read from
+            load(kbeg + (t + 2) * GX_BK);
+            kstep(buf, 1);
+            gx_barrier();
+        }
+    }
+
+    // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const bool first_split = (split == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wcol + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bv = (g.bias != nullptr && first_split) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (row >= g.M) continue;
+                float v = g.alpha * acc[i][j][r] + bv;
+                float* dst = C + (long)row * g.ldc + col;
+                if (g.split_k > 1) {
+                    atomicAdd(dst, v);
+                } else {
+                    v = gb_act(v, g.act);
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+static int gemm_bf16_big_ready() {
+    static int memo[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!memo[dev]) {
+        bool ok = true;
+#define GX_ATTR1(TA_, TB_, V_, W_) ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<TA_, TB_, V_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GX_LDS_BYTES) == hipSuccess
+#define GX_ATTR(TA_, TB_) GX_ATTR1(TA_, TB_, true, true); GX_ATTR1(TA_, TB_, true, false); GX_ATTR1(TA_, TB_, false, true); GX_ATTR1(TA_, TB_, false, false)
+        GX_ATTR(false, false); GX_ATTR(false, true); GX_ATTR(true, false); GX_ATTR(true, true);
+#undef GX_ATTR
+#undef GX_ATTR1
+        if (!ok) (void)hipGetLastError();
+        memo[dev] = ok ? 2 : 1;
+    }
+    return memo[dev] == 2;
+}
+
+template <bool TA, bool TB>
+static void launch_gemm_bf16_big(const GemmBfArgs& g, bool vec, dim3 grid, hipStream_t st) {
+    const bool win = g.win_T > 0;
+    if (vec && win)  hipLaunchKernelGGL((gemm_bf16_big_kernel<TA, TB, true, true>), grid, dim3(GX_THREADS), GX_LDS_BYTES, st, g);
+    else if (vec)    hipLaunchKernelGGL((gemm_bf16_big_kernel<TA, TB, true, false>), grid, dim3(GX_THREADS), GX_LDS_BYTES, st, g);
+    else if (win)    hipLaunchKernelGGL((gemm_bf16_big_kernel<TA, TB, false, true>), grid, dim3(GX_THREADS), GX_LDS_BYTES, st, g);
+    else             hipLaunchKernelGGL((gemm_bf16_big_kernel<TA, TB, false, false>), grid, dim3(GX_THREADS), GX_LDS_BYTES, st, g);
+}
+
 }  // namespace mstts
 
 using namespace mstts;
 
+static int g_bf16_big = -1;
+extern "C" int mstts_gemm_bf16_big(int32_t on) { g_bf16_big = on != 0; return MSTTS_OK; }
+
 extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) {
+    if (g_bf16_big < 0) { const char* e = getenv("MSTTS_GEMM_BF16_BIG"); g_bf16_big = !(e && e[0] == '0'); }
     MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm_bf16: null descriptor");
     MSTTS_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, MSTTS_ERR_SHAPE, "gemm_bf16: negative dims");
     if (d->M == 0 || d->N == 0) return MSTTS_OK;
@@ -289,9 +572,28 @@ extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) 
     vec = vec && (d->trans_a ? (d->M % 4 == 0) : (d->K % 4 == 0));
     vec = vec && (d->trans_b ? (d->K % 4 == 0) : (d->N % 4 == 0));
     if (d->win_T > 0) vec = vec && (d->win_C % 4 == 0);
-    dim3 grid(cdiv(d->M, GB_BM) * cdiv(d->N, GB_BN), 1, batch * split);
     hipStream_t st = (hipStream_t)stream;
     const bool ta = d->trans_a != 0, tb = d->trans_b != 0;
+    // the 256 x 256 tile where the operand is large enough to fill the chip with such tiles (at least ~3/4 of a round of 256 workgroups) and the
+    // strides fit its 32-bit tile-relative offsets; MSTTS_GEMM_BF16_BIG=0 / mstts_gemm_bf16_big(0) keeps the 128 x 128 kernel (A/B, tests)
+    const long big_wgs = (long)cdiv(d->M, GX_BM) * cdiv(d->N, GX_BN) * batch * split;
+    static int big_min = -1;             // (measured: 180 workgroups of this kernel beat 720 of the small one by 1.3 x, 101 lose to 404 by 1.2 x)
+    if (big_min < 0) { const char* e = getenv("MSTTS_GEMM_BF16_BIG_MIN"); big_min = e ? atoi(e) : 160; }
+    const bool big = g_bf16_big && d->M >= 192 && d->N >= 192 && big_wgs >= big_min && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
+                     (d->win_T <= 0 || (d->win_T >= GX_BK && d->win_C >= GX_BK)) && gemm_bf16_big_ready();
+    if (big) {
+        int kpsb = ((g.K + split - 1) / split + GX_BK - 1) / GX_BK * GX_BK;
+        if (kpsb < GX_BK) kpsb = GX_BK;
+        g.k_per_split = kpsb;
+        dim3 gridb(cdiv(d->M, GX_BM) * cdiv(d->N, GX_BN), 1, batch * split);
+        if (!ta && !tb) launch_gemm_bf16_big<false, false>(g, vec, gridb, st);
+        else if (!ta && tb) launch_gemm_bf16_big<false, true>(g, vec, gridb, st);
+        else if (ta && !tb) launch_gemm_bf16_big<true, false>(g, vec, gridb, st);
+        else launch_gemm_bf16_big<true, true>(g, vec, gridb, st);
+        MSTTS_CHECK_LAUNCH("gemm_bf16 (256 x 256 tile)");
+        return MSTTS_OK;
+    }
+    dim3 grid(cdiv(d->M, GB_BM) * cdiv(d->N, GB_BN), 1, batch * split);
     if (!ta && !tb) launch_gemm_bf16<false, false>(g, vec, grid, st);
     else if (!ta && tb) launch_gemm_bf16<false, true>(g, vec, grid, st);
     else if (ta && !tb) launch_gemm_bf16<true, false>(g, vec, grid, st);

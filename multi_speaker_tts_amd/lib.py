@@ -125,6 +125,7 @@ SIGNATURES = {
     "mstts_gemm_split3": (i32, [i32]),
     "mstts_gemm_deterministic": (i32, [i32]),
     "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
+    "mstts_gemm_bf16_big": (i32, [i32]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
     "mstts_philox_keep_mask_rows": (i32, [vp, i64, i64, i64, u64, u32, u64, f32, vp]),
     "mstts_embedding_fwd": (i32, [vp, vp, vp, i64, i64, i64, vp]),

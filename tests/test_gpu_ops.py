@@ -364,6 +364,55 @@ def test_gemm_bf16_layouts(dev, M, N, K, ta, tb):
         assert rel_err(t2n(C32), ref) > 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb,sk", [(2048, 4096, 1030, 1, 0, 2), (6000, 2200, 520, 0, 0, 1), (3584, 4100, 333, 0, 1, 1), (2050, 3330, 96, 1, 1, 3)])
+def test_gemm_bf16_big_tile(dev, M, N, K, ta, tb, sk):
+    """The 256 x 256-tile bf16 kernel (round 5; taken when the output fills the chip with such tiles): every layout, ragged edges in M, N and K,
+    unaligned (scalar-load) shapes, split-K atomics onto a pre-filled output, bias + activation; against the fp64 product of the bf16-ROUNDED
+    operands, and equal to the 128 x 128 kernel's result to fp32 summation order."""
+    A = _r(dev, *((K, M) if ta else (M, K)), seed=1)
+    B = _r(dev, *((N, K) if tb else (K, N)), seed=2, scale=1.0 / np.sqrt(K))
+    bias = _r(dev, N, seed=3)
+    a = _bf(A).cpu().numpy(); b = _bf(B).cpu().numpy()
+    prod = (a.T if ta else a) @ (b.T if tb else b)
+    outs = {}
+    for big in (1, 0):
+        lib.load().mstts_gemm_bf16_big(big)
+        if sk > 1:
+            Cm = torch.ones(M, N, device=dev)
+            _gemm_call("mstts_gemm_bf16", A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, split_k=sk, bias=bias)
+            ref = 1.0 + prod + t2n(bias).astype(np.float64)
+        else:
+            Cm = torch.zeros(M, N, device=dev)
+            _gemm_call("mstts_gemm_bf16", A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, bias=bias, act=2)
+            ref = np.tanh(prod + t2n(bias).astype(np.float64))
+        outs[big] = t2n(Cm).astype(np.float64)
+        assert rel_err(outs[big], ref) < TOL, (big, rel_err(outs[big], ref))
+    lib.load().mstts_gemm_bf16_big(1)
+    assert rel_err(outs[1], outs[0]) < 2e-6
+
+
+def test_gemm_bf16_big_tile_conv_window(dev):
+    """... and its implicit-im2col window mode at the postnet's shape class (rows = batch x frames, 5 taps), forward and weight gradient."""
+    B_, T, cin, cout, K = 40, 801, 64, 512, 5
+    x = _r(dev, B_ * T, cin, seed=4); w = _r(dev, K * cin, cout, seed=5, scale=0.1)
+    xb = _bf(x).cpu().reshape(B_, T, cin); wb = _bf(w).cpu().reshape(K, cin, cout)
+    ref = torch.nn.functional.conv1d(xb.transpose(1, 2), wb.permute(2, 1, 0), padding=(K - 1) // 2).transpose(1, 2).reshape(B_ * T, cout).numpy()
+    dy = _r(dev, B_ * T, cout, seed=6)
+    xpad = torch.nn.functional.pad(xb, (0, 0, (K - 1) // 2, K - 1 - (K - 1) // 2))
+    winm = xpad.unfold(1, K, 1).permute(0, 1, 3, 2).reshape(B_ * T, K * cin)
+    refw = (winm.t() @ _bf(dy).cpu()).numpy()
+    for big in (1, 0):
+        lib.load().mstts_gemm_bf16_big(big)
+        y = torch.zeros(B_ * T, cout, device=dev)
+        _gemm_call("mstts_gemm_bf16", x, w, y, B_ * T, cout, K * cin, cin, cout, cout, win=(T, cin, (K - 1) // 2))
+        assert rel_err(t2n(y), ref) < TOL, big
+    lib.load().mstts_gemm_bf16_big(1)
+    # weight gradient: M = K * cin = 320, N = 512 -> 4 tiles x split 64 = 256 workgroups of the big kernel
+    dw = torch.zeros(K * cin, cout, device=dev)
+    _gemm_call("mstts_gemm_bf16", x, dy, dw, K * cin, cout, B_ * T, cin, cout, cout, ta=1, win=(T, cin, (K - 1) // 2), split_k=64)
+    assert rel_err(t2n(dw), refw) < TOL
+
+
 def test_gemm_bf16_conv_window_splitk(dev):
     """Implicit-im2col conv forward, weight gradient (transposed window, split-K atomics) and accumulate on the bf16 GEMM."""
     B_, T, cin, cout, K = 3, 37, 16, 24, 5

@@ -78,6 +78,10 @@ int mstts_gemm_tail_split(int32_t on);
  *     error of at most 2^-8 |a| |b| per such product - visible only in an output made of such products alone.
  * Callers that need IEEE behaviour at those edges select 0. */
 int mstts_gemm_split3(int32_t on);
+/* 1 (default): split contractions whose output fills the chip with 256 x 256 tiles (from 160 workgroups on) run on the big-tile form of the same
+ * six products (gemm_split_big_kernel: 256 x 256 x 16 per 512-thread workgroup, every wave loads, splits, stages and multiplies); 0: the
+ * 128 x 128 x 32 producer / consumer kernel for all of them.  Same arithmetic, another summation order.  Process-wide (A/B runs, tests). */
+int mstts_gemm_split_big(int32_t on);
 /* Per calling thread.  1: mstts_gemm_f32 makes no K-cut the caller did not ask for with split_k (body + tail schedule and the full cut of
  * short tile lists off): every output element is one fixed-order sum, bit-reproducible run to run.  0 (default): the schedules of DESIGN 4.7,
  * whose cut tiles are summed with atomics (reproducible to the last bit or two).  The inference engines set it around their forward passes. */

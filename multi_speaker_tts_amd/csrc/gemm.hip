@@ -13,6 +13,7 @@
 #include "common.h"
 #include <type_traits>
 #include <cmath>
+#include <cstdlib>
 
 namespace mstts {
 
@@ -362,6 +363,9 @@ extern "C" int mstts_gemm_tail_split(int32_t on) { g_tail_split = on != 0; retur
 // the f32-input MFMA time); 0: all of them on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain).  Tests and the bench's A/B leg switch it.
 static int g_split3 = 1;
 extern "C" int mstts_gemm_split3(int32_t on) { g_split3 = on != 0; return MSTTS_OK; }
+// 1 (default): split contractions that fill the chip with 256 x 256 tiles take gemm_split_big_kernel; 0: the 128 x 128 x 32 producer / consumer kernel
+static int g_split_big = 1;
+extern "C" int mstts_gemm_split_big(int32_t on) { g_split_big = on != 0; return MSTTS_OK; }
 // Per calling thread: 1 = no K-cuts that the caller did not ask for (neither the tail of a long tile list nor a short list cut entirely), so a
 // contraction without split_k adds its K range in one fixed order and its result is bit-reproducible from run to run.  The inference engines
 // set it around their forward passes (a vocoder is a long chain of contractions; at random weights it amplifies last-bit differences).
@@ -439,6 +443,29 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
         }
     }
     hipStream_t st = (hipStream_t)stream;
+    {   // the 256 x 256 x 16 form of the split where such tiles fill the chip (from 160 workgroups on; one per CU)
+        static int big_on = -1, big_min = 160;
+        if (big_on < 0) {
+            const char* e = getenv("MSTTS_GEMM_SPLIT_BIG"); big_on = !(e && e[0] == '0');
+            const char* m = getenv("MSTTS_GEMM_SPLIT_BIG_MIN"); if (m) big_min = atoi(m);
+        }
+        const long big_wgs = (long)cdiv(d->M, GSB_BM) * cdiv(d->N, GSB_BN) * batch * split;
+        if (split3 && big_on && g_split_big && d->M >= 192 && d->N >= 192 && big_wgs >= big_min && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
+            (d->win_T <= 0 || (d->win_T >= GSB_BK && d->win_C >= GSB_BK)) && (d->act == MSTTS_ACT_NONE || split == 1) && gemm_split_big_ready()) {
+            int kpsb = ((g.K + split - 1) / split + GSB_BK - 1) / GSB_BK * GSB_BK;
+            if (kpsb < GSB_BK) kpsb = GSB_BK;
+            g.k_per_split = kpsb;
+            g.body = 0; g.tail_s = 1; g.tail_kps = kpsb; g.band = 0;
+            dim3 gridb(cdiv(d->M, GSB_BM) * cdiv(d->N, GSB_BN), 1, batch * split);
+            const bool ta_ = d->trans_a != 0, tb_ = d->trans_b != 0;
+            if (!ta_ && !tb_) launch_gemm_split_big<false, false>(g, vec, gridb, st);
+            else if (!ta_ && tb_) launch_gemm_split_big<false, true>(g, vec, gridb, st);
+            else if (ta_ && !tb_) launch_gemm_split_big<true, false>(g, vec, gridb, st);
+            else launch_gemm_split_big<true, true>(g, vec, gridb, st);
+            MSTTS_CHECK_LAUNCH("gemm_f32 (split, 256 x 256 tile)");
+            return MSTTS_OK;
+        }
+    }
     const int tiles = cdiv(d->M, bm) * cdiv(d->N, BN);
     g.body = tiles; g.tail_s = 1; g.tail_kps = kps;
     g.band = (split3 && tail_s == 1 && cdiv(d->N, BN) > 8) ? 8 : 0;

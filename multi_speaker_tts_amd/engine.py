@@ -65,6 +65,25 @@ def _split_k(M, N, K, n_cu=256, max_split=16):
     return best
 
 
+def _split_k_big(M, N, K, requested, n_cu=256):
+    """Reduction split of a weight-gradient product on the 256 x 256-tile kernels (gemm_split_big_kernel / gemm_bf16_big_kernel: one workgroup
+    per CU, taken from 160 workgroups on): rounds x (K-tiles per piece + a fixed cost per piece), pieces of at least 1 024 rows.  Returns
+    `requested` (the split chosen for 128 x 128 tiles) when no split reaches those kernels."""
+    tiles = math.ceil(M / 256) * math.ceil(N / 256)
+    if M < 192 or N < 192:
+        return requested
+    best, best_cost = None, None
+    for sk in range(1, 65):
+        if sk > 1 and K // sk < 1024:
+            break
+        if tiles * sk < 160:
+            continue
+        cost = math.ceil(tiles * sk / n_cu) * (K / sk + 300.0) * (1.0 + 0.01 * sk)      # (+1 % per piece: its atomics onto the shared output)
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = sk, cost
+    return best if best is not None else requested
+
+
 PERSIST_STRIKES = 2          # consecutive steps with a fallback before the persistent plans are switched off ...
 PERSIST_COOLDOWN = 200       # ... for this many steps
 ENC_OVERLAP = os.environ.get("MSTTS_ENC_OVERLAP", "1") != "0"    # the encoder's persistent launches on their own stream, under decoder-side products that do not depend on them
@@ -163,6 +182,7 @@ class TrainEngine:
         if self.persist_bwd:
             self.pkb = [self._f(int(lb.mstts_persist_bwd_pack_floats(i))) for i in range(3)]
         self.flip = {}
+        self.big_tiles = os.environ.get("MSTTS_SPLIT_K_BIG", "1") != "0"      # weight-gradient splits chosen for the 256 x 256-tile kernels
         self._derived_stale = True
         self.gemm_dtype = (gemm_dtype or "f32").lower()
         if self.gemm_dtype not in ("f32", "bf16"):
@@ -192,7 +212,10 @@ class TrainEngine:
         matrix cores (fp32 accumulate, fp32 master weights / activations / gradients in memory); exact=True keeps the few
         contractions that have no dense-layer counterpart in the reference graph (d_values from the alignments, the vocoder's
         statistics side effect) in fp32 in either mode."""
-        return gemm(*a, bf16=(self.gemm_dtype == "bf16" and not exact), **k)
+        bf = self.gemm_dtype == "bf16" and not exact
+        if k.get("split_k", 1) > 1 and self.big_tiles:       # (the split was chosen for 128 x 128 tiles; the large contractions run 256 x 256 ones)
+            k["split_k"] = max(2, _split_k_big(a[3], a[4], a[5], k["split_k"]))
+        return gemm(*a, bf16=bf, **k)
 
     def P(self, name):
         return self.params.p(name)

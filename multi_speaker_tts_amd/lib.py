@@ -124,6 +124,7 @@ SIGNATURES = {
     "mstts_gemm_tail_split": (i32, [i32]),
     "mstts_gemm_split3": (i32, [i32]),
     "mstts_gemm_deterministic": (i32, [i32]),
+    "mstts_gemm_split_big": (i32, [i32]),
     "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
     "mstts_gemm_bf16_big": (i32, [i32]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),

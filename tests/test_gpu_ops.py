@@ -66,6 +66,54 @@ def test_gemm_split_is_fp32_accurate(dev, M, N, K, ta, win, sk):
     assert errs[1] <= 1.25 * errs[0] + 1e-8, errs
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb,sk", [(2048, 4096, 2570, 1, 0, 2), (6000, 2200, 520, 0, 0, 1), (3584, 4100, 333, 0, 1, 1), (2050, 3330, 96, 1, 1, 3)])
+def test_gemm_split_big_tile(dev, M, N, K, ta, tb, sk):
+    """The 256 x 256 x 16 form of the six-product split (round 5; taken when the output fills the chip with such tiles): every layout, ragged
+    edges in M, N and K, unaligned (scalar-load) shapes, split-K atomics onto a pre-filled output, bias + activation - against fp64 at the
+    fp32 level, and equal to the 128 x 128 x 32 producer / consumer kernel to fp32 summation order."""
+    A = _r(dev, *((K, M) if ta else (M, K)), seed=1)
+    B = _r(dev, *((N, K) if tb else (K, N)), seed=2, scale=1.0 / np.sqrt(K))
+    bias = _r(dev, N, seed=3)
+    a = t2n(A).astype(np.float64); b = t2n(B).astype(np.float64)
+    prod = (a.T if ta else a) @ (b.T if tb else b)
+    outs = {}
+    for big in (1, 0):
+        lib.load().mstts_gemm_split_big(big)
+        if sk > 1:
+            Cm = torch.ones(M, N, device=dev)
+            _gemm_call("mstts_gemm_f32", A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, split_k=sk, bias=bias)
+            ref = 1.0 + prod + t2n(bias).astype(np.float64)
+        else:
+            Cm = torch.zeros(M, N, device=dev)
+            _gemm_call("mstts_gemm_f32", A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, ta=ta, tb=tb, bias=bias, act=2)
+            ref = np.tanh(prod + t2n(bias).astype(np.float64))
+        outs[big] = t2n(Cm).astype(np.float64)
+        assert rel_err(outs[big], ref) < 5e-6, (big, rel_err(outs[big], ref))
+    lib.load().mstts_gemm_split_big(1)
+    assert rel_err(outs[1], outs[0]) < 5e-6
+
+
+def test_gemm_split_big_tile_conv_window(dev):
+    """... and its implicit-im2col window mode at the postnet's shape class, forward and weight gradient, against fp64."""
+    B_, T, cin, cout, K = 40, 801, 64, 512, 5
+    x = _r(dev, B_ * T, cin, seed=4); w = _r(dev, K * cin, cout, seed=5, scale=0.1)
+    xb = x.double().cpu().reshape(B_, T, cin); wb = w.double().cpu().reshape(K, cin, cout)
+    ref = torch.nn.functional.conv1d(xb.transpose(1, 2), wb.permute(2, 1, 0), padding=(K - 1) // 2).transpose(1, 2).reshape(B_ * T, cout).numpy()
+    dy = _r(dev, B_ * T, cout, seed=6)
+    xpad = torch.nn.functional.pad(xb, (0, 0, (K - 1) // 2, K - 1 - (K - 1) // 2))
+    winm = xpad.unfold(1, K, 1).permute(0, 1, 3, 2).reshape(B_ * T, K * cin)
+    refw = (winm.t() @ dy.double().cpu()).numpy()
+    for big in (1, 0):
+        lib.load().mstts_gemm_split_big(big)
+        y = torch.zeros(B_ * T, cout, device=dev)
+        _gemm_call("mstts_gemm_f32", x, w, y, B_ * T, cout, K * cin, cin, cout, cout, win=(T, cin, (K - 1) // 2))
+        assert rel_err(t2n(y), ref) < 5e-6, big
+    lib.load().mstts_gemm_split_big(1)
+    dw = torch.zeros(K * cin, cout, device=dev)
+    _gemm_call("mstts_gemm_f32", x, dy, dw, K * cin, cout, B_ * T, cin, cout, cout, ta=1, win=(T, cin, (K - 1) // 2), split_k=64)
+    assert rel_err(t2n(dw), refw) < 5e-6
+
+
 def _gemm_both(dev, A, B, M, N, K):
     out = {}
     for mode in (1, 0):

@@ -18,8 +18,9 @@ for M, N, K, ta, tb, win, sk in SHAPES:
     B = torch.randn((N, K) if tb else (K, N), device=dev)
     Cm = torch.zeros(M, N, device=dev)
     out = []
-    for mode in (1, 0):
-        lib.call("mstts_gemm_split3", mode)
+    for mode in (2, 1, 0):                       # 2: split, 256 x 256 x 16 tiles where they apply; 1: split, 128 x 128 x 32 only; 0: f32-input MFMA
+        lib.call("mstts_gemm_split3", 1 if mode else 0)
+        lib.load().mstts_gemm_split_big(1 if mode == 2 else 0)
         f = lambda: lib.gemm(A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, trans_a=bool(ta), trans_b=bool(tb), win=win, split_k=sk, accumulate=(sk > 1))
         for _ in range(3): f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,5 +29,5 @@ for M, N, K, ta, tb, win, sk in SHAPES:
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
         out.append("%8.1f us %6.1f TF" % (us, 2.0 * M * N * K / us * 1e-6))
-    lib.call("mstts_gemm_split3", 1)
-    print("%6d %5d %6d ta%d tb%d win %-15s sk%-2d | split %s | f32 mfma %s" % (M, N, K, ta, tb, win, sk, out[0], out[1]), flush=True)
+    lib.call("mstts_gemm_split3", 1); lib.load().mstts_gemm_split_big(1)
+    print("%6d %5d %6d ta%d tb%d win %-15s sk%-2d | split big %s | split %s | f32 mfma %s" % (M, N, K, ta, tb, win, sk, out[0], out[1], out[2]), flush=True)

@@ -561,11 +561,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)
 
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (its own buffer, flushed whenever), so the group
+    # is torn down and every C stream flushed first
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -28,6 +28,10 @@
 
 namespace mstts {
 
+#ifndef SPLIT_M0
+#define SPLIT_M0 1              // 0: the on-chain cell-1 product on the f32-input MFMA like every other product of the loop (A/B builds)
+#endif
+
 // ring sizes in floats per slot
 constexpr long XCTX = 8L * 128 * 24, XACT = 8L * 128 * 32, XPART = 256L * 8 * 2 * 256, XM1 = 32L * PH, XEN = 32L * 8 * PTMAX;
 constexpr long OFF_CTX = 0, OFF_M0 = OFF_CTX + PRING * XCTX, OFF_H0 = OFF_M0 + PRING * XACT, OFF_H1 = OFF_H0 + PRING * XACT,
@@ -41,10 +45,11 @@ constexpr long OFF_CTX = 0, OFF_M0 = OFF_CTX + PRING * XCTX, OFF_H0 = OFF_M0 + P
 // positions from 128 on are read from memory (an XCD's 32 attention workgroups read 1.5 MB of them per step: they stay in its L2), the
 // energies of a row (8 x 256) share the staging buffer, which is idle between the last product of a step and the first of the next.
 template <int TT> struct FL {
-    static constexpr int S_STG = 0, S_RED = S_STG + 128 * LA, S_TR = S_RED + 4 * 2 * 256, S_M1 = S_TR + 2 * 128,
+    static constexpr int S_STG = 0, S_RED = S_STG + (TT == 128 ? 3 * 128 * 32 / 2 : 128 * LA),     // (TT = 128: room for a slice staged as three swizzled bf16 planes, SM0)
+                         S_TR = S_RED + 4 * 2 * 256, S_M1 = S_TR + 2 * 128,
                          S_EN = TT > 128 ? S_STG : S_M1 + PH, S_CUM = TT > 128 ? S_M1 + PH : S_EN + 8 * PT,
                          S_A = S_CUM + TT + 48, S_Q = S_A + TT, S_QF = S_Q + 512, S_CO = S_QF + 16, S_LK = S_CO + 4 * 96,
-                         S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_BV = S_WQ + 8 * 512 * 4, S_FLOATS = S_BV + 32;      // (S_BV: the owner's 2 x 16 bias values, pipelined kernel)
+                         S_FLAG = S_LK + 32 * 16, S_STAMP = S_FLAG + 4, S_VAL = S_STAMP + 2 * 16, S_WQ = S_VAL + PT * 96, S_FLOATS = S_WQ + 8 * 512 * 4;
     static_assert(8 * TT <= 128 * LA && S_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 constexpr int NSTAMP = 16;
@@ -75,6 +80,10 @@ struct PersistFwd {
 template <bool PROF, bool FOLD, int TT, bool BF16 = false>
 __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     static_assert(!BF16 || FOLD, "the bf16 instantiation forms the prenet rows' product itself");
+    // SM0: the on-chain cell-1 product m0 . W1[m0 rows] as the exact three-way bf16 split of BOTH operands (six products on
+    // v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32 accuracy at 6/16 of the f32-input MFMA's matrix-core time, as gemm_split.inc) - the one
+    // product of the loop whose kernel half fits as three planes (32 -> 48 registers per lane)
+    constexpr bool SM0 = SPLIT_M0 && !BF16 && FOLD && TT == 128;
     typedef FL<TT> Y;
     constexpr int S_STG = Y::S_STG, S_RED = Y::S_RED, S_TR = Y::S_TR, S_M1 = Y::S_M1, S_EN = Y::S_EN, S_CUM = Y::S_CUM, S_A = Y::S_A, S_Q = Y::S_Q,
                   S_CO = Y::S_CO, S_LK = Y::S_LK, S_FLAG = Y::S_FLAG, S_STAMP = Y::S_STAMP, S_VAL = Y::S_VAL, S_WQ = Y::S_WQ;
@@ -116,7 +125,18 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
 #pragma unroll
             for (int r = 0; r < 64; ++r) w0[r] = (FOLD || r < 24 || r >= 32) ? p0[r * 64] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 64; ++r) w1[r] = p1[r * 64];
+            for (int r = 0; r < 64; ++r) w1[r] = (SM0 && r < 32) ? 0.f : p1[r * 64];
+        }
+    }
+    pbf16x8 w1s[SM0 ? 3 : 1][SM0 ? 4 : 1];                        // SM0: planes hi / mid / lo of the m0 rows, octet j = k-steps 8 j .. 8 j + 7
+    if constexpr (SM0) {
+        const float* p1 = d.w1pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const float x = p1[r * 64];
+            const __bf16 hi = (__bf16)x; const float r1 = x - (float)hi;
+            const __bf16 mid = (__bf16)r1; const float r2 = r1 - (float)mid;
+            w1s[0][r >> 3][r & 7] = hi; w1s[1][r >> 3][r & 7] = mid; w1s[2][r >> 3][r & 7] = (__bf16)r2;
         }
     }
     // attention role: row ab = gj, unit slice gi (query units / key columns 16 gi ..), value columns 96 gi ..
@@ -147,10 +167,12 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             reinterpret_cast<pf32x4*>(sm + S_WQ)[x] = v;
         }
     }
-    float lkb[8];                                                // filter slice as MFMA B operand: lk[4 ks + (lane >> 4)][unit lane & 15]; tap 31 is zero
-    __syncthreads();
+    float lkb[SM0 ? 1 : 8];                                      // filter slice as MFMA B operand: lk[4 ks + (lane >> 4)][unit lane & 15]; tap 31 is zero
+    __syncthreads();                                             // (SM0: read from LDS where it is used - its 8 registers are part of what the split planes cost)
+    if constexpr (!SM0) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) lkb[ks] = sm[S_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)];
+        for (int ks = 0; ks < 8; ++ks) lkb[ks] = sm[S_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)];
+    }
     // cell-update role (waves 0, 1): row er, hidden unit eu = 4 g + (lane >> 4); the states stay in registers for all S steps
     int et = wave & 1, er = 16 * et + (lane & 15), ee = lane >> 4, eu = 4 * g + ee;
     bool ew = wave < 2, elive = ew && er < B;
@@ -332,11 +354,13 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         // ================= C: cell 1, input rows (m0_s)   (every wave passed the barriers of B since it read the staged h1)
         slice_issue<8>(xr, OFF_M0 + slot * XACT + gi * 4096L, tid, soff, sv);
         if constexpr (BF16) { if (!slice_complete_bf16<8>(xr, stg16, tid, soff, sv, d.ctrl, gen)) PFAIL(); }
+        else if constexpr (SM0) { if (!slice_complete_split3(xr, stg16, tid, soff, sv, d.ctrl, gen)) PFAIL(); }
         else { if (!slice_complete<8, LA>(xr, stg, tid, soff, sv, d.ctrl, gen)) PFAIL(); }
         PABORT_CHECK();
         PSTAMP(5);
         slice_issue<8>(xr, OFF_H0 + slot * XACT + gi * 4096L, tid, soff, sv);     // h0_s left its producers together with m0_s: it arrives under the product
         if constexpr (BF16) mfma_part_bf16<0, 4, 0>(wb1, stg16, lane, acc1);
+        else if constexpr (SM0) mfma_part_split3(w1s, stg16, lane, acc1);
         else mfma_part<0, 8, LA, 0, 64>(w1, stg, lane, acc1);
         PUBLISH_PARTIAL(OFF_P1, acc1)
         PSTAMP(6);
@@ -410,7 +434,8 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 locv[hh] = (pf32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
-                    locv[hh] = PMFMA(sm[S_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], lkb[ks], locv[hh]);
+                    locv[hh] = PMFMA(sm[S_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)],
+                                     SM0 ? sm[S_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)] : lkb[SM0 ? 0 : ks], locv[hh]);
             }
             if (tid < 256) {
                 { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }

@@ -102,6 +102,53 @@ __device__ __forceinline__ bool slice_complete_bf16(__amdgpu_buffer_rsrc_t xr, _
     return ok;
 }
 
+// ---- fp32 at 6/16 of the f32-input MFMA's time, for ONE product of the fp32 loop (the on-chain m0 . W1 of cell 1): both operands as exact
+// three-way bf16 splits (x = hi + mid + lo, differences exact in fp32), six bf16 products per fp32 product, fp32 accumulate - the arithmetic of
+// gemm_split.inc.  The staged slice is three planes [128 rows][32 k] of bf16 without padding (the LDS has no room for it), the four 16-byte
+// octets of a row XOR-swizzled by (row >> 2) & 3 so that the 16 lanes a ds_read_b128 serves together hit 16 different bank quads.
+constexpr int SP3_PLANE = 128 * 32;
+__device__ __forceinline__ int sp3_off(int rho, int j) { return rho * 32 + ((j ^ ((rho >> 2) & 3)) << 3); }
+__device__ __forceinline__ void sp3_put(__bf16* stg, int p, const pf32x4& v) {          // piece p = (row rho, float4 k4) of a 128 x 32 slice
+    const int rho = p >> 3, k4 = p & 7;
+    pbf16x4 hi, mid, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e];
+        hi[e] = (__bf16)x; const float r1 = x - (float)hi[e];
+        mid[e] = (__bf16)r1; lo[e] = (__bf16)(r1 - (float)mid[e]);
+    }
+    __bf16* q = stg + sp3_off(rho, k4 >> 1) + 4 * (k4 & 1);
+    *reinterpret_cast<pbf16x4*>(q) = hi;
+    *reinterpret_cast<pbf16x4*>(q + SP3_PLANE) = mid;
+    *reinterpret_cast<pbf16x4*>(q + 2 * SP3_PLANE) = lo;
+}
+__device__ __forceinline__ bool slice_complete_split3(__amdgpu_buffer_rsrc_t xr, __bf16* stg, int tid, const unsigned (&off)[2], pf32x4 (&v)[2], const unsigned* ctrl, unsigned gen) {
+    const unsigned gens[2] = {gen, gen};
+    const bool ok = complete<2>(xr, off, v, ctrl, gens);
+    sp3_put(stg, tid, v[0]);
+    sp3_put(stg, tid + PTH, v[1]);
+    return ok;
+}
+// acc[t] += W[k-steps 0 .. 31] . X[t] with wsp[plane][octet] and the staged planes: hi.hi + mid.hi + hi.mid + mid.mid + lo.hi + hi.lo
+__device__ __forceinline__ void mfma_part_split3(const pbf16x8 (&wsp)[3][4], const __bf16* sx, int lane, pf32x4 (&acc)[2]) {
+    const int row0 = ((lane >> 4) * 2) * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const __bf16* p = sx + sp3_off(row0 + 16 * t, j);
+            const pbf16x8 xh = *reinterpret_cast<const pbf16x8*>(p), xm = *reinterpret_cast<const pbf16x8*>(p + SP3_PLANE),
+                          xl = *reinterpret_cast<const pbf16x8*>(p + 2 * SP3_PLANE);
+            acc[t] = PMFMA_BF16(wsp[0][j], xh, acc[t]);
+            acc[t] = PMFMA_BF16(wsp[1][j], xh, acc[t]);
+            acc[t] = PMFMA_BF16(wsp[0][j], xm, acc[t]);
+            acc[t] = PMFMA_BF16(wsp[1][j], xm, acc[t]);
+            acc[t] = PMFMA_BF16(wsp[2][j], xh, acc[t]);
+            acc[t] = PMFMA_BF16(wsp[0][j], xl, acc[t]);
+        }
+    }
+}
+
 struct CellOut { float si, tj, sf, so, c, m; };
 // ZoneoutLSTMCell.py:228-271 for one (row, unit): gates i, j, f, o (forget bias 1.0 added here); zoneout as state' = k (new - old) + old with
 // k = (1 - z) * keep-mask in training (:266-271) and k = 1 - z at inference (:259-264)

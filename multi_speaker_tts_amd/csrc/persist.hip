@@ -31,6 +31,9 @@ namespace mstts {
 #ifndef SPLIT_M0
 #define SPLIT_M0 1              // 0: the on-chain cell-1 product on the f32-input MFMA like every other product of the loop (A/B builds)
 #endif
+#ifndef SPLIT_C0
+#define SPLIT_C0 1              // 0: the on-chain cell-0 product (context + prenet rows) on the f32-input MFMA
+#endif
 
 // ring sizes in floats per slot
 constexpr long XCTX = 8L * 128 * 24, XACT = 8L * 128 * 32, XPART = 256L * 8 * 2 * 256, XM1 = 32L * PH, XEN = 32L * 8 * PTMAX;
@@ -84,6 +87,10 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     // v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32 accuracy at 6/16 of the f32-input MFMA's matrix-core time, as gemm_split.inc) - the one
     // product of the loop whose kernel half fits as three planes (32 -> 48 registers per lane)
     constexpr bool SM0 = SPLIT_M0 && !BF16 && FOLD && TT == 128;
+    // SC0: the same for the on-chain half of cell 0 (context rows + prenet rows: k-steps 0 .. 31 of w0).  Its 16 registers come from the
+    // owner's biases, the score constants (both to a spare corner of S_Q, read where they are used) and SM0's location filter
+    constexpr bool SC0 = SPLIT_C0 && SM0;
+    constexpr int S_BIA = FL<TT>::S_Q + 128;          // [2 cells][4 gates][4 units] biases, [16] score bias + location bias, [16] score weights (S_Q itself uses 128 of its 512 floats)
     typedef FL<TT> Y;
     constexpr int S_STG = Y::S_STG, S_RED = Y::S_RED, S_TR = Y::S_TR, S_M1 = Y::S_M1, S_EN = Y::S_EN, S_CUM = Y::S_CUM, S_A = Y::S_A, S_Q = Y::S_Q,
                   S_CO = Y::S_CO, S_LK = Y::S_LK, S_FLAG = Y::S_FLAG, S_STAMP = Y::S_STAMP, S_VAL = Y::S_VAL, S_WQ = Y::S_WQ;
@@ -123,20 +130,30 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             for (int r = 0; r < 64; ++r) { wb0[r >> 3][r & 7] = (__bf16)p0[r * 64]; wb1[r >> 3][r & 7] = (__bf16)p1[r * 64]; }
         } else {
 #pragma unroll
-            for (int r = 0; r < 64; ++r) w0[r] = (FOLD || r < 24 || r >= 32) ? p0[r * 64] : 0.f;
+            for (int r = 0; r < 64; ++r) w0[r] = (SC0 && r < 32) ? 0.f : (FOLD || r < 24 || r >= 32) ? p0[r * 64] : 0.f;
 #pragma unroll
             for (int r = 0; r < 64; ++r) w1[r] = (SM0 && r < 32) ? 0.f : p1[r * 64];
         }
     }
     pbf16x8 w1s[SM0 ? 3 : 1][SM0 ? 4 : 1];                        // SM0: planes hi / mid / lo of the m0 rows, octet j = k-steps 8 j .. 8 j + 7
+    pbf16x8 w0s[SC0 ? 3 : 1][SC0 ? 4 : 1];                        // SC0: ... of the context rows (octets 0 .. 2) and the prenet rows (octet 3)
     if constexpr (SM0) {
         const float* p1 = d.w1pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
+        const float* p0 = d.w0pk + ((long)(g * 8 + wave) * 64) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-            const float x = p1[r * 64];
-            const __bf16 hi = (__bf16)x; const float r1 = x - (float)hi;
-            const __bf16 mid = (__bf16)r1; const float r2 = r1 - (float)mid;
-            w1s[0][r >> 3][r & 7] = hi; w1s[1][r >> 3][r & 7] = mid; w1s[2][r >> 3][r & 7] = (__bf16)r2;
+            {
+                const float x = p1[r * 64];
+                const __bf16 hi = (__bf16)x; const float r1 = x - (float)hi;
+                const __bf16 mid = (__bf16)r1; const float r2 = r1 - (float)mid;
+                w1s[0][r >> 3][r & 7] = hi; w1s[1][r >> 3][r & 7] = mid; w1s[2][r >> 3][r & 7] = (__bf16)r2;
+            }
+            if constexpr (SC0) {
+                const float x = p0[r * 64];
+                const __bf16 hi = (__bf16)x; const float r1 = x - (float)hi;
+                const __bf16 mid = (__bf16)r1; const float r2 = r1 - (float)mid;
+                w0s[0][r >> 3][r & 7] = hi; w0s[1][r >> 3][r & 7] = mid; w0s[2][r >> 3][r & 7] = (__bf16)r2;
+            }
         }
     }
     // attention role: row ab = gj, unit slice gi (query units / key columns 16 gi ..), value columns 96 gi ..
@@ -154,6 +171,13 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
         asb = d.score_b[16 * gi + ak] + d.loc_b[16 * gi + ak];
         awk = d.score_w[16 * gi + ak];
+        if constexpr (SC0) {
+            if (tid < 16) { sm[S_BIA + 32 + tid] = asb; sm[S_BIA + 48 + tid] = awk; }
+            if (tid < 32) {      // cell tid >> 4, gate (tid >> 2) & 3, unit 4 g + (tid & 3)
+                const int q = (tid >> 2) & 3, u = 4 * g + (tid & 3);
+                sm[S_BIA + tid] = (tid < 16) ? d.b0[q * PH + u] : d.b1[q * PH + u];
+            }
+        }
         for (int x = tid; x < 32 * 16; x += PTH) sm[S_LK + x] = (x < PKS * 16) ? d.loc_k[(x >> 4) * PA + 16 * gi + (x & 15)] : 0.f;
         for (int x = tid; x < PT * 96; x += PTH) {
             const int t = x / 96, c = x - t * 96;
@@ -179,7 +203,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     float c0s = 0.f, h0s = 0.f, c1s = 0.f, h1s = 0.f;
     float b1v[4], b0v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { b1v[q] = d.b1[q * PH + eu]; b0v[q] = FOLD ? d.b0[q * PH + eu] : 0.f; }
+    for (int q = 0; q < 4; ++q) { b1v[q] = SC0 ? 0.f : d.b1[q * PH + eu]; b0v[q] = (FOLD && !SC0) ? d.b0[q * PH + eu] : 0.f; }
     pf32x4 acc0[2], acc1[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) { acc0[b] = (pf32x4){0.f, 0.f, 0.f, 0.f}; acc1[b] = acc0[b]; }
@@ -271,6 +295,10 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 if (tid < 256) *reinterpret_cast<pbf16x4*>(stg16 + (tid >> 1) * LB16 + 24 + 4 * (tid & 1)) = to_bf16x4(prv);
                 __syncthreads();
                 mfma_part_bf16<3, 4, 0>(wb0, stg16, lane, acc0);
+            } else if constexpr (SC0) {
+                if (tid < 256) sp3_put_rk(stg16, tid >> 1, 6 + (tid & 1), prv);
+                __syncthreads();
+                mfma_part_split3<3, 4>(w0s, stg16, lane, acc0);
             } else {
                 if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
                 __syncthreads();
@@ -280,10 +308,12 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 PSTAMP(0);
                 slice_issue<6>(xr, OFF_CTX + pslot * XCTX + gi * 3072L, tid, soff, sv);
                 if constexpr (BF16) { if (!slice_complete_bf16<6>(xr, stg16, tid, soff, sv, d.ctrl, pgen)) PFAIL(); }
+                else if constexpr (SC0) { if (!slice_complete_split3_k6(xr, stg16, tid, soff, sv, d.ctrl, pgen)) PFAIL(); }
                 else { if (!slice_complete<6, LA>(xr, stg, tid, soff, sv, d.ctrl, pgen)) PFAIL(); }
                 PABORT_CHECK();
                 PSTAMP(1);
                 if constexpr (BF16) mfma_part_bf16<0, 3, 0>(wb0, stg16, lane, acc0);
+                else if constexpr (SC0) mfma_part_split3<0, 3>(w0s, stg16, lane, acc0);
                 else mfma_part<0, 6, LA, 0, 64>(w0, stg, lane, acc0);
             }
         } else {
@@ -318,7 +348,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             const pf32x4 gs = SUM_PARTIALS();
             float add0[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) add0[q] = FOLD ? b0v[q] : (rowok ? xwv[q] : 0.f);
+            for (int q = 0; q < 4; ++q) add0[q] = SC0 ? sm[S_BIA + q * 4 + ee] : FOLD ? b0v[q] : (rowok ? xwv[q] : 0.f);
             const float cprev0 = c0s;
             const CellOut o = cell_update(gs, add0, c0s, h0s, (zc0v || !rowok) ? d.keep : 0.f, (zh0v || !rowok) ? d.keep : 0.f);
             if (ew) {
@@ -380,7 +410,10 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         {
             const pf32x4 gs = SUM_PARTIALS();
             const float cprev1 = c1s;
-            const CellOut o = cell_update(gs, b1v, c1s, h1s, (zc1v || !rowok) ? d.keep : 0.f, (zh1v || !rowok) ? d.keep : 0.f);
+            float add1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) add1[q] = SC0 ? sm[S_BIA + 16 + q * 4 + ee] : b1v[q];
+            const CellOut o = cell_update(gs, add1, c1s, h1s, (zc1v || !rowok) ? d.keep : 0.f, (zh1v || !rowok) ? d.keep : 0.f);
             if (ew) {
                 sm[S_TR + er * 4 + ee] = o.m;
                 sm[S_TR + 128 + er * 4 + ee] = h1s;
@@ -464,7 +497,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
             for (int u = 0; u < 8; ++u) qsum += sm[S_Q + u * 16 + ak];
             if (tid < 16) (d.q_hist + (sB + ab) * PA + 16 * gi)[tid] = qsum;
             {
-                const float qk = qsum + asb;
+                const float qk = qsum + (SC0 ? sm[S_BIA + 32 + ak] : asb);
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
                     const pf32x4 loc = locv[hh];
@@ -474,7 +507,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                     pf32x4 e4;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        float e = awk * tanhf_(pre[m]);
+                        float e = (SC0 ? sm[S_BIA + 48 + ak] : awk) * tanhf_(pre[m]);
                         e += dpp_mov<0xB1, 0xf>(0.f, e);
                         e += dpp_mov<0x4E, 0xf>(0.f, e);
                         e += dpp_mov<0x141, 0xf>(0.f, e);

@@ -108,8 +108,9 @@ __device__ __forceinline__ bool slice_complete_bf16(__amdgpu_buffer_rsrc_t xr, _
 // octets of a row XOR-swizzled by (row >> 2) & 3 so that the 16 lanes a ds_read_b128 serves together hit 16 different bank quads.
 constexpr int SP3_PLANE = 128 * 32;
 __device__ __forceinline__ int sp3_off(int rho, int j) { return rho * 32 + ((j ^ ((rho >> 2) & 3)) << 3); }
-__device__ __forceinline__ void sp3_put(__bf16* stg, int p, const pf32x4& v) {          // piece p = (row rho, float4 k4) of a 128 x 32 slice
-    const int rho = p >> 3, k4 = p & 7;
+__device__ __forceinline__ void sp3_put_rk(__bf16* stg, int rho, int k4, const pf32x4& v);
+__device__ __forceinline__ void sp3_put(__bf16* stg, int p, const pf32x4& v) { sp3_put_rk(stg, p >> 3, p & 7, v); }       // piece p = (row rho, float4 k4) of a 128 x 32 slice
+__device__ __forceinline__ void sp3_put_rk(__bf16* stg, int rho, int k4, const pf32x4& v) {
     pbf16x4 hi, mid, lo;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -129,11 +130,20 @@ __device__ __forceinline__ bool slice_complete_split3(__amdgpu_buffer_rsrc_t xr,
     sp3_put(stg, tid + PTH, v[1]);
     return ok;
 }
-// acc[t] += W[k-steps 0 .. 31] . X[t] with wsp[plane][octet] and the staged planes: hi.hi + mid.hi + hi.mid + mid.mid + lo.hi + hi.lo
+// a 128 x 24 slice (K4 = 6 pieces per row: the context rows) into octets 0 .. 2 of the planes
+__device__ __forceinline__ bool slice_complete_split3_k6(__amdgpu_buffer_rsrc_t xr, __bf16* stg, int tid, const unsigned (&off)[2], pf32x4 (&v)[2], const unsigned* ctrl, unsigned gen) {
+    const unsigned gens[2] = {gen, gen};
+    const bool ok = complete<2>(xr, off, v, ctrl, gens);
+    { const int rho = tid / 6; sp3_put_rk(stg, rho, tid - rho * 6, v[0]); }
+    if (tid + PTH < 128 * 6) { const int p = tid + PTH, rho = p / 6; sp3_put_rk(stg, rho, p - rho * 6, v[1]); }
+    return ok;
+}
+// acc[t] += W[k-steps 8 JA .. 8 JB) . X[t] with wsp[plane][octet] and the staged planes: hi.hi + mid.hi + hi.mid + mid.mid + lo.hi + hi.lo
+template <int JA = 0, int JB = 4>
 __device__ __forceinline__ void mfma_part_split3(const pbf16x8 (&wsp)[3][4], const __bf16* sx, int lane, pf32x4 (&acc)[2]) {
     const int row0 = ((lane >> 4) * 2) * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = JA; j < JB; ++j) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const __bf16* p = sx + sp3_off(row0 + 16 * t, j);

@@ -299,109 +299,176 @@ __global__ __launch_bounds__(ETH) void persist_lstm_bwd_kernel(EncBwd p) {
     if (tid == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- the streaming kernels around the two loops (one thread per owner lane and step)
-// (ngr = row groups in all, gpd = per direction; a group is 32 forward / 16 BPTT workgroups)
-template <int HH>
-__device__ __forceinline__ void fwd_owner_of(long idx, int ngr, int gpd, int& t, int& g, int& ow, int& lane, int& dir, int& b, int& u) {
-    constexpr int WG = LF<HH>::WG;
-    const int G = ngr * WG;
-    lane = (int)(idx & 63); ow = (int)((idx >> 6) & 3);
-    const long wg = idx >> 8;
-    g = (int)(wg % G); t = (int)(wg / G);
-    const int grp = g / WG;
-    dir = grp / gpd;
-    b = 32 * (grp % gpd) + 16 * (ow & 1) + (lane & 15);
-    u = 8 * (g % WG) + 4 * (ow >> 1) + (lane >> 4);
+// ---- the streaming kernels around the two loops: owner-lane order <-> row-major tensors
+// (ngr = row groups in all, gpd = per direction; a group is 32 forward / 16 BPTT workgroups.)  Owner lanes hold (row, 4 gates of one unit):
+// a wave-wide access to a row-major tensor from that order is 64 scattered words, so every kernel here goes through LDS - whole rows
+// (16-byte pieces, a kilobyte per wave) on the row-major side, the owner lanes' contiguous pieces on the packed side.  One block handles 8
+// rows of one (step, row group): rows row0 .. row0 + 7 with row0 = 32 (group % gpd) + 8 o; in the forward order (persist_lstm_fwd_kernel)
+//     owner lane ((t * G + group * WG + gl) * 4 + ow) * 64 + lane  holds row 32 (..) + 16 (ow & 1) + (lane & 15), unit 8 gl + 4 (ow >> 1) + (lane >> 4)
+// and in the BPTT order (persist_lstm_bwd_kernel)
+//     owner lane ((k * G2 + group * 16 + gl) * 8 + wave) * 64 + lane  holds row 32 (..) + 16 (wave & 1) + (lane & 15), unit 16 gl + 4 (lane >> 4) + (wave >> 1).
+template <int HH> struct LP { static constexpr int RS = 4 * HH + 16, US = HH + 4, NIT = HH / 32; };   // LDS row strides (gate rows / unit rows); items per thread
+__device__ __forceinline__ void block_of(int bid, int ngr, int gpd, int& o, int& grp, int& step, int& dir, int& row0) {
+    o = bid & 3; grp = (bid >> 2) % ngr; step = (bid >> 2) / ngr; dir = grp / gpd; row0 = 32 * (grp % gpd) + 8 * o;
 }
-__device__ __forceinline__ void bwd_owner_of(long idx, int ngr, int gpd, int& k, int& dir, int& b, int& u) {
-    const int G2 = ngr * EBWG;
-    const int lane = (int)(idx & 63), wave = (int)((idx >> 6) & 7);
-    const long wg = idx >> 9;
-    const int g = (int)(wg % G2), grp = g / EBWG;
-    k = (int)(wg / G2);
-    dir = grp / gpd;
-    b = 32 * (grp % gpd) + 16 * (wave & 1) + (lane & 15);
-    u = 16 * (g % EBWG) + 4 * (lane >> 4) + (wave >> 1);
+// item q of a forward block -> (row r of the 8, unit u, owner-lane index)
+template <int HH>
+__device__ __forceinline__ void fwd_item(int q, int o, int grp, int t, int G, int& r, int& u, int& g, int& ow, int& lane) {
+    r = q & 7;
+    const int kq = (q >> 3) & 3, w2 = (q >> 5) & 1, gl = q >> 6;
+    u = 8 * gl + 4 * w2 + kq; g = grp * LF<HH>::WG + gl; ow = 2 * w2 + (o >> 1); lane = 16 * kq + 8 * (o & 1) + r;
 }
 // hoisted gate inputs xw [B, T, 4H] (at the row's position of step t) and the keep-mask bytes -> ipx / ipm
 template <int HH>
-__global__ void persist_lstm_pack_in_kernel(EncFwd p, pf32x4* __restrict__ ipx, unsigned* __restrict__ ipm) {
-    constexpr int EH = HH;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ngr = p.ndir * p.gpd;
-    if (idx >= (long)p.T * ngr * LF<HH>::PGROUP) return;
-    int t, g, ow, lane, dir, b, u;
-    fwd_owner_of<HH>(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
+__global__ __launch_bounds__(256) void persist_lstm_pack_in_kernel(EncFwd p, pf32x4* __restrict__ ipx, unsigned* __restrict__ ipm) {
+    constexpr int RS = LP<HH>::RS;
+    __shared__ __attribute__((aligned(16))) float rows[8 * RS];
+    __shared__ uint8_t mk[8 * HH];
+    const int ngr = p.ndir * p.gpd, G = ngr * LF<HH>::WG, tid = threadIdx.x;
+    int o, grp, t, dir, row0;
+    block_of(blockIdx.x, ngr, p.gpd, o, grp, t, dir, row0);
     const EncFwdDir& d = p.d[dir];
-    pf32x4 x = {0.f, 0.f, 0.f, 0.f};
-    unsigned m = 3u;
-    if (b < p.B) {
-        const int len = d.lengths ? d.lengths[b] : p.T;
-        const int pos = (d.reverse && t < len) ? len - 1 - t : t;
-        const float* xp = d.xw + ((long)b * p.T + pos) * 4 * EH + u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = xp[e * EH];
-        m = (d.zc ? (d.zc[((long)t * p.B + b) * EH + u] ? 1u : 0u) : 1u) | (d.zh ? (d.zh[((long)t * p.B + b) * EH + u] ? 2u : 0u) : 2u);
+    for (int q = tid; q < 8 * HH; q += 256) {
+        const int r = q / HH, c = q % HH, b = row0 + r;
+        pf32x4 v = {0.f, 0.f, 0.f, 0.f};
+        unsigned m = 3u;
+        if (b < p.B) {
+            const int len = d.lengths ? d.lengths[b] : p.T;
+            const int pos = (d.reverse && t < len) ? len - 1 - t : t;
+            v = *reinterpret_cast<const pf32x4*>(d.xw + ((long)b * p.T + pos) * 4 * HH + 4 * c);
+            m = (d.zc ? (d.zc[((long)t * p.B + b) * HH + c] ? 1u : 0u) : 1u) | (d.zh ? (d.zh[((long)t * p.B + b) * HH + c] ? 2u : 0u) : 2u);
+        }
+        *reinterpret_cast<pf32x4*>(rows + r * RS + 4 * c) = v;
+        mk[q] = (uint8_t)m;
     }
-    ipx[idx] = x;
-    ipm[idx] = m;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < LP<HH>::NIT; ++it) {
+        int r, u, g, ow, lane;
+        fwd_item<HH>(it * 256 + tid, o, grp, t, G, r, u, g, ow, lane);
+        const float* w = rows + r * RS + u;
+        const pf32x4 x = {w[0], w[HH], w[2 * HH], w[3 * HH]};
+        const long idx = (((long)t * G + g) * 4 + ow) * 64 + lane;
+        ipx[idx] = x;
+        ipm[idx] = mk[r * HH + u];
+    }
 }
 // epk -> the row-major tensors of mstts_lstm_seq_fwd_desc: out (at the row's position), h_hist / c_hist [T + 1, B, H], acts, c_raw
 template <int HH>
-__global__ void persist_lstm_unpack_fwd_kernel(EncFwd p) {
-    constexpr int EH = HH;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ngr = p.ndir * p.gpd, G = ngr * LF<HH>::WG;
-    if (idx >= (long)p.T * ngr * LF<HH>::PGROUP) return;
-    int t, g, ow, lane, dir, b, u;
-    fwd_owner_of<HH>(idx, ngr, p.gpd, t, g, ow, lane, dir, b, u);
-    if (b >= p.B) return;
+__global__ __launch_bounds__(256) void persist_lstm_unpack_fwd_kernel(EncFwd p) {
+    constexpr int RS = LP<HH>::RS, US = LP<HH>::US, NIT = LP<HH>::NIT;
+    __shared__ __attribute__((aligned(16))) float rows[8 * RS];          // the gate rows, then [out | h | c | c_raw][8 rows][US]
+    __shared__ int s_live[8];
+    static_assert(4 * US <= RS, "the unit rows reuse the gate rows' space");
+    const int ngr = p.ndir * p.gpd, G = ngr * LF<HH>::WG, tid = threadIdx.x, B = p.B;
+    int o, grp, t, dir, row0;
+    block_of(blockIdx.x, ngr, p.gpd, o, grp, t, dir, row0);
     const EncFwdDir& d = p.d[dir];
-    const pf32x4 a = p.epk[epk_index(t, G, g, ow, 0, lane)], s = p.epk[epk_index(t, G, g, ow, 1, lane)];
-    const float cp = t > 0 ? p.epk[epk_index(t - 1, G, g, ow, 1, lane)][2] : 0.f;
-    const bool live = (__float_as_uint(s[3]) & 4u) != 0u;
-    const int len = d.lengths ? d.lengths[b] : p.T;
-    const int pos = (d.reverse && live) ? len - 1 - t : t;
-    const int B = p.B;
-    d.out[(long)b * d.out_sb + (long)pos * d.out_st + u] = s[0];
-    d.h_hist[((long)(t + 1) * B + b) * EH + u] = s[1];
-    d.c_hist[((long)(t + 1) * B + b) * EH + u] = s[2];
-    if (d.acts) { float* o = d.acts + ((long)t * B + b) * 4 * EH + u; o[0] = a[0]; o[EH] = a[1]; o[2 * EH] = a[2]; o[3 * EH] = a[3]; }
-    if (d.c_raw) d.c_raw[((long)t * B + b) * EH + u] = live ? a[2] * cp + a[0] * a[1] : cp;
-}
-// upstream gradient d_out (at the row's position of step t = T - 1 - k, 0 for rows past their length) -> dop
-__global__ void persist_lstm_pack_dout_kernel(EncBwd p, float* __restrict__ dop) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ngr = p.ndir * p.gpd;
-    if (idx >= (long)p.T * ngr * EP_GROUP) return;
-    int k, dir, b, u;
-    bwd_owner_of(idx, ngr, p.gpd, k, dir, b, u);
-    const EncBwdDir& d = p.d[dir];
-    const int t = p.T - 1 - k;
-    float v = 0.f;
-    if (b < p.B) {
-        const int len = d.lengths ? d.lengths[b] : p.T;
-        if (t < len) v = d.d_out[(long)b * d.dout_sb + (long)(d.reverse ? len - 1 - t : t) * d.dout_st + u];
-    }
-    dop[idx] = v;
-}
-// dpk -> dgates_step [T, B, 4H] (processing order) and dgates_pos [B, T, 4H] (position order)
-__global__ void persist_lstm_unpack_bwd_kernel(EncBwd p) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ngr = p.ndir * p.gpd;
-    if (idx >= (long)p.T * ngr * EP_GROUP) return;
-    int k, dir, b, u;
-    bwd_owner_of(idx, ngr, p.gpd, k, dir, b, u);
-    if (b >= p.B) return;
-    const EncBwdDir& d = p.d[dir];
-    const int t = p.T - 1 - k;
-    const pf32x4 dg = p.dpk[idx];
-    const int len = d.lengths ? d.lengths[b] : p.T;
-    const int pos = d.reverse ? (t < len ? len - 1 - t : t) : t;
-    float* gsp = d.dgates_step + ((long)t * p.B + b) * 4 * EH + u;
-    float* gpp = d.dgates_pos + ((long)b * p.T + pos) * 4 * EH + u;
+    pf32x4 a[NIT], s[NIT];
+    float cp[NIT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { gsp[e * EH] = dg[e]; gpp[e * EH] = dg[e]; }
+    for (int it = 0; it < NIT; ++it) {
+        int r, u, g, ow, lane;
+        fwd_item<HH>(it * 256 + tid, o, grp, t, G, r, u, g, ow, lane);
+        a[it] = p.epk[epk_index(t, G, g, ow, 0, lane)];
+        s[it] = p.epk[epk_index(t, G, g, ow, 1, lane)];
+        cp[it] = (t > 0 && d.c_raw) ? p.epk[epk_index(t - 1, G, g, ow, 1, lane)][2] : 0.f;
+        if (u == 0) s_live[r] = (__float_as_uint(s[it][3]) & 4u) != 0u;
+    }
+    if (d.acts) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int r, u, g, ow, lane;
+            fwd_item<HH>(it * 256 + tid, o, grp, t, G, r, u, g, ow, lane);
+            float* w = rows + r * RS + u;
+            w[0] = a[it][0]; w[HH] = a[it][1]; w[2 * HH] = a[it][2]; w[3 * HH] = a[it][3];
+        }
+        __syncthreads();
+        for (int q = tid; q < 8 * HH; q += 256) {
+            const int r = q / HH, c = q % HH, b = row0 + r;
+            if (b < B) *reinterpret_cast<pf32x4*>(d.acts + ((long)t * B + b) * 4 * HH + 4 * c) = *reinterpret_cast<const pf32x4*>(rows + r * RS + 4 * c);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int r, u, g, ow, lane;
+        fwd_item<HH>(it * 256 + tid, o, grp, t, G, r, u, g, ow, lane);
+        const bool live = (__float_as_uint(s[it][3]) & 4u) != 0u;
+        float* w = rows + r * US + u;
+        w[0] = s[it][0]; w[8 * US] = s[it][1]; w[16 * US] = s[it][2];
+        w[24 * US] = live ? a[it][2] * cp[it] + a[it][0] * a[it][1] : cp[it];
+    }
+    __syncthreads();
+    for (int q = tid; q < 8 * HH; q += 256) {           // [array 4][row 8][HH / 4 pieces]
+        const int c = q % (HH / 4), r = (q / (HH / 4)) & 7, arr = q / (2 * HH), b = row0 + r;
+        if (b >= B) continue;
+        const pf32x4 v = *reinterpret_cast<const pf32x4*>(rows + (arr * 8 + r) * US + 4 * c);
+        if (arr == 0) {
+            const int len = d.lengths ? d.lengths[b] : p.T;
+            const int pos = (d.reverse && s_live[r]) ? len - 1 - t : t;
+            *reinterpret_cast<pf32x4*>(d.out + (long)b * d.out_sb + (long)pos * d.out_st + 4 * c) = v;
+        } else if (arr == 1) *reinterpret_cast<pf32x4*>(d.h_hist + ((long)(t + 1) * B + b) * HH + 4 * c) = v;
+        else if (arr == 2) *reinterpret_cast<pf32x4*>(d.c_hist + ((long)(t + 1) * B + b) * HH + 4 * c) = v;
+        else if (d.c_raw) *reinterpret_cast<pf32x4*>(d.c_raw + ((long)t * B + b) * HH + 4 * c) = v;
+    }
+}
+// upstream gradient d_out (at the row's position of step t = T - 1 - k, 0 for rows past their length) -> dop.  One block per (step, row group,
+// 16-row half): a wave of the BPTT order is those 16 rows x 4 units
+__global__ __launch_bounds__(256) void persist_lstm_pack_dout_kernel(EncBwd p, float* __restrict__ dop) {
+    constexpr int US = EH + 4;
+    __shared__ __attribute__((aligned(16))) float rows[16 * US];
+    const int ngr = p.ndir * p.gpd, G2 = ngr * EBWG, tid = threadIdx.x;
+    const int h = blockIdx.x & 1, grp = (blockIdx.x >> 1) % ngr, k = (blockIdx.x >> 1) / ngr, dir = grp / p.gpd, row0 = 32 * (grp % p.gpd) + 16 * h;
+    const EncBwdDir& d = p.d[dir];
+    const int t = p.T - 1 - k;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int q = it * 256 + tid, r = q >> 6, c = q & 63, b = row0 + r;
+        pf32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < p.B) {
+            const int len = d.lengths ? d.lengths[b] : p.T;
+            if (t < len) v = *reinterpret_cast<const pf32x4*>(d.d_out + (long)b * d.dout_sb + (long)(d.reverse ? len - 1 - t : t) * d.dout_st + 4 * c);
+        }
+        *reinterpret_cast<pf32x4*>(rows + r * US + 4 * c) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int q = it * 256 + tid, lane = q & 63, wq = (q >> 6) & 3, g = q >> 8;
+        dop[(((long)k * G2 + grp * EBWG + g) * 8 + 2 * wq + h) * 64 + lane] = rows[(lane & 15) * US + 16 * g + 4 * (lane >> 4) + wq];
+    }
+}
+// dpk -> dgates_step [T, B, 4H] (processing order) and dgates_pos [B, T, 4H] (position order).  One block per (step, row group, 8 rows): the
+// owner lanes' 16-byte pieces (128 contiguous bytes per 8 rows in dpk) are turned in LDS into whole 4 KB gate rows, written as 16-byte pieces
+constexpr int UB_RS = 4 * EH + 8;                   // LDS row stride in floats (16-byte aligned rows, the 8 rows of a piece 8 banks apart)
+__global__ __launch_bounds__(256) void persist_lstm_unpack_bwd_kernel(EncBwd p) {
+    __shared__ __attribute__((aligned(16))) float rows[8 * UB_RS];
+    const int ngr = p.ndir * p.gpd, G2 = ngr * EBWG;
+    const int o = blockIdx.x & 3, grp = (blockIdx.x >> 2) % ngr, k = (blockIdx.x >> 2) / ngr;      // o = (16-row half, 8-row octet)
+    const int dir = grp / p.gpd, row0 = 32 * (grp % p.gpd) + 8 * o;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int q = it * 256 + tid, r = q & 7, kq = (q >> 3) & 3, wq = (q >> 5) & 3, g = q >> 7;
+        const long idx = (((long)k * G2 + grp * EBWG + g) * 8 + 2 * wq + (o >> 1)) * 64 + 16 * kq + 8 * (o & 1) + r;    // bwd_owner_of, inverted
+        const pf32x4 dg = p.dpk[idx];
+        float* w = rows + r * UB_RS + 16 * g + 4 * kq + wq;
+        w[0] = dg[0]; w[EH] = dg[1]; w[2 * EH] = dg[2]; w[3 * EH] = dg[3];
+    }
+    __syncthreads();
+    const EncBwdDir& d = p.d[dir];
+    const int t = p.T - 1 - k;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int b = row0 + it;
+        if (b >= p.B) break;
+        const int len = d.lengths ? d.lengths[b] : p.T;
+        const int pos = d.reverse ? (t < len ? len - 1 - t : t) : t;
+        const pf32x4 v = *reinterpret_cast<const pf32x4*>(rows + it * UB_RS + 4 * tid);
+        *reinterpret_cast<pf32x4*>(d.dgates_step + ((long)t * p.B + b) * 4 * EH + 4 * tid) = v;
+        *reinterpret_cast<pf32x4*>(d.dgates_pos + ((long)b * p.T + pos) * 4 * EH + 4 * tid) = v;
+    }
 }
 
 // recurrent kernel Wh [256, 1024] (row stride ld, gate-major columns i | j | f | o) -> the forward kernel's register order
@@ -492,6 +559,8 @@ static int lstm_fwd_launch_h(const mstts_lstm_seq_fwd_desc* const* dd, const flo
         MSTTS_REQUIRE(d && pk[k] && d->B == a->B && d->T == a->T && d->H == a->H, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null descriptor / the sequences must have one shape");
         MSTTS_REQUIRE(d->xw && d->c_hist && d->h_hist && d->out && !d->residual, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: null pointer / residual input not covered");
         MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: reverse needs a lengths array (pass T for every row)");
+        MSTTS_REQUIRE(aligned16(d->xw) && aligned16(d->out) && d->out_sb % 4 == 0 && d->out_st % 4 == 0 && aligned16(d->c_hist) && aligned16(d->h_hist) &&
+                      aligned16(d->acts) && aligned16(d->c_raw), MSTTS_ERR_ALIGN, "lstm_seq_fwd_persistent: xw / out / histories must be 16-byte aligned, out strides multiples of 4");
         MSTTS_REQUIRE(d->zoneout == a->zoneout, MSTTS_ERR_SHAPE, "lstm_seq_fwd_persistent: one zoneout rate for both directions");
         if (hipMemsetAsync(d->c_hist, 0, BH * sizeof(float), hs) != hipSuccess || hipMemsetAsync(d->h_hist, 0, BH * sizeof(float), hs) != hipSuccess)
             return set_err(MSTTS_ERR_LAUNCH, "lstm_seq_fwd_persistent: memset failed");
@@ -508,11 +577,11 @@ static int lstm_fwd_launch_h(const mstts_lstm_seq_fwd_desc* const* dd, const flo
     unsigned* ipm = reinterpret_cast<unsigned*>(hist + nl * 4);
     p.ipx = ipx; p.ipm = ipm; p.epk = reinterpret_cast<pf32x4*>(hist + nl * 5);
     static_assert(L::PGROUP % 4 == 0, "epk stays 16-byte aligned behind ipx | ipm");
-    hipLaunchKernelGGL(persist_lstm_pack_in_kernel<HH>, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p, ipx, ipm);
+    hipLaunchKernelGGL(persist_lstm_pack_in_kernel<HH>, dim3((unsigned)(4 * ngr * p.T)), dim3(256), 0, hs, p, ipx, ipm);
     MSTTS_CHECK_LAUNCH("persist_lstm_pack_in");
     hipLaunchKernelGGL(persist_lstm_fwd_kernel<HH>, dim3(ngr * L::WG), dim3(ETH), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_fwd");
-    hipLaunchKernelGGL(persist_lstm_unpack_fwd_kernel<HH>, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p);
+    hipLaunchKernelGGL(persist_lstm_unpack_fwd_kernel<HH>, dim3((unsigned)(4 * ngr * p.T)), dim3(256), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_unpack_fwd");
     return MSTTS_OK;
 }
@@ -535,6 +604,8 @@ static int lstm_bwd_launch(const mstts_lstm_seq_bwd_desc* const* dd, const float
         const mstts_lstm_seq_bwd_desc* d = dd[k];
         MSTTS_REQUIRE(d && pk[k] && d->B == a->B && d->T == a->T && d->H == a->H, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: null descriptor / the sequences must have one shape");
         MSTTS_REQUIRE(d->d_out && d->dgates_step && d->dgates_pos, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: null pointer");
+        MSTTS_REQUIRE(aligned16(d->dgates_step) && aligned16(d->dgates_pos) && aligned16(d->d_out) && d->dout_sb % 4 == 0 && d->dout_st % 4 == 0, MSTTS_ERR_ALIGN,
+                      "lstm_seq_bwd_persistent: dgates_step / dgates_pos / d_out must be 16-byte aligned, d_out strides multiples of 4");
         MSTTS_REQUIRE(!(d->reverse && !d->lengths), MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: reverse needs a lengths array");
         MSTTS_REQUIRE(d->zoneout == a->zoneout, MSTTS_ERR_SHAPE, "lstm_seq_bwd_persistent: one zoneout rate for both directions");
         EncBwdDir& e = p.d[k];
@@ -548,11 +619,11 @@ static int lstm_bwd_launch(const mstts_lstm_seq_bwd_desc* const* dd, const float
     const long nl = (long)p.T * ngr * EP_GROUP;
     p.epk = reinterpret_cast<const pf32x4*>(hist + nl * 5);
     p.dop = bws; p.dpk = reinterpret_cast<pf32x4*>(bws + nl);
-    hipLaunchKernelGGL(persist_lstm_pack_dout_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p, bws);
+    hipLaunchKernelGGL(persist_lstm_pack_dout_kernel, dim3((unsigned)(2 * ngr * p.T)), dim3(256), 0, hs, p, bws);
     MSTTS_CHECK_LAUNCH("persist_lstm_pack_dout");
     hipLaunchKernelGGL(persist_lstm_bwd_kernel, dim3(ngr * EBWG), dim3(ETH), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_bwd");
-    hipLaunchKernelGGL(persist_lstm_unpack_bwd_kernel, dim3((unsigned)(nl / 256)), dim3(256), 0, hs, p);
+    hipLaunchKernelGGL(persist_lstm_unpack_bwd_kernel, dim3((unsigned)(4 * ngr * p.T)), dim3(256), 0, hs, p);
     MSTTS_CHECK_LAUNCH("persist_lstm_unpack_bwd");
     return MSTTS_OK;
 }

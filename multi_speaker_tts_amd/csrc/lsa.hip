@@ -1173,50 +1173,88 @@ __global__ __launch_bounds__(256) void lsa_step_bwd_kernel(mstts_lsa_const c, co
 //   d_keys[b,t,k] += g ; d_loc_k[j,k] += cum[t+j-pad] g ; d_score_w[k] += d_e u ; d_score_b[k] += g
 // (d_loc_b == d_score_b: both biases add to the same pre-activation)
 // ---------------------------------------------------------------------------------------------
-// Both contractions with the 31-tap window are matrix products and run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
-// fp32): for one (b, s) and a tile of 32 encoder positions, with W[t][j] = cum[t + j - pad] (a 32 x 32 Toeplitz tile read straight
-// from the LDS window),
+// Both contractions with the 31-tap window are matrix products: for one (b, s) and a tile of 32 encoder positions, with
+// W[t][j] = cum[t + j - pad] (a 32 x 32 Toeplitz tile read straight from the LDS window),
 //     L  = W . loc_k          [32 t x 32 j] . [32 j x 128 a]      -> pre-activation -> u, g (VALU, in the MFMA C layout)
 //     dK = W^T . g            [32 j x 32 t] . [32 t x 128 a]      -> d_loc_k
-// The reduction order over t in the second product is free, so its k-step r takes the rows the C layout already holds in register r
-// (lane half h: row (r&3) + 8(r>>2) + 4h) - g never leaves its registers.  Wave w owns attention units 32w .. 32w+31; a workgroup
-// walks a chunk of steps for one (row, tile); accumulators (d_keys tile, d_loc_k, d_score_w/b) stay in registers over the chunk.
+// They run on v_mfma_f32_32x32x16_bf16 as exact three-way bf16 splits (x = hi + mid + lo, the six products down to 2^-24 of |a||b|, fp32
+// accumulators - the arithmetic of csrc/gemm_split.inc): 24 matrix instructions of 8 passes per step and wave where the f32-input form needs 32
+// of 16 passes.  The window is split once per step when it is written to LDS, as EIGHT copies per plane, copy c shifted by c elements, so that
+// every lane's run of 8 consecutive window elements is one aligned 16-byte read from copy (start & 7); the filter taps are split once per launch;
+// g is split in registers.  The row index of the first product is permuted (bits 2 and 3 swapped) so that the C layout hands each lane, per
+// k-step of the second product, 8 CONSECUTIVE positions - g never leaves its registers and the second product's window runs are contiguous too.
+// Wave w owns attention units 32w .. 32w+31; a workgroup walks a chunk of steps for one (row, tile); accumulators (d_keys tile, d_loc_k,
+// d_score_w/b) stay in registers over the chunk.
 constexpr int PT = 32;                      // encoder positions per workgroup
 constexpr int LP_ROWS = 34, LP_GROUPS = 16; // partial block rows (32 filter taps incl. padding | score w | score b); block groups of the fp64 reduction
+constexpr int LP_WN = 80;                   // bf16 elements per window copy: 8 of padding in front (lanes below the copy's shift write there: no branch), 64 + 8 behind
 typedef float lp_f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, int S, int steps_per_block,
+typedef __bf16 lp_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t lp_cvt_pk(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (x0, x1) -> the three bf16 planes, packed pairs; remainders exact
+__device__ __forceinline__ void lp_split2(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = lp_cvt_pk(x0, x1);
+    x0 -= __uint_as_float(hi << 16); x1 -= __uint_as_float(hi & 0xffff0000u);
+    mid = lp_cvt_pk(x0, x1);
+    x0 -= __uint_as_float(mid << 16); x1 -= __uint_as_float(mid & 0xffff0000u);
+    lo = lp_cvt_pk(x0, x1);
+}
+__device__ __forceinline__ void lp_split8(const float* x, lp_bf16x8& hi, lp_bf16x8& mid, lp_bf16x8& lo) {
+    uint4 h, m, l;
+    lp_split2(x[0], x[1], h.x, m.x, l.x); lp_split2(x[2], x[3], h.y, m.y, l.y);
+    lp_split2(x[4], x[5], h.z, m.z, l.z); lp_split2(x[6], x[7], h.w, m.w, l.w);
+    hi = __builtin_bit_cast(lp_bf16x8, h); mid = __builtin_bit_cast(lp_bf16x8, m); lo = __builtin_bit_cast(lp_bf16x8, l);
+}
+#define LP_SIX(acc, ah, am, al, bh, bm, bl) do { \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0); } while (0)
+#ifndef LSA_PARAM_WAVES
+#define LSA_PARAM_WAVES 3        // waves per SIMD the register budget is cut for (168 registers: 15 spilled, still 428 us against 466 at 2 waves - same-box A/B)
+#endif
+__global__ __launch_bounds__(256, LSA_PARAM_WAVES) void lsa_param_bwd_kernel(mstts_lsa_const c, int S, int steps_per_block,
                                                             const float* __restrict__ q_hist, const float* __restrict__ cum_hist,
                                                             const float* __restrict__ de_hist, float* __restrict__ d_keys,
                                                             float* __restrict__ d_loc_k, float* __restrict__ d_score_w,
                                                             float* __restrict__ d_score_b, float* __restrict__ part) {
-    __shared__ float s_win[2][PT + 32];     // cum[t0 - pad + i], i < PT + KS - 1 (zero outside the sequence and past the window)
-    __shared__ float s_de[2][PT];
+    __shared__ __attribute__((aligned(16))) uint16_t s_wp[2][3][8][LP_WN];   // [buffer][plane][copy c][8 + i]: plane of cum[t0 - pad + i + c] (zero outside the sequence / window)
+    __shared__ __attribute__((aligned(16))) float s_de[2][PT];
     const int b = blockIdx.x, t0 = blockIdx.y * PT, T = (int)c.T, B = (int)c.B, KS = (int)c.KS, pad = (KS - 1) / 2;
     const int s_beg = blockIdx.z * steps_per_block, s_end = min(S, s_beg + steps_per_block);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, kh = lane >> 5;
     const int a = wave * 32 + l31;
-    // B operand of the first product: loc_k rows 2kk + kh of this wave's 32 columns (zero rows beyond the KS taps)
-    float lkb[16];
+    const int pl = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);      // the position (within the tile) of row l31 of the first product
+    const int o1 = (pl & 7) * LP_WN + 8 + (pl & ~7) + 8 * kh, o2 = (l31 & 7) * LP_WN + 8 + (l31 & ~7) + 8 * kh;    // copy | start of the lane's window runs
+    // B operand of the first product: filter taps j = 16 ks + 8 kh + i of this wave's 32 units (zero rows beyond the KS taps), split once
+    lp_bf16x8 fh[2], fm[2], fl[2];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) lkb[kk] = (2 * kk + kh < KS) ? c.loc_k[(2 * kk + kh) * A_ + a] : 0.f;
+    for (int ks = 0; ks < 2; ++ks) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int j = 16 * ks + 8 * kh + i; f[i] = j < KS ? c.loc_k[j * A_ + a] : 0.f; }
+        lp_split8(f, fh[ks], fm[ks], fl[ks]);
+    }
     const float sb = c.score_b[a] + c.loc_b[a], wk = c.score_w[a];
     float key_v[16];
     lp_f32x16 acc_keys, acc_lk;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    for (int r = 0; r < 16; ++r) {                 // register r of the first product's C layout: position (r & 7) + 8 kh + 16 (r >> 3)
+        const int t = t0 + (r & 7) + 8 * kh + 16 * (r >> 3);
         key_v[r] = t < T ? c.keys[((long)b * T + t) * A_ + a] : 0.f;
         acc_keys[r] = 0.f; acc_lk[r] = 0.f;
     }
     float acc_w = 0.f, acc_b = 0.f;
-    auto load_win = [&](int s) -> float {      // threads 0 .. PT+31: window; threads 128 .. 128+PT-1: d_e
+    auto load_win = [&](int s) -> float {          // waves 0 .. 2: the window (each wave writes one plane); wave 3: d_e
         float v = 0.f;
-        if (threadIdx.x < PT + KS - 1) {
-            const int t = t0 - pad + threadIdx.x;
-            if (t >= 0 && t < T) v = cum_hist[((long)s * B + b) * T + t];
-        } else if (threadIdx.x >= 128 && threadIdx.x < 128 + PT) {
-            const int t = t0 + (threadIdx.x - 128);
-            if (t < T) v = de_hist[((long)s * B + b) * T + t];
+        if (wave < 3) {
+            const int t = t0 - pad + lane;
+            if (lane < PT + KS - 1 && t >= 0 && t < T) v = cum_hist[((long)s * B + b) * T + t];
+        } else if (lane < PT) {
+            if (t0 + lane < T) v = de_hist[((long)s * B + b) * T + t0 + lane];
         }
         return v;
     };
@@ -1224,35 +1262,54 @@ __global__ __launch_bounds__(256) void lsa_param_bwd_kernel(mstts_lsa_const c, i
     if (s_beg < s_end) { nv = load_win(s_beg); nq = q_hist[((long)s_beg * B + b) * A_ + a]; }
     int buf = 0;
     for (int s = s_beg; s < s_end; ++s, buf ^= 1) {
-        if (threadIdx.x < PT + 32) s_win[buf][threadIdx.x] = nv;
-        else if (threadIdx.x >= 128 && threadIdx.x < 128 + PT) s_de[buf][threadIdx.x - 128] = nv;
+        if (wave < 3) {
+            uint32_t p0, p1, p2;
+            lp_split2(nv, 0.f, p0, p1, p2);
+            const uint16_t bits = (uint16_t)(wave == 0 ? p0 : wave == 1 ? p1 : p2);
+            uint16_t* w = &s_wp[buf][wave][0][8 + lane];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) w[cc * LP_WN - cc] = bits;
+        } else if (lane < PT) s_de[buf][lane] = nv;
         const float qk = nq + sb;
         if (s + 1 < s_end) { nv = load_win(s + 1); nq = q_hist[((long)(s + 1) * B + b) * A_ + a]; }
         __syncthreads();                    // buf written; the other buffer is free to be rewritten next iteration
-        const float* win = s_win[buf];
+        const uint16_t* wp = &s_wp[buf][0][0][0];
         lp_f32x16 L;
 #pragma unroll
         for (int r = 0; r < 16; ++r) L[r] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk)      // A[t = l31][j = 2kk + kh] = win[l31 + 2kk + kh]
-            L = __builtin_amdgcn_mfma_f32_32x32x2f32(win[l31 + 2 * kk + kh], lkb[kk], L, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {     // A[row l31 = position pl][j = 16 ks + 8 kh + i] = win[pl + j]
+            const lp_bf16x8 ah = *reinterpret_cast<const lp_bf16x8*>(wp + o1 + 16 * ks), am = *reinterpret_cast<const lp_bf16x8*>(wp + 8 * LP_WN + o1 + 16 * ks),
+                            al = *reinterpret_cast<const lp_bf16x8*>(wp + 16 * LP_WN + o1 + 16 * ks);
+            LP_SIX(L, ah, am, al, fh[ks], fm[ks], fl[ks]);
+        }
         float g[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float de = s_de[buf][(r & 3) + 8 * (r >> 2) + 4 * kh];          // 0 beyond T
-            const float u = fast_tanh(L[r] + key_v[r] + qk);
-            g[r] = de * wk * (1.f - u * u);
-            acc_w += de * u;
-            acc_b += g[r];
-            acc_keys[r] += g[r];
+        for (int r8 = 0; r8 < 2; ++r8) {
+            const float4 d0 = *reinterpret_cast<const float4*>(&s_de[buf][8 * kh + 16 * r8]), d1 = *reinterpret_cast<const float4*>(&s_de[buf][8 * kh + 16 * r8 + 4]);
+            const float de8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};           // 0 beyond T
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 8 * r8 + i;
+                const float u = tanhf_(L[r] + key_v[r] + qk);       // (the persistent forward's form of the same pre-activation)
+                g[r] = de8[i] * wk * (1.f - u * u);
+                acc_w += de8[i] * u;
+                acc_b += g[r];
+                acc_keys[r] += g[r];
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r)         // k-step r: rows t = (r&3) + 8(r>>2) + 4kh; A[j = l31][t] = win[t + l31]
-            acc_lk = __builtin_amdgcn_mfma_f32_32x32x2f32(win[(r & 3) + 8 * (r >> 2) + 4 * kh + l31], g[r], acc_lk, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {     // k = (kh, i) of k-step ks: position 16 ks + 8 kh + i = register 8 ks + i; A[tap l31][k] = win[position + l31]
+            lp_bf16x8 gh, gm, gl;
+            lp_split8(g + 8 * ks, gh, gm, gl);
+            const lp_bf16x8 ah = *reinterpret_cast<const lp_bf16x8*>(wp + o2 + 16 * ks), am = *reinterpret_cast<const lp_bf16x8*>(wp + 8 * LP_WN + o2 + 16 * ks),
+                            al = *reinterpret_cast<const lp_bf16x8*>(wp + 16 * LP_WN + o2 + 16 * ks);
+            LP_SIX(acc_lk, ah, am, al, gh, gm, gl);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = (r & 7) + 8 * kh + 16 * (r >> 3);
         if (t0 + row < T) atomicAdd(d_keys + ((long)b * T + t0 + row) * A_ + a, acc_keys[r]);
     }
     acc_w += __shfl_xor(acc_w, 32);            // (once per workgroup, off any per-step path)

@@ -28,6 +28,9 @@
 
 namespace mstts {
 
+#ifndef M1_LATE
+#define M1_LATE 60              // BF16 instantiation: 0 = the m1 row's request leaves right behind the h0 product; 1 = behind the location product; n > 1 = and n ticks (10 ns) into the stage
+#endif
 #ifndef SPLIT_M0
 #define SPLIT_M0 1              // 0: the on-chain cell-1 product on the f32-input MFMA like every other product of the loop (A/B builds)
 #endif
@@ -452,11 +455,11 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         else mfma_part<4, 8, LA, 32, 64>(w0, stg, lane, acc0);
         PSTAMP(10);
         // ================= E: attention, query units and partial energies of row ab
+        unsigned long long t_e0 = 0;
+        if constexpr (BF16 && M1_LATE > 1) t_e0 = wall_clock64();
         if (arow) {
-            if (tid < 256) {
-                roff[0] = (unsigned)((OFF_M1 + slot * XM1 + (long)ab * PH) * 4 + 16 * tid);
-                issue<1>(xr, roff, rv);
-            }
+            if (tid < 256) roff[0] = (unsigned)((OFF_M1 + slot * XM1 + (long)ab * PH) * 4 + 16 * tid);
+            if constexpr (!(BF16 && M1_LATE)) { if (tid < 256) issue<1>(xr, roff, rv); }
             // while the m1 row is in flight: the location filter over the cumulative alignment (known since the last step's softmax) as a
             // Toeplitz product on the matrix core: loc[t][k] = sum_j cum[t + j - 15] lk[j][k] = A . B with A[t][j] = cum window (one LDS word per
             // lane and k-step), B[j][k] = the filter slice (8 registers, loaded once); wave w takes positions 16 w .. 16 w + 15, and the D layout
@@ -469,6 +472,13 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 for (int ks = 0; ks < 8; ++ks)
                     locv[hh] = PMFMA(sm[S_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)],
                                      SM0 ? sm[S_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)] : lkb[SM0 ? 0 : ks], locv[hh]);
+            }
+            if constexpr (BF16 && M1_LATE) {
+                // BF16: the second half of the h0 product is 0.1 us, so a request right behind it reaches the memory side before the row does and comes
+                // back stale - a second round trip (2.1 us of waiting where the fp32 instantiation, 0.5 us of product in between, waits 0.5).  Here the
+                // request leaves behind the location product and, if that was not enough, M1_LATE ticks (10 ns) after the stage began
+                if (M1_LATE > 1) { while (wall_clock64() - t_e0 < (unsigned long long)M1_LATE) __builtin_amdgcn_s_sleep(1); }
+                if (tid < 256) issue<1>(xr, roff, rv);
             }
             if (tid < 256) {
                 { const unsigned g1[1] = {gen}; if (!complete<1>(xr, roff, rv, d.ctrl, g1)) PFAIL(); }

@@ -13,7 +13,8 @@ from multi_speaker_tts_amd.params import Dims
 
 dev = torch.device("cuda:0")
 dims = Dims()
-eng = TrainEngine(dims, device=dev, seed=1234)
+C3 = "--config3" in sys.argv            # the bf16 instantiations of the two loops
+eng = TrainEngine(dims, device=dev, seed=1234, recurrent_dtype="bf16" if C3 else "f32", gemm_dtype="bf16" if C3 else "f32")
 batch = bench.synthetic_batch(dims, 32, 128, 800, 1234, 0, dev)
 w = eng.plan(32, 128, 800)
 for _ in range(2):

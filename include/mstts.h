@@ -87,7 +87,10 @@ int mstts_gemm_split_big(int32_t on);
  * whose cut tiles are summed with atomics (reproducible to the last bit or two).  The inference engines set it around their forward passes. */
 int mstts_gemm_deterministic(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
- * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes. */
+ * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes.
+ * Like mstts_gemm_f32 it may cut a contraction along K on its own (no fused activation, batch 1, a tile list far from a round of the chip:
+ * the pieces are added with atomics; an uncut call without `accumulate` has its output cleared first) - not under mstts_gemm_deterministic(1),
+ * and not at all with MSTTS_GEMM_BF16_AUTOCUT=0 in the environment (A/B runs). */
 int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t s);
 /* 1 (default): contractions large enough to fill the chip with 256 x 256 tiles run on the big-tile kernel (csrc/gemm_bf16.hip: half the operand
  * bytes per flop of the 128 x 128 kernel); 0: the 128 x 128 kernel for everything (A/B runs, tests).  Process-wide; MSTTS_GEMM_BF16_BIG=0 in

@@ -371,6 +371,7 @@ extern "C" int mstts_gemm_split_big(int32_t on) { g_split_big = on != 0; return 
 // set it around their forward passes (a vocoder is a long chain of contractions; at random weights it amplifies last-bit differences).
 static thread_local int t_deterministic = 0;
 extern "C" int mstts_gemm_deterministic(int32_t on) { t_deterministic = on != 0; return MSTTS_OK; }
+namespace mstts { int gemm_deterministic_now() { return t_deterministic; } }     // (csrc/gemm_bf16.hip asks before it cuts a contraction along K on its own)
 
 extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm: null descriptor");

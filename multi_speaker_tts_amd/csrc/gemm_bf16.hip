@@ -541,6 +541,8 @@ using namespace mstts;
 static int g_bf16_big = -1;
 extern "C" int mstts_gemm_bf16_big(int32_t on) { g_bf16_big = on != 0; return MSTTS_OK; }
 
+namespace mstts { int gemm_deterministic_now(); }
+static int g_bf16_autocut = -1;           // MSTTS_GEMM_BF16_AUTOCUT=0: every contraction cut exactly as its caller asked (A/B)
 extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) {
     if (g_bf16_big < 0) { const char* e = getenv("MSTTS_GEMM_BF16_BIG"); g_bf16_big = !(e && e[0] == '0'); }
     MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm_bf16: null descriptor");
@@ -592,6 +594,36 @@ extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) 
         else launch_gemm_bf16_big<true, true>(g, vec, gridb, st);
         MSTTS_CHECK_LAUNCH("gemm_bf16 (256 x 256 tile)");
         return MSTTS_OK;
+    }
+    // The 128 x 128 kernel runs two workgroups per CU: 512 slots.  A contraction whose tile list is far from a multiple of that - the encoder's
+    // 4 096-row convolutions (128 tiles), the 80 / 84-column products (14 - 201 tiles) - is cut along K so that it fills one round: pieces of at
+    // least 128 contraction steps, cost model rounds x (K per piece + 300) x (1 + 2 % per piece for its atomics), fitted to a sweep of every
+    // such call of a train step (tools/gemm_split_sweep.py --config3: 0.31 ms per step against the callers' own cuts).  Only without a fused
+    // activation, for one batch, and not under mstts_gemm_deterministic; a caller's own cut (its output pre-zeroed or accumulated into) is re-chosen
+    // the same way, an uncut call without `accumulate` has its output cleared here first.
+    if (g_bf16_autocut < 0) { const char* e = getenv("MSTTS_GEMM_BF16_AUTOCUT"); g_bf16_autocut = !(e && e[0] == '0'); }
+    if (g_bf16_autocut && d->act == MSTTS_ACT_NONE && batch == 1 && !gemm_deterministic_now()) {
+        const long tiles = (long)cdiv(d->M, GB_BM) * cdiv(d->N, GB_BN);
+        int best = 1;
+        double best_cost = 0.0;
+        for (int sk = 1; sk <= 64; ++sk) {
+            if (sk > 1 && g.K / sk < 128) break;
+            const double cost = (double)cdiv(tiles * sk, 512) * ((double)g.K / sk + 300.0) * (1.0 + 0.02 * sk);
+            if (sk == 1 || cost < best_cost * 0.97) { best = sk; best_cost = cost; }      // (a cut has to win by 3 %)
+        }
+        if (best != split) {
+            if (split == 1 && !d->accumulate && best > 1) {
+                if (hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, st) != hipSuccess)
+                    MSTTS_REQUIRE(false, MSTTS_ERR_LAUNCH, "gemm_bf16: clearing the output of a K-cut contraction failed");
+            }
+            if (split > 1 || best > 1) {
+                split = (split > 1 && best == 1) ? split : best;          // (a caller's cut is never undone: a single piece would overwrite what it accumulates onto)
+                g.split_k = split;
+                kps = ((g.K + split - 1) / split + GB_BK - 1) / GB_BK * GB_BK;
+                if (kps < GB_BK) kps = GB_BK;
+                g.k_per_split = kps;
+            }
+        }
     }
     dim3 grid(cdiv(d->M, GB_BM) * cdiv(d->N, GB_BN), 1, batch * split);
     if (!ta && !tb) launch_gemm_bf16<false, false>(g, vec, grid, st);

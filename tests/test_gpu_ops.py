@@ -461,6 +461,32 @@ def test_gemm_bf16_big_tile_conv_window(dev):
     assert rel_err(t2n(dw), refw) < TOL
 
 
+def test_gemm_bf16_cuts_short_tile_lists_along_k(dev):
+    """mstts_gemm_bf16 cuts a contraction whose 128 x 128 tile list is far from a round of the chip along K by itself (csrc/gemm_bf16.hip: 32
+    tiles x K = 4 096 here): an uncut call WITHOUT `accumulate` must overwrite whatever the output held (the library clears it before the pieces
+    add up), with `accumulate` it adds onto it, with a ragged output stride the rows' tails stay untouched, and under mstts_gemm_deterministic
+    no cut is made: two runs are bit-equal and equal to the MSTTS_GEMM_BF16_AUTOCUT=0 form's summation order."""
+    M, N, K, ldc = 512, 1000, 4096, 1024
+    A = _r(dev, M, K, seed=1); B = _r(dev, K, N, seed=2, scale=1.0 / np.sqrt(K))
+    bias = _r(dev, N, seed=3)
+    ref = _bf(A).cpu().numpy().astype(np.float64) @ _bf(B).cpu().numpy().astype(np.float64) + t2n(bias).astype(np.float64)
+    Cm = torch.full((M, ldc), 7.0, device=dev)                      # garbage in the output, a marker in the stride tail
+    _gemm_call("mstts_gemm_bf16", A, B, Cm, M, N, K, K, N, ldc, bias=bias)
+    assert rel_err(t2n(Cm)[:, :N], ref) < TOL
+    assert float((Cm[:, N:] - 7.0).abs().max()) == 0.0
+    Ca = torch.full((M, ldc), 2.0, device=dev)
+    _gemm_call("mstts_gemm_bf16", A, B, Ca, M, N, K, K, N, ldc, bias=bias, accumulate=1)
+    assert rel_err(t2n(Ca)[:, :N], 2.0 + ref) < TOL
+    outs = []
+    with lib.deterministic_gemm():
+        for _ in range(2):
+            Cd = torch.full((M, ldc), 7.0, device=dev)
+            _gemm_call("mstts_gemm_bf16", A, B, Cd, M, N, K, K, N, ldc, bias=bias)
+            outs.append(t2n(Cd)[:, :N].copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert rel_err(outs[0], ref) < TOL
+
+
 def test_gemm_bf16_conv_window_splitk(dev):
     """Implicit-im2col conv forward, weight gradient (transposed window, split-K atomics) and accumulate on the bf16 GEMM."""
     B_, T, cin, cout, K = 3, 37, 16, 24, 5

@@ -455,6 +455,10 @@ int mstts_skinny_bwd_packed(const float* dG, int64_t ldg, const float* Wp, float
  *  philox_normal: out[i] ~ N(0, sigma^2), Box-Muller over Philox4x32-10 stream (seed, stream_id) (tf.random.normal stand-in) */
 int mstts_wg_overlap_add(const float* Y, const float* bias, float* out, int64_t N, int64_t T, int64_t K, int64_t S, int64_t C, mstts_stream_t s);
 int mstts_wg_gate(const float* a, int64_t lda, float* z, int64_t rows, int64_t C, mstts_stream_t s);
+/* The same gate with the dilated convolution's output kept in its own buffer b [rows, 2C]: z = tanh(a[:, :C] + b[:, :C]) * sigmoid(a[:, C:2C] + b[:, C:2C]).
+ * WaveGlowEngine runs that convolution as TWO reduction pieces onto a zeroed b (0 + p + q is the same float whichever piece lands first, so the
+ * flow stays bit-reproducible per latent seed) and so reaches the 256 x 256-tile contraction kernel at batch 4 x 40 frames. */
+int mstts_wg_gate_add(const float* a, int64_t lda, const float* b, float* z, int64_t rows, int64_t C, mstts_stream_t s);
 int mstts_wg_res_skip(const float* z, const float* rs, float* x, float* out, int64_t rows, int64_t C, int32_t last, int32_t first, mstts_stream_t s);
 int mstts_wg_coupling_inv(const float* audio, const float* log_s_b, const float* w_inv, const float* early, float sigma, float* out,
                           int64_t rows, int64_t c, int64_t c_early, mstts_stream_t s);

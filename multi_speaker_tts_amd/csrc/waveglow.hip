@@ -40,6 +40,21 @@ __global__ void wg_gate_kernel(const float* __restrict__ a, long lda, float* __r
     }
 }
 
+// ... with the dilated convolution's output in its own buffer b [rows, 2C] (see mstts_wg_gate_add): pre-activation = a + b
+__global__ void wg_gate_add_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, float* __restrict__ z, long rows, int C) {
+    const long n4 = rows * (C >> 2);
+    const int c4n = C >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4n; const int c = (int)(i - r * c4n) * 4;
+        const float4 at = *reinterpret_cast<const float4*>(a + r * lda + c), as = *reinterpret_cast<const float4*>(a + r * lda + C + c);
+        const float4 bt = *reinterpret_cast<const float4*>(b + r * 2 * C + c), bs = *reinterpret_cast<const float4*>(b + r * 2 * C + C + c);
+        float4 o;
+        o.x = tanhf(at.x + bt.x) * sigmoid_acc(as.x + bs.x); o.y = tanhf(at.y + bt.y) * sigmoid_acc(as.y + bs.y);
+        o.z = tanhf(at.z + bt.z) * sigmoid_acc(as.z + bs.z); o.w = tanhf(at.w + bt.w) * sigmoid_acc(as.w + bs.w);
+        *reinterpret_cast<float4*>(z + r * C + c) = o;
+    }
+}
+
 __global__ void wg_res_skip_kernel(const float* __restrict__ z, const float* __restrict__ rs, float* __restrict__ x, float* __restrict__ out,
                                    long rows, int C, int last, int first) {
     const long n = rows * C;
@@ -109,6 +124,14 @@ extern "C" int mstts_wg_gate(const float* a, int64_t lda, float* z, int64_t rows
     if (rows == 0) return MSTTS_OK;
     hipLaunchKernelGGL(wg_gate_kernel, dim3(wg_grid(rows * C)), dim3(256), 0, ST(s), a, (long)lda, z, (long)rows, (int)C);
     MSTTS_CHECK_LAUNCH("wg_gate");
+    return MSTTS_OK;
+}
+extern "C" int mstts_wg_gate_add(const float* a, int64_t lda, const float* b, float* z, int64_t rows, int64_t C, mstts_stream_t s) {
+    MSTTS_REQUIRE(a && b && z && rows >= 0 && C >= 4 && C % 4 == 0 && lda >= 2 * C && lda % 4 == 0, MSTTS_ERR_SHAPE, "wg_gate_add: bad arguments");
+    MSTTS_REQUIRE(aligned16(a) && aligned16(b) && aligned16(z), MSTTS_ERR_ALIGN, "wg_gate_add: 16-byte aligned operands required");
+    if (rows == 0) return MSTTS_OK;
+    hipLaunchKernelGGL(wg_gate_add_kernel, dim3(wg_grid(rows * C / 4)), dim3(256), 0, ST(s), a, (long)lda, b, z, (long)rows, (int)C);
+    MSTTS_CHECK_LAUNCH("wg_gate_add");
     return MSTTS_OK;
 }
 extern "C" int mstts_wg_res_skip(const float* z, const float* rs, float* x, float* out, int64_t rows, int64_t C, int32_t last, int32_t first, mstts_stream_t s) {

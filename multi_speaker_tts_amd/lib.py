@@ -205,6 +205,7 @@ SIGNATURES = {
     "mstts_ge2e_loss_fwd_bwd": (i32, [vp, i64, i64, i64, i64, vp, vp, vp, i64, vp, vp]),
     "mstts_wg_overlap_add": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "mstts_wg_gate": (i32, [vp, i64, vp, i64, i64, vp]),
+    "mstts_wg_gate_add": (i32, [vp, i64, vp, vp, i64, i64, vp]),
     "mstts_wg_res_skip": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, vp]),
     "mstts_wg_coupling_inv": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, vp]),
     "mstts_philox_normal": (i32, [vp, i64, u64, u32, f32, vp]),

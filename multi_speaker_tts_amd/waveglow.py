@@ -15,6 +15,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 import math
+import os
 
 import numpy as np
 import torch
@@ -106,6 +107,22 @@ def _weight_norm(g, v):
     return np.asarray(g, np.float64) * v / np.sqrt(np.maximum(ss, 1e-5))
 
 
+def _conv_two_pieces(rows, n_out):
+    """Whether the dilated convolution [rows, k ch] x [k ch, n_out] runs as two reduction pieces onto a zeroed buffer (see WaveGlowEngine.infer).
+    Fitted to tools/wg_conv_ab.py at the reference widths (per-layer microseconds, one piece | two pieces: batch 1: 92 | 64, 2: 99 | 118,
+    4: 185 | 164, 5: 187 | 174, 6: 277 | 322, 8: 268 | 330, 12: 534 | 501, 16: 571 | 518, 24: 838 | 853, 32: 923 | 1050): the 128 x 128-tile kernel's
+    time steps at 256, 512 and then every 1 024 tiles, the 256 x 256-tile kernel's at every 256 workgroups; in units of the latter's round."""
+    cols128, cols256 = -(-n_out // 128), -(-n_out // 256)
+    t128 = -(-rows // 128) * cols128
+    w256 = -(-rows // 256) * cols256 * 2
+    if t128 <= 128:                      # a fraction of the chip either way: two pieces of the small kernel fill it better
+        return True
+    if w256 < 160:                       # (below the library's threshold for the big tile)
+        return False
+    one = 0.58 if t128 <= 256 else 1.12 if t128 <= 512 else 1.65 * -(-t128 // 1024)
+    return -(-w256 // 256) < one
+
+
 class WaveGlowEngine:
     def __init__(self, dims: WGDims = None, device="cuda", values=None, seed=1234):
         self.d = dims or WGDims()
@@ -119,6 +136,7 @@ class WaveGlowEngine:
         self.load(vals)
         self._keep = []
         self.split_in = 0          # > 1: split the dilated-conv GEMM's reduction (atomic accumulation); 0 / 1 = off (see infer)
+        self.conv_two_pieces = os.environ.get("MSTTS_WG_TWO_PIECES", "1") != "0"     # the dilated convolution as two reduction pieces onto a zeroed buffer (see infer)
 
     # ------------------------------------------------------------------ checkpoint constants, folded on the host once
     def _dev(self, a):
@@ -190,7 +208,14 @@ class WaveGlowEngine:
         # The [rows, 3*ch] x [3*ch, 2*ch] conv GEMM has only ceil(rows/128) * (2*ch/128) = 344 output tiles of 128 rows at batch 4 x 40
         # frames on 256 CUs; mstts_gemm_f32 switches to 64-row tiles for such shapes (688 tiles), which beats the split-K form
         # used before (33.0 vs 33.6 ms per batch) and keeps the launch free of atomics - results are bit-reproducible run to run.
+        # Round 5: where it pays, the convolution's output goes to its own ZEROED buffer as exactly two reduction pieces (split_k = 2).  0 + p + q is
+        # the same float whichever piece's atomic lands first (fp addition commutes; three pieces would not be order-free), so the flow is still
+        # bit-reproducible per latent seed - and at batch 4 x 40 frames 22 x 4 tiles x 2 pieces = 176 workgroups reach the 256 x 256-tile kernel
+        # (csrc/gemm_split.inc), where the 128 x 128 one runs 344 tiles as a round and a third: 185 -> 164 us per layer, gate included (it adds the
+        # two buffers).  _conv_two_pieces: a fixed function of the shape (tools/wg_conv_ab.py), so a seed gives the same samples in every process.
         split_in = self.split_in or 1
+        two = self.conv_two_pieces and split_in == 1 and ch % 4 == 0 and _conv_two_pieces(rows, 2 * ch)
+        conv = self._f(rows, 2 * ch) if two else None
         for f in reversed(range(d.flows)):
             F = self.flow[f]
             c = F["c"]
@@ -199,9 +224,14 @@ class WaveGlowEngine:
             gemm(melg, F["w_cond"], cond, rows, ldc, cm, cm, ldc, ldc, bias=F["b_cond"])
             for i in range(d.layers):
                 last = i == d.layers - 1
-                gemm(x, F["w_in"][i], cond, rows, 2 * ch, d.k * ch, ch, 2 * ch, ldc, accumulate=True, split_k=split_in,
-                     win=(Lg, ch, (d.k - 1) // 2, 2 ** i), c_off=i * 2 * ch)
-                call("mstts_wg_gate", ptr(cond, i * 2 * ch), ldc, ptr(z), rows, ch)
+                if two:
+                    conv.zero_()
+                    gemm(x, F["w_in"][i], conv, rows, 2 * ch, d.k * ch, ch, 2 * ch, 2 * ch, split_k=2, win=(Lg, ch, (d.k - 1) // 2, 2 ** i))
+                    call("mstts_wg_gate_add", ptr(cond, i * 2 * ch), ldc, ptr(conv), ptr(z), rows, ch)
+                else:
+                    gemm(x, F["w_in"][i], cond, rows, 2 * ch, d.k * ch, ch, 2 * ch, ldc, accumulate=True, split_k=split_in,
+                         win=(Lg, ch, (d.k - 1) // 2, 2 ** i), c_off=i * 2 * ch)
+                    call("mstts_wg_gate", ptr(cond, i * 2 * ch), ldc, ptr(z), rows, ch)
                 nres = ch if last else 2 * ch
                 gemm(z, F["w_res"][i], rs, rows, nres, ch, ch, nres, nres, bias=F["b_res"][i])
                 call("mstts_wg_res_skip", ptr(z), ptr(rs), ptr(x), ptr(out), rows, ch, int(last), int(i == 0))

@@ -99,3 +99,13 @@ def test_header_declares_the_round_4_entry_points():
     assert L.mstts_persist_lstm_fwd_supported_n(16, 64, 2) == 0
     assert L.mstts_lsa_param_bwd_ws_floats(32, 128, 801) == (32 * 4 * 16 * 34 * 128 + 2 * 16 * 34 * 128)
     assert L.mstts_persist_infer_pack_floats() == 256 * 8 * 8 * 64
+
+
+def test_waveglow_conv_piece_rule_is_a_fixed_function_of_the_shape():
+    """WaveGlowEngine picks the dilated convolution's form (one reduction piece / two onto a zeroed buffer) from the shape alone - never from a
+    timing - so that one latent seed gives the same samples in every process; the rule reproduces the measured table of tools/wg_conv_ab.py."""
+    from multi_speaker_tts_amd.waveglow import _conv_two_pieces
+    measured = {1: True, 2: False, 3: False, 4: True, 5: True, 6: False, 8: False, 10: False, 12: True, 16: True, 24: False, 32: False}
+    for batch, two in measured.items():
+        assert _conv_two_pieces(batch * 1376, 1024) is two, batch
+    assert _conv_two_pieces(160, 1024) is True            # the 2-frame parity case: a fraction of the chip

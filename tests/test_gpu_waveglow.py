@@ -154,20 +154,42 @@ def _ref_size_values():
 
 def test_glow_inference_reference_size(dev):
     """The whole inference flow AT THE REFERENCE SIZE (268 M parameters) against the fp64 oracle: N = 1, T = 2 frames -> 1280 samples,
-    every coupling layer at 512 channels / 8 dilated layers, identical injected latents."""
+    every coupling layer at 512 channels / 8 dilated layers, identical injected latents.
+
+    Twelve affine couplings at random weights amplify a last-bit difference of an early contraction: ANY fp32 evaluation of this graph sits
+    3e-4 .. 4e-3 from the fp64 one depending on the draw (profiles/r05_waveglow_reference_size_errors.txt: six draws, the oracle itself run in
+    fp32 on the host 3.5e-4 .. 1.8e-3, the engine 3e-4 .. 2.9e-3 with the dilated convolution accumulated in one piece and 4.9e-4 .. 4.2e-3 in two).
+    A single draw against a fixed bound therefore tests the draw (round 4's 1e-3 held for its seed in one summation order and not in the other).
+    The test runs FIVE draws and compares like with like: the engine's median error must stay within 2.5 x the median error of the fp32 oracle
+    (same graph, same inputs, fp32 on the host), and no draw may leave 1e-2.  Both summation orders of the engine are held to it."""
     od, values = _ref_size_values()
     pd = WG.WGDims(**REF_WG)
     N, T = 1, 2
-    g = np.random.default_rng(8)
-    mel = np.clip(g.normal(0, 1.5, (N, T, od.n_mel)), -4, 4)
     L = (T - 1) * od.up_stride + od.up_k
     assert L == 256 * T + 768
-    noise = OW.make_noise(od, N, L // od.groups, seed=9)
-    ref = OW.glow_inference(OW.to_torch(values), od, torch.tensor(mel), {k: torch.tensor(v) for k, v in noise.items()}, sigma=0.8)
-    eng = WG.WaveGlowEngine(pd, device=dev, values=values)
-    got = eng.infer(mel.astype(np.float32), noise=noise, sigma=0.8)
-    assert got.shape == (N, L) and bool(torch.isfinite(got).all())
-    assert rel_err(t2n(got), t2n(ref)) < 1e-3, rel_err(t2n(got), t2n(ref))
+    v64 = OW.to_torch(values)
+    v32 = {k: (v.float() if torch.is_tensor(v) and v.dtype == torch.float64 else v) for k, v in v64.items()}
+    engines = {}
+    for two in (True, False):
+        engines[two] = WG.WaveGlowEngine(pd, device=dev, values=values)
+        engines[two].conv_two_pieces = two
+    errs = {True: [], False: [], "fp32 oracle": []}
+    for draw in range(5):
+        mel = np.clip(np.random.default_rng(8 + draw).normal(0, 1.5, (N, T, od.n_mel)), -4, 4)
+        noise = OW.make_noise(od, N, L // od.groups, seed=9 + draw)
+        ref = OW.glow_inference(v64, od, torch.tensor(mel), {k: torch.tensor(v) for k, v in noise.items()}, sigma=0.8)
+        r32 = OW.glow_inference(v32, od, torch.tensor(mel).float(), {k: torch.tensor(v).float() for k, v in noise.items()}, sigma=0.8)
+        errs["fp32 oracle"].append(rel_err(t2n(r32), t2n(ref)))
+        for two, eng in engines.items():
+            got = eng.infer(mel.astype(np.float32), noise=noise, sigma=0.8)
+            assert got.shape == (N, L) and bool(torch.isfinite(got).all())
+            errs[two].append(rel_err(t2n(got), t2n(ref)))
+    med = {k: float(np.median(v)) for k, v in errs.items()}
+    print("error against the fp64 oracle over five draws: " + "; ".join("%s: median %.2e, max %.2e" % (
+        {True: "engine (two pieces)", False: "engine (one piece)"}.get(k, k), med[k], max(v)) for k, v in errs.items()))
+    for two in (True, False):
+        assert med[two] <= 2.5 * med["fp32 oracle"] + 2e-4, (two, med)
+        assert max(errs[two]) < 1e-2, (two, errs[two])
 
 
 def test_glow_inference_reference_size_properties(dev):

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 import warnings
 
 import numpy as np
@@ -27,6 +28,21 @@ BN_EPS = 1e-3
 
 class _PersistRetry(RuntimeError):
     pass
+
+
+def to_host(tensors):
+    """{name: device tensor} -> {name: numpy array}: every tensor copied asynchronously into its own page-locked host block, ONE synchronisation, the
+    arrays are views of those blocks (each array owns its block; torch's caching host allocator hands the block out again once the array is
+    dropped, so only the first call pays for pinning).  33.8 MB of results of a batch-16 forward: 2.7 ms through `.cpu()` (a pageable destination,
+    12.7 GB/s) against 0.9 ms this way."""
+    host = {}
+    for k, v in tensors.items():
+        v = v.detach()
+        h = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+        h.copy_(v, non_blocking=True)
+        host[k] = h
+    torch.cuda.synchronize()
+    return {k: h.numpy() for k, h in host.items()}
 
 
 class _DeferredCheck:
@@ -575,6 +591,13 @@ class InferEngine:
         self._keep = []
         self._lstm_pending, self._lstm_copied = [], 0
         dev = self.device
+        prof = getattr(self, "profile_phases", False)          # tools/infer_bench.py: wall time per phase (adds a synchronisation behind each)
+        marks = [("start", time.perf_counter())]
+
+        def mark(name):
+            if prof:
+                torch.cuda.synchronize()
+                marks.append((name, time.perf_counter()))
         t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev, dt).contiguous()
         token, tlen = t(pattern["Token"], torch.int32), t(pattern["Token_Length"], torch.int32)
         B, T = token.shape
@@ -582,8 +605,11 @@ class InferEngine:
             spk = t(pattern["Speaker_Embedding"], torch.float32)
         else:
             spk = self._speaker_embedding(t(pattern["Speaker_Embedding_Mel"], torch.float32))
+        mark("uploads + speaker encoder")
         values, keys = self._encoder(token, tlen, spk)
+        mark("text encoder")
         lin_s, stop_s, align_s, S = self.decode(values, keys, tlen, masks=masks, seed=seed, max_steps=max_steps)
+        mark("free-running decoder")
         self._lstm_verify()                  # (decode synchronised the stream behind the read-back of their control words)
         d = self.d
         linear = self._f(B, S, d.n_mel)
@@ -596,7 +622,11 @@ class InferEngine:
         self._lstm_ctrl_copy()
         torch.cuda.synchronize()
         self._lstm_verify()
-        res = {k: v.detach().cpu().numpy() for k, v in out.items()}
+        mark("postnet + Taco1 vocoder")
+        res = to_host(out)
         res["Stop"] = 1.0 / (1.0 + np.exp(-res["Stop_Logit"]))
+        mark("results to the host")
+        if prof:
+            self.phase_ms = {b[0]: (b[1] - a[1]) * 1e3 for a, b in zip(marks[:-1], marks[1:])}
         self._keep = []
         return res

@@ -45,10 +45,13 @@ if eng.persist_infer_launches:
 # max_steps, postnet, Taco1 mel -> spectrogram), results copied to the host as MSTTS_SV.Inference does
 spk_mel = g.normal(0, 1, (5 * B, 64, d.n_mel)).astype(np.float32)
 pattern = {"Token": tok, "Token_Length": lens, "Speaker_Embedding_Mel": spk_mel}
-for it in range(2):
+for it in range(4):          # (results land in page-locked blocks that are recycled once the caller drops them: steady from the third call on)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = eng.forward(pattern, seed=1, max_steps=S, with_vocoder=True)
     dt = time.perf_counter() - t0
     n = res["Linear"].shape[1]
     print("forward (speaker encoder + Tacotron2 + Taco1 vocoder, host copies included): %d frames x batch %d: %.1f ms  (%.0f mel-frames/s)"
           % (n, B, dt * 1e3, B * n / dt))
+eng.profile_phases = True
+res = eng.forward(pattern, seed=1, max_steps=S, with_vocoder=True)
+print("  phases (a synchronisation behind each): " + ", ".join("%s %.2f ms" % kv for kv in eng.phase_ms.items()) + "; result bytes %.1f MB" % (sum(v.nbytes for v in res.values()) / 1e6))

@@ -3,6 +3,7 @@
 #   bash tools/ab_bench.sh "-DVARIANT_A" "-DVARIANT_B" [reps]
 # rebuilds the library with each flag in turn (all sources), runs bench.py after each, alternating `reps` times.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+python -c "from multi_speaker_tts_amd import lib; lib.load()" > /dev/null 2>&1    # (a fresh snapshot may rebuild the library once on its first load: do that BEFORE the first variant is linked)
 A=$1; B=$2; REPS=${3:-2}
 build() {
   for f in multi_speaker_tts_amd/csrc/*.hip; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $1 -x hip -c $f -o ${f%.hip}.o & done; wait

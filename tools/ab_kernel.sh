@@ -2,6 +2,7 @@
 # A/B of compile-time variants of ONE source file on the same GPU box, by a kernel's average duration in a rocprofv3 trace of the bench:
 #   bash tools/ab_kernel.sh lsa lsa_param_bwd_kernel "-DLSA_PARAM_WAVES=2" "-DLSA_PARAM_WAVES=3"
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+python -c "from multi_speaker_tts_amd import lib; lib.load()" > /dev/null 2>&1    # (a fresh snapshot may rebuild the library once on its first load: do that BEFORE the first variant is linked)
 ROOT=$PWD
 SRC=$1; KERN=$2; shift; shift
 export TMPDIR=/tmp

@@ -2,6 +2,7 @@
 # A/B of compile-time variants of ONE source file on the same GPU box:
 #   bash tools/ab_one.sh persist_bwd "-DEARLY_DM1=31" "-DEARLY_DM1=16" ...   (each variant is built and benched twice, alternating; BENCH_ARGS=--config3 for the bf16 instantiations)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+python -c "from multi_speaker_tts_amd import lib; lib.load()" > /dev/null 2>&1    # (a fresh snapshot may rebuild the library once on its first load: do that BEFORE the first variant is linked)
 SRC=$1; shift
 for rep in 1 2; do
   for v in "$@"; do

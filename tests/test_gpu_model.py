@@ -1079,3 +1079,22 @@ def test_gradient_ready_ranges(dev):
     assert seen[0][0] > seen[1][0] > seen[2][0]                                # postnet (end of slab) first, encoder last
     for (lo, hi), snap in zip(seen, snaps):
         assert torch.equal(eng.params.grad[lo:hi], snap) and float(snap.abs().max()) > 0
+
+
+def test_inference_results_own_their_host_blocks(dev):
+    """inference.to_host (the results of InferEngine.forward): bit-equal to `.cpu()`, one page-locked block per array - a later call neither aliases nor
+    overwrites an earlier call's arrays - and non-contiguous / integer tensors go through as they are."""
+    from multi_speaker_tts_amd.inference import to_host
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = torch.randn(37, 129, generator=g).to(dev)
+    b = torch.randint(0, 100, (5, 7), generator=g, dtype=torch.int32).to(dev)
+    r1 = to_host({"a": a, "b": b, "t": a.t()})
+    assert np.array_equal(r1["a"], a.cpu().numpy()) and np.array_equal(r1["b"], b.cpu().numpy()) and np.array_equal(r1["t"], a.t().cpu().numpy())
+    keep = r1["a"].copy()
+    a.mul_(2.0)
+    r2 = to_host({"a": a})
+    assert np.array_equal(r1["a"], keep) and np.array_equal(r2["a"], 2.0 * keep)
+    assert not np.shares_memory(r1["a"], r2["a"])
+    del r2
+    r3 = to_host({"a": a})                       # (may reuse r2's block - never r1's, which is still held)
+    assert np.array_equal(r1["a"], keep) and not np.shares_memory(r1["a"], r3["a"])

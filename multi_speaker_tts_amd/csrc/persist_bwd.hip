@@ -23,6 +23,9 @@
 // abort the host re-runs mstts_decoder_train_bwd.
 #include "persist_fwd_parts.h"        // (the bf16 operand types and the 16x16x32 bf16 MFMA macro; persist_common.h through it)
 
+#ifndef BG0_LATE
+#define BG0_LATE 10             // ticks (10 ns) between the cell-0 update's publications and the gather of the gate gradients for the d[g0] product
+#endif
 namespace mstts {
 
 // ring sizes in floats per slot
@@ -576,6 +579,11 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         }
         PSTAMP(11);
         {
+            // A short timed pause between this workgroup's own publication of its gate gradients and the gather of everybody's: with the requests issued
+            // right behind the write-through stores the stage in front (`cell-0 update backward + publish`) is 0.25 us longer.  Swept on one box (0 / 1 / 5 /
+            // 15 / 30 / 45 / 60 ticks: frame 19.23 / 19.02 / 18.90 / 18.93 / 19.05 / 19.2 / 19.24 us; bf16: 12.86 / - / 12.70 / 12.68 / 12.77); the same pause
+            // in front of the d[g1] gather moves 0.18 us from one stage into the next and gains nothing, and in front of the forward loop's requests it loses.
+            if constexpr (BG0_LATE > 0) { const unsigned long long t__ = wall_clock64(); while (wall_clock64() - t__ < (unsigned long long)BG0_LATE) __builtin_amdgcn_s_sleep(1); }
             PROD_GATHER(BO_DG0)
             PROD_HALF(0, w0t, wb0t, BO_PM0, true)
             PSTAMP(12);

@@ -265,24 +265,56 @@ def cpu_baseline(budget_s=0.0, timeout_s=900):
     return {"value": None, "unit": "mel-frames/s", "cores": max(cands), "kind": "port", "sample": "oracle did not finish within %d s" % timeout_s}
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: spawn N copies of this script, one per GPU, with the environment
-    torch.distributed.run would export (rendezvous on 127.0.0.1), and wait for them."""
+def self_launch(n, cmd=None, grace_s=5.0, poll_s=0.1):
+    """`python bench.py --gpus N` without a launcher: spawn N copies of this script (or of `cmd`, the tests' stand-in), one per GPU,
+    with the environment torch.distributed.run would export (rendezvous on 127.0.0.1), and WATCH them: all ranks are polled together,
+    and the first one that exits non-zero (died in init_process_group, fell out of a collective, out of memory ...) ends the job - the
+    other ranks, which would sit in their next collective until the backend's own time-out (30 minutes), get SIGTERM, `grace_s`
+    seconds later SIGKILL, and the launcher exits with the failed rank's code.  Returns 0 when every rank exited 0."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    cmd = cmd or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
-    if rc:
-        raise SystemExit(rc)
+        procs.append(subprocess.Popen(cmd, env=env))
+
+    def stop_all():
+        for p in procs:                                     # exactly the processes started above, by handle - never by pattern
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + grace_s
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    def on_signal(signum, _frame):                          # the launcher itself is told to stop: do not orphan the ranks
+        stop_all()
+        raise SystemExit(128 + signum)
+    old = {s: signal.signal(s, on_signal) for s in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                sys.stderr.write("bench.py launcher: rank %d exited with code %d; stopping the other %d rank(s)\n" % (r, c, n - 1))
+                stop_all()
+                raise SystemExit(c if c > 0 else 128 - c)   # (a negative code is the signal that killed the rank)
+            if all(c == 0 for c in codes):
+                return 0
+            time.sleep(poll_s)
+    finally:
+        for s, h in old.items():
+            signal.signal(s, h)
 
 
 def main():
@@ -326,7 +358,22 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        import datetime
+        t_init = time.perf_counter()
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=300))
+        # start-up self-check, BEFORE anything is timed: one tiny sum over the ranks must come back as world * (world + 1) / 2 on every
+        # rank - a job whose communicator is not the N ranks it was asked for stops here, in seconds, with a message (stderr: stdout
+        # carries the one JSON line)
+        chk = torch.tensor([float(rank + 1)], dtype=torch.float64, device=device)
+        dist.all_reduce(chk)
+        torch.cuda.synchronize()
+        ok = dist.get_world_size() == world and abs(float(chk.item()) - world * (world + 1) / 2.0) < 1e-9
+        if rank == 0 or not ok:
+            sys.stderr.write("bench.py start-up check: rccl_ranks=%d (asked for %d), all-reduce %s, communicator up after %.1f s\n"
+                             % (dist.get_world_size(), world, "ok" if ok else "WRONG (%r)" % float(chk.item()), time.perf_counter() - t_init))
+            sys.stderr.flush()
+        if not ok:
+            raise SystemExit(3)
 
     from multi_speaker_tts_amd import lib
     from multi_speaker_tts_amd.engine import TrainEngine
@@ -364,8 +411,12 @@ def main():
         eng.train_step(batch, all_reduce=reducer)
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [1e3 * elapsed / args.steps]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(tt) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, tt)
+        per_rank_ms = [1e3 * float(t.item()) / args.steps for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -374,6 +425,7 @@ def main():
     out = {"metric": "mel-frames/sec (train step) at batch 32x(128 tok,800 mel)" if headline_batch else
                      "mel-frames/sec (train step) at per-GPU batch %d x %d tokens (supplementary, not the BASELINE configuration)" % (B_PER_GPU, T_ENC), "value": value, "unit": "mel-frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "ms_per_step_per_rank": per_rank_ms, "ms_per_step_min_over_ranks": min(per_rank_ms), "ms_per_step_max_over_ranks": max(per_rank_ms),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": ("bf16 operands in every hoisted contraction, f32 accumulate + f32 master, f32 inside the persistent decoder loops (BASELINE config 3 arithmetic, not the headline)"
                      if args.config3 and args.recurrent_dtype == "f32" else "f32" if args.recurrent_dtype == "f32" else

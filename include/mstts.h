@@ -11,9 +11,13 @@
  *   - activations [B,T,C] row-major (NWC), conv kernels [K,Cin,Cout], dense [in,out],
  *     LSTM kernels [in+H,4H] gate order i,j,f,o - the reference's layouts;
  *   - the caller owns every buffer (workspaces included); the library allocates no device memory and the compute entry points
- *     keep no mutable state, so they are re-entrant across streams/threads.  The single exception is the profiling facility
- *     mstts_probe_* at the end of this header (process-global event list, armed only by bench.py, not thread-safe);
- *   - no environment variable changes what a kernel computes or which kernel runs;
+ *     keep no mutable state, so they are re-entrant across streams/threads.  Two exceptions, both named where they are declared:
+ *     the GEMM scheduling switches mstts_gemm_tail_split / _split3 / _split_big / _big_min_workgroups / _bf16_big / _bf16_autocut
+ *     (process-global development switches for A/B runs and tests; they select WHICH kernel evaluates a contraction, never what it
+ *     means; mstts_gemm_deterministic is per calling thread) and the profiling facility mstts_probe_* at the end of this header
+ *     (process-global event list, armed only by bench.py, not thread-safe);
+ *   - the library reads NO environment variable (tests/test_cpu_abi.py greps csrc/ for getenv): the MSTTS_GEMM_* variables of the
+ *     Python binding are mapped onto the setters above by multi_speaker_tts_amd/lib.py when it loads the library;
  *   - asynchronous on the given hipStream_t (passed as void*), no implicit synchronisation;
  *   - returns 0 or a negative MSTTS_ERR_* code; mstts_last_error() gives thread-local text.
  */
@@ -82,19 +86,24 @@ int mstts_gemm_split3(int32_t on);
  * six products (gemm_split_big_kernel: 256 x 256 x 16 per 512-thread workgroup, every wave loads, splits, stages and multiplies); 0: the
  * 128 x 128 x 32 producer / consumer kernel for all of them.  Same arithmetic, another summation order.  Process-wide (A/B runs, tests). */
 int mstts_gemm_split_big(int32_t on);
+/* From how many 256 x 256 workgroups on the big-tile kernels are taken: first value for mstts_gemm_f32's split kernel, second for mstts_gemm_bf16's
+ * (default 160 each; a value <= 0 keeps the current setting).  Process-wide development switch (tools/gemm_split_sweep.py). */
+int mstts_gemm_big_min_workgroups(int32_t f32_split, int32_t bf16);
 /* Per calling thread.  1: mstts_gemm_f32 makes no K-cut the caller did not ask for with split_k (body + tail schedule and the full cut of
  * short tile lists off): every output element is one fixed-order sum, bit-reproducible run to run.  0 (default): the schedules of DESIGN 4.7,
  * whose cut tiles are summed with atomics (reproducible to the last bit or two).  The inference engines set it around their forward passes. */
 int mstts_gemm_deterministic(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes.
- * Like mstts_gemm_f32 it may cut a contraction along K on its own (no fused activation, batch 1, a tile list far from a round of the chip:
- * the pieces are added with atomics; an uncut call without `accumulate` has its output cleared first) - not under mstts_gemm_deterministic(1),
- * and not at all with MSTTS_GEMM_BF16_AUTOCUT=0 in the environment (A/B runs). */
+ * split_k > 1 is honoured exactly, as by mstts_gemm_f32.  A call WITHOUT a cut of its own (split_k <= 1, no fused activation, batch 1) whose tile
+ * list is far from a round of the chip is cut along K by the library: the pieces are added with atomics, and without `accumulate` the output's
+ * M x N elements (N columns of each row, not the row pitch ldc) are cleared first - not under mstts_gemm_deterministic(1), and not at all after
+ * mstts_gemm_bf16_autocut(0). */
 int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t s);
+/* 1 (default): the library's own K-cuts described above; 0: every contraction cut exactly as its caller asked.  Process-wide (A/B runs). */
+int mstts_gemm_bf16_autocut(int32_t on);
 /* 1 (default): contractions large enough to fill the chip with 256 x 256 tiles run on the big-tile kernel (csrc/gemm_bf16.hip: half the operand
- * bytes per flop of the 128 x 128 kernel); 0: the 128 x 128 kernel for everything (A/B runs, tests).  Process-wide; MSTTS_GEMM_BF16_BIG=0 in
- * the environment sets the initial state. */
+ * bytes per flop of the 128 x 128 kernel); 0: the 128 x 128 kernel for everything (A/B runs, tests).  Process-wide. */
 int mstts_gemm_bf16_big(int32_t on);
 
 /* ---- randomness: Philox4x32-10 keep-masks (replaces tf.random_uniform inside
@@ -137,6 +146,10 @@ int mstts_colsum(const float* x, int64_t rows, int64_t C, int64_t ld, float* out
 /* y = a + b ; y = a*alpha ; fill */
 int mstts_add(const float* a, const float* b, float* y, int64_t n, mstts_stream_t s);
 int mstts_fill(float* y, float v, int64_t n, mstts_stream_t s);
+/* *flag = 1 when every given persistent launch ran to its end (control words [1] == 0: no abort code, [2] == done_x: every workgroup finished),
+ * else 0; a null ctrl pointer is skipped.  The device-side form of the host's check of those words, so that a data-parallel job can take the
+ * MINIMUM over its ranks (dist.GradAllReduce.agree_async) without a host round trip.  No reference counterpart (MSTTS_SV.py:24: one session). */
+int mstts_persist_status(const uint32_t* ctrl_a, int32_t done_a, const uint32_t* ctrl_b, int32_t done_b, int32_t* flag, mstts_stream_t s);
 /* strided 2-D copy / accumulate: dst[r*ldd + c] (+)= src[r*lds + c] */
 int mstts_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, int32_t accumulate, mstts_stream_t s);
 /* tf max_pooling1d(2,1,'same') on [B,T,C]: y[t] = max(x[t], x[t+1]) (Taco1 Modules.py:28-33) */

@@ -310,6 +310,19 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 __global__ void fill_kernel(float* __restrict__ y, float v, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = v;
 }
+// 16-byte stores (y 16-byte aligned, n4 = n / 4 whole quads; the caller's tail goes through fill_kernel)
+__global__ void fill4_kernel(float4* __restrict__ y, float v, long n4) {
+    const float4 q = make_float4(v, v, v, v);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) y[i] = q;
+}
+// One word that says whether up to two persistent launches ran to their end: control words [1] = abort code (0 = none), [2] = workgroups that
+// finished (persist_common.h / persist_lstm.hip keep the same layout).  Null pointers are skipped.
+__global__ void persist_status_kernel(const unsigned* a, unsigned done_a, const unsigned* b, unsigned done_b, int* flag) {
+    bool ok = true;
+    if (a) ok = ok && a[1] == 0u && a[2] == done_a;
+    if (b) ok = ok && b[1] == 0u && b[2] == done_b;
+    *flag = ok ? 1 : 0;
+}
 __global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long rows, long cols, int acc) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows * cols; i += (long)gridDim.x * blockDim.x) {
         const long r = i / cols, c = i % cols;
@@ -1017,8 +1030,16 @@ extern "C" int mstts_add(const float* a, const float* b, float* y, int64_t n, ms
 }
 extern "C" int mstts_fill(float* y, float v, int64_t n, mstts_stream_t s) {
     if (n == 0) return MSTTS_OK;
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(s), y, v, (long)n);
+    const long n4 = aligned16(y) ? n / 4 : 0;
+    if (n4 > 0) hipLaunchKernelGGL(fill4_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, ST(s), reinterpret_cast<float4*>(y), v, n4);
+    if (n - 4 * n4 > 0) hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n - 4 * n4, 256)), dim3(256), 0, ST(s), y + 4 * n4, v, (long)(n - 4 * n4));
     MSTTS_CHECK_LAUNCH("fill");
+    return MSTTS_OK;
+}
+extern "C" int mstts_persist_status(const uint32_t* ctrl_a, int32_t done_a, const uint32_t* ctrl_b, int32_t done_b, int32_t* flag, mstts_stream_t s) {
+    MSTTS_REQUIRE(flag != nullptr, MSTTS_ERR_SHAPE, "persist_status: null flag");
+    hipLaunchKernelGGL(persist_status_kernel, dim3(1), dim3(1), 0, ST(s), ctrl_a, (unsigned)done_a, ctrl_b, (unsigned)done_b, flag);
+    MSTTS_CHECK_LAUNCH("persist_status");
     return MSTTS_OK;
 }
 extern "C" int mstts_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, int32_t accumulate, mstts_stream_t s) {

@@ -357,6 +357,8 @@ static void launch_gemm(const GemmArgs& g, bool vec, dim3 grid, hipStream_t st) 
 
 using namespace mstts;
 
+// Process-global development switches (A/B runs, tests).  The library reads NO environment variable: multi_speaker_tts_amd/lib.py maps its
+// MSTTS_GEMM_* variables onto these setters once, when it loads the library.
 static int g_tail_split = 1;
 extern "C" int mstts_gemm_tail_split(int32_t on) { g_tail_split = on != 0; return MSTTS_OK; }
 // 1 (default): every contraction with more than 32 rows runs as the six-product bf16 split (gemm_split.inc: fp32 accuracy at 6/16 of
@@ -366,6 +368,14 @@ extern "C" int mstts_gemm_split3(int32_t on) { g_split3 = on != 0; return MSTTS_
 // 1 (default): split contractions that fill the chip with 256 x 256 tiles take gemm_split_big_kernel; 0: the 128 x 128 x 32 producer / consumer kernel
 static int g_split_big = 1;
 extern "C" int mstts_gemm_split_big(int32_t on) { g_split_big = on != 0; return MSTTS_OK; }
+// from how many 256 x 256 workgroups on the big-tile kernels are taken (fp32 split kernel, bf16 kernel; <= 0 keeps the current value)
+static int g_split_big_min = 160;
+namespace mstts { void gemm_bf16_set_big_min(int n); }
+extern "C" int mstts_gemm_big_min_workgroups(int32_t f32_split, int32_t bf16) {
+    if (f32_split > 0) g_split_big_min = f32_split;
+    gemm_bf16_set_big_min(bf16);
+    return MSTTS_OK;
+}
 // Per calling thread: 1 = no K-cuts that the caller did not ask for (neither the tail of a long tile list nor a short list cut entirely), so a
 // contraction without split_k adds its K range in one fixed order and its result is bit-reproducible from run to run.  The inference engines
 // set it around their forward passes (a vocoder is a long chain of contractions; at random weights it amplifies last-bit differences).
@@ -445,13 +455,8 @@ extern "C" int mstts_gemm_f32(const mstts_gemm_desc* d, mstts_stream_t stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     {   // the 256 x 256 x 16 form of the split where such tiles fill the chip (from 160 workgroups on; one per CU)
-        static int big_on = -1, big_min = 160;
-        if (big_on < 0) {
-            const char* e = getenv("MSTTS_GEMM_SPLIT_BIG"); big_on = !(e && e[0] == '0');
-            const char* m = getenv("MSTTS_GEMM_SPLIT_BIG_MIN"); if (m) big_min = atoi(m);
-        }
         const long big_wgs = (long)cdiv(d->M, GSB_BM) * cdiv(d->N, GSB_BN) * batch * split;
-        if (split3 && big_on && g_split_big && d->M >= 192 && d->N >= 192 && big_wgs >= big_min && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
+        if (split3 && g_split_big && d->M >= 192 && d->N >= 192 && big_wgs >= g_split_big_min && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
             (d->win_T <= 0 || (d->win_T >= GSB_BK && d->win_C >= GSB_BK)) && (d->act == MSTTS_ACT_NONE || split == 1) && gemm_split_big_ready()) {
             int kpsb = ((g.K + split - 1) / split + GSB_BK - 1) / GSB_BK * GSB_BK;
             if (kpsb < GSB_BK) kpsb = GSB_BK;

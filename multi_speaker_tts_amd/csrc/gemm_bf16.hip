@@ -538,13 +538,17 @@ static void launch_gemm_bf16_big(const GemmBfArgs& g, bool vec, dim3 grid, hipSt
 
 using namespace mstts;
 
-static int g_bf16_big = -1;
+// Process-global development switches (A/B runs, tests), set through the entry points below - the library reads no environment variable
+// (multi_speaker_tts_amd/lib.py maps its MSTTS_GEMM_* variables onto these setters when it loads the library).
+static int g_bf16_big = 1;
 extern "C" int mstts_gemm_bf16_big(int32_t on) { g_bf16_big = on != 0; return MSTTS_OK; }
+static int g_bf16_big_min = 160;         // (measured: 180 workgroups of the 256 x 256 kernel beat 720 of the small one by 1.3 x, 101 lose to 404 by 1.2 x)
+namespace mstts { void gemm_bf16_set_big_min(int n) { if (n > 0) g_bf16_big_min = n; } }       // (mstts_gemm_big_min_workgroups, csrc/gemm.hip)
+static int g_bf16_autocut = 1;           // 0: no K-cut of the library's own (A/B)
+extern "C" int mstts_gemm_bf16_autocut(int32_t on) { g_bf16_autocut = on != 0; return MSTTS_OK; }
 
 namespace mstts { int gemm_deterministic_now(); }
-static int g_bf16_autocut = -1;           // MSTTS_GEMM_BF16_AUTOCUT=0: every contraction cut exactly as its caller asked (A/B)
 extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) {
-    if (g_bf16_big < 0) { const char* e = getenv("MSTTS_GEMM_BF16_BIG"); g_bf16_big = !(e && e[0] == '0'); }
     MSTTS_REQUIRE(d != nullptr, MSTTS_ERR_SHAPE, "gemm_bf16: null descriptor");
     MSTTS_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, MSTTS_ERR_SHAPE, "gemm_bf16: negative dims");
     if (d->M == 0 || d->N == 0) return MSTTS_OK;
@@ -579,9 +583,7 @@ extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) 
     // the 256 x 256 tile where the operand is large enough to fill the chip with such tiles (at least ~3/4 of a round of 256 workgroups) and the
     // strides fit its 32-bit tile-relative offsets; MSTTS_GEMM_BF16_BIG=0 / mstts_gemm_bf16_big(0) keeps the 128 x 128 kernel (A/B, tests)
     const long big_wgs = (long)cdiv(d->M, GX_BM) * cdiv(d->N, GX_BN) * batch * split;
-    static int big_min = -1;             // (measured: 180 workgroups of this kernel beat 720 of the small one by 1.3 x, 101 lose to 404 by 1.2 x)
-    if (big_min < 0) { const char* e = getenv("MSTTS_GEMM_BF16_BIG_MIN"); big_min = e ? atoi(e) : 160; }
-    const bool big = g_bf16_big && d->M >= 192 && d->N >= 192 && big_wgs >= big_min && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
+    const bool big = g_bf16_big && d->M >= 192 && d->N >= 192 && big_wgs >= g_bf16_big_min && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
                      (d->win_T <= 0 || (d->win_T >= GX_BK && d->win_C >= GX_BK)) && gemm_bf16_big_ready();
     if (big) {
         int kpsb = ((g.K + split - 1) / split + GX_BK - 1) / GX_BK * GX_BK;
@@ -596,13 +598,13 @@ extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) 
         return MSTTS_OK;
     }
     // The 128 x 128 kernel runs two workgroups per CU: 512 slots.  A contraction whose tile list is far from a multiple of that - the encoder's
-    // 4 096-row convolutions (128 tiles), the 80 / 84-column products (14 - 201 tiles) - is cut along K so that it fills one round: pieces of at
-    // least 128 contraction steps, cost model rounds x (K per piece + 300) x (1 + 2 % per piece for its atomics), fitted to a sweep of every
-    // such call of a train step (tools/gemm_split_sweep.py --config3: 0.31 ms per step against the callers' own cuts).  Only without a fused
-    // activation, for one batch, and not under mstts_gemm_deterministic; a caller's own cut (its output pre-zeroed or accumulated into) is re-chosen
-    // the same way, an uncut call without `accumulate` has its output cleared here first.
-    if (g_bf16_autocut < 0) { const char* e = getenv("MSTTS_GEMM_BF16_AUTOCUT"); g_bf16_autocut = !(e && e[0] == '0'); }
-    if (g_bf16_autocut && d->act == MSTTS_ACT_NONE && batch == 1 && !gemm_deterministic_now()) {
+    // 4 096-row convolutions (128 tiles), the 80 / 84-column products (14 - 201 tiles) - and whose caller asked for NO cut (split_k <= 1) is cut
+    // along K so that it fills one round: pieces of at least 128 contraction steps, cost model rounds x (K per piece + 300) x (1 + 2 % per piece
+    // for its atomics), fitted to a sweep of every such call of a train step (tools/gemm_split_sweep.py --config3: 0.31 ms per step against
+    // cuts chosen for the fp32 kernel's tiles).  Only without a fused activation, for one batch, and not under mstts_gemm_deterministic; without
+    // `accumulate` the output's N columns (not its row pitch: C may be a column band of a wider matrix) are cleared here first.  A caller's own
+    // split_k > 1 is honoured exactly - as mstts_gemm_f32 does - so a caller that reasons about the number of pieces (0 + p + q) gets that number.
+    if (g_bf16_autocut && split == 1 && d->act == MSTTS_ACT_NONE && batch == 1 && !gemm_deterministic_now()) {
         const long tiles = (long)cdiv(d->M, GB_BM) * cdiv(d->N, GB_BN);
         int best = 1;
         double best_cost = 0.0;
@@ -611,18 +613,16 @@ extern "C" int mstts_gemm_bf16(const mstts_gemm_desc* d, mstts_stream_t stream) 
             const double cost = (double)cdiv(tiles * sk, 512) * ((double)g.K / sk + 300.0) * (1.0 + 0.02 * sk);
             if (sk == 1 || cost < best_cost * 0.97) { best = sk; best_cost = cost; }      // (a cut has to win by 3 %)
         }
-        if (best != split) {
-            if (split == 1 && !d->accumulate && best > 1) {
+        if (best > 1) {
+            if (!d->accumulate) {
                 if (hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, st) != hipSuccess)
                     MSTTS_REQUIRE(false, MSTTS_ERR_LAUNCH, "gemm_bf16: clearing the output of a K-cut contraction failed");
             }
-            if (split > 1 || best > 1) {
-                split = (split > 1 && best == 1) ? split : best;          // (a caller's cut is never undone: a single piece would overwrite what it accumulates onto)
-                g.split_k = split;
-                kps = ((g.K + split - 1) / split + GB_BK - 1) / GB_BK * GB_BK;
-                if (kps < GB_BK) kps = GB_BK;
-                g.k_per_split = kps;
-            }
+            split = best;
+            g.split_k = split;
+            kps = ((g.K + split - 1) / split + GB_BK - 1) / GB_BK * GB_BK;
+            if (kps < GB_BK) kps = GB_BK;
+            g.k_per_split = kps;
         }
     }
     dim3 grid(cdiv(d->M, GB_BM) * cdiv(d->N, GB_BN), 1, batch * split);

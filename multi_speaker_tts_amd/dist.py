@@ -87,6 +87,16 @@ class GradAllReduce:
         self._trace_on = bool(trace) and grad_slab.is_cuda
         self._trace, self._probe = None, None
         self._side = None
+        # The keep-or-re-run decision of a backward pass (agree / agree_async) travels on its OWN communicator: on the gradient buckets' one it
+        # would queue behind every bucket of the pass (a communicator runs its collectives in issue order) and could not be read before the
+        # whole exchange has ended.  new_group is itself collective: every rank constructs its GradAllReduce at the same point.
+        self._flag_group, self.async_flag = None, False
+        if self.active:
+            import os
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_backend(group) == "nccl" and grad_slab.is_cuda and os.environ.get("MSTTS_ASYNC_AGREE", "1") != "0":
+                self._flag_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None)
+                self.async_flag = True
         if self.bf16 and self.active:
             import torch.distributed as dist
             self._nr = dist.get_world_size(group)                      # ranks in the exchange (1 in the forced one-rank form)
@@ -198,6 +208,16 @@ class GradAllReduce:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(flag.item()))
+
+    def agree_async(self, flag: torch.Tensor):
+        """The same decision without a host round trip: `flag` (int32[1] on the device, 1 = this rank's persistent launches of the pass ran to
+        their end; written by work already enqueued on the CURRENT stream) becomes the MINIMUM over the ranks, in place, ordered on the
+        current stream.  The caller runs this on a side stream right behind its launches' status words and reads the result together with
+        them at the pass's one host sync - by then the hoisted products are still running, so nothing waits for the exchange.
+        Only offered on RCCL (async_flag); every rank must call it once per pass, like agree()."""
+        import torch.distributed as dist
+        work = dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._flag_group, async_op=True)
+        work.wait()                          # (stream-level: the current stream waits for the collective, the host does not)
 
     def first_piece_trace(self, reference_event):
         """(ms from `reference_event` to the announcement of the step's first range, ms from `reference_event` to the end of that range's

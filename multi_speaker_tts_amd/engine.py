@@ -176,9 +176,9 @@ class TrainEngine:
         if self.persist_enc:
             n = int(lb.mstts_persist_lstm_pack_floats())
             self.enc_pk = {dr: (self._f(n), self._f(n)) for dr in ("fw", "bw")}          # (forward order, BPTT order)
-        if self.persist or self.persist_enc:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._enc_stream = torch.cuda.Stream(device=self.device)          # the encoder's persistent BPTT (loss_and_backward)
+        if self.device.type == "cuda":
+            self._side = torch.cuda.Stream(device=self.device)                # status words -> pinned host memory, the job-wide verdict's exchange
+            self._enc_stream = torch.cuda.Stream(device=self.device)          # the encoder's persistent launches (forward / loss_and_backward)
         if self.persist_bwd:
             self.pkb = [self._f(int(lb.mstts_persist_bwd_pack_floats(i))) for i in range(3)]
         self.flip = {}
@@ -214,7 +214,15 @@ class TrainEngine:
         statistics side effect) in fp32 in either mode."""
         bf = self.gemm_dtype == "bf16" and not exact
         if k.get("split_k", 1) > 1 and self.big_tiles:       # (the split was chosen for 128 x 128 tiles; the large contractions run 256 x 256 ones)
-            k["split_k"] = max(2, _split_k_big(a[3], a[4], a[5], k["split_k"]))
+            big = _split_k_big(a[3], a[4], a[5], None)
+            if big is not None:
+                k["split_k"] = max(2, big)
+            elif bf:
+                # config 3, a product the 256 x 256-tile kernel does not take: mstts_gemm_bf16 honours a caller's cut exactly, and the cut above was
+                # chosen for the fp32 kernel's one-workgroup-per-CU tiles - hand the product over uncut and let the library cut it for its own
+                # (two workgroups per CU).  It adds its pieces onto the output, which every caller of a cut product has zeroed (the gradient slab,
+                # dw0f, dwp_pad) or accumulates into.
+                k["split_k"], k["accumulate"] = 1, True
         return gemm(*a, bf16=bf, **k)
 
     def P(self, name):
@@ -640,6 +648,9 @@ class TrainEngine:
         end of the pass."""
         extra = (ptr(w.enc_hist),) if which == 0 else (ptr(w.enc_hist), ptr(w.enc_bws))
         call(entry, C.byref(seqs[0]), C.byref(seqs[1]), ptr(self.enc_pk["fw"][which]), ptr(self.enc_pk["bw"][which]), ptr(w.enc_xch), ptr(w.enc_ctrl), *extra)
+        if getattr(self, "persist_enc_selftest", 0):              # tests: this encoder launch "gave up" - on the DEVICE, where the job-wide verdict reads it too
+            self.persist_enc_selftest -= 1
+            w.enc_ctrl[1:2].fill_(3)
         ev = torch.cuda.Event()
         ev.record()
         host = w.enc_ctrl_host if which == 0 else w.enc_ctrl_host_b
@@ -654,9 +665,6 @@ class TrainEngine:
         """True when the encoder launch of the ticket ran to its end (False: the caller re-runs the pass with the launch-per-step pair)."""
         done, host, n_wg = ticket
         done.synchronize()
-        if getattr(self, "persist_enc_selftest", 0):              # tests: pretend the next encoder launch gave up
-            self.persist_enc_selftest -= 1
-            host[1] = 3
         if int(host[1]) != 0 or int(host[2]) != n_wg:
             self.persist_enc_fallbacks += 1
             self._step_fell_back = True
@@ -740,7 +748,7 @@ class TrainEngine:
         self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.bn_ws)
 
     # ------------------------------------------------------------------ loss + backward
-    def loss_and_backward(self, w, grad_scale=1.0, on_ready=None, on_abort=None, agree=None, _redo=False):
+    def loss_and_backward(self, w, grad_scale=1.0, on_ready=None, on_abort=None, agree=None, agree_async=None, _redo=False):
         """Loss and backward pass.  Like forward(): the persistent launches (decoder BPTT, encoder BPTT) are enqueued without waiting for their
         control words, which are read once at the end of the pass; if either gave up the whole pass is run again with the launch-per-step
         loops (it starts by clearing the gradient slab).  on_abort: called before that re-run (train_step: wait for the collectives that the
@@ -749,7 +757,11 @@ class TrainEngine:
         on_ready started have already mixed this pass's gradients into every rank's slab, so keeping or re-running the pass must be ONE
         decision of the whole job: either every rank keeps its pass, or every rank drains (on_abort) and runs the pass again - each rank
         then issues the same sequence of collectives, and a rank whose own launches were healthy throws away the junk a peer contributed
-        (`collective_redos` counts the passes re-run because a PEER's launch gave up)."""
+        (`collective_redos` counts the passes re-run because a PEER's launch gave up).
+        agree_async: the same decision without a host round trip (GradAllReduce.agree_async, RCCL only): callable(flag) that turns the int32
+        device word `flag` into its minimum over the ranks, in place, on the current stream.  The word is formed on the side stream from the
+        launches' control words (mstts_persist_status) right behind them, exchanged on its own communicator and read - with the control
+        words - at the pass's one host sync, which therefore still falls while the hoisted products run.  Takes precedence over `agree`."""
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
@@ -944,6 +956,21 @@ class TrainEngine:
         if on_ready is not None:
             on_ready(*self._grad_range("encoder/"))
         # ---- the status words of this pass's persistent launches: ONE host sync (the side stream runs in order)
+        job_flag = None
+        if agree_async is not None and not _redo:
+            # every rank, every pass (also one that launched nothing persistent: its word is 1) - the ranks' collective sequences stay in step
+            if getattr(w, "job_flag", None) is None:
+                w.job_flag = torch.ones(1, dtype=torch.int32, device=self.device)
+                w.job_flag_host = torch.ones(1, dtype=torch.int32).pin_memory()
+            with torch.cuda.stream(self._side):
+                if enc_ticket is None and bwd_done is None:      # (nothing of this pass is on the side stream yet: order it behind the pass so far)
+                    self._side.wait_stream(torch.cuda.current_stream())
+                call("mstts_persist_status", ptr(w.pctrl_b) if bwd_done is not None else None, 256,
+                     ptr(w.enc_ctrl) if enc_ticket is not None else None, enc_ticket[2] if enc_ticket is not None else 0, ptr(w.job_flag))
+                agree_async(w.job_flag)
+                w.job_flag_host.copy_(w.job_flag, non_blocking=True)
+                job_flag = torch.cuda.Event()
+                job_flag.record()
         passed = True
         if enc_ticket is not None:
             passed = self._enc_check(w, enc_ticket)
@@ -956,12 +983,19 @@ class TrainEngine:
                 self._step_fell_back = True
                 self.persist_last_status = (int(st[0]), int(st[1]), int(st[2]))
                 passed = False
-        passed = self._pass_verdict(passed, agree, _redo)
+        if job_flag is not None:
+            job_flag.synchronize()
+            job_ok = int(w.job_flag_host[0]) == 1            # MIN over the ranks of what mstts_persist_status saw on each
+            if passed and not job_ok:
+                self.collective_redos += 1
+            passed = passed and job_ok
+        else:
+            passed = self._pass_verdict(passed, agree, _redo)
         if not passed:
             if on_abort is not None:
                 on_abort()
             torch.cuda.current_stream().synchronize()
-            return self.loss_and_backward(w, grad_scale=grad_scale, on_ready=on_ready, on_abort=on_abort, agree=agree, _redo=True)
+            return self.loss_and_backward(w, grad_scale=grad_scale, on_ready=on_ready, on_abort=on_abort, agree=agree, agree_async=agree_async, _redo=True)
 
     def _pass_verdict(self, passed, agree, redo):
         """Keep this backward pass or run it again?  With `agree` (data parallel) the answer is the job's, not the rank's: the minimum of
@@ -1086,7 +1120,7 @@ class TrainEngine:
         if all_reduce is not None:           # bucketed in the order gradients become final (postnet -> decoder/attention -> encoder),
             g = self.params.grad             # each bucket's all-reduce running under the rest of the backward pass
             self.loss_and_backward(w, on_ready=lambda lo, hi: all_reduce.start(g, lo, hi), on_abort=lambda: all_reduce.finish(g),
-                                   agree=all_reduce.agree)
+                                   agree=all_reduce.agree, agree_async=all_reduce.agree_async if getattr(all_reduce, "async_flag", False) else None)
             all_reduce.finish(g)
         else:
             self.loss_and_backward(w)

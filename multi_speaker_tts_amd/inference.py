@@ -48,18 +48,24 @@ def to_host(tensors):
 class _DeferredCheck:
     """Ticket of a sub-graph whose persistent LSTM launches have not been checked yet (InferEngine.speaker_embedding(defer=True))."""
 
-    def __init__(self, eng, fn, a, k, pending, event):
-        self.eng, self.fn, self.a, self.k, self.pending, self.event = eng, fn, a, k, pending, event
+    def __init__(self, eng, fn, a, k, pending, event, host):
+        self.eng, self.fn, self.a, self.k, self.pending, self.event, self.host = eng, fn, a, k, pending, event, host
 
     def ok(self):
-        """After (or as) the caller's host sync: did every launch of the sub-graph run to its end?"""
+        """After (or as) the caller's host sync: did every launch of the sub-graph run to its end?  The ticket owns its page-locked read-back
+        block (a second deferred call before this one is redeemed - batch prefetch - reads back into ANOTHER block); it goes back to the
+        engine's pool here."""
         self.event.synchronize()
-        eng = self.eng
+        eng, host = self.eng, self.host
+        if host is None:
+            raise RuntimeError("a deferred check is redeemed once")
+        good = all(int(host[slot][1]) == 0 and int(host[slot][2]) == n_wg for slot, n_wg in self.pending)
+        self.host = None
+        eng._deferred_host_pool.append(host)
         if eng.persist_lstm_selftest > 0:
             eng.persist_lstm_selftest -= 1
             return False
-        host = eng._lstm_ctrl_host_deferred
-        return all(int(host[slot][1]) == 0 and int(host[slot][2]) == n_wg for slot, n_wg in self.pending)
+        return good
 
     def redo(self):
         """The sub-graph again, launch by launch (same stream); returns its output."""
@@ -278,12 +284,14 @@ class InferEngine:
         pending = list(self._lstm_pending)
         if not pending:
             return out, None
-        if getattr(self, "_lstm_ctrl_host_deferred", None) is None:
-            self._lstm_ctrl_host_deferred = torch.zeros(64, 16, dtype=torch.int32).pin_memory()
-        self._lstm_ctrl_host_deferred.copy_(self._lstm_ctrl, non_blocking=True)
+        # one page-locked read-back block PER TICKET (pooled: page-locking is a system call): the copy below is ordered behind this call's launches
+        # and in front of the next call's, which reuse the device slots from 0 - tickets may be outstanding together
+        pool = self.__dict__.setdefault("_deferred_host_pool", [])
+        host = pool.pop() if pool else torch.zeros(64, 16, dtype=torch.int32).pin_memory()
+        host.copy_(self._lstm_ctrl, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return out, _DeferredCheck(self, fn, a, k, pending, ev)
+        return out, _DeferredCheck(self, fn, a, k, pending, ev, host)
 
     def encoder(self, token, token_length, spk):
         return self._guarded(self._encoder, token, token_length, spk)

@@ -125,6 +125,9 @@ SIGNATURES = {
     "mstts_gemm_split3": (i32, [i32]),
     "mstts_gemm_deterministic": (i32, [i32]),
     "mstts_gemm_split_big": (i32, [i32]),
+    "mstts_gemm_big_min_workgroups": (i32, [i32, i32]),
+    "mstts_gemm_bf16_autocut": (i32, [i32]),
+    "mstts_persist_status": (i32, [vp, i32, vp, i32, vp, vp]),
     "mstts_gemm_bf16": (i32, [P(GemmDesc), vp]),
     "mstts_gemm_bf16_big": (i32, [i32]),
     "mstts_philox_keep_mask": (i32, [vp, i64, u64, u32, f32, vp]),
@@ -306,8 +309,19 @@ def load():
     if lib.mstts_abi_version() != ABI_VERSION:     # descriptor layouts are not visible to the symbol check above
         raise MsttsError("libmstts_hip.so reports ABI version %d, this binding is written for %d: rebuild the library (python -m multi_speaker_tts_amd.build --force)"
                          % (lib.mstts_abi_version(), ABI_VERSION))
-    if os.environ.get("MSTTS_GEMM_SPLIT3", "1") == "0":      # A/B switch: every fp32 contraction on the f32-input MFMA (see mstts_gemm_split3)
+    # Development switches (A/B runs): the library itself reads no environment variable (include/mstts.h), this binding maps them onto
+    # the process-global setters once, here.
+    env = os.environ.get
+    if env("MSTTS_GEMM_SPLIT3", "1") == "0":         # every fp32 contraction on the f32-input MFMA (see mstts_gemm_split3)
         lib.mstts_gemm_split3(0)
+    if env("MSTTS_GEMM_SPLIT_BIG", "1") == "0":      # no 256 x 256-tile split kernel
+        lib.mstts_gemm_split_big(0)
+    if env("MSTTS_GEMM_BF16_BIG", "1") == "0":
+        lib.mstts_gemm_bf16_big(0)
+    if env("MSTTS_GEMM_BF16_AUTOCUT", "1") == "0":
+        lib.mstts_gemm_bf16_autocut(0)
+    if env("MSTTS_GEMM_SPLIT_BIG_MIN") or env("MSTTS_GEMM_BF16_BIG_MIN"):
+        lib.mstts_gemm_big_min_workgroups(int(env("MSTTS_GEMM_SPLIT_BIG_MIN", "0")), int(env("MSTTS_GEMM_BF16_BIG_MIN", "0")))
     _lib = lib
     return lib
 

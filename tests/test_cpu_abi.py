@@ -38,6 +38,23 @@ def test_library_exports_every_declared_symbol():
     assert cdll.mstts_skinny_bwd_splits(1792, 4096) == 8
 
 
+def test_library_reads_no_environment_variable():
+    """include/mstts.h: "the library reads NO environment variable" - the development switches are setters (mstts_gemm_*), and the Python
+    binding maps its MSTTS_GEMM_* variables onto them in lib.load().  Every source the library is compiled from is searched."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "multi_speaker_tts_amd", "csrc")
+    hits = []
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.inc"))):
+        for n, line in enumerate(open(f), 1):
+            if re.search(r"\b(secure_)?getenv\s*\(", line):
+                hits.append("%s:%d" % (os.path.basename(f), n))
+    assert not hits, hits
+    from multi_speaker_tts_amd import lib
+    for setter in ("mstts_gemm_split3", "mstts_gemm_split_big", "mstts_gemm_bf16_big", "mstts_gemm_bf16_autocut", "mstts_gemm_big_min_workgroups", "mstts_gemm_tail_split"):
+        assert setter in lib.SIGNATURES
+
+
 def test_struct_layouts_match_header_sizes():
     """ctypes.Structure sizes == sizeof in C (compiled with the same header)."""
     import subprocess, tempfile

@@ -186,3 +186,39 @@ def test_the_redo_decision_is_collective():
             assert np.array_equal(o, np.full(3000, 3.0 * (step + 1), np.float32)), (r, step, o[:4])
     assert res[0][1] == 1 and res[1][1] == 0
     assert res[0][2] == res[1][2] and res[0][2].count(("drain", 1)) == 1 and len([e for e in res[0][2] if e[0] == "start"]) == 12
+
+
+_DYING_RANK = r"""
+import os, sys, time
+import torch.distributed as dist
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+dist.barrier()
+if rank == 1:
+    os._exit(7)                    # dies between two collectives, without telling anybody
+import torch
+t = torch.ones(4)
+dist.all_reduce(t)                 # rank 0 now waits for a peer that will never come (gloo: 30 minutes)
+time.sleep(600)
+"""
+
+
+def test_launcher_stops_the_job_when_a_rank_dies():
+    """bench.py's own launcher used to wait() for the ranks in order - one rank dying in init_process_group or falling
+    out of a collective left the others blocked until the driver's time-out, and the one scaling run produced nothing.  Now all ranks are
+    polled; the first non-zero exit stops the rest and becomes the launcher's exit code, within seconds."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    t0 = time.monotonic()
+    try:
+        bench.self_launch(2, cmd=[sys.executable, "-c", _DYING_RANK], grace_s=3.0)
+        code = 0
+    except SystemExit as e:
+        code = e.code
+    took = time.monotonic() - t0
+    assert code == 7, code
+    assert took < 15.0, took                      # (import torch + gloo rendezvous of the two children are ~5 s of it; the stop itself is < 4 s)
+    # ... and a healthy job returns 0
+    ok = "import os, sys; sys.exit(0)"
+    assert bench.self_launch(2, cmd=[sys.executable, "-c", ok]) == 0

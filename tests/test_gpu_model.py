@@ -8,7 +8,7 @@ import torch
 
 from multi_speaker_tts_amd import lib
 from multi_speaker_tts_amd.engine import TrainEngine
-from multi_speaker_tts_amd.params import LSA
+from multi_speaker_tts_amd.params import LSA, Dims
 from oracle import model as OM, train as OT, audio as OA
 from tests.helpers import dims_pair, rel_err, t2n, to_dev
 
@@ -1098,3 +1098,48 @@ def test_inference_results_own_their_host_blocks(dev):
     del r2
     r3 = to_host({"a": a})                       # (may reuse r2's block - never r1's, which is still held)
     assert np.array_equal(r1["a"], keep) and not np.shares_memory(r1["a"], r3["a"])
+
+
+def test_mel_to_spectrogram_reference_widths(dev):
+    """VERDICT r5 missing #3 / weak #3: the mel -> spectrogram network (Taco1_Mel_to_Spect/Modules.py:8-105 as wired at MSTTS_SV.py:100-115)
+    and the speaker encoder (Speaker_Embedding/Modules.py:6-37,127-137) had oracle checks at reduced widths only; at the reference's
+    widths the only tests compared the engine with itself.  Here: EVERY width is the reference's (conv bank 8 x 128 -> max-pool -> 1024 -> 256
+    -> 80, residual, highway 4 x 80, BiRNN 2 x 128, dense 1025; speaker stack dense 256 + 3 x LSTM 256 with residual wrappers on cells 0 / 1),
+    at BASELINE configs[3]'s size - batch 16 x 401 frames and 5 x 16 speaker windows of 64 frames - against the fp64 oracle, tolerance 1e-3
+    (north_star), persistent recurrences asserted to have run (Q13: no length masking in the BiRNN; Q14: whole-tensor l2 normalisation)."""
+    from multi_speaker_tts_amd.inference import InferEngine
+    pd, od = Dims(), OM.Dims()
+    assert (od.bank_k, od.bank_ch, od.proj1_ch, od.n_mel, od.highway_n, od.birnn, od.n_spec, od.spk_lstm, od.spk_lstm_n, od.spk) == (8, 128, 256, 80, 4, 128, 1025, 256, 3, 256)
+    values = OM.init_params(od, 41)
+    g = np.random.default_rng(17)
+    for k in values:                       # trained-like statistics: moving moments away from (0, 1), non-zero biases
+        if not k.startswith(("mel_to_spectrogram", "speaker_embedding")):
+            continue
+        if k.endswith("moving_mean"):
+            values[k] = g.normal(0, 0.2, values[k].shape)
+        if k.endswith("moving_variance"):
+            values[k] = 0.5 + np.abs(g.normal(0, 0.5, values[k].shape))
+        if k.endswith(("bias", "beta")) and "highway" not in k:
+            values[k] = g.normal(0, 0.1, values[k].shape)
+    B, S = 16, 401
+    mel = np.clip(g.normal(0, 1.5, (B, S, od.n_mel)), -4, 4).astype(np.float32)
+    spk_mel = np.clip(g.normal(0, 1.5, (B * od.spk_samples, od.spk_frames, od.n_mel)), -4, 4).astype(np.float32)
+    p64 = OM.to_torch({k: v for k, v in values.items() if k.startswith(("mel_to_spectrogram", "speaker_embedding"))})
+    with torch.no_grad():
+        ref_spec = OM.taco1_forward(p64, od, torch.tensor(mel, dtype=torch.float64), False).numpy()
+        ref_emb = OM.speaker_encoder(p64, od, torch.tensor(spk_mel, dtype=torch.float64), False).numpy()
+    eng = InferEngine(pd, device=dev, values=values)
+    n0 = eng.persist_lstm_launches
+    spec = t2n(eng.mel_to_spectrogram(torch.tensor(mel, device=dev).view(B * S, od.n_mel), B, S))
+    emb = t2n(eng.speaker_embedding(torch.tensor(spk_mel, device=dev)))
+    assert spec.shape == (B, S, od.n_spec) and emb.shape == (B, od.spk)
+    e_spec, e_emb = rel_err(spec, ref_spec), rel_err(emb, ref_emb)
+    # per-frame check as well: the BiRNN's backward direction starts at the LAST frame, the forward one at the first - both ends must hold
+    e_ends = max(rel_err(spec[:, :3], ref_spec[:, :3]), rel_err(spec[:, -3:], ref_spec[:, -3:]))
+    print("taco1 @ reference widths: spectrogram %.2e (ends %.2e), speaker embedding %.2e, persistent LSTM launches %d, fallbacks %d"
+          % (e_spec, e_ends, e_emb, eng.persist_lstm_launches - n0, eng.persist_lstm_fallbacks))
+    assert e_spec < 1e-3 and e_ends < 1e-3, (e_spec, e_ends)
+    assert e_emb < 1e-3, e_emb
+    assert abs(float(np.sqrt((emb.astype(np.float64) ** 2).sum())) - 1.0) < 1e-5          # Q14: the WHOLE [B, 256] tensor has unit norm
+    if lib.load().mstts_persist_lstm_fwd_supported_n(B, pd.birnn, 2):
+        assert eng.persist_lstm_launches - n0 == 1 + pd.spk_lstm_n and eng.persist_lstm_fallbacks == 0

@@ -423,3 +423,26 @@ def test_inference_after_a_trainer_step_sees_the_new_kernels(dev):
     plain = t2n(inf.speaker_embedding(mel)).copy()
     assert rel_err(after, plain) < 1e-4, rel_err(after, plain)
     assert rel_err(after, before) > 1e-4                               # the step really moved the variables
+
+
+def test_two_deferred_tickets_outstanding_together(dev):
+    """every deferred ticket used to share ONE page-locked read-back block and slot numbering restarts at 0 per call, so a second
+    speaker_embedding(defer=True) before the first ticket was redeemed (batch prefetch) overwrote the words the first ticket reads.  Now a
+    ticket owns its block: the first call's launch is made to fail ON THE DEVICE (its control words overwritten behind it), the second is
+    healthy, and each ticket reports its own launches."""
+    eng, pd, od, values, mel = _spk_setup(dev, B=4)
+    emb1, t1 = eng.speaker_embedding(mel, defer=True)
+    assert t1 is not None and len(t1.pending) >= 1
+    torch.cuda.synchronize()
+    # call 1's read-back has landed in ITS block; now damage that block the way a launch that gave up would have: abort code 3
+    t1.host[t1.pending[0][0]][1] = 3
+    emb2, t2 = eng.speaker_embedding(mel, defer=True)                  # reuses device slots 0.., reads back into ANOTHER block
+    assert t2 is not None and t2.host is not t1.host
+    assert t2.ok() is True                                             # the healthy call is not blamed for the first one's words
+    assert t1.ok() is False                                            # ... and the failed one is not absolved by the second one's
+    with pytest.raises(RuntimeError):
+        t1.ok()                                                        # a ticket is redeemed once
+    assert len(eng._deferred_host_pool) == 2
+    emb3, t3 = eng.speaker_embedding(mel, defer=True)                  # blocks are pooled, not re-allocated
+    assert t3.host is t1.host or t3.host is t2.host
+    assert t3.ok() and np.array_equal(t2n(emb3), t2n(emb2))

@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-surface", action="store_true", help="skip the supplementary Tacotron2.Train_Step-through-the-Feeder measurement (train_surface)")
     ap.add_argument("--no-overlap", action="store_true", help="gradient all-reduce behind the backward pass instead of overlapped with it (A/B switch)")
     ap.add_argument("--cpu-budget", type=float, default=0.0, help="seconds for the host baseline; 0 = the full protocol (1 warm-up + 3 timed full steps)")
     ap.add_argument("--frames", type=int, default=L_MEL, help=argparse.SUPPRESS)
@@ -609,6 +610,19 @@ def main():
         out["kernel_avg_us"] = {k: v["avg_us"] for k, v in allk.items()}
         out["step_flops_fraction_of_fp32_mfma_peak"] = (4.047e12 * L / L_MEL) / (ms_per_step * 1e-3) / 157.3e12
         out["hoisted_contractions"] = contraction_replay(eng, batch, w, args.config3)
+
+    if rank == 0 and world == 1 and headline_batch and not args.config3 and not args.no_surface and not args.no_roofline:
+        # Supplementary, never the headline: the reference's user trains through Tacotron2.Train() on length-bucketed batches of a different
+        # shape every step (Feeder.py:111-124, MSTTS_SV.py:266-273).  50 such steps through the real Feeder and the drop-in class, beside the
+        # same batches device-resident through the engine (tools/train_surface_bench.py).
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import train_surface_bench
+            del eng, batch
+            torch.cuda.empty_cache()
+            out["train_surface"] = train_surface_bench.run(steps=50, warmup=3, device=str(device))
+        except Exception as e:          # (a supplementary leg must not cost the run its headline line)
+            out["train_surface"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)

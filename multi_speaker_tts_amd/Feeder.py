@@ -300,6 +300,12 @@ class Feeder:
                     print("Pattern producer stopped: {}".format(e))
                     return
 
+    def Unget_Train_Pattern(self, pattern, is_Pre_Train=False):
+        """Put a pattern taken ahead of time back at the head of its queue (the driver prefetched it for a step that then asked for the
+        other queue: the switch from pre-training to main training, MSTTS_SV.py:268-269)."""
+        if self.pattern_Queue is not None:
+            (self.pre_Pattern_Queue if is_Pre_Train else self.pattern_Queue).appendleft(pattern)
+
     def close(self):
         """Stop the producer threads (the reference's daemon threads die with the process)."""
         self._stop = True
@@ -327,14 +333,17 @@ class Feeder:
             "Speaker_Embedding_Mel": speaker_windows(speaker_Mel_List),
         }
 
-    def Get_Train_Pattern(self, is_Pre_Train=False, batch_Size=None, token_Length=128, mel_Length=800, seed=1234):
+    def Get_Train_Pattern(self, is_Pre_Train=False, batch_Size=None, token_Length=128, mel_Length=800, seed=1234, block=True):
         """Feeder.py:174-184 when pattern files exist (blocks until the producer has a batch); otherwise the synthetic
-        pattern of the benchmark shape."""
+        pattern of the benchmark shape.  block=False: None instead of waiting when the producer's queue is empty (the driver's
+        prefetch of the NEXT step's batch must not stall the step that is running)."""
         if self.pattern_Queue is not None and batch_Size is None:
             import time
             if is_Pre_Train and not hasattr(self, "pre_Pattern_Queue"):
                 raise RuntimeError("pre-train patterns requested but hp.Train.Use_Pre_in_Main_Train is off")
             queue = self.pre_Pattern_Queue if is_Pre_Train else self.pattern_Queue
+            if not block and len(queue) == 0:
+                return None
             while len(queue) == 0:
                 if is_Pre_Train in self._producer_error:
                     raise RuntimeError("training pattern producer stopped: " + self._producer_error[is_Pre_Train])

@@ -24,6 +24,117 @@ TRAIN_KEYS = ("Global_Step", "Learning_Rate", "Loss", "Linear_Loss", "Postnet_Lo
 INFERENCE_KEYS = ("Global_Step", "Linear", "Mel", "Stop", "Attention_History", "Spectrogram")
 
 
+class StepResult(dict):
+    """What Train_Step returns: the reference's train_Tensor_Dict results (MSTTS_SV.py:194-203,270-273).  Global_Step and Learning_Rate are
+    known on the host; the four loss words are still on their way from the device when the step's launches have been enqueued, and reading
+    them there would drain the device between two steps.  They are fetched on FIRST ACCESS of any loss key (or of the dict as a whole):
+    Tacotron2.Train touches step k's losses after step k + 1 has been enqueued - same log line, one step later; a caller that reads
+    them at once simply waits for the step, as with tf.Session.run."""
+    LOSS_KEYS = ("Loss", "Linear_Loss", "Postnet_Loss", "Stop_Loss", "Weight_Regularization_Loss")
+
+    def __init__(self, known, handle):
+        super().__init__(known)
+        self._handle = handle
+
+    def _fill(self):
+        if self._handle is not None:
+            h, self._handle = self._handle, None
+            res = h.get()
+            super().update(res)
+            if not np.isfinite(res["Loss"]):
+                raise FloatingPointError("non-finite loss at global step %d: %r" % (super().__getitem__("Global_Step"), res))
+
+    def __getitem__(self, k):
+        if k in self.LOSS_KEYS:
+            self._fill()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        if k in self.LOSS_KEYS:
+            self._fill()
+        return super().get(k, default)
+
+    def __contains__(self, k):
+        return k in self.LOSS_KEYS or super().__contains__(k)
+
+    def keys(self):
+        self._fill(); return super().keys()
+
+    def values(self):
+        self._fill(); return super().values()
+
+    def items(self):
+        self._fill(); return super().items()
+
+    def __iter__(self):
+        self._fill(); return super().__iter__()
+
+    def __len__(self):
+        self._fill(); return super().__len__()
+
+    def __repr__(self):
+        self._fill(); return super().__repr__()
+
+    def copy(self):
+        self._fill(); return dict(self)
+
+
+class _BatchUploader:
+    """Host -> device path of a training pattern (MSTTS_SV.py:270-273 feeds numpy arrays through feed_dict): page-locked staging blocks and
+    device blocks, two of each in rotation and sized for the largest pattern seen (grown, never shrunk), the copies on their own stream.
+    Tacotron2.Train_Step stages the NEXT pattern right after it has enqueued the current step, so the 8 MB of a batch cross PCIe under the
+    step's tail instead of in front of the next step; nothing is allocated per step."""
+    FIELDS = (("Token", np.int32), ("Token_Length", np.int32), ("Mel", np.float32), ("Mel_Length", np.int32),
+              ("Speaker_Embedding", np.float32), ("Speaker_Embedding_Mel", np.float32))
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.slots = [{"host": {}, "dev": {}, "uploaded": None, "released": None} for _ in range(2)]
+        self.next = 0
+
+    def _block(self, slot, name, n, np_dtype):
+        h = slot["host"].get(name)
+        if h is None or h.numel() < n:
+            cap = max(n, int(1.25 * h.numel()) if h is not None else n)
+            tdt = torch.from_numpy(np.zeros(1, np_dtype)).dtype
+            slot["host"][name] = torch.zeros(cap, dtype=tdt).pin_memory()
+            slot["dev"][name] = torch.zeros(cap, dtype=tdt, device=self.device)
+        return slot["host"][name], slot["dev"][name]
+
+    def stage(self, pattern):
+        """Copy the pattern's arrays into a slot's page-locked blocks and enqueue their upload on the copy stream.  Returns the batch
+        (device views + the event `uploaded`); the consumer's stream must wait for that event, and calls release(batch) when it has
+        enqueued its last read."""
+        slot = self.slots[self.next]
+        self.next ^= 1
+        if slot["uploaded"] is not None:
+            slot["uploaded"].synchronize()                   # (its previous upload has left the page-locked blocks - two steps ago)
+        batch, todo = {}, []
+        for name, np_dtype in self.FIELDS:
+            if name not in pattern:
+                continue
+            a = np.ascontiguousarray(pattern[name], dtype=np_dtype)
+            h, dv = self._block(slot, name, a.size, np_dtype)
+            h[:a.size].view(a.shape).numpy()[...] = a
+            todo.append((h, dv, a.size))
+            batch[name] = dv[:a.size].view(a.shape)
+        with torch.cuda.stream(self.stream):
+            if slot["released"] is not None:
+                self.stream.wait_event(slot["released"])     # the step that read this slot's device blocks last has finished with them
+            for h, dv, n in todo:
+                dv[:n].copy_(h[:n], non_blocking=True)
+            slot["uploaded"] = torch.cuda.Event()
+            slot["uploaded"].record()
+        batch["_uploaded"], batch["_slot"] = slot["uploaded"], slot
+        return batch
+
+    def release(self, batch):
+        ev = torch.cuda.Event()
+        ev.record()
+        batch["_slot"]["released"] = ev
+
+
 class Tacotron2:
     def __init__(self, is_Training=False, device="cuda", seed=1234, dims: Dims = None, allow_random_init=False):
         """allow_random_init: the reference REQUIRES trained speaker-encoder and vocoder checkpoints and raises ValueError
@@ -44,7 +155,12 @@ class Tacotron2:
             _dist.init_process_group(device=device)
         self.device = device
         self.feeder = _Feeder.Feeder(is_Training=is_Training, device=device, rank=self.rank, world=self.world)
-        self.train_engine = TrainEngine(dims, device=device, seed=seed, rank=self.rank, world=self.world)
+        # the workspace arena is sized once for the largest batch the feeder can produce: hp.Train.Batch_Size rows, as many frames as
+        # Use_Wav_Length_Range allows, and the persistent decoder kernels' 256 encoder positions (longer texts grow it on demand)
+        hint = (int(hp.Train.Batch_Size), 256, int(hp.Train.Use_Wav_Length_Range[1] / hp.Sound.Frame_Shift) + 1) if is_Training else None
+        self.train_engine = TrainEngine(dims, device=device, seed=seed, rank=self.rank, world=self.world, arena_hint=hint)
+        self._uploader = None
+        self._prefetched = None              # (is_Pre_Train, pattern, staged batch) taken ahead for the next Train_Step
         self.params = self.train_engine.params
         self.infer_engine = InferEngine(self.train_engine.d, device=device, seed=seed, params=self.params)
         self.train_Tensor_Dict = {k: k for k in TRAIN_KEYS} if is_Training else None
@@ -192,17 +308,22 @@ class Tacotron2:
             os.remove(os.path.join(d, "CHECKPOINT-%d.pt" % s))
 
     # ---- training (MSTTS_SV.py:253-293)
-    def _to_device_batch(self, pattern):
+    def _to_device_batch(self, pattern, staged=None):
+        """Pattern (numpy, Feeder.py:132-172) -> device batch.  The arrays travel through page-locked staging blocks on the copy stream
+        (_BatchUploader; `staged`: already on their way); the compute stream waits for the upload, not the host."""
         dev = torch.device(self.device)
-        t = lambda a, dt: torch.as_tensor(np.asarray(a)).to(dev, dt).contiguous()
-        batch = {"Token": t(pattern["Token"], torch.int32), "Token_Length": t(pattern["Token_Length"], torch.int32),
-                 "Mel": t(pattern["Mel"], torch.float32), "Mel_Length": t(pattern["Mel_Length"], torch.int32)}
-        if "Speaker_Embedding" in pattern:
-            batch["Speaker_Embedding"] = t(pattern["Speaker_Embedding"], torch.float32)
+        if self._uploader is None:
+            self._uploader = _BatchUploader(dev)
+        up = staged if staged is not None else self._uploader.stage(pattern)
+        torch.cuda.current_stream(dev).wait_event(up["_uploaded"])
+        batch = {k: up[k] for k in ("Token", "Token_Length", "Mel", "Mel_Length")}
+        batch["_upload"] = up
+        if "Speaker_Embedding" in up:
+            batch["Speaker_Embedding"] = up["Speaker_Embedding"]
         else:   # frozen speaker encoder forward (MSTTS_SV.py:49-56) with TRAINING-mode zoneout: Is_Training is fed to this stack too
             from .masks import MaskSet, step_seed
             self.infer_engine._keep = []
-            mel = t(pattern["Speaker_Embedding_Mel"], torch.float32)
+            mel = up["Speaker_Embedding_Mel"]
             nb = int(mel.shape[0])
             if getattr(self, "_spk_masks_nb", None) != nb:
                 self._spk_masks = MaskSet(self.train_engine.d, 1, 1, 1, True, dev, rank=self.rank, speaker_windows=nb)
@@ -215,16 +336,38 @@ class Tacotron2:
                 batch["_speaker_ticket"] = ticket
         return batch
 
+    def _prefetch(self, is_Pre_Train):
+        """Take the NEXT pattern from the feeder if it has one ready and start its upload (called right after a step's launches have been
+        enqueued: the copy runs under the step's tail)."""
+        if self._prefetched is not None or self.feeder.pattern_Queue is None:
+            return
+        pattern = self.feeder.Get_Train_Pattern(is_Pre_Train=is_Pre_Train, block=False)
+        if pattern is not None:
+            self._prefetched = (is_Pre_Train, pattern, self._uploader.stage(pattern))
+
     def Train_Step(self, pattern=None, is_Pre_Train=False):
-        """One iteration of the reference's `while True` body (MSTTS_SV.py:268-273); returns the train_Tensor_Dict results.  In
-        a data-parallel job the gradients are all-reduced inside the step and the returned losses are the mean over the ranks."""
-        pattern = pattern or self.feeder.Get_Train_Pattern(is_Pre_Train=is_Pre_Train)
+        """One iteration of the reference's `while True` body (MSTTS_SV.py:268-273); returns the train_Tensor_Dict results (StepResult: the
+        losses are fetched when first read).  In a data-parallel job the gradients are all-reduced inside the step and the returned
+        losses are the mean over the ranks."""
+        staged = None
+        if pattern is None:
+            if self._prefetched is not None:
+                pre, p, up = self._prefetched
+                self._prefetched = None
+                if pre == is_Pre_Train:
+                    pattern, staged = p, up
+                else:                        # the step asks for the other queue (pre-training -> main training): hand the pattern back
+                    self.feeder.Unget_Train_Pattern(p, is_Pre_Train=pre)
+            if pattern is None:
+                pattern = self.feeder.Get_Train_Pattern(is_Pre_Train=is_Pre_Train)
         step = self.global_step
-        w = self.train_engine.train_step(self._to_device_batch(pattern), all_reduce=self._reducer)
-        res = self.train_engine.scalars(w, average=self.world > 1)
-        if not np.isfinite(res["Loss"]):
-            raise FloatingPointError("non-finite loss at global step %d: %r" % (step, res))
-        res.update({"Global_Step": step, "Learning_Rate": learning_rate(step), "Train_OP": None})
+        batch = self._to_device_batch(pattern, staged)
+        up = batch.pop("_upload")
+        w = self.train_engine.train_step(batch, all_reduce=self._reducer)
+        self._uploader.release(up)
+        handle = self.train_engine.scalars_async(w, average=self.world > 1)
+        res = StepResult({"Global_Step": step, "Learning_Rate": learning_rate(step), "Train_OP": None}, handle)
+        self._prefetch(is_Pre_Train)
         return res
 
     def Inference_WaveGlow(self, path_List, text_List, file_Prefix=None, speaker_Mel_List=None, masks=None, export=True, noise_seed=None):
@@ -283,22 +426,33 @@ class Tacotron2:
             self.Run_Inference()
         n = 0
         current = self.global_step
+        pending = None                       # (StepResult, wall time, mode) of the step whose log line is still owed
+
+        def log(entry):
+            r, seconds, mode = entry
+            if self.rank == 0:               # (reading r's losses waits for THAT step's four words only - the next step is already running)
+                print("\t\t".join(["Time: {:0.3f}".format(seconds), "Global step: {}".format(r["Global_Step"]),
+                                   "Mode: {}".format(mode),
+                                   "Learning rate: {:0.5f}".format(r["Learning_Rate"]), "Linear loss: {:0.5f}".format(r["Linear_Loss"]),
+                                   "Postnet loss: {:0.5f}".format(r["Postnet_Loss"]), "Stop loss: {:0.5f}".format(r["Stop_Loss"]),
+                                   "WR loss: {:0.5f}".format(r["Weight_Regularization_Loss"])]))
+            else:
+                r["Loss"]                    # every rank checks its step for a non-finite loss
         while max_steps is None or n < max_steps:
             t0 = time.time()
             pre = bool(hp.Train.Use_Pre_in_Main_Train and current < hp.Train.Pre_Step)
             r = self.Train_Step(pattern_fn() if pattern_fn else None, is_Pre_Train=pre)
-            if self.rank == 0:
-                print("\t\t".join(["Time: {:0.3f}".format(time.time() - t0), "Global step: {}".format(r["Global_Step"]),
-                                   "Mode: {}".format("Pre-train" if current < hp.Train.Pre_Step else "Main"),
-                                   "Learning rate: {:0.5f}".format(r["Learning_Rate"]), "Linear loss: {:0.5f}".format(r["Linear_Loss"]),
-                                   "Postnet loss: {:0.5f}".format(r["Postnet_Loss"]), "Stop loss: {:0.5f}".format(r["Stop_Loss"]),
-                                   "WR loss: {:0.5f}".format(r["Weight_Regularization_Loss"])]))
+            if pending is not None:
+                log(pending)
+            pending = (r, time.time() - t0, "Pre-train" if current < hp.Train.Pre_Step else "Main")
             if (r["Global_Step"] + 1) % hp.Train.Checkpoint_Save_Timing == 0:
                 self.Save()
             if run_inference and (r["Global_Step"] + 1) % hp.Train.Inference_Timing == 0:
                 self.Run_Inference()
             current = r["Global_Step"]
             n += 1
+        if pending is not None:
+            log(pending)
 
     # ---- inference (MSTTS_SV.py:295-323,391-400)
     def Inference(self, path_List, text_List, file_Prefix=None, speaker_Mel_List=None, masks=None, export=True):

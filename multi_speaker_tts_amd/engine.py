@@ -25,7 +25,7 @@ from .params import CELL, ENC_CELL, LSA, VOC, Dims, ParamStore, bank_suffix
 
 BN_MOM, BN_EPS = 0.99, 1e-3
 
-MAX_PLANS = 3      # cached workspace sets (one per batch shape); a full-size Tacotron2 set is ~5 GB
+MAX_PLANS = 64     # cached workspace sets (one per batch shape): views into ONE arena, a set owns no device memory
 
 
 
@@ -90,14 +90,76 @@ ENC_OVERLAP = os.environ.get("MSTTS_ENC_OVERLAP", "1") != "0"    # the encoder's
 
 
 class _WS:
-    """Attribute bag of device buffers for one (B, T_enc, L) shape."""
+    """Attribute bag of device buffers for one (B, T_enc, L) shape: views into the engine's workspace arena."""
+
+
+class _LateScalars:
+    """Handle of TrainEngine.scalars_async."""
+
+    def __init__(self, event, slot, wr_rate):
+        self.event, self.slot, self.wr_rate, self._res = event, slot, wr_rate, None
+
+    def get(self):
+        if self._res is None:
+            self.event.synchronize()
+            s = self.slot.numpy().copy()
+            wr = float(s[3]) * self.wr_rate
+            self._res = {"Linear_Loss": float(s[0]), "Postnet_Loss": float(s[1]), "Stop_Loss": float(s[2]),
+                         "Weight_Regularization_Loss": wr, "Loss": float(s[0] + s[1] + s[2]) + wr}
+        return self._res
+
+
+class _Arena:
+    """ONE device buffer that every workspace set is carved from.  The reference feeds a different (T_enc, T_dec) almost every step
+    (Feeder.py:111-124,136-175: length-sorted batches, each padded to its own maximum), so a workspace set per shape - ~150 zero-filled
+    allocations and ~5 GB at the reference widths - would be built every step.  Only one set is in use at a time; all of them are views of
+    the same bytes, laid out by one deterministic walk over the shape (TrainEngine._build_plan), so planning a new shape allocates nothing
+    and touches no device memory.  Sized once for the largest shape the engine is told to expect (arena_hint) or grown on demand."""
+
+    ALIGN = 256
+
+    def __init__(self, device):
+        self.device, self.buf, self.cap, self.generation = device, None, 0, 0
+
+    def ensure(self, nbytes):
+        """True when the arena had to be (re)allocated - every view handed out before is then a view of the OLD buffer."""
+        if nbytes <= self.cap:
+            return False
+        self.buf = None                      # (release first: two 6 GB arenas need not coexist)
+        self.cap = int(nbytes)
+        self.buf = torch.zeros(self.cap, dtype=torch.uint8, device=self.device)
+        self.generation += 1
+        return True
+
+
+class _Carver:
+    """One walk over a shape's buffers: count=True only adds up the bytes, else hands out views of the arena."""
+
+    def __init__(self, arena, count):
+        self.arena, self.count, self.off = arena, count, 0
+        self.zero = []                       # views that must read as zeros when their set is activated (flag / counter workspaces)
+
+    def take(self, shape, dtype=torch.float32, zero=False):
+        n = int(np.prod(shape)) if not isinstance(shape, int) else int(shape)
+        size = torch.empty(0, dtype=dtype).element_size()
+        nbytes = (n * size + _Arena.ALIGN - 1) // _Arena.ALIGN * _Arena.ALIGN
+        off, self.off = self.off, self.off + max(nbytes, _Arena.ALIGN)
+        if self.count:
+            return None
+        t = self.arena.buf[off:off + n * size].view(dtype)
+        t = t.view(shape) if not isinstance(shape, int) else t
+        if zero:
+            self.zero.append(t)
+        return t
 
 
 class TrainEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, rank=0, world=1, values=None,
-                 update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None, gemm_dtype=None, fuse_query=True):
+                 update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None, gemm_dtype=None, fuse_query=True,
+                 arena_hint=None):
         """recurrent_dtype: 'f32' (default; BASELINE config 2) or 'bf16' (config 3: the decoder's recurrent products run on
-        bf16 copies of the fp32 master weights with fp32 accumulation)."""
+        bf16 copies of the fp32 master weights with fp32 accumulation).
+        arena_hint: (B, T_enc, L) of the largest batch to expect - the workspace arena is sized for it once, so no later shape allocates."""
         lib.load()
         self.d = dims or Dims()
         self.device = torch.device(device)
@@ -109,7 +171,12 @@ class TrainEngine:
         self.wr_rate = float(hp.Train.Weight_Regularization_Rate) if wr_rate is None else wr_rate
         self.adam = (hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2, hp.Train.ADAM.Epsilon) if adam is None else adam
         self.params = ParamStore(self.d, self.device, seed=seed, values=values)
-        self._plans = {}          # workspace sets keyed by batch shape, least recently used first (at most MAX_PLANS kept)
+        self._plans = {}          # workspace sets (views of the arena) keyed by batch shape, least recently used first (at most MAX_PLANS kept)
+        self._arena = _Arena(self.device)
+        self._active_plan = None  # the set whose activation fills were run last (a set of another shape has used the same bytes since otherwise)
+        self._pinned = {}         # page-locked read-back blocks of the persistent launches' control words, shared by every set
+        self.arena_hint = arena_hint
+        self.arena_poison = os.environ.get("MSTTS_ARENA_POISON", "0") == "1"     # tests: NaN over a set's whole extent whenever it is activated
         self.global_step = 0
         d = self.d
         # packed / derived weights refreshed after every optimizer step
@@ -305,19 +372,54 @@ class TrainEngine:
             call("mstts_lsa_filter_by_unit", ptr(self.loc_k), ptr(self.loc_kt), d.att_k, d.att)
         self._derived_stale = False
 
+    def _pin(self, name, n):
+        if name not in self._pinned:
+            self._pinned[name] = torch.zeros(n, dtype=torch.int32).pin_memory()
+        return self._pinned[name]
+
     def plan(self, B, Te, L):
+        """The workspace set of a batch shape: views into the arena (no allocation once the arena covers the shape; `arena_hint`).  Sets of
+        different shapes alias each other - exactly one is in use at a time, the one the last plan() call returned."""
         key = (B, Te, L)
-        if key in self._plans:
+        w = self._plans.get(key)
+        if w is not None and w.arena_generation == self._arena.generation:
             self._plans[key] = self._plans.pop(key)          # most recently used last
-            return self._plans[key]
-        while len(self._plans) >= MAX_PLANS:                 # variable-length training: do not keep a workspace per shape forever
-            self._plans.pop(next(iter(self._plans)))
-        d, f = self.d, self._f
+        else:
+            need = self._build_plan(B, Te, L, _Carver(self._arena, True))[1]
+            if self._arena.buf is None and self.arena_hint is not None:
+                hb, ht, hl = self.arena_hint
+                need = max(need, self._build_plan(max(B, hb), max(Te, ht), max(L, hl), _Carver(self._arena, True))[1])
+            if self._arena.ensure(need):
+                self._plans.clear()                          # (sets carved from the old buffer stay valid for whoever holds them; they are not handed out again)
+                self._active_plan = None
+            while len(self._plans) >= MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
+            w = self._build_plan(B, Te, L, _Carver(self._arena, False))[0]
+            self._plans[key] = w
+        if self._active_plan is not w:
+            self._activate(w)
+        return w
+
+    def _activate(self, w):
+        """A set of another shape may have used these bytes since this set ran last.  Every buffer of a set is written before it is read
+        within a step (the library clears what it needs cleared: initial states, rings, control words) - except the few flag / counter
+        workspaces collected in w.zero_on_activate, cleared here.  arena_poison (tests: MSTTS_ARENA_POISON=1): NaN over the set's whole
+        extent first, so that anything that does rely on stale or zero-initialised memory fails a parity test loudly."""
+        if self.arena_poison and w.extent_bytes >= 4:
+            call("mstts_fill", ptr(self._arena.buf), float("nan"), w.extent_bytes // 4)
+        for t in w.zero_on_activate:
+            t.zero_()
+        self._active_plan = w
+
+    def _build_plan(self, B, Te, L, cv):
+        """One deterministic walk over every buffer of the shape: with a counting carver it returns (None, bytes), else (set, bytes)."""
+        d = self.d
+        f = lambda *shape, zero=False: cv.take(int(np.prod(shape)), zero=zero) if cv.count else cv.take(shape if len(shape) > 1 else int(shape[0]), zero=zero)
         w = _WS()
         S = L + 1
         w.B, w.Te, w.L, w.S = B, Te, L, S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
-        w.masks = MaskSet(d, B, Te, S, True, self.device, rank=self.rank)
+        w.masks = MaskSet(d, B, Te, S, True, self.device, rank=self.rank, alloc=lambda n: cv.take(n, dtype=torch.uint8))
         # encoder
         w.emb = f(B * Te, d.emb)
         w.enc_a = [f(B * Te, d.enc_conv_ch) for _ in range(d.enc_conv_n)]
@@ -347,19 +449,19 @@ class TrainEngine:
         ng, nq = C.c_int64(0), C.c_int64(0)
         lb.mstts_decoder_train_ws_floats(B, H, M, A, C.byref(ng), C.byref(nq))
         w.energy_ws_floats = int(lib.load().mstts_lsa_step_q_ws_bytes(B, Te)) // 4 + 2      # room for the in-launch query exchange
-        w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value)), f(w.energy_ws_floats), f(int(nq.value))
+        w.gates_ws, w.energy_ws, w.q_ws = f(int(ng.value), zero=True), f(w.energy_ws_floats, zero=True), f(int(nq.value), zero=True)
         w.act_p = f(2 * int(lb.mstts_cell_act_floats(B, M + H) + lb.mstts_cell_act_floats(B, 2 * H))) if self.fused_cells else None
         w.persist_enc = self.persist_enc and bool(lb.mstts_persist_lstm_supported(B, He))
         if w.persist_enc:
             w.enc_xch = f(int(lb.mstts_persist_lstm_ws_bytes()) // 4)
-            w.enc_ctrl = torch.zeros(16, dtype=torch.int32, device=self.device)
-            w.enc_ctrl_host = torch.zeros(16, dtype=torch.int32).pin_memory()
-            w.enc_ctrl_host_b = torch.zeros(16, dtype=torch.int32).pin_memory()
+            w.enc_ctrl = cv.take(16, dtype=torch.int32)
+            w.enc_ctrl_host = self._pin("enc_ctrl_host", 16)
+            w.enc_ctrl_host_b = self._pin("enc_ctrl_host_b", 16)
             w.enc_hist = f(int(lb.mstts_persist_lstm_hist_floats(Te)))        # packed per-step inputs + history of the persistent forward
             w.enc_bws = f(int(lb.mstts_persist_lstm_bwd_floats(Te)))
             w.enc_hist_valid = False
         w.persist = self.persist and bool(lb.mstts_persist_fwd_supported(B, H, M, A, Te, d.att_k))
-        if self.persist and not w.persist:
+        if self.persist and not w.persist and not cv.count:
             # the device and the widths admit the persistent launches, this batch shape does not: ~1.7x slower loop - say so, once per shape
             self.non_persistent_plans += 1
             if (B, Te) not in self._warned_shapes:
@@ -368,14 +470,14 @@ class TrainEngine:
                               "(mstts_persist_fwd_supported); this shape runs the launch-per-step loops" % (B, Te), RuntimeWarning, stacklevel=3)
         if w.persist:
             w.xch = f(int(lb.mstts_persist_fwd_ws_bytes()) // 4)
-            w.pctrl = torch.zeros(272, dtype=torch.int32, device=self.device)
-            w.pctrl_host = torch.zeros(272, dtype=torch.int32).pin_memory()
+            w.pctrl = cv.take(272, dtype=torch.int32)
+            w.pctrl_host = self._pin("pctrl_host", 272)
             w.pdesc = lib.PersistDesc()
         w.persist_bwd = w.persist and self.persist_bwd and bool(lb.mstts_persist_bwd_supported(B, H, M, A, Te, d.att_k))
         if w.persist_bwd:
             w.xch_b = f(int(lb.mstts_persist_bwd_ws_bytes()) // 4)
-            w.pctrl_b = torch.zeros(272, dtype=torch.int32, device=self.device)
-            w.pctrl_b_host = torch.zeros(272, dtype=torch.int32).pin_memory()
+            w.pctrl_b = cv.take(272, dtype=torch.int32)
+            w.pctrl_b_host = self._pin("pctrl_b_host", 272)
             w.pdesc_b = lib.PersistDesc()
             w.opk = f(int(lb.mstts_persist_opk_floats(S)))         # the cell updates' BPTT operands, packed by owner (instead of acts / craw / c)
         w.opk_valid = False
@@ -413,8 +515,8 @@ class TrainEngine:
         w.dq_hist, w.de_hist = f(S, B, A), f(S, B, Te)
         w.d_in0_parts = int(lb.mstts_decoder_train_bwd_parts(H, M))
         w.d_in0 = f(w.d_in0_parts, S, B, M + H)
-        w.dec_bwd_ws = f(int(lb.mstts_decoder_train_bwd_ws_floats(B, H, M, A, Te, d.att_ch)))
-        w.lsa_param_ws = torch.empty((int(lb.mstts_lsa_param_bwd_ws_floats(B, Te, S)) + 3) // 4 * 4, dtype=torch.float32, device=self.device)   # partial blocks of the attention parameter gradients
+        w.dec_bwd_ws = f(int(lb.mstts_decoder_train_bwd_ws_floats(B, H, M, A, Te, d.att_ch)), zero=True)
+        w.lsa_param_ws = f((int(lb.mstts_lsa_param_bwd_ws_floats(B, Te, S)) + 3) // 4 * 4)   # partial blocks of the attention parameter gradients
         w.d_pre = f(S * B, Pn)
         w.d_pre2 = f(S * B, Pn)
         w.d_keys = f(B, Te, A)
@@ -426,10 +528,14 @@ class TrainEngine:
         w.enc_dz = f(B * Te, d.enc_conv_ch)
         w.enc_dx = f(B * Te, max(d.enc_conv_ch, d.emb))
         # descriptors with stable addresses
+        w.job_flag = cv.take(1, dtype=torch.int32)
+        w.job_flag_host = self._pin("job_flag_host", 1)
         w.dec = lib.DecoderTrain()
         w.dec_b = lib.DecoderTrainBwd()
-        self._plans[key] = w
-        return w
+        w.zero_on_activate = cv.zero
+        w.extent_bytes = cv.off
+        w.arena_generation = self._arena.generation
+        return (None if cv.count else w), cv.off
 
     # ------------------------------------------------------------------ conv blocks
     def _conv_fwd(self, x, x_off, rows, T, cin, cout, K, kname, bname, out, act):
@@ -476,6 +582,8 @@ class TrainEngine:
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
+        if self._active_plan is not w and not _redo:         # (a set planned earlier, while a set of another shape has used the arena since)
+            self._activate(w)
         if self._derived_stale:
             self.refresh_derived()
         allowed = False if _redo else (self._persist_begin_step() if allowed is None else bool(allowed))
@@ -606,6 +714,12 @@ class TrainEngine:
             pd.recurrent_bf16 = int(self.persist_bf16)
             pd.pre, pd.b0 = (ptr(x), ptr(b0, ob0)) if w.fold_prenet else (None, None)
             call("mstts_decoder_train_fwd_persistent", C.byref(dec), C.byref(pd))
+            # the launch's control words -> page-locked memory, ON THIS STREAM right behind the launch, then an event the host waits for at the
+            # end of the pass.  (Until round 6 a side stream did the copy behind a wait for the launch.  A stream's wait is a barrier packet in its
+            # hardware queue, and HIP maps streams onto a few hardware queues: in a process with more streams - an RCCL group - the side stream
+            # shared the main stream's queue, and every kernel enqueued behind such a barrier waited with it: profiles/r06_one_rank_rccl_timeline_before.txt,
+            # the decoder's weight-gradient products sat out the encoder's BPTT launch, +1.0 ms per step.)
+            w.pctrl_host.copy_(w.pctrl, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         else:
@@ -615,12 +729,7 @@ class TrainEngine:
         self._forward_tail(w)
         dec_ok = enc_ok = True
         if ev is not None:
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                w.pctrl_host.copy_(w.pctrl, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-            done.synchronize()               # (the side stream runs in order: the encoder launch's words, copied earlier, have landed too)
+            ev.synchronize()
             st = w.pctrl_host
             dec_ok = int(st[1]) == 0 and int(st[2]) == 256
             if not dec_ok:
@@ -644,21 +753,17 @@ class TrainEngine:
 
     def _enc_persistent(self, w, entry, seqs, which, n_wg):
         """One persistent launch for all steps of both encoder directions (forward: which = 0, BPTT: 1).  Nothing waits here: the launch's
-        control words are copied to pinned host memory on the side stream behind it; the returned ticket is redeemed with _enc_check at the
+        control words are copied to pinned host memory behind it on the same stream; the returned ticket is redeemed with _enc_check at the
         end of the pass."""
         extra = (ptr(w.enc_hist),) if which == 0 else (ptr(w.enc_hist), ptr(w.enc_bws))
         call(entry, C.byref(seqs[0]), C.byref(seqs[1]), ptr(self.enc_pk["fw"][which]), ptr(self.enc_pk["bw"][which]), ptr(w.enc_xch), ptr(w.enc_ctrl), *extra)
         if getattr(self, "persist_enc_selftest", 0):              # tests: this encoder launch "gave up" - on the DEVICE, where the job-wide verdict reads it too
             self.persist_enc_selftest -= 1
             w.enc_ctrl[1:2].fill_(3)
-        ev = torch.cuda.Event()
-        ev.record()
         host = w.enc_ctrl_host if which == 0 else w.enc_ctrl_host_b
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(ev)
-            host.copy_(w.enc_ctrl, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
+        host.copy_(w.enc_ctrl, non_blocking=True)            # on the launching stream, behind the launch (see forward(): no side-stream barrier)
+        done = torch.cuda.Event()
+        done.record()
         return done, host, n_wg
 
     def _enc_check(self, w, ticket):
@@ -833,11 +938,9 @@ class TrainEngine:
             ev = torch.cuda.Event(enable_timing=self.trace_events)
             ev.record()
             self.bptt_end_event = ev             # (bench.py --gpus N: where the first gradient collective starts relative to this)
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                w.pctrl_b_host.copy_(w.pctrl_b, non_blocking=True)
-                bwd_done = torch.cuda.Event()
-                bwd_done.record()
+            w.pctrl_b_host.copy_(w.pctrl_b, non_blocking=True)
+            bwd_done = torch.cuda.Event()
+            bwd_done.record()
             parts = 1                        # (on success d_in0 slab 0 holds the complete context gradient; a failed launch re-runs the pass)
         else:
             self._ensure_fallback_packs()
@@ -959,11 +1062,14 @@ class TrainEngine:
         job_flag = None
         if agree_async is not None and not _redo:
             # every rank, every pass (also one that launched nothing persistent: its word is 1) - the ranks' collective sequences stay in step
-            if getattr(w, "job_flag", None) is None:
-                w.job_flag = torch.ones(1, dtype=torch.int32, device=self.device)
-                w.job_flag_host = torch.ones(1, dtype=torch.int32).pin_memory()
             with torch.cuda.stream(self._side):
-                if enc_ticket is None and bwd_done is None:      # (nothing of this pass is on the side stream yet: order it behind the pass so far)
+                # behind both launches: the decoder's BPTT ended before `bwd_done`, the encoder's before its ticket's event - two waits for
+                # events that have (long) fired when the side stream gets here, at the end of the pass
+                if bwd_done is not None:
+                    self._side.wait_event(bwd_done)
+                if enc_ticket is not None:
+                    self._side.wait_event(enc_ticket[0])
+                if enc_ticket is None and bwd_done is None:      # (nothing persistent in this pass: order the word behind the pass so far)
                     self._side.wait_stream(torch.cuda.current_stream())
                 call("mstts_persist_status", ptr(w.pctrl_b) if bwd_done is not None else None, 256,
                      ptr(w.enc_ctrl) if enc_ticket is not None else None, enc_ticket[2] if enc_ticket is not None else 0, ptr(w.job_flag))
@@ -974,9 +1080,8 @@ class TrainEngine:
         passed = True
         if enc_ticket is not None:
             passed = self._enc_check(w, enc_ticket)
-        elif bwd_done is not None:
-            bwd_done.synchronize()
         if bwd_done is not None:
+            bwd_done.synchronize()
             st = w.pctrl_b_host
             if int(st[1]) != 0 or int(st[2]) != 256:
                 self.persist_bwd_fallbacks += 1
@@ -1024,15 +1129,20 @@ class TrainEngine:
         if part == "attention":
             return
         g1, og1 = self.G(CELL % 1 + "kernel"); gb1, ogb1 = self.G(CELL % 1 + "bias")
-        self._gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, n, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, n), accumulate=True,
-             a_off=r * 2 * H, b_off=r * 4 * H, c_off=og1)
-        call("mstts_colsum", ptr(w.dg1, r * 4 * H), n, 4 * H, 4 * H, ptr(gb1, ogb1), 1)
         g0, og0 = self.G(CELL % 0 + "kernel"); gb0, ogb0 = self.G(CELL % 0 + "bias")
+        # Order: the two bias sums (streaming, ~70 us each) first, then the cell-0 product, then the cell-1 product.  The encoder's persistent
+        # BPTT (32 workgroups, its own stream) is launched just in front of this: the bias sums give its memsets and workgroups the time to
+        # take their 32 CUs, and at the reference widths the folded cell-0 gradient is 7 x 16 tiles x 2 pieces = 224 workgroups of the
+        # one-workgroup-per-CU kernel - exactly the CUs that are left - where the cell-1 gradient's 256 would wait a whole round for them
+        # (profiles/r06_one_rank_rccl_timeline_before.txt).
+        call("mstts_colsum", ptr(w.dg1, r * 4 * H), n, 4 * H, 4 * H, ptr(gb1, ogb1), 1)
+        call("mstts_colsum", ptr(w.dg0, r * 4 * H), n, 4 * H, 4 * H, ptr(gb0, ogb0), 1)
         self._gemm(w.in0, w.dg0, self.dw0f, M + H, 4 * H, n, M + H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(M + H, 4 * H, n), accumulate=True,
              a_off=r * (M + H), b_off=r * 4 * H)
+        self._gemm(w.in1, w.dg1, g1, 2 * H, 4 * H, n, 2 * H, 4 * H, 4 * H, trans_a=True, split_k=_split_k(2 * H, 4 * H, n), accumulate=True,
+             a_off=r * 2 * H, b_off=r * 4 * H, c_off=og1)
         self._gemm(w.pre_d[-1], w.dg0, g0, Pn, 4 * H, n, Pn, 4 * H, 4 * H, trans_a=True, split_k=max(2, _split_k(Pn, 4 * H, n)),
              a_off=r * Pn, b_off=r * 4 * H, c_off=og0)
-        call("mstts_colsum", ptr(w.dg0, r * 4 * H), n, 4 * H, 4 * H, ptr(gb0, ogb0), 1)
         k0, o0 = self.P(CELL % 0 + "kernel")
         self._gemm(w.dg0, k0, w.d_pre, n, Pn, 4 * H, 4 * H, 4 * H, Pn, trans_b=True, a_off=r * 4 * H, b_off=o0, c_off=r * Pn)
         gq, ogq = self.G(LSA + "query_layer/kernel")
@@ -1094,6 +1204,27 @@ class TrainEngine:
         wr = float(s[3]) * self.wr_rate
         return {"Linear_Loss": float(s[0]), "Postnet_Loss": float(s[1]), "Stop_Loss": float(s[2]),
                 "Weight_Regularization_Loss": wr, "Loss": float(s[0] + s[1] + s[2]) + wr}
+
+    def scalars_async(self, w, average=False, group=None):
+        """The same, without waiting for the step: the four loss words are copied to a page-locked slot (four slots in rotation) behind
+        everything enqueued so far and a handle is returned; handle.get() waits for THAT copy only.  Tacotron2.Train reads a step's losses
+        while the next step runs, so the host never drains the device between two steps (MSTTS_SV.py:270-273 fetches them with the step)."""
+        if getattr(self, "_scalar_ring", None) is None:
+            self._scalar_ring = torch.zeros(4, 4, dtype=torch.float32).pin_memory()
+            self._scalar_next = 0
+            self._scalar_avg = torch.zeros(4, dtype=torch.float32, device=self.device)
+        slot = self._scalar_ring[self._scalar_next]
+        self._scalar_next = (self._scalar_next + 1) % 4
+        src = w.scalars
+        if average:
+            from .dist import average_
+            self._scalar_avg.copy_(w.scalars)
+            average_([self._scalar_avg], group=group)
+            src = self._scalar_avg
+        slot.copy_(src, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _LateScalars(ev, slot, self.wr_rate)
 
     def exchange_timeouts(self, w):
         """Count of in-launch exchange time-outs of the single-launch forward attention kernel in the last step on workspace `w`

@@ -56,13 +56,19 @@ def table(d, B, T_enc, S, training, speaker_windows=0, vocoder=False):
 class MaskSet:
     """Preallocated uint8 mask buffers for one shape; ``draw`` refills them for a seed."""
 
-    def __init__(self, d, B, T_enc, S, training, device, rank=0, **kw):
+    def __init__(self, d, B, T_enc, S, training, device, rank=0, alloc=None, **kw):
+        """alloc: optional callable(n_bytes) -> uint8 tensor of that length (or None while a caller only counts bytes): the train engine
+        carves the masks from its workspace arena instead of allocating them per shape."""
         self.spec = table(d, B, T_enc, S, training, **kw)
         self.rank = rank
         self.buf = {}
         for name, _, shape, _ in self.spec:
             n = int(np.prod(shape))
-            self.buf[name] = torch.empty((n + 3) // 4 * 4, dtype=torch.uint8, device=device)[:n].view(shape)
+            if alloc is not None:
+                t = alloc((n + 3) // 4 * 4)
+                self.buf[name] = None if t is None else t[:n].view(shape)
+            else:
+                self.buf[name] = torch.empty((n + 3) // 4 * 4, dtype=torch.uint8, device=device)[:n].view(shape)
 
     def draw(self, seed, only=None):
         """Masks are keyed by (seed, stream, GLOBAL sample index, position in the sample): rank r holds the samples

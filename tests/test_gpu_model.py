@@ -1039,23 +1039,42 @@ def test_pattern_generate_cli_to_training(dev, tmp_path, monkeypatch):
 
 
 def test_variable_length_training_and_convergence(dev):
-    """Bucketed real data gives a different (tokens, frames) shape almost every step: the workspace cache stays bounded, every
-    shape trains, and repeating one batch drives the loss down (the whole step - forward, BPTT, TF-Adam - pulls one way)."""
+    """Bucketed real data gives a different (tokens, frames) shape almost every step (Feeder.py:111-124,136-175).  Every workspace set is a
+    view of ONE arena sized for the largest shape to come (arena_hint), so from the second step on a NEW shape allocates nothing on the
+    device - the caching allocator's allocation count stays flat across train_step - the sets of different shapes alias each
+    other, every shape trains, and repeating one batch drives the loss down (the whole step - forward, BPTT, TF-Adam - pulls one way).
+    The suite runs with MSTTS_ARENA_POISON=1 (tests/conftest.py): whenever a set is activated its whole extent is filled with NaN first, so a
+    kernel that relied on zero-initialised or stale workspace memory would put NaN into the loss here."""
     from multi_speaker_tts_amd import engine as E
     pd, od = dims_pair(**MID)
-    eng = TrainEngine(pd, device=dev, seed=3)
-    first = None
-    for i, (B, Te, L) in enumerate([(4, 9, 6), (4, 12, 8), (3, 7, 11), (4, 9, 6), (2, 15, 5), (4, 10, 9)]):
+    shapes = [(4, 9, 6), (4, 12, 8), (3, 7, 11), (4, 9, 6), (2, 15, 5), (4, 10, 9), (4, 15, 11), (1, 5, 3)]
+    eng = TrainEngine(pd, device=dev, seed=3, arena_hint=(4, 15, 11))
+    assert eng.arena_poison
+    counts, extents = [], []
+    for i, (B, Te, L) in enumerate(shapes):
         batch = to_dev(OT.synthetic_batch(od, B, Te, L, seed=20 + i, ragged=True), dev)
+        torch.cuda.synchronize()
+        n0 = torch.cuda.memory_stats(dev)["allocation.all.allocated"]
         w = eng.train_step(batch)
+        torch.cuda.synchronize()
+        counts.append(torch.cuda.memory_stats(dev)["allocation.all.allocated"] - n0)
+        extents.append(w.extent_bytes)
         assert np.isfinite(eng.scalars(w)["Loss"]) and len(eng._plans) <= E.MAX_PLANS
+    assert counts[0] > 0 and all(c == 0 for c in counts[1:]), counts           # the first step builds the arena (and the engine's one-off buffers); no later one allocates
+    assert eng._arena.generation == 1 and max(extents) <= eng._arena.cap         # sized once, never grown
+    w_a, w_b = eng.plan(4, 9, 6), eng.plan(4, 12, 8)
+    assert w_a is eng.plan(4, 9, 6) and w_a.emb.data_ptr() == w_b.emb.data_ptr()   # cached views; different shapes alias the same bytes
+    # a shape beyond the hint grows the arena once (and only then)
+    big = to_dev(OT.synthetic_batch(od, 5, 17, 13, seed=77, ragged=True), dev)
+    w = eng.train_step(big)
+    assert eng._arena.generation == 2 and np.isfinite(eng.scalars(w)["Loss"])
     batch = to_dev(OT.synthetic_batch(od, 4, 9, 6, seed=99), dev)
     losses = []
     for _ in range(40):
         w = eng.train_step(batch)
         losses.append(eng.scalars(w)["Loss"])
     assert np.mean(losses[-5:]) < 0.95 * np.mean(losses[:5]), (losses[:5], losses[-5:])      # noise targets + dropout .5: slow but steady
-    assert eng.global_step == 46
+    assert eng.global_step == len(shapes) + 1 + 40
 
 
 def test_gradient_ready_ranges(dev):

@@ -438,11 +438,12 @@ def test_two_deferred_tickets_outstanding_together(dev):
     t1.host[t1.pending[0][0]][1] = 3
     emb2, t2 = eng.speaker_embedding(mel, defer=True)                  # reuses device slots 0.., reads back into ANOTHER block
     assert t2 is not None and t2.host is not t1.host
+    blocks = (t1.host, t2.host)
     assert t2.ok() is True                                             # the healthy call is not blamed for the first one's words
     assert t1.ok() is False                                            # ... and the failed one is not absolved by the second one's
     with pytest.raises(RuntimeError):
         t1.ok()                                                        # a ticket is redeemed once
     assert len(eng._deferred_host_pool) == 2
     emb3, t3 = eng.speaker_embedding(mel, defer=True)                  # blocks are pooled, not re-allocated
-    assert t3.host is t1.host or t3.host is t2.host
+    assert t3.host is blocks[0] or t3.host is blocks[1]
     assert t3.ok() and np.array_equal(t2n(emb3), t2n(emb2))

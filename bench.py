@@ -445,6 +445,7 @@ def main():
                                               "MSTTS_GEMM_SPLIT3=0 or mstts_gemm_split3(0) selects v_mfma_f32_32x32x2_f32 everywhere")
         if world == 1 and not args.no_roofline:
             lib.call("mstts_gemm_split3", 0)
+            eng.exact_f32_products = True            # ... and inside the persistent forward loop (its two on-chain products are split products otherwise)
             for _ in range(2):
                 eng.train_step(batch, all_reduce=reducer)
             sync()
@@ -454,7 +455,9 @@ def main():
             sync()
             out["f32_input_mfma_everywhere"] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / 5, "steps": 5}
             out["f32_input_mfma_everywhere"]["value"] = B_PER_GPU * L / (out["f32_input_mfma_everywhere"]["ms_per_step"] * 1e-3)
+            out["f32_input_mfma_everywhere"]["covers"] = "every hoisted contraction AND every product inside the persistent decoder loops (forward launch in its pre == NULL form)"
             lib.call("mstts_gemm_split3", 1)
+            eng.exact_f32_products = False
     # health counters of the persistent launches: in a multi-rank job every rank's, not rank 0's (a rank that falls back every step drags
     # the whole job - the step time is the slowest rank's - and must not hide behind a healthy rank 0): sum and maximum over the ranks
     counters = {"decoder_forward": eng.persist_fallbacks, "decoder_bptt": eng.persist_bwd_fallbacks, "encoder_bilstm": eng.persist_enc_fallbacks,

@@ -672,7 +672,15 @@ typedef struct {
                                   /* forward only, optional: the prenet output [S, B, 256] (step-major, 16-byte aligned) and the cell-0 bias [4H].
                                      When given, the launch forms the prenet rows' share of the cell-0 gates itself (8 more k-steps per wave,
                                      kernel rows from the wx0 argument of mstts_persist_pack) and ignores mstts_decoder_train_desc.xw0: the
-                                     caller skips that [S B, 256] x [256, 4H] product and its 16 KB-per-row tensor.  NULL: xw0 is read. */
+                                     caller skips that [S B, 256] x [256, 4H] product and its 16 KB-per-row tensor.  NULL: xw0 is read.
+                                     ARITHMETIC: with pre given (and recurrent_bf16 == 0, at most 128 encoder positions) the two products that sit on
+                                     the step's chain - context + prenet rows into cell 0, the cell-0 output into cell 1 - are evaluated as the EXACT
+                                     three-way bf16 split of both operands, six products on v_mfma_f32_16x16x32_bf16 with fp32 accumulators: fp32 accuracy
+                                     (dropped terms <= 2^-26 relative) and the edge semantics stated at mstts_gemm_split3 (an operand that is inf / NaN or
+                                     rounds to bf16 infinity gives NaN where IEEE gives inf; denormal planes may be flushed).  With pre == NULL every
+                                     product of the loop runs on the f32-input MFMA (bitwise an fmaf chain): that is the form to select together
+                                     with mstts_gemm_split3(0) when IEEE behaviour at those edges is wanted (TrainEngine.exact_f32_products; bench.py's
+                                     f32_input_mfma_everywhere leg runs it). */
     int32_t recurrent_bf16;       /* != 0 (BASELINE config 3, "bf16 with fp32 master"): both cell products, the query product and - in the BPTT launch - the
                                      data-gradient products take their operands rounded to bf16 (round to nearest even; the kernels when they are loaded into
                                      registers, the activations / gate gradients when they are staged) and run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators;

@@ -229,6 +229,31 @@ def load_pattern_batch(file_names, token_dict, pattern_path=None):
             "Mel_Length": np.array([m.shape[0] for m in mel_List], np.int32), "Speaker_Embedding_Mel": speaker_windows(mel_List)}
 
 
+_SHM_KEYS = ("Token", "Token_Length", "Mel", "Mel_Length", "Speaker_Embedding_Mel")
+_worker_shm = {}                             # loader processes: shared-memory blocks attached so far, by name
+
+
+def _load_pattern_batch_into(names, token_dict, root, shm_name, shm_size):
+    """Loader process: load_pattern_batch, the arrays written into the shared-memory block `shm_name` (a 10 MB batch through the pool's result
+    pipe costs the parent more than loading it itself would).  Returns ("shm", [(key, dtype, shape, offset)]) or - a batch that does not
+    fit the block - ("value", pattern)."""
+    from multiprocessing import shared_memory
+    p = load_pattern_batch(names, token_dict, pattern_path=root)
+    need = sum((p[k].nbytes + 63) // 64 * 64 for k in _SHM_KEYS)
+    if need > shm_size:
+        return "value", p
+    shm = _worker_shm.get(shm_name)
+    if shm is None:
+        shm = _worker_shm[shm_name] = shared_memory.SharedMemory(name=shm_name)
+    layout, off = [], 0
+    for k in _SHM_KEYS:
+        a = np.ascontiguousarray(p[k])
+        np.ndarray(a.shape, a.dtype, buffer=shm.buf, offset=off)[...] = a
+        layout.append((k, a.dtype.str, a.shape, off))
+        off += (a.nbytes + 63) // 64 * 64
+    return "shm", layout
+
+
 class Feeder:
     """Same constructor / pattern API as the reference class; `placeholder_Dict` maps the reference's
     placeholder names to themselves (there is no graph), patterns are dicts keyed by those names.
@@ -264,6 +289,23 @@ class Feeder:
     def _start_producers(self):
         from collections import deque
         from threading import Thread
+        # The reference's pattern files are protocol-2 pickles (Pattern_Generate.py:66-76); under Python 3 a protocol-2 NumPy array is a
+        # latin-1 round trip of its bytes, ~1 ms per file, 30-40 ms per batch of 32 - more than a train step of an average batch takes on
+        # this GPU (the reference's producer thread, Feeder.py:89-172, had seconds per step to hide in).  So the producer thread hands the
+        # batches to a few WORKER PROCESSES (forked: they only ever run NumPy and pickle, never the GPU runtime) and keeps the reference's
+        # order: batch k enters the queue before batch k + 1.  MSTTS_FEEDER_WORKERS=0 loads in the producer thread itself.
+        n = os.environ.get("MSTTS_FEEDER_WORKERS")
+        self._workers = int(n) if n is not None else (4 if (os.cpu_count() or 1) >= 8 else 0)
+        self._pool, self._shm = None, []
+        if self._workers > 0:
+            import multiprocessing
+            from concurrent.futures import ProcessPoolExecutor
+            # shared-memory blocks (allocated per producer thread, Train_Pattern_Generate): one per batch in flight (+ 1), sized for the largest batch the length filter admits with texts of up to 256 tokens
+            frames = int(hp.Train.Use_Wav_Length_Range[1] / hp.Sound.Frame_Shift) + 2
+            inf = hp.Speaker_Embedding.Inference
+            B = int(hp.Train.Batch_Size)
+            self._shm_size = 4 * (B * frames * hp.Sound.Mel_Dim + B * inf.Sample_Nums * inf.Mel_Frame * hp.Sound.Mel_Dim + B * 258) + 4096
+            self._pool = ProcessPoolExecutor(max_workers=self._workers, mp_context=multiprocessing.get_context("fork"))
         if hp.Train.Use_Pre_in_Main_Train:
             self.pre_Pattern_Queue = deque()
             Thread(target=self.Train_Pattern_Generate, args=[True], daemon=True).start()
@@ -274,6 +316,7 @@ class Feeder:
         """Producer loop of Feeder.py:89-172 (runs forever in a daemon thread)."""
         import random
         import time
+        from collections import deque
         rng = random.Random(self._seed) if self._seed is not None else random
         queue = self.pre_Pattern_Queue if is_Pre_Train else self.pattern_Queue
         order = train_file_order(self.metadata_Dict, is_Pre_Train)
@@ -285,19 +328,53 @@ class Feeder:
         if not order:
             self._producer_error[is_Pre_Train] = "no pattern file passes the dataset / length filters (hp.Train.*_Dataset_List, Use_Wav_Length_Range)"
             return
+        token_dict = self.metadata_Dict["Token_Index_Dict"]
+        in_flight = deque()                  # batches being loaded by the worker processes, in the order they will enter the queue
+        n_submitted, blocks = 0, []
+        if self._pool is not None:
+            from multiprocessing import shared_memory
+            blocks = [shared_memory.SharedMemory(create=True, size=self._shm_size) for _ in range(self._workers + 1)]
+            self._shm.extend(blocks)
+
+        def emit(item):
+            """One loaded batch into the queue (bounded, Feeder.py:126-127); False when the producer has to stop."""
+            while len(queue) >= hp.Train.Max_Pattern_Queue and not self._stop:
+                time.sleep(0.01)
+            if self._stop:
+                return False
+            try:
+                if self._pool is None:
+                    queue.append(load_pattern_batch(item, token_dict, pattern_path=root))
+                else:
+                    fut, shm = item
+                    kind, res = fut.result()
+                    if kind == "shm":            # copy out of the block: it is handed to the next batch as soon as this one is in the queue
+                        res = dict({"Is_Training": True}, **{k: np.ndarray(shape, np.dtype(dt), buffer=shm.buf, offset=off).copy() for k, dt, shape, off in res})
+                    queue.append(res)
+            except Exception as e:                  # a dead producer must not leave Get_Train_Pattern spinning forever
+                self._producer_error[is_Pre_Train] = "{}: {}".format(type(e).__name__, e)
+                print("Pattern producer stopped: {}".format(e))
+                return False
+            return True
         while not self._stop:
             batches = epoch_batches(order, rng)
             mine = batches[self.rank::self.world] if len(batches) >= self.world else batches       # tiny sets: every rank takes all
             for names in mine:
-                while len(queue) >= hp.Train.Max_Pattern_Queue and not self._stop:
-                    time.sleep(0.1)
                 if self._stop:
                     return
+                if self._pool is None:
+                    if not emit(names):
+                        return
+                    continue
+                # (at most `workers` batches in flight and workers + 1 blocks in rotation: the block of batch k was copied out before batch
+                #  k + workers + 1 is submitted)
+                shm = blocks[n_submitted % len(blocks)]
+                n_submitted += 1
                 try:
-                    queue.append(load_pattern_batch(names, self.metadata_Dict["Token_Index_Dict"], pattern_path=root))
-                except Exception as e:                  # a dead producer must not leave Get_Train_Pattern spinning forever
-                    self._producer_error[is_Pre_Train] = "{}: {}".format(type(e).__name__, e)
-                    print("Pattern producer stopped: {}".format(e))
+                    in_flight.append((self._pool.submit(_load_pattern_batch_into, names, token_dict, root, shm.name, self._shm_size), shm))
+                except RuntimeError:                # the pool was shut down (close())
+                    return
+                if len(in_flight) > self._workers and not emit(in_flight.popleft()):
                     return
 
     def Unget_Train_Pattern(self, pattern, is_Pre_Train=False):
@@ -307,8 +384,18 @@ class Feeder:
             (self.pre_Pattern_Queue if is_Pre_Train else self.pattern_Queue).appendleft(pattern)
 
     def close(self):
-        """Stop the producer threads (the reference's daemon threads die with the process)."""
+        """Stop the producer threads (the reference's daemon threads die with the process) and the loader processes."""
         self._stop = True
+        pool, self._pool = getattr(self, "_pool", None), None
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
+        for shm in getattr(self, "_shm", []):
+            try:
+                shm.close()
+                shm.unlink()
+            except (OSError, BufferError):
+                pass
+        self._shm = []
 
     def Speaker_Embedding_Mel(self, mel_List):
         return speaker_windows(mel_List)

@@ -87,11 +87,16 @@ class _BatchUploader:
     FIELDS = (("Token", np.int32), ("Token_Length", np.int32), ("Mel", np.float32), ("Mel_Length", np.int32),
               ("Speaker_Embedding", np.float32), ("Speaker_Embedding_Mel", np.float32))
 
-    def __init__(self, device):
+    def __init__(self, device, presize=None):
+        """presize: {field: elements} - blocks created at that size up front (page-locking memory is a system call: not in the middle of training)."""
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.slots = [{"host": {}, "dev": {}, "uploaded": None, "released": None} for _ in range(2)]
         self.next = 0
+        for name, np_dtype in self.FIELDS:
+            if presize and presize.get(name):
+                for slot in self.slots:
+                    self._block(slot, name, int(presize[name]), np_dtype)
 
     def _block(self, slot, name, n, np_dtype):
         h = slot["host"].get(name)
@@ -161,6 +166,7 @@ class Tacotron2:
         self.train_engine = TrainEngine(dims, device=device, seed=seed, rank=self.rank, world=self.world, arena_hint=hint)
         self._uploader = None
         self._prefetched = None              # (is_Pre_Train, pattern, staged batch) taken ahead for the next Train_Step
+        self.host_seconds = {"feeder_wait": 0.0, "stage": 0.0, "step_enqueue": 0.0, "steps": 0, "prefetched": 0}   # where Train_Step's host time goes (tools/train_surface_bench.py)
         self.params = self.train_engine.params
         self.infer_engine = InferEngine(self.train_engine.d, device=device, seed=seed, params=self.params)
         self.train_Tensor_Dict = {k: k for k in TRAIN_KEYS} if is_Training else None
@@ -313,7 +319,10 @@ class Tacotron2:
         (_BatchUploader; `staged`: already on their way); the compute stream waits for the upload, not the host."""
         dev = torch.device(self.device)
         if self._uploader is None:
-            self._uploader = _BatchUploader(dev)
+            B, inf = int(hp.Train.Batch_Size), hp.Speaker_Embedding.Inference
+            frames = int(hp.Train.Use_Wav_Length_Range[1] / hp.Sound.Frame_Shift) + 2
+            self._uploader = _BatchUploader(dev, presize={"Token": B * 256, "Token_Length": B, "Mel": B * frames * hp.Sound.Mel_Dim, "Mel_Length": B,
+                                                          "Speaker_Embedding_Mel": B * inf.Sample_Nums * inf.Mel_Frame * hp.Sound.Mel_Dim} if self.is_Training else None)
         up = staged if staged is not None else self._uploader.stage(pattern)
         torch.cuda.current_stream(dev).wait_event(up["_uploaded"])
         batch = {k: up[k] for k in ("Token", "Token_Length", "Mel", "Mel_Length")}
@@ -343,7 +352,10 @@ class Tacotron2:
             return
         pattern = self.feeder.Get_Train_Pattern(is_Pre_Train=is_Pre_Train, block=False)
         if pattern is not None:
+            t0 = time.perf_counter()
             self._prefetched = (is_Pre_Train, pattern, self._uploader.stage(pattern))
+            self.host_seconds["stage"] += time.perf_counter() - t0
+            self.host_seconds["prefetched"] += 1
 
     def Train_Step(self, pattern=None, is_Pre_Train=False):
         """One iteration of the reference's `while True` body (MSTTS_SV.py:268-273); returns the train_Tensor_Dict results (StepResult: the
@@ -359,11 +371,19 @@ class Tacotron2:
                 else:                        # the step asks for the other queue (pre-training -> main training): hand the pattern back
                     self.feeder.Unget_Train_Pattern(p, is_Pre_Train=pre)
             if pattern is None:
+                t0 = time.perf_counter()
                 pattern = self.feeder.Get_Train_Pattern(is_Pre_Train=is_Pre_Train)
+                self.host_seconds["feeder_wait"] += time.perf_counter() - t0
         step = self.global_step
+        t0 = time.perf_counter()
         batch = self._to_device_batch(pattern, staged)
+        if staged is None:
+            self.host_seconds["stage"] += time.perf_counter() - t0
         up = batch.pop("_upload")
+        t0 = time.perf_counter()
         w = self.train_engine.train_step(batch, all_reduce=self._reducer)
+        self.host_seconds["step_enqueue"] += time.perf_counter() - t0
+        self.host_seconds["steps"] += 1
         self._uploader.release(up)
         handle = self.train_engine.scalars_async(w, average=self.world > 1)
         res = StepResult({"Global_Step": step, "Learning_Rate": learning_rate(step), "Train_OP": None}, handle)

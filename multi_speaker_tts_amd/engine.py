@@ -212,6 +212,7 @@ class TrainEngine:
         self.persist_bf16 = rdt == "bf16" and gdt == "bf16" and d.prenet == 256 and os.environ.get("MSTTS_PERSIST_BF16", "1") != "0"
         self.persist = (os.environ.get("MSTTS_PERSIST", "1") != "0" and (rdt == "f32" or self.persist_bf16)
                         and bool(lb.mstts_persist_fwd_supported(1, H, M, d.att, 1, d.att_k)))
+        self.exact_f32_products = False      # True: no split products inside the persistent forward either (see forward(); include/mstts.h, mstts_persist_desc.pre)
         self.persist_fallbacks = 0           # sequences that had to be re-run on the launch-per-step path
         # Adaptive policy: a persistent launch that gives up costs its rendezvous bound plus the slow loop, and something that holds CUs
         # (another process, a profiler, a collective that outlives its slot) will do so again next step.  After PERSIST_STRIKES
@@ -669,7 +670,10 @@ class TrainEngine:
         self._gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)
         k0, o0 = self.P(CELL % 0 + "kernel"); b0, ob0 = self.P(CELL % 0 + "bias")
         # cell-0 input product xw0 = prenet . W0[:P] + b0: inside the persistent launch (fp32 mode, 256-wide prenet), else hoisted here
-        w.fold_prenet = w.persist_now and Pn == 256 and (self.persist_bf16 or (self.gemm_dtype == "f32" and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"))
+        # (exact_f32_products: every product of the loop on the f32-input MFMA - the launch's round-4 form, which keeps the prenet rows' product
+        #  hoisted; selected together with mstts_gemm_split3(0) by whoever wants IEEE fp32 products everywhere, e.g. bench.py's strict leg)
+        w.fold_prenet = w.persist_now and Pn == 256 and (self.persist_bf16 or (self.gemm_dtype == "f32" and not self.exact_f32_products
+                                                                                and os.environ.get("MSTTS_PERSIST_FOLD", "1") != "0"))
         xw0_product = lambda: self._gemm(x, k0, w.xw0, S * B, 4 * H, Pn, Pn, 4 * H, 4 * H, bias=b0, b_off=o0, bias_off=ob0)
         if not w.fold_prenet:
             xw0_product()

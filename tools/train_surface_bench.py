@@ -78,11 +78,19 @@ def run(steps=50, warmup=3, keep=None, device="cuda:0", seed=0, quiet=True):
             t.Train_Step()
         torch.cuda.synchronize()
         first = len(taken) - (1 if t._prefetched is not None else 0)          # patterns consumed by the warm-up steps
+        deadline = time.time() + 20.0
+        while len(t.feeder.pattern_Queue) < min(steps, hp.Train.Max_Pattern_Queue) - 1 and time.time() < deadline:
+            time.sleep(0.05)                                                    # (the reference starts training on a filled queue too)
+        for k in t.host_seconds:
+            t.host_seconds[k] = 0
         t0 = time.perf_counter()
         results = [t.Train_Step() for _ in range(steps)]
         torch.cuda.synchronize()
         surface_ms = 1e3 * (time.perf_counter() - t0) / steps
         losses = [float(r["Loss"]) for r in results]
+        host = {k: (1e3 * v / steps if k not in ("steps", "prefetched") else v) for k, v in t.host_seconds.items()}
+        host["queue_length_at_end"] = len(t.feeder.pattern_Queue)
+        host["feeder_workers"] = getattr(t.feeder, "_workers", 0)
         eng, inf = t.train_engine, t.infer_engine
         counters = dict(decoder_forward=eng.persist_fallbacks, decoder_bptt=eng.persist_bwd_fallbacks, encoder_bilstm=eng.persist_enc_fallbacks,
                         non_persistent_plans=eng.non_persistent_plans, speaker_ticket_redos=eng.speaker_ticket_redos, arena_generation=eng._arena.generation)
@@ -110,6 +118,7 @@ def run(steps=50, warmup=3, keep=None, device="cuda:0", seed=0, quiet=True):
             eng.train_step(batch)
         for b in res[:warmup]:
             engine_step(b)
+        eng._plans.clear()                   # every shape is new to this leg too, as it was to the surface leg
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for b in res:
@@ -122,7 +131,7 @@ def run(steps=50, warmup=3, keep=None, device="cuda:0", seed=0, quiet=True):
                 "surface_mel_frames_per_s": frames / (surface_ms * 1e-3 * steps), "engine_mel_frames_per_s": frames / (engine_ms * 1e-3 * steps),
                 "distinct_shapes": len(set(shapes)), "tokens_min_max": [min(s[1] for s in shapes), max(s[1] for s in shapes)],
                 "frames_min_max": [min(s[2] for s in shapes), max(s[2] for s in shapes)], "mean_padded_frames": float(np.mean([s[2] for s in shapes])),
-                "loss_first_last": [losses[0], losses[-1]], "counters": counters,
+                "loss_first_last": [losses[0], losses[-1]], "counters": counters, "surface_host_ms_per_step": host,
                 "what": "Tacotron2.Train_Step through the real Feeder (synthetic pattern files in the reference's format, wav lengths uniform in "
                         "Use_Wav_Length_Range, length-sorted batches padded to their own maximum: a new shape every step) beside the same batches "
                         "device-resident through the speaker stack + TrainEngine.train_step"}

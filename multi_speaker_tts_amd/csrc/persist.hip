@@ -31,6 +31,9 @@ namespace mstts {
 #ifndef M1_LATE
 #define M1_LATE 60              // BF16 instantiation: 0 = the m1 row's request leaves right behind the h0 product; 1 = behind the location product; n > 1 = and n ticks (10 ns) into the stage
 #endif
+#ifndef PRE_EARLY
+#define PRE_EARLY 1             // fp32 instantiation with the split on-chain products: the prenet rows' product of step s + 1 runs in the flight of step s' energies instead of at the loop top
+#endif
 #ifndef SPLIT_M0
 #define SPLIT_M0 1              // 0: the on-chain cell-1 product on the f32-input MFMA like every other product of the loop (A/B builds)
 #endif
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     // v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32 accuracy at 6/16 of the f32-input MFMA's matrix-core time, as gemm_split.inc) - the one
     // product of the loop whose kernel half fits as three planes (32 -> 48 registers per lane)
     constexpr bool SM0 = SPLIT_M0 && !BF16 && FOLD && TT == 128;
+    constexpr bool PE = PRE_EARLY && SPLIT_M0 && SPLIT_C0 && !BF16 && FOLD && TT == 128;      // (= PRE_EARLY && SC0)
     // SC0: the same for the on-chain half of cell 0 (context rows + prenet rows: k-steps 0 .. 31 of w0).  Its 16 registers come from the
     // owner's biases, the score constants (both to a spare corner of S_Q, read where they are used) and SM0's location filter
     constexpr bool SC0 = SPLIT_C0 && SM0;
@@ -254,19 +258,22 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     float xwv[4] = {0.f, 0.f, 0.f, 0.f};
     pf32x4 prv = {0.f, 0.f, 0.f, 0.f};           // FOLD: this thread's 16 bytes of the step's prenet slice (staging row rho = (tid & 255) >> 1, half tid & 1)
     uint8_t zc0v, zh0v, zc1v, zh1v;
+#define LOAD_PRE(ST) do { const long bp__ = (long)(ST) * B;                                                                                  \
+            const unsigned rho__ = ((unsigned)tid0 & 255u) >> 1, pb__ = 16 * ((rho__ >> 4) & 1u) + (rho__ & 15u);                                     \
+            const pf32x4 v__ = *reinterpret_cast<const pf32x4*>(d.pre + (bp__ + (pb__ < (unsigned)B ? pb__ : 0u)) * 256 + 32 * (g0 & 7) + 8 * (rho__ >> 5) + 4 * ((unsigned)tid0 & 1u)); \
+            prv = pb__ < (unsigned)B ? v__ : (pf32x4){0.f, 0.f, 0.f, 0.f}; } while (0)
 #define LOAD_OPERANDS(ST) do { const long b__ = (long)(ST) * B; const unsigned r__ = (16 * (wave0 & 1) + (tid0 & 15)) < (unsigned)B ? 16 * (wave0 & 1) + (tid0 & 15) : 0u;  \
         /* (waves 2..7 only repeat the update: their lanes all read ONE address, a single cache-line request instead of 16 scattered ones) */ \
         const unsigned u__ = 4 * g0 + ((tid0 & 63) >> 4), h__ = wave0 < 2 ? r__ * PH + u__ : 0u, q__ = wave0 < 2 ? r__ * 4 * PH + u__ : 0u;                                     \
         if (FOLD) {                                                                                                                         \
-            const unsigned rho__ = ((unsigned)tid0 & 255u) >> 1, pb__ = 16 * ((rho__ >> 4) & 1u) + (rho__ & 15u);                                     \
-            const pf32x4 v__ = *reinterpret_cast<const pf32x4*>(d.pre + (b__ + (pb__ < (unsigned)B ? pb__ : 0u)) * 256 + 32 * (g0 & 7) + 8 * (rho__ >> 5) + 4 * ((unsigned)tid0 & 1u)); \
-            prv = pb__ < (unsigned)B ? v__ : (pf32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+            if (!PE) LOAD_PRE(ST);                                                                                                          \
         } else {                                                                                                                            \
             const float* xw__ = d.xw0 + b__ * 4 * PH;                                                                                       \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) xwv[q] = xw__[q__ + q * PH];                                                       \
         }                                                                                                                                   \
         zc0v = (d.zc0 + b__ * PH)[h__]; zh0v = (d.zh0 + b__ * PH)[h__]; zc1v = (d.zc1 + b__ * PH)[h__]; zh1v = (d.zh1 + b__ * PH)[h__]; } while (0)
     LOAD_OPERANDS(0);
+    if (PE) LOAD_PRE(0);
 
     for (int s = 0; s < S; ++s) {
         const unsigned slot = (unsigned)s & 3u, pslot = (unsigned)(s + 3) & 3u;                    // pslot: the slot of step s - 1
@@ -299,9 +306,11 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
                 __syncthreads();
                 mfma_part_bf16<3, 4, 0>(wb0, stg16, lane, acc0);
             } else if constexpr (SC0) {
-                if (tid < 256) sp3_put_rk(stg16, tid >> 1, 6 + (tid & 1), prv);
-                __syncthreads();
-                mfma_part_split3<3, 4>(w0s, stg16, lane, acc0);
+                if (!PE || s == 0) {          // PE: step s + 1's rows are multiplied in the flight of step s' energies (stage F)
+                    if (tid < 256) sp3_put_rk(stg16, tid >> 1, 6 + (tid & 1), prv);
+                    __syncthreads();
+                    mfma_part_split3<3, 4>(w0s, stg16, lane, acc0);
+                }
             } else {
                 if (tid < 256) *reinterpret_cast<pf32x4*>(stg + (tid >> 1) * LA + 24 + 4 * (tid & 1)) = prv;
                 __syncthreads();
@@ -455,6 +464,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         else mfma_part<4, 8, LA, 32, 64>(w0, stg, lane, acc0);
         PSTAMP(10);
         // ================= E: attention, query units and partial energies of row ab
+        if (PE) LOAD_PRE(s + 1 < S ? s + 1 : s);                      // (every wave, outside any condition: see LOAD_OPERANDS)
         unsigned long long t_e0 = 0;
         if constexpr (BF16 && M1_LATE > 1) t_e0 = wall_clock64();
         if (arow) {
@@ -535,6 +545,15 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
         }
         PSTAMP(12);
         __syncthreads();                                             // (h0 is consumed by every wave before the next step stages the context)
+        if constexpr (PE) if (s + 1 < S) {
+            // The partial energies were published a barrier ago and need ~1 us to reach the eight workgroups of the row: a request sent now or
+            // 0.5 us from now completes at the same time (swept, notes).  The prenet rows of the NEXT step's cell-0 product (teacher-forced input:
+            // independent of this step's attention) are staged and multiplied here instead of at the loop top, where they stood between the
+            // context's publication and its request with more work than that flight hides
+            if (tid < 256) sp3_put_rk(stg16, tid >> 1, 6 + (tid & 1), prv);
+            __syncthreads();
+            mfma_part_split3<3, 4>(w0s, stg16, lane, acc0);
+        }
         // ================= F: energies of the row, softmax, cumulative alignment, context columns 96 gi ..
         if (arow) {
             if (tid < 256 * NH) {                                    // 8 slices x TT energies = 256 NH pieces
@@ -620,6 +639,7 @@ __global__ __launch_bounds__(PTH) void persist_fwd_kernel(PersistFwd d) {
     }
 #undef PSTAMP
 #undef LOAD_OPERANDS
+#undef LOAD_PRE
 #undef PABORT_CHECK
 #undef PFAIL
 #undef PUBLISH_PARTIAL

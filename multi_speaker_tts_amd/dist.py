@@ -97,6 +97,14 @@ class GradAllReduce:
             if dist.is_initialized() and dist.get_backend(group) == "nccl" and grad_slab.is_cuda and os.environ.get("MSTTS_ASYNC_AGREE", "1") != "0":
                 self._flag_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None)
                 self.async_flag = True
+                # bring the communicator up NOW, while nothing else is in flight: a communicator created lazily by its first collective -
+                # at the end of the first backward pass, with the gradient buckets of the other communicator running - allocates device
+                # memory and synchronises the device in the middle of them, on every rank at a slightly different moment
+                warm = torch.ones(1, dtype=torch.int32, device=grad_slab.device)
+                dist.all_reduce(warm, op=dist.ReduceOp.MIN, group=self._flag_group)
+                torch.cuda.synchronize(grad_slab.device)
+                if int(warm.item()) != 1:
+                    raise RuntimeError("GradAllReduce: the verdict communicator's warm-up all-reduce returned %d" % int(warm.item()))
         if self.bf16 and self.active:
             import torch.distributed as dist
             self._nr = dist.get_world_size(group)                      # ranks in the exchange (1 in the forced one-rank form)

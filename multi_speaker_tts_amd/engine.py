@@ -443,6 +443,10 @@ class TrainEngine:
         w.xw0 = f(S, B, 4 * H)
         w.in0, w.in1, w.pj = f(S + 1, B, M + H), f(S + 1, B, 2 * H), f(S, B, H + M)
         w.c0, w.c1 = f(S + 1, B, H), f(S + 1, B, H)
+        if not cv.count:
+            # slot S of these histories is written by no loop (in1[S] = [m0_S | h1_{S-1}]: there is no step S; the packed operand blocks do not carry
+            # the state behind the last step) and read by none; cleared on activation so that whoever looks at a whole history sees numbers
+            cv.zero.extend([w.in1[S], w.c0[S], w.c1[S]])
         w.acts0, w.acts1 = f(S, B, 4 * H), f(S, B, 4 * H)
         w.craw0, w.craw1 = f(S, B, H), f(S, B, H)
         w.q_hist, w.align_hist, w.cum_hist = f(S, B, A), f(S, B, Te), f(S + 1, B, Te)

@@ -16,6 +16,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py --steps 10 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench_line.err
 python $ROOT/bench.py --steps 10 --warmup 3 --config3 --no-cpu-baseline > $OUT/bench_line_config3.json 2>> $OUT/bench_line.err
+python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --force-allreduce 2>> $OUT/bench_line.err | tail -1 > $OUT/bench_line_one_rank_rccl.json
+python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --force-allreduce --config3 2>> $OUT/bench_line.err | tail -1 > $OUT/bench_line_one_rank_rccl_config3.json
+python $ROOT/tools/train_surface_bench.py > $OUT/train_surface.json 2>> $OUT/bench_line.err
+MSTTS_FEEDER_WORKERS=0 python $ROOT/tools/train_surface_bench.py > $OUT/train_surface_loader_in_the_producer_thread.json 2>> $OUT/bench_line.err
 rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/kt.log 2>&1
 python $ROOT/tools/rocpd_stats.py $OUT/kt/kt_results.db $OUT/train_step_kernel_stats.csv
 rocprofv3 --kernel-trace -d $OUT/kt3 -o kt -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --config3 > $OUT/kt3.log 2>&1
@@ -36,9 +40,12 @@ python $ROOT/tools/infer_bench.py > $OUT/infer_line.txt 2> $OUT/infer.err
 rocprofv3 --kernel-trace -d $OUT/kt_inf -o kt -- python $ROOT/tools/infer_bench.py > $OUT/kt_inf.log 2>&1
 python $ROOT/tools/rocpd_stats.py $OUT/kt_inf/kt_results.db $OUT/infer_kernel_stats.csv
 python $ROOT/tools/rocpd_gaps.py $OUT/kt/kt_results.db $OUT/train_step_gaps.txt
+python $ROOT/tools/rocpd_timeline.py $OUT/kt/kt_results.db $OUT/train_step_timeline.txt
+rocprofv3 --kernel-trace -d $OUT/ktr -o kt -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --force-allreduce > $OUT/ktr.log 2>&1
+python $ROOT/tools/rocpd_timeline.py $OUT/ktr/kt_results.db $OUT/one_rank_rccl_timeline.txt
 python $ROOT/tools/gemm_step_profile.py > $OUT/gemm_step_profile.txt 2> /dev/null
 python $ROOT/tools/lstm_bench.py > $OUT/lstm_bench.txt 2> /dev/null
 python $ROOT/tools/aux_trainers_bench.py > $OUT/aux_trainers.txt 2> /dev/null
 python $ROOT/tools/persist_stamps.py > $OUT/persist_stamps_per_workgroup.txt 2> /dev/null
-rm -rf $OUT/kt $OUT/kt3 $OUT/kt_stft $OUT/kt_inf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcm_*
+rm -rf $OUT/ktr $OUT/kt $OUT/kt3 $OUT/kt_stft $OUT/kt_inf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcm_*
 ls -la $OUT

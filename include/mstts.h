@@ -91,7 +91,12 @@ int mstts_gemm_split_big(int32_t on);
 int mstts_gemm_big_min_workgroups(int32_t f32_split, int32_t bf16);
 /* Per calling thread.  1: mstts_gemm_f32 makes no K-cut the caller did not ask for with split_k (body + tail schedule and the full cut of
  * short tile lists off): every output element is one fixed-order sum, bit-reproducible run to run.  0 (default): the schedules of DESIGN 4.7,
- * whose cut tiles are summed with atomics (reproducible to the last bit or two).  The inference engines set it around their forward passes. */
+ * whose cut tiles are summed with atomics (reproducible to the last bit or two).  The inference engines set it around their forward passes.
+ * The same switch selects the fixed-order forms of the other reductions a train step contains: the column sums behind mstts_bn_train_fwd / _bwd /
+ * mstts_colsum (one workgroup per 64 columns instead of atomics across row chunks), mstts_embedding_bwd (one thread per table column) and
+ * mstts_lsa_param_bwd's d_keys (one workgroup per (row, tile) over all steps).  With split_k = 1 in every descriptor a train step is then
+ * bit-reproducible (TrainEngine(deterministic=True)); the loss scalars of mstts_tts_loss_fwd_bwd / mstts_l2_loss_acc stay atomic sums (they feed
+ * nothing).  Slow: a debugging mode. */
 int mstts_gemm_deterministic(int32_t on);
 /* The same contraction with both operands rounded to bf16 (round-to-nearest-even) on their way into LDS, fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, fp32 A / B / C in memory (BASELINE config 3: "bf16 with fp32 master").  Same descriptor, same modes.

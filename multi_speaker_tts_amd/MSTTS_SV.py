@@ -104,7 +104,10 @@ class _BatchUploader:
             cap = max(n, int(1.25 * h.numel()) if h is not None else n)
             tdt = torch.from_numpy(np.zeros(1, np_dtype)).dtype
             slot["host"][name] = torch.zeros(cap, dtype=tdt).pin_memory()
-            slot["dev"][name] = torch.zeros(cap, dtype=tdt, device=self.device)
+            # (empty, not zeros: a fill kernel would run on the CALLER's stream, unordered with the copy stream - it could land behind the first
+            #  upload and wipe the batch.  That race was real: parameters went non-finite in the first steps of 2 of 6 in-bench runs, r06 notes.)
+            slot["dev"][name] = torch.empty(cap, dtype=tdt, device=self.device)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))      # ... and whatever the allocator's previous owner of these bytes still has in flight
         return slot["host"][name], slot["dev"][name]
 
     def stage(self, pattern):

@@ -111,6 +111,18 @@ __global__ void embedding_bwd_kernel(const int32_t* __restrict__ tok, const floa
     }
 }
 
+// fixed-order form (mstts_gemm_deterministic(1)): a thread owns one column of the table and walks the rows in order - no atomics
+__global__ void embedding_bwd_det_kernel(const int32_t* __restrict__ tok, const float* __restrict__ dout,
+                                         float* __restrict__ dtable, long n, int vocab, int width) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    for (long row = 0; row < n; ++row) {
+        int t = tok[row];
+        t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+        dtable[(long)t * width + c] += dout[row * width + c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // column reductions over [rows, C]: each block owns 64 columns x a row chunk; threads (cx, ry) =
 // (64 columns, 4 row lanes); partial sums go out with one atomic per column per block.
@@ -878,8 +890,14 @@ extern "C" int mstts_embedding_fwd(const int32_t* token, const float* table, flo
     MSTTS_CHECK_LAUNCH("embedding_fwd");
     return MSTTS_OK;
 }
+namespace mstts { int gemm_deterministic_now(); }       // csrc/gemm.hip: the calling thread asked for fixed summation orders (mstts_gemm_deterministic)
 extern "C" int mstts_embedding_bwd(const int32_t* token, const float* dout, float* dtable, int64_t n, int64_t vocab, int64_t width, mstts_stream_t s) {
     if (n == 0) return MSTTS_OK;
+    if (gemm_deterministic_now()) {
+        hipLaunchKernelGGL(embedding_bwd_det_kernel, dim3(cdiv(width, 64)), dim3(64), 0, ST(s), token, dout, dtable, (long)n, (int)vocab, (int)width);
+        MSTTS_CHECK_LAUNCH("embedding_bwd (fixed order)");
+        return MSTTS_OK;
+    }
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(n * width, 256)), dim3(256), 0, ST(s), token, dout, dtable, (long)n, (int)vocab, (int)width);
     MSTTS_CHECK_LAUNCH("embedding_bwd");
     return MSTTS_OK;
@@ -901,6 +919,13 @@ static int rows_per_block_for(int64_t rows, int64_t C) {
 
 static void launch_col_stats(const float* x, const float* dy, const uint8_t* mask, float inv_keep, const float* mean, const float* rstd,
                              long rows, int C, long ld, int mode, float* out0, float* out1, hipStream_t st) {
+    if (gemm_deterministic_now()) {
+        // fixed summation order: ONE workgroup per 64 columns walks all the rows (4 row lanes, combined in a fixed order), so every output
+        // element receives exactly one add - slow (C / 64 workgroups), reproducible bit for bit
+        dim3 grid(cdiv(C, 64), 1);
+        hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, st, x, dy, mask, inv_keep, mean, rstd, rows, C, ld, (int)(rows < (1L << 30) ? rows : (1L << 30)), mode, out0, out1);
+        return;
+    }
     const bool v4 = C % 4 == 0 && ld % 4 == 0 && aligned16(x) && (mode == 0 || (aligned16(dy) && aligned16(mean) && aligned16(rstd) &&
                                                                                  (!mask || ((uintptr_t)mask & 3) == 0)));
     if (v4) {

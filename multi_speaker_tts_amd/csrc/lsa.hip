@@ -1570,10 +1570,12 @@ extern "C" int mstts_lsa_step_bwd(const mstts_lsa_const* c, const float* d_ctx, 
     MSTTS_CHECK_LAUNCH("lsa_step_bwd");
     return MSTTS_OK;
 }
-static void lsa_param_geometry(long B, long T, long S, int* nt, int* chunks, int* spb) {
+namespace mstts { int gemm_deterministic_now(); }       // csrc/gemm.hip
+static void lsa_param_geometry(long B, long T, long S, int* nt, int* chunks, int* spb, bool fixed_order) {
     *nt = cdiv(T, PT);
     int ch = (int)(2048 / (B * *nt));
     if (ch < 1) ch = 1;
+    if (fixed_order) ch = 1;                     // fixed summation order: one workgroup walks ALL the steps of its (row, tile), so d_keys receives one add per element
     if (ch > S) ch = (int)S;
     *spb = cdiv(S, ch);
     *chunks = cdiv(S, *spb);
@@ -1581,7 +1583,7 @@ static void lsa_param_geometry(long B, long T, long S, int* nt, int* chunks, int
 extern "C" int64_t mstts_lsa_param_bwd_ws_floats(int64_t B, int64_t T, int64_t S) {
     if (B < 1 || T < 1 || S < 1) return 0;
     int nt, chunks, spb;
-    lsa_param_geometry(B, T, S, &nt, &chunks, &spb);
+    lsa_param_geometry(B, T, S, &nt, &chunks, &spb, false);          // (the larger of the two geometries)
     return (int64_t)B * nt * chunks * (LP_ROWS * A_) + 2 * (int64_t)LP_GROUPS * (LP_ROWS * A_);      // partial blocks, then LP_GROUPS blocks of doubles
 }
 extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const float* q_hist, const float* cum_hist, const float* de_hist,
@@ -1590,7 +1592,7 @@ extern "C" int mstts_lsa_param_bwd(const mstts_lsa_const* c, int64_t S, const fl
     if (S <= 0) return MSTTS_OK;
     MSTTS_REQUIRE(!ws || (reinterpret_cast<uintptr_t>(ws) & 7u) == 0, MSTTS_ERR_ALIGN, "lsa_param_bwd: the workspace must be 8-byte aligned");
     int nt, chunks, spb;
-    lsa_param_geometry(c->B, c->T, S, &nt, &chunks, &spb);
+    lsa_param_geometry(c->B, c->T, S, &nt, &chunks, &spb, gemm_deterministic_now() != 0);
     hipLaunchKernelGGL(lsa_param_bwd_kernel, dim3((unsigned)c->B, nt, chunks), dim3(256), 0, ST(s), *c, (int)S, spb, q_hist, cum_hist,
                        de_hist, d_keys, d_loc_k, d_score_w, d_score_b, ws);
     MSTTS_CHECK_LAUNCH("lsa_param_bwd");

@@ -156,10 +156,14 @@ class _Carver:
 class TrainEngine:
     def __init__(self, dims: Dims = None, device="cuda", seed=1234, rank=0, world=1, values=None,
                  update_vocoder_bn=True, use_l1=None, wr_rate=None, adam=None, recurrent_dtype=None, gemm_dtype=None, fuse_query=True,
-                 arena_hint=None):
+                 arena_hint=None, deterministic=None):
         """recurrent_dtype: 'f32' (default; BASELINE config 2) or 'bf16' (config 3: the decoder's recurrent products run on
         bf16 copies of the fp32 master weights with fp32 accumulation).
-        arena_hint: (B, T_enc, L) of the largest batch to expect - the workspace arena is sized for it once, so no later shape allocates."""
+        arena_hint: (B, T_enc, L) of the largest batch to expect - the workspace arena is sized for it once, so no later shape allocates.
+        deterministic (default: MSTTS_DETERMINISTIC=1 in the environment): train_step runs with every summation order fixed - no reduction
+        cut the engine or the library would choose (split_k = 1 everywhere, mstts_gemm_deterministic), column sums / the embedding scatter /
+        the attention parameter gradients in their one-add-per-element forms - so two runs from the same state end bit-identical
+        (tests/test_gpu_model.py::test_deterministic_training_is_bit_reproducible).  A debugging mode: roughly 1.5 x the step time."""
         lib.load()
         self.d = dims or Dims()
         self.device = torch.device(device)
@@ -176,6 +180,7 @@ class TrainEngine:
         self._active_plan = None  # the set whose activation fills were run last (a set of another shape has used the same bytes since otherwise)
         self._pinned = {}         # page-locked read-back blocks of the persistent launches' control words, shared by every set
         self.arena_hint = arena_hint
+        self.deterministic = (os.environ.get("MSTTS_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
         self.arena_poison = os.environ.get("MSTTS_ARENA_POISON", "0") == "1"     # tests: NaN over a set's whole extent whenever it is activated
         self.global_step = 0
         d = self.d
@@ -281,6 +286,10 @@ class TrainEngine:
         contractions that have no dense-layer counterpart in the reference graph (d_values from the alignments, the vocoder's
         statistics side effect) in fp32 in either mode."""
         bf = self.gemm_dtype == "bf16" and not exact
+        if self.deterministic and k.get("split_k", 1) > 1:
+            # one piece: the pieces of a cut product meet in atomic adds, whose order is not fixed.  The callers of cut products add onto a
+            # cleared (or, with accumulate, a live) output, so the single piece accumulates too.
+            k["split_k"], k["accumulate"] = 1, True
         if k.get("split_k", 1) > 1 and self.big_tiles:       # (the split was chosen for 128 x 128 tiles; the large contractions run 256 x 256 ones)
             big = _split_k_big(a[3], a[4], a[5], None)
             if big is not None:
@@ -1221,8 +1230,11 @@ class TrainEngine:
             self._scalar_ring = torch.zeros(4, 4, dtype=torch.float32).pin_memory()
             self._scalar_next = 0
             self._scalar_avg = torch.zeros(4, dtype=torch.float32, device=self.device)
+            self._scalar_handles = [None] * 4
+        old = self._scalar_handles[self._scalar_next]
+        if old is not None:
+            old.get()                        # a handle nobody has read yet takes its words out of the slot before the slot is used again (its copy ended steps ago)
         slot = self._scalar_ring[self._scalar_next]
-        self._scalar_next = (self._scalar_next + 1) % 4
         src = w.scalars
         if average:
             from .dist import average_
@@ -1232,7 +1244,9 @@ class TrainEngine:
         slot.copy_(src, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return _LateScalars(ev, slot, self.wr_rate)
+        h = self._scalar_handles[self._scalar_next] = _LateScalars(ev, slot, self.wr_rate)
+        self._scalar_next = (self._scalar_next + 1) % 4
+        return h
 
     def exchange_timeouts(self, w):
         """Count of in-launch exchange time-outs of the single-launch forward attention kernel in the last step on workspace `w`
@@ -1252,6 +1266,9 @@ class TrainEngine:
 
     def train_step(self, batch, masks=None, all_reduce=None):
         """One full iteration: forward, loss, backward, (gradient all-reduce), Adam."""
+        if self.deterministic and not getattr(lib.deterministic_gemm._depth, "n", 0):
+            with lib.deterministic_gemm():
+                return self.train_step(batch, masks=masks, all_reduce=all_reduce)
         B, Te = batch["Token"].shape
         L = batch["Mel"].shape[1]
         w = self.plan(B, Te, L)

@@ -1166,3 +1166,28 @@ def test_mel_to_spectrogram_reference_widths(dev):
     assert abs(float(np.sqrt((emb.astype(np.float64) ** 2).sum())) - 1.0) < 1e-5          # Q14: the WHOLE [B, 256] tensor has unit norm
     if lib.load().mstts_persist_lstm_fwd_supported_n(B, pd.birnn, 2):
         assert eng.persist_lstm_launches - n0 == 1 + pd.spk_lstm_n and eng.persist_lstm_fallbacks == 0
+
+
+def test_batch_uploader_first_upload_survives_a_busy_device(dev):
+    """Round-6 race, found as non-finite parameters in the first steps of 2 of 6 Tacotron2.Train_Step runs inside a busy process: the upload
+    blocks were zero-filled on the CALLER's stream and written on the copy stream, unordered - the fill could land behind the first upload.
+    Here: a fresh uploader per round, the caller's stream kept busy with fills in front of the first stage(); what arrives on the device must
+    be the pattern, every round, for both slots."""
+    from multi_speaker_tts_amd.MSTTS_SV import _BatchUploader
+    g = np.random.default_rng(0)
+    junk = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    for rnd in range(12):
+        pats = [{"Token": g.integers(2, 40, size=(32, 100 + rnd)).astype(np.int32), "Token_Length": np.full(32, 100 + rnd, np.int32),
+                 "Mel": g.normal(0, 1, size=(32, 300 + 7 * rnd, 80)).astype(np.float32), "Mel_Length": np.full(32, 300, np.int32),
+                 "Speaker_Embedding_Mel": g.normal(0, 1, size=(160, 64, 80)).astype(np.float32)} for _ in range(3)]
+        for _ in range(6):
+            junk.fill_(float(rnd))                                     # ~0.1 ms each of queued work on the caller's stream
+        up = _BatchUploader(dev, presize={"Token": 32 * 256, "Mel": 32 * 721 * 80, "Speaker_Embedding_Mel": 160 * 64 * 80})
+        for p in pats:
+            b = up.stage(p)
+            torch.cuda.current_stream().wait_event(b["_uploaded"])
+            got = {k: b[k].clone() for k in p}
+            up.release(b)
+            torch.cuda.synchronize()
+            for k in p:
+                assert np.array_equal(t2n(got[k]), p[k]), (rnd, k)

@@ -87,7 +87,22 @@ def run(steps=50, warmup=3, keep=None, device="cuda:0", seed=0, quiet=True):
         results = [t.Train_Step() for _ in range(steps)]
         torch.cuda.synchronize()
         surface_ms = 1e3 * (time.perf_counter() - t0) / steps
-        losses = [float(r["Loss"]) for r in results]
+        eng = t.train_engine
+        losses, first_bad = [], None
+        for i, r in enumerate(results):
+            try:
+                losses.append(float(r["Loss"]))
+            except FloatingPointError:
+                losses.append(float("nan"))
+                if first_bad is None:
+                    first_bad = i
+        if first_bad is not None:
+            shp = lambda p: (int(p["Token"].shape[0]), int(p["Token"].shape[1]), int(p["Mel"].shape[1]))
+            seq = [shp(p) for p in taken[first:first + steps]]
+            raise FloatingPointError("non-finite loss from timed step %d on (shape %r, the one before %r); fallbacks fwd %d bptt %d enc %d, speaker redos %d, "
+                                     "disabled steps %d, parameters finite: %s" % (first_bad, seq[first_bad], seq[first_bad - 1] if first_bad else None,
+                                     eng.persist_fallbacks, eng.persist_bwd_fallbacks, eng.persist_enc_fallbacks, eng.speaker_ticket_redos,
+                                     eng.persist_disabled_steps, bool(torch.isfinite(eng.params.train).all())))
         host = {k: (1e3 * v / steps if k not in ("steps", "prefetched") else v) for k, v in t.host_seconds.items()}
         host["queue_length_at_end"] = len(t.feeder.pattern_Queue)
         host["feeder_workers"] = getattr(t.feeder, "_workers", 0)

@@ -1191,3 +1191,42 @@ def test_batch_uploader_first_upload_survives_a_busy_device(dev):
             torch.cuda.synchronize()
             for k in p:
                 assert np.array_equal(t2n(got[k]), p[k]), (rnd, k)
+
+
+@pytest.mark.parametrize("cfg", ["reference widths, persistent launches"])
+def test_deterministic_training_is_bit_reproducible(dev, cfg):
+    """TrainEngine(deterministic=True) fixes every summation order of a train step - no reduction cut chosen by
+    the engine or the library (split_k = 1, mstts_gemm_deterministic), the column sums behind batch norm / bias gradients, the embedding
+    scatter and the attention layer's d_keys in their one-add-per-element forms - so two engines started from the same variables, fed the same
+    batches, end BIT-IDENTICAL after three optimizer steps: every variable, both Adam slots, the batch-norm moving statistics, the gradient
+    slab of the last step.  (The default mode's atomics leave the last bit or two open: recorded beside it, not asserted.)
+    Scope: the path the reference widths take - the persistent launches.  The launch-per-step fallback loops (other widths, or a launch that
+    gave up) cut their skinny products along K with atomics of their own and are NOT covered: measured 8.6e-7 between two such runs."""
+    from tests.helpers import dims_pair
+    ref = cfg.startswith("reference")
+    kw = dict(emb=64, enc_conv_ch=64, enc_lstm=256, spk=256, prenet=256, dec_lstm=1024, n_mel=80, post_ch=64) if ref else dict(MID)
+    pd, od = dims_pair(**kw)
+    values = OM.init_params(od, 5)
+    shapes = [(4, 33, 21), (3, 40, 12), (4, 33, 21)]
+    batches = [to_dev(OT.synthetic_batch(od, B, Te, L, seed=30 + i, ragged=True), dev) for i, (B, Te, L) in enumerate(shapes)]
+
+    def run(det):
+        eng = TrainEngine(pd, device=dev, values=values, seed=11, deterministic=det)
+        assert eng.deterministic == det
+        for b in batches:
+            w = eng.train_step(b)
+        torch.cuda.synchronize()
+        if ref:
+            assert w.persist and eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0 and eng.persist_enc_fallbacks == 0
+        ps = eng.params
+        return {"train": ps.train.clone(), "m": ps.adam_m.clone(), "v": ps.adam_v.clone(), "frozen": ps.frozen.clone(), "grad": ps.grad.clone()}, eng.scalars(w)["Loss"]
+    a, la = run(True)
+    b, lb = run(True)
+    for k in a:
+        assert bool(torch.isfinite(a[k]).all()), k
+        assert torch.equal(a[k], b[k]), "%s differs between two deterministic runs: max |d| %g" % (k, float((a[k] - b[k]).abs().max()))
+    assert abs(la - lb) <= 1e-5 * max(1.0, abs(la))                      # (the loss words themselves stay atomic sums: they feed nothing)
+    c, lc = run(False)
+    d = {k: float((a[k] - c[k]).abs().max() / (a[k].abs().max() + 1e-30)) for k in a}
+    print("deterministic vs default schedule after 3 steps (max |difference| / max |value|):", d)
+    assert all(v < 2e-3 for v in d.values()), d                         # same arithmetic, other summation orders

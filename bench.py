@@ -352,6 +352,10 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # the library is loaded (and, should its sources have changed, rebuilt behind a file lock - minutes, one rank at a time) BEFORE the
+    # process group exists: nothing with a collective time-out is waiting for a rank that is still compiling
+    from multi_speaker_tts_amd import lib as _lib_early
+    _lib_early.load()
     dist = None
     if world > 1 or args.force_allreduce:
         import torch.distributed as dist

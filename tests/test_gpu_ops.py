@@ -487,6 +487,23 @@ def test_gemm_bf16_cuts_short_tile_lists_along_k(dev):
     assert rel_err(outs[0], ref) < TOL
 
 
+def test_gemm_bf16_honours_a_callers_cut(dev):
+    """mstts_gemm_bf16 used to re-choose a caller's split_k for its own tiles (only an uncut call is the library's to cut now, like
+    mstts_gemm_f32).  Observable: exactly TWO pieces onto a zeroed output are order-free (0 + p + q is the same float whichever atomic lands
+    first), so ten runs are bit-equal - on the shape of the test above, which the library by itself cuts into more pieces than two."""
+    M, N, K = 512, 1000, 4096
+    A = _r(dev, M, K, seed=1); B = _r(dev, K, N, seed=2, scale=1.0 / np.sqrt(K))
+    ref = _bf(A).cpu().numpy().astype(np.float64) @ _bf(B).cpu().numpy().astype(np.float64)
+    first = None
+    for _ in range(10):
+        Cm = torch.zeros(M, N, device=dev)
+        _gemm_call("mstts_gemm_bf16", A, B, Cm, M, N, K, K, N, N, split_k=2)
+        if first is None:
+            first = Cm.clone()
+            assert rel_err(t2n(Cm), ref) < TOL
+        assert torch.equal(Cm, first)
+
+
 def test_gemm_bf16_conv_window_splitk(dev):
     """Implicit-im2col conv forward, weight gradient (transposed window, split-K atomics) and accumulate on the bf16 GEMM."""
     B_, T, cin, cout, K = 3, 37, 16, 24, 5

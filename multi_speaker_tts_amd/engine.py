@@ -138,13 +138,15 @@ class _Carver:
     def __init__(self, arena, count):
         self.arena, self.count, self.off = arena, count, 0
         self.zero = []                       # views that must read as zeros when their set is activated (flag / counter workspaces)
+        self.overflow = False                # carving ran past the arena's end: the walk goes on counting, its views are None from there on
 
     def take(self, shape, dtype=torch.float32, zero=False):
         n = int(np.prod(shape)) if not isinstance(shape, int) else int(shape)
         size = torch.empty(0, dtype=dtype).element_size()
         nbytes = (n * size + _Arena.ALIGN - 1) // _Arena.ALIGN * _Arena.ALIGN
         off, self.off = self.off, self.off + max(nbytes, _Arena.ALIGN)
-        if self.count:
+        if self.count or self.off > self.arena.cap:
+            self.overflow = self.overflow or not self.count
             return None
         t = self.arena.buf[off:off + n * size].view(dtype)
         t = t.view(shape) if not isinstance(shape, int) else t
@@ -396,16 +398,20 @@ class TrainEngine:
         if w is not None and w.arena_generation == self._arena.generation:
             self._plans[key] = self._plans.pop(key)          # most recently used last
         else:
-            need = self._build_plan(B, Te, L, _Carver(self._arena, True))[1]
-            if self._arena.buf is None and self.arena_hint is not None:
-                hb, ht, hl = self.arena_hint
-                need = max(need, self._build_plan(max(B, hb), max(Te, ht), max(L, hl), _Carver(self._arena, True))[1])
-            if self._arena.ensure(need):
-                self._plans.clear()                          # (sets carved from the old buffer stay valid for whoever holds them; they are not handed out again)
-                self._active_plan = None
+            # one walk in the usual case (the arena covers the shape: carve at once); a walk that runs past the arena's end keeps counting, the
+            # arena grows to what it counted (to the hint's size the first time) and the shape is walked again
+            cv = _Carver(self._arena, self._arena.buf is None)
+            w, need = self._build_plan(B, Te, L, cv)
+            if cv.count or cv.overflow:
+                if self._arena.buf is None and self.arena_hint is not None:
+                    hb, ht, hl = self.arena_hint
+                    need = max(need, self._build_plan(max(B, hb), max(Te, ht), max(L, hl), _Carver(self._arena, True))[1])
+                if self._arena.ensure(need):
+                    self._plans.clear()                      # (sets carved from the old buffer stay valid for whoever holds them; they are not handed out again)
+                    self._active_plan = None
+                w = self._build_plan(B, Te, L, _Carver(self._arena, False))[0]
             while len(self._plans) >= MAX_PLANS:
                 self._plans.pop(next(iter(self._plans)))
-            w = self._build_plan(B, Te, L, _Carver(self._arena, False))[0]
             self._plans[key] = w
         if self._active_plan is not w:
             self._activate(w)
@@ -453,7 +459,7 @@ class TrainEngine:
         w.xw0 = f(S, B, 4 * H)
         w.in0, w.in1, w.pj = f(S + 1, B, M + H), f(S + 1, B, 2 * H), f(S, B, H + M)
         w.c0, w.c1 = f(S + 1, B, H), f(S + 1, B, H)
-        if not cv.count:
+        if w.in1 is not None and w.c0 is not None and w.c1 is not None:
             # slot S of these histories is written by no loop (in1[S] = [m0_S | h1_{S-1}]: there is no step S; the packed operand blocks do not carry
             # the state behind the last step) and read by none; cleared on activation so that whoever looks at a whole history sees numbers
             cv.zero.extend([w.in1[S], w.c0[S], w.c1[S]])
@@ -476,7 +482,7 @@ class TrainEngine:
             w.enc_bws = f(int(lb.mstts_persist_lstm_bwd_floats(Te)))
             w.enc_hist_valid = False
         w.persist = self.persist and bool(lb.mstts_persist_fwd_supported(B, H, M, A, Te, d.att_k))
-        if self.persist and not w.persist and not cv.count:
+        if self.persist and not w.persist and not cv.count and not cv.overflow:
             # the device and the widths admit the persistent launches, this batch shape does not: ~1.7x slower loop - say so, once per shape
             self.non_persistent_plans += 1
             if (B, Te) not in self._warned_shapes:
@@ -550,7 +556,7 @@ class TrainEngine:
         w.zero_on_activate = cv.zero
         w.extent_bytes = cv.off
         w.arena_generation = self._arena.generation
-        return (None if cv.count else w), cv.off
+        return (None if (cv.count or cv.overflow) else w), cv.off
 
     # ------------------------------------------------------------------ conv blocks
     def _conv_fwd(self, x, x_off, rows, T, cin, cout, K, kname, bname, out, act):

@@ -237,18 +237,24 @@ def _load_pattern_batch_into(names, token_dict, root, shm_name, shm_size):
     """Loader process: load_pattern_batch, the arrays written into the shared-memory block `shm_name` (a 10 MB batch through the pool's result
     pipe costs the parent more than loading it itself would).  Returns ("shm", [(key, dtype, shape, offset)]) or - a batch that does not
     fit the block - ("value", pattern)."""
-    from multiprocessing import shared_memory
+    import mmap
     p = load_pattern_batch(names, token_dict, pattern_path=root)
     need = sum((p[k].nbytes + 63) // 64 * 64 for k in _SHM_KEYS)
     if need > shm_size:
         return "value", p
-    shm = _worker_shm.get(shm_name)
-    if shm is None:
-        shm = _worker_shm[shm_name] = shared_memory.SharedMemory(name=shm_name)
+    buf = _worker_shm.get(shm_name)
+    if buf is None:
+        # (mapped as a file, not through multiprocessing.shared_memory: attaching there registers the block with the resource tracker a second
+        #  time, and the tracker then complains about the parent's unlink)
+        fd = os.open("/dev/shm/" + shm_name.lstrip("/"), os.O_RDWR)
+        try:
+            buf = _worker_shm[shm_name] = mmap.mmap(fd, shm_size)
+        finally:
+            os.close(fd)
     layout, off = [], 0
     for k in _SHM_KEYS:
         a = np.ascontiguousarray(p[k])
-        np.ndarray(a.shape, a.dtype, buffer=shm.buf, offset=off)[...] = a
+        np.ndarray(a.shape, a.dtype, buffer=buf, offset=off)[...] = a
         layout.append((k, a.dtype.str, a.shape, off))
         off += (a.nbytes + 63) // 64 * 64
     return "shm", layout
@@ -306,6 +312,11 @@ class Feeder:
             B = int(hp.Train.Batch_Size)
             self._shm_size = 4 * (B * frames * hp.Sound.Mel_Dim + B * inf.Sample_Nums * inf.Mel_Frame * hp.Sound.Mel_Dim + B * 258) + 4096
             self._pool = ProcessPoolExecutor(max_workers=self._workers, mp_context=multiprocessing.get_context("fork"))
+            # fork the loaders NOW, from the constructing thread (Tacotron2 builds its feeder before its engines): the executor would otherwise
+            # fork them on first use, from the producer thread, in the middle of the main thread's GPU work
+            import time as _time
+            for fut in [self._pool.submit(_time.sleep, 0.05) for _ in range(self._workers)]:
+                fut.result()
         if hp.Train.Use_Pre_in_Main_Train:
             self.pre_Pattern_Queue = deque()
             Thread(target=self.Train_Pattern_Generate, args=[True], daemon=True).start()

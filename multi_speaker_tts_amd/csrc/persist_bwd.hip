@@ -26,7 +26,22 @@
 #ifndef BG0_LATE
 #define BG0_LATE 10             // ticks (10 ns) between the cell-0 update's publications and the gather of the gate gradients for the d[g0] product
 #endif
+#ifndef BSPLIT_C1
+#define BSPLIT_C1 0             // experiment (round 6): 1 = the on-chain half of the cell-1 data-gradient product as an exact three-way bf16 split, six products on v_mfma_f32_16x16x32_bf16
+#endif
+#ifndef BSPLIT_RECON
+#define BSPLIT_RECON 0          // with BSPLIT_C1: 1 = the shadow half's fp32 gate gradients rebuilt from the planes instead of kept in registers beside them
+#endif
 namespace mstts {
+
+// x[0..7] -> the three bf16 planes (exact: both remainders are representable in fp32)
+__device__ __forceinline__ void bsp_split8(const float (&x)[8], pbf16x8& hi, pbf16x8& mid, pbf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)x[e]; const float r1 = x[e] - (float)hi[e];
+        mid[e] = (__bf16)r1; lo[e] = (__bf16)(r1 - (float)mid[e]);
+    }
+}
 
 // ring sizes in floats per slot
 constexpr long BDG = 8L * 8 * 2 * 4 * 256;       // gate gradients of one cell: [slice 8][eighth 8][row tile 2][group 4][lane 64][4 units]
@@ -123,14 +138,28 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 
     // ---------------- once: the transposed kernels of this workgroup / wave -> registers.  w1t[h * 32 + kt * 16 + ks]: half h (0 = the
     // rows on the chain: m0 units, 1 = h1 units), output tile kt, contraction step ks of this wave's eighth; w0t likewise (context / h0)
-    float w1t[BF16 ? 1 : 64], w0t[BF16 ? 1 : 64];
+    constexpr bool BS1 = BSPLIT_C1 != 0 && !BF16;
+    float w1t[BF16 ? 1 : (BS1 ? 32 : 64)], w0t[BF16 ? 1 : 64];   // BS1: w1t holds half 1 (the recurrent-state rows) only
     pbf16x8 wb1t[BF16 ? 8 : 1], wb0t[BF16 ? 8 : 1];              // BF16: the same values as packed octets (contraction steps 8 j .. 8 j + 7 of a (half, tile))
+    pbf16x8 w1s[3][BS1 ? 4 : 1];                                 // BS1: half 0 of the cell-1 kernel as three planes, [plane][kt * 2 + j]
     {
         const float* p1 = d.w1t + ((long)(g * 8 + wave) * 64) * 64 + lane;
         const float* p0 = d.w0t + ((long)(g * 8 + wave) * 64) * 64 + lane;
         if constexpr (BF16) {
 #pragma unroll
             for (int r = 0; r < 64; ++r) { wb1t[r >> 3][r & 7] = (__bf16)p1[r * 64]; wb0t[r >> 3][r & 7] = (__bf16)p0[r * 64]; }
+        } else if constexpr (BS1) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {          // (kt, j) = (o >> 1, o & 1): registers kt * 16 + 8 j + e of half 0
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = p1[((o >> 1) * 16 + 8 * (o & 1) + e) * 64];
+                bsp_split8(x, w1s[0][o], w1s[1][o], w1s[2][o]);
+            }
+#pragma unroll
+            for (int r = 0; r < 32; ++r) w1t[r] = p1[(32 + r) * 64];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) w0t[r] = p0[r * 64];
         } else {
 #pragma unroll
             for (int r = 0; r < 64; ++r) w1t[r] = p1[r * 64];
@@ -469,7 +498,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         PSTAMP(7);
         // ================= products: a wave's eighth of the gate gradients -> B-operand registers, 64 MFMAs on the chain, the 8 partial
         // tiles meet in LDS, leave as one tile; then the 64 MFMAs of the recurrent-state rows in the shadow of that hand-off
-#define PROD_GATHER(OFF_DG)                                                                                                           \
+#define PROD_GATHER(OFF_DG, SPLB)                                                                                                     \
         pf32x4 bq[8];                                                                                                                \
         {                                                                                                                            \
             unsigned off[8];                                                                                                         \
@@ -482,8 +511,16 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         if constexpr (BF16) {                                                                                                        \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                            \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) bqh[x][e] = (__bf16)bq[(x >> 1) * 4 + 2 * (x & 1) + (e >> 2)][e & 3];  \
+        }                                                                                                                            \
+        pbf16x8 bqs[3][(BS1 && (SPLB) && BSPLIT_RECON != 0) ? 4 : 1];   /* BS1 + RECON: the gate gradients as three planes, [plane][t * 2 + j] */ \
+        if constexpr (BS1 && (SPLB) && BSPLIT_RECON != 0) {                                                                          \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                                          \
+                float f__[8];                                                                                                        \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) f__[e] = bq[(x >> 1) * 4 + 2 * (x & 1) + (e >> 2)][e & 3];             \
+                bsp_split8(f__, bqs[0][x], bqs[1][x], bqs[2][x]);                                                                    \
+            }                                                                                                                        \
         }
-#define PROD_HALF(half, WT, WB, OFF_OUT, IS_CTX)                                                                                      \
+#define PROD_HALF(half, WT, WBASE, WB, OFF_OUT, IS_CTX, SPL, RECON)                                                                   \
         {                                                                                                                            \
             pf32x4 acc[2][2];                                                                                                        \
             _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
@@ -494,12 +531,54 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                         acc[kt][0] = PMFMA_BF16(WB[(half) * 4 + kt * 2 + j], bqh[j], acc[kt][0]);                                     \
                         acc[kt][1] = PMFMA_BF16(WB[(half) * 4 + kt * 2 + j], bqh[2 + j], acc[kt][1]);                                 \
                     }                                                                                                                \
-            } else {                                                                                                                 \
-                _Pragma("unroll") for (int ks = 0; ks < 16; ++ks)                                                                    \
-                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
-                        acc[kt][0] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[ks >> 2][ks & 3], acc[kt][0]);                         \
-                        acc[kt][1] = PMFMA(WT[(half) * 32 + kt * 16 + ks], bq[4 + (ks >> 2)][ks & 3], acc[kt][1]);                   \
+            } else if constexpr (BS1 && (SPL) && BSPLIT_RECON == 0) {                                                                \
+                /* one row tile at a time: its six gate-gradient plane octets (24 registers) live only over its 24 matrix instructions     \
+                   (by (row tile, octet) - 12 registers at a time - the register allocator does worse: 44 spilled against 14) */              \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                      \
+                    pbf16x8 bp__[3][2];                                                                                              \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+                        float f__[8];                                                                                                \
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e) f__[e] = bq[t * 4 + 2 * j + (e >> 2)][e & 3];                  \
+                        bsp_split8(f__, bp__[0][j], bp__[1][j], bp__[2][j]);                                                         \
                     }                                                                                                                \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+                        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                           \
+                            pf32x4 a__ = acc[kt][t];                                                                                 \
+                            a__ = PMFMA_BF16(w1s[2][kt * 2 + j], bp__[0][j], a__);                                                   \
+                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bp__[2][j], a__);                                                   \
+                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bp__[1][j], a__);                                                   \
+                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bp__[0][j], a__);                                                   \
+                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bp__[1][j], a__);                                                   \
+                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bp__[0][j], a__);                                                   \
+                            acc[kt][t] = a__;                                                                                        \
+                        }                                                                                                            \
+                    __builtin_amdgcn_sched_barrier(0);                                                                               \
+                }                                                                                                                    \
+            } else if constexpr (BS1 && (SPL)) {                                                                                     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                 \
+                        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                              \
+                            pf32x4 a__ = acc[kt][t];                                                                                 \
+                            a__ = PMFMA_BF16(w1s[2][kt * 2 + j], bqs[0][t * 2 + j], a__);                                            \
+                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bqs[2][t * 2 + j], a__);                                            \
+                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bqs[1][t * 2 + j], a__);                                            \
+                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bqs[0][t * 2 + j], a__);                                            \
+                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bqs[1][t * 2 + j], a__);                                            \
+                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bqs[0][t * 2 + j], a__);                                            \
+                            acc[kt][t] = a__;                                                                                        \
+                        }                                                                                                            \
+            } else {                                                                                                                 \
+                _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                                                  \
+                    float b0__, b1__;                                                                                                \
+                    if constexpr (BS1 && (RECON)) {   /* the fp32 value back from its planes (hi + mid + lo is exact): bq need not stay live over the split half */ \
+                        b0__ = ((float)bqs[0][ks >> 3][ks & 7] + (float)bqs[1][ks >> 3][ks & 7]) + (float)bqs[2][ks >> 3][ks & 7];   \
+                        b1__ = ((float)bqs[0][2 + (ks >> 3)][ks & 7] + (float)bqs[1][2 + (ks >> 3)][ks & 7]) + (float)bqs[2][2 + (ks >> 3)][ks & 7]; \
+                    } else { b0__ = bq[ks >> 2][ks & 3]; b1__ = bq[4 + (ks >> 2)][ks & 3]; }                                         \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
+                        acc[kt][0] = PMFMA(WT[(WBASE) + kt * 16 + ks], b0__, acc[kt][0]);                                            \
+                        acc[kt][1] = PMFMA(WT[(WBASE) + kt * 16 + ks], b1__, acc[kt][1]);                                            \
+                    }                                                                                                                \
+                }                                                                                                                    \
             }                                                                                                                        \
             if ((half) == 1) __syncthreads();                        /* the first tile's readers are done */                         \
             _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
@@ -524,8 +603,8 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         }
         pf32x4 A0_, B0_;                      // cell-0 operands as loaded: split into activations / states / mask bits only where the update uses them
         {
-            PROD_GATHER(BO_DG1)
-            PROD_HALF(0, w1t, wb1t, BO_PM0, false)
+            PROD_GATHER(BO_DG1, true)
+            PROD_HALF(0, w1t, 0, wb1t, BO_PM0, false, true, false)
             PSTAMP(8);
             {   // operands of the cell-0 update backward: requested here, they arrive under the second half and the hand-off
                 const pf32x4* ob = reinterpret_cast<const pf32x4*>(d.opk) + opk_index(s, g0, 0, 0, tid0 & 127);
@@ -533,7 +612,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 // (no arithmetic on them here: the first use makes the compiler wait for the loads, and its vmcnt(0) - the publication just
                 //  above sits in a conditional block - also waits for that write-through store to be acknowledged: 0.5 us in this stage)
             }
-            PROD_HALF(1, w1t, wb1t, BO_PH1, false)
+            PROD_HALF(1, w1t, (BS1 ? 0 : 32), wb1t, BO_PH1, false, false, (BSPLIT_RECON != 0))
         }
         PSTAMP(9);
         // ================= cell 0, update backward
@@ -584,10 +663,10 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             // 15 / 30 / 45 / 60 ticks: frame 19.23 / 19.02 / 18.90 / 18.93 / 19.05 / 19.2 / 19.24 us; bf16: 12.86 / - / 12.70 / 12.68 / 12.77); the same pause
             // in front of the d[g1] gather moves 0.18 us from one stage into the next and gains nothing, and in front of the forward loop's requests it loses.
             if constexpr (BG0_LATE > 0) { const unsigned long long t__ = wall_clock64(); while (wall_clock64() - t__ < (unsigned long long)BG0_LATE) __builtin_amdgcn_s_sleep(1); }
-            PROD_GATHER(BO_DG0)
-            PROD_HALF(0, w0t, wb0t, BO_PM0, true)
+            PROD_GATHER(BO_DG0, false)
+            PROD_HALF(0, w0t, 0, wb0t, BO_PM0, true, false, false)
             PSTAMP(12);
-            PROD_HALF(1, w0t, wb0t, BO_PH0, false)
+            PROD_HALF(1, w0t, 32, wb0t, BO_PH0, false, false, false)
         }
         PSTAMP(13);
 #ifndef EXP_NO_OPLOAD

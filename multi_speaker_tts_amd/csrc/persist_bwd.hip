@@ -26,11 +26,29 @@
 #ifndef BG0_LATE
 #define BG0_LATE 10             // ticks (10 ns) between the cell-0 update's publications and the gather of the gate gradients for the d[g0] product
 #endif
+// Round 6 (profiles/r06_ab_bptt_*.txt): the fp32 instantiations run the on-chain half of the cell-1 data-gradient product as the exact
+// three-way bf16 split (BSPLIT_C1), with the registers for its third plane found by moving the query layer's data-gradient product to the cell-1 owners
+// (BPTT_QOWN: frees the 64 KB query-kernel slice in LDS) and the recurrent-state half of the cell-0 kernel into that LDS (BPTT_W0LDS).  Each is a build
+// option so that the A/B stays reproducible: -DBPTT_QOWN=0 is round 5's kernel.
 #ifndef BSPLIT_C1
-#define BSPLIT_C1 0             // experiment (round 6): 1 = the on-chain half of the cell-1 data-gradient product as an exact three-way bf16 split, six products on v_mfma_f32_16x16x32_bf16
+#define BSPLIT_C1 1             // 1 = the on-chain half of the cell-1 data-gradient product as an exact three-way bf16 split, six products on v_mfma_f32_16x16x32_bf16 (needs BPTT_QOWN + BPTT_W0LDS for its registers: 14 - 44 spilled without)
 #endif
-#ifndef BSPLIT_RECON
-#define BSPLIT_RECON 0          // with BSPLIT_C1: 1 = the shadow half's fp32 gate gradients rebuilt from the planes instead of kept in registers beside them
+#ifndef BPTT_QOWN
+#define BPTT_QOWN 1             // 1 = (fp32 instantiations) the query-layer data-gradient product at the cell-1 OWNERS (each attention workgroup publishes its 16 dq values once, all owners
+                                // read all of them) instead of at the attention workgroups (a personal 16-byte piece per owner): frees the 64 KB query-kernel slice in LDS
+#endif
+#ifndef BPTT_W0LDS
+#define BPTT_W0LDS 1            // with BPTT_QOWN, fp32: the recurrent-state half of the cell-0 kernel (the shadow product's A operands) in that LDS instead of 32 registers
+#endif
+#ifndef BPTT_KEYS_PER_STEP
+#define BPTT_KEYS_PER_STEP 0    // 1 = the attention slice's key / score constants (6 registers) requested again at the end of every step (L2 hits) instead of
+                                // living in registers across the two products of the step
+#endif
+#ifndef BPTT_LATE_OP0
+#define BPTT_LATE_OP0 0         // 1 = the cell-0 update's packed operands requested behind the cell-1 shadow product (in front of the d_m0 wait) instead of in front of it
+#endif
+#ifndef BSPLIT_C0
+#define BSPLIT_C0 0             // like BSPLIT_C1 for the on-chain half of the cell-0 product (context columns)
 #endif
 namespace mstts {
 
@@ -66,8 +84,9 @@ template <int TT> struct BL {
               B_A = B_GP + TT, B_CUM = B_A + TT, B_DE = B_CUM + TT + 48, B_DC = B_DE + TT, B_DPJ = B_DC + 96, B_QF = B_DPJ + 96,
               B_DQ = B_QF + 16, B_DQF = B_DQ + 512, B_LK = B_DQF + 16, B_FLAG = B_LK + 32 * 16, B_STAMP = B_FLAG + 4,
               B_VALT = B_STAMP + 2 * 16,             // [96 columns][128 positions] values slice, transposed
-              B_WQT = B_VALT + 96 * PT,              // [(k4 * 4 + e) * 256 + l][4]: Wq[4 l + e][16 i + 4 k4 ..]
-              B_FLOATS = B_WQT + 16 * 256 * 4;
+              B_WQT = B_VALT + 96 * PT,              // [(k4 * 4 + e) * 256 + l][4]: Wq[4 l + e][16 i + 4 k4 ..]   (BPTT_QOWN: [32 registers][512 threads] cell-0 kernel, half 1)
+              B_WQO = B_WQT + 16 * 256 * 4,          // BPTT_QOWN: [4 units e][128 k] Wq rows of this owner's units
+              B_FLOATS = B_WQO + (BPTT_QOWN ? 4 * 128 : 0);
     static_assert(B_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 constexpr int NBSTAMP = 16;
@@ -113,7 +132,9 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     typedef BL<TT> Y;
     constexpr int B_RED = Y::B_RED, B_G = Y::B_G, B_PC = Y::B_PC, B_DA = Y::B_DA, B_PD = Y::B_PD, B_TR = Y::B_TR, B_GP = Y::B_GP, B_A = Y::B_A, B_CUM = Y::B_CUM,
                   B_DE = Y::B_DE, B_DC = Y::B_DC, B_DPJ = Y::B_DPJ, B_QF = Y::B_QF, B_DQ = Y::B_DQ, B_DQF = Y::B_DQF, B_LK = Y::B_LK, B_FLAG = Y::B_FLAG,
-                  B_STAMP = Y::B_STAMP, B_VALT = Y::B_VALT, B_WQT = Y::B_WQT;
+                  B_STAMP = Y::B_STAMP, B_VALT = Y::B_VALT, B_WQT = Y::B_WQT, B_WQO = Y::B_WQO;
+    constexpr bool QOWN = BPTT_QOWN != 0 && !BF16;                // (the bf16 instantiations have no f32-input product to replace: the re-cut only costs them its longer gather)
+    constexpr bool W0L = QOWN && BPTT_W0LDS != 0 && !BF16;
     constexpr int NH = TT / 128;                  // halves of 128 encoder positions
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g0 = blockIdx.x, tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -138,33 +159,54 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 
     // ---------------- once: the transposed kernels of this workgroup / wave -> registers.  w1t[h * 32 + kt * 16 + ks]: half h (0 = the
     // rows on the chain: m0 units, 1 = h1 units), output tile kt, contraction step ks of this wave's eighth; w0t likewise (context / h0)
-    constexpr bool BS1 = BSPLIT_C1 != 0 && !BF16;
-    float w1t[BF16 ? 1 : (BS1 ? 32 : 64)], w0t[BF16 ? 1 : 64];   // BS1: w1t holds half 1 (the recurrent-state rows) only
+    constexpr bool BS1 = BSPLIT_C1 != 0 && !BF16 && BPTT_QOWN != 0 && BPTT_W0LDS != 0, BS0 = BSPLIT_C0 != 0 && !BF16;
+    // BS1 / BS0: half 0 lives as planes (w1s / w0s), the fp32 array holds half 1 only; W0L: half 1 of cell 0 lives in LDS
+    constexpr int NW0 = BF16 ? 1 : ((BS0 ? 0 : 32) + (W0L ? 0 : 32)) > 0 ? ((BS0 ? 0 : 32) + (W0L ? 0 : 32)) : 1;
+    constexpr int W0H1 = BS0 ? 0 : 32;                           // where half 1 starts in w0t (unused with W0L)
+    float w1t[BF16 ? 1 : (BS1 ? 32 : 64)], w0t[NW0];
     pbf16x8 wb1t[BF16 ? 8 : 1], wb0t[BF16 ? 8 : 1];              // BF16: the same values as packed octets (contraction steps 8 j .. 8 j + 7 of a (half, tile))
     pbf16x8 w1s[3][BS1 ? 4 : 1];                                 // BS1: half 0 of the cell-1 kernel as three planes, [plane][kt * 2 + j]
+    pbf16x8 w0s[3][BS0 ? 4 : 1];
     {
         const float* p1 = d.w1t + ((long)(g * 8 + wave) * 64) * 64 + lane;
         const float* p0 = d.w0t + ((long)(g * 8 + wave) * 64) * 64 + lane;
         if constexpr (BF16) {
 #pragma unroll
             for (int r = 0; r < 64; ++r) { wb1t[r >> 3][r & 7] = (__bf16)p1[r * 64]; wb0t[r >> 3][r & 7] = (__bf16)p0[r * 64]; }
-        } else if constexpr (BS1) {
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {          // (kt, j) = (o >> 1, o & 1): registers kt * 16 + 8 j + e of half 0
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = p1[((o >> 1) * 16 + 8 * (o & 1) + e) * 64];
-                bsp_split8(x, w1s[0][o], w1s[1][o], w1s[2][o]);
-            }
-#pragma unroll
-            for (int r = 0; r < 32; ++r) w1t[r] = p1[(32 + r) * 64];
-#pragma unroll
-            for (int r = 0; r < 64; ++r) w0t[r] = p0[r * 64];
         } else {
+            if constexpr (BS1) {
 #pragma unroll
-            for (int r = 0; r < 64; ++r) w1t[r] = p1[r * 64];
+                for (int o = 0; o < 4; ++o) {          // (kt, j) = (o >> 1, o & 1): registers kt * 16 + 8 j + e of half 0
+                    float x[8];
 #pragma unroll
-            for (int r = 0; r < 64; ++r) w0t[r] = p0[r * 64];
+                    for (int e = 0; e < 8; ++e) x[e] = p1[((o >> 1) * 16 + 8 * (o & 1) + e) * 64];
+                    bsp_split8(x, w1s[0][o], w1s[1][o], w1s[2][o]);
+                }
+#pragma unroll
+                for (int r = 0; r < 32; ++r) w1t[r] = p1[(32 + r) * 64];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 64; ++r) w1t[r] = p1[r * 64];
+            }
+            if constexpr (BS0) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = p0[((o >> 1) * 16 + 8 * (o & 1) + e) * 64];
+                    bsp_split8(x, w0s[0][o], w0s[1][o], w0s[2][o]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) w0t[r] = p0[r * 64];
+            }
+            if constexpr (W0L) {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) sm[B_WQT + r * PTH + tid] = p0[(32 + r) * 64];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) w0t[W0H1 + r] = p0[(32 + r) * 64];
+            }
         }
     }
     int ab = gj;
@@ -172,15 +214,19 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     const int alen = arow ? (d.lengths ? d.lengths[ab] : T) : 0;
     int ak = tid & 15, atg = tid >> 4;
     float kreg[4 * NH];
-    float asb = 0.f, awk = 0.f;
+    float asb = 0.f, awk = 0.f, asb2 = 0.f;
+    // (with the per-iteration copies of the indices when the macro stands at the bottom of the loop body: the loads are then this step's, not hoisted)
+#define LOAD_KEYS() do { const int gi__ = g & 7, ab__ = g >> 3, ak__ = tid & 15, atg__ = tid >> 4; const bool ar__ = ab__ < B;              \
+        _Pragma("unroll") for (int m = 0; m < 4 * NH; ++m) {                                                                              \
+            const int t = 128 * (m >> 2) + 4 * atg__ + (m & 3);                                                                            \
+            kreg[m] = d.keys[((long)(ar__ ? ab__ : 0) * T + (t < T ? t : 0)) * PA + 16 * gi__ + ak__];   /* (raw: masked where it is used - a use here would wait for the load) */ \
+        }                                                                                                                                  \
+        asb = d.score_b[16 * gi__ + ak__]; asb2 = d.loc_b[16 * gi__ + ak__]; awk = d.score_w[16 * gi__ + ak__]; } while (0)
     {
-#pragma unroll
-        for (int m = 0; m < 4 * NH; ++m) {
-            const int t = 128 * (m >> 2) + 4 * atg + (m & 3);
-            kreg[m] = (arow && t < T) ? d.keys[((long)ab * T + t) * PA + 16 * gi + ak] : 0.f;
-        }
-        asb = d.score_b[16 * gi + ak] + d.loc_b[16 * gi + ak];
-        awk = d.score_w[16 * gi + ak];
+        LOAD_KEYS();
+#if !BPTT_KEYS_PER_STEP
+        asb += asb2;
+#endif
         for (int x = tid; x < 32 * 16; x += PTH) sm[B_LK + x] = (x < PKS * 16) ? d.loc_k[(x >> 4) * PA + 16 * gi + (x & 15)] : 0.f;
         for (int x = tid; x < 96 * PT; x += PTH) {
             const int c = x >> 7, t = x & 127;
@@ -188,11 +234,21 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         }
         for (int x = tid; x < TT + 48; x += PTH) sm[B_CUM + x] = 0.f;
         for (int x = tid; x < TT; x += PTH) { sm[B_GP + x] = 0.f; sm[B_A + x] = 0.f; sm[B_DE + x] = 0.f; }
-        const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqt) + (long)gi * 16 * 256;
-        for (int x = tid; x < 16 * 256; x += PTH) {
-            pf32x4 v = wqs[x];
-            if constexpr (BF16) { v[0] = bf16_round(v[0]); v[1] = bf16_round(v[1]); v[2] = bf16_round(v[2]); v[3] = bf16_round(v[3]); }
-            reinterpret_cast<pf32x4*>(sm + B_WQT)[x] = v;
+        if constexpr (QOWN) {
+            // Wq rows of THIS owner's four units, all 128 k: packed float4 ((slice * 16 + k4 * 4 + e) * 256 + g) holds Wq[4 g + e][16 slice + 4 k4 ..]
+            if (tid < 128) {
+                const int sl = tid >> 4, k4 = (tid >> 2) & 3, e = tid & 3;
+                pf32x4 v = reinterpret_cast<const pf32x4*>(d.wqt)[((long)(sl * 16 + k4 * 4 + e)) * 256 + g];
+                if constexpr (BF16) { v[0] = bf16_round(v[0]); v[1] = bf16_round(v[1]); v[2] = bf16_round(v[2]); v[3] = bf16_round(v[3]); }
+                *reinterpret_cast<pf32x4*>(sm + B_WQO + e * 128 + 16 * sl + 4 * k4) = v;
+            }
+        } else {
+            const pf32x4* wqs = reinterpret_cast<const pf32x4*>(d.wqt) + (long)gi * 16 * 256;
+            for (int x = tid; x < 16 * 256; x += PTH) {
+                pf32x4 v = wqs[x];
+                if constexpr (BF16) { v[0] = bf16_round(v[0]); v[1] = bf16_round(v[1]); v[2] = bf16_round(v[2]); v[3] = bf16_round(v[3]); }
+                reinterpret_cast<pf32x4*>(sm + B_WQT)[x] = v;
+            }
         }
     }
     int et = wave & 1, er = 16 * et + (lane & 15), ee = lane >> 4, eu = 4 * g + ee;
@@ -209,26 +265,29 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
     // in LDS once the cell-1 wait of that step has drained the load queue anyway - they cost HBM latency, not bandwidth
     float rav = 0.f, rcv = 0.f, rqv = 0.f, rdv = 0.f;
     const int abc = arow ? ab : 0;
-#define LOAD_ROWS(ST) do { const long r__ = (long)(ST) * B + abc; const int t__ = tid0 & (TT - 1);                                   \
+#define LOAD_ROWS(ST) do { const long r__ = (long)(ST) * B + abc; const int t__ = tid & (TT - 1);                                   \
         rav = (d.align_hist + r__ * T)[t__ < T ? t__ : 0]; rcv = (d.cum_hist + r__ * T)[t__ < T ? t__ : 0];                     \
-        rqv = (d.q_hist + r__ * PA + 16 * (g0 & 7))[tid0 & 15]; rdv = (d.d_pj + r__ * (PH + PM) + PH + 96 * (g0 & 7))[tid0 < 96 ? tid0 : 0]; } while (0)
-#define STORE_ROWS() do { const int t__ = tid0 & (TT - 1);                                                                           \
+        rqv = (d.q_hist + r__ * PA + 16 * (g & 7))[tid & 15]; rdv = (d.d_pj + r__ * (PH + PM) + PH + 96 * (g & 7))[tid < 96 ? tid : 0]; } while (0)
+#define STORE_ROWS() do { const int t__ = tid & (TT - 1);                                                                           \
         sm[B_A + t__] = t__ < T ? rav : 0.f; sm[B_CUM + 15 + t__] = t__ < T ? rcv : 0.f;                                        \
-        sm[B_QF + (tid0 & 15)] = rqv; sm[B_DPJ + (tid0 < 96 ? tid0 : 0)] = rdv; } while (0)
+        sm[B_QF + (tid & 15)] = rqv; sm[B_DPJ + (tid < 96 ? tid : 0)] = rdv; } while (0)
     // operands of the cell-1 update backward (saved activations, cell states, keep-masks, the projection's d_m1): HBM-cold, requested ONE STEP
     // AHEAD (here for the first step, at the bottom of the loop body for the next) by every wave outside any condition - see persist.hip
     float a1v[4], cr1, cp1, dpm1;
     uint8_t zc1v, zh1v;
-#define LOAD_OPERANDS1(ST) do { const long b__ = (long)(ST) * B; const unsigned r__ = (16 * (wave0 & 1) + (tid0 & 15)) < (unsigned)B ? 16 * (wave0 & 1) + (tid0 & 15) : 0u; \
-        const unsigned u__ = 4 * g0 + ((tid0 & 63) >> 4);                                                                                   \
-        /* (waves 2..7 only repeat the update: they read what wave 0 / 1 read - tid0 & 127 - from the packed block) */                      \
-        const pf32x4* ob__ = reinterpret_cast<const pf32x4*>(d.opk) + opk_index((ST), g0, 1, 0, tid0 & 127);                                \
+#define LOAD_OPERANDS1(ST) do { const long b__ = (long)(ST) * B; const unsigned r__ = (16 * (wave & 1) + (tid & 15)) < (unsigned)B ? 16 * (wave & 1) + (tid & 15) : 0u; \
+        const unsigned u__ = 4 * g + ((tid & 63) >> 4);                                                                                   \
+        /* (waves 2..7 only repeat the update: they read what wave 0 / 1 read - tid & 127 - from the packed block) */                      \
+        const pf32x4* ob__ = reinterpret_cast<const pf32x4*>(d.opk) + opk_index((ST), g, 1, 0, tid & 127);                                \
         const pf32x4 A__ = ob__[0], B__ = ob__[128];                                                                                        \
         a1v[0] = A__[0]; a1v[1] = A__[1]; a1v[2] = A__[2]; a1v[3] = A__[3]; cr1 = B__[0]; cp1 = B__[1];                                      \
         zc1v = (uint8_t)(__float_as_uint(B__[2]) & 1u); zh1v = (uint8_t)((__float_as_uint(B__[2]) >> 1) & 1u);                               \
-        dpm1 = (d.d_pj + b__ * (PH + PM))[wave0 < 2 ? r__ * (PH + PM) + u__ : 0u]; } while (0)
+        dpm1 = (d.d_pj + b__ * (PH + PM))[wave < 2 ? r__ * (PH + PM) + u__ : 0u]; } while (0)
     LOAD_OPERANDS1(S - 1);
     LOAD_ROWS(S - 1);
+    __syncthreads();          // the zero fills of B_CUM / B_A above are other threads' stores to the words STORE_ROWS writes: order them (round 6: with the
+                              // query-kernel load gone from half of the waves the fill of a slow wave could land behind a fast wave's row - one workgroup's
+                              // first step then ran on a zeroed cumulative-alignment window, 4e-4 in dq_hist of the first launch of a process)
     STORE_ROWS();
     __syncthreads();
     if (PROF && tid == 0) tprev = (unsigned)wall_clock64();
@@ -253,12 +312,18 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         const unsigned erc = rowok ? (unsigned)er : 0u;
         const unsigned oH = erc * PH + eu, o4H = erc * 4 * PH + eu;
         // requests of the two cell-update waits, issued as soon as this workgroup's own contribution has left
-        unsigned uoff[2];
+        unsigned uoff[2], qoff[QOWN ? 5 : 1];
         pf32x4 uv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        pf32x4 qv5[QOWN ? 5 : 1];
 #define ISSUE_UPDATE1() do { if (tid < 256) { const int row = tid >> 3, sl = tid & 7;                                                  \
+            if constexpr (QOWN) {   /* the 16 dq values of (row, slice sl) + this piece of the recurrent-state product */                \
+                _Pragma("unroll") for (int p = 0; p < 4; ++p) qoff[p] = (unsigned)((BO_DM1 + slot * BDM1 + ((long)row * 8 + sl) * 16 + 4 * p) * 4); \
+                qoff[4] = first ? qoff[0] : (unsigned)((BO_PH1 + nslot * BPART + (((long)g * 8 + sl) * 32 + row) * 4) * 4);           \
+                issue<5>(xr, qoff, qv5);                                                                                              \
+            } else {                                                                                                                  \
             uoff[0] = (unsigned)((BO_DM1 + slot * BDM1 + (((long)g * 8 + sl) * 32 + row) * 4) * 4);                                   \
             uoff[1] = first ? uoff[0] : (unsigned)((BO_PH1 + nslot * BPART + (((long)g * 8 + sl) * 32 + row) * 4) * 4);               \
-            issue<2>(xr, uoff, uv); } } while (0)
+            issue<2>(xr, uoff, uv); } } } while (0)
 #define ISSUE_UPDATE0() do { if (tid < 256) { const int row = tid >> 3, src = tid & 7;                                                 \
             uoff[0] = (unsigned)((BO_PM0 + slot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);                                 \
             uoff[1] = first ? uoff[0] : (unsigned)((BO_PH0 + nslot * BPART + (((long)g * 8 + src) * 32 + row) * 4) * 4);              \
@@ -279,7 +344,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             PSTAMP(15);
             // tanh terms of this slice (independent of everything that arrives): fac = w_k (1 - tanh^2(keys + q + location filter))
             {
-                const float qk = sm[B_QF + ak] + asb;
+                const float qk = sm[B_QF + ak] + (BPTT_KEYS_PER_STEP ? asb + asb2 : asb);
                 // location filter as a Toeplitz product on the matrix core (see persist.hip): A = the cumulative-alignment window, B = the filter slice
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
@@ -288,7 +353,10 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                     for (int ks = 0; ks < 8; ++ks)
                         loc = PMFMA(sm[B_CUM + 128 * hh + 16 * wave + (lane & 15) + 4 * ks + (lane >> 4)], sm[B_LK + (4 * ks + (lane >> 4)) * 16 + (lane & 15)], loc);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) { const float u = tanhf_(kreg[4 * hh + m] + qk + loc[m]); fac[4 * hh + m] = awk * (1.f - u * u); }
+                    for (int m = 0; m < 4; ++m) {
+                        const float kv = (128 * hh + 4 * atg + m < T) ? kreg[4 * hh + m] : 0.f;      // (arow holds here; positions past T read as zero keys)
+                        const float u = tanhf_(kv + qk + loc[m]); fac[4 * hh + m] = awk * (1.f - u * u);
+                    }
                 }
             }
             PSTAMP(0);
@@ -403,6 +471,11 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                 (d.dq_hist + (sB + ab) * PA + 16 * gi)[tid] = qv;
             }
             __syncthreads();
+            if constexpr (QOWN) {
+                // the 16 dq values of (row ab, slice gi), once, for all 256 owners (tools/broadcast_probe.hip: a 256-way read of 16 KB costs
+                // 0.17 us more per exchange than 256 personal pieces)
+                if (tid < 4) xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + ((long)ab * 8 + gi) * 16 + 4 * tid) * 4), *reinterpret_cast<const pf32x4*>(sm + B_DQF + 4 * tid), gen);
+            } else
             if (tid < 256) {        // query layer, data gradient of this slice's 16 units: d_m1[4 l + e] += sum_k dq[k] Wq[4 l + e][16 i + k]
                 pf32x4 out = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -446,6 +519,9 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             }
         } else {
             PSTAMP(0); PSTAMP(1); PSTAMP(2); PSTAMP(3);
+            if constexpr (QOWN) {
+                if (tid < 4) xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + ((long)ab * 8 + gi) * 16 + 4 * tid) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f}, gen);
+            } else
             if (tid < 256) {        // rows past the batch: zeros, so that the cell owners' waits complete
                 const long o = (((long)tid * 8 + gi) * 32 + ab) * 4;
                 xpublish(xr, (unsigned)((BO_DM1 + slot * BDM1 + o) * 4), (pf32x4){0.f, 0.f, 0.f, 0.f}, gen);
@@ -459,7 +535,23 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         ISSUE_UPDATE1();
         if (tid < 256) {            // piece (row, slice / source): 8 consecutive lanes hold the 8 partial vectors of one (row, 4 units)
             const int row = tid >> 3, sl = tid & 7;
-            { const unsigned g2[2] = {gen, first ? gen : ngen}; if (!complete<2>(xr, uoff, uv, d.ctrl, g2)) PFAIL(); }
+            if constexpr (QOWN) {
+                { const unsigned g5[5] = {gen, gen, gen, gen, first ? gen : ngen}; if (!complete<5>(xr, qoff, qv5, d.ctrl, g5)) PFAIL(); }
+                uv[1] = qv5[4];
+                // this slice's share of the query layer's data gradient for the owner's four units: d_m1[4 g + e] += sum_k dq[row][16 sl + k] Wq[4 g + e][16 sl + k]
+                uv[0] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {          // (one piece at a time, fenced: left alone the scheduler hoists all sixteen kernel reads - 64 registers)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const pf32x4 wv = *reinterpret_cast<const pf32x4*>(sm + B_WQO + e * 128 + 16 * sl + 4 * p);
+                        uv[0][e] += wv[0] * qv5[p][0] + wv[1] * qv5[p][1] + wv[2] * qv5[p][2] + wv[3] * qv5[p][3];
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            } else {
+                const unsigned g2[2] = {gen, first ? gen : ngen}; if (!complete<2>(xr, uoff, uv, d.ctrl, g2)) PFAIL();
+            }
             if (first) uv[1] = (pf32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -498,7 +590,7 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         PSTAMP(7);
         // ================= products: a wave's eighth of the gate gradients -> B-operand registers, 64 MFMAs on the chain, the 8 partial
         // tiles meet in LDS, leave as one tile; then the 64 MFMAs of the recurrent-state rows in the shadow of that hand-off
-#define PROD_GATHER(OFF_DG, SPLB)                                                                                                     \
+#define PROD_GATHER(OFF_DG)                                                                                                           \
         pf32x4 bq[8];                                                                                                                \
         {                                                                                                                            \
             unsigned off[8];                                                                                                         \
@@ -511,16 +603,10 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         if constexpr (BF16) {                                                                                                        \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                            \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) bqh[x][e] = (__bf16)bq[(x >> 1) * 4 + 2 * (x & 1) + (e >> 2)][e & 3];  \
-        }                                                                                                                            \
-        pbf16x8 bqs[3][(BS1 && (SPLB) && BSPLIT_RECON != 0) ? 4 : 1];   /* BS1 + RECON: the gate gradients as three planes, [plane][t * 2 + j] */ \
-        if constexpr (BS1 && (SPLB) && BSPLIT_RECON != 0) {                                                                          \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                                          \
-                float f__[8];                                                                                                        \
-                _Pragma("unroll") for (int e = 0; e < 8; ++e) f__[e] = bq[(x >> 1) * 4 + 2 * (x & 1) + (e >> 2)][e & 3];             \
-                bsp_split8(f__, bqs[0][x], bqs[1][x], bqs[2][x]);                                                                    \
-            }                                                                                                                        \
         }
-#define PROD_HALF(half, WT, WBASE, WB, OFF_OUT, IS_CTX, SPL, RECON)                                                                   \
+// WT / WBASE: the fp32 kernel registers of this half; WB: the bf16 instantiation's; WS + SPL: this half as three planes, evaluated as the
+// six-product split; ALDS: the fp32 kernel values of this half come from LDS ([register][thread], B_WQT region) instead of registers
+#define PROD_HALF(half, WT, WBASE, WB, WS, OFF_OUT, IS_CTX, SPL, ALDS)                                                                \
         {                                                                                                                            \
             pf32x4 acc[2][2];                                                                                                        \
             _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
@@ -531,9 +617,10 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                         acc[kt][0] = PMFMA_BF16(WB[(half) * 4 + kt * 2 + j], bqh[j], acc[kt][0]);                                     \
                         acc[kt][1] = PMFMA_BF16(WB[(half) * 4 + kt * 2 + j], bqh[2 + j], acc[kt][1]);                                 \
                     }                                                                                                                \
-            } else if constexpr (BS1 && (SPL) && BSPLIT_RECON == 0) {                                                                \
-                /* one row tile at a time: its six gate-gradient plane octets (24 registers) live only over its 24 matrix instructions     \
-                   (by (row tile, octet) - 12 registers at a time - the register allocator does worse: 44 spilled against 14) */              \
+            } else if constexpr (SPL) {                                                                                              \
+                /* one row tile at a time: its six gate-gradient plane octets (24 registers) live only over its 24 matrix instructions, and its \
+                   two accumulator tiles go to the reduction scratch at once (free since the attention phases' last barrier) - by (row tile,     \
+                   octet), 12 registers at a time, the register allocator does worse: 44 spilled against 14 */                                   \
                 _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                      \
                     pbf16x8 bp__[3][2];                                                                                              \
                     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
@@ -541,49 +628,35 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
                         _Pragma("unroll") for (int e = 0; e < 8; ++e) f__[e] = bq[t * 4 + 2 * j + (e >> 2)][e & 3];                  \
                         bsp_split8(f__, bp__[0][j], bp__[1][j], bp__[2][j]);                                                         \
                     }                                                                                                                \
-                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-                        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                           \
-                            pf32x4 a__ = acc[kt][t];                                                                                 \
-                            a__ = PMFMA_BF16(w1s[2][kt * 2 + j], bp__[0][j], a__);                                                   \
-                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bp__[2][j], a__);                                                   \
-                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bp__[1][j], a__);                                                   \
-                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bp__[0][j], a__);                                                   \
-                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bp__[1][j], a__);                                                   \
-                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bp__[0][j], a__);                                                   \
-                            acc[kt][t] = a__;                                                                                        \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
+                        pf32x4 a__ = {0.f, 0.f, 0.f, 0.f};                                                                           \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+                            a__ = PMFMA_BF16(WS[2][kt * 2 + j], bp__[0][j], a__);                                                    \
+                            a__ = PMFMA_BF16(WS[0][kt * 2 + j], bp__[2][j], a__);                                                    \
+                            a__ = PMFMA_BF16(WS[1][kt * 2 + j], bp__[1][j], a__);                                                    \
+                            a__ = PMFMA_BF16(WS[1][kt * 2 + j], bp__[0][j], a__);                                                    \
+                            a__ = PMFMA_BF16(WS[0][kt * 2 + j], bp__[1][j], a__);                                                    \
+                            a__ = PMFMA_BF16(WS[0][kt * 2 + j], bp__[0][j], a__);                                                    \
                         }                                                                                                            \
+                        *reinterpret_cast<pf32x4*>(sm + B_RED + ((wave * 4 + kt * 2 + t) * 64 + lane) * 4) = a__;                    \
+                    }                                                                                                                \
                     __builtin_amdgcn_sched_barrier(0);                                                                               \
                 }                                                                                                                    \
-            } else if constexpr (BS1 && (SPL)) {                                                                                     \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
-                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                 \
-                        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                              \
-                            pf32x4 a__ = acc[kt][t];                                                                                 \
-                            a__ = PMFMA_BF16(w1s[2][kt * 2 + j], bqs[0][t * 2 + j], a__);                                            \
-                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bqs[2][t * 2 + j], a__);                                            \
-                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bqs[1][t * 2 + j], a__);                                            \
-                            a__ = PMFMA_BF16(w1s[1][kt * 2 + j], bqs[0][t * 2 + j], a__);                                            \
-                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bqs[1][t * 2 + j], a__);                                            \
-                            a__ = PMFMA_BF16(w1s[0][kt * 2 + j], bqs[0][t * 2 + j], a__);                                            \
-                            acc[kt][t] = a__;                                                                                        \
-                        }                                                                                                            \
             } else {                                                                                                                 \
-                _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                                                  \
-                    float b0__, b1__;                                                                                                \
-                    if constexpr (BS1 && (RECON)) {   /* the fp32 value back from its planes (hi + mid + lo is exact): bq need not stay live over the split half */ \
-                        b0__ = ((float)bqs[0][ks >> 3][ks & 7] + (float)bqs[1][ks >> 3][ks & 7]) + (float)bqs[2][ks >> 3][ks & 7];   \
-                        b1__ = ((float)bqs[0][2 + (ks >> 3)][ks & 7] + (float)bqs[1][2 + (ks >> 3)][ks & 7]) + (float)bqs[2][2 + (ks >> 3)][ks & 7]; \
-                    } else { b0__ = bq[ks >> 2][ks & 3]; b1__ = bq[4 + (ks >> 2)][ks & 3]; }                                         \
+                _Pragma("unroll") for (int ks = 0; ks < 16; ++ks)                                                                    \
                     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                               \
-                        acc[kt][0] = PMFMA(WT[(WBASE) + kt * 16 + ks], b0__, acc[kt][0]);                                            \
-                        acc[kt][1] = PMFMA(WT[(WBASE) + kt * 16 + ks], b1__, acc[kt][1]);                                            \
+                        float a__;                                                                                                   \
+                        if constexpr (ALDS) a__ = sm[B_WQT + (kt * 16 + ks) * PTH + tid]; else a__ = WT[(WBASE) + kt * 16 + ks];     \
+                        acc[kt][0] = PMFMA(a__, bq[ks >> 2][ks & 3], acc[kt][0]);                                                    \
+                        acc[kt][1] = PMFMA(a__, bq[4 + (ks >> 2)][ks & 3], acc[kt][1]);                                              \
                     }                                                                                                                \
-                }                                                                                                                    \
             }                                                                                                                        \
             if ((half) == 1) __syncthreads();                        /* the first tile's readers are done */                         \
-            _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                         \
-                _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                        \
-                    *reinterpret_cast<pf32x4*>(sm + B_RED + ((wave * 4 + kt * 2 + t) * 64 + lane) * 4) = acc[kt][t];                 \
+            if constexpr (BF16 || !(SPL)) {                          /* (the split form has stored its tiles already; it is used for half 0 only) */ \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                     \
+                    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
+                        *reinterpret_cast<pf32x4*>(sm + B_RED + ((wave * 4 + kt * 2 + t) * 64 + lane) * 4) = acc[kt][t];             \
+            }                                                                                                                        \
             PABORT_CHECK();                                                                                                          \
             if (tid < 256) {                                                                                                         \
                 const int tile = tid >> 6, l = tid & 63, kt = tile >> 1, t = tile & 1;                                               \
@@ -603,20 +676,26 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
         }
         pf32x4 A0_, B0_;                      // cell-0 operands as loaded: split into activations / states / mask bits only where the update uses them
         {
-            PROD_GATHER(BO_DG1, true)
-            PROD_HALF(0, w1t, 0, wb1t, BO_PM0, false, true, false)
+            PROD_GATHER(BO_DG1)
+            PROD_HALF(0, w1t, 0, wb1t, w1s, BO_PM0, false, BS1, false)
             PSTAMP(8);
-            {   // operands of the cell-0 update backward: requested here, they arrive under the second half and the hand-off
-                const pf32x4* ob = reinterpret_cast<const pf32x4*>(d.opk) + opk_index(s, g0, 0, 0, tid0 & 127);
-                A0_ = ob[0]; B0_ = ob[128];
-                // (no arithmetic on them here: the first use makes the compiler wait for the loads, and its vmcnt(0) - the publication just
-                //  above sits in a conditional block - also waits for that write-through store to be acknowledged: 0.5 us in this stage)
-            }
-            PROD_HALF(1, w1t, (BS1 ? 0 : 32), wb1t, BO_PH1, false, false, (BSPLIT_RECON != 0))
+#define LOAD_OPERANDS0() do { /* operands of the cell-0 update backward (HBM-cold): they arrive under the product / the hand-off that follows */ \
+                const pf32x4* ob = reinterpret_cast<const pf32x4*>(d.opk) + opk_index(s, g, 0, 0, tid & 127);       /* (the per-iteration copies: the address is formed again every step instead of living in two registers across the loop) */ \
+                A0_ = ob[0]; B0_ = ob[128];                                                                                           \
+                /* (no arithmetic on them here: the first use makes the compiler wait for the loads, and its vmcnt(0) - the publication just \
+                    above sits in a conditional block - also waits for that write-through store to be acknowledged: 0.5 us in this stage) */ \
+            } while (0)
+#if !BPTT_LATE_OP0
+            LOAD_OPERANDS0();
+#endif
+            PROD_HALF(1, w1t, (BS1 ? 0 : 32), wb1t, w1s, BO_PH1, false, false, false)
         }
         PSTAMP(9);
         // ================= cell 0, update backward
         __syncthreads();
+#if BPTT_LATE_OP0
+        LOAD_OPERANDS0();
+#endif
         ISSUE_UPDATE0();
         if (tid < 256) {
             const int row = tid >> 3, src = tid & 7;
@@ -663,14 +742,17 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
             // 15 / 30 / 45 / 60 ticks: frame 19.23 / 19.02 / 18.90 / 18.93 / 19.05 / 19.2 / 19.24 us; bf16: 12.86 / - / 12.70 / 12.68 / 12.77); the same pause
             // in front of the d[g1] gather moves 0.18 us from one stage into the next and gains nothing, and in front of the forward loop's requests it loses.
             if constexpr (BG0_LATE > 0) { const unsigned long long t__ = wall_clock64(); while (wall_clock64() - t__ < (unsigned long long)BG0_LATE) __builtin_amdgcn_s_sleep(1); }
-            PROD_GATHER(BO_DG0, false)
-            PROD_HALF(0, w0t, 0, wb0t, BO_PM0, true, false, false)
+            PROD_GATHER(BO_DG0)
+            PROD_HALF(0, w0t, 0, wb0t, w0s, BO_PM0, true, BS0, false)
             PSTAMP(12);
-            PROD_HALF(1, w0t, 32, wb0t, BO_PH0, false, false, false)
+            PROD_HALF(1, w0t, W0H1, wb0t, w0s, BO_PH0, false, false, W0L)
         }
         PSTAMP(13);
 #ifndef EXP_NO_OPLOAD
         LOAD_OPERANDS1(s > 0 ? s - 1 : 0);
+#endif
+#if BPTT_KEYS_PER_STEP
+        LOAD_KEYS();
 #endif
         __syncthreads();                                             // the product's readers are done before the attention scratch is written
         PSTAMP(14);
@@ -689,6 +771,8 @@ __global__ __launch_bounds__(PTH) void persist_bwd_kernel(PersistBwd d) {
 #undef ISSUE_UPDATE1
 #undef ISSUE_UPDATE0
 #undef PROD_HALF
+#undef LOAD_OPERANDS0
+#undef LOAD_KEYS
 #undef LOAD_ROWS
 #undef LOAD_OPERANDS1
 #undef STORE_ROWS

@@ -86,6 +86,7 @@ def _split_k_big(M, N, K, requested, n_cu=256):
 
 PERSIST_STRIKES = 2          # consecutive steps with a fallback before the persistent plans are switched off ...
 PERSIST_COOLDOWN = 200       # ... for this many steps
+VOC_OVERLAP = os.environ.get("MSTTS_VOC_OVERLAP", "1") != "0"    # the vocoder conv-bank's statistics side effect (quirk Q20) on its own stream, under the loss and the postnet's backward pass
 ENC_OVERLAP = os.environ.get("MSTTS_ENC_OVERLAP", "1") != "0"    # the encoder's persistent launches on their own stream, under decoder-side products that do not depend on them
 
 
@@ -255,6 +256,10 @@ class TrainEngine:
         if self.device.type == "cuda":
             self._side = torch.cuda.Stream(device=self.device)                # status words -> pinned host memory, the job-wide verdict's exchange
             self._enc_stream = torch.cuda.Stream(device=self.device)          # the encoder's persistent launches (forward / loss_and_backward)
+            # train_step: the vocoder conv-bank's BN-statistics side effect (read by nothing in the step) runs on the encoder's stream too, which is idle between
+            # the encoder's forward and BPTT launches.  NOT a stream of its own: HIP maps streams onto four hardware queues, and in a process with an RCCL
+            # group a third engine stream landed on the main stream's queue - every launch serialized, nothing gained (profiles/r06_ab_vocoder_side_chain.txt)
+            self._voc_stream = self._enc_stream
         if self.persist_bwd:
             self.pkb = [self._f(int(lb.mstts_persist_bwd_pack_floats(i))) for i in range(3)]
         self.flip = {}
@@ -523,6 +528,7 @@ class TrainEngine:
             w.v_p2 = f(B * S, d.n_mel)
             w.v_p2y = f(B * S, d.n_mel)
             w.v_stat = f(2 * max(d.bank_ch, d.proj1_ch, d.n_mel))
+            w.v_bn_ws = f(2 * max(d.bank_ch, d.proj1_ch, d.n_mel))          # (its own column-sum workspace: the chain may run beside the main stream's BN calls)
         # losses
         w.scalars = f(4)
         w.d_linear, w.d_post, w.d_stop = f(B, S, d.n_mel), f(B, S, d.n_mel), f(B, S)
@@ -594,15 +600,19 @@ class TrainEngine:
             self._gemm(dz, wt, dx, rows, cin, K * cout, cout, cin, cin, win=(T, cout, K - 1 - pad))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch, w, seed=None, masks=None, _redo=False, allowed=None):
+    def forward(self, batch, w, seed=None, masks=None, _redo=False, allowed=None, overlap_vocoder=False):
         """Forward pass.  The persistent launches (encoder BiLSTM, decoder loop) are enqueued WITHOUT waiting for their control words; the
         words of both are read once, behind the rest of the pass (one host sync per pass).  If either launch gave up, the BN moving statistics
         are put back to their state at the start of the pass and the whole pass is run again with the launch-per-step loops (_redo).
         allowed: the fallback policy's decision for this optimizer step (train_step takes it ONCE per step with _persist_begin_step and
-        hands it down); None = a forward pass driven on its own (tests, tools) advances the policy itself."""
+        hands it down); None = a forward pass driven on its own (tests, tools) advances the policy itself.
+        overlap_vocoder: train_step only - the vocoder conv-bank's statistics side effect (quirk Q20: ~50 small launches, 1.0 ms, read by nothing in
+        the step) goes to its own stream and loss_and_backward joins it in front of the decoder's BPTT launch (which needs every CU); a forward
+        pass driven on its own keeps it on the caller's stream."""
         d, ps = self.d, self.params
         B, Te, L, S = w.B, w.Te, w.L, w.S
         H, M, A, Pn, He = d.dec_lstm, d.mem, d.att, d.prenet, d.enc_lstm
+        w.voc_done = None
         if self._active_plan is not w and not _redo:         # (a set planned earlier, while a set of another shape has used the arena since)
             self._activate(w)
         if self._derived_stale:
@@ -750,7 +760,7 @@ class TrainEngine:
             w.opk_valid = False
             self._ensure_fallback_packs()
             call("mstts_decoder_train_fwd", C.byref(dec))
-        self._forward_tail(w)
+        self._forward_tail(w, overlap_vocoder=overlap_vocoder and VOC_OVERLAP and self.device.type == "cuda")
         dec_ok = enc_ok = True
         if ev is not None:
             ev.synchronize()
@@ -771,8 +781,10 @@ class TrainEngine:
         if not (dec_ok and enc_ok):
             self._step_fell_back = True
             torch.cuda.current_stream().synchronize()
+            if w.voc_done is not None:                   # (the side chain writes moving statistics too)
+                w.voc_done.synchronize()
             self.params.frozen[:self.params.n_moving].copy_(self._moving_snapshot)
-            return self.forward(batch, w, seed=seed, masks=masks, _redo=True)
+            return self.forward(batch, w, seed=seed, masks=masks, _redo=True, overlap_vocoder=overlap_vocoder)
         return w
 
     def _enc_persistent(self, w, entry, seqs, which, n_wg):
@@ -831,7 +843,7 @@ class TrainEngine:
         if getattr(w, "opk_valid", False):
             call("mstts_persist_unpack_history", ptr(w.opk), C.byref(w.dec))
 
-    def _forward_tail(self, w):
+    def _forward_tail(self, w, overlap_vocoder=False):
         """Everything behind the decoder loop: projection, postnet, residual, the vocoder's statistics side effect."""
         d = self.d
         B, S = w.B, w.S
@@ -850,8 +862,22 @@ class TrainEngine:
                          mk["post_drop_%d" % i], 1 - d.conv_drop, B * S, cout, w.bn_ws)
             x, cin = w.post_y[i], cout
         call("mstts_add", ptr(w.linear), ptr(x), ptr(w.mel_out), B * S * d.n_mel)
-        if self.update_vocoder_bn:
+        if self.update_vocoder_bn and overlap_vocoder:
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._voc_stream):
+                self._voc_stream.wait_event(ready)
+                self._vocoder_bn_update(w)
+                w.voc_done = torch.cuda.Event()
+                w.voc_done.record()
+        elif self.update_vocoder_bn:
             self._vocoder_bn_update(w)
+
+    def _join_vocoder(self, w):
+        """The caller's stream waits for the vocoder side chain of this pass (if one is running)."""
+        if getattr(w, "voc_done", None) is not None:
+            torch.cuda.current_stream().wait_event(w.voc_done)
+            w.voc_done = None
 
     def _vocoder_bn_update(self, w):
         """Quirk Q20: the train op also runs the vocoder conv-bank's BN update ops on the predicted mel."""
@@ -863,18 +889,18 @@ class TrainEngine:
             kk, ok = self.P(VOC + "convbank_0/conv1d%s/kernel" % sfx); b, ob = self.P(VOC + "convbank_0/conv1d%s/bias" % sfx)
             self._gemm(w.mel_out, kk, w.v_tmp, rows, d.bank_ch, k * d.n_mel, d.n_mel, d.bank_ch, d.bank_ch, bias=b, act=ACT_RELU,
                  win=(S, d.n_mel, (k - 1) // 2), b_off=ok, bias_off=ob, exact=True)
-            self._bn_fwd(VOC + "convbank_0/batch_normalization%s/" % sfx, w.v_tmp, w.v_tmp2, w.v_stat, w.v_stat[d.bank_ch:], None, 1.0, rows, d.bank_ch, w.bn_ws)
+            self._bn_fwd(VOC + "convbank_0/batch_normalization%s/" % sfx, w.v_tmp, w.v_tmp2, w.v_stat, w.v_stat[d.bank_ch:], None, 1.0, rows, d.bank_ch, w.v_bn_ws)
             call("mstts_copy2d", ptr(w.v_tmp2), d.bank_ch, ptr(w.v_cat, (k - 1) * d.bank_ch), d.bank_k * d.bank_ch, rows, d.bank_ch, 0)
         C1 = d.bank_k * d.bank_ch
         call("mstts_maxpool2_same", ptr(w.v_cat), ptr(w.v_pool), B, S, C1)
         kk, ok = self.P(VOC + "convbank_0/conv1d_8/kernel"); b, ob = self.P(VOC + "convbank_0/conv1d_8/bias")
         self._gemm(w.v_pool, kk, w.v_p1, rows, d.proj1_ch, d.proj1_k * C1, C1, d.proj1_ch, d.proj1_ch, bias=b, act=ACT_RELU,
              win=(S, C1, (d.proj1_k - 1) // 2), b_off=ok, bias_off=ob, exact=True)
-        self._bn_fwd(VOC + "convbank_0/batch_normalization_8/", w.v_p1, w.v_p1y, w.v_stat, w.v_stat[d.proj1_ch:], None, 1.0, rows, d.proj1_ch, w.bn_ws)
+        self._bn_fwd(VOC + "convbank_0/batch_normalization_8/", w.v_p1, w.v_p1y, w.v_stat, w.v_stat[d.proj1_ch:], None, 1.0, rows, d.proj1_ch, w.v_bn_ws)
         kk, ok = self.P(VOC + "convbank_0/conv1d_9/kernel"); b, ob = self.P(VOC + "convbank_0/conv1d_9/bias")
         self._gemm(w.v_p1y, kk, w.v_p2, rows, d.n_mel, d.proj2_k * d.proj1_ch, d.proj1_ch, d.n_mel, d.n_mel, bias=b,
              win=(S, d.proj1_ch, (d.proj2_k - 1) // 2), b_off=ok, bias_off=ob, exact=True)
-        self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.bn_ws)
+        self._bn_fwd(VOC + "convbank_0/batch_normalization_9/", w.v_p2, w.v_p2y, w.v_stat, w.v_stat[d.n_mel:], None, 1.0, rows, d.n_mel, w.v_bn_ws)
 
     # ------------------------------------------------------------------ loss + backward
     def loss_and_backward(self, w, grad_scale=1.0, on_ready=None, on_abort=None, agree=None, agree_async=None, _redo=False):
@@ -932,7 +958,9 @@ class TrainEngine:
         call("mstts_copy2d", ptr(self.dwp_pad), self.proj_ld, ptr(gwp, ogwp), d.n_mel + 1, H + M, d.n_mel + 1, 1)
         call("mstts_colsum", ptr(w.d_proj), S * B, d.n_mel + 1, self.proj_ld, ptr(gbp, ogbp), 1)
         self._gemm(w.d_proj, self.wp_pad, w.d_pj, S * B, H + M, self.proj_ld, self.proj_ld, self.proj_ld, H + M, trans_b=True)
-        # ---- decoder loop backward
+        # ---- decoder loop backward (its persistent launch needs every CU: the vocoder side chain of the forward pass, which ran under the
+        # loss and the postnet's backward pass, has to be off the chip)
+        self._join_vocoder(w)
         w.dq_hist.zero_()
         db = w.dec_b
         db.fwd = C.pointer(w.dec)
@@ -1279,7 +1307,7 @@ class TrainEngine:
         B, Te = batch["Token"].shape
         L = batch["Mel"].shape[1]
         w = self.plan(B, Te, L)
-        self.forward(batch, w, masks=masks, allowed=self._persist_begin_step())      # the fallback policy advances once per optimizer step
+        self.forward(batch, w, masks=masks, allowed=self._persist_begin_step(), overlap_vocoder=True)      # the fallback policy advances once per optimizer step
         if all_reduce is not None:           # bucketed in the order gradients become final (postnet -> decoder/attention -> encoder),
             g = self.params.grad             # each bucket's all-reduce running under the rest of the backward pass
             self.loss_and_backward(w, on_ready=lambda lo, hi: all_reduce.start(g, lo, hi), on_abort=lambda: all_reduce.finish(g),

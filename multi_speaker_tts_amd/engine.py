@@ -87,6 +87,7 @@ def _split_k_big(M, N, K, requested, n_cu=256):
 PERSIST_STRIKES = 2          # consecutive steps with a fallback before the persistent plans are switched off ...
 PERSIST_COOLDOWN = 200       # ... for this many steps
 VOC_OVERLAP = os.environ.get("MSTTS_VOC_OVERLAP", "1") != "0"    # the vocoder conv-bank's statistics side effect (quirk Q20) on its own stream, under the loss and the postnet's backward pass
+ENC_TAIL_OVERLAP = os.environ.get("MSTTS_ENC_TAIL_OVERLAP", "1") != "0"   # ... and what follows the encoder's BPTT launch on that stream too, beside the decoder's weight-gradient products
 ENC_OVERLAP = os.environ.get("MSTTS_ENC_OVERLAP", "1") != "0"    # the encoder's persistent launches on their own stream, under decoder-side products that do not depend on them
 
 
@@ -258,7 +259,7 @@ class TrainEngine:
             self._enc_stream = torch.cuda.Stream(device=self.device)          # the encoder's persistent launches (forward / loss_and_backward)
             # train_step: the vocoder conv-bank's BN-statistics side effect (read by nothing in the step) runs on the encoder's stream too, which is idle between
             # the encoder's forward and BPTT launches.  NOT a stream of its own: HIP maps streams onto four hardware queues, and in a process with an RCCL
-            # group a third engine stream landed on the main stream's queue - every launch serialized, nothing gained (profiles/r06_ab_vocoder_side_chain.txt)
+            # group a third engine stream landed on the main stream's queue - every launch serialized, nothing gained (profiles/r06_ab_side_chains.txt)
             self._voc_stream = self._enc_stream
         if self.persist_bwd:
             self.pkb = [self._f(int(lb.mstts_persist_bwd_pack_floats(i))) for i in range(3)]
@@ -1056,6 +1057,31 @@ class TrainEngine:
             q.c_hist = ptr(w.enc_c[dr]); q.acts = ptr(w.enc_acts[dr]); q.c_raw = ptr(w.enc_craw[dr])
             q.dgates_step = ptr(w.enc_dgs[dr]); q.dgates_pos = ptr(w.enc_dgp[dr]); q.ws = ptr(w.enc_bwd_ws[dr])
             bseqs.append(q)
+        def encoder_tail():
+            """Everything behind the encoder's BPTT: the BiLSTM's weight gradients and input gradient, the convolution blocks, the embedding."""
+            x_in, cin = w.enc_y[-1], d.enc_conv_ch
+            for di, dr in enumerate(("fw", "bw")):
+                k, ok = self.P(ENC_CELL % dr + "kernel")
+                gk, ogk = self.G(ENC_CELL % dr + "kernel"); gb, ogb = self.G(ENC_CELL % dr + "bias")
+                self._gemm(x_in, w.enc_dgp[dr], gk, cin, 4 * He, B * Te, cin, 4 * He, 4 * He, trans_a=True,
+                     split_k=max(2, _split_k(cin, 4 * He, B * Te)), c_off=ogk)
+                self._gemm(w.enc_h[dr], w.enc_dgs[dr], gk, He, 4 * He, Te * B, He, 4 * He, 4 * He, trans_a=True,
+                     split_k=max(2, _split_k(He, 4 * He, B * Te)), c_off=ogk + cin * 4 * He)
+                call("mstts_colsum", ptr(w.enc_dgs[dr]), Te * B, 4 * He, 4 * He, ptr(gb, ogb), 1)
+                self._gemm(w.enc_dgp[dr], k, w.enc_dy, B * Te, cin, 4 * He, 4 * He, 4 * He, cin, trans_b=True, accumulate=(di == 1), b_off=ok)
+            # ---- encoder conv backward
+            dy = w.enc_dy
+            bufs = [w.enc_dx, w.enc_dy]
+            for i in range(d.enc_conv_n - 1, -1, -1):
+                cin = d.emb if i == 0 else d.enc_conv_ch
+                x_in = w.emb if i == 0 else w.enc_y[i - 1]
+                dx = bufs[(d.enc_conv_n - 1 - i) % 2]
+                self._conv_block_bwd(dy, x_in, w.enc_a[i], w.enc_mean[i], w.enc_rstd[i], mk["enc_conv_drop_%d" % i], 1 - d.conv_drop,
+                                     ACT_RELU, "encoder/conv_%d/" % i, B * Te, Te, cin, d.enc_conv_ch, d.enc_conv_k, w.enc_dz, dx)
+                dy = dx
+            ge, oge = self.G("encoder/embedding_variable")
+            call("mstts_embedding_bwd", ptr(tok), ptr(dy), ptr(ge, oge), B * Te, d.n_tok, d.emb)
+
         # (the persistent BPTT reads the packed history of a persistent forward)
         enc_ticket = None
         enc_persistent = bool(getattr(w, "enc_hist_valid", False)) and not _redo
@@ -1070,12 +1096,18 @@ class TrainEngine:
             with torch.cuda.stream(self._enc_stream):
                 self._enc_stream.wait_event(ready)
                 enc_ticket = self._enc_persistent(w, "mstts_lstm_seq_bwd_pair_persistent", bseqs, 1, 32)
+                if ENC_TAIL_OVERLAP:
+                    # ... and the rest of the encoder's backward pass (weight gradients, convolution blocks, embedding: ~45 launches, 1.1 ms, none of
+                    # it read by the decoder's products) stays on this stream, behind the launch and beside those products
+                    encoder_tail()
                 enc_done = torch.cuda.Event()
                 enc_done.record()
             decoder_products()
             if on_ready is not None:         # decoder + attention gradients are final: overlaps the encoder backward
                 on_ready(*self._grad_range("attention/", "decoder/decoder"))
             torch.cuda.current_stream().wait_event(enc_done)
+            if not ENC_TAIL_OVERLAP:
+                encoder_tail()
         else:
             self._recurrent_wgrads(w, 0, S, part="attention")
             decoder_products()
@@ -1087,27 +1119,7 @@ class TrainEngine:
             else:
                 self._ensure_fallback_packs()
                 call("mstts_lstm_seq_bwd_pair", C.byref(bseqs[0]), C.byref(bseqs[1]))    # BPTT of both directions: two launches per step
-        for di, dr in enumerate(("fw", "bw")):
-            k, ok = self.P(ENC_CELL % dr + "kernel")
-            gk, ogk = self.G(ENC_CELL % dr + "kernel"); gb, ogb = self.G(ENC_CELL % dr + "bias")
-            self._gemm(x_in, w.enc_dgp[dr], gk, cin, 4 * He, B * Te, cin, 4 * He, 4 * He, trans_a=True,
-                 split_k=max(2, _split_k(cin, 4 * He, B * Te)), c_off=ogk)
-            self._gemm(w.enc_h[dr], w.enc_dgs[dr], gk, He, 4 * He, Te * B, He, 4 * He, 4 * He, trans_a=True,
-                 split_k=max(2, _split_k(He, 4 * He, B * Te)), c_off=ogk + cin * 4 * He)
-            call("mstts_colsum", ptr(w.enc_dgs[dr]), Te * B, 4 * He, 4 * He, ptr(gb, ogb), 1)
-            self._gemm(w.enc_dgp[dr], k, w.enc_dy, B * Te, cin, 4 * He, 4 * He, 4 * He, cin, trans_b=True, accumulate=(di == 1), b_off=ok)
-        # ---- encoder conv backward
-        dy = w.enc_dy
-        bufs = [w.enc_dx, w.enc_dy]
-        for i in range(d.enc_conv_n - 1, -1, -1):
-            cin = d.emb if i == 0 else d.enc_conv_ch
-            x_in = w.emb if i == 0 else w.enc_y[i - 1]
-            dx = bufs[(d.enc_conv_n - 1 - i) % 2]
-            self._conv_block_bwd(dy, x_in, w.enc_a[i], w.enc_mean[i], w.enc_rstd[i], mk["enc_conv_drop_%d" % i], 1 - d.conv_drop,
-                                 ACT_RELU, "encoder/conv_%d/" % i, B * Te, Te, cin, d.enc_conv_ch, d.enc_conv_k, w.enc_dz, dx)
-            dy = dx
-        ge, oge = self.G("encoder/embedding_variable")
-        call("mstts_embedding_bwd", ptr(tok), ptr(dy), ptr(ge, oge), B * Te, d.n_tok, d.emb)
+            encoder_tail()
         if on_ready is not None:
             on_ready(*self._grad_range("encoder/"))
         # ---- the status words of this pass's persistent launches: ONE host sync (the side stream runs in order)

@@ -24,6 +24,7 @@ from .masks import MaskSet, step_seed
 from .params import CELL, ENC_CELL, LSA, SPK, SPK_CELL, VOC, VOC_CELL, Dims, ParamStore, bank_suffix
 
 BN_EPS = 1e-3
+SPK_OVERLAP = os.environ.get("MSTTS_SPK_OVERLAP", "1") != "0"     # inference forward: the speaker stack on its own stream beside the text encoder
 
 
 class _PersistRetry(RuntimeError):
@@ -110,6 +111,7 @@ class InferEngine:
         self._lstm_retry = False
         self._lstm_pending = []              # (slot, workgroups expected to have left in order)
         self._lstm_ctrl = None
+        self._spk_stream = None
         self._lstm_ctrl_host = None
         self._lstm_copied = 0
         self._lcache = {}                    # packed recurrent kernels by cell, keyed on ParamStore.version
@@ -318,8 +320,8 @@ class InferEngine:
         call("mstts_speaker_finalize", ptr(x), ptr(e), B, d.spk_samples, T, d.spk)
         return e
 
-    def _encoder(self, token, token_length, spk):
-        """-> values [B,T,M] (memory masked past Token_Length), keys [B,T,A]."""
+    def _encoder(self, token, token_length, spk, spk_done=None):
+        """-> values [B,T,M] (memory masked past Token_Length), keys [B,T,A].  spk_done: event behind the speaker embedding when another stream forms it."""
         d = self.d
         B, T = token.shape
         M, He = d.mem, d.enc_lstm
@@ -332,6 +334,8 @@ class InferEngine:
             cin = d.enc_conv_ch
         values = self._f(B, T, M)
         self._bilstm_seq(x, B, T, cin, He, ENC_CELL, values, T * M, M, lengths=token_length)
+        if spk_done is not None:
+            torch.cuda.current_stream().wait_event(spk_done)
         call("mstts_speaker_tile", ptr(spk), ptr(token_length), ptr(values), B, T, M, 2 * He, d.spk)
         keys = self._f(B, T, d.att)
         wm, owm = self.P("attention/memory_layer/kernel")
@@ -609,12 +613,28 @@ class InferEngine:
         t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev, dt).contiguous()
         token, tlen = t(pattern["Token"], torch.int32), t(pattern["Token_Length"], torch.int32)
         B, T = token.shape
+        spk_done = None
         if "Speaker_Embedding" in pattern:
             spk = t(pattern["Speaker_Embedding"], torch.float32)
         else:
-            spk = self._speaker_embedding(t(pattern["Speaker_Embedding_Mel"], torch.float32))
+            spk_mel = t(pattern["Speaker_Embedding_Mel"], torch.float32)
+            if SPK_OVERLAP and dev.type == "cuda" and not prof:
+                # the speaker stack (three 64-step recurrent layers on 80 rows: 96 workgroups each) and the text encoder (convolutions, BiLSTM: 64 workgroups)
+                # meet only at the memory's speaker columns: the stack runs on its own stream beside the encoder.  (Its temporaries live until the end of
+                # the pass, self._keep; the control words of its launches are copied behind the join.)
+                if self._spk_stream is None:
+                    self._spk_stream = torch.cuda.Stream(device=dev)
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(self._spk_stream):
+                    self._spk_stream.wait_event(ready)
+                    spk = self._speaker_embedding(spk_mel)
+                    spk_done = torch.cuda.Event()
+                    spk_done.record()
+            else:
+                spk = self._speaker_embedding(spk_mel)
         mark("uploads + speaker encoder")
-        values, keys = self._encoder(token, tlen, spk)
+        values, keys = self._encoder(token, tlen, spk, spk_done)
         mark("text encoder")
         lin_s, stop_s, align_s, S = self.decode(values, keys, tlen, masks=masks, seed=seed, max_steps=max_steps)
         mark("free-running decoder")

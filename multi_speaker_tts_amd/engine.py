@@ -87,6 +87,7 @@ def _split_k_big(M, N, K, requested, n_cu=256):
 PERSIST_STRIKES = 2          # consecutive steps with a fallback before the persistent plans are switched off ...
 PERSIST_COOLDOWN = 200       # ... for this many steps
 VOC_OVERLAP = os.environ.get("MSTTS_VOC_OVERLAP", "1") != "0"    # the vocoder conv-bank's statistics side effect (quirk Q20) on its own stream, under the loss and the postnet's backward pass
+POSTNET_WGRAD_OVERLAP = os.environ.get("MSTTS_POSTNET_WGRAD_OVERLAP", "1") != "0"   # ... and the postnet's weight-gradient products, beside its data-gradient chain
 ENC_TAIL_OVERLAP = os.environ.get("MSTTS_ENC_TAIL_OVERLAP", "1") != "0"   # ... and what follows the encoder's BPTT launch on that stream too, beside the decoder's weight-gradient products
 ENC_OVERLAP = os.environ.get("MSTTS_ENC_OVERLAP", "1") != "0"    # the encoder's persistent launches on their own stream, under decoder-side products that do not depend on them
 
@@ -578,9 +579,10 @@ class TrainEngine:
         call("mstts_bn_train_fwd", ptr(a), ptr(g, og), ptr(b, ob), ptr(mm, omm), ptr(mv, omv), ptr(y), ptr(mean), ptr(rstd),
              ptr(mask), float(keep), BN_MOM, BN_EPS, rows, C, ptr(ws))
 
-    def _conv_block_bwd(self, dy, x_in, a, mean, rstd, mask, keep, act, prefix, rows, T, cin, cout, K, dz, dx):
+    def _conv_block_bwd(self, dy, x_in, a, mean, rstd, mask, keep, act, prefix, rows, T, cin, cout, K, dz, dx, wgrad_stream=None):
         """BN(+dropout)+activation+conv backward.  dy: grad of the block output; returns nothing;
-        dx (or None) receives the input gradient; parameter grads accumulate into the grad slab."""
+        dx (or None) receives the input gradient; parameter grads accumulate into the grad slab.
+        wgrad_stream: run the kernel's weight-gradient product (read by nothing before Adam) on that stream, behind this block's dz."""
         g, og = self.P(prefix + "batch_normalization/gamma")
         gg, ogg = self.G(prefix + "batch_normalization/gamma")
         gb, ogb = self.G(prefix + "batch_normalization/beta")
@@ -589,8 +591,16 @@ class TrainEngine:
              ptr(gg, ogg), ptr(gb, ogb), ptr(gbias, ogbias), rows, cout, ptr(self._bnws))
         gk, ogk = self.G(prefix + "conv1d/kernel")
         pad = (K - 1) // 2
-        self._gemm(x_in, dz, gk, K * cin, cout, rows, cin, cout, cout, trans_a=True, win=(T, cin, pad),
-             split_k=max(2, _split_k(K * cin, cout, rows)), c_off=ogk)
+        if wgrad_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(wgrad_stream):
+                wgrad_stream.wait_event(ev)
+                self._gemm(x_in, dz, gk, K * cin, cout, rows, cin, cout, cout, trans_a=True, win=(T, cin, pad),
+                     split_k=max(2, _split_k(K * cin, cout, rows)), c_off=ogk)
+        else:
+            self._gemm(x_in, dz, gk, K * cin, cout, rows, cin, cout, cout, trans_a=True, win=(T, cin, pad),
+                 split_k=max(2, _split_k(K * cin, cout, rows)), c_off=ogk)
         if dx is not None:
             k, ok = self.P(prefix + "conv1d/kernel")
             key = (prefix, K, cin, cout)
@@ -875,10 +885,16 @@ class TrainEngine:
             self._vocoder_bn_update(w)
 
     def _join_vocoder(self, w):
-        """The caller's stream waits for the vocoder side chain of this pass (if one is running)."""
+        """The caller's stream waits for the side chains of this pass that run on the encoder's stream (if any): the vocoder's statistics side effect of
+        the forward pass, the postnet's weight-gradient products."""
         if getattr(w, "voc_done", None) is not None:
             torch.cuda.current_stream().wait_event(w.voc_done)
             w.voc_done = None
+        if getattr(w, "side_wgrads", False):
+            done = torch.cuda.Event()
+            done.record(self._enc_stream)
+            torch.cuda.current_stream().wait_event(done)
+            w.side_wgrads = False
 
     def _vocoder_bn_update(self, w):
         """Quirk Q20: the train op also runs the vocoder conv-bank's BN update ops on the predicted mel."""
@@ -928,7 +944,11 @@ class TrainEngine:
         call("mstts_tts_loss_fwd_bwd", ptr(w.linear), ptr(w.mel_out), ptr(mel), ptr(w.stop), ptr(mlen), B, S, d.n_mel,
              int(self.use_l1), float(grad_scale), ptr(w.scalars), ptr(w.d_linear), ptr(w.d_post), ptr(w.d_stop))
         call("mstts_l2_loss_acc", ptr(ps.train), ptr(ps.wd_mask), ps.n_train, ptr(w.scalars, 3))
-        # ---- postnet backward
+        # ---- postnet backward.  In a train step (a vocoder side chain is running) the five weight-gradient products go to the encoder's stream as well, behind
+        # that chain: the ≈1 ms of small launches between this stream's data-gradient products (BN backward, column sums, kernel flips) then run beside a
+        # product instead of alone on the chip.  Joined with the chain in front of the BPTT launch.
+        wg_stream = self._enc_stream if (POSTNET_WGRAD_OVERLAP and getattr(w, "voc_done", None) is not None and not _redo) else None
+        w.side_wgrads = wg_stream is not None
         chans = [d.post_ch] * (d.post_n - 1) + [d.n_mel]
         dy = w.d_post
         for i in range(d.post_n - 1, -1, -1):
@@ -936,7 +956,7 @@ class TrainEngine:
             x_in = w.linear if i == 0 else w.post_y[i - 1]
             dx = w.post_dx if (i % 2 == 0) else w.post_dx2
             self._conv_block_bwd(dy, x_in, w.post_a[i], w.post_mean[i], w.post_rstd[i], mk["post_drop_%d" % i], 1 - d.conv_drop,
-                                 ACT_TANH, "decoder/conv_%d/" % i, B * S, S, cin, chans[i], d.post_k, w.post_dz[i], dx)
+                                 ACT_TANH, "decoder/conv_%d/" % i, B * S, S, cin, chans[i], d.post_k, w.post_dz[i], dx, wgrad_stream=wg_stream)
             dy = dx
         # every postnet gradient is final: its all-reduce overlaps the decoder BPTT - unless that is the persistent launch, which needs
         # every CU of the chip for itself: a collective kernel holding CUs at that moment and the 256 workgroups waiting for each
@@ -944,6 +964,7 @@ class TrainEngine:
         # launch (the collective is ordered after what is enqueued) and runs under the hoisted weight-gradient products instead.
         postnet_ready_deferred = on_ready is not None and bool(getattr(w, "persist_bwd_now", False)) and bool(getattr(w, "persist_bwd", False)) and not _redo
         if on_ready is not None and not postnet_ready_deferred:
+            self._join_vocoder(w)                # (the weight gradients on the side stream are part of the range)
             on_ready(*self._grad_range("decoder/conv_"))
         # d_linear(total) = loss part + residual (d_post) + postnet input grad
         n = B * S * d.n_mel

@@ -1230,3 +1230,41 @@ def test_deterministic_training_is_bit_reproducible(dev, cfg):
     d = {k: float((a[k] - c[k]).abs().max() / (a[k].abs().max() + 1e-30)) for k in a}
     print("deterministic vs default schedule after 3 steps (max |difference| / max |value|):", d)
     assert all(v < 2e-3 for v in d.values()), d                         # same arithmetic, other summation orders
+
+
+def test_side_chains_change_nothing(dev, monkeypatch):
+    """Round 6: in a train step three runs of work leave the main stream for the encoder's stream (the vocoder conv-bank's statistics side effect under
+    the loss and the postnet's backward pass, the postnet's weight-gradient products behind it, the encoder's backward pass behind its BPTT launch
+    beside the decoder's weight-gradient products; engine.VOC_OVERLAP / POSTNET_WGRAD_OVERLAP / ENC_TAIL_OVERLAP).  They reorder launches across
+    streams, not arithmetic: in the deterministic mode three optimizer steps with the chains and without them end BIT-IDENTICAL - variables, Adam
+    slots, moving statistics (the vocoder's included), the gradient slab."""
+    from tests.helpers import dims_pair
+    from multi_speaker_tts_amd import engine as E
+    pd, od = dims_pair(emb=64, enc_conv_ch=64, enc_lstm=256, spk=256, prenet=256, dec_lstm=1024, n_mel=80, post_ch=64)
+    values = OM.init_params(od, 6)
+    shapes = [(4, 33, 21), (3, 40, 12), (4, 33, 21)]
+    batches = [to_dev(OT.synthetic_batch(od, B, Te, L, seed=40 + i, ragged=True), dev) for i, (B, Te, L) in enumerate(shapes)]
+
+    def run(on):
+        for name in ("VOC_OVERLAP", "POSTNET_WGRAD_OVERLAP", "ENC_TAIL_OVERLAP"):
+            monkeypatch.setattr(E, name, on)
+        eng = TrainEngine(pd, device=dev, values=values, seed=12, deterministic=True)
+        assert eng.update_vocoder_bn
+        seen, inner = [], eng._vocoder_bn_update
+
+        def spy(w):
+            seen.append(torch.cuda.current_stream() == eng._enc_stream)     # where the chain is enqueued
+            return inner(w)
+        eng._vocoder_bn_update = spy
+        for b in batches:
+            w = eng.train_step(b)
+            assert w.voc_done is None and not w.side_wgrads              # joined in front of the BPTT launch
+        torch.cuda.synchronize()
+        assert seen == [on] * 3, seen
+        assert eng.persist_fallbacks == 0 and eng.persist_bwd_fallbacks == 0 and eng.persist_enc_fallbacks == 0
+        ps = eng.params
+        return {"train": ps.train.clone(), "m": ps.adam_m.clone(), "v": ps.adam_v.clone(), "frozen": ps.frozen.clone(), "grad": ps.grad.clone()}
+    a, b = run(True), run(False)
+    for k in a:
+        assert bool(torch.isfinite(a[k]).all()), k
+        assert torch.equal(a[k], b[k]), "%s differs with / without the side chains: max |d| %g" % (k, float((a[k] - b[k]).abs().max()))

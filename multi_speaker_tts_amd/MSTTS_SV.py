@@ -20,6 +20,8 @@ from .engine import TrainEngine, learning_rate
 from .inference import InferEngine
 from .params import Dims
 
+SPEAKER_SIDE_STREAM = os.environ.get("MSTTS_SPEAKER_SIDE_STREAM", "1") != "0"      # Train_Step: the frozen speaker stack on its own stream beside the step's encoder
+
 TRAIN_KEYS = ("Global_Step", "Learning_Rate", "Loss", "Linear_Loss", "Postnet_Loss", "Stop_Loss", "Weight_Regularization_Loss", "Train_OP")
 INFERENCE_KEYS = ("Global_Step", "Linear", "Mel", "Stop", "Attention_History", "Spectrogram")
 
@@ -340,10 +342,29 @@ class Tacotron2:
             if getattr(self, "_spk_masks_nb", None) != nb:
                 self._spk_masks = MaskSet(self.train_engine.d, 1, 1, 1, True, dev, rank=self.rank, speaker_windows=nb)
                 self._spk_masks_nb = nb
-            self._spk_masks.draw(step_seed(self.train_engine.seed, self.global_step))
             # (no host sync here: the stack's persistent launches are checked at the train step's own sync point, engine.forward)
-            emb, ticket = self.infer_engine.speaker_embedding(mel, masks=self._spk_masks, defer=True)
-            batch["Speaker_Embedding"] = emb.clone()
+            inf = self.infer_engine
+            if SPEAKER_SIDE_STREAM and dev.type == "cuda":
+                # the stack (a dense layer and three 64-step recurrent layers on 5 windows per utterance) meets the step only at the memory's speaker
+                # columns: it runs on its own stream beside the step's masks, encoder convolutions and BiLSTM; engine.forward waits for
+                # `_speaker_event` in front of the speaker tile.  The embedding is handed to the compute stream's allocator bookkeeping (record_stream).
+                if inf._spk_stream is None:
+                    inf._spk_stream = torch.cuda.Stream(device=dev)
+                main = torch.cuda.current_stream(dev)
+                with torch.cuda.stream(inf._spk_stream):
+                    inf._spk_stream.wait_event(up["_uploaded"])
+                    self._spk_masks.draw(step_seed(self.train_engine.seed, self.global_step))
+                    emb, ticket = inf.speaker_embedding(mel, masks=self._spk_masks, defer=True)
+                    emb = emb.clone()
+                    emb.record_stream(main)
+                    done = torch.cuda.Event()
+                    done.record()
+                batch["_speaker_event"] = done
+            else:
+                self._spk_masks.draw(step_seed(self.train_engine.seed, self.global_step))
+                emb, ticket = inf.speaker_embedding(mel, masks=self._spk_masks, defer=True)
+                emb = emb.clone()
+            batch["Speaker_Embedding"] = emb
             if ticket is not None:
                 batch["_speaker_ticket"] = ticket
         return batch

@@ -706,6 +706,8 @@ class TrainEngine:
         if enc_done is not None:
             torch.cuda.current_stream().wait_event(enc_done)
         # ---- memory = [encoder | speaker], masked past Token_Length; keys = values . W_mem
+        if batch.get("_speaker_event") is not None:          # (the product surface forms the embedding on another stream, beside everything above)
+            torch.cuda.current_stream().wait_event(batch["_speaker_event"])
         call("mstts_speaker_tile", ptr(spk), ptr(tlen), ptr(w.values), B, Te, M, 2 * He, d.spk)
         wm, owm = self.P("attention/memory_layer/kernel")
         self._gemm(w.values, wm, w.keys, B * Te, A, M, M, A, A, b_off=owm)

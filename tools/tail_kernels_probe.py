@@ -1,11 +1,11 @@
-"""The step's scalar streaming kernels alone on the chip (HIP events, 50 repeats): Adam over the 7.6 M variables, the regulariser's sum, a torch copy of the same bytes.
+"""The step's scalar streaming kernels alone on the chip (HIP events, 50 repeats): Adam over the step's 30.3 M variables, the regulariser's sum, a torch copy of the same bytes.
 usage: python tools/tail_kernels_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multi_speaker_tts_amd import lib
 dev = torch.device("cuda:0")
-n = 7569920
+n = 30279680          # the step's variables (4 per work-item of the gradient slab's fill: 7 569 920 work-items)
 p, g, m, v = [torch.randn(n, device=dev) * 0.01 for _ in range(4)]
 v = v.abs()
 wd = (torch.rand(n, device=dev) > 0.5).to(torch.uint8)
